@@ -1,0 +1,99 @@
+"""Synthetic banded Hi-C matrices (SURVEY.md §8-D2 recipe).
+
+numpy-only and free of any device code so the same generator feeds the golden
+fixture script (run under the reference's interpreter), the CPU tests and the
+small-size GPU parity tests.  `bench.py` uses the device-side twin in
+`hicpeaks_amd.bandgen` for full-size configs.
+
+The output is the *upper band* of a symmetric contact matrix in the band layout
+used everywhere in this package: ``raw[r, k]`` holds the count of pixel
+``(r, r + k)`` for ``0 <= k < num`` (0 where ``r + k >= n``).
+"""
+import numpy as np
+
+
+def synth_band(n, num, depth=60.0, alpha=1.0, nloops=20, seed=0,
+               nan_frac=0.025, enrich=8.0, loop_dist=None, dtype=np.int32):
+    """Return ``(raw, weight, loops)``.
+
+    raw     int array [n, num]: Poisson(depth * (1 + k) ** -alpha) per diagonal k, with
+            `nloops` planted 3x3 enrichments (x `enrich` over the local rate).
+    weight  f64 [n]: 1 / sqrt(rowsum + 1) balancing-like weights with NaN runs
+            (one long "centromere" run plus isolated bins) covering ~nan_frac of
+            the bins (pyHICCUPS:163-166 treats NaN / 0 weights as masked bins).
+    loops   int array [nloops, 2] of planted (row, col) anchors.
+    """
+    rng = np.random.default_rng(seed)
+    k = np.arange(num, dtype=np.float64)
+    lam = depth * (1.0 + k) ** (-alpha)
+    lam2d = np.broadcast_to(lam, (n, num)).copy()
+    loops = []
+    if nloops > 0:
+        lo_d, hi_d = loop_dist if loop_dist is not None else (10, max(11, num - 15))
+        hi_d = max(hi_d, lo_d + 1)
+        for _ in range(nloops):
+            d = int(rng.integers(lo_d, hi_d))
+            r = int(rng.integers(2, max(3, n - d - 2)))
+            loops.append((r, r + d))
+            for dr in (-1, 0, 1):
+                for dc in (-1, 0, 1):
+                    rr, cc = r + dr, r + d + dc
+                    kk = cc - rr
+                    if 0 <= rr < n and 0 <= cc < n and 0 <= kk < num:
+                        lam2d[rr, kk] *= enrich
+    raw = rng.poisson(lam2d).astype(dtype)
+    # zero the part of the band that falls outside the matrix
+    rr = np.arange(n)[:, None]
+    raw[(rr + np.arange(num)[None, :]) >= n] = 0
+
+    # marginal sums of the symmetric matrix restricted to the band
+    rowsum = raw.sum(axis=1).astype(np.float64)
+    colsum = np.zeros(n)
+    for kk in range(1, num):
+        colsum[kk:] += raw[: n - kk, kk]
+    weight = 1.0 / np.sqrt(rowsum + colsum + 1.0)
+
+    nbad = int(round(n * nan_frac))
+    if nbad > 0:
+        run = max(1, (2 * nbad) // 3)
+        start = int(rng.integers(n // 3, max(n // 3 + 1, 2 * n // 3 - run)))
+        weight[start:start + run] = np.nan
+        rest = nbad - run
+        if rest > 0:
+            idx = rng.choice(n, size=rest, replace=False)
+            weight[idx] = np.nan
+    return raw, weight, np.array(loops, dtype=np.int64).reshape(-1, 2)
+
+
+def balanced_band(raw, weight, mw=0):
+    """f64 band of balanced values ``(count * w_r) * w_c`` with NaN -> 0 and
+    diagonals < mw zeroed (the `cDiags` of pyHICCUPS:149-158, as one array)."""
+    n, num = raw.shape
+    r = np.arange(n)[:, None]
+    c = r + np.arange(num)[None, :]
+    wc = np.where(c < n, weight[np.minimum(c, n - 1)], 0.0)
+    bal = (raw.astype(np.float64) * weight[:, None]) * wc
+    bal[np.isnan(bal)] = 0.0
+    bal[:, :mw] = 0.0
+    bal[c >= n] = 0.0
+    return bal
+
+
+def band_to_coo(raw):
+    """Upper-triangle COO triplets (i, j, v) of the non-zero band pixels."""
+    r, k = np.nonzero(raw)
+    return r.astype(np.int64), (r + k).astype(np.int64), raw[r, k]
+
+
+HG38_SIZES = {
+    '1': 248956422, '2': 242193529, '3': 198295559, '4': 190214555, '5': 181538259,
+    '6': 170805979, '7': 159345973, '8': 145138636, '9': 138394717, '10': 133797422,
+    '11': 135086622, '12': 133275309, '13': 114364328, '14': 107043718, '15': 101991189,
+    '16': 90338345, '17': 83257441, '18': 80373285, '19': 58617616, '20': 64444167,
+    '21': 46709983, '22': 50818468, 'X': 156040895,
+}
+
+
+def hg38_bins(res):
+    """Bin counts of chr1-22,X at `res` bp (CLI default --chroms '#' 'X')."""
+    return {c: -(-s // res) for c, s in HG38_SIZES.items()}

@@ -1,0 +1,56 @@
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN_DIR = os.path.join(REPO, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+class Golden(object):
+    """One fixture produced by oracle/gen_golden.py from the real reference."""
+
+    def __init__(self, path):
+        self.z = np.load(path, allow_pickle=False)
+        self.meta = json.loads(str(self.z['meta']))
+        self.name = self.meta['name']
+        self.mode = self.meta['mode']
+        self.params = self.meta['params']
+
+    def __getitem__(self, k):
+        return self.z[k]
+
+    def __contains__(self, k):
+        return k in self.z.files
+
+    @property
+    def mw(self):
+        return min(self.params['ww']) if self.mode == 'hiccups' else self.params['ww']
+
+
+def golden_names(mode=None):
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, '*.npz'))):
+        name = os.path.basename(p)[:-4]
+        if mode is None or name.startswith(mode):
+            out.append(name)
+    return out
+
+
+def load_golden(name):
+    return Golden(os.path.join(GOLDEN_DIR, name + '.npz'))
+
+
+@pytest.fixture
+def golden():
+    return load_golden
