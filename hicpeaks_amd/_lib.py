@@ -1,0 +1,325 @@
+"""ctypes binding of libhpk.so (include/hpk.h).
+
+The library is the only compute path: if it cannot be loaded, or no gfx950 device is usable, the
+callers raise `HpkError` - there is no CPU fallback in this package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libhpk.so')
+CSRC = os.path.join(HERE, 'csrc')
+
+HPK_MAX_PAIRS = 8
+HPK_MAX_W = 20
+HPK_MAX_STEPS = 64
+HPK_NB = 128
+
+MODE_HICCUPS = 0
+MODE_BHFDR = 1
+FLAG_DENSE_E = 1
+FLAG_DENSE_SUMS = 2
+FLAG_NO_SCORE = 4
+
+HPK_OK = 0
+ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_EMPTY_STEP, ERR_PLAN, ERR_NOMEM = -1, -2, -3, -4, -5, -6
+
+# every symbol include/hpk.h declares (tests check the built library exports all of them)
+ABI_SYMBOLS = ['hpk_create', 'hpk_destroy', 'hpk_last_error', 'hpk_abi_version', 'hpk_score_band',
+               'hpk_result_free', 'hpk_plan_rings', 'hpk_chunk_bounds', 'hpk_set_chunk_bounds',
+               'hpk_device_info', 'hpk_poisson_sf', 'hpk_bruteforce_sums']
+
+
+class HpkError(RuntimeError):
+    def __init__(self, status, msg):
+        RuntimeError.__init__(self, 'libhpk status %d: %s' % (status, msg))
+        self.status = status
+
+
+class EmptyStepError(HpkError, ValueError, ZeroDivisionError):
+    """A widening step was entered with no unresolved candidate.  The reference raises at this point
+    (ValueError from scipy 1.7 fancy indexing, ZeroDivisionError with newer scipy; hicpeaks/callers.py:203-208,
+    487-492), so the drop-in raises too; the class derives from both."""
+
+
+class Params(C.Structure):
+    _fields_ = [('mode', C.c_int32), ('npairs', C.c_int32), ('pw', C.c_int32 * HPK_MAX_PAIRS),
+                ('ww', C.c_int32 * HPK_MAX_PAIRS), ('maxww', C.c_int32), ('min_local_reads', C.c_int32),
+                ('maxapart', C.c_int64), ('res', C.c_int64), ('sig', C.c_double), ('flags', C.c_int32),
+                ('reserved', C.c_int32)]
+
+
+class Band(C.Structure):
+    _fields_ = [('n', C.c_int32), ('num', C.c_int32), ('ld', C.c_int64), ('raw', C.c_void_p),
+                ('balanced', C.c_void_p), ('weight', C.c_void_p), ('IR', C.c_void_p), ('bias1', C.c_void_p),
+                ('bias2', C.c_void_p), ('on_device', C.c_int32), ('reserved', C.c_int32)]
+
+
+class Set(C.Structure):
+    _fields_ = [('pair', C.c_int32), ('fl', C.c_int32), ('nvalid', C.c_int64), ('numbin', C.c_int32),
+                ('reserved', C.c_int32), ('emax', C.c_double), ('begin', C.c_int64), ('end', C.c_int64)]
+
+
+class Result(C.Structure):
+    _fields_ = [('nsteps', C.c_int32), ('step_pi', C.c_int32 * HPK_MAX_STEPS), ('step_wi', C.c_int32 * HPK_MAX_STEPS),
+                ('step_executed', C.c_int32 * HPK_MAX_STEPS), ('step_resolved', C.c_int64 * HPK_MAX_STEPS),
+                ('frozen_w', C.c_int32), ('nslots', C.c_int32), ('slot_pi', C.c_int32 * HPK_MAX_PAIRS),
+                ('ncand', C.c_int64), ('nsets', C.c_int32), ('sets', Set * (2 * HPK_MAX_PAIRS)),
+                ('nsig', C.c_int64), ('x', C.POINTER(C.c_int32)), ('y', C.POINTER(C.c_int32)),
+                ('O', C.POINTER(C.c_double)), ('bal', C.POINTER(C.c_double)), ('E', C.POINTER(C.c_double)),
+                ('p', C.POINTER(C.c_double)), ('q', C.POINTER(C.c_double)), ('other_zero', C.POINTER(C.c_uint8)),
+                ('gap', C.POINTER(C.c_uint8)), ('dense_ld', C.c_int64), ('dense_E', C.POINTER(C.c_double)),
+                ('dense_w', C.POINTER(C.c_uint8)), ('dense_sums', C.POINTER(C.c_double)),
+                ('ms_h2d', C.c_float), ('ms_stencil', C.c_float), ('ms_freeze', C.c_float), ('ms_score', C.c_float),
+                ('ms_gap', C.c_float), ('ms_d2h', C.c_float), ('ms_host_bh', C.c_float), ('ms_total', C.c_float),
+                ('stencil_tiles', C.c_int64), ('band_px', C.c_int64)]
+
+
+def build(force=False, quiet=True):
+    """Compile libhpk.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, '..', 'include', 'hpk.h')]
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(s) for s in srcs)
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    out = subprocess.run(['make', '-C', CSRC], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if out.returncode != 0:
+        raise RuntimeError('building libhpk.so failed:\n' + out.stdout)
+    if not quiet:
+        print(out.stdout)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load libhpk.so (never builds; `__graft_entry__.build()` / `make -C hicpeaks_amd/csrc` does)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HpkError(ERR_NO_DEVICE, 'libhpk.so is not built (%s); run `make -C hicpeaks_amd/csrc` - there is '
+                       'no CPU fallback' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.hpk_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    lib.hpk_create.restype = C.c_int
+    lib.hpk_destroy.argtypes = [C.c_void_p]
+    lib.hpk_destroy.restype = None
+    lib.hpk_last_error.argtypes = [C.c_void_p]
+    lib.hpk_last_error.restype = C.c_char_p
+    lib.hpk_abi_version.restype = C.c_int
+    lib.hpk_score_band.argtypes = [C.c_void_p, C.POINTER(Band), C.POINTER(Params), C.POINTER(C.POINTER(Result))]
+    lib.hpk_score_band.restype = C.c_int
+    lib.hpk_result_free.argtypes = [C.POINTER(Result)]
+    lib.hpk_result_free.restype = None
+    lib.hpk_plan_rings.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.hpk_plan_rings.restype = C.c_int
+    lib.hpk_chunk_bounds.argtypes = [C.c_void_p, C.c_int32]
+    lib.hpk_chunk_bounds.restype = C.c_int
+    lib.hpk_set_chunk_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    lib.hpk_set_chunk_bounds.restype = C.c_int
+    lib.hpk_device_info.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    lib.hpk_device_info.restype = C.c_int
+    lib.hpk_poisson_sf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.hpk_poisson_sf.restype = C.c_int
+    lib.hpk_bruteforce_sums.argtypes = [C.c_void_p, C.POINTER(Band), C.POINTER(Params), C.c_int32, C.c_void_p,
+                                        C.c_void_p, C.c_int64, C.c_void_p]
+    lib.hpk_bruteforce_sums.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def make_params(mode, pw, ww, maxww, sig, maxapart, res, min_local_reads=16, flags=0):
+    pw = [int(v) for v in (pw if np.ndim(pw) else [pw])]
+    ww = [int(v) for v in (ww if np.ndim(ww) else [ww])]
+    if len(pw) != len(ww):
+        npairs = min(len(pw), len(ww))      # zip(pw, ww) truncates (callers.py:18, 239)
+        pw, ww = pw[:npairs], ww[:npairs]
+    if not pw:
+        raise ValueError('pw / ww are empty')
+    if len(pw) > HPK_MAX_PAIRS:
+        raise HpkError(ERR_INVALID, 'at most %d (pw, ww) pairs' % HPK_MAX_PAIRS)
+    p = Params()
+    p.mode = mode
+    p.npairs = len(pw)
+    for i, (a, b) in enumerate(zip(pw, ww)):
+        p.pw[i] = a
+        p.ww[i] = b
+    p.maxww = int(maxww)
+    p.min_local_reads = int(np.ceil(min_local_reads))
+    p.maxapart = int(maxapart)
+    p.res = int(res)
+    p.sig = float(sig)
+    p.flags = int(flags)
+    return p
+
+
+def plan_rings(params):
+    """(steps [(pi, wi)], mult_K [nsteps, W+1], mult_reads) - host only, no device needed."""
+    lib = load()
+    sp = np.zeros(HPK_MAX_STEPS, np.int32)
+    sw = np.zeros(HPK_MAX_STEPS, np.int32)
+    mk = np.zeros((HPK_MAX_STEPS, HPK_MAX_W + 1), np.int32)
+    mr = np.zeros((HPK_MAX_STEPS, HPK_MAX_W + 1), np.int32)
+    rc = lib.hpk_plan_rings(C.byref(params), sp.ctypes.data, sw.ctypes.data, mk.ctypes.data, mr.ctypes.data)
+    if rc < 0:
+        raise HpkError(rc, lib.hpk_last_error(None).decode())
+    return list(zip(sp[:rc].tolist(), sw[:rc].tolist())), mk[:rc].copy(), mr[:rc].copy()
+
+
+def _arr(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+class BandResult(object):
+    """Host copy of one hpk_result."""
+
+    def __init__(self, r, n):
+        self.steps = [(r.step_pi[s], r.step_wi[s], int(r.step_resolved[s]), bool(r.step_executed[s]))
+                      for s in range(r.nsteps)]
+        self.frozen_w = r.frozen_w
+        self.slot_pi = [r.slot_pi[i] for i in range(r.nslots)]
+        self.ncand = int(r.ncand)
+        self.band_px = int(r.band_px)
+        self.tiles = int(r.stencil_tiles)
+        ns = int(r.nsig)
+        x, y = _arr(r.x, ns, np.int64), _arr(r.y, ns, np.int64)
+        O, bal, E = _arr(r.O, ns, np.float64), _arr(r.bal, ns, np.float64), _arr(r.E, ns, np.float64)
+        p, q, oz = _arr(r.p, ns, np.float64), _arr(r.q, ns, np.float64), _arr(r.other_zero, ns, np.uint8)
+        self.sets = []
+        for i in range(r.nsets):
+            s = r.sets[i]
+            sl = slice(int(s.begin), int(s.end))
+            self.sets.append(dict(pair=s.pair, fl='KY'[s.fl], nvalid=int(s.nvalid), numbin=s.numbin, emax=s.emax,
+                                  x=x[sl], y=y[sl], O=O[sl], bal=bal[sl], E=E[sl], p=p[sl], q=q[sl],
+                                  other_zero=oz[sl].astype(bool)))
+        self.gap = _arr(r.gap, n, np.uint8).astype(bool)
+        self.timing = dict(h2d=r.ms_h2d, stencil=r.ms_stencil, freeze=r.ms_freeze, score=r.ms_score, gap=r.ms_gap,
+                           d2h=r.ms_d2h, host_bh=r.ms_host_bh, total=r.ms_total)
+        self.dense_E = self.dense_w = self.dense_sums = None
+        if r.dense_E:
+            ld = int(r.dense_ld)
+            k = r.nslots * n * ld
+            self.dense_E = np.ctypeslib.as_array(r.dense_E, shape=(k * 2,)).reshape(r.nslots, n, ld, 2).copy()
+            self.dense_w = np.ctypeslib.as_array(r.dense_w, shape=(k,)).reshape(r.nslots, n, ld).copy()
+            if r.dense_sums:
+                self.dense_sums = np.ctypeslib.as_array(r.dense_sums, shape=(k * 4,)).reshape(r.nslots, n, ld, 4).copy()
+
+
+class Context(object):
+    """One hpk_ctx = one GPU.  Not shared between threads."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.hpk_create(int(device), C.byref(h))
+        if rc != HPK_OK:
+            raise HpkError(rc, self.lib.hpk_last_error(None).decode())
+        self.h = h
+        self.device = device
+        # chunk boundaries exactly as the reference's numpy produces them (callers.py:36-37)
+        b = np.array([np.power(2, ((i - 1) / 3.)) for i in range(1, HPK_NB + 1)], dtype=np.float64)
+        self._check(self.lib.hpk_set_chunk_bounds(self.h, b.ctypes.data, HPK_NB))
+        self.bounds = b
+
+    def _check(self, rc):
+        if rc != HPK_OK:
+            msg = self.lib.hpk_last_error(self.h).decode()
+            raise (EmptyStepError if rc == ERR_EMPTY_STEP else HpkError)(rc, msg)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.hpk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        name = C.create_string_buffer(128)
+        cus = C.c_int32()
+        hbm = C.c_int64()
+        self._check(self.lib.hpk_device_info(self.h, name, 128, C.byref(cus), C.byref(hbm)))
+        return dict(name=name.value.decode(), cus=cus.value, hbm_bytes=hbm.value)
+
+    # -- band helpers
+    @staticmethod
+    def _band(n, num, ld, raw, balanced, weight, IR, b1, b2, on_device):
+        bd = Band()
+        bd.n, bd.num, bd.ld = int(n), int(num), int(ld)
+        bd.raw, bd.balanced, bd.weight, bd.IR, bd.bias1, bd.bias2 = raw, balanced, weight, IR, b1, b2
+        bd.on_device = 1 if on_device else 0
+        return bd
+
+    def _host_band(self, raw, IR, bias1, bias2, balanced=None, weight=None):
+        raw = np.ascontiguousarray(raw, dtype=np.float32)
+        n, ld = raw.shape
+        keep = [raw]
+        IR = np.ascontiguousarray(IR, dtype=np.float64)
+        b1 = np.ascontiguousarray(bias1, dtype=np.float64)
+        b2 = b1 if bias2 is bias1 else np.ascontiguousarray(bias2, dtype=np.float64)
+        keep += [IR, b1, b2]
+        balp = wp = None
+        if balanced is not None:
+            balanced = np.ascontiguousarray(balanced, dtype=np.float64)
+            assert balanced.shape == raw.shape
+            keep.append(balanced)
+            balp = balanced.ctypes.data
+        else:
+            weight = np.ascontiguousarray(weight, dtype=np.float64)
+            keep.append(weight)
+            wp = weight.ctypes.data
+        bd = self._band(n, IR.size, ld, raw.ctypes.data, balp, wp, IR.ctypes.data, b1.ctypes.data, b2.ctypes.data, False)
+        return bd, keep
+
+    def score(self, band, params, n):
+        res = C.POINTER(Result)()
+        rc = self.lib.hpk_score_band(self.h, C.byref(band), C.byref(params), C.byref(res))
+        self._check(rc)
+        try:
+            return BandResult(res.contents, n)
+        finally:
+            self.lib.hpk_result_free(res)
+
+    def score_host(self, raw, IR, bias1, bias2, params, balanced=None, weight=None):
+        bd, keep = self._host_band(raw, IR, bias1, bias2, balanced, weight)
+        return self.score(bd, params, raw.shape[0])
+
+    def score_device(self, n, num, ld, raw_ptr, IR_ptr, b1_ptr, b2_ptr, params, balanced_ptr=None, weight_ptr=None):
+        bd = self._band(n, num, ld, raw_ptr, balanced_ptr, weight_ptr, IR_ptr, b1_ptr, b2_ptr, True)
+        return self.score(bd, params, n)
+
+    def poisson_sf(self, k, lam):
+        k = np.ascontiguousarray(k, dtype=np.float64)
+        lam = np.ascontiguousarray(np.broadcast_to(lam, k.shape), dtype=np.float64)
+        out = np.empty_like(k)
+        self._check(self.lib.hpk_poisson_sf(self.h, k.ctypes.data, lam.ctypes.data, out.ctypes.data, k.size))
+        return out
+
+    def bruteforce_sums(self, raw, IR, bias1, bias2, params, step, rows, cols, balanced=None, weight=None):
+        bd, keep = self._host_band(raw, IR, bias1, bias2, balanced, weight)
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        out = np.empty((rows.size, 5), dtype=np.float64)
+        self._check(self.lib.hpk_bruteforce_sums(self.h, C.byref(bd), C.byref(params), int(step), rows.ctypes.data,
+                                                 cols.ctypes.data, rows.size, out.ctypes.data))
+        return out
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    """Process-wide context per device (the callers are invoked once per chromosome)."""
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

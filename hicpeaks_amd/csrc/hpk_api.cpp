@@ -1,0 +1,651 @@
+// libhpk.so entry points (include/hpk.h): context, staging, the per-chromosome pipeline and the
+// Benjamini-Hochberg step on the compacted survivors.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/hpk.h"
+#include "hpk_kernels.h"
+#include "hpk_plan.h"
+
+namespace {
+
+std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct hpk_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    std::string err;
+    hipEvent_t ev[10];
+    int nev = 0;
+    char name[128] = {0};
+    int cus = 0;
+    size_t hbm = 0;
+    // constant tables
+    std::vector<double> h_bounds;
+    std::vector<int32_t> h_off;
+    std::vector<double> h_sfe;
+    DevBuf d_bounds, d_off, d_sfe, d_ptab;
+    // workspaces (grow only)
+    DevBuf raw, bal, weight, IR, b1, b2, plan, etab, outE, outW, outS, small, gap;
+    DevBuf sx, sy, sset, schunk, sflag, sO, sE, sp, sbal;
+    DevBuf tmpA, tmpB, tmpC, tmpD;
+};
+
+namespace {
+
+int fail(hpk_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e__ = (call);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return fail(ctx, (e__ == hipErrorOutOfMemory) ? HPK_ERR_NOMEM : HPK_ERR_HIP, "%s -> %s", #call, \
+                        hipGetErrorName(e__));                                                         \
+    } while (0)
+
+void fill_bounds(std::vector<double>& b) {
+    b.resize(HPK_NB);
+    for (int i = 1; i <= HPK_NB; ++i) b[i - 1] = std::pow(2.0, (double)(i - 1) / 3.0);   // callers.py:36-37
+}
+
+// Table length per chunk: beyond lam + t with t^2 / (2 (lam + t/3)) >= 40 the Poisson tail is < 2^-57, i.e.
+// 1 - cdf rounds to exactly 0.
+void fill_offsets(const std::vector<double>& b, std::vector<int32_t>& off) {
+    off.assign(HPK_NB_TAB + 2, 0);
+    int32_t total = 0;
+    for (int ch = 1; ch <= HPK_NB_TAB; ++ch) {
+        const double lam = b[ch - 1];
+        const double t = (26.7 + std::sqrt(26.7 * 26.7 + 320.0 * lam)) / 2.0;
+        off[ch] = total;
+        total += (int32_t)std::ceil(lam + t) + 4;
+    }
+    off[HPK_NB_TAB + 1] = total;
+}
+
+void fill_sfe(std::vector<double>& sfe) {
+    sfe.resize(32);
+    sfe[0] = 0.0;
+    const long double half_log_2pi = 0.5L * logl(2.0L * acosl(-1.0L));
+    for (int n = 1; n < 32; ++n) {
+        const long double x = (long double)n;
+        sfe[n] = (double)(lgammal(x + 1.0L) - (x + 0.5L) * logl(x) + x - half_log_2pi);
+    }
+}
+
+int upload_tables(hpk_ctx* c) {
+    fill_offsets(c->h_bounds, c->h_off);
+    const int32_t total = c->h_off[HPK_NB_TAB + 1];
+    HIPCHK(c, c->d_bounds.reserve(sizeof(double) * HPK_NB));
+    HIPCHK(c, c->d_off.reserve(sizeof(int32_t) * (HPK_NB_TAB + 2)));
+    HIPCHK(c, c->d_sfe.reserve(sizeof(double) * 32));
+    HIPCHK(c, c->d_ptab.reserve(sizeof(double) * (size_t)total));
+    HIPCHK(c, hipMemcpyAsync(c->d_bounds.p, c->h_bounds.data(), sizeof(double) * HPK_NB, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_off.p, c->h_off.data(), sizeof(int32_t) * (HPK_NB_TAB + 2), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_sfe.p, c->h_sfe.data(), sizeof(double) * 32, hipMemcpyHostToDevice, c->stream));
+    hpk_launch_ptab(c->d_bounds.as<double>(), c->d_off.as<int32_t>(), c->d_sfe.as<double>(), c->d_ptab.as<double>(), total, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HPK_OK;
+}
+
+struct ResultBox {
+    hpk_result pub;          // must stay first
+    std::vector<int32_t> x, y;
+    std::vector<double> O, bal, E, p, q;
+    std::vector<uint8_t> oz, gap, denseW;
+    std::vector<double> denseE, denseS;
+};
+
+struct Surv { int32_t x, y; uint8_t set, chunk, flag, keep; float O; double E, p, bal, q; };
+
+// Benjamini-Hochberg on the p <= sig subset of one family of m tests (statsmodels fdr_bh): the subset holds
+// the m' smallest p-values, so their ranks and step-up q-values are those of the full family.
+void bh_family(std::vector<Surv*>& fam, unsigned long long m, double sig, bool use_reject_mask) {
+    std::sort(fam.begin(), fam.end(), [](const Surv* a, const Surv* b) { return a->p < b->p; });
+    const size_t k = fam.size();
+    double running = INFINITY;
+    long rejectmax = -1;
+    for (size_t j = k; j-- > 0;) {
+        const double ecdf = (double)(j + 1) / (double)m;
+        const double qraw = fam[j]->p / ecdf;
+        running = std::min(running, qraw);
+        fam[j]->q = running > 1.0 ? 1.0 : running;
+        if (use_reject_mask && rejectmax < 0 && fam[j]->p <= ecdf * sig) rejectmax = (long)j;
+    }
+    // hiccups keeps q <= sig (callers.py:279); bhfdr keeps statsmodels' step-up mask (callers.py:546)
+    for (size_t j = 0; j < k; ++j)
+        fam[j]->keep = use_reject_mask ? ((long)j <= rejectmax) : (fam[j]->q <= sig);
+}
+
+}  // namespace
+
+extern "C" {
+
+int hpk_abi_version(void) { return HPK_ABI_VERSION; }
+
+const char* hpk_last_error(const hpk_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int hpk_create(int device, hpk_ctx** out) {
+    if (!out) return fail(nullptr, HPK_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, HPK_ERR_NO_DEVICE, "no HIP device (hipGetDeviceCount -> %s, count %d); libhpk has no CPU path",
+                    hipGetErrorName(e), count);
+    if (device < 0 || device >= count) return fail(nullptr, HPK_ERR_INVALID, "device %d out of range (count %d)", device, count);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device)) != hipSuccess)
+        return fail(nullptr, HPK_ERR_HIP, "hipGetDeviceProperties -> %s", hipGetErrorName(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, HPK_ERR_NO_DEVICE, "device %d is %s; libhpk is built for gfx950 only", device, prop.gcnArchName);
+    if ((e = hipSetDevice(device)) != hipSuccess) return fail(nullptr, HPK_ERR_HIP, "hipSetDevice -> %s", hipGetErrorName(e));
+    hpk_ctx* c = new hpk_ctx();
+    c->device = device;
+    std::snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
+    c->cus = prop.multiProcessorCount;
+    c->hbm = prop.totalGlobalMem;
+    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
+        delete c;
+        return fail(nullptr, HPK_ERR_HIP, "hipStreamCreate -> %s", hipGetErrorName(e));
+    }
+    for (int i = 0; i < 10; ++i) { if (hipEventCreate(&c->ev[i]) == hipSuccess) c->nev++; }
+    fill_bounds(c->h_bounds);
+    fill_sfe(c->h_sfe);
+    int rc = upload_tables(c);
+    if (rc != HPK_OK) { g_create_error = c->err; hpk_destroy(c); return rc; }
+    *out = c;
+    return HPK_OK;
+}
+
+void hpk_destroy(hpk_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    DevBuf* all[] = {&c->d_bounds, &c->d_off, &c->d_sfe, &c->d_ptab, &c->raw, &c->bal, &c->weight, &c->IR, &c->b1, &c->b2,
+                     &c->plan, &c->etab, &c->outE, &c->outW, &c->outS, &c->small, &c->gap, &c->sx, &c->sy, &c->sset,
+                     &c->schunk, &c->sflag, &c->sO, &c->sE, &c->sp, &c->sbal, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD};
+    for (DevBuf* b : all) b->release();
+    for (int i = 0; i < c->nev; ++i) (void)hipEventDestroy(c->ev[i]);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int hpk_set_chunk_bounds(hpk_ctx* c, const double* bounds, int32_t count) {
+    if (!c || !bounds || count != HPK_NB) return fail(c, HPK_ERR_INVALID, "need %d bounds", HPK_NB);
+    (void)hipSetDevice(c->device);
+    for (int i = 0; i < HPK_NB; ++i) {
+        if (!(bounds[i] > 0.0) || (i && !(bounds[i] > bounds[i - 1]))) return fail(c, HPK_ERR_INVALID, "bounds must increase");
+        c->h_bounds[i] = bounds[i];
+    }
+    return upload_tables(c);
+}
+
+int hpk_chunk_bounds(double* bounds, int32_t count) {
+    if (!bounds || count < 1 || count > HPK_NB) return HPK_ERR_INVALID;
+    std::vector<double> b;
+    fill_bounds(b);
+    std::memcpy(bounds, b.data(), sizeof(double) * count);
+    return HPK_OK;
+}
+
+int hpk_plan_rings(const hpk_params* params, int32_t* step_pi, int32_t* step_wi, int32_t* mult_K, int32_t* mult_reads) {
+    if (!params) return HPK_ERR_INVALID;
+    HpkDevPlan plan;
+    char msg[256];
+    int rc = hpk_build_plan(params, &plan, msg);
+    if (rc != HPK_OK) { g_create_error = msg; return rc; }
+    for (int s = 0; s < plan.nsteps; ++s) {
+        if (step_pi) step_pi[s] = plan.steps[s].pi;
+        if (step_wi) step_wi[s] = plan.steps[s].wi;
+        for (int r = 0; r <= HPK_MAX_W; ++r) {
+            if (mult_K) mult_K[s * (HPK_MAX_W + 1) + r] = plan.steps[s].m[r];
+            if (mult_reads) mult_reads[s * (HPK_MAX_W + 1) + r] = plan.steps[s].mr[r];
+        }
+    }
+    return plan.nsteps;
+}
+
+int hpk_device_info(hpk_ctx* c, char* name, int32_t name_len, int32_t* cus, int64_t* hbm_bytes) {
+    if (!c) return HPK_ERR_INVALID;
+    if (name && name_len > 0) { std::strncpy(name, c->name, name_len - 1); name[name_len - 1] = 0; }
+    if (cus) *cus = c->cus;
+    if (hbm_bytes) *hbm_bytes = (int64_t)c->hbm;
+    return HPK_OK;
+}
+
+int hpk_poisson_sf(hpk_ctx* c, const double* k, const double* lam, double* out, int64_t count) {
+    if (!c || !k || !lam || !out || count < 0) return fail(c, HPK_ERR_INVALID, "bad arguments");
+    if (count == 0) return HPK_OK;
+    (void)hipSetDevice(c->device);
+    const size_t bytes = sizeof(double) * (size_t)count;
+    HIPCHK(c, c->tmpA.reserve(bytes));
+    HIPCHK(c, c->tmpB.reserve(bytes));
+    HIPCHK(c, c->tmpC.reserve(bytes));
+    HIPCHK(c, hipMemcpyAsync(c->tmpA.p, k, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->tmpB.p, lam, bytes, hipMemcpyHostToDevice, c->stream));
+    hpk_launch_poisson_sf(c->tmpA.as<double>(), c->tmpB.as<double>(), c->d_sfe.as<double>(), c->tmpC.as<double>(), count, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->tmpC.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HPK_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------- staging shared by score / brute
+namespace {
+
+struct Staged {
+    const float* raw = nullptr;
+    const double* bal = nullptr;
+    const double* weight = nullptr;
+    const double* IR = nullptr;
+    const double* b1 = nullptr;
+    const double* b2 = nullptr;
+    std::vector<double> hIR;
+};
+
+int stage_inputs(hpk_ctx* c, const hpk_band* band, Staged* s) {
+    const size_t n = (size_t)band->n, num = (size_t)band->num, ld = (size_t)band->ld;
+    s->hIR.resize(num);
+    if (band->on_device) {
+        s->raw = band->raw; s->bal = band->balanced; s->weight = band->weight; s->IR = band->IR; s->b1 = band->bias1; s->b2 = band->bias2;
+        HIPCHK(c, hipMemcpyAsync(s->hIR.data(), band->IR, sizeof(double) * num, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return HPK_OK;
+    }
+    std::memcpy(s->hIR.data(), band->IR, sizeof(double) * num);
+    HIPCHK(c, c->raw.reserve(sizeof(float) * n * ld));
+    HIPCHK(c, hipMemcpyAsync(c->raw.p, band->raw, sizeof(float) * n * ld, hipMemcpyHostToDevice, c->stream));
+    s->raw = c->raw.as<float>();
+    if (band->balanced) {
+        HIPCHK(c, c->bal.reserve(sizeof(double) * n * ld));
+        HIPCHK(c, hipMemcpyAsync(c->bal.p, band->balanced, sizeof(double) * n * ld, hipMemcpyHostToDevice, c->stream));
+        s->bal = c->bal.as<double>();
+    } else {
+        HIPCHK(c, c->weight.reserve(sizeof(double) * n));
+        HIPCHK(c, hipMemcpyAsync(c->weight.p, band->weight, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        s->weight = c->weight.as<double>();
+    }
+    HIPCHK(c, c->IR.reserve(sizeof(double) * num));
+    HIPCHK(c, hipMemcpyAsync(c->IR.p, band->IR, sizeof(double) * num, hipMemcpyHostToDevice, c->stream));
+    s->IR = c->IR.as<double>();
+    HIPCHK(c, c->b1.reserve(sizeof(double) * n));
+    HIPCHK(c, hipMemcpyAsync(c->b1.p, band->bias1, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    s->b1 = c->b1.as<double>();
+    if (band->bias2 == band->bias1) s->b2 = s->b1;
+    else {
+        HIPCHK(c, c->b2.reserve(sizeof(double) * n));
+        HIPCHK(c, hipMemcpyAsync(c->b2.p, band->bias2, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+        s->b2 = c->b2.as<double>();
+    }
+    return HPK_OK;
+}
+
+int check_band(hpk_ctx* c, const hpk_band* band) {
+    if (!band || band->n <= 0 || band->num <= 0 || band->ld < band->num) return fail(c, HPK_ERR_INVALID, "bad band shape");
+    if (!band->raw || !band->IR || !band->bias1 || !band->bias2) return fail(c, HPK_ERR_INVALID, "raw / IR / bias pointers required");
+    if (!band->balanced && !band->weight) return fail(c, HPK_ERR_INVALID, "either balanced or weight must be given");
+    return HPK_OK;
+}
+
+// small device scratch block layout (bytes)
+constexpr size_t OFF_HIST = 0;                                                   // u64[65]
+constexpr size_t OFF_FROZEN = OFF_HIST + 8 * (HPK_MAX_STEPS + 1);               // i32
+constexpr size_t OFF_ERR = OFF_FROZEN + 8;                                       // i32
+constexpr size_t OFF_EXEC = OFF_ERR + 8;                                         // i32[64]
+constexpr size_t OFF_NSURV = OFF_EXEC + 4 * HPK_MAX_STEPS;                       // u64
+constexpr size_t OFF_NVALID = OFF_NSURV + 8;                                     // u64[16]
+constexpr size_t OFF_EMAX = OFF_NVALID + 8 * 2 * HPK_MAX_PAIRS;                  // u64[16]
+constexpr size_t OFF_CHIST = OFF_EMAX + 8 * 2 * HPK_MAX_PAIRS;                   // u32[16][129]
+constexpr size_t SMALL_BYTES = OFF_CHIST + 4 * 2 * HPK_MAX_PAIRS * (HPK_NB + 1);
+
+}  // namespace
+
+extern "C" {
+
+void hpk_result_free(hpk_result* res) {
+    if (res) delete reinterpret_cast<ResultBox*>(res);
+}
+
+int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_result** out) {
+    if (!c) return HPK_ERR_INVALID;
+    if (!out || !prm) return fail(c, HPK_ERR_INVALID, "params / out is NULL");
+    *out = nullptr;
+    int rc = check_band(c, band);
+    if (rc != HPK_OK) return rc;
+    (void)hipSetDevice(c->device);
+    const double t_begin = now_ms();
+
+    HpkDevPlan plan;
+    char msg[256];
+    rc = hpk_build_plan(prm, &plan, msg);
+    if (rc != HPK_OK) return fail(c, rc, "%s", msg);
+    const int W = plan.W, mw = plan.mw, D = plan.D;
+    const int n = band->n, num = band->num;
+    const int TR = HPK_LR - 2 * W - 1, TC = HPK_LC - 2 * W - 1;
+    if (D < mw) return fail(c, HPK_ERR_INVALID, "maxapart / res (%d) is below min(ww) (%d)", D, mw);
+    const int nsets = (plan.mode == HPK_MODE_BHFDR) ? 1 : 2 * plan.npairs;
+    const bool sums = (prm->flags & HPK_FLAG_DENSE_SUMS) != 0;
+    const bool dense = sums || (prm->flags & HPK_FLAG_DENSE_E) != 0;
+    const bool do_score = (prm->flags & HPK_FLAG_NO_SCORE) == 0;
+
+    ResultBox* box = new ResultBox();
+    std::memset(&box->pub, 0, sizeof(box->pub));
+    hpk_result& R = box->pub;
+    struct Guard { ResultBox* b; ~Guard() { delete b; } } guard{box};
+
+    // ---- inputs
+    Staged in;
+    (void)hipEventRecord(c->ev[0], c->stream);
+    rc = stage_inputs(c, band, &in);
+    if (rc != HPK_OK) return rc;
+    std::vector<double> etab((size_t)plan.nsteps * 2 * (D + 1));
+    hpk_build_etab(&plan, in.hIR.data(), num, etab.data());
+    HIPCHK(c, c->plan.reserve(sizeof(HpkDevPlan)));
+    HIPCHK(c, hipMemcpyAsync(c->plan.p, &plan, sizeof(plan), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, c->etab.reserve(sizeof(double) * std::max<size_t>(etab.size(), 1)));
+    if (!etab.empty())
+        HIPCHK(c, hipMemcpyAsync(c->etab.p, etab.data(), sizeof(double) * etab.size(), hipMemcpyHostToDevice, c->stream));
+    const int64_t ldo = ((int64_t)(D + 1) + 31) / 32 * 32;
+    const size_t dense_elems = (size_t)plan.nslots * (size_t)n * (size_t)ldo;
+    HIPCHK(c, c->outE.reserve(sizeof(double2) * dense_elems));
+    HIPCHK(c, c->outW.reserve(dense_elems));
+    if (sums) HIPCHK(c, c->outS.reserve(sizeof(double4) * dense_elems));
+    HIPCHK(c, c->small.reserve(SMALL_BYTES));
+    HIPCHK(c, hipMemsetAsync(c->small.p, 0, SMALL_BYTES, c->stream));
+    HIPCHK(c, c->gap.reserve((size_t)n));
+    if (dense) {   // pixels outside the band are never written by the kernel
+        HIPCHK(c, hipMemsetAsync(c->outE.p, 0, sizeof(double2) * dense_elems, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->outW.p, 0, dense_elems, c->stream));
+        if (sums) HIPCHK(c, hipMemsetAsync(c->outS.p, 0, sizeof(double4) * dense_elems, c->stream));
+    }
+    (void)hipEventRecord(c->ev[1], c->stream);
+
+    unsigned char* small = c->small.as<unsigned char>();
+    unsigned long long* d_hist = reinterpret_cast<unsigned long long*>(small + OFF_HIST);
+    int32_t* d_frozen = reinterpret_cast<int32_t*>(small + OFF_FROZEN);
+    int32_t* d_err = reinterpret_cast<int32_t*>(small + OFF_ERR);
+    int32_t* d_exec = reinterpret_cast<int32_t*>(small + OFF_EXEC);
+    unsigned long long* d_nsurv = reinterpret_cast<unsigned long long*>(small + OFF_NSURV);
+    unsigned long long* d_nvalid = reinterpret_cast<unsigned long long*>(small + OFF_NVALID);
+    unsigned long long* d_emax = reinterpret_cast<unsigned long long*>(small + OFF_EMAX);
+    unsigned int* d_chist = reinterpret_cast<unsigned int*>(small + OFF_CHIST);
+
+    // ---- stencil
+    HpkStencilArgs sa;
+    std::memset(&sa, 0, sizeof(sa));
+    sa.raw = in.raw; sa.bal = in.bal; sa.weight = in.weight; sa.IR = in.IR; sa.b1 = in.b1; sa.b2 = in.b2;
+    sa.plan = c->plan.as<HpkDevPlan>(); sa.etab = c->etab.as<double>();
+    sa.outE = c->outE.as<double2>(); sa.outW = c->outW.as<uint8_t>(); sa.outS = sums ? c->outS.as<double4>() : nullptr;
+    sa.hist = d_hist;
+    sa.n = n; sa.num = num; sa.ld = band->ld; sa.ldo = ldo; sa.W = W; sa.mw = mw; sa.D = D; sa.TR = TR; sa.TC = TC;
+    sa.J = (TR + D - mw + TC - 1) / TC;
+    const int RB = (n + TR - 1) / TR;
+    sa.ntiles = RB * sa.J;
+    sa.chunk = (sa.ntiles + 7) / 8;
+    hpk_launch_stencil(sa, in.bal != nullptr, sums, c->stream);
+    HIPCHK(c, hipGetLastError());
+    (void)hipEventRecord(c->ev[2], c->stream);
+    hpk_launch_freeze(sa.plan, d_hist, d_frozen, d_exec, d_err, c->stream);
+    HIPCHK(c, hipGetLastError());
+    (void)hipEventRecord(c->ev[3], c->stream);
+
+    // band pixel count (pixels with mw <= d <= D inside the matrix)
+    int64_t band_px = 0;
+    for (int d = mw; d <= std::min(D, num - 1); ++d) if (n - d > 0) band_px += n - d;
+    R.band_px = band_px;
+    R.stencil_tiles = sa.ntiles;
+
+    // ---- scoring
+    int64_t cap = 0;
+    if (do_score) {
+        cap = std::max<int64_t>(1 << 16, band_px * nsets / 6);
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            HIPCHK(c, c->sx.reserve(4 * (size_t)cap));
+            HIPCHK(c, c->sy.reserve(4 * (size_t)cap));
+            HIPCHK(c, c->sset.reserve((size_t)cap));
+            HIPCHK(c, c->schunk.reserve((size_t)cap));
+            HIPCHK(c, c->sflag.reserve((size_t)cap));
+            HIPCHK(c, c->sO.reserve(4 * (size_t)cap));
+            HIPCHK(c, c->sE.reserve(8 * (size_t)cap));
+            HIPCHK(c, c->sp.reserve(8 * (size_t)cap));
+            HIPCHK(c, c->sbal.reserve(8 * (size_t)cap));
+            HpkScoreArgs sc;
+            std::memset(&sc, 0, sizeof(sc));
+            sc.raw = in.raw; sc.bal = in.bal; sc.weight = in.weight; sc.outE = sa.outE; sc.outW = sa.outW; sc.plan = sa.plan;
+            sc.frozen = d_frozen; sc.bounds = c->d_bounds.as<double>(); sc.ptab = c->d_ptab.as<double>();
+            sc.ptab_off = c->d_off.as<int32_t>(); sc.sfe = c->d_sfe.as<double>(); sc.sig = prm->sig;
+            sc.n = n; sc.num = num; sc.ld = band->ld; sc.ldo = ldo; sc.mw = mw; sc.D = D;
+            sc.chunk_hist = d_chist; sc.emax_bits = d_emax; sc.nvalid = d_nvalid; sc.nsurv = d_nsurv; sc.cap = cap;
+            sc.sx = c->sx.as<int32_t>(); sc.sy = c->sy.as<int32_t>(); sc.sset = c->sset.as<uint8_t>();
+            sc.schunk = c->schunk.as<uint8_t>(); sc.sflag = c->sflag.as<uint8_t>(); sc.sO = c->sO.as<float>();
+            sc.sE = c->sE.as<double>(); sc.sp = c->sp.as<double>(); sc.sbal = c->sbal.as<double>();
+            hpk_launch_score(sc, c->stream);
+            HIPCHK(c, hipGetLastError());
+            unsigned long long ns = 0;
+            HIPCHK(c, hipMemcpyAsync(&ns, d_nsurv, 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if ((int64_t)ns <= cap) break;
+            if (attempt == 1) return fail(c, HPK_ERR_NOMEM, "survivor buffer overflow");
+            cap = (int64_t)ns + 1024;           // rerun with room for everything
+            HIPCHK(c, hipMemsetAsync(small + OFF_NSURV, 0, SMALL_BYTES - OFF_NSURV, c->stream));
+        }
+    }
+    (void)hipEventRecord(c->ev[4], c->stream);
+    hpk_launch_gap(in.raw, in.bal, in.weight, n, num, band->ld, mw, c->gap.as<uint8_t>(), c->stream);
+    HIPCHK(c, hipGetLastError());
+    (void)hipEventRecord(c->ev[5], c->stream);
+
+    // ---- results to host
+    std::vector<unsigned char> hsmall(SMALL_BYTES);
+    HIPCHK(c, hipMemcpyAsync(hsmall.data(), small, SMALL_BYTES, hipMemcpyDeviceToHost, c->stream));
+    box->gap.resize(n);
+    HIPCHK(c, hipMemcpyAsync(box->gap.data(), c->gap.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const unsigned long long* h_hist = reinterpret_cast<const unsigned long long*>(hsmall.data() + OFF_HIST);
+    const int32_t h_frozen = *reinterpret_cast<const int32_t*>(hsmall.data() + OFF_FROZEN);
+    const int32_t h_err = *reinterpret_cast<const int32_t*>(hsmall.data() + OFF_ERR);
+    const int32_t* h_exec = reinterpret_cast<const int32_t*>(hsmall.data() + OFF_EXEC);
+    const unsigned long long h_nsurv = *reinterpret_cast<const unsigned long long*>(hsmall.data() + OFF_NSURV);
+    const unsigned long long* h_nvalid = reinterpret_cast<const unsigned long long*>(hsmall.data() + OFF_NVALID);
+    const unsigned long long* h_emax = reinterpret_cast<const unsigned long long*>(hsmall.data() + OFF_EMAX);
+    const unsigned int* h_chist = reinterpret_cast<const unsigned int*>(hsmall.data() + OFF_CHIST);
+
+    R.nsteps = plan.nsteps;
+    for (int s = 0; s < plan.nsteps; ++s) {
+        R.step_pi[s] = plan.steps[s].pi;
+        R.step_wi[s] = plan.steps[s].wi;
+        R.step_executed[s] = h_exec[s];
+        R.step_resolved[s] = (int64_t)h_hist[s];
+    }
+    R.frozen_w = h_frozen;
+    R.nslots = plan.nslots;
+    for (int q = 0; q < plan.nslots; ++q) R.slot_pi[q] = plan.slot_pi[q];
+    R.ncand = (int64_t)h_hist[HPK_HIST_NCAND];
+    R.gap = box->gap.data();
+    if (h_err != 0) {
+        const HpkDevStep& st = plan.steps[h_err - 1];
+        return fail(c, HPK_ERR_EMPTY_STEP, "step (%d,%d) entered with no unresolved candidate (of %lld); the reference raises here "
+                    "(hicpeaks/callers.py:203-208)", st.pi, st.wi, (long long)R.ncand);
+    }
+
+    const double t_d2h0 = now_ms();
+    std::vector<Surv> sv;
+    if (do_score && h_nsurv) {
+        const size_t ns = (size_t)h_nsurv;
+        std::vector<int32_t> hx(ns), hy(ns);
+        std::vector<uint8_t> hset(ns), hch(ns), hfl(ns);
+        std::vector<float> hO(ns);
+        std::vector<double> hE(ns), hp(ns), hb(ns);
+        HIPCHK(c, hipMemcpyAsync(hx.data(), c->sx.p, 4 * ns, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hy.data(), c->sy.p, 4 * ns, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hset.data(), c->sset.p, ns, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hch.data(), c->schunk.p, ns, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hfl.data(), c->sflag.p, ns, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hO.data(), c->sO.p, 4 * ns, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hE.data(), c->sE.p, 8 * ns, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hp.data(), c->sp.p, 8 * ns, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(hb.data(), c->sbal.p, 8 * ns, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        sv.resize(ns);
+        for (size_t i = 0; i < ns; ++i)
+            sv[i] = Surv{hx[i], hy[i], hset[i], hch[i], hfl[i], 0, hO[i], hE[i], hp[i], hb[i], 1.0};
+    }
+    if (dense) {
+        box->denseE.resize(dense_elems * 2);
+        box->denseW.resize(dense_elems);
+        HIPCHK(c, hipMemcpyAsync(box->denseE.data(), c->outE.p, sizeof(double2) * dense_elems, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(box->denseW.data(), c->outW.p, dense_elems, hipMemcpyDeviceToHost, c->stream));
+        if (sums) {
+            box->denseS.resize(dense_elems * 4);
+            HIPCHK(c, hipMemcpyAsync(box->denseS.data(), c->outS.p, sizeof(double4) * dense_elems, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        R.dense_ld = ldo;
+        R.dense_E = box->denseE.data();
+        R.dense_w = box->denseW.data();
+        R.dense_sums = sums ? box->denseS.data() : nullptr;
+    }
+    const double t_d2h1 = now_ms();
+
+    // ---- lambda chunks (callers.py:30) + Benjamini-Hochberg per family (callers.py:273 / 545)
+    R.nsets = do_score ? nsets : 0;
+    std::vector<std::vector<Surv*>> kept(nsets);
+    if (do_score) {
+        // families: (set, chunk)
+        std::vector<std::vector<Surv*>> fam((size_t)nsets * (HPK_NB + 1));
+        for (Surv& s : sv) fam[(size_t)s.set * (HPK_NB + 1) + s.chunk].push_back(&s);
+        for (int s = 0; s < nsets; ++s) {
+            hpk_set& hs = R.sets[s];
+            hs.pair = (plan.mode == HPK_MODE_BHFDR) ? 0 : s / 2;
+            hs.fl = (plan.mode == HPK_MODE_BHFDR) ? 0 : s % 2;
+            hs.nvalid = (int64_t)h_nvalid[s];
+            double emax = 0.0;
+            std::memcpy(&emax, &h_emax[s], 8);
+            hs.emax = emax;
+            int numbin = 0;
+            if (plan.mode == HPK_MODE_HICCUPS && hs.nvalid > 0) {
+                const double nb = std::ceil(std::log(emax) / std::log(2.0) * 3.0 + 1.0);
+                numbin = nb < 0 ? 0 : (nb > HPK_NB ? HPK_NB : (int)nb);
+            }
+            hs.numbin = numbin;
+            const int last = (plan.mode == HPK_MODE_BHFDR) ? 1 : numbin;
+            for (int ch = 1; ch <= last; ++ch) {
+                std::vector<Surv*>& f = fam[(size_t)s * (HPK_NB + 1) + ch];
+                if (f.empty()) continue;
+                bh_family(f, h_chist[(size_t)s * (HPK_NB + 1) + ch], prm->sig, plan.mode == HPK_MODE_BHFDR);
+                for (Surv* p : f) if (p->keep) kept[s].push_back(p);
+            }
+            std::sort(kept[s].begin(), kept[s].end(), [](const Surv* a, const Surv* b) {
+                return a->x != b->x ? a->x < b->x : a->y < b->y; });
+        }
+        size_t total = 0;
+        for (int s = 0; s < nsets; ++s) total += kept[s].size();
+        box->x.reserve(total); box->y.reserve(total); box->O.reserve(total); box->bal.reserve(total);
+        box->E.reserve(total); box->p.reserve(total); box->q.reserve(total); box->oz.reserve(total);
+        for (int s = 0; s < nsets; ++s) {
+            R.sets[s].begin = (int64_t)box->x.size();
+            for (const Surv* p : kept[s]) {
+                box->x.push_back(p->x); box->y.push_back(p->y); box->O.push_back((double)p->O); box->bal.push_back(p->bal);
+                box->E.push_back(p->E); box->p.push_back(p->p); box->q.push_back(p->q); box->oz.push_back(p->flag);
+            }
+            R.sets[s].end = (int64_t)box->x.size();
+        }
+        R.nsig = (int64_t)total;
+        R.x = box->x.data(); R.y = box->y.data(); R.O = box->O.data(); R.bal = box->bal.data();
+        R.E = box->E.data(); R.p = box->p.data(); R.q = box->q.data(); R.other_zero = box->oz.data();
+    }
+    const double t_end = now_ms();
+
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) R.ms_h2d = ms;
+    if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) R.ms_stencil = ms;
+    if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) R.ms_freeze = ms;
+    if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) R.ms_score = ms;
+    if (hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) R.ms_gap = ms;
+    R.ms_d2h = (float)(t_d2h1 - t_d2h0);
+    R.ms_host_bh = (float)(t_end - t_d2h1);
+    R.ms_total = (float)(t_end - t_begin);
+
+    guard.b = nullptr;
+    *out = &box->pub;
+    return HPK_OK;
+}
+
+int hpk_bruteforce_sums(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, int32_t step, const int32_t* rows,
+                        const int32_t* cols, int64_t count, double* out) {
+    if (!c) return HPK_ERR_INVALID;
+    if (!prm || !rows || !cols || !out || count < 0) return fail(c, HPK_ERR_INVALID, "bad arguments");
+    int rc = check_band(c, band);
+    if (rc != HPK_OK) return rc;
+    if (count == 0) return HPK_OK;
+    (void)hipSetDevice(c->device);
+    HpkDevPlan plan;
+    char msg[256];
+    rc = hpk_build_plan(prm, &plan, msg);
+    if (rc != HPK_OK) return fail(c, rc, "%s", msg);
+    if (step < 0 || step >= plan.nsteps) return fail(c, HPK_ERR_INVALID, "step out of range");
+    Staged in;
+    rc = stage_inputs(c, band, &in);
+    if (rc != HPK_OK) return rc;
+    HIPCHK(c, c->plan.reserve(sizeof(HpkDevPlan)));
+    HIPCHK(c, hipMemcpyAsync(c->plan.p, &plan, sizeof(plan), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, c->tmpA.reserve(4 * (size_t)count));
+    HIPCHK(c, c->tmpB.reserve(4 * (size_t)count));
+    HIPCHK(c, c->tmpC.reserve(8 * 5 * (size_t)count));
+    HIPCHK(c, hipMemcpyAsync(c->tmpA.p, rows, 4 * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->tmpB.p, cols, 4 * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    HpkBruteArgs a;
+    a.raw = in.raw; a.bal = in.bal; a.weight = in.weight; a.IR = in.IR; a.plan = c->plan.as<HpkDevPlan>();
+    a.n = band->n; a.num = band->num; a.ld = band->ld; a.step = step;
+    a.rows = c->tmpA.as<int32_t>(); a.cols = c->tmpB.as<int32_t>(); a.count = count; a.out = c->tmpC.as<double>();
+    hpk_launch_brute(a, c->stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->tmpC.p, 8 * 5 * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return HPK_OK;
+}
+
+}  // extern "C"

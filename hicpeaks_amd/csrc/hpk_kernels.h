@@ -1,0 +1,77 @@
+// Kernel argument blocks and launchers (implemented in hpk_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "hpk_plan.h"
+
+#define HPK_LC 128                      // SAT columns per tile (two cells per lane)
+#define HPK_LR 80                       // SAT rows per tile: 80 * 128 * 16 B = 160 KiB, the whole LDS of one CU
+#define HPK_HIST_NCAND HPK_MAX_STEPS    // hist[HPK_MAX_STEPS] counts the candidates
+
+struct HpkStencilArgs {
+    const float*  raw;
+    const double* bal;                  // f64 band or nullptr
+    const double* weight;               // f64[n] or nullptr
+    const double* IR;
+    const double* b1;
+    const double* b2;
+    const HpkDevPlan* plan;
+    const double* etab;                 // [nsteps][2][D + 1]
+    double2* outE;                      // [nslots][n][ldo]
+    uint8_t* outW;                      // [nslots][n][ldo]
+    double4* outS;                      // debug sums or nullptr
+    unsigned long long* hist;           // [HPK_MAX_STEPS + 1]
+    int32_t n, num;
+    int64_t ld, ldo;
+    int32_t W, mw, D;
+    int32_t TR, TC;                     // output tile = (HPK_LR - 2W - 1) x (HPK_LC - 2W - 1)
+    int32_t J;                          // column chunks per row block
+    int32_t ntiles, chunk;              // chunk = ceil(ntiles / 8): tiles handed to one XCD
+};
+
+struct HpkScoreArgs {
+    const float*  raw;
+    const double* bal;
+    const double* weight;
+    const double2* outE;
+    const uint8_t* outW;
+    const HpkDevPlan* plan;
+    const int32_t* frozen;              // device scalar written by the freeze kernel
+    const double* bounds;               // [HPK_NB] chunk upper bounds
+    const double* ptab;                 // Poisson survival table
+    const int32_t* ptab_off;            // [HPK_NB_TAB + 2]
+    const double* sfe;                  // stirlerr(0..31)
+    double sig;
+    int32_t n, num;
+    int64_t ld, ldo;
+    int32_t mw, D;
+    // outputs
+    unsigned int* chunk_hist;           // [nsets][HPK_NB + 1]
+    unsigned long long* emax_bits;      // [nsets]
+    unsigned long long* nvalid;         // [nsets]
+    unsigned long long* nsurv;          // scalar
+    int64_t cap;                        // survivor capacity
+    int32_t* sx; int32_t* sy; uint8_t* sset; uint8_t* schunk; uint8_t* sflag;
+    float* sO; double* sE; double* sp; double* sbal;
+};
+
+struct HpkBruteArgs {
+    const float* raw; const double* bal; const double* weight; const double* IR;
+    const HpkDevPlan* plan;
+    int32_t n, num; int64_t ld; int32_t step;
+    const int32_t* rows; const int32_t* cols; int64_t count;
+    double* out;                        // [count][5]
+};
+
+int  hpk_stencil_lds_bytes();
+void hpk_launch_stencil(const HpkStencilArgs& a, bool balf64, bool sums, hipStream_t st);
+void hpk_launch_freeze(const HpkDevPlan* plan, const unsigned long long* hist, int32_t* frozen,
+                       int32_t* executed, int32_t* err, hipStream_t st);
+void hpk_launch_gap(const float* raw, const double* bal, const double* weight, int32_t n, int32_t num,
+                    int64_t ld, int32_t mw, uint8_t* gap, hipStream_t st);
+void hpk_launch_score(const HpkScoreArgs& a, hipStream_t st);
+void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,
+                     hipStream_t st);
+void hpk_launch_poisson_sf(const double* k, const double* lam, const double* sfe, double* out, int64_t count,
+                           hipStream_t st);
+void hpk_launch_brute(const HpkBruteArgs& a, hipStream_t st);

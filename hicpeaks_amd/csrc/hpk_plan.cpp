@@ -1,0 +1,159 @@
+// Widening plan builder (host).  See hpk_plan.h.
+//
+// The reference walks a (2w+1)^2 window cell by cell and adds one shifted copy of the band per cell
+// (hicpeaks/callers.py:147-198).  Which cells are visited at a step, and with which sign, depends only on
+// the cell's Chebyshev radius rho = max(|di|, |dj|) ("bgloc", callers.py:149/176), on whether it lies on
+// the centre cross and on whether it lies in the lower-left quadrant - so the accumulated matrices are
+// sum_rho m_rho * ring_rho with small integer multiplicities m_rho.  This file replays the reference's
+// control flow on rings instead of cells and converts the multiplicities to box terms
+// sum_rho m_rho * ring_rho = sum_rho (m_rho - m_{rho+1}) * Box_rho.
+#include "hpk_plan.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct RawStep { int p, w; };
+
+void box_terms(const int* m, int W, int32_t* n_out, int32_t* rho_out, int32_t* coef_out) {
+    int n = 0;
+    for (int rho = 1; rho <= W; ++rho) {
+        int next = (rho < W) ? m[rho + 1] : 0;
+        int c = m[rho] - next;
+        if (c != 0) { rho_out[n] = rho; coef_out[n] = c; ++n; }
+    }
+    *n_out = n;
+}
+
+}  // namespace
+
+int hpk_build_plan(const hpk_params* prm, HpkDevPlan* plan, char* msg) {
+    std::memset(plan, 0, sizeof(*plan));
+    msg[0] = 0;
+    const int W = prm->maxww;
+    if (prm->npairs < 1 || prm->npairs > HPK_MAX_PAIRS) { std::snprintf(msg, 256, "npairs must be 1..%d", HPK_MAX_PAIRS); return HPK_ERR_INVALID; }
+    if (W < 1 || W > HPK_MAX_W) { std::snprintf(msg, 256, "maxww must be 1..%d", HPK_MAX_W); return HPK_ERR_INVALID; }
+    if (prm->res <= 0 || prm->maxapart < 0) { std::snprintf(msg, 256, "res/maxapart invalid"); return HPK_ERR_INVALID; }
+    if (prm->mode != HPK_MODE_HICCUPS && prm->mode != HPK_MODE_BHFDR) { std::snprintf(msg, 256, "unknown mode"); return HPK_ERR_INVALID; }
+    if (prm->mode == HPK_MODE_BHFDR && prm->npairs != 1) { std::snprintf(msg, 256, "bhfdr takes one (pw, ww) pair"); return HPK_ERR_INVALID; }
+    int mw = prm->ww[0], maxw = prm->ww[0], minp = prm->pw[0];
+    for (int i = 0; i < prm->npairs; ++i) {
+        if (prm->pw[i] < 0 || prm->ww[i] < 1) { std::snprintf(msg, 256, "pw >= 0 and ww >= 1 required"); return HPK_ERR_INVALID; }
+        mw = std::min(mw, prm->ww[i]);
+        maxw = std::max(maxw, prm->ww[i]);
+        minp = std::min(minp, prm->pw[i]);
+    }
+    plan->mode = prm->mode;
+    plan->W = W;
+    plan->mw = mw;
+    plan->maxw = maxw;
+    plan->D = (int32_t)(prm->maxapart / prm->res);
+    plan->min_reads = (prm->mode == HPK_MODE_BHFDR) ? 16 : prm->min_local_reads;   // callers.py:490
+    plan->npairs = prm->npairs;
+
+    // output slots: distinct peak widths in order of appearance (the bSV / bEV / RefIdx dict keys, callers.py:107-119)
+    for (int i = 0; i < prm->npairs; ++i) {
+        int s = -1;
+        for (int j = 0; j < plan->nslots; ++j) if (plan->slot_pi[j] == prm->pw[i]) s = j;
+        if (s < 0) { s = plan->nslots++; plan->slot_pi[s] = prm->pw[i]; }
+        plan->pair_slot[i] = s;
+        plan->pair_wi[i] = prm->ww[i];
+    }
+    if (plan->nslots > HPK_KSLOTS) { std::snprintf(msg, 256, "at most %d distinct peak widths", HPK_KSLOTS); return HPK_ERR_INVALID; }
+
+    // step order
+    std::vector<RawStep> order;
+    if (prm->mode == HPK_MODE_HICCUPS) {                               // pw_ww_pairs, callers.py:15-23
+        for (int i = 0; i < prm->npairs; ++i)
+            for (int w = prm->ww[i]; w <= W; ++w) order.push_back({prm->pw[i], w});
+        std::stable_sort(order.begin(), order.end(), [](const RawStep& a, const RawStep& b) {
+            return a.w != b.w ? a.w < b.w : a.p < b.p; });
+    } else {                                                            // callers.py:440
+        for (int w = prm->ww[0]; w <= W; ++w) order.push_back({prm->pw[0], w});
+    }
+    if ((int)order.size() > HPK_MAX_STEPS) { std::snprintf(msg, 256, "plan has %zu steps, max %d", order.size(), HPK_MAX_STEPS); return HPK_ERR_INVALID; }
+    plan->nsteps = (int32_t)order.size();
+
+    int mK[HPK_MAX_W + 2] = {0};
+    int mR[HPK_MAX_W + 2] = {0};
+    bool limit = false;
+    int last_pi = 0, last_wi = 0;
+    int reads_id = -1;
+    for (int s = 0; s < plan->nsteps; ++s) {
+        const int pi = order[s].p, wi = order[s].w;
+        bool reads_changed = false;
+        for (int rho = 1; rho <= wi; ++rho) {
+            if (prm->mode == HPK_MODE_HICCUPS) {
+                if (limit && (((rho <= last_wi) && (rho > std::max(pi, last_pi))) || (rho <= std::min(pi, last_pi))))
+                    continue;                                           // callers.py:150-152
+                if (rho > pi) {                                         // outside P1 (callers.py:138, 179)
+                    bool plus = (!limit) || rho > last_wi || (rho > pi && rho <= last_pi);   // callers.py:180, 187
+                    mK[rho] += plus ? 1 : -1;
+                    if ((!limit) || (pi == minp && rho > last_wi)) { mR[rho] += 1; reads_changed = true; }  // 197
+                }
+            } else {
+                if (limit && rho < wi) continue;                        // callers.py:455
+                if (rho > pi) { mK[rho] += 1; mR[rho] += 1; reads_changed = true; }   // 481-485
+            }
+        }
+        limit = true;
+        last_pi = pi;
+        last_wi = wi;
+        if (reads_changed || reads_id < 0) ++reads_id;
+
+        HpkDevStep& st = plan->steps[s];
+        st.pi = pi;
+        st.wi = wi;
+        st.reads_id = reads_id;
+        st.slot = -1;
+        for (int j = 0; j < plan->nslots; ++j) if (plan->slot_pi[j] == pi) st.slot = j;
+        for (int rho = 0; rho <= W; ++rho) {
+            if (mK[rho] < 0 || mR[rho] < 0) {
+                std::snprintf(msg, 256, "step (%d,%d): negative ring multiplicity at radius %d", pi, wi, rho);
+                return HPK_ERR_PLAN;
+            }
+            st.m[rho] = mK[rho];
+            st.mr[rho] = mR[rho];
+        }
+        box_terms(mK, W, &st.nkt, st.kt_rho, st.kt_coef);
+        box_terms(mR, W, &st.nrt, st.rt_rho, st.rt_coef);
+    }
+    return HPK_OK;
+}
+
+void hpk_build_etab(const HpkDevPlan* plan, const double* IR, int32_t num, double* etab) {
+    const int W = plan->W, D = plan->D, mw = plan->mw;
+    const int span = 4 * W + 1;                 // delta = dj - di in [-2W, 2W]
+    std::vector<int> aK(span), aY(span);
+    for (int s = 0; s < plan->nsteps; ++s) {
+        const HpkDevStep& st = plan->steps[s];
+        std::fill(aK.begin(), aK.end(), 0);
+        std::fill(aY.begin(), aY.end(), 0);
+        for (int rho = 1; rho <= W; ++rho) {
+            const int m = st.m[rho];
+            if (m == 0) continue;
+            for (int di = -rho; di <= rho; ++di)
+                for (int dj = -rho; dj <= rho; ++dj) {
+                    if (std::max(std::abs(di), std::abs(dj)) != rho || di == 0 || dj == 0) continue;
+                    aK[dj - di + 2 * W] += m;
+                    if (di > 0 && dj < 0) aY[dj - di + 2 * W] += m;
+                }
+        }
+        double* tK = etab + (size_t)(s * 2 + 0) * (D + 1);
+        double* tY = etab + (size_t)(s * 2 + 1) * (D + 1);
+        for (int d = 0; d <= D; ++d) {
+            double sk = 0.0, sy = 0.0;
+            for (int t = 0; t < span; ++t) {
+                const int kk = d + t - 2 * W;
+                if (kk < mw || kk >= num) continue;
+                if (aK[t]) sk += (double)aK[t] * IR[kk];
+                if (aY[t]) sy += (double)aY[t] * IR[kk];
+            }
+            tK[d] = sk;
+            tY[d] = sy;
+        }
+    }
+}

@@ -1,0 +1,47 @@
+// Host-side widening plan: the as-coded step sequence of hicpeaks/callers.py:15-23 + 132-201 (hiccups)
+// and callers.py:440-485 (bhfdr) reduced to per-ring multiplicities, plus the box-term form the
+// kernels consume.  Shared by host (.cpp) and device (.hip) code: plain structs only.
+#pragma once
+#include <stdint.h>
+#include "../../include/hpk.h"
+
+#define HPK_KSLOTS 4            // distinct peak widths the stencil kernel keeps in registers
+#define HPK_NB     128          // lambda-chunk boundaries 2^((i-1)/3), i = 1..HPK_NB
+#define HPK_NB_TAB 46           // chunks served from the device-built Poisson table (rv <= 2^15)
+
+struct HpkDevStep {
+    int32_t slot;               // output slot = index of pi among the distinct peak widths
+    int32_t pi, wi;
+    int32_t reads_id;           // steps with equal id see the same Reads matrix
+    int32_t nkt;                // donut / lower-left:  sum_j kt_coef[j] * Box(kt_rho[j])
+    int32_t kt_rho[HPK_MAX_W + 1];
+    int32_t kt_coef[HPK_MAX_W + 1];
+    int32_t nrt;                // Reads:               sum_j rt_coef[j] * BoxLL(rt_rho[j])
+    int32_t rt_rho[HPK_MAX_W + 1];
+    int32_t rt_coef[HPK_MAX_W + 1];
+    int32_t m[HPK_MAX_W + 1];   // cumulative ring multiplicity after this step (edge path, E tables)
+    int32_t mr[HPK_MAX_W + 1];  // same for Reads
+};
+
+struct HpkDevPlan {
+    int32_t mode;
+    int32_t nsteps;
+    int32_t nslots;
+    int32_t W;                  // maxww
+    int32_t mw;                 // min(ww)
+    int32_t maxw;               // max(ww)
+    int32_t D;                  // maxapart / res
+    int32_t min_reads;
+    int32_t slot_pi[HPK_MAX_PAIRS];
+    int32_t npairs;
+    int32_t pair_slot[HPK_MAX_PAIRS];
+    int32_t pair_wi[HPK_MAX_PAIRS];
+    HpkDevStep steps[HPK_MAX_STEPS];
+};
+
+// Returns HPK_OK or a negative status; msg (>= 256 bytes) receives the reason.
+int hpk_build_plan(const hpk_params* prm, HpkDevPlan* plan, char* msg);
+
+// Interior local-expected sums: etab[(s * 2 + fl) * (D + 1) + d] = sum over the window cells of step s
+// (with multiplicity) of IR[d + dj - di]; valid for pixels at least W bins away from both matrix ends.
+void hpk_build_etab(const HpkDevPlan* plan, const double* IR, int32_t num, double* etab);

@@ -1,0 +1,180 @@
+/*
+ * hpk.h - C ABI of libhpk.so: the MI355X (gfx950) HiCCUPS / BH-FDR scoring core.
+ *
+ * This is the drop-in boundary for the hot path of XiaoTaoWang/HiCPeaks 0.3.9.  The reference has no
+ * FFI of its own (it is pure Python); the seam it offers is two functions,
+ *
+ *     hicpeaks/callers.py:44-46   hiccups(M, cM, B1, B2, IR, chromLen, Diags, cDiags, num, chrom, pw, ww, ...)
+ *     hicpeaks/callers.py:364-365 bhfdr  (M, cM, B1, B2, IR, chromLen, Diags, cDiags, num, chrom, pw, ww, ...)
+ *
+ * called once per chromosome from scripts/pyHICCUPS:170-173 and scripts/pyBHFDR:143-144.  Everything those
+ * functions do between "inputs arrive" and "q <= sig pixels are known" (callers.py:50-287 and 367-553:
+ * zero-padded band, donut / lower-left box sums, adaptive widening, corrected expected, lambda-chunk
+ * Poisson p-values, Benjamini-Hochberg q-values) happens behind hpk_score_band(); the gap filter,
+ * donut/LL combination, clustering and text output (callers.py:289-362, 555-590, scripts/pyHICCUPS:200-210)
+ * stay in the host language above this ABI (hicpeaks_amd/callers.py).
+ *
+ * Conventions: plain C, no exceptions across the boundary.  Every entry point returns HPK_OK or a
+ * negative hpk_status; hpk_last_error() gives the message.  The caller owns all inputs (never written),
+ * the library owns everything reachable from hpk_result until hpk_result_free().  One hpk_ctx per device
+ * and per host thread; calls block until the result is complete (ctypes releases the GIL around them).
+ * There is no CPU fallback: hpk_create() fails when no gfx950 device is usable.
+ *
+ * Band layout (both inputs and dense outputs): element (r, k) of a [n][ld] row-major array is matrix
+ * pixel (row r, column r + k); entries with r + k >= n are ignored.
+ */
+#ifndef HPK_H
+#define HPK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HPK_ABI_VERSION 1
+#define HPK_MAX_PAIRS   8      /* (pw, ww) pairs per call */
+#define HPK_MAX_W       20     /* largest supported maxww (reference keyword default, callers.py:45) */
+#define HPK_MAX_STEPS   64     /* widening steps in one plan (lane-indexed histogram) */
+
+typedef enum {
+    HPK_OK = 0,
+    HPK_ERR_INVALID = -1,      /* bad argument */
+    HPK_ERR_HIP = -2,          /* HIP runtime error (message has the call and hipError name) */
+    HPK_ERR_NO_DEVICE = -3,    /* no gfx950 device / extension unusable: there is no CPU path */
+    HPK_ERR_EMPTY_STEP = -4,   /* a widening step was entered with no unresolved candidate for its peak
+                                  width - the reference raises here (callers.py:203-208, 487-492) */
+    HPK_ERR_PLAN = -5,         /* (pw, ww, maxww) give a negative ring multiplicity; not representable */
+    HPK_ERR_NOMEM = -6
+} hpk_status;
+
+typedef enum {
+    HPK_MODE_HICCUPS = 0,      /* callers.py:44-362: donut (K) + lower-left (Y), lambda chunks */
+    HPK_MODE_BHFDR = 1         /* callers.py:364-590: donut only, per-pixel Poisson, one BH */
+} hpk_mode;
+
+enum {
+    HPK_FLAG_DENSE_E = 1,      /* copy the dense per-slot local expected (E_K, E_Y) and resolving width back */
+    HPK_FLAG_DENSE_SUMS = 2,   /* debug: also the four raw sums (bS_K, bE_K, bS_Y, bE_Y) at every candidate */
+    HPK_FLAG_NO_SCORE = 4      /* stop after the stencil (bench: time the donut kernel alone) */
+};
+
+/* hiccups(): pw/ww lists, maxww, sig, maxapart, res, min_local_reads (callers.py:44-46);
+ * bhfdr(): one pair, min_local_reads is ignored (hard-coded 16, callers.py:490). */
+typedef struct {
+    int32_t mode;
+    int32_t npairs;
+    int32_t pw[HPK_MAX_PAIRS];
+    int32_t ww[HPK_MAX_PAIRS];
+    int32_t maxww;
+    int32_t min_local_reads;
+    int64_t maxapart;
+    int64_t res;
+    double  sig;
+    int32_t flags;
+    int32_t reserved;
+} hpk_params;
+
+/* One intra-chromosomal band.  Replaces (M, cM, B1, B2, IR, chromLen, Diags, cDiags, num) of callers.py:44.
+ * Either `balanced` (f64 band, NaN already zeroed = cDiags, scripts/pyHICCUPS:149-158) or `weight`
+ * (f64[n], NaN/0 = masked bin; balanced is then formed on chip as (raw * w[r]) * w[c]) must be given. */
+typedef struct {
+    int32_t n;                 /* chromLen */
+    int32_t num;               /* stored diagonals: maxapart/res + maxww + 1 (scripts/pyHICCUPS:146) */
+    int64_t ld;                /* row pitch of raw / balanced in elements, >= num */
+    const float*  raw;         /* [n][ld] raw counts (exact below 2^24) = Diags */
+    const double* balanced;    /* [n][ld] or NULL */
+    const double* weight;      /* [n] or NULL */
+    const double* IR;          /* [num] 1-D expected per diagonal, 0 below min(ww) (scripts/pyHICCUPS:150-156) */
+    const double* bias1;       /* [n] B1 (callers.py:249) */
+    const double* bias2;       /* [n] B2 */
+    int32_t on_device;         /* non-zero: all pointers above are device pointers on the ctx's device */
+    int32_t reserved;
+} hpk_band;
+
+/* One scored (pair, filter) set = one pass of callers.py:242-287. */
+typedef struct {
+    int32_t pair;              /* index into params.pw/ww */
+    int32_t fl;                /* 0 = 'K' donut, 1 = 'Y' lower-left */
+    int64_t nvalid;            /* pixels with E > 0 (callers.py:257) */
+    int32_t numbin;            /* lambda chunks (callers.py:30); 0 for bhfdr */
+    int32_t reserved;
+    double  emax;
+    int64_t begin, end;        /* slice of the survivor arrays: pixels with q <= sig (callers.py:279) */
+} hpk_set;
+
+typedef struct {
+    /* widening log (callers.py:203-232) */
+    int32_t nsteps;
+    int32_t step_pi[HPK_MAX_STEPS];
+    int32_t step_wi[HPK_MAX_STEPS];
+    int32_t step_executed[HPK_MAX_STEPS];
+    int64_t step_resolved[HPK_MAX_STEPS];
+    int32_t frozen_w;
+    int32_t nslots;            /* distinct peak widths */
+    int32_t slot_pi[HPK_MAX_PAIRS];
+    int64_t ncand;             /* nonzero pixels with min(ww) <= d <= maxapart/res (callers.py:101-104) */
+
+    int32_t nsets;
+    hpk_set sets[2 * HPK_MAX_PAIRS];
+
+    /* survivors, row-major within each set */
+    int64_t nsig;
+    const int32_t* x;
+    const int32_t* y;
+    const double*  O;          /* raw count */
+    const double*  bal;        /* balanced value at the pixel (cM[x, y]) */
+    const double*  E;          /* corrected expected */
+    const double*  p;
+    const double*  q;
+    const uint8_t* other_zero; /* K sets: 1 if the lower-left corrected expected is 0 there (callers.py:330) */
+
+    const uint8_t* gap;        /* [n] 1 = row of the balanced band sums to 0 (callers.py:238) */
+
+    /* optional dense outputs (HPK_FLAG_DENSE_*): [nslots][n][dense_ld] */
+    int64_t dense_ld;
+    const double*  dense_E;    /* [..][2] = (E_K, E_Y), 0 where unresolved */
+    const uint8_t* dense_w;    /* resolving donut width, 0 = never resolved */
+    const double*  dense_sums; /* [..][4] = (bS_K, bE_K, bS_Y, bE_Y) */
+
+    /* timing, milliseconds (HIP events on the ctx stream; wall for host parts) */
+    float ms_h2d, ms_stencil, ms_freeze, ms_score, ms_gap, ms_d2h, ms_host_bh, ms_total;
+    int64_t stencil_tiles;
+    int64_t band_px;           /* pixels with min(ww) <= d <= maxapart/res inside the matrix */
+} hpk_result;
+
+typedef struct hpk_ctx hpk_ctx;
+
+/* device >= 0: HIP device ordinal.  Fails with HPK_ERR_NO_DEVICE when it is not a gfx950 GPU. */
+int  hpk_create(int device, hpk_ctx** out);
+void hpk_destroy(hpk_ctx* ctx);
+const char* hpk_last_error(const hpk_ctx* ctx);      /* ctx may be NULL: last create() failure */
+int  hpk_abi_version(void);
+
+/* The whole path for one chromosome.  *out is allocated by the library. */
+int  hpk_score_band(hpk_ctx* ctx, const hpk_band* band, const hpk_params* params, hpk_result** out);
+void hpk_result_free(hpk_result* res);
+
+/* Host-only helpers (no device needed): the widening plan of callers.py:15-23 + 132-201 as ring
+ * multiplicities.  mult is [HPK_MAX_STEPS][HPK_MAX_W + 1]; returns the number of steps or a status. */
+int  hpk_plan_rings(const hpk_params* params, int32_t* step_pi, int32_t* step_wi,
+                    int32_t* mult_K, int32_t* mult_reads);
+/* lambda-chunk boundaries 2^((i-1)/3), i = 1..count (callers.py:33-37) as the library computes them. */
+int  hpk_chunk_bounds(double* bounds, int32_t count);
+/* Replace the boundaries (count must be 128) - the Python layer hands over numpy's own np.power(2, (i-1)/3.)
+ * values so that chunk membership is decided on the very numbers the reference compares with. */
+int  hpk_set_chunk_bounds(hpk_ctx* ctx, const double* bounds, int32_t count);
+
+/* Device helpers used by tests and bench. */
+int  hpk_device_info(hpk_ctx* ctx, char* name, int32_t name_len, int32_t* cus, int64_t* hbm_bytes);
+/* Poisson survival 1 - cdf(k; lam) exactly as the scoring kernel evaluates it (callers.py:268-270, 536-540). */
+int  hpk_poisson_sf(hpk_ctx* ctx, const double* k, const double* lam, double* out, int64_t count);
+/* Independent brute-force check kernel: explicit (2w+1)^2 window sums at `count` sampled pixels
+ * (no summed-area table); out is [count][5] = (bS_K, bE_K, bS_Y, bE_Y, Reads) for one step. */
+int  hpk_bruteforce_sums(hpk_ctx* ctx, const hpk_band* band, const hpk_params* params, int32_t step,
+                         const int32_t* rows, const int32_t* cols, int64_t count, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HPK_H */

@@ -128,7 +128,7 @@ class _Shifter(object):
 
 
 # ----------------------------------------------------------------------------- box sums + widening (A3-A6)
-def hiccups_local_sums(raw, cband, IR, n, num, pw, ww, maxww, maxapart, res, min_local_reads):
+def hiccups_local_sums(raw, cband, IR, n, num, pw, ww, maxww, maxapart, res, min_local_reads, trace=None):
     """callers.py:98-232.  Returns dict with candidate coords and bSV/bEV[pi][fl], step log, frozen_w."""
     mw = min(ww)
     D = maxapart // res
@@ -187,6 +187,8 @@ def hiccups_local_sums(raw, cband, IR, n, num, pw, ww, maxww, maxapart, res, min
                     Reads = Reads + SR(di, dj)
         limit = True
         last_pi, last_wi = pi, wi
+        if trace is not None:
+            trace(len(steps), pi, wi, bS, bE, Reads)
 
         idx = RefIdx[pi]
         if idx.size == 0:

@@ -1,0 +1,191 @@
+"""Parity of the HIP path (through the C ABI) with the reference fixtures and the CPU oracle.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+from hicpeaks_amd import _lib, callers
+from hicpeaks_amd.cli import format_hiccups, format_bhfdr
+from oracle import hiccups_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+Q_ATOL = 1e-9      # north_star allows 1e-6 on q-values
+P_ATOL = 1e-12
+E_RTOL = 1e-9
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _inputs(g):
+    num = g.meta['num']
+    raw = g['raw'][:, :num]
+    IR, cband, biases = orc.prep_from_band(raw, g['weight'], g.mw)
+    return raw, IR, cband, biases
+
+
+def _call(g, ctx, mode, detail):
+    p = g.params
+    raw, IR, cband, biases = _inputs(g)
+    kw = dict(balanced=cband) if mode == 'balanced' else dict(weight=g['weight'])
+    if g.mode == 'hiccups':
+        return callers.hiccups_band(raw.astype(np.float32), IR, biases, biases, chrom='T', pw=p['pw'], ww=p['ww'],
+                                    maxww=p['maxww'], sig=p['sig'], sumq=p['sumq'], double_fold=p['double_fold'],
+                                    single_fold=p['single_fold'], maxapart=p['maxapart'], res=p['res'],
+                                    use_raw=p['use_raw'], min_marginal_peaks=p['min_marginal_peaks'],
+                                    onlyanchor=p['onlyanchor'], min_local_reads=p['min_local_reads'], ctx=ctx,
+                                    detail=detail, **kw)
+    return callers.bhfdr_band(raw.astype(np.float32), IR, biases, biases, chrom='T', pw=p['pw'], ww=p['ww'],
+                              sig=p['sig'], maxww=p['maxww'], maxapart=p['maxapart'], res=p['res'],
+                              min_marginal_peaks=p['min_marginal_peaks'], onlyanchor=p['onlyanchor'], ctx=ctx,
+                              detail=detail, **kw)
+
+
+def _table_arrays(table):
+    keys = sorted(table)
+    if not keys:
+        return np.zeros((0, 2), np.int64), np.zeros((0, 0))
+    return np.array(keys, dtype=np.int64), np.array([[float(v) for v in table[k]] for k in keys])
+
+
+def _check_set(s, vx, vy, E, O, p, q, sig, reject=None):
+    """library survivors (q <= sig) against the full per-pixel arrays of the reference"""
+    assert s['nvalid'] == vx.size
+    sel = (q <= sig) if reject is None else reject
+    firm = np.abs(q - sig) > 1e-8                       # ignore pixels sitting on the threshold
+    want = set(zip(vx[sel & firm].tolist(), vy[sel & firm].tolist()))
+    maybe = set(zip(vx[~firm].tolist(), vy[~firm].tolist()))
+    got = set(zip(s['x'].tolist(), s['y'].tolist()))
+    assert want <= got and got <= (want | maybe), (len(want - got), len(got - want))
+    idx = {k: i for i, k in enumerate(zip(vx.tolist(), vy.tolist()))}
+    ii = np.array([idx[k] for k in zip(s['x'].tolist(), s['y'].tolist())], dtype=np.int64)
+    if ii.size:
+        np.testing.assert_array_equal(s['O'], O[ii])
+        np.testing.assert_allclose(s['E'], E[ii], rtol=E_RTOL, atol=0)
+        np.testing.assert_allclose(s['p'], p[ii], rtol=0, atol=P_ATOL)
+        np.testing.assert_allclose(s['q'], q[ii], rtol=0, atol=Q_ATOL)
+
+
+@pytest.mark.parametrize('mode', ['weight', 'balanced'])
+@pytest.mark.parametrize('name', golden_names())
+def test_golden_parity(name, mode, ctx):
+    g = load_golden(name)
+    if 'prep_exception' in g.meta:
+        pytest.skip('reference prep raised')
+    detail = {}
+    if 'exception' in g.meta:
+        with pytest.raises((ValueError, ZeroDivisionError)):
+            _call(g, ctx, mode, detail)
+        return
+    final = _call(g, ctx, mode, detail)
+    R = detail['result']
+    p = g.params
+    sig = p['sig']
+
+    # G4: resolve counts of the executed steps
+    got_steps = [(a, b, c) for a, b, c, ex in R.steps if ex]
+    assert got_steps == [tuple(int(v) for v in s) for s in g['steps']]
+    assert R.ncand == g.meta['ncand']
+
+    # G5: per-set scoring
+    if g.mode == 'hiccups':
+        assert len(R.sets) == g.meta['nsets']
+        for t, s in enumerate(R.sets):
+            E = g['s%d_E' % t]
+            _check_set(s, g['s%d_vx' % t].astype(np.int64), g['s%d_vy' % t].astype(np.int64), E, g['s%d_O' % t],
+                       g['s%d_p' % t], g['s%d_q' % t], sig)
+            if E.size:
+                assert s['numbin'] == int(np.ceil(np.log(E.max()) / np.log(2) * 3 + 1))
+    else:
+        _check_set(R.sets[0], g['s0_vx'].astype(np.int64), g['s0_vy'].astype(np.int64), g['s0_E'], g['s0_O'],
+                   g['s0_p'], g['s0_q'], sig, reject=g['s0_reject'])
+
+    # gap rows
+    np.testing.assert_array_equal(R.gap, g['cband'].sum(axis=1) == 0)
+
+    # G7: final table + text
+    k, v = _table_arrays(final)
+    np.testing.assert_array_equal(k, g['final_keys'])
+    if k.size:
+        np.testing.assert_allclose(v, g['final_vals'], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize('name', ['hiccups_union_shallow', 'hiccups_p2w5_shallow', 'hiccups_swapped_pairs',
+                                  'hiccups_p1w3_short', 'hiccups_union_frozen'])
+def test_dense_sums_match_oracle(name, ctx):
+    """bS / bE / resolving width at every candidate (G3/G4) against the oracle's cell-by-cell accumulators."""
+    g = load_golden(name)
+    p = g.params
+    raw, IR, cband, biases = _inputs(g)
+    n, num = raw.shape
+    loc = orc.hiccups_local_sums(raw, cband, IR, n, num, p['pw'], p['ww'], p['maxww'], p['maxapart'], p['res'],
+                                 p['min_local_reads'])
+    for mode in ('weight', 'balanced'):
+        detail = dict(dense=True)
+        _call(g, ctx, mode, detail)
+        R = detail['result']
+        vx, vy = loc['vx'], loc['vy']
+        for slot, pi in enumerate(R.slot_pi):
+            w = R.dense_w[slot][vx, vy - vx].astype(np.int64)
+            w = np.where(w > R.frozen_w, 0, w)
+            np.testing.assert_array_equal(w, loc['wres'][pi])
+            sums = R.dense_sums[slot][vx, vy - vx]
+            res_ = w > 0
+            for col, (fl, arr) in enumerate([('K', 'bSV'), ('K', 'bEV'), ('Y', 'bSV'), ('Y', 'bEV')]):
+                want = loc[arr][pi][fl]
+                np.testing.assert_allclose(sums[res_, col], want[res_], rtol=1e-11, atol=0)
+                # exact zeros stay exact zeros
+                assert np.array_equal(sums[res_, col] == 0, want[res_] == 0)
+
+
+def test_poisson_sf_matches_scipy(ctx):
+    from scipy.special import pdtr
+    rng = np.random.default_rng(0)
+    lam = np.r_[ctx.bounds[:60], rng.uniform(0.01, 3000, 4000), rng.uniform(0.001, 30, 4000)]
+    k = np.floor(np.maximum(lam + rng.normal(0, 1, lam.size) * np.sqrt(lam) * 6, 0))
+    k = np.r_[k, np.floor(lam), np.floor(lam) + 1, np.zeros(lam.size), np.floor(lam * 3 + 20)]
+    lam = np.r_[lam, lam, lam, lam, lam]
+    got = ctx.poisson_sf(k, lam)
+    want = 1 - pdtr(k, lam)
+    np.testing.assert_allclose(got, want, rtol=0, atol=2e-14)
+    # the far tail reaches exactly 0 like 1 - cdf does
+    far = want == 0
+    assert far.any() and np.all(got[far] < 1e-15)
+
+
+@pytest.mark.parametrize('pw,ww', [([2], [5]), ([1, 2, 4], [3, 5, 7])])
+def test_sat_kernel_equals_bruteforce(pw, ww, ctx):
+    """Independent explicit-window kernel vs the summed-area-table kernel on a larger random band,
+    including pixels at both chromosome ends."""
+    from hicpeaks_amd import synthetic
+    n, num = 3000, 211
+    raw, weight, _ = synthetic.synth_band(n, num, depth=20.0, nloops=40, seed=11)
+    mw = min(ww)
+    IR, cband, biases = orc.prep_from_band(raw, weight, mw)
+    prm = _lib.make_params(_lib.MODE_HICCUPS, pw, ww, 10, 0.05, 2000000, 10000, 16, _lib.FLAG_DENSE_SUMS | _lib.FLAG_NO_SCORE)
+    R = ctx.score_host(raw.astype(np.float32), IR, biases, biases, prm, weight=weight)
+    rng = np.random.default_rng(1)
+    steps = [(a, b) for a, b, c, e in R.steps]
+    rr, kk = np.nonzero(raw[:, mw:201])
+    kk = kk + mw
+    pick = rng.choice(rr.size, 20000, replace=False)
+    edge = np.where((rr < 12) | (rr + kk >= n - 12))[0]
+    pick = np.unique(np.r_[pick, edge])
+    rows, cols = rr[pick].astype(np.int32), (rr + kk)[pick].astype(np.int32)
+    for slot, pi in enumerate(R.slot_pi):
+        w = R.dense_w[slot][rows, cols - rows]
+        sums = R.dense_sums[slot][rows, cols - rows]
+        for si, (spi, swi) in enumerate(steps):
+            if spi != pi:
+                continue
+            sel = w == swi
+            if not sel.any():
+                continue
+            bf = ctx.bruteforce_sums(raw.astype(np.float32), IR, biases, biases, prm, si, rows[sel], cols[sel], weight=weight)
+            np.testing.assert_allclose(sums[sel], bf[:, :4], rtol=1e-11, atol=0)
+            assert np.all(bf[:, 4] >= 16)
+            assert np.array_equal(sums[sel] == 0, bf[:, :4] == 0)
