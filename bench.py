@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""bench.py - band pixels scored / s (donut + lower-left) on synthetic banded Hi-C matrices.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config chr1_10kb]
+
+One "step" = one pass of the whole hot path (hpk_score_band: stencil -> freeze -> lambda-chunk Poisson
+scoring -> survivor compaction -> Benjamini-Hochberg) over one synthetic chromosome whose band is already
+resident in HBM.  N > 1: one process per GPU (torch.distributed / RCCL only for the barrier and the max over
+ranks); chromosomes are independent, every rank scores its own chromosome of the same shape, no data-path
+collective (weak scaling).  Rank 0 prints ONE JSON line.
+
+`roofline`   : the stencil kernel against HBM: algorithmic bytes = 20 B per band pixel per (p, w) pair
+               (4 B f32 count read + 2 x 8 B f64 local expected written) divided by
+               the kernel's mean duration from HIP events on the library's stream.
+`cpu_baseline`: the numpy oracle (oracle/hiccups_oracle.py, a restatement of the reference's algorithm pinned
+               to it by fixtures) timed on a bounded row sample of the same workload, rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+CONFIGS = {
+    # BASELINE.json configs[1]: hg38 chr1 at 10 kb, (p=2, w=5), 5 Mb band
+    'chr1_10kb': dict(n=24896, res=10000, maxapart=5000000, pw=[2], ww=[5], maxww=10, depth=60.0, nloops=400,
+                      workload='hg38 chr1 @10kb (n=24896), (p,w)=(2,5), 5Mb band, weight-balanced, synthetic Poisson band'),
+    # configs[2] style, one chromosome: union of three pairs
+    'chr1_10kb_union': dict(n=24896, res=10000, maxapart=5000000, pw=[1, 2, 4], ww=[3, 5, 7], maxww=10, depth=60.0,
+                            nloops=400, workload='hg38 chr1 @10kb, union (1,3)/(2,5)/(4,7), 5Mb band'),
+    # configs[3] largest item: chr1 at 5 kb, (4,7), 10 Mb band
+    'chr1_5kb': dict(n=49792, res=5000, maxapart=10000000, pw=[4], ww=[7], maxww=10, depth=25.0, nloops=800,
+                     workload='hg38 chr1 @5kb (n=49792), (p,w)=(4,7), 10Mb band'),
+    # configs[4]: synthetic 1 kb deep Hi-C stress
+    'deep_1kb': dict(n=250000, res=1000, maxapart=2000000, pw=[2], ww=[5], maxww=10, depth=8.0, nloops=2000,
+                     workload='synthetic 1kb (n=250000), (p,w)=(2,5), 2Mb band'),
+    'tiny': dict(n=3000, res=10000, maxapart=2000000, pw=[2], ww=[5], maxww=10, depth=60.0, nloops=40,
+                 workload='tiny self-test'),
+}
+SIG, MIN_READS = 0.05, 16
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_PER_PX = 20.0
+
+
+def make_band_host(cfg, seed, n=None):
+    from hicpeaks_amd import synthetic, band
+    n = n or cfg['n']
+    num = cfg['maxapart'] // cfg['res'] + cfg['maxww'] + 1
+    raw, weight, _ = synthetic.synth_band(n, num, depth=cfg['depth'], nloops=max(1, cfg['nloops'] * n // cfg['n']),
+                                          seed=seed)
+    IR, biases = band.expected_and_biases(raw, weight, min(cfg['ww']))
+    return raw, weight, IR, biases, num
+
+
+def cpu_baseline(cfg, rows):
+    """Oracle on a row sample of the same workload; returns px/s on one core."""
+    from oracle import hiccups_oracle as orc
+    from hicpeaks_amd import band
+    raw, weight, IR, biases, num = make_band_host(cfg, seed=12345, n=rows)
+    mw = min(cfg['ww'])
+    t0 = time.perf_counter()
+    IRo, cband, b = orc.prep_from_band(raw, weight, mw)
+    t1 = time.perf_counter()
+    orc.hiccups(raw, cband, b, b, IRo, rows, num, pw=cfg['pw'], ww=cfg['ww'], maxww=cfg['maxww'], sig=SIG,
+                maxapart=cfg['maxapart'], res=cfg['res'], min_local_reads=MIN_READS, min_marginal_peaks=2,
+                onlyanchor=False)
+    t2 = time.perf_counter()
+    px = band.band_pixels(rows, num, mw, cfg['maxapart'] // cfg['res']) * len(cfg['pw'])
+    return dict(value=px / (t2 - t1), unit='band px/s', cores=1, kind='port',
+                sample='%d-row slice of the workload (%d band px), numpy oracle hiccups() %.1f s (+%.1f s prep)' % (
+                    rows, px, t2 - t1, t1 - t0))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='chr1_10kb', choices=sorted(CONFIGS))
+    ap.add_argument('--cpu-rows', type=int, default=12000, help='rows of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--stencil-only', action='store_true', help='time the stencil kernel alone (HPK_FLAG_NO_SCORE)')
+    args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+
+    import torch
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: there is no CPU path')
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    from hicpeaks_amd import _lib, band
+    ctx = _lib.Context(local)
+    raw, weight, IR, biases, num = make_band_host(cfg, seed=rank)
+    n = cfg['n']
+    mw = min(cfg['ww'])
+    D = cfg['maxapart'] // cfg['res']
+    ld = (num + 63) // 64 * 64
+    dev = torch.device('cuda', local)
+    raw_d = torch.zeros((n, ld), dtype=torch.float32, device=dev)
+    raw_d[:, :num] = torch.from_numpy(raw.astype(np.float32)).to(dev)
+    w_d = torch.from_numpy(weight).to(dev)
+    ir_d = torch.from_numpy(IR).to(dev)
+    b_d = torch.from_numpy(biases).to(dev)
+    flags = _lib.FLAG_NO_SCORE if args.stencil_only else 0
+    prm = _lib.make_params(_lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], cfg['maxww'], SIG, cfg['maxapart'], cfg['res'],
+                           MIN_READS, flags)
+    px_per_step = band.band_pixels(n, num, mw, D) * len(cfg['pw'])
+
+    def step():
+        return ctx.score_device(n, num, ld, raw_d.data_ptr(), ir_d.data_ptr(), b_d.data_ptr(), b_d.data_ptr(), prm,
+                                weight_ptr=w_d.data_ptr())
+
+    for _ in range(args.warmup):
+        R = step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    stencil_ms, score_ms = [], []
+    for _ in range(args.steps):
+        R = step()
+        stencil_ms.append(R.timing['stencil'])
+        score_ms.append(R.timing['score'])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_step = elapsed / args.steps * 1e3
+        st = float(np.mean(stencil_ms))
+        achieved = BYTES_PER_PX * px_per_step / (st * 1e-3) / 1e9
+        out = {
+            'metric': 'band pixels scored/sec (donut+LL)', 'value': world * px_per_step * args.steps / elapsed,
+            'unit': 'band px/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': cfg['workload'], 'name': args.config, 'band_px_per_step': px_per_step,
+                       'candidates': R.ncand, 'significant_px': int(sum(s['x'].size for s in R.sets)),
+                       'parallelism': 'one chromosome per GPU, no collective',
+                       'stencil_only': bool(args.stencil_only)},
+            'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'kernel_ms': st, 'algorithmic_bytes_per_launch': BYTES_PER_PX * px_per_step},
+            'phases_ms': {k: float(v) for k, v in R.timing.items()},
+        }
+        if world == 1 and args.cpu_rows > 0:
+            out['cpu_baseline'] = cpu_baseline(cfg, min(args.cpu_rows, n))
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -59,7 +59,7 @@ struct hpk_ctx {
     std::vector<double> h_sfe;
     DevBuf d_bounds, d_off, d_sfe, d_ptab;
     // workspaces (grow only)
-    DevBuf raw, bal, weight, IR, b1, b2, plan, etab, outE, outW, outS, small, gap;
+    DevBuf raw, bal, weight, IR, b1, b2, plan, etab, outS, outW, dE, dW, dS, small, gap, histpart;
     DevBuf sx, sy, sset, schunk, sflag, sO, sE, sp, sbal;
     DevBuf tmpA, tmpB, tmpC, tmpD;
 };
@@ -203,7 +203,7 @@ void hpk_destroy(hpk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf* all[] = {&c->d_bounds, &c->d_off, &c->d_sfe, &c->d_ptab, &c->raw, &c->bal, &c->weight, &c->IR, &c->b1, &c->b2,
-                     &c->plan, &c->etab, &c->outE, &c->outW, &c->outS, &c->small, &c->gap, &c->sx, &c->sy, &c->sset,
+                     &c->plan, &c->etab, &c->outS, &c->outW, &c->dE, &c->dW, &c->dS, &c->histpart, &c->small, &c->gap, &c->sx, &c->sy, &c->sset,
                      &c->schunk, &c->sflag, &c->sO, &c->sE, &c->sp, &c->sbal, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD};
     for (DevBuf* b : all) b->release();
     for (int i = 0; i < c->nev; ++i) (void)hipEventDestroy(c->ev[i]);
@@ -332,7 +332,7 @@ int check_band(hpk_ctx* c, const hpk_band* band) {
 
 // small device scratch block layout (bytes)
 constexpr size_t OFF_HIST = 0;                                                   // u64[65]
-constexpr size_t OFF_FROZEN = OFF_HIST + 8 * (HPK_MAX_STEPS + 1);               // i32
+constexpr size_t OFF_FROZEN = OFF_HIST + 8 * (HPK_MAX_STEPS + 1 + 8);   // + 8 profiling slots               // i32
 constexpr size_t OFF_ERR = OFF_FROZEN + 8;                                       // i32
 constexpr size_t OFF_EXEC = OFF_ERR + 8;                                         // i32[64]
 constexpr size_t OFF_NSURV = OFF_EXEC + 4 * HPK_MAX_STEPS;                       // u64
@@ -390,16 +390,21 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
         HIPCHK(c, hipMemcpyAsync(c->etab.p, etab.data(), sizeof(double) * etab.size(), hipMemcpyHostToDevice, c->stream));
     const int64_t ldo = ((int64_t)(D + 1) + 31) / 32 * 32;
     const size_t dense_elems = (size_t)plan.nslots * (size_t)n * (size_t)ldo;
-    HIPCHK(c, c->outE.reserve(sizeof(double2) * dense_elems));
+    HIPCHK(c, c->outS.reserve(sizeof(double2) * dense_elems));
     HIPCHK(c, c->outW.reserve(dense_elems));
-    if (sums) HIPCHK(c, c->outS.reserve(sizeof(double4) * dense_elems));
+    if (dense) {
+        HIPCHK(c, c->dE.reserve(sizeof(double2) * dense_elems));
+        HIPCHK(c, c->dW.reserve(dense_elems));
+        if (sums) HIPCHK(c, c->dS.reserve(sizeof(double4) * dense_elems));
+    }
     HIPCHK(c, c->small.reserve(SMALL_BYTES));
     HIPCHK(c, hipMemsetAsync(c->small.p, 0, SMALL_BYTES, c->stream));
     HIPCHK(c, c->gap.reserve((size_t)n));
     if (dense) {   // pixels outside the band are never written by the kernel
-        HIPCHK(c, hipMemsetAsync(c->outE.p, 0, sizeof(double2) * dense_elems, c->stream));
         HIPCHK(c, hipMemsetAsync(c->outW.p, 0, dense_elems, c->stream));
-        if (sums) HIPCHK(c, hipMemsetAsync(c->outS.p, 0, sizeof(double4) * dense_elems, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->dE.p, 0, sizeof(double2) * dense_elems, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->dW.p, 0, dense_elems, c->stream));
+        if (sums) HIPCHK(c, hipMemsetAsync(c->dS.p, 0, sizeof(double4) * dense_elems, c->stream));
     }
     (void)hipEventRecord(c->ev[1], c->stream);
 
@@ -416,19 +421,24 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     // ---- stencil
     HpkStencilArgs sa;
     std::memset(&sa, 0, sizeof(sa));
-    sa.raw = in.raw; sa.bal = in.bal; sa.weight = in.weight; sa.IR = in.IR; sa.b1 = in.b1; sa.b2 = in.b2;
-    sa.plan = c->plan.as<HpkDevPlan>(); sa.etab = c->etab.as<double>();
-    sa.outE = c->outE.as<double2>(); sa.outW = c->outW.as<uint8_t>(); sa.outS = sums ? c->outS.as<double4>() : nullptr;
+    sa.raw = in.raw; sa.bal = in.bal; sa.weight = in.weight;
+    sa.plan = c->plan.as<HpkDevPlan>();
+    sa.outS = c->outS.as<double2>(); sa.outW = c->outW.as<uint8_t>();
     sa.hist = d_hist;
     sa.n = n; sa.num = num; sa.ld = band->ld; sa.ldo = ldo; sa.W = W; sa.mw = mw; sa.D = D; sa.TR = TR; sa.TC = TC;
     sa.J = (TR + D - mw + TC - 1) / TC;
     const int RB = (n + TR - 1) / TR;
     sa.ntiles = RB * sa.J;
     sa.chunk = (sa.ntiles + 7) / 8;
-    hpk_launch_stencil(sa, in.bal != nullptr, sums, c->stream);
+    { const char* e = std::getenv("HPK_DBG_STOP"); sa.dbg_stop = e ? std::atoi(e) : 0; }
+    HIPCHK(c, c->histpart.reserve(sizeof(unsigned) * (size_t)sa.ntiles * (HPK_MAX_STEPS + 1)));
+    HIPCHK(c, hipMemsetAsync(c->histpart.p, 0, sizeof(unsigned) * (size_t)sa.ntiles * (HPK_MAX_STEPS + 1), c->stream));
+    sa.hist_part = c->histpart.as<unsigned>();
+    (void)hipEventRecord(c->ev[1], c->stream);
+    hpk_launch_stencil(sa, in.bal != nullptr, plan.simple_reads != 0 && !std::getenv("HPK_GENERIC_SEARCH"), c->stream);
     HIPCHK(c, hipGetLastError());
     (void)hipEventRecord(c->ev[2], c->stream);
-    hpk_launch_freeze(sa.plan, d_hist, d_frozen, d_exec, d_err, c->stream);
+    hpk_launch_freeze(sa.plan, d_hist, sa.hist_part, sa.ntiles, d_frozen, d_exec, d_err, c->stream);
     HIPCHK(c, hipGetLastError());
     (void)hipEventRecord(c->ev[3], c->stream);
 
@@ -454,7 +464,8 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
             HIPCHK(c, c->sbal.reserve(8 * (size_t)cap));
             HpkScoreArgs sc;
             std::memset(&sc, 0, sizeof(sc));
-            sc.raw = in.raw; sc.bal = in.bal; sc.weight = in.weight; sc.outE = sa.outE; sc.outW = sa.outW; sc.plan = sa.plan;
+            sc.raw = in.raw; sc.bal = in.bal; sc.weight = in.weight; sc.outS = sa.outS; sc.outW = sa.outW; sc.plan = sa.plan;
+            sc.etab = c->etab.as<double>(); sc.IR = in.IR; sc.b1 = in.b1; sc.b2 = in.b2;
             sc.frozen = d_frozen; sc.bounds = c->d_bounds.as<double>(); sc.ptab = c->d_ptab.as<double>();
             sc.ptab_off = c->d_off.as<int32_t>(); sc.sfe = c->d_sfe.as<double>(); sc.sig = prm->sig;
             sc.n = n; sc.num = num; sc.ld = band->ld; sc.ldo = ldo; sc.mw = mw; sc.D = D;
@@ -462,7 +473,7 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
             sc.sx = c->sx.as<int32_t>(); sc.sy = c->sy.as<int32_t>(); sc.sset = c->sset.as<uint8_t>();
             sc.schunk = c->schunk.as<uint8_t>(); sc.sflag = c->sflag.as<uint8_t>(); sc.sO = c->sO.as<float>();
             sc.sE = c->sE.as<double>(); sc.sp = c->sp.as<double>(); sc.sbal = c->sbal.as<double>();
-            hpk_launch_score(sc, c->stream);
+            hpk_launch_score(sc, c->cus, c->stream);
             HIPCHK(c, hipGetLastError());
             unsigned long long ns = 0;
             HIPCHK(c, hipMemcpyAsync(&ns, d_nsurv, 8, hipMemcpyDeviceToHost, c->stream));
@@ -504,8 +515,12 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     R.nslots = plan.nslots;
     for (int q = 0; q < plan.nslots; ++q) R.slot_pi[q] = plan.slot_pi[q];
     R.ncand = (int64_t)h_hist[HPK_HIST_NCAND];
+    if (sa.dbg_stop == 7)
+        std::fprintf(stderr, "[hpk prof] wave-cycles cand=%llu pix=%llu wstar=%llu slots=%llu B=%llu store=%llu\n",
+                     h_hist[HPK_MAX_STEPS + 1], h_hist[HPK_MAX_STEPS + 2], h_hist[HPK_MAX_STEPS + 3],
+                     h_hist[HPK_MAX_STEPS + 4], h_hist[HPK_MAX_STEPS + 5], h_hist[HPK_MAX_STEPS + 6]);
     R.gap = box->gap.data();
-    if (h_err != 0) {
+    if (h_err != 0 && sa.dbg_stop == 0) {
         const HpkDevStep& st = plan.steps[h_err - 1];
         return fail(c, HPK_ERR_EMPTY_STEP, "step (%d,%d) entered with no unresolved candidate (of %lld); the reference raises here "
                     "(hicpeaks/callers.py:203-208)", st.pi, st.wi, (long long)R.ncand);
@@ -534,13 +549,19 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
             sv[i] = Surv{hx[i], hy[i], hset[i], hch[i], hfl[i], 0, hO[i], hE[i], hp[i], hb[i], 1.0};
     }
     if (dense) {
+        HpkDenseArgs da;
+        da.outS = sa.outS; da.outW = sa.outW; da.plan = sa.plan; da.etab = c->etab.as<double>();
+        da.IR = in.IR; da.b1 = in.b1; da.b2 = in.b2; da.n = n; da.num = num; da.ldo = ldo; da.mw = mw; da.D = D;
+        da.dE = c->dE.as<double2>(); da.dW = c->dW.as<uint8_t>(); da.dS = sums ? c->dS.as<double4>() : nullptr;
+        hpk_launch_dense(da, c->stream);
+        HIPCHK(c, hipGetLastError());
         box->denseE.resize(dense_elems * 2);
         box->denseW.resize(dense_elems);
-        HIPCHK(c, hipMemcpyAsync(box->denseE.data(), c->outE.p, sizeof(double2) * dense_elems, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(box->denseW.data(), c->outW.p, dense_elems, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(box->denseE.data(), c->dE.p, sizeof(double2) * dense_elems, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(box->denseW.data(), c->dW.p, dense_elems, hipMemcpyDeviceToHost, c->stream));
         if (sums) {
             box->denseS.resize(dense_elems * 4);
-            HIPCHK(c, hipMemcpyAsync(box->denseS.data(), c->outS.p, sizeof(double4) * dense_elems, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(box->denseS.data(), c->dS.p, sizeof(double4) * dense_elems, hipMemcpyDeviceToHost, c->stream));
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
         R.dense_ld = ldo;

@@ -12,30 +12,31 @@ struct HpkStencilArgs {
     const float*  raw;
     const double* bal;                  // f64 band or nullptr
     const double* weight;               // f64[n] or nullptr
-    const double* IR;
-    const double* b1;
-    const double* b2;
     const HpkDevPlan* plan;
-    const double* etab;                 // [nsteps][2][D + 1]
-    double2* outE;                      // [nslots][n][ldo]
-    uint8_t* outW;                      // [nslots][n][ldo]
-    double4* outS;                      // debug sums or nullptr
-    unsigned long long* hist;           // [HPK_MAX_STEPS + 1]
+    double2* outS;                      // [nslots][n][ldo]  (bS_K, bS_Y) at the resolving step
+    uint8_t* outW;                      // [nslots][n][ldo]  resolving step + 1, 0 = unresolved
+    unsigned long long* hist;           // [HPK_MAX_STEPS + 1 + 8] totals (written by hpk_freeze) + profiling slots
+    unsigned* hist_part;                // [ntiles][HPK_MAX_STEPS + 1] per-tile resolve counts, [..][HPK_MAX_STEPS] = candidates
     int32_t n, num;
     int64_t ld, ldo;
     int32_t W, mw, D;
     int32_t TR, TC;                     // output tile = (HPK_LR - 2W - 1) x (HPK_LC - 2W - 1)
     int32_t J;                          // column chunks per row block
     int32_t ntiles, chunk;              // chunk = ceil(ntiles / 8): tiles handed to one XCD
+    int32_t dbg_stop;                   // profiling ablation: 1 = stop after the loads, 2 = after the SAT
 };
 
 struct HpkScoreArgs {
     const float*  raw;
     const double* bal;
     const double* weight;
-    const double2* outE;
+    const double2* outS;
     const uint8_t* outW;
     const HpkDevPlan* plan;
+    const double* etab;                 // [nsteps][2][D + 1]
+    const double* IR;
+    const double* b1;
+    const double* b2;
     const int32_t* frozen;              // device scalar written by the freeze kernel
     const double* bounds;               // [HPK_NB] chunk upper bounds
     const double* ptab;                 // Poisson survival table
@@ -55,6 +56,13 @@ struct HpkScoreArgs {
     float* sO; double* sE; double* sp; double* sbal;
 };
 
+struct HpkDenseArgs {
+    const double2* outS; const uint8_t* outW; const HpkDevPlan* plan; const double* etab;
+    const double* IR; const double* b1; const double* b2;
+    int32_t n, num; int64_t ldo; int32_t mw, D;
+    double2* dE; uint8_t* dW; double4* dS;
+};
+
 struct HpkBruteArgs {
     const float* raw; const double* bal; const double* weight; const double* IR;
     const HpkDevPlan* plan;
@@ -64,12 +72,13 @@ struct HpkBruteArgs {
 };
 
 int  hpk_stencil_lds_bytes();
-void hpk_launch_stencil(const HpkStencilArgs& a, bool balf64, bool sums, hipStream_t st);
-void hpk_launch_freeze(const HpkDevPlan* plan, const unsigned long long* hist, int32_t* frozen,
-                       int32_t* executed, int32_t* err, hipStream_t st);
+void hpk_launch_stencil(const HpkStencilArgs& a, bool balf64, bool simple, hipStream_t st);
+void hpk_launch_dense(const HpkDenseArgs& a, hipStream_t st);
+void hpk_launch_freeze(const HpkDevPlan* plan, unsigned long long* hist, const unsigned* hist_part, int nparts,
+                       int32_t* frozen, int32_t* executed, int32_t* err, hipStream_t st);
 void hpk_launch_gap(const float* raw, const double* bal, const double* weight, int32_t n, int32_t num,
                     int64_t ld, int32_t mw, uint8_t* gap, hipStream_t st);
-void hpk_launch_score(const HpkScoreArgs& a, hipStream_t st);
+void hpk_launch_score(const HpkScoreArgs& a, int cus, hipStream_t st);
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,
                      hipStream_t st);
 void hpk_launch_poisson_sf(const double* k, const double* lam, const double* sfe, double* out, int64_t count,

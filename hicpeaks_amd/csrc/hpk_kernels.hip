@@ -28,10 +28,13 @@ namespace {
 constexpr int LC = HPK_LC;
 constexpr int LR = HPK_LR;
 
-struct __attribute__((aligned(16))) Cell {
-    double c;        // balanced
-    unsigned r;      // raw count
-    unsigned v;      // raw count where balanced != 0
+// The SAT is kept as three planes so that every access pattern of the evaluation phase is bank-conflict free
+// (lanes walk along x): f64 balanced (8-byte stride, ds_read_b64), u32 raw and u32 valid-raw (4-byte stride,
+// ds_read_b32).  Sizes: 80 KiB + 40 KiB + 40 KiB = 160 KiB.
+struct Sat {
+    double* c;       // balanced
+    unsigned* r;     // raw count
+    unsigned* v;     // raw count where balanced != 0
 };
 
 // ------------------------------------------------------------------ wave64 DPP scan (gfx9 DPP controls)
@@ -69,26 +72,38 @@ __device__ __forceinline__ void wave_exclusive_scan(double& c, unsigned& r, unsi
 }
 
 // ------------------------------------------------------------------ box sums on the SAT
-// Four off-cross quadrants (donut support) and the lower-left quadrant at Chebyshev radius rho around
-// SAT cell (Y, X).  pixc / pixv: the pixel's own balanced value / valid count; sYXm1 = S(Y, X-1).
-__device__ __forceinline__ void box_ky(const Cell* __restrict__ S, int Y, int X, int rho, double pixc, unsigned pixv,
-                                       const Cell& sYXm1, double& kc, unsigned& kv, double& yc, unsigned& yv) {
-    const int t = Y - rho - 1, b = Y + rho, xl = X - rho - 1, xr = X + rho;
-    const Cell tl = S[t * LC + xl], tm1 = S[t * LC + X - 1], tm = S[t * LC + X], tr = S[t * LC + xr];
-    const Cell bl = S[b * LC + xl], bm1 = S[b * LC + X - 1], bm = S[b * LC + X], br = S[b * LC + xr];
-    const Cell ml0 = S[(Y - 1) * LC + xl], ml1 = S[Y * LC + xl], mr0 = S[(Y - 1) * LC + xr], mr1 = S[Y * LC + xr];
-    const double top = (tl.c - tm1.c) + (tm.c - tr.c);
-    const double bot = (br.c - bm.c) + (bm1.c - bl.c);
-    const double mid = (ml1.c - ml0.c) + (mr0.c - mr1.c);
+// Four off-cross quadrants (donut support) and the lower-left quadrant at Chebyshev radius rho (per lane)
+// around SAT cell `base` = Y * LC + X.  pixc: the pixel's own balanced value; sc = S(Y, X-1).
+__device__ __forceinline__ void box_ky(const double* __restrict__ Sc, int base, int rho, double pixc, double sc,
+                                       double& kc, double& yc) {
+    const int t = base - (rho + 1) * LC, b = base + rho * LC, m0 = base - LC;
+    const int xl = -(rho + 1), xr = rho;
+    const double tl = Sc[t + xl], tm1 = Sc[t - 1], tm = Sc[t], tr = Sc[t + xr];
+    const double bl = Sc[b + xl], bm1 = Sc[b - 1], bm = Sc[b], br = Sc[b + xr];
+    const double ml0 = Sc[m0 + xl], ml1 = Sc[base + xl], mr0 = Sc[m0 + xr], mr1 = Sc[base + xr];
+    const double top = (tl - tm1) + (tm - tr);
+    const double bot = (br - bm) + (bm1 - bl);
+    const double mid = (ml1 - ml0) + (mr0 - mr1);
     kc = ((top + bot) + mid) + pixc;
-    kv = tl.v - tm1.v + tm.v - tr.v + br.v - bm.v + bm1.v - bl.v + ml1.v - ml0.v + mr0.v - mr1.v + pixv;
-    yc = (bm1.c - bl.c) - (sYXm1.c - ml1.c);
-    yv = bm1.v - bl.v - sYXm1.v + ml1.v;
+    yc = (bm1 - bl) - (sc - ml1);
+}
+// the same two boxes on the u32 valid-raw plane (exact, wrapping): decides whether a tiny f64 box sum is an
+// exact zero (every contributing balanced value is 0) or just small
+__device__ __noinline__ unsigned long long box_ky_valid(const unsigned* __restrict__ Sv, int base, int rho, unsigned pixv,
+                                                        unsigned sv) {
+    const int t = base - (rho + 1) * LC, b = base + rho * LC, m0 = base - LC;
+    const int xl = -(rho + 1), xr = rho;
+    const unsigned vtl = Sv[t + xl], vtm1 = Sv[t - 1], vtm = Sv[t], vtr = Sv[t + xr];
+    const unsigned vbl = Sv[b + xl], vbm1 = Sv[b - 1], vbm = Sv[b], vbr = Sv[b + xr];
+    const unsigned vml0 = Sv[m0 + xl], vml1 = Sv[base + xl], vmr0 = Sv[m0 + xr], vmr1 = Sv[base + xr];
+    const unsigned kv = vtl - vtm1 + vtm - vtr + vbr - vbm + vbm1 - vbl + vml1 - vml0 + vmr0 - vmr1 + pixv;
+    const unsigned yv = vbm1 - vbl - sv + vml1;
+    return (unsigned long long)kv | (unsigned long long)yv << 32;      // in registers: no scratch round trip
 }
 
-__device__ __forceinline__ unsigned reads_box(const Cell* __restrict__ S, int Y, int X, int rho, unsigned sYXm1r) {
-    const int b = Y + rho, xl = X - rho - 1;
-    return S[b * LC + X - 1].r - sYXm1r - S[b * LC + xl].r + S[Y * LC + xl].r;
+__device__ __forceinline__ unsigned reads_box(const unsigned* __restrict__ Sr, int base, int rho, unsigned sr) {
+    const int b = base + rho * LC, xl = -(rho + 1);
+    return Sr[b - 1] - sr - Sr[b + xl] + Sr[base + xl];
 }
 
 // balanced value of pixel (rr, cc) on diagonal k (formed on chip in weight mode): (raw * w_r) * w_c, NaN -> 0
@@ -98,20 +113,19 @@ __device__ __forceinline__ double balanced_of(float raw, double wr, double wc) {
 }
 
 // explicit local-expected sums for pixels whose window is clipped by the matrix ends (callers.py:50-96 padding)
-__device__ __noinline__ void edge_expected(const HpkDevStep& st, const double* __restrict__ IR, int r, int c, int n,
-                                           int num, int mw, double& EK, double& EY) {
+__device__ __noinline__ void edge_expected(const int32_t* __restrict__ m, int wi, const double* __restrict__ IR, int r,
+                                           int c, int n, int num, int mw, double& EK, double& EY) {
     double ek = 0.0, ey = 0.0;
-    const int wi = st.wi;
     for (int di = -wi; di <= wi; ++di) {
         for (int dj = -wi; dj <= wi; ++dj) {
             if (di == 0 || dj == 0) continue;
             const int adi = di < 0 ? -di : di, adj = dj < 0 ? -dj : dj;
             const int rho = adi > adj ? adi : adj;
-            const int m = st.m[rho];
-            if (m == 0) continue;
+            const int mm = m[rho];
+            if (mm == 0) continue;
             const int rr = r + di, cc = c + dj, kk = cc - rr;
             if (rr < 0 || cc >= n || kk < mw || kk >= num) continue;
-            const double v = (double)m * IR[kk];
+            const double v = (double)mm * IR[kk];
             ek += v;
             if (di > 0 && dj < 0) ey += v;
         }
@@ -121,12 +135,15 @@ __device__ __noinline__ void edge_expected(const HpkDevStep& st, const double* _
 }
 
 // ------------------------------------------------------------------ stencil
-template <int NW, bool BALF64, bool SUMS>
+template <int NW, bool BALF64, bool SIMPLE>
 __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a) {
     constexpr int RPW = LR / NW;
     static_assert(RPW * NW == LR, "rows must split evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Cell* S = reinterpret_cast<Cell*>(smem);
+    Sat S;
+    S.c = reinterpret_cast<double*>(smem);
+    S.r = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 8);
+    S.v = S.r + LR * LC;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -140,6 +157,20 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a) {
     const int c0 = r0 + a.mw + cj * a.TC;
     const int W = a.W, n = a.n, num = a.num, mw = a.mw, D = a.D;
     if (c0 >= n || (mw + cj * a.TC - (a.TR - 1)) > D) return;   // no band pixel inside the matrix
+
+    // Per-lane / per-row weights of the evaluation phase (weight mode), requested now so that their latency hides
+    // behind the SAT construction: column weights of the two 64-pixel column blocks (per lane) and the row weights
+    // of the rows this wave will evaluate (row i of the wave in lane i, fetched back with v_readlane).  The
+    // evaluation phase itself issues NO global loads: gfx9 has one vmcnt counter for loads and stores, so a load
+    // consumed after the previous pass's stores would wait for those stores to be acknowledged.
+    double ev_wc0 = 0.0, ev_wc1 = 0.0, ev_wr = 0.0;
+    if (!BALF64) {
+        const int ca = c0 + lane, cb = c0 + 64 + lane;
+        if (lane < a.TC && ca < n) ev_wc0 = a.weight[ca];
+        if (64 + lane < a.TC && cb < n) ev_wc1 = a.weight[cb];
+        const int yr = wave + NW * lane, rr = r0 + yr;
+        if (yr < a.TR && rr < n) ev_wr = a.weight[rr];
+    }
 
     // ---- phase 1: read this wave's RPW rows x 128 columns, form balanced values, column totals
     const int xx0 = 2 * lane;
@@ -186,21 +217,22 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a) {
             tv[e] += (bv != 0.0) ? ru : 0u;
         }
     }
-    // column totals of this wave's row segment -> LDS (aliases the SAT; consumed before the SAT is written)
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        Cell t; t.c = tc[e]; t.r = tr[e]; t.v = tv[e];
-        S[wave * LC + xx0 + e] = t;
+    if (a.dbg_stop == 1) {
+        if (tc[0] + tc[1] == -1.0 && tr[0] + tv[1] == 77u) a.hist[0] = 1ull;     // keep the loads live
+        return;
     }
+    // column totals of this wave's row segment -> LDS (aliases the SAT; consumed before the SAT is written)
+    *reinterpret_cast<double2*>(&S.c[wave * LC + xx0]) = make_double2(tc[0], tc[1]);
+    *reinterpret_cast<uint2*>(&S.r[wave * LC + xx0]) = make_uint2(tr[0], tr[1]);
+    *reinterpret_cast<uint2*>(&S.v[wave * LC + xx0]) = make_uint2(tv[0], tv[1]);
     __syncthreads();
     double ac[2] = {0.0, 0.0};           // running column sums of row-prefixed values = SAT of the rows above
     unsigned ar[2] = {0u, 0u}, av[2] = {0u, 0u};
     for (int w2 = 0; w2 < wave; ++w2) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const Cell t = S[w2 * LC + xx0 + e];
-            ac[e] += t.c; ar[e] += t.r; av[e] += t.v;
-        }
+        const double2 t = *reinterpret_cast<const double2*>(&S.c[w2 * LC + xx0]);
+        const uint2 u = *reinterpret_cast<const uint2*>(&S.r[w2 * LC + xx0]);
+        const uint2 q = *reinterpret_cast<const uint2*>(&S.v[w2 * LC + xx0]);
+        ac[0] += t.x; ac[1] += t.y; ar[0] += u.x; ar[1] += u.y; av[0] += q.x; av[1] += q.y;
     }
     __syncthreads();
     {   // prefix of the segment base along the row
@@ -221,132 +253,287 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a) {
         wave_exclusive_scan(pc, pr, pv);
         ac[0] += pc + c0v; ar[0] += pr + r0u; av[0] += pv + v0;
         ac[1] += pc + l1c; ar[1] += pr + l1r; av[1] += pv + l1v;
-        Cell o0; o0.c = ac[0]; o0.r = ar[0]; o0.v = av[0];
-        Cell o1; o1.c = ac[1]; o1.r = ar[1]; o1.v = av[1];
-        S[(wave * RPW + j) * LC + xx0] = o0;
-        S[(wave * RPW + j) * LC + xx0 + 1] = o1;
+        const int o = (wave * RPW + j) * LC + xx0;
+        *reinterpret_cast<double2*>(&S.c[o]) = make_double2(ac[0], ac[1]);
+        *reinterpret_cast<uint2*>(&S.r[o]) = make_uint2(ar[0], ar[1]);
+        *reinterpret_cast<uint2*>(&S.v[o]) = make_uint2(av[0], av[1]);
     }
     __syncthreads();
+    if (a.dbg_stop == 2) {
+        if (S.c[threadIdx.x] == -1.0) a.hist[0] = 1ull;
+        return;
+    }
 
     // ---- phase 3: every band pixel of the tile
+    // The widening plan lives in registers: lane s holds step s (HpkDevPlan::packed).  (A) every lane finds, per
+    // output slot, the first step whose Reads reach min_local_reads - three u32 SAT reads per radius, for "simple"
+    // plans without any step loop; (B) the donut / lower-left sums are then evaluated once per slot with per-lane
+    // radii (each lane fetches its own step's box terms with ds_bpermute), so the expensive part runs at the
+    // candidate density of the row instead of once per step for a few stragglers.  Output per slot and pixel:
+    // (bS_K, bS_Y) f64 + resolving step + 1 (u8).  The local expected, the biases and the division are applied
+    // by the scoring kernel.  Loops are deliberately not unrolled: the kernel stays inside the instruction cache.
     const HpkDevPlan* __restrict__ plan = a.plan;
     const int nsteps = plan->nsteps, nslots = plan->nslots, min_reads = plan->min_reads;
+    int pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, pk6 = 0;
+    if (lane < nsteps) {
+        const uint32_t* pk = plan->packed[lane];
+        pk0 = (int)pk[0]; pk1 = (int)pk[1]; pk2 = (int)pk[2]; pk3 = (int)pk[3];
+        pk4 = (int)pk[4]; pk5 = (int)pk[5]; pk6 = (int)pk[6];
+    }
+    // simple-Reads plans: lane (q & 1) * 32 + w of tab[q >> 1] = step of slot q at width w; lane q of wfv = first width
+    int tab0 = 0xff, tab1 = 0xff, wfv = 0;
+    int p0 = 0, wmin = 0;
+    if (SIMPLE) {
+        tab0 = plan->step_of[lane >> 5][lane & 31];
+        tab1 = plan->step_of[2 + (lane >> 5)][lane & 31];
+        wfv = plan->slot_wfirst[lane & (HPK_KSLOTS - 1)];
+        p0 = plan->reads_p0;
+        wmin = plan->wmin;
+    }
     const unsigned alldone = (1u << nslots) - 1u;
     unsigned myhist = 0u, mycand = 0u;
     const int64_t slot_stride = (int64_t)n * a.ldo;
+    const double tiny_thr = 1e-9 * S.c[LR * LC - 1];
+    // Everything the evaluation needs is in registers / LDS from here on.  gfx9 counts loads and stores on one
+    // vmcnt: a compiler-placed wait for any of these one-time loads *inside* the pixel loops would also drain the
+    // stores of the previous pass (measured: 16k cycles per pass).  Passing each value through an empty asm makes
+    // the compiler wait here, once, and treat the registers as plain values afterwards.
+#define HPK_PIN_I(x) asm volatile("" : "+v"(x))
+#define HPK_PIN_D(x) do { int lo__ = __double2loint(x), hi__ = __double2hiint(x); asm volatile("" : "+v"(lo__), "+v"(hi__)); \
+                          x = __hiloint2double(hi__, lo__); } while (0)
+    HPK_PIN_I(pk0); HPK_PIN_I(pk1); HPK_PIN_I(pk2); HPK_PIN_I(pk3); HPK_PIN_I(pk4); HPK_PIN_I(pk5); HPK_PIN_I(pk6);
+    HPK_PIN_I(tab0); HPK_PIN_I(tab1); HPK_PIN_I(wfv);
+    HPK_PIN_D(ev_wc0); HPK_PIN_D(ev_wc1); HPK_PIN_D(ev_wr);
+    const int nsteps_p = __builtin_amdgcn_readfirstlane(nsteps), nslots_p = __builtin_amdgcn_readfirstlane(nslots);
+    const int minr_p = __builtin_amdgcn_readfirstlane(min_reads), p0_p = __builtin_amdgcn_readfirstlane(p0);
+    const int wmin_p = __builtin_amdgcn_readfirstlane(wmin);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const bool prof = a.dbg_stop == 7;
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tk0 = 0, tk1 = 0;
+#define HPK_TICK(i) if (prof) { tk1 = __builtin_amdgcn_s_memtime(); tacc[i] += tk1 - tk0; tk0 = tk1; }
 
-    for (int y = wave; y < a.TR; y += NW) {
+#pragma unroll 1
+    for (int yi = 0; wave + NW * yi < a.TR; ++yi) {
+        const int y = wave + NW * yi;
         const int r = r0 + y;
         if (r >= n) break;
         const int Y = y + W + 1;
+        const double wr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ev_wr), yi),
+                                           __builtin_amdgcn_readlane(__double2loint(ev_wr), yi));
+#pragma unroll 1
         for (int xb = 0; xb < a.TC; xb += 64) {
+            if (prof) tk0 = __builtin_amdgcn_s_memtime();
             const int x = xb + lane;
             const int c = c0 + x;
             const int d = c - r;
             const bool inband = x < a.TC && c < n && d >= mw && d <= D && d < num;
-            const int X = x + W + 1;
-            float rawpix = 0.f;
-            if (inband) rawpix = a.raw[(int64_t)r * a.ld + d];
-            const bool cand = inband && rawpix != 0.f;
-            double eKs[HPK_KSLOTS], eYs[HPK_KSLOTS];
-            double4 sums[SUMS ? HPK_KSLOTS : 1];
-            unsigned wres = 0u;          // 8 bits per slot
-#pragma unroll
-            for (int q = 0; q < HPK_KSLOTS; ++q) { eKs[q] = 0.0; eYs[q] = 0.0; }
-            if (SUMS) {
-#pragma unroll
-                for (int q = 0; q < HPK_KSLOTS; ++q) sums[q] = make_double4(0.0, 0.0, 0.0, 0.0);
+            const int base = Y * LC + x + W + 1;
+            // the pixel's own count out of the u32 SAT (exact)
+            unsigned sr = 0u, rawu = 0u;
+            if (inband) {
+                sr = S.r[base - 1];
+                rawu = S.r[base] - S.r[base - LC] - sr + S.r[base - LC - 1];
             }
+            const bool cand = inband && rawu != 0u && a.dbg_stop != 4 && a.dbg_stop != 9;
             const unsigned long long candmask = __ballot(cand);
             if (lane == 0) mycand += (unsigned)__popcll(candmask);
-            if (candmask != 0ull) {
-                double pixc = 0.0, ir = 0.0, b1r = 0.0, b2c = 0.0;
-                unsigned pixv = 0u;
-                Cell sYXm1; sYXm1.c = 0.0; sYXm1.r = 0u; sYXm1.v = 0u;
+
+            HPK_TICK(0)
+            unsigned sstar = 0xffffffffu;           // resolving step index, 8 bits per slot (0xff = none)
+            double sc = 0.0, pixc = 0.0;
+            unsigned sv = 0u, pixv = 0u;
+            if (candmask != 0ull && a.dbg_stop != 15) {
                 if (cand) {
-                    if (BALF64) { pixc = a.bal[(int64_t)r * a.ld + d]; pixc = (pixc == pixc) ? pixc : 0.0; }
-                    else pixc = balanced_of(rawpix, a.weight[r], a.weight[c]);
-                    pixv = (pixc != 0.0) ? (unsigned)rawpix : 0u;
-                    ir = a.IR[d];
-                    b1r = a.b1[r];
-                    b2c = a.b2[c];
-                    sYXm1 = S[Y * LC + X - 1];
-                }
-                const bool edge = (r < W) || (c >= n - W);
-                unsigned done = cand ? 0u : alldone;
-                int cur_rid = -1;
-                unsigned reads = 0u;
-                for (int s = 0; s < nsteps; ++s) {
-                    const HpkDevStep& st = plan->steps[s];
-                    const bool need = ((done >> st.slot) & 1u) == 0u;
-                    if (__ballot(need) == 0ull) continue;
-                    if (st.reads_id != cur_rid) {
-                        cur_rid = st.reads_id;
-                        if (done != alldone) {
-                            unsigned acc = 0u;
-                            for (int j = 0; j < st.nrt; ++j)
-                                acc += (unsigned)st.rt_coef[j] * reads_box(S, Y, X, st.rt_rho[j], sYXm1.r);
-                            reads = acc;
-                        }
+                    sc = S.c[base - 1]; sv = S.v[base - 1];
+                    if (BALF64) {       // the pixel's balanced value back out of the SAT planes
+                        pixc = (S.c[base] - S.c[base - LC]) - (sc - S.c[base - LC - 1]);
+                        pixv = S.v[base] - S.v[base - LC] - sv + S.v[base - LC - 1];
+                        if (pixv == 0u) pixc = 0.0;
+                    } else {
+                        pixc = balanced_of((float)rawu, wr, xb ? ev_wc1 : ev_wc0);
+                        pixv = (pixc != 0.0) ? rawu : 0u;
                     }
-                    const bool hit = need && (reads >= (unsigned)min_reads);
-                    const unsigned long long hitmask = __ballot(hit);
-                    if (lane == s) myhist += (unsigned)__popcll(hitmask);
-                    if (hit) {
-                        double SK = 0.0, SY = 0.0;
-                        unsigned VK = 0u, VY = 0u;
-                        for (int j = 0; j < st.nkt; ++j) {
-                            double kc, yc; unsigned kv, yv;
-                            box_ky(S, Y, X, st.kt_rho[j], pixc, pixv, sYXm1, kc, kv, yc, yv);
-                            const double cf = (double)st.kt_coef[j];
-                            SK += cf * kc; SY += cf * yc;
-                            VK += (unsigned)st.kt_coef[j] * kv; VY += (unsigned)st.kt_coef[j] * yv;
-                        }
-                        if (VK == 0u) SK = 0.0;          // every contributing balanced value is 0: exact 0
-                        if (VY == 0u) SY = 0.0;
-                        double EK, EY;
-                        if (!edge) {
-                            EK = a.etab[(int64_t)(s * 2) * (D + 1) + d];
-                            EY = a.etab[(int64_t)(s * 2 + 1) * (D + 1) + d];
-                        } else {
-                            edge_expected(st, a.IR, r, c, n, num, mw, EK, EY);
-                        }
-                        // callers.py:244-249: E = ((IR[d] * (bS / bE)) * B1[x]) * B2[y] where bE != 0
-                        const double eK = (EK != 0.0) ? ((ir * (SK / EK)) * b1r) * b2c : 0.0;
-                        const double eY = (EY != 0.0) ? ((ir * (SY / EY)) * b1r) * b2c : 0.0;
+                }
+                HPK_TICK(1)
+                // ---- (A) resolving step per slot
+                if (SIMPLE) {
+                    // first width w* whose lower-left rings p0_p+1 .. w hold >= min_local_reads counts
+                    int wstar = 255;
+                    unsigned b0 = 0u;
+                    if (a.dbg_stop == 13 || a.dbg_stop == 14) { if (cand) wstar = wmin_p; }
+                    else if (cand) {
+                        b0 = (p0_p > 0) ? reads_box(S.r, base, p0_p, sr) : 0u;
+                        if (reads_box(S.r, base, wmin_p, sr) - b0 >= (unsigned)minr_p) wstar = wmin_p;
+                    }
+                    if (__ballot(cand && wstar == 255) != 0ull) {
+                        if (cand && wstar == 255) {
+                            // all remaining boxes in one batch of independent LDS reads (one round trip)
+                            unsigned bw[HPK_MAX_W];
 #pragma unroll
-                        for (int q = 0; q < HPK_KSLOTS; ++q) {
-                            if (q == st.slot) {
-                                eKs[q] = eK; eYs[q] = eY;
-                                if (SUMS) sums[q] = make_double4(SK, EK, SY, EY);
+                            for (int k = 0; k < HPK_MAX_W; ++k) {
+                                const int w = wmin_p + 1 + k;
+                                bw[k] = (w <= W) ? reads_box(S.r, base, w, sr) : 0u;
+                            }
+#pragma unroll
+                            for (int k = HPK_MAX_W - 1; k >= 0; --k) {
+                                const int w = wmin_p + 1 + k;
+                                if (w <= W && bw[k] - b0 >= (unsigned)minr_p) wstar = w;
                             }
                         }
-                        wres |= (unsigned)st.wi << (8 * st.slot);
-                        done |= 1u << st.slot;
                     }
-                    if (__ballot(done != alldone) == 0ull) break;
+                    HPK_TICK(2)
+#pragma unroll 1
+                    for (int q = 0; q < nslots_p && a.dbg_stop != 12 && a.dbg_stop != 14; ++q) {
+                        const int wf = __builtin_amdgcn_readlane(wfv, q);
+                        const int wq = wstar > wf ? wstar : wf;
+                        int sq = __shfl((q >> 1) ? tab1 : tab0, ((q & 1) << 5) + (wq & 31));
+                        if (!cand || wstar == 255) sq = 0xff;
+                        sstar = (sstar & ~(0xffu << (8 * q))) | ((unsigned)(sq & 0xff) << (8 * q));
+                        // histogram: one ballot per distinct resolving step present in the wave
+                        unsigned long long left = (a.dbg_stop == 11) ? 0ull : __ballot(sq != 0xff);
+                        while (left != 0ull) {
+                            const int ln = __ffsll((long long)left) - 1;
+                            const int sv0 = __builtin_amdgcn_readlane(sq, ln);
+                            const unsigned long long same = __ballot(sq == sv0);
+                            if (lane == sv0) myhist += (unsigned)__popcll(same);
+                            left &= ~same;
+                        }
+                    }
+                } else {
+                    unsigned done = cand ? 0u : alldone;
+                    int cur_rid = -1;
+                    unsigned reads = 0u;
+#pragma unroll 1
+                    for (int s = 0; s < nsteps_p; ++s) {
+                        const unsigned w0 = (unsigned)__builtin_amdgcn_readlane(pk0, s);
+                        const int slot = (int)(w0 & 3u), rid = (int)((w0 >> 10) & 63u), nrt = (int)((w0 >> 16) & 15u);
+                        const bool need = ((done >> slot) & 1u) == 0u;
+                        if (__ballot(need) == 0ull) continue;
+                        if (rid != cur_rid) {
+                            cur_rid = rid;
+                            const unsigned long long rt = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(pk1, s) |
+                                                          (unsigned long long)(unsigned)__builtin_amdgcn_readlane(pk2, s) << 32;
+                            if (done != alldone) {
+                                unsigned acc = 0u;
+                                for (int j = 0; j < nrt; ++j) {
+                                    const unsigned t = (unsigned)(rt >> (16 * j)) & 0xffffu;
+                                    acc += (unsigned)(int)(signed char)(t >> 8) * reads_box(S.r, base, (int)(t & 0xffu), sr);
+                                }
+                                reads = acc;
+                            }
+                        }
+                        const bool hit = need && (reads >= (unsigned)minr_p);
+                        const unsigned long long hitmask = __ballot(hit);
+                        if (lane == s) myhist += (unsigned)__popcll(hitmask);
+                        if (hit) {
+                            sstar = (sstar & ~(0xffu << (8 * slot))) | ((unsigned)s << (8 * slot));
+                            done |= 1u << slot;
+                        }
+                        if (__ballot(done != alldone) == 0ull) break;
+                    }
                 }
+                if (a.dbg_stop == 5) sstar = (sstar == 0x12345678u) ? 0u : 0xffffffffu;
             }
-            if (inband) {
-                const int64_t o = (int64_t)r * a.ldo + d;
-#pragma unroll
-                for (int q = 0; q < HPK_KSLOTS; ++q) {
-                    if (q < nslots) {
-                        a.outE[q * slot_stride + o] = make_double2(eKs[q], eYs[q]);
-                        a.outW[q * slot_stride + o] = (uint8_t)((wres >> (8 * q)) & 0xffu);
-                        if (SUMS) a.outS[q * slot_stride + o] = sums[q];
+            HPK_TICK(3)
+            // ---- (B) sums at the resolving step, once per slot; the slot's outputs are stored right away
+#pragma unroll 1
+            for (int q = 0; q < nslots_p; ++q) {
+                const int sq = (int)((sstar >> (8 * q)) & 0xffu);
+                const bool act = cand && sq != 0xff;
+                double SK = 0.0, SY = 0.0;
+                if (__ballot(act) != 0ull) {
+                    const int src = act ? sq : 0;
+                    const unsigned w0 = (unsigned)__shfl(pk0, src);
+                    const unsigned k0 = (unsigned)__shfl(pk3, src), k1 = (unsigned)__shfl(pk4, src);
+                    const unsigned k2 = (unsigned)__shfl(pk5, src), k3 = (unsigned)__shfl(pk6, src);
+                    const int nkt = act ? (int)((w0 >> 20) & 15u) : 0;
+#pragma unroll 1
+                    for (int j = 0; j < HPK_PK_KT; ++j) {
+                        const bool on = j < nkt;
+                        if (__ballot(on) == 0ull) break;
+                        if (on) {
+                            const unsigned kw = (j < 2) ? k0 : (j < 4) ? k1 : (j < 6) ? k2 : k3;
+                            const unsigned t = (kw >> (16 * (j & 1))) & 0xffffu;
+                            double kc, yc;
+                            box_ky(S.c, base, (int)(t & 0xffu), pixc, sc, kc, yc);
+                            const double cf = (double)(int)(signed char)(t >> 8);
+                            SK += cf * kc; SY += cf * yc;
+                        }
                     }
+                    // A lower-left cell on ring rho lies at least rho + 1 diagonals nearer to the main diagonal: with
+                    // rho_min the smallest ring of this step, the whole lower-left support is off the band (bS_Y = 0
+                    // exactly) for d < mw + rho_min + 1.
+                    if (d - (int)((w0 >> 24) & 31u) - 1 < mw) SY = 0.0;
+                    // A box whose balanced values are all 0 must come out as exact 0 (as the reference's CSR adds
+                    // do); the f64 SAT leaves rounding residue of at most ~1e-13 of the tile total there.  Sums
+                    // below 1e-9 of the tile total are re-examined on the exact u32 valid-raw plane.
+                    const bool tiny = act && (SK <= tiny_thr || (SY <= tiny_thr && SY != 0.0));
+                    if (__ballot(tiny) != 0ull) {
+                        if (tiny) {
+                            unsigned VK = 0u, VY = 0u;
+#pragma unroll 1
+                            for (int j = 0; j < nkt; ++j) {
+                                const unsigned kw = (j < 2) ? k0 : (j < 4) ? k1 : (j < 6) ? k2 : k3;
+                                const unsigned t = (kw >> (16 * (j & 1))) & 0xffffu;
+                                const unsigned long long kyv = box_ky_valid(S.v, base, (int)(t & 0xffu), pixv, sv);
+                                VK += (unsigned)(int)(signed char)(t >> 8) * (unsigned)kyv;
+                                VY += (unsigned)(int)(signed char)(t >> 8) * (unsigned)(kyv >> 32);
+                            }
+                            if (VK == 0u) SK = 0.0;
+                            if (VY == 0u) SY = 0.0;
+                        }
+                    }
+                    if (!act) { SK = 0.0; SY = 0.0; }
                 }
+                HPK_TICK(4)
+                if (inband && (a.dbg_stop != 3 || SK == -1.0)) {
+                    const int64_t o = q * slot_stride + (int64_t)r * a.ldo + d;
+                    if (a.dbg_stop == 8) { SK = 0.0; SY = 0.0; }                 // real work, zeros stored
+                    if (a.dbg_stop == 9) { SK = (double)(lane + r) * 1.37; SY = (double)d * 0.77; }   // no work, non-zeros stored
+                    a.outS[o] = make_double2(SK, SY);
+                    if (a.dbg_stop != 10) a.outW[o] = act ? (uint8_t)(sq + 1) : (uint8_t)0;
+                }
+                HPK_TICK(5)
             }
         }
     }
-    if (lane < nsteps && myhist) atomicAdd(&a.hist[lane], (unsigned long long)myhist);
-    if (lane == 0 && mycand) atomicAdd(&a.hist[HPK_HIST_NCAND], (unsigned long long)mycand);
+    if (prof && lane == 0) for (int i = 0; i < 6; ++i) atomicAdd(&a.hist[HPK_MAX_STEPS + 1 + i], tacc[i]);
+    // Resolve histogram: 40k same-address atomics (one per wave) serialise at ~90 per microsecond in L2 - 0.46 ms,
+    // several times the kernel itself.  Instead the waves meet in LDS (the SAT is dead now) and the block writes its
+    // partial counts with plain stores; hpk_freeze sums the partials.
+    __syncthreads();
+    unsigned* red = reinterpret_cast<unsigned*>(smem);
+    red[wave * (HPK_MAX_STEPS + 1) + lane] = myhist;
+    if (lane == 0) red[wave * (HPK_MAX_STEPS + 1) + HPK_MAX_STEPS] = mycand;
+    __syncthreads();
+    if (threadIdx.x <= HPK_MAX_STEPS) {
+        unsigned tot = 0u;
+        for (int w2 = 0; w2 < NW; ++w2) tot += red[w2 * (HPK_MAX_STEPS + 1) + threadIdx.x];
+        a.hist_part[(int64_t)tid * (HPK_MAX_STEPS + 1) + threadIdx.x] = tot;
+    }
 }
 
 // ------------------------------------------------------------------ freeze (one thread)
-__global__ void hpk_freeze(const HpkDevPlan* __restrict__ plan, const unsigned long long* __restrict__ hist,
-                           int32_t* frozen, int32_t* executed, int32_t* err) {
+__global__ void __launch_bounds__(1024) hpk_freeze(const HpkDevPlan* __restrict__ plan, unsigned long long* __restrict__ hist,
+                                                    const unsigned* __restrict__ hist_part, int nparts,
+                                                    int32_t* frozen, int32_t* executed, int32_t* err) {
+    // sum the per-tile partial histograms: thread (g, k) adds column k of rows g, g + 15, ...
+    __shared__ unsigned long long acc[15][HPK_MAX_STEPS + 1];
+    {
+        const int k = threadIdx.x % (HPK_MAX_STEPS + 1), g = threadIdx.x / (HPK_MAX_STEPS + 1);
+        if (g < 15) {
+            unsigned long long t = 0ull;
+            for (int p = g; p < nparts; p += 15) t += hist_part[(int64_t)p * (HPK_MAX_STEPS + 1) + k];
+            acc[g][k] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x <= HPK_MAX_STEPS) {
+            unsigned long long t = 0ull;
+            for (int g2 = 0; g2 < 15; ++g2) t += acc[g2][threadIdx.x];
+            hist[threadIdx.x] = t;
+        }
+        __syncthreads();
+    }
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const long long total = (long long)hist[HPK_HIST_NCAND];
     long long unres[HPK_KSLOTS];
@@ -463,87 +650,127 @@ __global__ void __launch_bounds__(256) hpk_poisson_sf_k(const double* __restrict
 }
 
 // ------------------------------------------------------------------ scoring
-// One thread per band pixel (row = blockIdx.x, diagonals mw + blockIdx.y * 256 + threadIdx.x).
+// local expected of a pixel at its resolving step: table value in the interior, explicit window where the window
+// is clipped by the matrix ends
+__device__ __forceinline__ void local_expected(const HpkDevPlan* __restrict__ plan, const double* __restrict__ etab,
+                                               const double* __restrict__ IR, int step, int r, int c, int d, int n,
+                                               int num, int mw, int D, int W, double& EK, double& EY) {
+    if (r >= W && c < n - W) {
+        EK = etab[(int64_t)(step * 2) * (D + 1) + d];
+        EY = etab[(int64_t)(step * 2 + 1) * (D + 1) + d];
+    } else {
+        edge_expected(plan->steps[step].m, plan->steps[step].wi, IR, r, c, n, num, mw, EK, EY);
+    }
+}
+
+// Persistent blocks: block b walks rows b, b + gridDim.x, ...; the per-(set, chunk) histogram lives in LDS for
+// the block's whole life and is flushed once.
 __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     __shared__ unsigned int lhist[2 * HPK_MAX_PAIRS][HPK_NB + 1];
     __shared__ unsigned long long lemax[2 * HPK_MAX_PAIRS];
     __shared__ unsigned int lvalid[2 * HPK_MAX_PAIRS];
+    __shared__ int lstepw[HPK_MAX_STEPS];
     const HpkDevPlan* __restrict__ plan = a.plan;
     const int mode = plan->mode;
     const int npairs = plan->npairs;
+    const int W = plan->W;
     const int nsets = (mode == HPK_MODE_BHFDR) ? 1 : 2 * npairs;
     for (int i = threadIdx.x; i < nsets * (HPK_NB + 1); i += blockDim.x) (&lhist[0][0])[i] = 0u;
     if (threadIdx.x < 2 * HPK_MAX_PAIRS) { lemax[threadIdx.x] = 0ull; lvalid[threadIdx.x] = 0u; }
+    if (threadIdx.x < HPK_MAX_STEPS) lstepw[threadIdx.x] = (threadIdx.x < plan->nsteps) ? plan->steps[threadIdx.x].wi : 0;
     __syncthreads();
 
-    const int r = blockIdx.x;
-    const int d = a.mw + blockIdx.y * 256 + threadIdx.x;
-    const int c = r + d;
     const int lane = threadIdx.x & 63;
-    const bool inband = d <= a.D && d < a.num && c < a.n;
-    float rawpix = 0.f;
-    if (inband) rawpix = a.raw[(int64_t)r * a.ld + d];
-    const bool cand = inband && rawpix != 0.f;
     const int frozen = *a.frozen;
     const int64_t slot_stride = (int64_t)a.n * a.ldo;
-    const int64_t o = (int64_t)r * a.ldo + d;
-    const double O = (double)rawpix;
+    const int wd = a.D - a.mw + 1;
+    for (int r = blockIdx.x; r < a.n; r += gridDim.x) {
+        const double b1r = a.b1[r];
+        for (int dd = threadIdx.x; dd < ((wd + 255) & ~255); dd += 256) {
+            const int d = a.mw + dd;
+            const int c = r + d;
+            const bool inband = dd < wd && d < a.num && c < a.n;
+            float rawpix = 0.f;
+            if (inband) rawpix = a.raw[(int64_t)r * a.ld + d];
+            const bool cand = inband && rawpix != 0.f;
+            if (__syncthreads_or(cand) == 0) continue;
+            const int64_t o = (int64_t)r * a.ldo + d;
+            const double O = (double)rawpix;
+            double ir = 0.0, b2c = 0.0;
+            if (cand) { ir = a.IR[d]; b2c = a.b2[c]; }
 
-    for (int pj = 0; pj < npairs; ++pj) {
-        const int slot = plan->pair_slot[pj];
-        const int wi0 = plan->pair_wi[pj];
-        bool ok = cand && d >= wi0;                                   // callers.py:244
-        double2 e2 = make_double2(0.0, 0.0);
-        if (ok) {
-            const unsigned w = a.outW[slot * slot_stride + o];
-            ok = (w != 0u) && ((int)w <= frozen);                     // resolved at an executed step
-            if (ok) e2 = a.outE[slot * slot_stride + o];
-        }
-        const int nfl = (mode == HPK_MODE_BHFDR) ? 1 : 2;
-        for (int fl = 0; fl < nfl; ++fl) {
-            const int set = (mode == HPK_MODE_BHFDR) ? 0 : pj * 2 + fl;
-            const double E = fl ? e2.y : e2.x;
-            const bool valid = ok && (E > 0.0);                       // callers.py:250
-            int chunk = 0;
-            double p = 1.0;
-            if (valid) {
-                atomicAdd(&lvalid[set], 1u);
-                atomicMax(&lemax[set], (unsigned long long)__double_as_longlong(E));
-                if (mode == HPK_MODE_BHFDR) {
-                    chunk = 1;
-                    p = poisson_sf(O, E, a.sfe);                      // callers.py:536-540
-                } else {
-                    // smallest i with E < bounds[i-1]; membership is strict on both sides (callers.py:38)
-                    int lo = 0, hi = HPK_NB;                          // search in bounds[0..HPK_NB)
-                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (E < a.bounds[mid]) hi = mid; else lo = mid + 1; }
-                    if (lo < HPK_NB && !(lo > 0 && E == a.bounds[lo - 1])) {
-                        chunk = lo + 1;
-                        if (chunk <= HPK_NB_TAB) {
-                            const int base = a.ptab_off[chunk], len = a.ptab_off[chunk + 1] - base;
-                            const long long kO = (long long)O;
-                            p = (kO < len) ? a.ptab[base + (int)kO] : 0.0;
-                        } else {
-                            p = poisson_sf(O, a.bounds[chunk - 1], a.sfe);   // callers.py:268-270
-                        }
+            for (int pj = 0; pj < npairs; ++pj) {
+                const int slot = plan->pair_slot[pj];
+                const int wi0 = plan->pair_wi[pj];
+                bool ok = cand && d >= wi0;                                   // callers.py:244
+                double eK = 0.0, eY = 0.0;
+                if (ok) {
+                    const int stp = (int)a.outW[slot * slot_stride + o];
+                    ok = (stp != 0) && (lstepw[stp - 1] <= frozen);           // resolved at an executed step
+                    if (ok) {
+                        const double2 s2 = a.outS[slot * slot_stride + o];
+                        double EK, EY;
+                        local_expected(plan, a.etab, a.IR, stp - 1, r, c, d, a.n, a.num, a.mw, a.D, W, EK, EY);
+                        // callers.py:244-249: E = ((IR[d] * (bS / bE)) * B1[x]) * B2[y] where bE != 0
+                        eK = (EK != 0.0) ? ((ir * (s2.x / EK)) * b1r) * b2c : 0.0;
+                        eY = (EY != 0.0) ? ((ir * (s2.y / EY)) * b1r) * b2c : 0.0;
                     }
                 }
-                if (chunk) atomicAdd(&lhist[set][chunk], 1u);
-            }
-            const bool surv = valid && chunk != 0 && p <= a.sig;      // only these can reach q <= sig
-            const unsigned long long sm = __ballot(surv);
-            if (sm != 0ull) {
-                unsigned long long base = 0ull;
-                if (lane == 0) base = atomicAdd(a.nsurv, (unsigned long long)__popcll(sm));
-                base = __shfl(base, 0);
-                if (surv) {
-                    const unsigned long long idx = base + (unsigned long long)__popcll(sm & ((1ull << lane) - 1ull));
-                    if ((int64_t)idx < a.cap) {
-                        double b;
-                        if (a.bal) { b = a.bal[(int64_t)r * a.ld + d]; b = (b == b) ? b : 0.0; }
-                        else b = balanced_of(rawpix, a.weight[r], a.weight[c]);
-                        a.sx[idx] = r; a.sy[idx] = c; a.sset[idx] = (uint8_t)set; a.schunk[idx] = (uint8_t)chunk;
-                        a.sflag[idx] = (fl == 0 && e2.y == 0.0) ? 1 : 0;      // callers.py:330
-                        a.sO[idx] = rawpix; a.sE[idx] = E; a.sp[idx] = p; a.sbal[idx] = b;
+                const int nfl = (mode == HPK_MODE_BHFDR) ? 1 : 2;
+                for (int fl = 0; fl < nfl; ++fl) {
+                    const int set = (mode == HPK_MODE_BHFDR) ? 0 : pj * 2 + fl;
+                    const double E = fl ? eY : eK;
+                    const bool valid = ok && (E > 0.0);                       // callers.py:250
+                    int chunk = 0;
+                    double p = 1.0;
+                    if (valid) {
+                        if (mode == HPK_MODE_BHFDR) {
+                            chunk = 1;
+                            p = poisson_sf(O, E, a.sfe);                      // callers.py:536-540
+                        } else {
+                            // smallest i with E < bounds[i-1]; membership is strict on both sides (callers.py:38)
+                            int lo = 0, hi = HPK_NB;
+                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (E < a.bounds[mid]) hi = mid; else lo = mid + 1; }
+                            if (lo < HPK_NB && !(lo > 0 && E == a.bounds[lo - 1])) {
+                                chunk = lo + 1;
+                                if (chunk <= HPK_NB_TAB) {
+                                    const int base = a.ptab_off[chunk], len = a.ptab_off[chunk + 1] - base;
+                                    const long long kO = (long long)O;
+                                    p = (kO < len) ? a.ptab[base + (int)kO] : 0.0;
+                                } else {
+                                    p = poisson_sf(O, a.bounds[chunk - 1], a.sfe);   // callers.py:268-270
+                                }
+                            }
+                        }
+                    }
+                    // per-wave aggregation before touching the LDS counters
+                    const unsigned long long vm = __ballot(valid);
+                    if (vm != 0ull) {
+                        double em = valid ? E : 0.0;
+                        for (int off = 32; off > 0; off >>= 1) em = fmax(em, __shfl_xor(em, off));
+                        if (lane == 0) {
+                            atomicAdd(&lvalid[set], (unsigned)__popcll(vm));
+                            atomicMax(&lemax[set], (unsigned long long)__double_as_longlong(em));
+                        }
+                        if (valid && chunk) atomicAdd(&lhist[set][chunk], 1u);
+                    }
+                    const bool surv = valid && chunk != 0 && p <= a.sig;      // only these can reach q <= sig
+                    const unsigned long long sm = __ballot(surv);
+                    if (sm != 0ull) {
+                        unsigned long long basei = 0ull;
+                        if (lane == 0) basei = atomicAdd(a.nsurv, (unsigned long long)__popcll(sm));
+                        basei = __shfl(basei, 0);
+                        if (surv) {
+                            const unsigned long long idx = basei + (unsigned long long)__popcll(sm & ((1ull << lane) - 1ull));
+                            if ((int64_t)idx < a.cap) {
+                                double b;
+                                if (a.bal) { b = a.bal[(int64_t)r * a.ld + d]; b = (b == b) ? b : 0.0; }
+                                else b = balanced_of(rawpix, a.weight[r], a.weight[c]);
+                                a.sx[idx] = r; a.sy[idx] = c; a.sset[idx] = (uint8_t)set; a.schunk[idx] = (uint8_t)chunk;
+                                a.sflag[idx] = (fl == 0 && eY == 0.0) ? 1 : 0;       // callers.py:330
+                                a.sO[idx] = rawpix; a.sE[idx] = E; a.sp[idx] = p; a.sbal[idx] = b;
+                            }
+                        }
                     }
                 }
             }
@@ -557,6 +784,38 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     if (threadIdx.x < nsets) {
         if (lvalid[threadIdx.x]) atomicAdd(&a.nvalid[threadIdx.x], (unsigned long long)lvalid[threadIdx.x]);
         if (lemax[threadIdx.x]) atomicMax(&a.emax_bits[threadIdx.x], lemax[threadIdx.x]);
+    }
+}
+
+// ------------------------------------------------------------------ dense debug outputs (tests: HPK_FLAG_DENSE_*)
+// Expands the stencil output to (E_K, E_Y), resolving width and (bS_K, bE_K, bS_Y, bE_Y) per slot and pixel.
+__global__ void __launch_bounds__(256) hpk_dense(HpkDenseArgs a) {
+    const HpkDevPlan* __restrict__ plan = a.plan;
+    const int r = blockIdx.x;
+    const int64_t slot_stride = (int64_t)a.n * a.ldo;
+    for (int d = a.mw + threadIdx.x; d <= a.D && d < a.num; d += blockDim.x) {
+        const int c = r + d;
+        if (c >= a.n) break;
+        const int64_t o = (int64_t)r * a.ldo + d;
+        for (int q = 0; q < plan->nslots; ++q) {
+            const int stp = (int)a.outW[q * slot_stride + o];
+            double2 e = make_double2(0.0, 0.0);
+            double4 sm = make_double4(0.0, 0.0, 0.0, 0.0);
+            uint8_t w = 0;
+            if (stp != 0) {
+                const double2 s2 = a.outS[q * slot_stride + o];
+                double EK, EY;
+                local_expected(plan, a.etab, a.IR, stp - 1, r, c, d, a.n, a.num, a.mw, a.D, plan->W, EK, EY);
+                const double ir = a.IR[d], b1r = a.b1[r], b2c = a.b2[c];
+                e.x = (EK != 0.0) ? ((ir * (s2.x / EK)) * b1r) * b2c : 0.0;
+                e.y = (EY != 0.0) ? ((ir * (s2.y / EY)) * b1r) * b2c : 0.0;
+                sm = make_double4(s2.x, EK, s2.y, EY);
+                w = (uint8_t)plan->steps[stp - 1].wi;
+            }
+            a.dE[q * slot_stride + o] = e;
+            a.dW[q * slot_stride + o] = w;
+            if (a.dS) a.dS[q * slot_stride + o] = sm;
+        }
     }
 }
 
@@ -596,11 +855,11 @@ __global__ void __launch_bounds__(64) hpk_brute(HpkBruteArgs a) {
 }  // namespace
 
 // ------------------------------------------------------------------ launchers
-int hpk_stencil_lds_bytes() { return LR * LC * (int)sizeof(Cell); }
+int hpk_stencil_lds_bytes() { return LR * LC * 16; }
 
-template <int NW, bool BALF64, bool SUMS>
+template <int NW, bool BALF64, bool SIMPLE>
 static void launch_stencil_t(const HpkStencilArgs& a, hipStream_t st) {
-    auto kern = hpk_stencil<NW, BALF64, SUMS>;
+    auto kern = hpk_stencil<NW, BALF64, SIMPLE>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -611,15 +870,20 @@ static void launch_stencil_t(const HpkStencilArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), hpk_stencil_lds_bytes(), st, a);
 }
 
-void hpk_launch_stencil(const HpkStencilArgs& a, bool balf64, bool sums, hipStream_t st) {
+void hpk_launch_stencil(const HpkStencilArgs& a, bool balf64, bool simple, hipStream_t st) {
     constexpr int NW = 16;
-    if (balf64) { if (sums) launch_stencil_t<NW, true, true>(a, st); else launch_stencil_t<NW, true, false>(a, st); }
-    else        { if (sums) launch_stencil_t<NW, false, true>(a, st); else launch_stencil_t<NW, false, false>(a, st); }
+    if (balf64) { if (simple) launch_stencil_t<NW, true, true>(a, st); else launch_stencil_t<NW, true, false>(a, st); }
+    else        { if (simple) launch_stencil_t<NW, false, true>(a, st); else launch_stencil_t<NW, false, false>(a, st); }
 }
 
-void hpk_launch_freeze(const HpkDevPlan* plan, const unsigned long long* hist, int32_t* frozen, int32_t* executed,
-                       int32_t* err, hipStream_t st) {
-    hipLaunchKernelGGL(hpk_freeze, dim3(1), dim3(64), 0, st, plan, hist, frozen, executed, err);
+void hpk_launch_dense(const HpkDenseArgs& a, hipStream_t st) {
+    if (a.n <= 0) return;
+    hipLaunchKernelGGL(hpk_dense, dim3(a.n), dim3(256), 0, st, a);
+}
+
+void hpk_launch_freeze(const HpkDevPlan* plan, unsigned long long* hist, const unsigned* hist_part, int nparts,
+                       int32_t* frozen, int32_t* executed, int32_t* err, hipStream_t st) {
+    hipLaunchKernelGGL(hpk_freeze, dim3(1), dim3(1024), 0, st, plan, hist, hist_part, nparts, frozen, executed, err);
 }
 
 void hpk_launch_gap(const float* raw, const double* bal, const double* weight, int32_t n, int32_t num, int64_t ld,
@@ -627,10 +891,11 @@ void hpk_launch_gap(const float* raw, const double* bal, const double* weight, i
     hipLaunchKernelGGL(hpk_gap, dim3((n + 3) / 4), dim3(256), 0, st, raw, bal, weight, n, num, ld, mw, gap);
 }
 
-void hpk_launch_score(const HpkScoreArgs& a, hipStream_t st) {
+void hpk_launch_score(const HpkScoreArgs& a, int cus, hipStream_t st) {
     const int wd = a.D - a.mw + 1;
     if (wd <= 0 || a.n <= 0) return;
-    hipLaunchKernelGGL(hpk_score, dim3(a.n, (wd + 255) / 256), dim3(256), 0, st, a);
+    const int grid = a.n < cus * 8 ? a.n : cus * 8;
+    hipLaunchKernelGGL(hpk_score, dim3(grid), dim3(256), 0, st, a);
 }
 
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,

@@ -120,7 +120,52 @@ int hpk_build_plan(const hpk_params* prm, HpkDevPlan* plan, char* msg) {
         }
         box_terms(mK, W, &st.nkt, st.kt_rho, st.kt_coef);
         box_terms(mR, W, &st.nrt, st.rt_rho, st.rt_coef);
+        if (st.nkt > HPK_PK_KT || st.nrt > HPK_PK_RT || reads_id > 63) {
+            std::snprintf(msg, 256, "step (%d,%d) needs %d donut / %d Reads box terms; the kernel packs %d / %d", pi, wi,
+                          st.nkt, st.nrt, HPK_PK_KT, HPK_PK_RT);
+            return HPK_ERR_PLAN;
+        }
+        uint32_t* pk = plan->packed[s];
+        int rho_min = 31;                       // smallest ring with a non-zero multiplicity
+        for (int rho = W; rho >= 1; --rho) if (mK[rho] > 0) rho_min = rho;
+        pk[0] = (uint32_t)st.slot | (uint32_t)wi << 4 | (uint32_t)reads_id << 10 | (uint32_t)st.nrt << 16 |
+                (uint32_t)st.nkt << 20 | (uint32_t)rho_min << 24;
+        for (int j = 0; j < st.nrt; ++j) {
+            if (st.rt_coef[j] < -128 || st.rt_coef[j] > 127) { std::snprintf(msg, 256, "box coefficient out of range"); return HPK_ERR_PLAN; }
+            pk[1 + j / 2] |= ((uint32_t)st.rt_rho[j] | ((uint32_t)(uint8_t)(int8_t)st.rt_coef[j]) << 8) << (16 * (j & 1));
+        }
+        for (int j = 0; j < st.nkt; ++j) {
+            if (st.kt_coef[j] < -128 || st.kt_coef[j] > 127) { std::snprintf(msg, 256, "box coefficient out of range"); return HPK_ERR_PLAN; }
+            pk[3 + j / 2] |= ((uint32_t)st.kt_rho[j] | ((uint32_t)(uint8_t)(int8_t)st.kt_coef[j]) << 8) << (16 * (j & 1));
+        }
     }
+
+    // simple-Reads detection
+    std::memset(plan->step_of, 0xff, sizeof(plan->step_of));
+    bool simple = plan->nsteps > 0;
+    int p0 = -1;
+    int lastw[HPK_KSLOTS];
+    for (int q = 0; q < HPK_KSLOTS; ++q) { lastw[q] = -1; plan->slot_wfirst[q] = 0; }
+    plan->wmin = plan->nsteps ? plan->steps[0].wi : 0;
+    for (int s = 0; s < plan->nsteps && simple; ++s) {
+        const HpkDevStep& st = plan->steps[s];
+        int lo = -1;
+        for (int rho = 1; rho <= W; ++rho) if (st.mr[rho]) { lo = rho; break; }
+        if (lo < 0) { simple = false; break; }
+        if (p0 < 0) p0 = lo - 1;
+        for (int rho = 0; rho <= W; ++rho)
+            if (st.mr[rho] != ((rho > p0 && rho <= st.wi) ? 1 : 0)) simple = false;
+        if (st.wi <= lastw[st.slot]) simple = false;               // widths must grow within a slot
+        if (lastw[st.slot] < 0) plan->slot_wfirst[st.slot] = st.wi;
+        lastw[st.slot] = st.wi;
+        if (st.wi < plan->wmin) simple = false;                     // plan order is by width
+        if (simple) plan->step_of[st.slot][st.wi] = (uint8_t)s;
+    }
+    // every width from a slot's first one up to W must have a step (so that max(w*, wfirst) always maps)
+    for (int q = 0; q < plan->nslots && simple; ++q)
+        for (int w = plan->slot_wfirst[q]; w <= W; ++w) if (plan->step_of[q][w] == 0xff) simple = false;
+    plan->simple_reads = simple ? 1 : 0;
+    plan->reads_p0 = simple ? p0 : 0;
     return HPK_OK;
 }
 

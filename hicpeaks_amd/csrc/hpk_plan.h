@@ -37,7 +37,23 @@ struct HpkDevPlan {
     int32_t pair_slot[HPK_MAX_PAIRS];
     int32_t pair_wi[HPK_MAX_PAIRS];
     HpkDevStep steps[HPK_MAX_STEPS];
+    // The same steps packed for the stencil kernel, which keeps step s in lane s of 7 VGPRs and reads it back
+    // with v_readlane (no memory access inside the per-pixel loop):
+    //   [0]    slot | wi << 4 | reads_id << 10 | nrt << 16 | nkt << 20 | rho_min << 24 (smallest ring with m > 0)
+    //   [1..2] up to HPK_PK_RT Reads box terms, 16 bits each: rho | (int8 coef) << 8
+    //   [3..6] up to HPK_PK_KT donut box terms, same encoding
+    uint32_t packed[HPK_MAX_STEPS][8];
+    // "Simple Reads" plans (every reference configuration with pairs listed in increasing order): the Reads matrix
+    // of a step of width wi is the lower-left rings p0+1 .. wi, so a pixel's first sufficient width w* does not
+    // depend on the slot and the resolving step of slot q is step_of[q][max(w*, slot_wfirst[q])].
+    int32_t simple_reads;
+    int32_t reads_p0;
+    int32_t wmin;                              // smallest step width
+    int32_t slot_wfirst[HPK_KSLOTS];
+    uint8_t step_of[HPK_KSLOTS][32];           // 0xff = no such step
 };
+#define HPK_PK_RT 4
+#define HPK_PK_KT 8
 
 // Returns HPK_OK or a negative status; msg (>= 256 bytes) receives the reason.
 int hpk_build_plan(const hpk_params* prm, HpkDevPlan* plan, char* msg);

@@ -1,0 +1,10 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT
+TAG=${1:-pmc}
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INST_LEVEL_LDS SQ_INSTS_VMEM SQ_INST_LEVEL_VMEM SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" \
+           "SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/$TAG -o p$i --output-format csv -- python $R/bench.py --steps 3 --warmup 1 --cpu-rows 0 --stencil-only > $R/gpurun_out/$TAG.p$i.log 2>&1
+done
