@@ -74,7 +74,8 @@ class Result(C.Structure):
                 ('gap', C.POINTER(C.c_uint8)), ('dense_ld', C.c_int64), ('dense_E', C.POINTER(C.c_double)),
                 ('dense_w', C.POINTER(C.c_uint8)), ('dense_sums', C.POINTER(C.c_double)),
                 ('ms_h2d', C.c_float), ('ms_stencil', C.c_float), ('ms_freeze', C.c_float), ('ms_score', C.c_float),
-                ('ms_gap', C.c_float), ('ms_d2h', C.c_float), ('ms_host_bh', C.c_float), ('ms_total', C.c_float),
+                ('ms_tighten', C.c_float), ('ms_gap', C.c_float), ('ms_d2h', C.c_float), ('ms_host_bh', C.c_float), ('ms_total', C.c_float),
+                ('reserved_f', C.c_float * 3), ('nsurv_sig', C.c_int64), ('nsurv_cut', C.c_int64),
                 ('stencil_tiles', C.c_int64), ('band_px', C.c_int64)]
 
 
@@ -200,7 +201,9 @@ class BandResult(object):
                                   x=x[sl], y=y[sl], O=O[sl], bal=bal[sl], E=E[sl], p=p[sl], q=q[sl],
                                   other_zero=oz[sl].astype(bool)))
         self.gap = _arr(r.gap, n, np.uint8).astype(bool)
-        self.timing = dict(h2d=r.ms_h2d, stencil=r.ms_stencil, freeze=r.ms_freeze, score=r.ms_score, gap=r.ms_gap,
+        self.nsurv_sig, self.nsurv_cut = int(r.nsurv_sig), int(r.nsurv_cut)
+        self.timing = dict(h2d=r.ms_h2d, stencil=r.ms_stencil, freeze=r.ms_freeze, score=r.ms_score, tighten=r.ms_tighten,
+                           gap=r.ms_gap,
                            d2h=r.ms_d2h, host_bh=r.ms_host_bh, total=r.ms_total)
         self.dense_E = self.dense_w = self.dense_sums = None
         if r.dense_E:

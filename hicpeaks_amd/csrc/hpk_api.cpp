@@ -60,7 +60,7 @@ struct hpk_ctx {
     DevBuf d_bounds, d_off, d_sfe, d_ptab;
     // workspaces (grow only)
     DevBuf raw, bal, weight, IR, b1, b2, plan, etab, outS, outW, dE, dW, dS, small, gap, histpart;
-    DevBuf sx, sy, sset, schunk, sflag, sO, sE, sp, sbal;
+    DevBuf surv, surv2;
     DevBuf tmpA, tmpB, tmpC, tmpD;
 };
 
@@ -138,6 +138,7 @@ struct ResultBox {
 };
 
 struct Surv { int32_t x, y; uint8_t set, chunk, flag, keep; float O; double E, p, bal, q; };
+static_assert(sizeof(HpkSurv) == 40, "survivor record layout");
 
 // Benjamini-Hochberg on the p <= sig subset of one family of m tests (statsmodels fdr_bh): the subset holds
 // the m' smallest p-values, so their ranks and step-up q-values are those of the full family.
@@ -203,8 +204,7 @@ void hpk_destroy(hpk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf* all[] = {&c->d_bounds, &c->d_off, &c->d_sfe, &c->d_ptab, &c->raw, &c->bal, &c->weight, &c->IR, &c->b1, &c->b2,
-                     &c->plan, &c->etab, &c->outS, &c->outW, &c->dE, &c->dW, &c->dS, &c->histpart, &c->small, &c->gap, &c->sx, &c->sy, &c->sset,
-                     &c->schunk, &c->sflag, &c->sO, &c->sE, &c->sp, &c->sbal, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD};
+                     &c->plan, &c->etab, &c->outS, &c->outW, &c->dE, &c->dW, &c->dS, &c->histpart, &c->small, &c->gap, &c->surv, &c->surv2, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD};
     for (DevBuf* b : all) b->release();
     for (int i = 0; i < c->nev; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -332,14 +332,17 @@ int check_band(hpk_ctx* c, const hpk_band* band) {
 
 // small device scratch block layout (bytes)
 constexpr size_t OFF_HIST = 0;                                                   // u64[65]
-constexpr size_t OFF_FROZEN = OFF_HIST + 8 * (HPK_MAX_STEPS + 1 + 8);   // + 8 profiling slots               // i32
+constexpr size_t OFF_FROZEN = OFF_HIST + 8 * (HPK_MAX_STEPS + 1);               // i32
 constexpr size_t OFF_ERR = OFF_FROZEN + 8;                                       // i32
 constexpr size_t OFF_EXEC = OFF_ERR + 8;                                         // i32[64]
 constexpr size_t OFF_NSURV = OFF_EXEC + 4 * HPK_MAX_STEPS;                       // u64
 constexpr size_t OFF_NVALID = OFF_NSURV + 8;                                     // u64[16]
 constexpr size_t OFF_EMAX = OFF_NVALID + 8 * 2 * HPK_MAX_PAIRS;                  // u64[16]
-constexpr size_t OFF_CHIST = OFF_EMAX + 8 * 2 * HPK_MAX_PAIRS;                   // u32[16][129]
-constexpr size_t SMALL_BYTES = OFF_CHIST + 4 * 2 * HPK_MAX_PAIRS * (HPK_NB + 1);
+constexpr size_t OFF_NOUT = OFF_EMAX + 8 * 2 * HPK_MAX_PAIRS;                    // u64
+constexpr size_t OFF_FAM_M = OFF_NOUT + 8;                                       // u32[HPK_NFAM]
+constexpr size_t OFF_FAM_F = OFF_FAM_M + 4 * HPK_NFAM;                           // u32[HPK_NFAM]
+constexpr size_t OFF_THR = OFF_FAM_F + 4 * HPK_NFAM;                             // f64[HPK_NFAM]
+constexpr size_t SMALL_BYTES = OFF_THR + 8 * HPK_NFAM;
 
 }  // namespace
 
@@ -416,7 +419,6 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     unsigned long long* d_nsurv = reinterpret_cast<unsigned long long*>(small + OFF_NSURV);
     unsigned long long* d_nvalid = reinterpret_cast<unsigned long long*>(small + OFF_NVALID);
     unsigned long long* d_emax = reinterpret_cast<unsigned long long*>(small + OFF_EMAX);
-    unsigned int* d_chist = reinterpret_cast<unsigned int*>(small + OFF_CHIST);
 
     // ---- stencil
     HpkStencilArgs sa;
@@ -448,20 +450,19 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     R.band_px = band_px;
     R.stencil_tiles = sa.ntiles;
 
-    // ---- scoring
+    // ---- scoring + BH cut tightening
+    unsigned long long* d_nout = reinterpret_cast<unsigned long long*>(small + OFF_NOUT);
+    unsigned int* d_fam_m = reinterpret_cast<unsigned int*>(small + OFF_FAM_M);
+    unsigned int* d_fam_f = reinterpret_cast<unsigned int*>(small + OFF_FAM_F);
+    double* d_thr = reinterpret_cast<double*>(small + OFF_THR);
+    std::vector<unsigned char> hsmall(SMALL_BYTES);
     int64_t cap = 0;
-    if (do_score) {
-        cap = std::max<int64_t>(1 << 16, band_px * nsets / 6);
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            HIPCHK(c, c->sx.reserve(4 * (size_t)cap));
-            HIPCHK(c, c->sy.reserve(4 * (size_t)cap));
-            HIPCHK(c, c->sset.reserve((size_t)cap));
-            HIPCHK(c, c->schunk.reserve((size_t)cap));
-            HIPCHK(c, c->sflag.reserve((size_t)cap));
-            HIPCHK(c, c->sO.reserve(4 * (size_t)cap));
-            HIPCHK(c, c->sE.reserve(8 * (size_t)cap));
-            HIPCHK(c, c->sp.reserve(8 * (size_t)cap));
-            HIPCHK(c, c->sbal.reserve(8 * (size_t)cap));
+    (void)hipEventRecord(c->ev[3], c->stream);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (do_score) {
+            if (cap == 0) cap = std::max<int64_t>(1 << 16, band_px * nsets / 6) + (int64_t)c->cus * 8 * 4 * 256 * 2;
+            HIPCHK(c, c->surv.reserve(sizeof(HpkSurv) * (size_t)cap));
+            HIPCHK(c, c->surv2.reserve(sizeof(HpkSurv) * (size_t)cap));
             HpkScoreArgs sc;
             std::memset(&sc, 0, sizeof(sc));
             sc.raw = in.raw; sc.bal = in.bal; sc.weight = in.weight; sc.outS = sa.outS; sc.outW = sa.outW; sc.plan = sa.plan;
@@ -469,40 +470,45 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
             sc.frozen = d_frozen; sc.bounds = c->d_bounds.as<double>(); sc.ptab = c->d_ptab.as<double>();
             sc.ptab_off = c->d_off.as<int32_t>(); sc.sfe = c->d_sfe.as<double>(); sc.sig = prm->sig;
             sc.n = n; sc.num = num; sc.ld = band->ld; sc.ldo = ldo; sc.mw = mw; sc.D = D;
-            sc.chunk_hist = d_chist; sc.emax_bits = d_emax; sc.nvalid = d_nvalid; sc.nsurv = d_nsurv; sc.cap = cap;
-            sc.sx = c->sx.as<int32_t>(); sc.sy = c->sy.as<int32_t>(); sc.sset = c->sset.as<uint8_t>();
-            sc.schunk = c->schunk.as<uint8_t>(); sc.sflag = c->sflag.as<uint8_t>(); sc.sO = c->sO.as<float>();
-            sc.sE = c->sE.as<double>(); sc.sp = c->sp.as<double>(); sc.sbal = c->sbal.as<double>();
+            sc.fam_m = d_fam_m; sc.fam_f = d_fam_f; sc.emax_bits = d_emax; sc.nvalid = d_nvalid; sc.nsurv = d_nsurv;
+            sc.cap = cap; sc.surv = c->surv.as<HpkSurv>();
             hpk_launch_score(sc, c->cus, c->stream);
             HIPCHK(c, hipGetLastError());
-            unsigned long long ns = 0;
-            HIPCHK(c, hipMemcpyAsync(&ns, d_nsurv, 8, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
-            if ((int64_t)ns <= cap) break;
-            if (attempt == 1) return fail(c, HPK_ERR_NOMEM, "survivor buffer overflow");
-            cap = (int64_t)ns + 1024;           // rerun with room for everything
-            HIPCHK(c, hipMemsetAsync(small + OFF_NSURV, 0, SMALL_BYTES - OFF_NSURV, c->stream));
+            (void)hipEventRecord(c->ev[4], c->stream);
+            hpk_launch_tighten(sc.surv, d_nsurv, cap, d_fam_m, d_fam_f, d_thr, prm->sig, 2, c->surv2.as<HpkSurv>(), d_nout,
+                               c->cus, c->stream);
+            HIPCHK(c, hipGetLastError());
+        } else {
+            (void)hipEventRecord(c->ev[4], c->stream);
         }
+        (void)hipEventRecord(c->ev[5], c->stream);
+        if (attempt == 0) {
+            hpk_launch_gap(in.raw, in.bal, in.weight, n, num, band->ld, mw, c->gap.as<uint8_t>(), c->stream);
+            HIPCHK(c, hipGetLastError());
+        }
+        (void)hipEventRecord(c->ev[6], c->stream);
+        HIPCHK(c, hipMemcpyAsync(hsmall.data(), small, SMALL_BYTES, hipMemcpyDeviceToHost, c->stream));
+        if (attempt == 0) {
+            box->gap.resize(n);
+            HIPCHK(c, hipMemcpyAsync(box->gap.data(), c->gap.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const unsigned long long ns = *reinterpret_cast<const unsigned long long*>(hsmall.data() + OFF_NSURV);
+        if (!do_score || (int64_t)ns <= cap) break;
+        if (attempt == 1) return fail(c, HPK_ERR_NOMEM, "survivor buffer overflow");
+        cap = (int64_t)ns * 2 + 1024;           // rerun the scoring with room for everything (slots are chunked)
+        HIPCHK(c, hipMemsetAsync(small + OFF_NSURV, 0, SMALL_BYTES - OFF_NSURV, c->stream));
     }
-    (void)hipEventRecord(c->ev[4], c->stream);
-    hpk_launch_gap(in.raw, in.bal, in.weight, n, num, band->ld, mw, c->gap.as<uint8_t>(), c->stream);
-    HIPCHK(c, hipGetLastError());
-    (void)hipEventRecord(c->ev[5], c->stream);
 
     // ---- results to host
-    std::vector<unsigned char> hsmall(SMALL_BYTES);
-    HIPCHK(c, hipMemcpyAsync(hsmall.data(), small, SMALL_BYTES, hipMemcpyDeviceToHost, c->stream));
-    box->gap.resize(n);
-    HIPCHK(c, hipMemcpyAsync(box->gap.data(), c->gap.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     const unsigned long long* h_hist = reinterpret_cast<const unsigned long long*>(hsmall.data() + OFF_HIST);
     const int32_t h_frozen = *reinterpret_cast<const int32_t*>(hsmall.data() + OFF_FROZEN);
     const int32_t h_err = *reinterpret_cast<const int32_t*>(hsmall.data() + OFF_ERR);
     const int32_t* h_exec = reinterpret_cast<const int32_t*>(hsmall.data() + OFF_EXEC);
-    const unsigned long long h_nsurv = *reinterpret_cast<const unsigned long long*>(hsmall.data() + OFF_NSURV);
+    const unsigned long long h_nsurv = *reinterpret_cast<const unsigned long long*>(hsmall.data() + OFF_NOUT);
     const unsigned long long* h_nvalid = reinterpret_cast<const unsigned long long*>(hsmall.data() + OFF_NVALID);
     const unsigned long long* h_emax = reinterpret_cast<const unsigned long long*>(hsmall.data() + OFF_EMAX);
-    const unsigned int* h_chist = reinterpret_cast<const unsigned int*>(hsmall.data() + OFF_CHIST);
+    const unsigned int* h_chist = reinterpret_cast<const unsigned int*>(hsmall.data() + OFF_FAM_M);
 
     R.nsteps = plan.nsteps;
     for (int s = 0; s < plan.nsteps; ++s) {
@@ -515,10 +521,9 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     R.nslots = plan.nslots;
     for (int q = 0; q < plan.nslots; ++q) R.slot_pi[q] = plan.slot_pi[q];
     R.ncand = (int64_t)h_hist[HPK_HIST_NCAND];
-    if (sa.dbg_stop == 7)
-        std::fprintf(stderr, "[hpk prof] wave-cycles cand=%llu pix=%llu wstar=%llu slots=%llu B=%llu store=%llu\n",
-                     h_hist[HPK_MAX_STEPS + 1], h_hist[HPK_MAX_STEPS + 2], h_hist[HPK_MAX_STEPS + 3],
-                     h_hist[HPK_MAX_STEPS + 4], h_hist[HPK_MAX_STEPS + 5], h_hist[HPK_MAX_STEPS + 6]);
+    R.nsurv_sig = 0;
+    for (int i = 0; i < HPK_NFAM; ++i) R.nsurv_sig += reinterpret_cast<const unsigned int*>(hsmall.data() + OFF_FAM_F)[i];
+    R.nsurv_cut = (int64_t)h_nsurv;
     R.gap = box->gap.data();
     if (h_err != 0 && sa.dbg_stop == 0) {
         const HpkDevStep& st = plan.steps[h_err - 1];
@@ -530,23 +535,13 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     std::vector<Surv> sv;
     if (do_score && h_nsurv) {
         const size_t ns = (size_t)h_nsurv;
-        std::vector<int32_t> hx(ns), hy(ns);
-        std::vector<uint8_t> hset(ns), hch(ns), hfl(ns);
-        std::vector<float> hO(ns);
-        std::vector<double> hE(ns), hp(ns), hb(ns);
-        HIPCHK(c, hipMemcpyAsync(hx.data(), c->sx.p, 4 * ns, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(hy.data(), c->sy.p, 4 * ns, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(hset.data(), c->sset.p, ns, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(hch.data(), c->schunk.p, ns, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(hfl.data(), c->sflag.p, ns, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(hO.data(), c->sO.p, 4 * ns, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(hE.data(), c->sE.p, 8 * ns, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(hp.data(), c->sp.p, 8 * ns, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(hb.data(), c->sbal.p, 8 * ns, hipMemcpyDeviceToHost, c->stream));
+        std::vector<HpkSurv> recs(ns);
+        HIPCHK(c, hipMemcpyAsync(recs.data(), c->surv2.p, sizeof(HpkSurv) * ns, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         sv.resize(ns);
         for (size_t i = 0; i < ns; ++i)
-            sv[i] = Surv{hx[i], hy[i], hset[i], hch[i], hfl[i], 0, hO[i], hE[i], hp[i], hb[i], 1.0};
+            sv[i] = Surv{recs[i].x, recs[i].y, recs[i].set, recs[i].chunk, recs[i].flag, 0, recs[i].O, recs[i].E, recs[i].p,
+                         recs[i].bal, 1.0};
     }
     if (dense) {
         HpkDenseArgs da;
@@ -625,7 +620,8 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) R.ms_stencil = ms;
     if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) R.ms_freeze = ms;
     if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) R.ms_score = ms;
-    if (hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) R.ms_gap = ms;
+    if (hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) R.ms_tighten = ms;
+    if (hipEventElapsedTime(&ms, c->ev[5], c->ev[6]) == hipSuccess) R.ms_gap = ms;
     R.ms_d2h = (float)(t_d2h1 - t_d2h0);
     R.ms_host_bh = (float)(t_end - t_d2h1);
     R.ms_total = (float)(t_end - t_begin);

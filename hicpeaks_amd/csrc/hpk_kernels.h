@@ -15,7 +15,7 @@ struct HpkStencilArgs {
     const HpkDevPlan* plan;
     double2* outS;                      // [nslots][n][ldo]  (bS_K, bS_Y) at the resolving step
     uint8_t* outW;                      // [nslots][n][ldo]  resolving step + 1, 0 = unresolved
-    unsigned long long* hist;           // [HPK_MAX_STEPS + 1 + 8] totals (written by hpk_freeze) + profiling slots
+    unsigned long long* hist;           // [HPK_MAX_STEPS + 1] totals, written by hpk_freeze
     unsigned* hist_part;                // [ntiles][HPK_MAX_STEPS + 1] per-tile resolve counts, [..][HPK_MAX_STEPS] = candidates
     int32_t n, num;
     int64_t ld, ldo;
@@ -23,8 +23,18 @@ struct HpkStencilArgs {
     int32_t TR, TC;                     // output tile = (HPK_LR - 2W - 1) x (HPK_LC - 2W - 1)
     int32_t J;                          // column chunks per row block
     int32_t ntiles, chunk;              // chunk = ceil(ntiles / 8): tiles handed to one XCD
-    int32_t dbg_stop;                   // profiling ablation: 1 = stop after the loads, 2 = after the SAT
+    int32_t dbg_stop;                   // profiling ablation (HPK_DBG_STOP): 1 stop after the loads, 2 after the SAT,
+                                        // 4 no candidates (loads + SAT + zero stores), 5 search without box sums
 };
+
+// One pixel that can still end with q <= sig (40 bytes).
+struct HpkSurv {
+    int32_t x, y;
+    float O;
+    uint8_t set, chunk, flag, pad;
+    double E, p, bal;
+};
+#define HPK_NFAM (2 * HPK_MAX_PAIRS * (HPK_NB + 1))     // (set, chunk) families
 
 struct HpkScoreArgs {
     const float*  raw;
@@ -47,13 +57,13 @@ struct HpkScoreArgs {
     int64_t ld, ldo;
     int32_t mw, D;
     // outputs
-    unsigned int* chunk_hist;           // [nsets][HPK_NB + 1]
+    unsigned int* fam_m;                // [HPK_NFAM] tests per family (chunk sizes, callers.py:266)
+    unsigned int* fam_f;                // [HPK_NFAM] of those, p <= sig
     unsigned long long* emax_bits;      // [nsets]
     unsigned long long* nvalid;         // [nsets]
     unsigned long long* nsurv;          // scalar
     int64_t cap;                        // survivor capacity
-    int32_t* sx; int32_t* sy; uint8_t* sset; uint8_t* schunk; uint8_t* sflag;
-    float* sO; double* sE; double* sp; double* sbal;
+    HpkSurv* surv;
 };
 
 struct HpkDenseArgs {
@@ -79,6 +89,11 @@ void hpk_launch_freeze(const HpkDevPlan* plan, unsigned long long* hist, const u
 void hpk_launch_gap(const float* raw, const double* bal, const double* weight, int32_t n, int32_t num,
                     int64_t ld, int32_t mw, uint8_t* gap, hipStream_t st);
 void hpk_launch_score(const HpkScoreArgs& a, int cus, hipStream_t st);
+// Benjamini-Hochberg cut tightening on the survivor list: thr[f] <- sig * #{p <= thr[f]} / m[f], `rounds` times,
+// then compaction of the records with p <= thr[f] into `out` (count in *nout).
+void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned int* fam_m,
+                        unsigned int* fam_cnt, double* fam_thr, double sig, int rounds, HpkSurv* out,
+                        unsigned long long* nout, int cus, hipStream_t st);
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,
                      hipStream_t st);
 void hpk_launch_poisson_sf(const double* k, const double* lam, const double* sfe, double* out, int64_t count,

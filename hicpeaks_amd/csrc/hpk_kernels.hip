@@ -308,9 +308,6 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a) {
     const int minr_p = __builtin_amdgcn_readfirstlane(min_reads), p0_p = __builtin_amdgcn_readfirstlane(p0);
     const int wmin_p = __builtin_amdgcn_readfirstlane(wmin);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    const bool prof = a.dbg_stop == 7;
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tk0 = 0, tk1 = 0;
-#define HPK_TICK(i) if (prof) { tk1 = __builtin_amdgcn_s_memtime(); tacc[i] += tk1 - tk0; tk0 = tk1; }
 
 #pragma unroll 1
     for (int yi = 0; wave + NW * yi < a.TR; ++yi) {
@@ -322,7 +319,6 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a) {
                                            __builtin_amdgcn_readlane(__double2loint(ev_wr), yi));
 #pragma unroll 1
         for (int xb = 0; xb < a.TC; xb += 64) {
-            if (prof) tk0 = __builtin_amdgcn_s_memtime();
             const int x = xb + lane;
             const int c = c0 + x;
             const int d = c - r;
@@ -334,15 +330,13 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a) {
                 sr = S.r[base - 1];
                 rawu = S.r[base] - S.r[base - LC] - sr + S.r[base - LC - 1];
             }
-            const bool cand = inband && rawu != 0u && a.dbg_stop != 4 && a.dbg_stop != 9;
+            const bool cand = inband && rawu != 0u && a.dbg_stop != 4;
             const unsigned long long candmask = __ballot(cand);
             if (lane == 0) mycand += (unsigned)__popcll(candmask);
-
-            HPK_TICK(0)
             unsigned sstar = 0xffffffffu;           // resolving step index, 8 bits per slot (0xff = none)
             double sc = 0.0, pixc = 0.0;
             unsigned sv = 0u, pixv = 0u;
-            if (candmask != 0ull && a.dbg_stop != 15) {
+            if (candmask != 0ull) {
                 if (cand) {
                     sc = S.c[base - 1]; sv = S.v[base - 1];
                     if (BALF64) {       // the pixel's balanced value back out of the SAT planes
@@ -354,43 +348,38 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a) {
                         pixv = (pixc != 0.0) ? rawu : 0u;
                     }
                 }
-                HPK_TICK(1)
                 // ---- (A) resolving step per slot
                 if (SIMPLE) {
                     // first width w* whose lower-left rings p0_p+1 .. w hold >= min_local_reads counts
                     int wstar = 255;
                     unsigned b0 = 0u;
-                    if (a.dbg_stop == 13 || a.dbg_stop == 14) { if (cand) wstar = wmin_p; }
-                    else if (cand) {
+                    if (cand) {
                         b0 = (p0_p > 0) ? reads_box(S.r, base, p0_p, sr) : 0u;
                         if (reads_box(S.r, base, wmin_p, sr) - b0 >= (unsigned)minr_p) wstar = wmin_p;
                     }
                     if (__ballot(cand && wstar == 255) != 0ull) {
                         if (cand && wstar == 255) {
-                            // all remaining boxes in one batch of independent LDS reads (one round trip)
-                            unsigned bw[HPK_MAX_W];
+                            // remaining widths, four boxes (12 independent LDS reads) per round trip
+#pragma unroll 1
+                            for (int w = wmin_p + 1; w <= W && wstar == 255; w += 4) {
+                                unsigned bw[4];
 #pragma unroll
-                            for (int k = 0; k < HPK_MAX_W; ++k) {
-                                const int w = wmin_p + 1 + k;
-                                bw[k] = (w <= W) ? reads_box(S.r, base, w, sr) : 0u;
-                            }
+                                for (int k = 0; k < 4; ++k) bw[k] = reads_box(S.r, base, (w + k <= W) ? w + k : W, sr);
 #pragma unroll
-                            for (int k = HPK_MAX_W - 1; k >= 0; --k) {
-                                const int w = wmin_p + 1 + k;
-                                if (w <= W && bw[k] - b0 >= (unsigned)minr_p) wstar = w;
+                                for (int k = 3; k >= 0; --k)
+                                    if (w + k <= W && bw[k] - b0 >= (unsigned)minr_p) wstar = w + k;
                             }
                         }
                     }
-                    HPK_TICK(2)
 #pragma unroll 1
-                    for (int q = 0; q < nslots_p && a.dbg_stop != 12 && a.dbg_stop != 14; ++q) {
+                    for (int q = 0; q < nslots_p; ++q) {
                         const int wf = __builtin_amdgcn_readlane(wfv, q);
                         const int wq = wstar > wf ? wstar : wf;
                         int sq = __shfl((q >> 1) ? tab1 : tab0, ((q & 1) << 5) + (wq & 31));
                         if (!cand || wstar == 255) sq = 0xff;
                         sstar = (sstar & ~(0xffu << (8 * q))) | ((unsigned)(sq & 0xff) << (8 * q));
                         // histogram: one ballot per distinct resolving step present in the wave
-                        unsigned long long left = (a.dbg_stop == 11) ? 0ull : __ballot(sq != 0xff);
+                        unsigned long long left = __ballot(sq != 0xff);
                         while (left != 0ull) {
                             const int ln = __ffsll((long long)left) - 1;
                             const int sv0 = __builtin_amdgcn_readlane(sq, ln);
@@ -434,7 +423,6 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a) {
                 }
                 if (a.dbg_stop == 5) sstar = (sstar == 0x12345678u) ? 0u : 0xffffffffu;
             }
-            HPK_TICK(3)
             // ---- (B) sums at the resolving step, once per slot; the slot's outputs are stored right away
 #pragma unroll 1
             for (int q = 0; q < nslots_p; ++q) {
@@ -485,19 +473,14 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a) {
                     }
                     if (!act) { SK = 0.0; SY = 0.0; }
                 }
-                HPK_TICK(4)
-                if (inband && (a.dbg_stop != 3 || SK == -1.0)) {
+                if (inband) {
                     const int64_t o = q * slot_stride + (int64_t)r * a.ldo + d;
-                    if (a.dbg_stop == 8) { SK = 0.0; SY = 0.0; }                 // real work, zeros stored
-                    if (a.dbg_stop == 9) { SK = (double)(lane + r) * 1.37; SY = (double)d * 0.77; }   // no work, non-zeros stored
                     a.outS[o] = make_double2(SK, SY);
-                    if (a.dbg_stop != 10) a.outW[o] = act ? (uint8_t)(sq + 1) : (uint8_t)0;
+                    a.outW[o] = act ? (uint8_t)(sq + 1) : (uint8_t)0;
                 }
-                HPK_TICK(5)
             }
         }
     }
-    if (prof && lane == 0) for (int i = 0; i < 6; ++i) atomicAdd(&a.hist[HPK_MAX_STEPS + 1 + i], tacc[i]);
     // Resolve histogram: 40k same-address atomics (one per wave) serialise at ~90 per microsecond in L2 - 0.46 ms,
     // several times the kernel itself.  Instead the waves meet in LDS (the SAT is dead now) and the block writes its
     // partial counts with plain stores; hpk_freeze sums the partials.
@@ -663,10 +646,13 @@ __device__ __forceinline__ void local_expected(const HpkDevPlan* __restrict__ pl
     }
 }
 
-// Persistent blocks: block b walks rows b, b + gridDim.x, ...; the per-(set, chunk) histogram lives in LDS for
-// the block's whole life and is flushed once.
+// Persistent blocks: block b walks rows b, b + gridDim.x, ...; the per-family counters live in LDS for the block's
+// whole life and are flushed once.  Chunk boundaries sit in LDS; the chunk of E is 3 * exponent(E) plus two
+// comparisons against the reference's own boundary values.
 __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
-    __shared__ unsigned int lhist[2 * HPK_MAX_PAIRS][HPK_NB + 1];
+    __shared__ unsigned int lm[2 * HPK_MAX_PAIRS][HPK_NB + 1];
+    __shared__ unsigned int lf[2 * HPK_MAX_PAIRS][HPK_NB + 1];
+    __shared__ double lbounds[HPK_NB];
     __shared__ unsigned long long lemax[2 * HPK_MAX_PAIRS];
     __shared__ unsigned int lvalid[2 * HPK_MAX_PAIRS];
     __shared__ int lstepw[HPK_MAX_STEPS];
@@ -675,7 +661,8 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     const int npairs = plan->npairs;
     const int W = plan->W;
     const int nsets = (mode == HPK_MODE_BHFDR) ? 1 : 2 * npairs;
-    for (int i = threadIdx.x; i < nsets * (HPK_NB + 1); i += blockDim.x) (&lhist[0][0])[i] = 0u;
+    for (int i = threadIdx.x; i < nsets * (HPK_NB + 1); i += blockDim.x) { (&lm[0][0])[i] = 0u; (&lf[0][0])[i] = 0u; }
+    if (threadIdx.x < HPK_NB) lbounds[threadIdx.x] = a.bounds[threadIdx.x];
     if (threadIdx.x < 2 * HPK_MAX_PAIRS) { lemax[threadIdx.x] = 0ull; lvalid[threadIdx.x] = 0u; }
     if (threadIdx.x < HPK_MAX_STEPS) lstepw[threadIdx.x] = (threadIdx.x < plan->nsteps) ? plan->steps[threadIdx.x].wi : 0;
     __syncthreads();
@@ -684,6 +671,11 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     const int frozen = *a.frozen;
     const int64_t slot_stride = (int64_t)a.n * a.ldo;
     const int wd = a.D - a.mw + 1;
+    // Survivor slots are reserved from the global counter HPK_SCH records at a time per wave (same-address atomics
+    // run at ~90 per microsecond device-wide); slots a wave leaves unused are marked invalid (set = 0xff).
+    constexpr unsigned HPK_SCH = 256;
+    unsigned long long wbase = 0ull;
+    unsigned wused = HPK_SCH;               // "no chunk yet"
     for (int r = blockIdx.x; r < a.n; r += gridDim.x) {
         const double b1r = a.b1[r];
         for (int dd = threadIdx.x; dd < ((wd + 255) & ~255); dd += 256) {
@@ -693,7 +685,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
             float rawpix = 0.f;
             if (inband) rawpix = a.raw[(int64_t)r * a.ld + d];
             const bool cand = inband && rawpix != 0.f;
-            if (__syncthreads_or(cand) == 0) continue;
+            if (__ballot(cand) == 0ull) continue;
             const int64_t o = (int64_t)r * a.ldo + d;
             const double O = (double)rawpix;
             double ir = 0.0, b2c = 0.0;
@@ -728,21 +720,27 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                             chunk = 1;
                             p = poisson_sf(O, E, a.sfe);                      // callers.py:536-540
                         } else {
-                            // smallest i with E < bounds[i-1]; membership is strict on both sides (callers.py:38)
-                            int lo = 0, hi = HPK_NB;
-                            while (lo < hi) { const int mid = (lo + hi) >> 1; if (E < a.bounds[mid]) hi = mid; else lo = mid + 1; }
-                            if (lo < HPK_NB && !(lo > 0 && E == a.bounds[lo - 1])) {
+                            // lo = number of boundaries <= E (boundaries are 2^(i/3), i = 0..); membership is strict on
+                            // both sides (callers.py:38), so E sitting on a boundary belongs to no chunk
+                            int lo = 0;
+                            if (E >= 1.0) {
+                                const int e3 = 3 * (((int)(__double_as_longlong(E) >> 52) & 0x7ff) - 1023);
+                                if (e3 + 2 < HPK_NB) lo = e3 + 1 + (E >= lbounds[e3 + 1] ? 1 : 0) + (E >= lbounds[e3 + 2] ? 1 : 0);
+                                else lo = HPK_NB;
+                            }
+                            if (lo < HPK_NB && !(lo > 0 && E == lbounds[lo - 1])) {
                                 chunk = lo + 1;
                                 if (chunk <= HPK_NB_TAB) {
                                     const int base = a.ptab_off[chunk], len = a.ptab_off[chunk + 1] - base;
                                     const long long kO = (long long)O;
                                     p = (kO < len) ? a.ptab[base + (int)kO] : 0.0;
                                 } else {
-                                    p = poisson_sf(O, a.bounds[chunk - 1], a.sfe);   // callers.py:268-270
+                                    p = poisson_sf(O, lbounds[chunk - 1], a.sfe);   // callers.py:268-270
                                 }
                             }
                         }
                     }
+                    const bool surv = valid && chunk != 0 && p <= a.sig;      // only these can reach q <= sig
                     // per-wave aggregation before touching the LDS counters
                     const unsigned long long vm = __ballot(valid);
                     if (vm != 0ull) {
@@ -752,23 +750,35 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                             atomicAdd(&lvalid[set], (unsigned)__popcll(vm));
                             atomicMax(&lemax[set], (unsigned long long)__double_as_longlong(em));
                         }
-                        if (valid && chunk) atomicAdd(&lhist[set][chunk], 1u);
+                        if (valid && chunk) atomicAdd(&lm[set][chunk], 1u);
+                        if (surv) atomicAdd(&lf[set][chunk], 1u);
                     }
-                    const bool surv = valid && chunk != 0 && p <= a.sig;      // only these can reach q <= sig
                     const unsigned long long sm = __ballot(surv);
                     if (sm != 0ull) {
-                        unsigned long long basei = 0ull;
-                        if (lane == 0) basei = atomicAdd(a.nsurv, (unsigned long long)__popcll(sm));
-                        basei = __shfl(basei, 0);
+                        const unsigned cnt = (unsigned)__popcll(sm);
+                        if (wused + cnt > HPK_SCH) {            // wave-uniform: retire the chunk, take a new one
+                            if (wused < HPK_SCH) {
+                                for (unsigned k = wused + lane; k < HPK_SCH; k += 64)
+                                    if ((int64_t)(wbase + k) < a.cap) a.surv[wbase + k].set = 0xff;
+                            }
+                            unsigned long long nb = 0ull;
+                            if (lane == 0) nb = atomicAdd(a.nsurv, (unsigned long long)HPK_SCH);
+                            wbase = __shfl(nb, 0);
+                            wused = 0u;
+                        }
+                        const unsigned long long basei = wbase + wused;
+                        wused += cnt;
                         if (surv) {
                             const unsigned long long idx = basei + (unsigned long long)__popcll(sm & ((1ull << lane) - 1ull));
                             if ((int64_t)idx < a.cap) {
                                 double b;
                                 if (a.bal) { b = a.bal[(int64_t)r * a.ld + d]; b = (b == b) ? b : 0.0; }
                                 else b = balanced_of(rawpix, a.weight[r], a.weight[c]);
-                                a.sx[idx] = r; a.sy[idx] = c; a.sset[idx] = (uint8_t)set; a.schunk[idx] = (uint8_t)chunk;
-                                a.sflag[idx] = (fl == 0 && eY == 0.0) ? 1 : 0;       // callers.py:330
-                                a.sO[idx] = rawpix; a.sE[idx] = E; a.sp[idx] = p; a.sbal[idx] = b;
+                                HpkSurv rec;
+                                rec.x = r; rec.y = c; rec.O = rawpix; rec.set = (uint8_t)set; rec.chunk = (uint8_t)chunk;
+                                rec.flag = (fl == 0 && eY == 0.0) ? 1 : 0;           // callers.py:330
+                                rec.pad = 0; rec.E = E; rec.p = p; rec.bal = b;
+                                a.surv[idx] = rec;
                             }
                         }
                     }
@@ -776,14 +786,77 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
             }
         }
     }
+    if (wused < HPK_SCH) {
+        for (unsigned k = wused + lane; k < HPK_SCH; k += 64)
+            if ((int64_t)(wbase + k) < a.cap) a.surv[wbase + k].set = 0xff;
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < nsets * (HPK_NB + 1); i += blockDim.x) {
-        const unsigned v = (&lhist[0][0])[i];
-        if (v) atomicAdd(&a.chunk_hist[i], v);
+        const unsigned v = (&lm[0][0])[i], f = (&lf[0][0])[i];
+        if (v) atomicAdd(&a.fam_m[i], v);
+        if (f) atomicAdd(&a.fam_f[i], f);
     }
     if (threadIdx.x < nsets) {
         if (lvalid[threadIdx.x]) atomicAdd(&a.nvalid[threadIdx.x], (unsigned long long)lvalid[threadIdx.x]);
         if (lemax[threadIdx.x]) atomicMax(&a.emax_bits[threadIdx.x], lemax[threadIdx.x]);
+    }
+}
+
+// ------------------------------------------------------------------ BH cut tightening on the survivor list
+// Benjamini-Hochberg rejects the k* smallest p-values of a family of m tests, k* = max{k : p_(k) <= sig k / m}.
+// With F(t) = #{p <= t}: k* <= F(sig), hence p_(k*) <= sig F(sig) / m =: T1 <= sig, then p_(k*) <= sig F(T1) / m, ...
+// Every p-value above the current bound is irrelevant both for the rejection set and for the q-values of the
+// rejected ones (their step-up terms exceed sig), so the list can be cut to p <= T before it leaves the device.
+__global__ void __launch_bounds__(256) hpk_thr_init(const unsigned int* fam_m, const unsigned int* fam_f, double* thr,
+                                                    unsigned int* cnt, double sig) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HPK_NFAM) return;
+    const unsigned m = fam_m[i];
+    thr[i] = m ? fmin(sig, sig * ((double)fam_f[i] / (double)m) * (1.0 + 1e-9)) : 0.0;
+    cnt[i] = 0u;
+}
+__global__ void __launch_bounds__(256) hpk_thr_count(const HpkSurv* __restrict__ surv, const unsigned long long* __restrict__ nsurv,
+                                                     int64_t cap, const double* __restrict__ thr, unsigned int* __restrict__ cnt) {
+    __shared__ unsigned int lc[HPK_NFAM];
+    for (int i = threadIdx.x; i < HPK_NFAM; i += blockDim.x) lc[i] = 0u;
+    __syncthreads();
+    int64_t n = (int64_t)*nsurv; if (n > cap) n = cap;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (surv[i].set == 0xff) continue;
+        const int f = (int)surv[i].set * (HPK_NB + 1) + (int)surv[i].chunk;
+        if (surv[i].p <= thr[f]) atomicAdd(&lc[f], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HPK_NFAM; i += blockDim.x) if (lc[i]) atomicAdd(&cnt[i], lc[i]);
+}
+__global__ void __launch_bounds__(256) hpk_thr_update(const unsigned int* __restrict__ fam_m, double* __restrict__ thr,
+                                                      unsigned int* __restrict__ cnt, double sig) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= HPK_NFAM) return;
+    const unsigned m = fam_m[i];
+    if (m) thr[i] = fmin(thr[i], sig * ((double)cnt[i] / (double)m) * (1.0 + 1e-9));
+    cnt[i] = 0u;
+}
+__global__ void __launch_bounds__(256) hpk_thr_compact(const HpkSurv* __restrict__ surv, const unsigned long long* __restrict__ nsurv,
+                                                       int64_t cap, const double* __restrict__ thr, HpkSurv* __restrict__ out,
+                                                       unsigned long long* __restrict__ nout) {
+    int64_t n = (int64_t)*nsurv; if (n > cap) n = cap;
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
+        const int64_t i = i0 + threadIdx.x;
+        bool keep = false;
+        HpkSurv rec;
+        if (i < n) {
+            rec = surv[i];
+            keep = rec.set != 0xff && rec.p <= thr[(int)rec.set * (HPK_NB + 1) + (int)rec.chunk];
+        }
+        const unsigned long long km = __ballot(keep);
+        if (km == 0ull) continue;
+        unsigned long long basei = 0ull;
+        if (lane == 0) basei = atomicAdd(nout, (unsigned long long)__popcll(km));
+        basei = __shfl(basei, 0);
+        if (keep) out[basei + (unsigned long long)__popcll(km & ((1ull << lane) - 1ull))] = rec;
     }
 }
 
@@ -896,6 +969,19 @@ void hpk_launch_score(const HpkScoreArgs& a, int cus, hipStream_t st) {
     if (wd <= 0 || a.n <= 0) return;
     const int grid = a.n < cus * 8 ? a.n : cus * 8;
     hipLaunchKernelGGL(hpk_score, dim3(grid), dim3(256), 0, st, a);
+}
+
+void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned int* fam_m,
+                        unsigned int* fam_cnt, double* fam_thr, double sig, int rounds, HpkSurv* out,
+                        unsigned long long* nout, int cus, hipStream_t st) {
+    const int fb = (HPK_NFAM + 255) / 256;
+    // fam_cnt enters holding F(sig) (written by hpk_score)
+    hipLaunchKernelGGL(hpk_thr_init, dim3(fb), dim3(256), 0, st, fam_m, fam_cnt, fam_thr, fam_cnt, sig);
+    for (int r = 0; r < rounds; ++r) {
+        hipLaunchKernelGGL(hpk_thr_count, dim3(cus * 2), dim3(256), 0, st, surv, nsurv, cap, fam_thr, fam_cnt);
+        hipLaunchKernelGGL(hpk_thr_update, dim3(fb), dim3(256), 0, st, fam_m, fam_thr, fam_cnt, sig);
+    }
+    hipLaunchKernelGGL(hpk_thr_compact, dim3(cus * 2), dim3(256), 0, st, surv, nsurv, cap, fam_thr, out, nout);
 }
 
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,

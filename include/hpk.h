@@ -138,7 +138,10 @@ typedef struct {
     const double*  dense_sums; /* [..][4] = (bS_K, bE_K, bS_Y, bE_Y) */
 
     /* timing, milliseconds (HIP events on the ctx stream; wall for host parts) */
-    float ms_h2d, ms_stencil, ms_freeze, ms_score, ms_gap, ms_d2h, ms_host_bh, ms_total;
+    float ms_h2d, ms_stencil, ms_freeze, ms_score, ms_tighten, ms_gap, ms_d2h, ms_host_bh, ms_total;
+    float reserved_f[3];
+    int64_t nsurv_sig;         /* pixels with p <= sig (before the BH cut is tightened on the device) */
+    int64_t nsurv_cut;         /* of those, how many were copied back for the final Benjamini-Hochberg step */
     int64_t stencil_tiles;
     int64_t band_px;           /* pixels with min(ww) <= d <= maxapart/res inside the matrix */
 } hpk_result;
