@@ -291,8 +291,6 @@ int stage_inputs(hpk_ctx* c, const hpk_band* band, Staged* s) {
     s->hIR.resize(num);
     if (band->on_device) {
         s->raw = band->raw; s->bal = band->balanced; s->weight = band->weight; s->IR = band->IR; s->b1 = band->bias1; s->b2 = band->bias2;
-        HIPCHK(c, hipMemcpyAsync(s->hIR.data(), band->IR, sizeof(double) * num, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
         return HPK_OK;
     }
     std::memcpy(s->hIR.data(), band->IR, sizeof(double) * num);
@@ -384,13 +382,11 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     (void)hipEventRecord(c->ev[0], c->stream);
     rc = stage_inputs(c, band, &in);
     if (rc != HPK_OK) return rc;
-    std::vector<double> etab((size_t)plan.nsteps * 2 * (D + 1));
-    hpk_build_etab(&plan, in.hIR.data(), num, etab.data());
     HIPCHK(c, c->plan.reserve(sizeof(HpkDevPlan)));
     HIPCHK(c, hipMemcpyAsync(c->plan.p, &plan, sizeof(plan), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, c->etab.reserve(sizeof(double) * std::max<size_t>(etab.size(), 1)));
-    if (!etab.empty())
-        HIPCHK(c, hipMemcpyAsync(c->etab.p, etab.data(), sizeof(double) * etab.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, c->etab.reserve(sizeof(double) * std::max<size_t>((size_t)plan.nsteps * 2 * (D + 1), 1)));
+    hpk_launch_etab(c->plan.as<HpkDevPlan>(), plan.nsteps, D, in.IR, num, c->etab.as<double>(), c->stream);
+    HIPCHK(c, hipGetLastError());
     const int64_t ldo = ((int64_t)(D + 1) + 31) / 32 * 32;
     const size_t dense_elems = (size_t)plan.nslots * (size_t)n * (size_t)ldo;
     HIPCHK(c, c->outS.reserve(sizeof(double2) * dense_elems));

@@ -496,27 +496,46 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a) {
     }
 }
 
-// ------------------------------------------------------------------ freeze (one thread)
-__global__ void __launch_bounds__(1024) hpk_freeze(const HpkDevPlan* __restrict__ plan, unsigned long long* __restrict__ hist,
-                                                    const unsigned* __restrict__ hist_part, int nparts,
-                                                    int32_t* frozen, int32_t* executed, int32_t* err) {
-    // sum the per-tile partial histograms: thread (g, k) adds column k of rows g, g + 15, ...
-    __shared__ unsigned long long acc[15][HPK_MAX_STEPS + 1];
-    {
-        const int k = threadIdx.x % (HPK_MAX_STEPS + 1), g = threadIdx.x / (HPK_MAX_STEPS + 1);
-        if (g < 15) {
-            unsigned long long t = 0ull;
-            for (int p = g; p < nparts; p += 15) t += hist_part[(int64_t)p * (HPK_MAX_STEPS + 1) + k];
-            acc[g][k] = t;
-        }
-        __syncthreads();
-        if (threadIdx.x <= HPK_MAX_STEPS) {
-            unsigned long long t = 0ull;
-            for (int g2 = 0; g2 < 15; ++g2) t += acc[g2][threadIdx.x];
-            hist[threadIdx.x] = t;
-        }
+// ------------------------------------------------------------------ local-expected tables (callers.py:66-72 + 175-198)
+// bE of step s / filter fl at an interior pixel depends on the diagonal only: sum over the window's diagonal offsets
+// of (cells at that offset, with multiplicity) * IR.  One thread per table entry, offsets added in ascending order.
+__global__ void __launch_bounds__(256) hpk_etab(const HpkDevPlan* __restrict__ plan, const double* __restrict__ IR, int num,
+                                                double* __restrict__ etab) {
+    const int D = plan->D, W = plan->W, mw = plan->mw;
+    const int total = plan->nsteps * 2 * (D + 1);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int d = i % (D + 1), sf = i / (D + 1);
+    const int16_t* cf = plan->ecoef[sf >> 1][sf & 1];
+    double acc = 0.0;
+    for (int k = 0; k <= 4 * W; ++k) {
+        const int kk = d + k - 2 * W;
+        const int c = cf[k];
+        if (c == 0 || kk < mw || kk >= num) continue;
+        acc += (double)c * IR[kk];
+    }
+    etab[i] = acc;
+}
+
+// ------------------------------------------------------------------ resolve histogram: column sums of the per-tile partials
+__global__ void __launch_bounds__(256) hpk_hist_reduce(const unsigned* __restrict__ hist_part, int nparts,
+                                                       unsigned long long* __restrict__ hist) {
+    __shared__ unsigned long long red[256];
+    const int k = blockIdx.x;
+    unsigned long long t = 0ull;
+    for (int p = threadIdx.x; p < nparts; p += 256) t += hist_part[(int64_t)p * (HPK_MAX_STEPS + 1) + k];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
+    if (threadIdx.x == 0) hist[k] = red[0];
+}
+
+// ------------------------------------------------------------------ freeze (one thread)
+__global__ void hpk_freeze(const HpkDevPlan* __restrict__ plan, const unsigned long long* __restrict__ hist,
+                           int32_t* frozen, int32_t* executed, int32_t* err) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const long long total = (long long)hist[HPK_HIST_NCAND];
     long long unres[HPK_KSLOTS];
@@ -592,7 +611,7 @@ __device__ __forceinline__ double dpois(double x, double lam, const double* __re
 }
 // 1 - cdf(k; lam) formed like the reference forms it (1 - pdtr): through the cdf rounded to f64, so that the
 // far tail quantises to multiples of 2^-53 and reaches exactly 0.
-__device__ double poisson_sf(double k, double lam, const double* __restrict__ sfe) {
+__device__ __noinline__ double poisson_sf(double k, double lam, const double* __restrict__ sfe) {
     if (!(lam > 0.0)) return 0.0;
     if (k < 0.0) return 1.0;
     k = floor(k);
@@ -956,7 +975,8 @@ void hpk_launch_dense(const HpkDenseArgs& a, hipStream_t st) {
 
 void hpk_launch_freeze(const HpkDevPlan* plan, unsigned long long* hist, const unsigned* hist_part, int nparts,
                        int32_t* frozen, int32_t* executed, int32_t* err, hipStream_t st) {
-    hipLaunchKernelGGL(hpk_freeze, dim3(1), dim3(1024), 0, st, plan, hist, hist_part, nparts, frozen, executed, err);
+    hipLaunchKernelGGL(hpk_hist_reduce, dim3(HPK_MAX_STEPS + 1), dim3(256), 0, st, hist_part, nparts, hist);
+    hipLaunchKernelGGL(hpk_freeze, dim3(1), dim3(64), 0, st, plan, hist, frozen, executed, err);
 }
 
 void hpk_launch_gap(const float* raw, const double* bal, const double* weight, int32_t n, int32_t num, int64_t ld,
@@ -982,6 +1002,12 @@ void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, in
         hipLaunchKernelGGL(hpk_thr_update, dim3(fb), dim3(256), 0, st, fam_m, fam_thr, fam_cnt, sig);
     }
     hipLaunchKernelGGL(hpk_thr_compact, dim3(cus * 2), dim3(256), 0, st, surv, nsurv, cap, fam_thr, out, nout);
+}
+
+void hpk_launch_etab(const HpkDevPlan* plan, int nsteps, int D, const double* IR, int num, double* etab, hipStream_t st) {
+    const int total = nsteps * 2 * (D + 1);
+    if (total <= 0) return;
+    hipLaunchKernelGGL(hpk_etab, dim3((total + 255) / 256), dim3(256), 0, st, plan, IR, num, etab);
 }
 
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,

@@ -166,39 +166,39 @@ int hpk_build_plan(const hpk_params* prm, HpkDevPlan* plan, char* msg) {
         for (int w = plan->slot_wfirst[q]; w <= W; ++w) if (plan->step_of[q][w] == 0xff) simple = false;
     plan->simple_reads = simple ? 1 : 0;
     plan->reads_p0 = simple ? p0 : 0;
-    return HPK_OK;
-}
 
-void hpk_build_etab(const HpkDevPlan* plan, const double* IR, int32_t num, double* etab) {
-    const int W = plan->W, D = plan->D, mw = plan->mw;
-    const int span = 4 * W + 1;                 // delta = dj - di in [-2W, 2W]
-    std::vector<int> aK(span), aY(span);
+    // cell counts per diagonal offset for the local-expected tables
     for (int s = 0; s < plan->nsteps; ++s) {
         const HpkDevStep& st = plan->steps[s];
-        std::fill(aK.begin(), aK.end(), 0);
-        std::fill(aY.begin(), aY.end(), 0);
         for (int rho = 1; rho <= W; ++rho) {
             const int m = st.m[rho];
             if (m == 0) continue;
             for (int di = -rho; di <= rho; ++di)
                 for (int dj = -rho; dj <= rho; ++dj) {
                     if (std::max(std::abs(di), std::abs(dj)) != rho || di == 0 || dj == 0) continue;
-                    aK[dj - di + 2 * W] += m;
-                    if (di > 0 && dj < 0) aY[dj - di + 2 * W] += m;
+                    plan->ecoef[s][0][dj - di + 2 * W] += (int16_t)m;
+                    if (di > 0 && dj < 0) plan->ecoef[s][1][dj - di + 2 * W] += (int16_t)m;
                 }
         }
-        double* tK = etab + (size_t)(s * 2 + 0) * (D + 1);
-        double* tY = etab + (size_t)(s * 2 + 1) * (D + 1);
-        for (int d = 0; d <= D; ++d) {
-            double sk = 0.0, sy = 0.0;
-            for (int t = 0; t < span; ++t) {
-                const int kk = d + t - 2 * W;
-                if (kk < mw || kk >= num) continue;
-                if (aK[t]) sk += (double)aK[t] * IR[kk];
-                if (aY[t]) sy += (double)aY[t] * IR[kk];
-            }
-            tK[d] = sk;
-            tY[d] = sy;
-        }
     }
+    return HPK_OK;
+}
+
+void hpk_build_etab(const HpkDevPlan* plan, const double* IR, int32_t num, double* etab) {
+    const int W = plan->W, D = plan->D, mw = plan->mw;
+    const int span = 4 * W + 1;                 // delta = dj - di in [-2W, 2W]
+    for (int s = 0; s < plan->nsteps; ++s)
+        for (int fl = 0; fl < 2; ++fl) {
+            double* t = etab + (size_t)(s * 2 + fl) * (D + 1);
+            for (int d = 0; d <= D; ++d) {
+                double acc = 0.0;
+                for (int k = 0; k < span; ++k) {
+                    const int kk = d + k - 2 * W;
+                    const int cf = plan->ecoef[s][fl][k];
+                    if (cf == 0 || kk < mw || kk >= num) continue;
+                    acc += (double)cf * IR[kk];
+                }
+                t[d] = acc;
+            }
+        }
 }

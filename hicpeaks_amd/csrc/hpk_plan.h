@@ -51,6 +51,9 @@ struct HpkDevPlan {
     int32_t wmin;                              // smallest step width
     int32_t slot_wfirst[HPK_KSLOTS];
     uint8_t step_of[HPK_KSLOTS][32];           // 0xff = no such step
+    // Local-expected stencils for the device-side table build: the window of step s holds ecoef[s][fl][t] cells
+    // (with multiplicity) at diagonal offset delta = t - 2W, so bE[s][fl](d) = sum_t ecoef * IR[d + t - 2W].
+    int16_t ecoef[HPK_MAX_STEPS][2][4 * HPK_MAX_W + 1];
 };
 #define HPK_PK_RT 4
 #define HPK_PK_KT 8
@@ -60,4 +63,4 @@ int hpk_build_plan(const hpk_params* prm, HpkDevPlan* plan, char* msg);
 
 // Interior local-expected sums: etab[(s * 2 + fl) * (D + 1) + d] = sum over the window cells of step s
 // (with multiplicity) of IR[d + dj - di]; valid for pixels at least W bins away from both matrix ends.
-void hpk_build_etab(const HpkDevPlan* plan, const double* IR, int32_t num, double* etab);
+void hpk_build_etab(const HpkDevPlan* plan, const double* IR, int32_t num, double* etab);   // host version (tests)
