@@ -101,19 +101,25 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29500')
         dist.init_process_group('nccl', rank=rank, world_size=world)
 
-    from hicpeaks_amd import _lib, band
+    from hicpeaks_amd import _lib, band, bandgen
     ctx = _lib.Context(local)
-    raw, weight, IR, biases, num = make_band_host(cfg, seed=rank)
     n = cfg['n']
     mw = min(cfg['ww'])
     D = cfg['maxapart'] // cfg['res']
+    num = D + cfg['maxww'] + 1
     ld = (num + 63) // 64 * 64
     dev = torch.device('cuda', local)
-    raw_d = torch.zeros((n, ld), dtype=torch.float32, device=dev)
-    raw_d[:, :num] = torch.from_numpy(raw.astype(np.float32)).to(dev)
-    w_d = torch.from_numpy(weight).to(dev)
-    ir_d = torch.from_numpy(IR).to(dev)
-    b_d = torch.from_numpy(biases).to(dev)
+    if n * num <= 20_000_000:         # small enough for the host generator shared with the tests
+        raw, weight, IR, biases, num = make_band_host(cfg, seed=rank)
+        raw_d = torch.zeros((n, ld), dtype=torch.float32, device=dev)
+        raw_d[:, :num] = torch.from_numpy(raw.astype(np.float32)).to(dev)
+        w_d = torch.from_numpy(weight).to(dev)
+        ir_d = torch.from_numpy(IR).to(dev)
+        b_d = torch.from_numpy(biases).to(dev)
+    else:                             # same recipe, generated in HBM
+        raw_d, w_d, ir_d, b_d = bandgen.device_band(n, num, ld, mw, depth=cfg['depth'], nloops=cfg['nloops'], seed=rank,
+                                                    device=dev)
+    torch.cuda.synchronize()
     flags = _lib.FLAG_NO_SCORE if args.stencil_only else 0
     prm = _lib.make_params(_lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], cfg['maxww'], SIG, cfg['maxapart'], cfg['res'],
                            MIN_READS, flags)

@@ -1,0 +1,66 @@
+"""Device-side synthetic bands for the large benchmark configurations (torch is used for memory and RNG only).
+
+Same recipe as `synthetic.synth_band` without the planted loops' host loop being a bottleneck:
+Poisson(depth * (1 + k)^-alpha) per diagonal, 3x3 enrichments, weights 1/sqrt(marginal + 1) with NaN runs.
+Returns torch tensors on `device`: raw f32 [n, ld], weight f64 [n], IR f64 [num], biases f64 [n].
+"""
+import numpy as np
+
+
+def device_band(n, num, ld, mw, depth=60.0, alpha=1.0, nloops=200, seed=0, nan_frac=0.025, enrich=8.0, device='cuda'):
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    k = torch.arange(num, device=device, dtype=torch.float32)
+    lam = depth * (1.0 + k) ** (-alpha)
+    raw = torch.zeros((n, ld), dtype=torch.float32, device=device)
+    rows = 8192
+    rng = np.random.default_rng(seed)
+    loops = []
+    for _ in range(nloops):
+        d = int(rng.integers(10, max(11, num - 15)))
+        r = int(rng.integers(2, max(3, n - d - 2)))
+        loops.append((r, d))
+    loops.sort()
+    for r0 in range(0, n, rows):
+        r1 = min(n, r0 + rows)
+        rate = lam.unsqueeze(0).expand(r1 - r0, num).clone()
+        for (r, d) in loops:
+            if r0 - 1 <= r <= r1:
+                for dr in (-1, 0, 1):
+                    for dc in (-1, 0, 1):
+                        rr, kk = r + dr, d + dc - dr
+                        if r0 <= rr < r1 and 0 <= kk < num:
+                            rate[rr - r0, kk] *= enrich
+        blk = torch.poisson(rate, generator=g)
+        rr = torch.arange(r0, r1, device=device).unsqueeze(1)
+        blk[(rr + torch.arange(num, device=device).unsqueeze(0)) >= n] = 0
+        raw[r0:r1, :num] = blk
+    band = raw[:, :num].to(torch.float64)
+    rowsum = band.sum(dim=1)
+    colsum = torch.zeros(n, dtype=torch.float64, device=device)
+    for kk in range(1, num):
+        colsum[kk:] += band[: n - kk, kk]
+    weight = 1.0 / torch.sqrt(rowsum + colsum + 1.0)
+    nbad = int(round(n * nan_frac))
+    if nbad > 0:
+        run = max(1, (2 * nbad) // 3)
+        start = int(rng.integers(n // 3, max(n // 3 + 1, 2 * n // 3 - run)))
+        weight[start:start + run] = float('nan')
+        if nbad - run > 0:
+            idx = torch.from_numpy(rng.choice(n, size=nbad - run, replace=False)).to(device)
+            weight[idx] = float('nan')
+    # IR[d] = mean over the diagonal of the balanced values, stored pixels in masked bins left out (pyHICCUPS:150-156)
+    IR = torch.zeros(num, dtype=torch.float64, device=device)
+    for d in range(mw, min(num, n)):
+        m = n - d
+        cnt = band[:m, d]
+        diag = (cnt * weight[:m]) * weight[d:d + m]
+        nan = torch.isnan(diag) & (cnt != 0)
+        diag = torch.where(cnt == 0, torch.zeros_like(diag), diag)
+        good = ~nan
+        IR[d] = diag[good].sum() / good.sum()
+    ok = ~((weight == 0) | torch.isnan(weight))
+    biases = torch.zeros_like(weight)
+    biases[ok] = 1.0 / weight[ok]
+    return raw, weight, IR, biases

@@ -24,3 +24,178 @@ def format_hiccups(chrom, table, res, sort=False):
 def format_bhfdr(chrom, table, res, sort=False):
     """13 columns (pyBHFDR:171)."""
     return _format(BHFDR_FMT, chrom, table, res, sort)
+
+
+# ----------------------------------------------------------------------------- command lines
+import argparse
+import logging
+import logging.handlers
+import sys
+
+
+def _hiccups_parser():
+    """Flags of scripts/pyHICCUPS:12-81 (same names and defaults) plus --device / --balanced-on-host."""
+    from . import __version__, __reference__
+    p = argparse.ArgumentParser(usage='%(prog)s <-O output> [options]',
+                                description='HiCCUPS peak calling on AMD MI355X (drop-in for pyHICCUPS of %s).' % __reference__,
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument('-v', '--version', action='version', version=' '.join(['%(prog)s', __version__]))
+    p.add_argument('-O', '--output', help='Output file name.')
+    p.add_argument('--logFile', default='pyHICCUPS.log', help='Logging file name.')
+    g1 = p.add_argument_group(title='Relate to Hi-C data:')
+    g1.add_argument('-p', '--path', help='Cooler URI (or a band archive .npz).')
+    g1.add_argument('-C', '--chroms', nargs='*', default=['#', 'X'],
+                    help='List of chromosome labels. "#" stands for chromosomes with numerical labels. '
+                    '"--chroms" with zero argument will include all chromosome data.')
+    g2 = p.add_argument_group(title='Algorithm Parameters:')
+    g2.add_argument('--pw', type=int, nargs='+', help='List of the peak widths.')
+    g2.add_argument('--ww', type=int, nargs='+', help='List of the donut widths.')
+    g2.add_argument('--maxww', type=int, default=10, help='Maximum donut width.')
+    g2.add_argument('--siglevel', type=float, default=0.05, help='Significant Level.')
+    g2.add_argument('--sumq', type=float, default=0.01, help='Maximum sum of the 2 q-values of an isolated peak pixel.')
+    g2.add_argument('--double-fold', type=float, default=1.75, help='Minimum fold enrichment over both backgrounds.')
+    g2.add_argument('--single-fold', type=float, default=2, help='Minimum fold enrichment over either background.')
+    g2.add_argument('--clr-weight-name', default='weight', help='Name of the weight column.')
+    g2.add_argument('--use-raw', action='store_true', help='Sort peak pixels by raw signals during local clustering.')
+    g2.add_argument('--min-marginal-peaks', type=int, default=2, help='Minimum marginal number of peaks of an anchor.')
+    g2.add_argument('--min-local-reads', type=int, default=16, help='Minimum sum of contacts in the vicinity of a loop.')
+    g2.add_argument('--only-anchors', action='store_true', help='Either of the peak loci must be an anchor.')
+    g2.add_argument('--maxapart', type=int, default=10000000, help='Maximum genomic distance between two loci.')
+    g2.add_argument('--nproc', type=int, default=1, help='Number of worker processes (one per GPU).')
+    g2.add_argument('--device', type=int, default=None, help='GPU ordinal (default: local rank / worker index).')
+    return p
+
+
+def _bhfdr_parser():
+    """Flags of scripts/pyBHFDR:12-58."""
+    from . import __version__, __reference__
+    p = argparse.ArgumentParser(usage='%(prog)s <-O output> [options]',
+                                description='BH-FDR peak calling on AMD MI355X (drop-in for pyBHFDR of %s).' % __reference__,
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    p.add_argument('-v', '--version', action='version', version=' '.join(['%(prog)s', __version__]))
+    p.add_argument('-O', '--output', help='Output file name.')
+    p.add_argument('--logFile', default='pyBHFDR.log', help='Logging file name.')
+    g1 = p.add_argument_group(title='Relate to Hi-C data:')
+    g1.add_argument('-p', '--path', help='Cooler URI (or a band archive .npz).')
+    g1.add_argument('-C', '--chroms', nargs='*', default=['#', 'X'], help='List of chromosome labels.')
+    g2 = p.add_argument_group(title='Algorithm Parameters:')
+    g2.add_argument('--pw', type=int, default=2, help='Width of the interaction region surrounding the peak.')
+    g2.add_argument('--ww', type=int, default=5, help='Width of the donut sampled.')
+    g2.add_argument('--maxww', type=int, default=10, help='Maximum donut width.')
+    g2.add_argument('--siglevel', type=float, default=0.05, help='Significant Level.')
+    g2.add_argument('--maxapart', type=int, default=2000000, help='Maximum genomic distance between two loci.')
+    g2.add_argument('--clr-weight-name', default='weight', help='Name of the weight column.')
+    g2.add_argument('--nproc', type=int, default=1, help='Number of worker processes (one per GPU).')
+    g2.add_argument('--device', type=int, default=None, help='GPU ordinal.')
+    return p
+
+
+def _setup_logging(logfile, rotating):
+    """Root logger as in scripts/pyHICCUPS:88-105 / scripts/pyBHFDR:66-84."""
+    logger = logging.getLogger()
+    logger.setLevel(10)
+    console = logging.StreamHandler()
+    fh = (logging.handlers.RotatingFileHandler(logfile, maxBytes=200000, backupCount=5) if rotating
+          else logging.FileHandler(logfile))
+    console.setLevel('INFO')
+    fh.setLevel('INFO')
+    fmt = logging.Formatter(fmt='%(name)-21s %(levelname)-7s @ %(asctime)s: %(message)s', datefmt='%m/%d/%y %H:%M:%S')
+    console.setFormatter(fmt)
+    fh.setFormatter(fmt)
+    logger.addHandler(console)
+    logger.addHandler(fh)
+    return logger
+
+
+def select_chroms(chromnames, chroms):
+    """scripts/pyHICCUPS:185-187."""
+    out = []
+    for key in chromnames:
+        label = key.lstrip('chr')
+        if (not chroms) or (label.isdigit() and '#' in chroms) or (label in chroms):
+            out.append(key)
+    return out
+
+
+def _score_chrom(args_dict, mode, key, device):
+    """One work item = one chromosome (the body of worker(), scripts/pyHICCUPS:139-175)."""
+    from . import band, callers, io, _lib
+    a = args_dict
+    src = io.open_source(a['path'])
+    res = src.binsize
+    ctx = _lib.default_context(device)
+    if mode == 'hiccups':
+        num = a['maxapart'] // res + a['maxww'] + 1
+        raw, w = src.fetch(key, num, a['clr_weight_name'])
+        IR, biases = band.expected_and_biases(raw, w, min(a['ww']))
+        table = callers.hiccups_band(raw, IR, biases, biases, chrom=key.lstrip('chr'), weight=w, pw=a['pw'], ww=a['ww'],
+                                     maxww=a['maxww'], sig=a['siglevel'], sumq=a['sumq'], double_fold=a['double_fold'],
+                                     single_fold=a['single_fold'], maxapart=a['maxapart'], res=res,
+                                     use_raw=a['use_raw'], min_marginal_peaks=a['min_marginal_peaks'],
+                                     onlyanchor=a['only_anchors'], min_local_reads=a['min_local_reads'], ctx=ctx)
+    else:
+        num = a['maxapart'] // res + a['maxww'] + 1
+        raw, w = src.fetch(key, num, a['clr_weight_name'])
+        IR, biases = band.expected_and_biases(raw, w, a['ww'])
+        table = callers.bhfdr_band(raw, IR, biases, biases, chrom=key.lstrip('chr'), weight=w, pw=a['pw'], ww=a['ww'],
+                                   sig=a['siglevel'], maxww=a['maxww'], maxapart=a['maxapart'], res=res, ctx=ctx)
+    return key.lstrip('chr'), table
+
+
+def _pool_worker(job):
+    args_dict, mode, keys, device = job
+    return [_score_chrom(args_dict, mode, k, device) for k in keys]
+
+
+def _run(mode, argv):
+    from . import io, parallel
+    parser = _hiccups_parser() if mode == 'hiccups' else _bhfdr_parser()
+    commands = list(sys.argv[1:] if argv is None else argv)
+    if not commands:
+        commands.append('-h')                       # scripts/pyHICCUPS:76-78
+    args = parser.parse_args(commands)
+    logger = _setup_logging(args.logFile, rotating=(mode == 'bhfdr'))
+    logger.info('Python Version: {}'.format(sys.version.split()[0]))
+    logger.info('\n# ARGUMENT LIST:\n' + '\n'.join('# {0} = {1}'.format(k, v) for k, v in sorted(vars(args).items())))
+    if mode == 'hiccups' and (not args.pw or not args.ww):
+        parser.error('--pw and --ww are required')
+    logger.info('Loading Hi-C data ...')
+    src = io.open_source(args.path)
+    res = src.binsize
+    keys = select_chroms(src.chromnames, args.chroms)
+    sizes = {k: src.nbins(k) for k in keys}
+    a = vars(args)
+    rank, world, local = parallel.dist_env()
+    logger.info('Calling Peaks ...')
+    if world > 1:                                    # torchrun: one rank per GPU, tables gathered on rank 0
+        import torch.distributed as dist
+        dist.init_process_group('gloo')              # only Python objects travel
+        dev = local if args.device is None else args.device
+        tables = parallel.run_sharded(sizes, lambda k: _score_chrom(a, mode, k, dev)[1], rank, world)
+        dist.destroy_process_group()
+        if rank != 0:
+            return 0
+        results = [(k.lstrip('chr'), tables[k]) for k in keys]
+    elif args.nproc > 1:                             # Pool.map over GPU workers (scripts/pyHICCUPS:195-198)
+        import multiprocessing as mp
+        parts = parallel.lpt_partition(sizes, args.nproc)
+        jobs = [(a, mode, part, (w if args.device is None else args.device)) for w, part in enumerate(parts)]
+        with mp.get_context('spawn').Pool(args.nproc) as pool:
+            done = dict(kv for part in pool.map(_pool_worker, jobs) for kv in part)
+        results = [(k.lstrip('chr'), done[k.lstrip('chr')]) for k in keys]
+    else:
+        dev = 0 if args.device is None else args.device
+        results = [_score_chrom(a, mode, k, dev) for k in keys]
+    with open(args.output, 'w') as out:
+        for key, table in results:
+            out.write(format_hiccups(key, table, res) if mode == 'hiccups' else format_bhfdr(key, table, res))
+    logger.info('Done!')
+    return 0
+
+
+def main_hiccups(argv=None):
+    return _run('hiccups', argv)
+
+
+def main_bhfdr(argv=None):
+    return _run('bhfdr', argv)

@@ -1,0 +1,94 @@
+"""Host-side plumbing that needs no GPU: flag parity with the reference command lines, chromosome selection,
+band archives, LPT sharding and the world_size-2 gather over gloo."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+from hicpeaks_amd import cli, io, parallel, synthetic
+
+
+def test_hiccups_flags_and_defaults_match_reference():
+    # scripts/pyHICCUPS:12-81
+    a = cli._hiccups_parser().parse_args(['-O', 'x', '-p', 'y', '--pw', '1', '2', '--ww', '3', '5'])
+    assert (a.maxww, a.siglevel, a.sumq, a.double_fold, a.single_fold) == (10, 0.05, 0.01, 1.75, 2)
+    assert (a.clr_weight_name, a.use_raw, a.min_marginal_peaks, a.min_local_reads) == ('weight', False, 2, 16)
+    assert (a.only_anchors, a.maxapart, a.nproc, a.chroms, a.logFile) == (False, 10000000, 1, ['#', 'X'], 'pyHICCUPS.log')
+    assert a.pw == [1, 2] and a.ww == [3, 5]
+
+
+def test_bhfdr_flags_and_defaults_match_reference():
+    # scripts/pyBHFDR:12-58
+    a = cli._bhfdr_parser().parse_args(['-O', 'x', '-p', 'y'])
+    assert (a.pw, a.ww, a.maxww, a.siglevel, a.maxapart, a.nproc, a.logFile) == (2, 5, 10, 0.05, 2000000, 1, 'pyBHFDR.log')
+
+
+def test_select_chroms_rule():
+    names = ['chr1', 'chr2', 'chrX', 'chrY', 'chrM', 'chr10_random']
+    assert cli.select_chroms(names, ['#', 'X']) == ['chr1', 'chr2', 'chrX']
+    assert cli.select_chroms(names, []) == names
+    assert cli.select_chroms(names, ['Y']) == ['chrY']
+
+
+def test_band_archive_roundtrip(tmp_path):
+    raw, w, _ = synthetic.synth_band(120, 31, depth=5.0, seed=1)
+    io.save_band_archive(str(tmp_path / 'b.npz'), 10000, {'chr1': (raw, w), 'chrX': (raw[:80], w[:80])})
+    src = io.open_source(str(tmp_path / 'b.npz'))
+    assert src.binsize == 10000 and src.chromnames == ['chr1', 'chrX'] and src.nbins('chrX') == 80
+    r, ww = src.fetch('chr1', 25)
+    assert r.shape == (120, 25) and r.dtype == np.float32
+    np.testing.assert_array_equal(r, raw[:, :25])
+    np.testing.assert_array_equal(ww, w)
+    r, _ = src.fetch('chr1', 40)          # wider than stored: zero padded
+    assert r.shape == (120, 40) and not r[:, 31:].any()
+
+
+def test_lpt_partition_balances_hg38():
+    sizes = synthetic.hg38_bins(10000)
+    parts = parallel.lpt_partition(sizes, 8)
+    assert sorted(c for p in parts for c in p) == sorted(sizes)
+    loads = [sum(sizes[c] for c in p) for p in parts]
+    assert max(loads) / (sum(loads) / 8.0) < 1.06          # 1.045
+    assert parallel.lpt_partition(sizes, 1) == [sorted(sizes, key=lambda k: (-sizes[k], k))]
+    assert parallel.lpt_partition({'a': 1}, 4)[0] == ['a']
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, %(repo)r)
+import torch.distributed as dist
+from hicpeaks_amd import parallel
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+sizes = {'chr%%d' %% i: 100 - i for i in range(1, 8)}
+seen = []
+def score(c):
+    seen.append(c)
+    return {(1, 2): (rank, c)}
+out = parallel.run_sharded(sizes, score, rank, world)
+mine = parallel.lpt_partition(sizes, world)[rank]
+assert seen == mine, (seen, mine)
+if rank == 0:
+    assert sorted(out) == sorted(sizes)
+    for r in range(world):
+        for c in parallel.lpt_partition(sizes, world)[r]:
+            assert out[c] == {(1, 2): (r, c)}
+    print('GATHER_OK', len(out))
+else:
+    assert out is None
+dist.destroy_process_group()
+'''
+
+
+def test_run_sharded_world2_gloo(tmp_path):
+    script = tmp_path / 'w.py'
+    script.write_text(WORKER % dict(repo=REPO))
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29631', WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert 'GATHER_OK 7' in outs[0]

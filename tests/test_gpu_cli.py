@@ -1,0 +1,52 @@
+"""End to end through the command lines on the GPU: band archive in, 16-/13-column text out, compared with the
+lines the real reference produced for the same input."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from hicpeaks_amd import cli, io
+
+pytestmark = pytest.mark.gpu
+
+
+def _lines(path):
+    return sorted(open(path).read().splitlines())
+
+
+def _numeric_equal(got, want):
+    assert len(got) == len(want), (len(got), len(want))
+    for g, w in zip(got, want):
+        gf, wf = g.split('\t'), w.split('\t')
+        assert gf[:7] == wf[:7] and gf[8:10] == wf[8:10]
+        for a, b in zip(gf[7:8] + gf[10:], wf[7:8] + wf[10:]):
+            assert abs(float(a) - float(b)) <= 1e-6 + 2e-3 * abs(float(b)), (g, w)      # .3g text
+
+
+@pytest.mark.parametrize('name', ['hiccups_union_shallow', 'hiccups_p2w5'])
+def test_pyhiccups_cli(name, tmp_path):
+    g = load_golden(name)
+    p = g.params
+    arc = str(tmp_path / 'in.npz')
+    io.save_band_archive(arc, p['res'], {'chrT': (g['raw'], g['weight'])})
+    out = str(tmp_path / 'out.bedpe')
+    argv = ['-O', out, '-p', arc, '-C', 'T', '--pw'] + [str(v) for v in p['pw']] + ['--ww'] + [str(v) for v in p['ww']] + [
+        '--maxww', str(p['maxww']), '--siglevel', str(p['sig']), '--sumq', str(p['sumq']), '--maxapart', str(p['maxapart']),
+        '--min-marginal-peaks', str(p['min_marginal_peaks']), '--min-local-reads', str(p['min_local_reads']),
+        '--logFile', str(tmp_path / 'log.txt')]
+    assert cli.main_hiccups(argv) == 0
+    _numeric_equal(_lines(out), sorted(g.meta['lines'].splitlines()))
+
+
+def test_pybhfdr_cli(tmp_path):
+    g = load_golden('bhfdr_p2w5')
+    p = g.params
+    arc = str(tmp_path / 'in.npz')
+    io.save_band_archive(arc, p['res'], {'chrT': (g['raw'], g['weight'])})
+    out = str(tmp_path / 'out.txt')
+    argv = ['-O', out, '-p', arc, '-C', 'T', '--pw', str(p['pw']), '--ww', str(p['ww']), '--maxww', str(p['maxww']),
+            '--siglevel', str(p['sig']), '--maxapart', str(p['maxapart']), '--logFile', str(tmp_path / 'log.txt')]
+    assert cli.main_bhfdr(argv) == 0
+    # pyBHFDR calls bhfdr() with its keyword defaults for clustering (min_marginal_peaks=3, onlyanchor=False)
+    _numeric_equal(_lines(out), sorted(g.meta['lines'].splitlines()))

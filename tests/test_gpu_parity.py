@@ -189,3 +189,46 @@ def test_sat_kernel_equals_bruteforce(pw, ww, ctx):
             np.testing.assert_allclose(sums[sel], bf[:, :4], rtol=1e-11, atol=0)
             assert np.all(bf[:, 4] >= 16)
             assert np.array_equal(sums[sel] == 0, bf[:, :4] == 0)
+
+
+def test_full_size_chr1_properties(ctx):
+    """BASELINE configs[1] at full size (n = 24896, 5 Mb band at 10 kb): size-independent checks - counting
+    identities of the widening log, gap rows, and an explicit-window recomputation of sampled pixels."""
+    from hicpeaks_amd import synthetic, band
+    n, num, mw, D = 24896, 511, 5, 500
+    raw, weight, _ = synthetic.synth_band(n, num, depth=60.0, nloops=100, seed=3)
+    IR, biases = band.expected_and_biases(raw, weight, mw)
+    prm = _lib.make_params(_lib.MODE_HICCUPS, [2], [5], 10, 0.05, 5000000, 10000, 16, _lib.FLAG_DENSE_SUMS)
+    rawf = raw.astype(np.float32)
+    R = ctx.score_host(rawf, IR, biases, biases, prm, weight=weight)
+    cand = (raw[:, mw:D + 1] != 0)
+    cand &= (np.arange(n)[:, None] + np.arange(mw, D + 1)[None, :]) < n
+    assert R.ncand == int(cand.sum())
+    assert R.band_px == band.band_pixels(n, num, mw, D)
+    done = sum(c for pi, wi, c, ex in R.steps)
+    w = R.dense_w[0]
+    assert done == int((w != 0).sum()) and done <= R.ncand
+    for pi, wi, c, ex in R.steps:
+        assert c == int((w == wi).sum())
+    # the executed steps are a prefix and stop at frozen_w
+    ex = [e for _, _, _, e in R.steps]
+    assert ex == sorted(ex, reverse=True) and all(wi <= R.frozen_w for _, wi, _, e in R.steps if e)
+    # gap rows
+    bal = synthetic.balanced_band(raw, weight, mw)
+    np.testing.assert_array_equal(R.gap, bal.sum(axis=1) == 0)
+    # sampled explicit windows
+    rng = np.random.default_rng(0)
+    rr, kk = np.nonzero(w)
+    pick = rng.choice(rr.size, 20000, replace=False)
+    rows, cols = rr[pick].astype(np.int32), (rr + kk)[pick].astype(np.int32)
+    steps = [(a, b) for a, b, c, e in R.steps]
+    for si, (spi, swi) in enumerate(steps):
+        sel = w[rows, cols - rows] == swi
+        if not sel.any():
+            continue
+        bf = ctx.bruteforce_sums(rawf, IR, biases, biases, prm, si, rows[sel], cols[sel], weight=weight)
+        np.testing.assert_allclose(R.dense_sums[0][rows[sel], (cols - rows)[sel]], bf[:, :4], rtol=1e-11, atol=0)
+    # every significant pixel is a candidate that resolved, with p <= q <= sig
+    for s in R.sets:
+        assert np.all(w[s['x'], s['y'] - s['x']] != 0)
+        assert np.all(s['p'] <= s['q'] + 1e-18) and np.all(s['q'] <= 0.05)
