@@ -429,14 +429,16 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     sa.ntiles = RB * sa.J;
     sa.chunk = (sa.ntiles + 7) / 8;
     { const char* e = std::getenv("HPK_DBG_STOP"); sa.dbg_stop = e ? std::atoi(e) : 0; }
-    HIPCHK(c, c->histpart.reserve(sizeof(unsigned) * (size_t)sa.ntiles * (HPK_MAX_STEPS + 1)));
-    HIPCHK(c, hipMemsetAsync(c->histpart.p, 0, sizeof(unsigned) * (size_t)sa.ntiles * (HPK_MAX_STEPS + 1), c->stream));
+    { const char* e = std::getenv("HPK_DENSE_ZERO"); sa.dense_zero = (e && std::atoi(e)) ? 1 : 0; }
+    sa.grid = std::max(8, std::min((c->cus / 8) * 8, ((sa.chunk + 0) * 8)));
+    HIPCHK(c, c->histpart.reserve(sizeof(unsigned) * (size_t)sa.grid * (HPK_MAX_STEPS + 1)));
+    HIPCHK(c, hipMemsetAsync(c->histpart.p, 0, sizeof(unsigned) * (size_t)sa.grid * (HPK_MAX_STEPS + 1), c->stream));
     sa.hist_part = c->histpart.as<unsigned>();
     (void)hipEventRecord(c->ev[1], c->stream);
     hpk_launch_stencil(sa, in.bal != nullptr, plan.simple_reads != 0 && !std::getenv("HPK_GENERIC_SEARCH"), c->stream);
     HIPCHK(c, hipGetLastError());
     (void)hipEventRecord(c->ev[2], c->stream);
-    hpk_launch_freeze(sa.plan, d_hist, sa.hist_part, sa.ntiles, d_frozen, d_exec, d_err, c->stream);
+    hpk_launch_freeze(sa.plan, d_hist, sa.hist_part, sa.grid, d_frozen, d_exec, d_err, c->stream);
     HIPCHK(c, hipGetLastError());
     (void)hipEventRecord(c->ev[3], c->stream);
 

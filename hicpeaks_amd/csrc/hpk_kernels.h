@@ -16,13 +16,15 @@ struct HpkStencilArgs {
     double2* outS;                      // [nslots][n][ldo]  (bS_K, bS_Y) at the resolving step
     uint8_t* outW;                      // [nslots][n][ldo]  resolving step + 1, 0 = unresolved
     unsigned long long* hist;           // [HPK_MAX_STEPS + 1] totals, written by hpk_freeze
-    unsigned* hist_part;                // [ntiles][HPK_MAX_STEPS + 1] per-tile resolve counts, [..][HPK_MAX_STEPS] = candidates
+    unsigned* hist_part;                // [grid][HPK_MAX_STEPS + 1] per-workgroup resolve counts, [..][HPK_MAX_STEPS] = candidates
     int32_t n, num;
     int64_t ld, ldo;
     int32_t W, mw, D;
     int32_t TR, TC;                     // output tile = (HPK_LR - 2W - 1) x (HPK_LC - 2W - 1)
     int32_t J;                          // column chunks per row block
     int32_t ntiles, chunk;              // chunk = ceil(ntiles / 8): tiles handed to one XCD
+    int32_t grid;                       // persistent workgroups (multiple of 8, one per CU)
+    int32_t dense_zero;                 // also write zeros at non-candidate pixels (HPK_DENSE_ZERO=1: the 20 B/px mode)
     int32_t dbg_stop;                   // profiling ablation (HPK_DBG_STOP): 1 stop after the loads, 2 after the SAT,
                                         // 4 no candidates (loads + SAT + zero stores), 5 search without box sums
 };

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <float.h>
+#include <stdlib.h>
 #include "hpk_kernels.h"
 
 namespace {
@@ -135,8 +136,65 @@ __device__ __noinline__ void edge_expected(const int32_t* __restrict__ m, int wi
 }
 
 // ------------------------------------------------------------------ stencil
+// Band rows of one tile as they sit in registers between the load and the SAT construction: this wave's RPW rows x
+// 128 columns, two cells per lane.
+template <int RPW, bool BALF64>
+struct TileRegs {
+    float raw[RPW][2];
+    double bal[BALF64 ? RPW : 1][2];    // f64 input mode: balanced values as given
+    double wc[2];                       // weight mode: column weights of the two cells
+    double wrow[BALF64 ? 1 : RPW];      // weight mode: row weights
+};
+
+template <int RPW, bool BALF64>
+__device__ __forceinline__ void tile_load(const HpkStencilArgs& a, const float* __restrict__ g_raw, const double* __restrict__ g_bal,
+                                          const double* __restrict__ g_w, int tid, int wave, int lane, TileRegs<RPW, BALF64>& t) {
+    const int rb = tid / a.J, cj = tid - rb * a.J;
+    const int r0 = rb * a.TR;
+    const int c0 = r0 + a.mw + cj * a.TC;
+    const int n = a.n, num = a.num;
+    const int cc0 = c0 - a.W - 1 + 2 * lane;
+    const int rr0 = r0 - a.W - 1 + wave * RPW;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int cc = cc0 + e;
+        t.wc[e] = 0.0;
+        if (!BALF64 && cc >= 0 && cc < n) t.wc[e] = g_w[cc];
+    }
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int rr = rr0 + j;
+        const bool rowok = rr >= 0 && rr < n;
+        if (!BALF64) t.wrow[j] = rowok ? g_w[rr] : 0.0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int cc = cc0 + e;
+            const int k = cc - rr;
+            const bool inb = rowok && cc < n && k >= 0 && k < num;
+            t.raw[j][e] = 0.f;
+            if (BALF64) t.bal[j][e] = 0.0;
+            if (inb) {
+                const int64_t off = (int64_t)rr * a.ld + k;
+                t.raw[j][e] = g_raw[off];
+                if (BALF64 && k >= a.mw) t.bal[j][e] = g_bal[off];
+            }
+        }
+    }
+}
+
+// XCD-aware persistent tile order: workgroup b runs on XCD b % 8 (observed); XCD x owns the contiguous run of tiles
+// [x * chunk, (x + 1) * chunk) and its workgroups walk it with stride = workgroups per XCD, so tiles processed at
+// the same time on one XCD are neighbours and share their halo rows/columns through that XCD's L2.
+__device__ __forceinline__ int tile_of(const HpkStencilArgs& a, int it) {
+    const int xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3), per = (int)(gridDim.x >> 3);
+    const int k = j + it * per;
+    return (k < a.chunk && xcd * a.chunk + k < a.ntiles) ? xcd * a.chunk + k : -1;
+}
+
 template <int NW, bool BALF64, bool SIMPLE>
-__global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a) {
+__global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const float* __restrict__ g_raw,
+                                                        const double* __restrict__ g_bal, const double* __restrict__ g_w,
+                                                        double2* __restrict__ g_outS, uint8_t* __restrict__ g_outW) {
     constexpr int RPW = LR / NW;
     static_assert(RPW * NW == LR, "rows must split evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -147,68 +205,76 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a) {
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int W = a.W, n = a.n, num = a.num, mw = a.mw, D = a.D;
 
-    // XCD-aware tile order: block b runs on XCD b % 8 (observed), give each XCD a contiguous run of tiles so
-    // that the halo rows/columns shared by neighbouring tiles are served by one L2.
-    const int tid = (int)(blockIdx.x & 7) * a.chunk + (int)(blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= (unsigned)a.chunk || tid >= a.ntiles) return;
+    // ---- per-workgroup constants.  The widening plan lives in registers: lane s holds step s (HpkDevPlan::packed),
+    // v_readlane / ds_bpermute hand the fields out, so the pixel loops touch memory only for the SAT and the stores.
+    const HpkDevPlan* __restrict__ plan = a.plan;
+    const int nsteps = plan->nsteps, nslots = plan->nslots, min_reads = plan->min_reads;
+    int pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, pk6 = 0;
+    if (lane < nsteps) {
+        const uint32_t* pk = plan->packed[lane];
+        pk0 = (int)pk[0]; pk1 = (int)pk[1]; pk2 = (int)pk[2]; pk3 = (int)pk[3];
+        pk4 = (int)pk[4]; pk5 = (int)pk[5]; pk6 = (int)pk[6];
+    }
+    // simple-Reads plans: lane (q & 1) * 32 + w of tab[q >> 1] = step of slot q at width w; lane q of wfv = first width
+    int tab0 = 0xff, tab1 = 0xff, wfv = 0;
+    int p0 = 0, wmin = 0;
+    if (SIMPLE) {
+        tab0 = plan->step_of[lane >> 5][lane & 31];
+        tab1 = plan->step_of[2 + (lane >> 5)][lane & 31];
+        wfv = plan->slot_wfirst[lane & (HPK_KSLOTS - 1)];
+        p0 = plan->reads_p0;
+        wmin = plan->wmin;
+    }
+    const unsigned alldone = (1u << nslots) - 1u;
+    unsigned myhist = 0u, mycand = 0u;
+    const int64_t slot_stride = (int64_t)n * a.ldo;
+    // gfx9 counts loads and stores on one vmcnt: a compiler-placed wait for any of these one-time loads *inside* the
+    // pixel loops would also drain the stores of the previous pass (measured: 16k cycles per pass).  Passing each
+    // value through an empty asm makes the compiler wait here, once, and treat the registers as plain values after.
+#define HPK_PIN_I(x) asm volatile("" : "+v"(x))
+    HPK_PIN_I(pk0); HPK_PIN_I(pk1); HPK_PIN_I(pk2); HPK_PIN_I(pk3); HPK_PIN_I(pk4); HPK_PIN_I(pk5); HPK_PIN_I(pk6);
+    HPK_PIN_I(tab0); HPK_PIN_I(tab1); HPK_PIN_I(wfv);
+    const int nsteps_p = __builtin_amdgcn_readfirstlane(nsteps), nslots_p = __builtin_amdgcn_readfirstlane(nslots);
+    const int minr_p = __builtin_amdgcn_readfirstlane(min_reads), p0_p = __builtin_amdgcn_readfirstlane(p0);
+    const int wmin_p = __builtin_amdgcn_readfirstlane(wmin);
+
+    // ---- persistent tile loop with register prefetch: while tile `cur` is evaluated out of LDS, the band rows of
+    // the next tile are already on their way into `nxt` (the evaluation itself issues no loads).
+    TileRegs<RPW, BALF64> nxt;
+    int tid = tile_of(a, 0);
+    if (tid >= 0) tile_load<RPW, BALF64>(a, g_raw, g_bal, g_w, tid, wave, lane, nxt);
+#pragma unroll 1
+    for (int it = 0; tid >= 0; ++it) {
     const int rb = tid / a.J, cj = tid - rb * a.J;
     const int r0 = rb * a.TR;
     const int c0 = r0 + a.mw + cj * a.TC;
-    const int W = a.W, n = a.n, num = a.num, mw = a.mw, D = a.D;
-    if (c0 >= n || (mw + cj * a.TC - (a.TR - 1)) > D) return;   // no band pixel inside the matrix
-
-    // Per-lane / per-row weights of the evaluation phase (weight mode), requested now so that their latency hides
-    // behind the SAT construction: column weights of the two 64-pixel column blocks (per lane) and the row weights
-    // of the rows this wave will evaluate (row i of the wave in lane i, fetched back with v_readlane).  The
-    // evaluation phase itself issues NO global loads: gfx9 has one vmcnt counter for loads and stores, so a load
-    // consumed after the previous pass's stores would wait for those stores to be acknowledged.
-    double ev_wc0 = 0.0, ev_wc1 = 0.0, ev_wr = 0.0;
-    if (!BALF64) {
-        const int ca = c0 + lane, cb = c0 + 64 + lane;
-        if (lane < a.TC && ca < n) ev_wc0 = a.weight[ca];
-        if (64 + lane < a.TC && cb < n) ev_wc1 = a.weight[cb];
-        const int yr = wave + NW * lane, rr = r0 + yr;
-        if (yr < a.TR && rr < n) ev_wr = a.weight[rr];
+    const bool empty_tile = c0 >= n || (mw + cj * a.TC - (a.TR - 1)) > D;      // no band pixel inside the matrix
+    const int tid_next = tile_of(a, it + 1);
+    if (empty_tile) {
+        if (tid_next >= 0) tile_load<RPW, BALF64>(a, g_raw, g_bal, g_w, tid_next, wave, lane, nxt);
+        tid = tid_next;
+        continue;
     }
 
-    // ---- phase 1: read this wave's RPW rows x 128 columns, form balanced values, column totals
+    // ---- phase 1: balanced values and column totals of this wave's rows (values arrive from the prefetch)
     const int xx0 = 2 * lane;
     const int cc0 = c0 - W - 1 + xx0;
     const int rr0 = r0 - W - 1 + wave * RPW;
     float rawv[RPW][2];
     double balv[RPW][2];
-    double wc[2] = {0.0, 0.0};
-    if (!BALF64) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int cc = cc0 + e;
-            wc[e] = (cc >= 0 && cc < n) ? a.weight[cc] : 0.0;
-        }
-    }
     double tc[2] = {0.0, 0.0};
     unsigned tr[2] = {0u, 0u}, tv[2] = {0u, 0u};
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
-        const int rr = rr0 + j;
-        const bool rowok = rr >= 0 && rr < n;
-        double wr = 0.0;
-        if (!BALF64) wr = rowok ? a.weight[rr] : 0.0;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const int cc = cc0 + e;
-            const int k = cc - rr;
-            const bool inb = rowok && cc < n && k >= 0 && k < num;
-            float rv = 0.f;
+            const float rv = nxt.raw[j][e];
+            const int k = cc0 + e - (rr0 + j);
             double bv = 0.0;
-            if (inb) {
-                const int64_t off = (int64_t)rr * a.ld + k;
-                rv = a.raw[off];
-                if (k >= mw) {
-                    if (BALF64) { bv = a.bal[off]; bv = (bv == bv) ? bv : 0.0; }
-                    else bv = balanced_of(rv, wr, wc[e]);
-                }
-            }
+            if (BALF64) { bv = nxt.bal[j][e]; bv = (bv == bv) ? bv : 0.0; }
+            else if (k >= mw) bv = balanced_of(rv, nxt.wrow[BALF64 ? 0 : j], nxt.wc[e]);
             rawv[j][e] = rv;
             balv[j][e] = bv;
             const unsigned ru = (unsigned)rv;
@@ -219,7 +285,9 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a) {
     }
     if (a.dbg_stop == 1) {
         if (tc[0] + tc[1] == -1.0 && tr[0] + tv[1] == 77u) a.hist[0] = 1ull;     // keep the loads live
-        return;
+        if (tid_next >= 0) tile_load<RPW, BALF64>(a, g_raw, g_bal, g_w, tid_next, wave, lane, nxt);
+        tid = tid_next;
+        continue;
     }
     // column totals of this wave's row segment -> LDS (aliases the SAT; consumed before the SAT is written)
     *reinterpret_cast<double2*>(&S.c[wave * LC + xx0]) = make_double2(tc[0], tc[1]);
@@ -259,232 +327,227 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a) {
         *reinterpret_cast<uint2*>(&S.v[o]) = make_uint2(av[0], av[1]);
     }
     __syncthreads();
+    // the next tile's rows start moving now; nothing below waits for them
+    if (tid_next >= 0) tile_load<RPW, BALF64>(a, g_raw, g_bal, g_w, tid_next, wave, lane, nxt);
     if (a.dbg_stop == 2) {
         if (S.c[threadIdx.x] == -1.0) a.hist[0] = 1ull;
-        return;
+        __syncthreads();
+        tid = tid_next;
+        continue;
     }
-
-    // ---- phase 3: every band pixel of the tile
-    // The widening plan lives in registers: lane s holds step s (HpkDevPlan::packed).  (A) every lane finds, per
-    // output slot, the first step whose Reads reach min_local_reads - three u32 SAT reads per radius, for "simple"
-    // plans without any step loop; (B) the donut / lower-left sums are then evaluated once per slot with per-lane
-    // radii (each lane fetches its own step's box terms with ds_bpermute), so the expensive part runs at the
-    // candidate density of the row instead of once per step for a few stragglers.  Output per slot and pixel:
-    // (bS_K, bS_Y) f64 + resolving step + 1 (u8).  The local expected, the biases and the division are applied
-    // by the scoring kernel.  Loops are deliberately not unrolled: the kernel stays inside the instruction cache.
-    const HpkDevPlan* __restrict__ plan = a.plan;
-    const int nsteps = plan->nsteps, nslots = plan->nslots, min_reads = plan->min_reads;
-    int pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, pk6 = 0;
-    if (lane < nsteps) {
-        const uint32_t* pk = plan->packed[lane];
-        pk0 = (int)pk[0]; pk1 = (int)pk[1]; pk2 = (int)pk[2]; pk3 = (int)pk[3];
-        pk4 = (int)pk[4]; pk5 = (int)pk[5]; pk6 = (int)pk[6];
-    }
-    // simple-Reads plans: lane (q & 1) * 32 + w of tab[q >> 1] = step of slot q at width w; lane q of wfv = first width
-    int tab0 = 0xff, tab1 = 0xff, wfv = 0;
-    int p0 = 0, wmin = 0;
-    if (SIMPLE) {
-        tab0 = plan->step_of[lane >> 5][lane & 31];
-        tab1 = plan->step_of[2 + (lane >> 5)][lane & 31];
-        wfv = plan->slot_wfirst[lane & (HPK_KSLOTS - 1)];
-        p0 = plan->reads_p0;
-        wmin = plan->wmin;
-    }
-    const unsigned alldone = (1u << nslots) - 1u;
-    unsigned myhist = 0u, mycand = 0u;
-    const int64_t slot_stride = (int64_t)n * a.ldo;
     const double tiny_thr = 1e-9 * S.c[LR * LC - 1];
-    // Everything the evaluation needs is in registers / LDS from here on.  gfx9 counts loads and stores on one
-    // vmcnt: a compiler-placed wait for any of these one-time loads *inside* the pixel loops would also drain the
-    // stores of the previous pass (measured: 16k cycles per pass).  Passing each value through an empty asm makes
-    // the compiler wait here, once, and treat the registers as plain values afterwards.
-#define HPK_PIN_I(x) asm volatile("" : "+v"(x))
-#define HPK_PIN_D(x) do { int lo__ = __double2loint(x), hi__ = __double2hiint(x); asm volatile("" : "+v"(lo__), "+v"(hi__)); \
-                          x = __hiloint2double(hi__, lo__); } while (0)
-    HPK_PIN_I(pk0); HPK_PIN_I(pk1); HPK_PIN_I(pk2); HPK_PIN_I(pk3); HPK_PIN_I(pk4); HPK_PIN_I(pk5); HPK_PIN_I(pk6);
-    HPK_PIN_I(tab0); HPK_PIN_I(tab1); HPK_PIN_I(wfv);
-    HPK_PIN_D(ev_wc0); HPK_PIN_D(ev_wc1); HPK_PIN_D(ev_wr);
-    const int nsteps_p = __builtin_amdgcn_readfirstlane(nsteps), nslots_p = __builtin_amdgcn_readfirstlane(nslots);
-    const int minr_p = __builtin_amdgcn_readfirstlane(min_reads), p0_p = __builtin_amdgcn_readfirstlane(p0);
-    const int wmin_p = __builtin_amdgcn_readfirstlane(wmin);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
+    // ---- phase 3: candidates of the tile.  Work is proportional to the candidates (non-zero pixels), not to the
+    // band pixels:
+    //   (L) each wave walks its rows (y = wave, wave + NW, ...), takes every pixel's count out of the u32 SAT and
+    //       compacts the candidates' ids (row slot << 7 | x) into a register list - one ds_permute per 64 pixels
+    //       (candidates rotate to the free lanes of the current list register, the rest to the remaining lanes);
+    //   (A) per batch of 64 candidates: first step whose Reads reach min_local_reads - three u32 SAT reads per
+    //       radius, for "simple" plans without a step loop;
+    //   (B) donut / lower-left sums once per slot with per-lane radii (each lane fetches its own step's box terms
+    //       with ds_bpermute), scattered 17-byte stores for the candidates only.
+    // Output per slot and candidate pixel: (bS_K, bS_Y) f64 + resolving step + 1 (u8); pixels with a zero count are
+    // never written (nothing reads them).  The local expected, biases and division belong to the scoring kernel.
+    constexpr int NLIST = (LR + NW - 1) / NW * 2;       // 64-lane list registers: rows per wave x 2 column blocks
+    unsigned L[NLIST];
+#pragma unroll
+    for (int k = 0; k < NLIST; ++k) L[k] = 0u;
+    int cnt = 0;
 #pragma unroll 1
     for (int yi = 0; wave + NW * yi < a.TR; ++yi) {
         const int y = wave + NW * yi;
         const int r = r0 + y;
         if (r >= n) break;
-        const int Y = y + W + 1;
-        const double wr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ev_wr), yi),
-                                           __builtin_amdgcn_readlane(__double2loint(ev_wr), yi));
-#pragma unroll 1
-        for (int xb = 0; xb < a.TC; xb += 64) {
-            const int x = xb + lane;
+        const int Yb = (y + W + 1) * LC + W + 1;
+        unsigned rawu[2];
+        bool cnd[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int x = e * 64 + lane;
             const int c = c0 + x;
             const int d = c - r;
-            const bool inband = x < a.TC && c < n && d >= mw && d <= D && d < num;
-            const int base = Y * LC + x + W + 1;
-            // the pixel's own count out of the u32 SAT (exact)
-            unsigned sr = 0u, rawu = 0u;
-            if (inband) {
-                sr = S.r[base - 1];
-                rawu = S.r[base] - S.r[base - LC] - sr + S.r[base - LC - 1];
-            }
-            const bool cand = inband && rawu != 0u && a.dbg_stop != 4;
-            const unsigned long long candmask = __ballot(cand);
-            if (lane == 0) mycand += (unsigned)__popcll(candmask);
-            unsigned sstar = 0xffffffffu;           // resolving step index, 8 bits per slot (0xff = none)
-            double sc = 0.0, pixc = 0.0;
-            unsigned sv = 0u, pixv = 0u;
-            if (candmask != 0ull) {
-                if (cand) {
-                    sc = S.c[base - 1]; sv = S.v[base - 1];
-                    if (BALF64) {       // the pixel's balanced value back out of the SAT planes
-                        pixc = (S.c[base] - S.c[base - LC]) - (sc - S.c[base - LC - 1]);
-                        pixv = S.v[base] - S.v[base - LC] - sv + S.v[base - LC - 1];
-                        if (pixv == 0u) pixc = 0.0;
-                    } else {
-                        pixc = balanced_of((float)rawu, wr, xb ? ev_wc1 : ev_wc0);
-                        pixv = (pixc != 0.0) ? rawu : 0u;
-                    }
-                }
-                // ---- (A) resolving step per slot
-                if (SIMPLE) {
-                    // first width w* whose lower-left rings p0_p+1 .. w hold >= min_local_reads counts
-                    int wstar = 255;
-                    unsigned b0 = 0u;
-                    if (cand) {
-                        b0 = (p0_p > 0) ? reads_box(S.r, base, p0_p, sr) : 0u;
-                        if (reads_box(S.r, base, wmin_p, sr) - b0 >= (unsigned)minr_p) wstar = wmin_p;
-                    }
-                    if (__ballot(cand && wstar == 255) != 0ull) {
-                        if (cand && wstar == 255) {
-                            // remaining widths, four boxes (12 independent LDS reads) per round trip
-#pragma unroll 1
-                            for (int w = wmin_p + 1; w <= W && wstar == 255; w += 4) {
-                                unsigned bw[4];
+            const bool inb = x < a.TC && c < n && d >= mw && d <= D && d < num;
+            const int base = Yb + (x < a.TC ? x : a.TC - 1);          // clamped: every lane reads inside the tile
+            rawu[e] = S.r[base] - S.r[base - LC] - S.r[base - 1] + S.r[base - LC - 1];
+            cnd[e] = inb && rawu[e] != 0u && a.dbg_stop != 4;
+        }
 #pragma unroll
-                                for (int k = 0; k < 4; ++k) bw[k] = reads_box(S.r, base, (w + k <= W) ? w + k : W, sr);
+        for (int e = 0; e < 2; ++e) {
+            const unsigned long long M = __ballot(cnd[e]);
+            if (M == 0ull) continue;
+            const int pc = __popcll(M);
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(M >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M, 0u));
+            const int a0 = cnt & 63, k0 = cnt >> 6;
+            // a bijection of the 64 lanes: candidates -> a0, a0+1, ... (mod 64), the others -> the lanes that remain
+            const int tgt = cnd[e] ? a0 + below : a0 + pc + (lane - below);
+            const unsigned id = ((unsigned)yi << 7) | (unsigned)(e * 64 + lane);
+            const unsigned R = (unsigned)__builtin_amdgcn_ds_permute((tgt & 63) << 2, (int)id);
+            const bool in0 = lane >= a0 && lane < a0 + pc;             // lands in list register k0
+            const bool in1 = lane < a0 + pc - 64;                       // wrapped: list register k0 + 1
 #pragma unroll
-                                for (int k = 3; k >= 0; --k)
-                                    if (w + k <= W && bw[k] - b0 >= (unsigned)minr_p) wstar = w + k;
-                            }
-                        }
-                    }
-#pragma unroll 1
-                    for (int q = 0; q < nslots_p; ++q) {
-                        const int wf = __builtin_amdgcn_readlane(wfv, q);
-                        const int wq = wstar > wf ? wstar : wf;
-                        int sq = __shfl((q >> 1) ? tab1 : tab0, ((q & 1) << 5) + (wq & 31));
-                        if (!cand || wstar == 255) sq = 0xff;
-                        sstar = (sstar & ~(0xffu << (8 * q))) | ((unsigned)(sq & 0xff) << (8 * q));
-                        // histogram: one ballot per distinct resolving step present in the wave
-                        unsigned long long left = __ballot(sq != 0xff);
-                        while (left != 0ull) {
-                            const int ln = __ffsll((long long)left) - 1;
-                            const int sv0 = __builtin_amdgcn_readlane(sq, ln);
-                            const unsigned long long same = __ballot(sq == sv0);
-                            if (lane == sv0) myhist += (unsigned)__popcll(same);
-                            left &= ~same;
-                        }
-                    }
-                } else {
-                    unsigned done = cand ? 0u : alldone;
-                    int cur_rid = -1;
-                    unsigned reads = 0u;
-#pragma unroll 1
-                    for (int s = 0; s < nsteps_p; ++s) {
-                        const unsigned w0 = (unsigned)__builtin_amdgcn_readlane(pk0, s);
-                        const int slot = (int)(w0 & 3u), rid = (int)((w0 >> 10) & 63u), nrt = (int)((w0 >> 16) & 15u);
-                        const bool need = ((done >> slot) & 1u) == 0u;
-                        if (__ballot(need) == 0ull) continue;
-                        if (rid != cur_rid) {
-                            cur_rid = rid;
-                            const unsigned long long rt = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(pk1, s) |
-                                                          (unsigned long long)(unsigned)__builtin_amdgcn_readlane(pk2, s) << 32;
-                            if (done != alldone) {
-                                unsigned acc = 0u;
-                                for (int j = 0; j < nrt; ++j) {
-                                    const unsigned t = (unsigned)(rt >> (16 * j)) & 0xffffu;
-                                    acc += (unsigned)(int)(signed char)(t >> 8) * reads_box(S.r, base, (int)(t & 0xffu), sr);
-                                }
-                                reads = acc;
-                            }
-                        }
-                        const bool hit = need && (reads >= (unsigned)minr_p);
-                        const unsigned long long hitmask = __ballot(hit);
-                        if (lane == s) myhist += (unsigned)__popcll(hitmask);
-                        if (hit) {
-                            sstar = (sstar & ~(0xffu << (8 * slot))) | ((unsigned)s << (8 * slot));
-                            done |= 1u << slot;
-                        }
-                        if (__ballot(done != alldone) == 0ull) break;
-                    }
-                }
-                if (a.dbg_stop == 5) sstar = (sstar == 0x12345678u) ? 0u : 0xffffffffu;
+            for (int k = 0; k < NLIST; ++k) {
+                if (k == k0 && in0) L[k] = R;
+                if (k == k0 + 1 && in1) L[k] = R;
             }
-            // ---- (B) sums at the resolving step, once per slot; the slot's outputs are stored right away
+            cnt += pc;
+        }
+    }
+    if (lane == 0) mycand += (unsigned)cnt;
+
+    const int nbatch = (cnt + 63) >> 6;
+#pragma unroll 1
+    for (int kb = 0; kb < nbatch; ++kb) {
+        unsigned id = 0u;
+#pragma unroll
+        for (int k = 0; k < NLIST; ++k) if (k == kb) id = L[k];
+        const bool cand = kb * 64 + lane < cnt;
+        const int yi = (int)(id >> 7), x = (int)(id & 127u);
+        const int y = wave + NW * yi;
+        const int r = r0 + y;
+        const int d = c0 + x - r;
+        const int base = (y + W + 1) * LC + W + 1 + x;       // idle lanes: id 0 -> a valid interior cell
+        // S(Y, X-1) of the planes, the pixel's own balanced value, and the first Reads boxes: one batch of reads
+        const unsigned sr = S.r[base - 1];
+        const double sc = S.c[base - 1];
+        const double pixc = cand ? (S.c[base] - S.c[base - LC]) - (sc - S.c[base - LC - 1]) : 0.0;
+        unsigned sstar = 0xffffffffu;           // resolving step index, 8 bits per slot (0xff = none)
+        // ---- (A) resolving step per slot
+        if (SIMPLE) {
+            // first width w* whose lower-left rings p0+1 .. w hold >= min_local_reads counts.  Rings are only ever
+            // added, so Reads is monotone in w: the narrowest and the widest box are read together (most candidates
+            // pass the first, far-from-diagonal ones often fail even the last), the lanes in between bisect.
+            const unsigned b0 = (p0_p > 0) ? reads_box(S.r, base, p0_p, sr) : 0u;
+            const unsigned bf = reads_box(S.r, base, wmin_p, sr);
+            const unsigned bl = reads_box(S.r, base, W, sr);
+            int wstar = 255;
+            if (cand && bf - b0 >= (unsigned)minr_p) wstar = wmin_p;
+            else if (cand && bl - b0 >= (unsigned)minr_p) wstar = W;
+            int lo = wmin_p, hi = W;            // invariant for bisecting lanes: Reads(lo) < min <= Reads(hi)
+            bool bis = cand && wstar == W && hi - lo > 1;
+            while (__ballot(bis) != 0ull) {
+                const int mid = (lo + hi) >> 1;
+                const unsigned bm = reads_box(S.r, base, bis ? mid : wmin_p, sr);
+                if (bis) {
+                    if (bm - b0 >= (unsigned)minr_p) hi = mid; else lo = mid;
+                    wstar = hi;
+                    bis = hi - lo > 1;
+                }
+            }
+            if (a.dbg_stop == 6 && cand) wstar = wmin_p;
 #pragma unroll 1
             for (int q = 0; q < nslots_p; ++q) {
-                const int sq = (int)((sstar >> (8 * q)) & 0xffu);
-                const bool act = cand && sq != 0xff;
-                double SK = 0.0, SY = 0.0;
-                if (__ballot(act) != 0ull) {
-                    const int src = act ? sq : 0;
-                    const unsigned w0 = (unsigned)__shfl(pk0, src);
-                    const unsigned k0 = (unsigned)__shfl(pk3, src), k1 = (unsigned)__shfl(pk4, src);
-                    const unsigned k2 = (unsigned)__shfl(pk5, src), k3 = (unsigned)__shfl(pk6, src);
-                    const int nkt = act ? (int)((w0 >> 20) & 15u) : 0;
+                const int wf = __builtin_amdgcn_readlane(wfv, q);
+                const int wq = wstar > wf ? wstar : wf;
+                int sq = __shfl((q >> 1) ? tab1 : tab0, ((q & 1) << 5) + (wq & 31));
+                if (!cand || wstar == 255) sq = 0xff;
+                sstar = (sstar & ~(0xffu << (8 * q))) | ((unsigned)(sq & 0xff) << (8 * q));
+                // histogram: one ballot per distinct resolving step present in the wave
+                unsigned long long left = __ballot(sq != 0xff);
+                while (left != 0ull) {
+                    const int ln = __ffsll((long long)left) - 1;
+                    const int sv0 = __builtin_amdgcn_readlane(sq, ln);
+                    const unsigned long long same = __ballot(sq == sv0);
+                    if (lane == sv0) myhist += (unsigned)__popcll(same);
+                    left &= ~same;
+                }
+            }
+        } else {
+            // generic plans: walk the steps (uniform), Reads recomputed when the step's Reads matrix changes
+            unsigned done = cand ? 0u : alldone;
+            int cur_rid = -1;
+            unsigned reads = 0u;
 #pragma unroll 1
-                    for (int j = 0; j < HPK_PK_KT; ++j) {
-                        const bool on = j < nkt;
-                        if (__ballot(on) == 0ull) break;
-                        if (on) {
+            for (int s2 = 0; s2 < nsteps_p; ++s2) {
+                const unsigned w0 = (unsigned)__builtin_amdgcn_readlane(pk0, s2);
+                const int slot = (int)(w0 & 3u), rid = (int)((w0 >> 10) & 63u), nrt = (int)((w0 >> 16) & 15u);
+                const bool need = ((done >> slot) & 1u) == 0u;
+                if (__ballot(need) == 0ull) continue;
+                if (rid != cur_rid) {
+                    cur_rid = rid;
+                    const unsigned long long rt = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(pk1, s2) |
+                                                  (unsigned long long)(unsigned)__builtin_amdgcn_readlane(pk2, s2) << 32;
+                    unsigned acc = 0u;
+                    for (int j = 0; j < nrt; ++j) {
+                        const unsigned t = (unsigned)(rt >> (16 * j)) & 0xffffu;
+                        acc += (unsigned)(int)(signed char)(t >> 8) * reads_box(S.r, base, (int)(t & 0xffu), sr);
+                    }
+                    reads = acc;
+                }
+                const bool hit = need && (reads >= (unsigned)minr_p);
+                const unsigned long long hitmask = __ballot(hit);
+                if (lane == s2) myhist += (unsigned)__popcll(hitmask);
+                if (hit) {
+                    sstar = (sstar & ~(0xffu << (8 * slot))) | ((unsigned)s2 << (8 * slot));
+                    done |= 1u << slot;
+                }
+                if (__ballot(done != alldone) == 0ull) break;
+            }
+        }
+        if (a.dbg_stop == 5) sstar = 0xffffffffu;
+        // ---- (B) sums at the resolving step, once per slot; outputs are stored right away
+#pragma unroll 1
+        for (int q = 0; q < nslots_p; ++q) {
+            const int sq = (int)((sstar >> (8 * q)) & 0xffu);
+            const bool act = cand && sq != 0xff;
+            double SK = 0.0, SY = 0.0;
+            if (__ballot(act) != 0ull) {
+                const int src = act ? sq : 0;
+                const unsigned w0 = (unsigned)__shfl(pk0, src);
+                const unsigned k0 = (unsigned)__shfl(pk3, src), k1 = (unsigned)__shfl(pk4, src);
+                const unsigned k2 = (unsigned)__shfl(pk5, src), k3 = (unsigned)__shfl(pk6, src);
+                const int nkt = act ? (int)((w0 >> 20) & 15u) : 0;
+#pragma unroll 1
+                for (int j = 0; j < HPK_PK_KT; ++j) {
+                    const bool on = j < nkt;
+                    if (__ballot(on) == 0ull) break;
+                    const unsigned kw = (j < 2) ? k0 : (j < 4) ? k1 : (j < 6) ? k2 : k3;
+                    const unsigned t = (kw >> (16 * (j & 1))) & 0xffffu;
+                    const int rho = on ? (int)(t & 0xffu) : 1;      // idle lanes read a harmless box
+                    const double cf = on ? (double)(int)(signed char)(t >> 8) : 0.0;
+                    double kc, yc;
+                    box_ky(S.c, base, rho, pixc, sc, kc, yc);
+                    SK += cf * kc; SY += cf * yc;
+                }
+                // A lower-left cell on ring rho lies at least rho + 1 diagonals nearer to the main diagonal: with
+                // rho_min the smallest ring of this step, the whole lower-left support is off the band (bS_Y = 0
+                // exactly) for d < mw + rho_min + 1.
+                if (d - (int)((w0 >> 24) & 31u) - 1 < mw) SY = 0.0;
+                // A box whose balanced values are all 0 must come out as exact 0 (as the reference's CSR adds do);
+                // the f64 SAT leaves rounding residue of at most ~1e-13 of the tile total there.  Sums below 1e-9
+                // of the tile total are re-examined on the exact u32 valid-raw plane.
+                const bool tiny = act && (SK <= tiny_thr || (SY <= tiny_thr && SY != 0.0));
+                if (__ballot(tiny) != 0ull) {
+                    if (tiny) {
+                        const unsigned sv = S.v[base - 1];
+                        const unsigned pv = S.v[base] - S.v[base - LC] - sv + S.v[base - LC - 1];
+                        unsigned VK = 0u, VY = 0u;
+#pragma unroll 1
+                        for (int j = 0; j < nkt; ++j) {
                             const unsigned kw = (j < 2) ? k0 : (j < 4) ? k1 : (j < 6) ? k2 : k3;
                             const unsigned t = (kw >> (16 * (j & 1))) & 0xffffu;
-                            double kc, yc;
-                            box_ky(S.c, base, (int)(t & 0xffu), pixc, sc, kc, yc);
-                            const double cf = (double)(int)(signed char)(t >> 8);
-                            SK += cf * kc; SY += cf * yc;
+                            const unsigned long long kyv = box_ky_valid(S.v, base, (int)(t & 0xffu), pv, sv);
+                            VK += (unsigned)(int)(signed char)(t >> 8) * (unsigned)kyv;
+                            VY += (unsigned)(int)(signed char)(t >> 8) * (unsigned)(kyv >> 32);
                         }
+                        if (VK == 0u) SK = 0.0;
+                        if (VY == 0u) SY = 0.0;
                     }
-                    // A lower-left cell on ring rho lies at least rho + 1 diagonals nearer to the main diagonal: with
-                    // rho_min the smallest ring of this step, the whole lower-left support is off the band (bS_Y = 0
-                    // exactly) for d < mw + rho_min + 1.
-                    if (d - (int)((w0 >> 24) & 31u) - 1 < mw) SY = 0.0;
-                    // A box whose balanced values are all 0 must come out as exact 0 (as the reference's CSR adds
-                    // do); the f64 SAT leaves rounding residue of at most ~1e-13 of the tile total there.  Sums
-                    // below 1e-9 of the tile total are re-examined on the exact u32 valid-raw plane.
-                    const bool tiny = act && (SK <= tiny_thr || (SY <= tiny_thr && SY != 0.0));
-                    if (__ballot(tiny) != 0ull) {
-                        if (tiny) {
-                            unsigned VK = 0u, VY = 0u;
-#pragma unroll 1
-                            for (int j = 0; j < nkt; ++j) {
-                                const unsigned kw = (j < 2) ? k0 : (j < 4) ? k1 : (j < 6) ? k2 : k3;
-                                const unsigned t = (kw >> (16 * (j & 1))) & 0xffffu;
-                                const unsigned long long kyv = box_ky_valid(S.v, base, (int)(t & 0xffu), pixv, sv);
-                                VK += (unsigned)(int)(signed char)(t >> 8) * (unsigned)kyv;
-                                VY += (unsigned)(int)(signed char)(t >> 8) * (unsigned)(kyv >> 32);
-                            }
-                            if (VK == 0u) SK = 0.0;
-                            if (VY == 0u) SY = 0.0;
-                        }
-                    }
-                    if (!act) { SK = 0.0; SY = 0.0; }
                 }
-                if (inband) {
-                    const int64_t o = q * slot_stride + (int64_t)r * a.ldo + d;
-                    a.outS[o] = make_double2(SK, SY);
-                    a.outW[o] = act ? (uint8_t)(sq + 1) : (uint8_t)0;
-                }
+            }
+            if (cand) {
+                const int64_t o = q * slot_stride + (int64_t)r * a.ldo + d;
+                g_outS[o] = make_double2(act ? SK : 0.0, act ? SY : 0.0);
+                g_outW[o] = act ? (uint8_t)(sq + 1) : (uint8_t)0;
             }
         }
     }
-    // Resolve histogram: 40k same-address atomics (one per wave) serialise at ~90 per microsecond in L2 - 0.46 ms,
-    // several times the kernel itself.  Instead the waves meet in LDS (the SAT is dead now) and the block writes its
-    // partial counts with plain stores; hpk_freeze sums the partials.
-    __syncthreads();
+    __syncthreads();                 // every wave is done with this tile's SAT
+    tid = tid_next;
+    }   // tile loop
+
+    // Resolve histogram: 40k same-address atomics (one per wave and tile) serialise at ~90 per microsecond in L2 -
+    // 0.46 ms, several times the kernel itself.  Instead the waves of the workgroup meet in LDS (the SAT is dead now)
+    // and the workgroup writes its partial counts with plain stores; hpk_hist_reduce sums the partials.
     unsigned* red = reinterpret_cast<unsigned*>(smem);
     red[wave * (HPK_MAX_STEPS + 1) + lane] = myhist;
     if (lane == 0) red[wave * (HPK_MAX_STEPS + 1) + HPK_MAX_STEPS] = mycand;
@@ -492,7 +555,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a) {
     if (threadIdx.x <= HPK_MAX_STEPS) {
         unsigned tot = 0u;
         for (int w2 = 0; w2 < NW; ++w2) tot += red[w2 * (HPK_MAX_STEPS + 1) + threadIdx.x];
-        a.hist_part[(int64_t)tid * (HPK_MAX_STEPS + 1) + threadIdx.x] = tot;
+        a.hist_part[(int64_t)blockIdx.x * (HPK_MAX_STEPS + 1) + threadIdx.x] = tot;
     }
 }
 
@@ -958,11 +1021,16 @@ static void launch_stencil_t(const HpkStencilArgs& a, hipStream_t st) {
                                   hpk_stencil_lds_bytes());
         attr_done = true;
     }
-    const int grid = a.chunk * 8;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), hpk_stencil_lds_bytes(), st, a);
+    hipLaunchKernelGGL(kern, dim3(a.grid), dim3(NW * 64), hpk_stencil_lds_bytes(), st, a, a.raw, a.bal, a.weight, a.outS, a.outW);
 }
 
 void hpk_launch_stencil(const HpkStencilArgs& a, bool balf64, bool simple, hipStream_t st) {
+    static const int nw = [] { const char* e = getenv("HPK_NW"); return e ? atoi(e) : 16; }();
+    if (nw == 8) {
+        if (balf64) { if (simple) launch_stencil_t<8, true, true>(a, st); else launch_stencil_t<8, true, false>(a, st); }
+        else        { if (simple) launch_stencil_t<8, false, true>(a, st); else launch_stencil_t<8, false, false>(a, st); }
+        return;
+    }
     constexpr int NW = 16;
     if (balf64) { if (simple) launch_stencil_t<NW, true, true>(a, st); else launch_stencil_t<NW, true, false>(a, st); }
     else        { if (simple) launch_stencil_t<NW, false, true>(a, st); else launch_stencil_t<NW, false, false>(a, st); }
