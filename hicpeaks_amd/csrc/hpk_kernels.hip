@@ -352,6 +352,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
     unsigned L[NLIST];
 #pragma unroll
     for (int k = 0; k < NLIST; ++k) L[k] = 0u;
+    unsigned curL = 0u;                 // the list register being filled; committed to L[] when it is full
     int cnt = 0;
 #pragma unroll 1
     for (int yi = 0; wave + NW * yi < a.TR; ++yi) {
@@ -359,38 +360,38 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
         const int r = r0 + y;
         if (r >= n) break;
         const int Yb = (y + W + 1) * LC + W + 1;
-        unsigned rawu[2];
-        bool cnd[2];
-#pragma unroll
+#pragma unroll 1
         for (int e = 0; e < 2; ++e) {
             const int x = e * 64 + lane;
             const int c = c0 + x;
             const int d = c - r;
             const bool inb = x < a.TC && c < n && d >= mw && d <= D && d < num;
             const int base = Yb + (x < a.TC ? x : a.TC - 1);          // clamped: every lane reads inside the tile
-            rawu[e] = S.r[base] - S.r[base - LC] - S.r[base - 1] + S.r[base - LC - 1];
-            cnd[e] = inb && rawu[e] != 0u && a.dbg_stop != 4;
-        }
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const unsigned long long M = __ballot(cnd[e]);
+            const unsigned rawu = S.r[base] - S.r[base - LC] - S.r[base - 1] + S.r[base - LC - 1];
+            const bool cnd = inb && rawu != 0u && a.dbg_stop != 4;
+            const unsigned long long M = __ballot(cnd);
             if (M == 0ull) continue;
             const int pc = __popcll(M);
             const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(M >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M, 0u));
-            const int a0 = cnt & 63, k0 = cnt >> 6;
+            const int a0 = cnt & 63;
             // a bijection of the 64 lanes: candidates -> a0, a0+1, ... (mod 64), the others -> the lanes that remain
-            const int tgt = cnd[e] ? a0 + below : a0 + pc + (lane - below);
-            const unsigned id = ((unsigned)yi << 7) | (unsigned)(e * 64 + lane);
+            const int tgt = cnd ? a0 + below : a0 + pc + (lane - below);
+            const unsigned id = ((unsigned)yi << 7) | (unsigned)x;
             const unsigned R = (unsigned)__builtin_amdgcn_ds_permute((tgt & 63) << 2, (int)id);
-            const bool in0 = lane >= a0 && lane < a0 + pc;             // lands in list register k0
-            const bool in1 = lane < a0 + pc - 64;                       // wrapped: list register k0 + 1
+            if (lane >= a0 && lane < a0 + pc) curL = R;
+            if (a0 + pc >= 64) {                 // register full: commit, the wrapped part starts the next one
+                const int kf = cnt >> 6;
 #pragma unroll
-            for (int k = 0; k < NLIST; ++k) {
-                if (k == k0 && in0) L[k] = R;
-                if (k == k0 + 1 && in1) L[k] = R;
+                for (int k = 0; k < NLIST; ++k) if (k == kf) L[k] = curL;
+                curL = (lane < a0 + pc - 64) ? R : 0u;
             }
             cnt += pc;
         }
+    }
+    {
+        const int kf = cnt >> 6;            // partially filled last register
+#pragma unroll
+        for (int k = 0; k < NLIST; ++k) if (k == kf) L[k] = curL;
     }
     if (lane == 0) mycand += (unsigned)cnt;
 
