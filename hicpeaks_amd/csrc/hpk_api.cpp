@@ -59,8 +59,8 @@ struct hpk_ctx {
     std::vector<double> h_sfe;
     DevBuf d_bounds, d_off, d_sfe, d_ptab;
     // workspaces (grow only)
-    DevBuf raw, bal, weight, IR, b1, b2, plan, etab, outS, outW, dE, dW, dS, small, gap, histpart;
-    DevBuf surv, surv2;
+    DevBuf raw, bal, weight, IR, b1, b2, plan, etab, recE, recS, recW, tilecnt, dE, dW, dS, small, gap, histpart;
+    DevBuf surv, surv2, chunkused;
     DevBuf tmpA, tmpB, tmpC, tmpD;
 };
 
@@ -204,7 +204,7 @@ void hpk_destroy(hpk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf* all[] = {&c->d_bounds, &c->d_off, &c->d_sfe, &c->d_ptab, &c->raw, &c->bal, &c->weight, &c->IR, &c->b1, &c->b2,
-                     &c->plan, &c->etab, &c->outS, &c->outW, &c->dE, &c->dW, &c->dS, &c->histpart, &c->small, &c->gap, &c->surv, &c->surv2, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD};
+                     &c->plan, &c->etab, &c->recE, &c->recS, &c->recW, &c->tilecnt, &c->dE, &c->dW, &c->dS, &c->histpart, &c->small, &c->gap, &c->surv, &c->surv2, &c->chunkused, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD};
     for (DevBuf* b : all) b->release();
     for (int i = 0; i < c->nev; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -389,8 +389,6 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     HIPCHK(c, hipGetLastError());
     const int64_t ldo = ((int64_t)(D + 1) + 31) / 32 * 32;
     const size_t dense_elems = (size_t)plan.nslots * (size_t)n * (size_t)ldo;
-    HIPCHK(c, c->outS.reserve(sizeof(double2) * dense_elems));
-    HIPCHK(c, c->outW.reserve(dense_elems));
     if (dense) {
         HIPCHK(c, c->dE.reserve(sizeof(double2) * dense_elems));
         HIPCHK(c, c->dW.reserve(dense_elems));
@@ -400,7 +398,6 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     HIPCHK(c, hipMemsetAsync(c->small.p, 0, SMALL_BYTES, c->stream));
     HIPCHK(c, c->gap.reserve((size_t)n));
     if (dense) {   // pixels outside the band are never written by the kernel
-        HIPCHK(c, hipMemsetAsync(c->outW.p, 0, dense_elems, c->stream));
         HIPCHK(c, hipMemsetAsync(c->dE.p, 0, sizeof(double2) * dense_elems, c->stream));
         HIPCHK(c, hipMemsetAsync(c->dW.p, 0, dense_elems, c->stream));
         if (sums) HIPCHK(c, hipMemsetAsync(c->dS.p, 0, sizeof(double4) * dense_elems, c->stream));
@@ -421,7 +418,6 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     std::memset(&sa, 0, sizeof(sa));
     sa.raw = in.raw; sa.bal = in.bal; sa.weight = in.weight;
     sa.plan = c->plan.as<HpkDevPlan>();
-    sa.outS = c->outS.as<double2>(); sa.outW = c->outW.as<uint8_t>();
     sa.hist = d_hist;
     sa.n = n; sa.num = num; sa.ld = band->ld; sa.ldo = ldo; sa.W = W; sa.mw = mw; sa.D = D; sa.TR = TR; sa.TC = TC;
     sa.J = (TR + D - mw + TC - 1) / TC;
@@ -434,6 +430,17 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     HIPCHK(c, c->histpart.reserve(sizeof(unsigned) * (size_t)sa.grid * (HPK_MAX_STEPS + 1)));
     HIPCHK(c, hipMemsetAsync(c->histpart.p, 0, sizeof(unsigned) * (size_t)sa.grid * (HPK_MAX_STEPS + 1), c->stream));
     sa.hist_part = c->histpart.as<unsigned>();
+    sa.tilecap = TR * TC;
+    sa.rec_stride = (int64_t)sa.ntiles * sa.tilecap;
+    HIPCHK(c, c->recE.reserve(sizeof(unsigned) * (size_t)sa.rec_stride));
+    HIPCHK(c, c->recS.reserve(sizeof(double2) * (size_t)sa.rec_stride * plan.nslots));
+    HIPCHK(c, c->recW.reserve((size_t)sa.rec_stride * plan.nslots));
+    HIPCHK(c, c->tilecnt.reserve(sizeof(unsigned) * (size_t)sa.ntiles));
+    HIPCHK(c, hipMemsetAsync(c->tilecnt.p, 0, sizeof(unsigned) * (size_t)sa.ntiles, c->stream));
+    sa.rec_ent = c->recE.as<unsigned>(); sa.rec_S = c->recS.as<double2>(); sa.rec_W = c->recW.as<uint8_t>();
+    sa.tile_cnt = c->tilecnt.as<unsigned>();
+    HIPCHK(c, hipMemsetAsync(c->gap.p, 1, (size_t)n, c->stream));
+    sa.gap = c->gap.as<uint8_t>();
     (void)hipEventRecord(c->ev[1], c->stream);
     hpk_launch_stencil(sa, in.bal != nullptr, plan.simple_reads != 0 && !std::getenv("HPK_GENERIC_SEARCH"), c->stream);
     HIPCHK(c, hipGetLastError());
@@ -459,28 +466,35 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (do_score) {
             if (cap == 0) cap = std::max<int64_t>(1 << 16, band_px * nsets / 6) + (int64_t)c->cus * 8 * 4 * 256 * 2;
+            cap = (cap + 255) / 256 * 256;
             HIPCHK(c, c->surv.reserve(sizeof(HpkSurv) * (size_t)cap));
+            HIPCHK(c, c->chunkused.reserve(sizeof(unsigned) * (size_t)(cap / 256 + 1)));
+            HIPCHK(c, hipMemsetAsync(c->chunkused.p, 0, sizeof(unsigned) * (size_t)(cap / 256 + 1), c->stream));
             HIPCHK(c, c->surv2.reserve(sizeof(HpkSurv) * (size_t)cap));
             HpkScoreArgs sc;
             std::memset(&sc, 0, sizeof(sc));
-            sc.raw = in.raw; sc.bal = in.bal; sc.weight = in.weight; sc.outS = sa.outS; sc.outW = sa.outW; sc.plan = sa.plan;
+            sc.raw = in.raw; sc.bal = in.bal; sc.weight = in.weight; sc.plan = sa.plan;
             sc.etab = c->etab.as<double>(); sc.IR = in.IR; sc.b1 = in.b1; sc.b2 = in.b2;
             sc.frozen = d_frozen; sc.bounds = c->d_bounds.as<double>(); sc.ptab = c->d_ptab.as<double>();
             sc.ptab_off = c->d_off.as<int32_t>(); sc.sfe = c->d_sfe.as<double>(); sc.sig = prm->sig;
             sc.n = n; sc.num = num; sc.ld = band->ld; sc.ldo = ldo; sc.mw = mw; sc.D = D;
+            sc.rec_ent = sa.rec_ent; sc.rec_S = sa.rec_S; sc.rec_W = sa.rec_W; sc.tile_cnt = sa.tile_cnt;
+            sc.tilecap = sa.tilecap; sc.rec_stride = sa.rec_stride; sc.ntiles = sa.ntiles;
+            sc.TR = TR; sc.TC = TC; sc.J = sa.J; sc.W = W;
             sc.fam_m = d_fam_m; sc.fam_f = d_fam_f; sc.emax_bits = d_emax; sc.nvalid = d_nvalid; sc.nsurv = d_nsurv;
-            sc.cap = cap; sc.surv = c->surv.as<HpkSurv>();
+            sc.cap = cap; sc.surv = c->surv.as<HpkSurv>(); sc.chunk_used = c->chunkused.as<unsigned>();
             hpk_launch_score(sc, c->cus, c->stream);
             HIPCHK(c, hipGetLastError());
             (void)hipEventRecord(c->ev[4], c->stream);
-            hpk_launch_tighten(sc.surv, d_nsurv, cap, d_fam_m, d_fam_f, d_thr, prm->sig, 2, c->surv2.as<HpkSurv>(), d_nout,
+            hpk_launch_tighten(sc.surv, d_nsurv, cap, sc.chunk_used, d_fam_m, d_fam_f, d_thr, prm->sig, 2, c->surv2.as<HpkSurv>(), d_nout,
                                c->cus, c->stream);
             HIPCHK(c, hipGetLastError());
         } else {
             (void)hipEventRecord(c->ev[4], c->stream);
         }
         (void)hipEventRecord(c->ev[5], c->stream);
-        if (attempt == 0) {
+        // gap rows are produced by the stencil kernel (hpk_gap remains as an independent check for the tests)
+        if (attempt == 0 && std::getenv("HPK_GAP_KERNEL")) {
             hpk_launch_gap(in.raw, in.bal, in.weight, n, num, band->ld, mw, c->gap.as<uint8_t>(), c->stream);
             HIPCHK(c, hipGetLastError());
         }
@@ -543,7 +557,9 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     }
     if (dense) {
         HpkDenseArgs da;
-        da.outS = sa.outS; da.outW = sa.outW; da.plan = sa.plan; da.etab = c->etab.as<double>();
+        da.rec_ent = sa.rec_ent; da.rec_S = sa.rec_S; da.rec_W = sa.rec_W; da.tile_cnt = sa.tile_cnt;
+        da.tilecap = sa.tilecap; da.rec_stride = sa.rec_stride; da.ntiles = sa.ntiles; da.TR = TR; da.TC = TC; da.J = sa.J;
+        da.plan = sa.plan; da.etab = c->etab.as<double>();
         da.IR = in.IR; da.b1 = in.b1; da.b2 = in.b2; da.n = n; da.num = num; da.ldo = ldo; da.mw = mw; da.D = D;
         da.dE = c->dE.as<double2>(); da.dW = c->dW.as<uint8_t>(); da.dS = sums ? c->dS.as<double4>() : nullptr;
         hpk_launch_dense(da, c->stream);

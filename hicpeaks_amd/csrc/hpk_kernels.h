@@ -7,14 +7,26 @@
 #define HPK_LC 128                      // SAT columns per tile (two cells per lane)
 #define HPK_LR 80                       // SAT rows per tile: 80 * 128 * 16 B = 160 KiB, the whole LDS of one CU
 #define HPK_HIST_NCAND HPK_MAX_STEPS    // hist[HPK_MAX_STEPS] counts the candidates
+#define HPK_NWAVES 16                   // waves per stencil workgroup
+#define HPK_RAWCAP 0x7ffffu              // largest count that fits a record entry; larger ones are re-read from the band
 
 struct HpkStencilArgs {
     const float*  raw;
     const double* bal;                  // f64 band or nullptr
     const double* weight;               // f64[n] or nullptr
     const HpkDevPlan* plan;
-    double2* outS;                      // [nslots][n][ldo]  (bS_K, bS_Y) at the resolving step
-    uint8_t* outW;                      // [nslots][n][ldo]  resolving step + 1, 0 = unresolved
+    // Output: compact candidate records, one region of `tilecap` records per tile.  Waves reserve their share of a
+    // region with one atomicAdd on tile_cnt[tile] (distinct addresses per tile: no serialisation).
+    //   rec_ent[tile * tilecap + i]                    x | row slot << 7 | stencil wave << 9 | min(raw, 2^19 - 1) << 13
+    //   rec_S[slot * rec_stride + tile * tilecap + i]  (bS_K, bS_Y) at the resolving step
+    //   rec_W[slot * rec_stride + tile * tilecap + i]  resolving step + 1, 0 = unresolved
+    unsigned* rec_ent;
+    double2* rec_S;
+    uint8_t* rec_W;
+    unsigned* tile_cnt;
+    int32_t tilecap;
+    int64_t rec_stride;
+    uint8_t* gap;                       // [n] preset to 1; cleared for rows with a non-zero balanced value
     unsigned long long* hist;           // [HPK_MAX_STEPS + 1] totals, written by hpk_freeze
     unsigned* hist_part;                // [grid][HPK_MAX_STEPS + 1] per-workgroup resolve counts, [..][HPK_MAX_STEPS] = candidates
     int32_t n, num;
@@ -42,8 +54,13 @@ struct HpkScoreArgs {
     const float*  raw;
     const double* bal;
     const double* weight;
-    const double2* outS;
-    const uint8_t* outW;
+    const unsigned* rec_ent;            // candidate records written by hpk_stencil
+    const double2* rec_S;
+    const uint8_t* rec_W;
+    const unsigned* tile_cnt;
+    int32_t tilecap;
+    int64_t rec_stride;
+    int32_t ntiles, TR, TC, J, W;       // tile geometry
     const HpkDevPlan* plan;
     const double* etab;                 // [nsteps][2][D + 1]
     const double* IR;
@@ -64,12 +81,15 @@ struct HpkScoreArgs {
     unsigned long long* emax_bits;      // [nsets]
     unsigned long long* nvalid;         // [nsets]
     unsigned long long* nsurv;          // scalar
-    int64_t cap;                        // survivor capacity
+    int64_t cap;                        // survivor capacity (multiple of 256)
     HpkSurv* surv;
+    unsigned* chunk_used;               // [cap / 256] filled slots per 256-record chunk
 };
 
 struct HpkDenseArgs {
-    const double2* outS; const uint8_t* outW; const HpkDevPlan* plan; const double* etab;
+    const unsigned* rec_ent; const double2* rec_S; const uint8_t* rec_W; const unsigned* tile_cnt;
+    int32_t tilecap; int64_t rec_stride; int32_t ntiles, TR, TC, J;
+    const HpkDevPlan* plan; const double* etab;
     const double* IR; const double* b1; const double* b2;
     int32_t n, num; int64_t ldo; int32_t mw, D;
     double2* dE; uint8_t* dW; double4* dS;
@@ -94,7 +114,8 @@ void hpk_launch_gap(const float* raw, const double* bal, const double* weight, i
 void hpk_launch_score(const HpkScoreArgs& a, int cus, hipStream_t st);
 // Benjamini-Hochberg cut tightening on the survivor list: thr[f] <- sig * #{p <= thr[f]} / m[f], `rounds` times,
 // then compaction of the records with p <= thr[f] into `out` (count in *nout).
-void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned int* fam_m,
+void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned* chunk_used,
+                        const unsigned int* fam_m,
                         unsigned int* fam_cnt, double* fam_thr, double sig, int rounds, HpkSurv* out,
                         unsigned long long* nout, int cus, hipStream_t st);
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,

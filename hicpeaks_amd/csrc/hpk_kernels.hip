@@ -194,7 +194,7 @@ __device__ __forceinline__ int tile_of(const HpkStencilArgs& a, int it) {
 template <int NW, bool BALF64, bool SIMPLE>
 __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const float* __restrict__ g_raw,
                                                         const double* __restrict__ g_bal, const double* __restrict__ g_w,
-                                                        double2* __restrict__ g_outS, uint8_t* __restrict__ g_outW) {
+                                                        double2* __restrict__ g_recS, uint8_t* __restrict__ g_recW) {
     constexpr int RPW = LR / NW;
     static_assert(RPW * NW == LR, "rows must split evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -229,7 +229,6 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
     }
     const unsigned alldone = (1u << nslots) - 1u;
     unsigned myhist = 0u, mycand = 0u;
-    const int64_t slot_stride = (int64_t)n * a.ldo;
     // gfx9 counts loads and stores on one vmcnt: a compiler-placed wait for any of these one-time loads *inside* the
     // pixel loops would also drain the stores of the previous pass (measured: 16k cycles per pass).  Passing each
     // value through an empty asm makes the compiler wait here, once, and treat the registers as plain values after.
@@ -280,7 +279,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
             const unsigned ru = (unsigned)rv;
             tc[e] += bv;
             tr[e] += ru;
-            tv[e] += (bv != 0.0) ? ru : 0u;
+            tv[e] += (bv != 0.0) ? (ru ? ru : 1u) : 0u;
         }
     }
     if (a.dbg_stop == 1) {
@@ -315,7 +314,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
     for (int j = 0; j < RPW; ++j) {
         const unsigned r0u = (unsigned)rawv[j][0], r1u = (unsigned)rawv[j][1];
         const double c0v = balv[j][0], c1v = balv[j][1];
-        const unsigned v0 = (c0v != 0.0) ? r0u : 0u, v1 = (c1v != 0.0) ? r1u : 0u;
+        const unsigned v0 = (c0v != 0.0) ? (r0u ? r0u : 1u) : 0u, v1 = (c1v != 0.0) ? (r1u ? r1u : 1u) : 0u;
         const double l1c = c0v + c1v; const unsigned l1r = r0u + r1u, l1v = v0 + v1;
         double pc = l1c; unsigned pr = l1r, pv = l1v;
         wave_exclusive_scan(pc, pr, pv);
@@ -336,6 +335,16 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
         continue;
     }
     const double tiny_thr = 1e-9 * S.c[LR * LC - 1];
+    // Gap rows (callers.py:238: rows of the balanced upper band that sum to 0): the valid-count plane gives the exact
+    // row sum of this tile's columns; the last tile of a row block also covers the maxww diagonals beyond D in its
+    // right halo.  gap[] is preset to 1, any tile that sees a non-zero balanced value in row r clears gap[r].
+    if ((int)threadIdx.x < a.TR && r0 + (int)threadIdx.x < n) {
+        const bool last = (cj == a.J - 1) || (c0 + a.TC >= n) || (mw + (cj + 1) * a.TC - (a.TR - 1)) > D;
+        const int Y = (int)threadIdx.x + W + 1;
+        const int xe = last ? LC - 1 : W + a.TC, xs = W;
+        const unsigned rs = S.v[Y * LC + xe] - S.v[(Y - 1) * LC + xe] - S.v[Y * LC + xs] + S.v[(Y - 1) * LC + xs];
+        if (rs != 0u) a.gap[r0 + (int)threadIdx.x] = 0;
+    }
 
     // ---- phase 3: candidates of the tile.  Work is proportional to the candidates (non-zero pixels), not to the
     // band pixels:
@@ -376,7 +385,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
             const int a0 = cnt & 63;
             // a bijection of the 64 lanes: candidates -> a0, a0+1, ... (mod 64), the others -> the lanes that remain
             const int tgt = cnd ? a0 + below : a0 + pc + (lane - below);
-            const unsigned id = ((unsigned)yi << 7) | (unsigned)x;
+            const unsigned id = (unsigned)x | ((unsigned)yi << 7) | ((unsigned)wave << 9) | ((rawu < HPK_RAWCAP ? rawu : HPK_RAWCAP) << 13);
             const unsigned R = (unsigned)__builtin_amdgcn_ds_permute((tgt & 63) << 2, (int)id);
             if (lane >= a0 && lane < a0 + pc) curL = R;
             if (a0 + pc >= 64) {                 // register full: commit, the wrapped part starts the next one
@@ -393,6 +402,13 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
 #pragma unroll
         for (int k = 0; k < NLIST; ++k) if (k == kf) L[k] = curL;
     }
+    // this wave's share of the tile's record region
+    unsigned woff = 0u;
+    if (cnt > 0) {
+        if (lane == 0) woff = atomicAdd(&a.tile_cnt[tid], (unsigned)cnt);
+        woff = (unsigned)__builtin_amdgcn_readfirstlane((int)woff);
+    }
+    const int64_t rec0 = (int64_t)tid * a.tilecap + woff;
     if (lane == 0) mycand += (unsigned)cnt;
 
     const int nbatch = (cnt + 63) >> 6;
@@ -402,8 +418,9 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
 #pragma unroll
         for (int k = 0; k < NLIST; ++k) if (k == kb) id = L[k];
         const bool cand = kb * 64 + lane < cnt;
-        const int yi = (int)(id >> 7), x = (int)(id & 127u);
+        const int yi = (int)((id >> 7) & 3u), x = (int)(id & 127u);
         const int y = wave + NW * yi;
+        if (cand) a.rec_ent[rec0 + kb * 64 + lane] = id;
         const int r = r0 + y;
         const int d = c0 + x - r;
         const int base = (y + W + 1) * LC + W + 1 + x;       // idle lanes: id 0 -> a valid interior cell
@@ -536,9 +553,9 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
                 }
             }
             if (cand) {
-                const int64_t o = q * slot_stride + (int64_t)r * a.ldo + d;
-                g_outS[o] = make_double2(act ? SK : 0.0, act ? SY : 0.0);
-                g_outW[o] = act ? (uint8_t)(sq + 1) : (uint8_t)0;
+                const int64_t o = q * a.rec_stride + rec0 + kb * 64 + lane;
+                g_recS[o] = make_double2(act ? SK : 0.0, act ? SY : 0.0);
+                g_recW[o] = act ? (uint8_t)(sq + 1) : (uint8_t)0;
             }
         }
     }
@@ -752,27 +769,38 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
 
     const int lane = threadIdx.x & 63;
     const int frozen = *a.frozen;
-    const int64_t slot_stride = (int64_t)a.n * a.ldo;
-    const int wd = a.D - a.mw + 1;
     // Survivor slots are reserved from the global counter HPK_SCH records at a time per wave (same-address atomics
-    // run at ~90 per microsecond device-wide); slots a wave leaves unused are marked invalid (set = 0xff).
+    // run at ~90 per microsecond device-wide); how many slots of a chunk were filled goes to chunk_used[].
     constexpr unsigned HPK_SCH = 256;
     unsigned long long wbase = 0ull;
     unsigned wused = HPK_SCH;               // "no chunk yet"
-    for (int r = blockIdx.x; r < a.n; r += gridDim.x) {
-        const double b1r = a.b1[r];
-        for (int dd = threadIdx.x; dd < ((wd + 255) & ~255); dd += 256) {
-            const int d = a.mw + dd;
-            const int c = r + d;
-            const bool inband = dd < wd && d < a.num && c < a.n;
-            float rawpix = 0.f;
-            if (inband) rawpix = a.raw[(int64_t)r * a.ld + d];
-            const bool cand = inband && rawpix != 0.f;
-            if (__ballot(cand) == 0ull) continue;
-            const int64_t o = (int64_t)r * a.ldo + d;
+    bool have_chunk = false;
+    // Work unit = 4 consecutive 64-record batches of one tile's record region; units are dealt round-robin to all
+    // waves of the grid (tiles differ a lot in candidate count), reads are coalesced.
+    const int bpt = (a.tilecap + 63) >> 6;                  // batches per tile region
+    const int upt = (bpt + 3) >> 2;                         // units per tile
+    const int64_t nunits = (int64_t)a.ntiles * upt;
+    const int64_t gw = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwv = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t u = gw; u < nunits; u += nwv) {
+        const int tile = (int)(u / upt), ub = (int)(u - (int64_t)tile * upt);
+        const int cnt = (int)a.tile_cnt[tile];
+        if (ub * 256 >= cnt) continue;
+        const int rb = tile / a.J, cj = tile - rb * a.J;
+        const int r0 = rb * a.TR, c0 = r0 + a.mw + cj * a.TC;
+        const int iend = (ub * 256 + 256 < cnt) ? ub * 256 + 256 : cnt;
+        for (int i0 = ub * 256; i0 < iend; i0 += 64) {
+            const bool cand = i0 + lane < cnt;
+            const int64_t ri = (int64_t)tile * a.tilecap + i0 + lane;
+            unsigned ent = 0u;
+            if (cand) ent = a.rec_ent[ri];
+            const int r = r0 + (int)((ent >> 9) & 15u) + HPK_NWAVES * (int)((ent >> 7) & 3u);
+            const int c = c0 + (int)(ent & 127u);
+            const int d = c - r;
+            float rawpix = (float)(ent >> 13);
+            if (cand && (ent >> 13) == HPK_RAWCAP) rawpix = a.raw[(int64_t)r * a.ld + d];     // count too large for the entry
             const double O = (double)rawpix;
-            double ir = 0.0, b2c = 0.0;
-            if (cand) { ir = a.IR[d]; b2c = a.b2[c]; }
+            double ir = 0.0, b2c = 0.0, b1r = 0.0;
+            if (cand) { ir = a.IR[d]; b2c = a.b2[c]; b1r = a.b1[r]; }
 
             for (int pj = 0; pj < npairs; ++pj) {
                 const int slot = plan->pair_slot[pj];
@@ -780,10 +808,10 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                 bool ok = cand && d >= wi0;                                   // callers.py:244
                 double eK = 0.0, eY = 0.0;
                 if (ok) {
-                    const int stp = (int)a.outW[slot * slot_stride + o];
+                    const int stp = (int)a.rec_W[slot * a.rec_stride + ri];
                     ok = (stp != 0) && (lstepw[stp - 1] <= frozen);           // resolved at an executed step
                     if (ok) {
-                        const double2 s2 = a.outS[slot * slot_stride + o];
+                        const double2 s2 = a.rec_S[slot * a.rec_stride + ri];
                         double EK, EY;
                         local_expected(plan, a.etab, a.IR, stp - 1, r, c, d, a.n, a.num, a.mw, a.D, W, EK, EY);
                         // callers.py:244-249: E = ((IR[d] * (bS / bE)) * B1[x]) * B2[y] where bE != 0
@@ -838,19 +866,17 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                     }
                     const unsigned long long sm = __ballot(surv);
                     if (sm != 0ull) {
-                        const unsigned cnt = (unsigned)__popcll(sm);
-                        if (wused + cnt > HPK_SCH) {            // wave-uniform: retire the chunk, take a new one
-                            if (wused < HPK_SCH) {
-                                for (unsigned k = wused + lane; k < HPK_SCH; k += 64)
-                                    if ((int64_t)(wbase + k) < a.cap) a.surv[wbase + k].set = 0xff;
-                            }
+                        const unsigned scnt = (unsigned)__popcll(sm);
+                        if (wused + scnt > HPK_SCH) {            // wave-uniform: retire the chunk, take a new one
+                            if (have_chunk && lane == 0 && (int64_t)wbase < a.cap) a.chunk_used[wbase / HPK_SCH] = wused;
+                            have_chunk = true;
                             unsigned long long nb = 0ull;
                             if (lane == 0) nb = atomicAdd(a.nsurv, (unsigned long long)HPK_SCH);
                             wbase = __shfl(nb, 0);
                             wused = 0u;
                         }
                         const unsigned long long basei = wbase + wused;
-                        wused += cnt;
+                        wused += scnt;
                         if (surv) {
                             const unsigned long long idx = basei + (unsigned long long)__popcll(sm & ((1ull << lane) - 1ull));
                             if ((int64_t)idx < a.cap) {
@@ -869,10 +895,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
             }
         }
     }
-    if (wused < HPK_SCH) {
-        for (unsigned k = wused + lane; k < HPK_SCH; k += 64)
-            if ((int64_t)(wbase + k) < a.cap) a.surv[wbase + k].set = 0xff;
-    }
+    if (have_chunk && lane == 0 && (int64_t)wbase < a.cap) a.chunk_used[wbase / HPK_SCH] = wused;
     __syncthreads();
     for (int i = threadIdx.x; i < nsets * (HPK_NB + 1); i += blockDim.x) {
         const unsigned v = (&lm[0][0])[i], f = (&lf[0][0])[i];
@@ -899,13 +922,14 @@ __global__ void __launch_bounds__(256) hpk_thr_init(const unsigned int* fam_m, c
     cnt[i] = 0u;
 }
 __global__ void __launch_bounds__(256) hpk_thr_count(const HpkSurv* __restrict__ surv, const unsigned long long* __restrict__ nsurv,
-                                                     int64_t cap, const double* __restrict__ thr, unsigned int* __restrict__ cnt) {
+                                                     int64_t cap, const unsigned* __restrict__ chunk_used,
+                                                     const double* __restrict__ thr, unsigned int* __restrict__ cnt) {
     __shared__ unsigned int lc[HPK_NFAM];
     for (int i = threadIdx.x; i < HPK_NFAM; i += blockDim.x) lc[i] = 0u;
     __syncthreads();
     int64_t n = (int64_t)*nsurv; if (n > cap) n = cap;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        if (surv[i].set == 0xff) continue;
+        if ((unsigned)(i & 255) >= chunk_used[i >> 8]) continue;
         const int f = (int)surv[i].set * (HPK_NB + 1) + (int)surv[i].chunk;
         if (surv[i].p <= thr[f]) atomicAdd(&lc[f], 1u);
     }
@@ -921,7 +945,8 @@ __global__ void __launch_bounds__(256) hpk_thr_update(const unsigned int* __rest
     cnt[i] = 0u;
 }
 __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkSurv* __restrict__ surv, const unsigned long long* __restrict__ nsurv,
-                                                       int64_t cap, const double* __restrict__ thr, HpkSurv* __restrict__ out,
+                                                       int64_t cap, const unsigned* __restrict__ chunk_used,
+                                                       const double* __restrict__ thr, HpkSurv* __restrict__ out,
                                                        unsigned long long* __restrict__ nout) {
     int64_t n = (int64_t)*nsurv; if (n > cap) n = cap;
     const int lane = threadIdx.x & 63;
@@ -931,8 +956,10 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkSurv* __restrict
         bool keep = false;
         HpkSurv rec;
         if (i < n) {
-            rec = surv[i];
-            keep = rec.set != 0xff && rec.p <= thr[(int)rec.set * (HPK_NB + 1) + (int)rec.chunk];
+            if ((unsigned)(i & 255) < chunk_used[i >> 8]) {
+                rec = surv[i];
+                keep = rec.p <= thr[(int)rec.set * (HPK_NB + 1) + (int)rec.chunk];
+            }
         }
         const unsigned long long km = __ballot(keep);
         if (km == 0ull) continue;
@@ -947,19 +974,25 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkSurv* __restrict
 // Expands the stencil output to (E_K, E_Y), resolving width and (bS_K, bE_K, bS_Y, bE_Y) per slot and pixel.
 __global__ void __launch_bounds__(256) hpk_dense(HpkDenseArgs a) {
     const HpkDevPlan* __restrict__ plan = a.plan;
-    const int r = blockIdx.x;
+    const int tile = blockIdx.x;
+    const int cnt = (int)a.tile_cnt[tile];
+    const int rb = tile / a.J, cj = tile - rb * a.J;
+    const int r0 = rb * a.TR, c0 = r0 + a.mw + cj * a.TC;
     const int64_t slot_stride = (int64_t)a.n * a.ldo;
-    for (int d = a.mw + threadIdx.x; d <= a.D && d < a.num; d += blockDim.x) {
-        const int c = r + d;
-        if (c >= a.n) break;
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const int64_t ri = (int64_t)tile * a.tilecap + i;
+        const unsigned ent = a.rec_ent[ri];
+        const int r = r0 + (int)((ent >> 9) & 15u) + HPK_NWAVES * (int)((ent >> 7) & 3u);
+        const int c = c0 + (int)(ent & 127u);
+        const int d = c - r;
         const int64_t o = (int64_t)r * a.ldo + d;
         for (int q = 0; q < plan->nslots; ++q) {
-            const int stp = (int)a.outW[q * slot_stride + o];
+            const int stp = (int)a.rec_W[q * a.rec_stride + ri];
             double2 e = make_double2(0.0, 0.0);
             double4 sm = make_double4(0.0, 0.0, 0.0, 0.0);
             uint8_t w = 0;
             if (stp != 0) {
-                const double2 s2 = a.outS[q * slot_stride + o];
+                const double2 s2 = a.rec_S[q * a.rec_stride + ri];
                 double EK, EY;
                 local_expected(plan, a.etab, a.IR, stp - 1, r, c, d, a.n, a.num, a.mw, a.D, plan->W, EK, EY);
                 const double ir = a.IR[d], b1r = a.b1[r], b2c = a.b2[c];
@@ -1022,24 +1055,18 @@ static void launch_stencil_t(const HpkStencilArgs& a, hipStream_t st) {
                                   hpk_stencil_lds_bytes());
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.grid), dim3(NW * 64), hpk_stencil_lds_bytes(), st, a, a.raw, a.bal, a.weight, a.outS, a.outW);
+    hipLaunchKernelGGL(kern, dim3(a.grid), dim3(NW * 64), hpk_stencil_lds_bytes(), st, a, a.raw, a.bal, a.weight, a.rec_S, a.rec_W);
 }
 
 void hpk_launch_stencil(const HpkStencilArgs& a, bool balf64, bool simple, hipStream_t st) {
-    static const int nw = [] { const char* e = getenv("HPK_NW"); return e ? atoi(e) : 16; }();
-    if (nw == 8) {
-        if (balf64) { if (simple) launch_stencil_t<8, true, true>(a, st); else launch_stencil_t<8, true, false>(a, st); }
-        else        { if (simple) launch_stencil_t<8, false, true>(a, st); else launch_stencil_t<8, false, false>(a, st); }
-        return;
-    }
-    constexpr int NW = 16;
+    constexpr int NW = HPK_NWAVES;
     if (balf64) { if (simple) launch_stencil_t<NW, true, true>(a, st); else launch_stencil_t<NW, true, false>(a, st); }
     else        { if (simple) launch_stencil_t<NW, false, true>(a, st); else launch_stencil_t<NW, false, false>(a, st); }
 }
 
 void hpk_launch_dense(const HpkDenseArgs& a, hipStream_t st) {
-    if (a.n <= 0) return;
-    hipLaunchKernelGGL(hpk_dense, dim3(a.n), dim3(256), 0, st, a);
+    if (a.ntiles <= 0) return;
+    hipLaunchKernelGGL(hpk_dense, dim3(a.ntiles), dim3(256), 0, st, a);
 }
 
 void hpk_launch_freeze(const HpkDevPlan* plan, unsigned long long* hist, const unsigned* hist_part, int nparts,
@@ -1054,23 +1081,23 @@ void hpk_launch_gap(const float* raw, const double* bal, const double* weight, i
 }
 
 void hpk_launch_score(const HpkScoreArgs& a, int cus, hipStream_t st) {
-    const int wd = a.D - a.mw + 1;
-    if (wd <= 0 || a.n <= 0) return;
-    const int grid = a.n < cus * 8 ? a.n : cus * 8;
+    if (a.ntiles <= 0 || a.n <= 0) return;
+    const int grid = cus * 8;
     hipLaunchKernelGGL(hpk_score, dim3(grid), dim3(256), 0, st, a);
 }
 
-void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned int* fam_m,
+void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned* chunk_used,
+                        const unsigned int* fam_m,
                         unsigned int* fam_cnt, double* fam_thr, double sig, int rounds, HpkSurv* out,
                         unsigned long long* nout, int cus, hipStream_t st) {
     const int fb = (HPK_NFAM + 255) / 256;
     // fam_cnt enters holding F(sig) (written by hpk_score)
     hipLaunchKernelGGL(hpk_thr_init, dim3(fb), dim3(256), 0, st, fam_m, fam_cnt, fam_thr, fam_cnt, sig);
     for (int r = 0; r < rounds; ++r) {
-        hipLaunchKernelGGL(hpk_thr_count, dim3(cus * 2), dim3(256), 0, st, surv, nsurv, cap, fam_thr, fam_cnt);
+        hipLaunchKernelGGL(hpk_thr_count, dim3(cus * 2), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_thr, fam_cnt);
         hipLaunchKernelGGL(hpk_thr_update, dim3(fb), dim3(256), 0, st, fam_m, fam_thr, fam_cnt, sig);
     }
-    hipLaunchKernelGGL(hpk_thr_compact, dim3(cus * 2), dim3(256), 0, st, surv, nsurv, cap, fam_thr, out, nout);
+    hipLaunchKernelGGL(hpk_thr_compact, dim3(cus * 2), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_thr, out, nout);
 }
 
 void hpk_launch_etab(const HpkDevPlan* plan, int nsteps, int D, const double* IR, int num, double* etab, hipStream_t st) {
