@@ -168,6 +168,13 @@ def main():
                          'kernel_ms': st, 'algorithmic_bytes_per_launch': BYTES_PER_PX * px_per_step},
             'phases_ms': {k: float(v) for k, v in R.timing.items()},
         }
+        try:        # HBM traffic per launch of the dominant kernel, measured off-line with rocprofv3 --pmc (profiles/)
+            tr = json.load(open(os.path.join(REPO, 'profiles', 'traffic.json'))).get(args.config)
+            if tr:
+                out['roofline']['traffic'] = tr['traffic_bytes']
+                out['roofline']['traffic_source'] = tr['source']
+        except Exception:
+            pass
         if world == 1 and args.cpu_rows > 0:
             out['cpu_baseline'] = cpu_baseline(cfg, min(args.cpu_rows, n))
         print(json.dumps(out))
