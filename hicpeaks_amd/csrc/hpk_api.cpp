@@ -425,7 +425,6 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     sa.ntiles = RB * sa.J;
     sa.chunk = (sa.ntiles + 7) / 8;
     { const char* e = std::getenv("HPK_DBG_STOP"); sa.dbg_stop = e ? std::atoi(e) : 0; }
-    { const char* e = std::getenv("HPK_DENSE_ZERO"); sa.dense_zero = (e && std::atoi(e)) ? 1 : 0; }
     sa.grid = std::max(8, std::min((c->cus / 8) * 8, ((sa.chunk + 0) * 8)));
     HIPCHK(c, c->histpart.reserve(sizeof(unsigned) * (size_t)sa.grid * (HPK_MAX_STEPS + 1)));
     HIPCHK(c, hipMemsetAsync(c->histpart.p, 0, sizeof(unsigned) * (size_t)sa.grid * (HPK_MAX_STEPS + 1), c->stream));

@@ -36,7 +36,6 @@ struct HpkStencilArgs {
     int32_t J;                          // column chunks per row block
     int32_t ntiles, chunk;              // chunk = ceil(ntiles / 8): tiles handed to one XCD
     int32_t grid;                       // persistent workgroups (multiple of 8, one per CU)
-    int32_t dense_zero;                 // also write zeros at non-candidate pixels (HPK_DENSE_ZERO=1: the 20 B/px mode)
     int32_t dbg_stop;                   // profiling ablation (HPK_DBG_STOP): 1 stop after the loads, 2 after the SAT,
                                         // 4 no candidates (loads + SAT + zero stores), 5 search without box sums
 };
