@@ -161,6 +161,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': cfg['workload'], 'name': args.config, 'band_px_per_step': px_per_step,
                        'candidates': R.ncand, 'significant_px': int(sum(s['x'].size for s in R.sets)),
+                       'px_with_p_le_sig': R.nsurv_sig, 'records_copied_back': R.nsurv_cut,
                        'parallelism': 'one chromosome per GPU, no collective',
                        'stencil_only': bool(args.stencil_only)},
             'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil', 'achieved': achieved, 'peak': HBM_PEAK_GBS,

@@ -61,6 +61,10 @@ struct hpk_ctx {
     // workspaces (grow only)
     DevBuf raw, bal, weight, IR, b1, b2, plan, etab, recE, recS, recW, tilecnt, dE, dW, dS, small, gap, histpart;
     DevBuf surv, surv2, chunkused;
+    // the device copy of the widening plan is reused while the parameters do not change
+    hpk_params plan_key;
+    bool plan_valid = false;
+    HpkDevPlan plan_host;
     DevBuf tmpA, tmpB, tmpC, tmpD;
 };
 
@@ -334,13 +338,14 @@ constexpr size_t OFF_FROZEN = OFF_HIST + 8 * (HPK_MAX_STEPS + 1);               
 constexpr size_t OFF_ERR = OFF_FROZEN + 8;                                       // i32
 constexpr size_t OFF_EXEC = OFF_ERR + 8;                                         // i32[64]
 constexpr size_t OFF_NSURV = OFF_EXEC + 4 * HPK_MAX_STEPS;                       // u64
-constexpr size_t OFF_NVALID = OFF_NSURV + 8;                                     // u64[16]
+constexpr size_t OFF_NVALID = OFF_NSURV + 8 * HPK_NREG * HPK_REG_STRIDE;          // u64[16]
 constexpr size_t OFF_EMAX = OFF_NVALID + 8 * 2 * HPK_MAX_PAIRS;                  // u64[16]
 constexpr size_t OFF_NOUT = OFF_EMAX + 8 * 2 * HPK_MAX_PAIRS;                    // u64
 constexpr size_t OFF_FAM_M = OFF_NOUT + 8;                                       // u32[HPK_NFAM]
 constexpr size_t OFF_FAM_F = OFF_FAM_M + 4 * HPK_NFAM;                           // u32[HPK_NFAM]
 constexpr size_t OFF_THR = OFF_FAM_F + 4 * HPK_NFAM;                             // f64[HPK_NFAM]
-constexpr size_t SMALL_BYTES = OFF_THR + 8 * HPK_NFAM;
+constexpr size_t OFF_CNT = OFF_THR + 8 * HPK_NFAM;                                // u32[HPK_NFAM] tightening scratch
+constexpr size_t SMALL_BYTES = OFF_CNT + 4 * HPK_NFAM;
 
 }  // namespace
 
@@ -359,10 +364,17 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     (void)hipSetDevice(c->device);
     const double t_begin = now_ms();
 
-    HpkDevPlan plan;
-    char msg[256];
-    rc = hpk_build_plan(prm, &plan, msg);
-    if (rc != HPK_OK) return fail(c, rc, "%s", msg);
+    hpk_params key = *prm;
+    key.flags = 0; key.reserved = 0;
+    for (int i = key.npairs > 0 ? key.npairs : 0; i < HPK_MAX_PAIRS; ++i) { key.pw[i] = 0; key.ww[i] = 0; }
+    const bool plan_hit = c->plan_valid && std::memcmp(&key, &c->plan_key, sizeof(key)) == 0;
+    if (!plan_hit) {
+        char msg[256];
+        c->plan_valid = false;
+        rc = hpk_build_plan(prm, &c->plan_host, msg);
+        if (rc != HPK_OK) return fail(c, rc, "%s", msg);
+    }
+    const HpkDevPlan& plan = c->plan_host;
     const int W = plan.W, mw = plan.mw, D = plan.D;
     const int n = band->n, num = band->num;
     const int TR = HPK_LR - 2 * W - 1, TC = HPK_LC - 2 * W - 1;
@@ -382,8 +394,12 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     (void)hipEventRecord(c->ev[0], c->stream);
     rc = stage_inputs(c, band, &in);
     if (rc != HPK_OK) return rc;
-    HIPCHK(c, c->plan.reserve(sizeof(HpkDevPlan)));
-    HIPCHK(c, hipMemcpyAsync(c->plan.p, &plan, sizeof(plan), hipMemcpyHostToDevice, c->stream));
+    if (!plan_hit) {
+        HIPCHK(c, c->plan.reserve(sizeof(HpkDevPlan)));
+        HIPCHK(c, hipMemcpyAsync(c->plan.p, &c->plan_host, sizeof(HpkDevPlan), hipMemcpyHostToDevice, c->stream));
+        c->plan_key = key;
+        c->plan_valid = true;
+    }
     HIPCHK(c, c->etab.reserve(sizeof(double) * std::max<size_t>((size_t)plan.nsteps * 2 * (D + 1), 1)));
     hpk_launch_etab(c->plan.as<HpkDevPlan>(), plan.nsteps, D, in.IR, num, c->etab.as<double>(), c->stream);
     HIPCHK(c, hipGetLastError());
@@ -394,8 +410,15 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
         HIPCHK(c, c->dW.reserve(dense_elems));
         if (sums) HIPCHK(c, c->dS.reserve(sizeof(double4) * dense_elems));
     }
-    HIPCHK(c, c->small.reserve(SMALL_BYTES));
-    HIPCHK(c, hipMemsetAsync(c->small.p, 0, SMALL_BYTES, c->stream));
+    // one zero-filled block: counters | per-workgroup histograms | per-tile record counts (sized below)
+    const int J_ = (TR + D - mw + TC - 1) / TC;
+    const int ntiles_ = ((n + TR - 1) / TR) * J_;
+    const int grid_ = std::max(8, std::min((c->cus / 8) * 8, ((ntiles_ + 7) / 8) * 8));
+    const size_t off_hp = (SMALL_BYTES + 255) / 256 * 256;
+    const size_t off_tc = off_hp + (sizeof(unsigned) * (size_t)grid_ * (HPK_MAX_STEPS + 1) + 255) / 256 * 256;
+    const size_t zero_bytes = off_tc + sizeof(unsigned) * (size_t)ntiles_;
+    HIPCHK(c, c->small.reserve(zero_bytes));
+    HIPCHK(c, hipMemsetAsync(c->small.p, 0, zero_bytes, c->stream));
     HIPCHK(c, c->gap.reserve((size_t)n));
     if (dense) {   // pixels outside the band are never written by the kernel
         HIPCHK(c, hipMemsetAsync(c->dE.p, 0, sizeof(double2) * dense_elems, c->stream));
@@ -426,18 +449,14 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     sa.chunk = (sa.ntiles + 7) / 8;
     { const char* e = std::getenv("HPK_DBG_STOP"); sa.dbg_stop = e ? std::atoi(e) : 0; }
     sa.grid = std::max(8, std::min((c->cus / 8) * 8, ((sa.chunk + 0) * 8)));
-    HIPCHK(c, c->histpart.reserve(sizeof(unsigned) * (size_t)sa.grid * (HPK_MAX_STEPS + 1)));
-    HIPCHK(c, hipMemsetAsync(c->histpart.p, 0, sizeof(unsigned) * (size_t)sa.grid * (HPK_MAX_STEPS + 1), c->stream));
-    sa.hist_part = c->histpart.as<unsigned>();
+    sa.hist_part = reinterpret_cast<unsigned*>(small + off_hp);
     sa.tilecap = TR * TC;
     sa.rec_stride = (int64_t)sa.ntiles * sa.tilecap;
     HIPCHK(c, c->recE.reserve(sizeof(unsigned) * (size_t)sa.rec_stride));
     HIPCHK(c, c->recS.reserve(sizeof(double2) * (size_t)sa.rec_stride * plan.nslots));
     HIPCHK(c, c->recW.reserve((size_t)sa.rec_stride * plan.nslots));
-    HIPCHK(c, c->tilecnt.reserve(sizeof(unsigned) * (size_t)sa.ntiles));
-    HIPCHK(c, hipMemsetAsync(c->tilecnt.p, 0, sizeof(unsigned) * (size_t)sa.ntiles, c->stream));
     sa.rec_ent = c->recE.as<unsigned>(); sa.rec_S = c->recS.as<double2>(); sa.rec_W = c->recW.as<uint8_t>();
-    sa.tile_cnt = c->tilecnt.as<unsigned>();
+    sa.tile_cnt = reinterpret_cast<unsigned*>(small + off_tc);
     HIPCHK(c, hipMemsetAsync(c->gap.p, 1, (size_t)n, c->stream));
     sa.gap = c->gap.as<uint8_t>();
     (void)hipEventRecord(c->ev[1], c->stream);
@@ -464,12 +483,13 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     (void)hipEventRecord(c->ev[3], c->stream);
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (do_score) {
-            if (cap == 0) cap = std::max<int64_t>(1 << 16, band_px * nsets / 6) + (int64_t)c->cus * 8 * 4 * 256 * 2;
+            // capacity per region; every scoring wave may hold one partly filled 256-record chunk
+            if (cap == 0) cap = (std::max<int64_t>(1 << 16, band_px * nsets / 6) + (int64_t)c->cus * 8 * 4 * 256 * 2) / HPK_NREG;
             cap = (cap + 255) / 256 * 256;
-            HIPCHK(c, c->surv.reserve(sizeof(HpkSurv) * (size_t)cap));
-            HIPCHK(c, c->chunkused.reserve(sizeof(unsigned) * (size_t)(cap / 256 + 1)));
-            HIPCHK(c, hipMemsetAsync(c->chunkused.p, 0, sizeof(unsigned) * (size_t)(cap / 256 + 1), c->stream));
-            HIPCHK(c, c->surv2.reserve(sizeof(HpkSurv) * (size_t)cap));
+            HIPCHK(c, c->surv.reserve(sizeof(HpkSurv) * (size_t)cap * HPK_NREG));
+            HIPCHK(c, c->chunkused.reserve(sizeof(unsigned) * (size_t)(cap / 256 * HPK_NREG + 1)));
+            HIPCHK(c, hipMemsetAsync(c->chunkused.p, 0, sizeof(unsigned) * (size_t)(cap / 256 * HPK_NREG + 1), c->stream));
+            HIPCHK(c, c->surv2.reserve(sizeof(HpkSurv) * (size_t)cap * HPK_NREG));
             HpkScoreArgs sc;
             std::memset(&sc, 0, sizeof(sc));
             sc.raw = in.raw; sc.bal = in.bal; sc.weight = in.weight; sc.plan = sa.plan;
@@ -485,7 +505,8 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
             hpk_launch_score(sc, c->cus, c->stream);
             HIPCHK(c, hipGetLastError());
             (void)hipEventRecord(c->ev[4], c->stream);
-            hpk_launch_tighten(sc.surv, d_nsurv, cap, sc.chunk_used, d_fam_m, d_fam_f, d_thr, prm->sig, 2, c->surv2.as<HpkSurv>(), d_nout,
+            hpk_launch_tighten(sc.surv, d_nsurv, cap, sc.chunk_used, d_fam_m, d_fam_f,
+                               reinterpret_cast<unsigned int*>(small + OFF_CNT), d_thr, prm->sig, (std::getenv("HPK_ROUNDS") ? std::atoi(std::getenv("HPK_ROUNDS")) : 3), c->surv2.as<HpkSurv>(), d_nout,
                                c->cus, c->stream);
             HIPCHK(c, hipGetLastError());
         } else {
@@ -504,7 +525,9 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
             HIPCHK(c, hipMemcpyAsync(box->gap.data(), c->gap.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        const unsigned long long ns = *reinterpret_cast<const unsigned long long*>(hsmall.data() + OFF_NSURV);
+        unsigned long long ns = 0;              // fullest region
+        for (int rg = 0; rg < HPK_NREG; ++rg)
+            ns = std::max(ns, reinterpret_cast<const unsigned long long*>(hsmall.data() + OFF_NSURV)[rg * HPK_REG_STRIDE]);
         if (!do_score || (int64_t)ns <= cap) break;
         if (attempt == 1) return fail(c, HPK_ERR_NOMEM, "survivor buffer overflow");
         cap = (int64_t)ns * 2 + 1024;           // rerun the scoring with room for everything (slots are chunked)
@@ -583,9 +606,15 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     R.nsets = do_score ? nsets : 0;
     std::vector<std::vector<Surv*>> kept(nsets);
     if (do_score) {
-        // families: (set, chunk)
-        std::vector<std::vector<Surv*>> fam((size_t)nsets * (HPK_NB + 1));
-        for (Surv& s : sv) fam[(size_t)s.set * (HPK_NB + 1) + s.chunk].push_back(&s);
+        // families = (set, chunk): one sort by (set, chunk, p), then Benjamini-Hochberg on each run
+        std::vector<Surv*> order(sv.size());
+        for (size_t i = 0; i < sv.size(); ++i) order[i] = &sv[i];
+        std::sort(order.begin(), order.end(), [](const Surv* a, const Surv* b) {
+            if (a->set != b->set) return a->set < b->set;
+            if (a->chunk != b->chunk) return a->chunk < b->chunk;
+            return a->p < b->p; });
+        const double t_h1 = now_ms();
+        std::vector<int> numbins(nsets, 0);
         for (int s = 0; s < nsets; ++s) {
             hpk_set& hs = R.sets[s];
             hs.pair = (plan.mode == HPK_MODE_BHFDR) ? 0 : s / 2;
@@ -596,20 +625,29 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
             hs.emax = emax;
             int numbin = 0;
             if (plan.mode == HPK_MODE_HICCUPS && hs.nvalid > 0) {
-                const double nb = std::ceil(std::log(emax) / std::log(2.0) * 3.0 + 1.0);
+                const double nb = std::ceil(std::log(emax) / std::log(2.0) * 3.0 + 1.0);     // callers.py:30
                 numbin = nb < 0 ? 0 : (nb > HPK_NB ? HPK_NB : (int)nb);
             }
             hs.numbin = numbin;
-            const int last = (plan.mode == HPK_MODE_BHFDR) ? 1 : numbin;
-            for (int ch = 1; ch <= last; ++ch) {
-                std::vector<Surv*>& f = fam[(size_t)s * (HPK_NB + 1) + ch];
-                if (f.empty()) continue;
+            numbins[s] = (plan.mode == HPK_MODE_BHFDR) ? 1 : numbin;
+        }
+        std::vector<Surv*> f;
+        for (size_t i = 0; i < order.size();) {
+            size_t j = i;
+            while (j < order.size() && order[j]->set == order[i]->set && order[j]->chunk == order[i]->chunk) ++j;
+            const int s = order[i]->set, ch = order[i]->chunk;
+            if (s < nsets && ch >= 1 && ch <= numbins[s]) {        // chunks beyond numbin keep p = q = 1 (callers.py:259-260)
+                f.assign(order.begin() + i, order.begin() + j);
                 bh_family(f, h_chist[(size_t)s * (HPK_NB + 1) + ch], prm->sig, plan.mode == HPK_MODE_BHFDR);
                 for (Surv* p : f) if (p->keep) kept[s].push_back(p);
             }
+            i = j;
+        }
+        const double t_h2 = now_ms();
+        for (int s = 0; s < nsets; ++s)
             std::sort(kept[s].begin(), kept[s].end(), [](const Surv* a, const Surv* b) {
                 return a->x != b->x ? a->x < b->x : a->y < b->y; });
-        }
+        if (std::getenv("HPK_HOST_PROF")) std::fprintf(stderr, "[hpk host] n=%zu sort=%.3f bh=%.3f\n", sv.size(), t_h1 - t_d2h1, t_h2 - t_h1);
         size_t total = 0;
         for (int s = 0; s < nsets; ++s) total += kept[s].size();
         box->x.reserve(total); box->y.reserve(total); box->O.reserve(total); box->bal.reserve(total);
@@ -627,6 +665,7 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
         R.E = box->E.data(); R.p = box->p.data(); R.q = box->q.data(); R.other_zero = box->oz.data();
     }
     const double t_end = now_ms();
+    if (std::getenv("HPK_HOST_PROF")) std::fprintf(stderr, "[hpk host] total host_bh=%.3f d2h=%.3f\n", t_end - t_d2h1, t_d2h1 - t_d2h0);
 
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) R.ms_h2d = ms;
@@ -660,6 +699,7 @@ int hpk_bruteforce_sums(hpk_ctx* c, const hpk_band* band, const hpk_params* prm,
     Staged in;
     rc = stage_inputs(c, band, &in);
     if (rc != HPK_OK) return rc;
+    c->plan_valid = false;
     HIPCHK(c, c->plan.reserve(sizeof(HpkDevPlan)));
     HIPCHK(c, hipMemcpyAsync(c->plan.p, &plan, sizeof(plan), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->tmpA.reserve(4 * (size_t)count));

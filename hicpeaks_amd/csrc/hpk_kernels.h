@@ -48,6 +48,8 @@ struct HpkSurv {
     double E, p, bal;
 };
 #define HPK_NFAM (2 * HPK_MAX_PAIRS * (HPK_NB + 1))     // (set, chunk) families
+#define HPK_NREG 64                     // independent survivor regions (one reservation counter each, 256 B apart)
+#define HPK_REG_STRIDE 32               // counters are u64[HPK_NREG * HPK_REG_STRIDE]
 
 struct HpkScoreArgs {
     const float*  raw;
@@ -79,10 +81,10 @@ struct HpkScoreArgs {
     unsigned int* fam_f;                // [HPK_NFAM] of those, p <= sig
     unsigned long long* emax_bits;      // [nsets]
     unsigned long long* nvalid;         // [nsets]
-    unsigned long long* nsurv;          // scalar
-    int64_t cap;                        // survivor capacity (multiple of 256)
+    unsigned long long* nsurv;          // [HPK_NREG * HPK_REG_STRIDE] reserved slots per region
+    int64_t cap;                        // survivor capacity per region (multiple of 256)
     HpkSurv* surv;
-    unsigned* chunk_used;               // [cap / 256] filled slots per 256-record chunk
+    unsigned* chunk_used;               // [HPK_NREG * cap / 256] filled slots per 256-record chunk
 };
 
 struct HpkDenseArgs {
@@ -114,7 +116,7 @@ void hpk_launch_score(const HpkScoreArgs& a, int cus, hipStream_t st);
 // Benjamini-Hochberg cut tightening on the survivor list: thr[f] <- sig * #{p <= thr[f]} / m[f], `rounds` times,
 // then compaction of the records with p <= thr[f] into `out` (count in *nout).
 void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned* chunk_used,
-                        const unsigned int* fam_m,
+                        const unsigned int* fam_m, const unsigned int* fam_f,
                         unsigned int* fam_cnt, double* fam_thr, double sig, int rounds, HpkSurv* out,
                         unsigned long long* nout, int cus, hipStream_t st);
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,

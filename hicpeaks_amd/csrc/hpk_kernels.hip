@@ -756,6 +756,8 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     __shared__ unsigned long long lemax[2 * HPK_MAX_PAIRS];
     __shared__ unsigned int lvalid[2 * HPK_MAX_PAIRS];
     __shared__ int lstepw[HPK_MAX_STEPS];
+    __shared__ int lpair_slot[HPK_MAX_PAIRS], lpair_wi[HPK_MAX_PAIRS];
+    __shared__ int lptoff[HPK_NB_TAB + 2];
     const HpkDevPlan* __restrict__ plan = a.plan;
     const int mode = plan->mode;
     const int npairs = plan->npairs;
@@ -765,6 +767,8 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     if (threadIdx.x < HPK_NB) lbounds[threadIdx.x] = a.bounds[threadIdx.x];
     if (threadIdx.x < 2 * HPK_MAX_PAIRS) { lemax[threadIdx.x] = 0ull; lvalid[threadIdx.x] = 0u; }
     if (threadIdx.x < HPK_MAX_STEPS) lstepw[threadIdx.x] = (threadIdx.x < plan->nsteps) ? plan->steps[threadIdx.x].wi : 0;
+    if (threadIdx.x < HPK_MAX_PAIRS) { lpair_slot[threadIdx.x] = plan->pair_slot[threadIdx.x]; lpair_wi[threadIdx.x] = plan->pair_wi[threadIdx.x]; }
+    if (threadIdx.x < HPK_NB_TAB + 2) lptoff[threadIdx.x] = a.ptab_off[threadIdx.x];
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
@@ -775,6 +779,8 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     unsigned long long wbase = 0ull;
     unsigned wused = HPK_SCH;               // "no chunk yet"
     bool have_chunk = false;
+    const int region = (int)((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) % HPK_NREG);
+    const int64_t rbase = (int64_t)region * a.cap;      // this wave's survivor region
     // Work unit = 4 consecutive 64-record batches of one tile's record region; units are dealt round-robin to all
     // waves of the grid (tiles differ a lot in candidate count), reads are coalesced.
     const int bpt = (a.tilecap + 63) >> 6;                  // batches per tile region
@@ -803,15 +809,15 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
             if (cand) { ir = a.IR[d]; b2c = a.b2[c]; b1r = a.b1[r]; }
 
             for (int pj = 0; pj < npairs; ++pj) {
-                const int slot = plan->pair_slot[pj];
-                const int wi0 = plan->pair_wi[pj];
+                const int slot = lpair_slot[pj];
+                const int wi0 = lpair_wi[pj];
                 bool ok = cand && d >= wi0;                                   // callers.py:244
                 double eK = 0.0, eY = 0.0;
                 if (ok) {
-                    const int stp = (int)a.rec_W[slot * a.rec_stride + ri];
-                    ok = (stp != 0) && (lstepw[stp - 1] <= frozen);           // resolved at an executed step
+                    const int stp = (int)a.rec_W[slot * a.rec_stride + ri];   // step and sums travel together
+                    const double2 s2 = a.rec_S[slot * a.rec_stride + ri];
+                    ok = (stp != 0) && (lstepw[stp > 0 ? stp - 1 : 0] <= frozen);   // resolved at an executed step
                     if (ok) {
-                        const double2 s2 = a.rec_S[slot * a.rec_stride + ri];
                         double EK, EY;
                         local_expected(plan, a.etab, a.IR, stp - 1, r, c, d, a.n, a.num, a.mw, a.D, W, EK, EY);
                         // callers.py:244-249: E = ((IR[d] * (bS / bE)) * B1[x]) * B2[y] where bE != 0
@@ -842,7 +848,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                             if (lo < HPK_NB && !(lo > 0 && E == lbounds[lo - 1])) {
                                 chunk = lo + 1;
                                 if (chunk <= HPK_NB_TAB) {
-                                    const int base = a.ptab_off[chunk], len = a.ptab_off[chunk + 1] - base;
+                                    const int base = lptoff[chunk], len = lptoff[chunk + 1] - base;
                                     const long long kO = (long long)O;
                                     p = (kO < len) ? a.ptab[base + (int)kO] : 0.0;
                                 } else {
@@ -868,10 +874,10 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                     if (sm != 0ull) {
                         const unsigned scnt = (unsigned)__popcll(sm);
                         if (wused + scnt > HPK_SCH) {            // wave-uniform: retire the chunk, take a new one
-                            if (have_chunk && lane == 0 && (int64_t)wbase < a.cap) a.chunk_used[wbase / HPK_SCH] = wused;
+                            if (have_chunk && lane == 0 && (int64_t)wbase < a.cap) a.chunk_used[(rbase + (int64_t)wbase) / HPK_SCH] = wused;
                             have_chunk = true;
                             unsigned long long nb = 0ull;
-                            if (lane == 0) nb = atomicAdd(a.nsurv, (unsigned long long)HPK_SCH);
+                            if (lane == 0) nb = atomicAdd(&a.nsurv[region * HPK_REG_STRIDE], (unsigned long long)HPK_SCH);
                             wbase = __shfl(nb, 0);
                             wused = 0u;
                         }
@@ -887,7 +893,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                                 rec.x = r; rec.y = c; rec.O = rawpix; rec.set = (uint8_t)set; rec.chunk = (uint8_t)chunk;
                                 rec.flag = (fl == 0 && eY == 0.0) ? 1 : 0;           // callers.py:330
                                 rec.pad = 0; rec.E = E; rec.p = p; rec.bal = b;
-                                a.surv[idx] = rec;
+                                a.surv[rbase + (int64_t)idx] = rec;
                             }
                         }
                     }
@@ -895,7 +901,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
             }
         }
     }
-    if (have_chunk && lane == 0 && (int64_t)wbase < a.cap) a.chunk_used[wbase / HPK_SCH] = wused;
+    if (have_chunk && lane == 0 && (int64_t)wbase < a.cap) a.chunk_used[(rbase + (int64_t)wbase) / HPK_SCH] = wused;
     __syncthreads();
     for (int i = threadIdx.x; i < nsets * (HPK_NB + 1); i += blockDim.x) {
         const unsigned v = (&lm[0][0])[i], f = (&lf[0][0])[i];
@@ -927,11 +933,16 @@ __global__ void __launch_bounds__(256) hpk_thr_count(const HpkSurv* __restrict__
     __shared__ unsigned int lc[HPK_NFAM];
     for (int i = threadIdx.x; i < HPK_NFAM; i += blockDim.x) lc[i] = 0u;
     __syncthreads();
-    int64_t n = (int64_t)*nsurv; if (n > cap) n = cap;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        if ((unsigned)(i & 255) >= chunk_used[i >> 8]) continue;
-        const int f = (int)surv[i].set * (HPK_NB + 1) + (int)surv[i].chunk;
-        if (surv[i].p <= thr[f]) atomicAdd(&lc[f], 1u);
+    {
+        const int reg = blockIdx.y;             // one grid row per survivor region
+        int64_t n = (int64_t)nsurv[reg * HPK_REG_STRIDE]; if (n > cap) n = cap;
+        const int64_t rb = (int64_t)reg * cap;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            if ((unsigned)(i & 255) >= chunk_used[(rb + i) >> 8]) continue;
+            const HpkSurv& rec = surv[rb + i];
+            const int f = (int)rec.set * (HPK_NB + 1) + (int)rec.chunk;
+            if (rec.p <= thr[f]) atomicAdd(&lc[f], 1u);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < HPK_NFAM; i += blockDim.x) if (lc[i]) atomicAdd(&cnt[i], lc[i]);
@@ -948,16 +959,19 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkSurv* __restrict
                                                        int64_t cap, const unsigned* __restrict__ chunk_used,
                                                        const double* __restrict__ thr, HpkSurv* __restrict__ out,
                                                        unsigned long long* __restrict__ nout) {
-    int64_t n = (int64_t)*nsurv; if (n > cap) n = cap;
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    {
+    const int reg = blockIdx.y;
+    int64_t n = (int64_t)nsurv[reg * HPK_REG_STRIDE]; if (n > cap) n = cap;
+    const int64_t rb = (int64_t)reg * cap;
     for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
         const int64_t i = i0 + threadIdx.x;
         bool keep = false;
         HpkSurv rec;
         if (i < n) {
-            if ((unsigned)(i & 255) < chunk_used[i >> 8]) {
-                rec = surv[i];
+            if ((unsigned)(i & 255) < chunk_used[(rb + i) >> 8]) {
+                rec = surv[rb + i];
                 keep = rec.p <= thr[(int)rec.set * (HPK_NB + 1) + (int)rec.chunk];
             }
         }
@@ -967,6 +981,7 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkSurv* __restrict
         if (lane == 0) basei = atomicAdd(nout, (unsigned long long)__popcll(km));
         basei = __shfl(basei, 0);
         if (keep) out[basei + (unsigned long long)__popcll(km & ((1ull << lane) - 1ull))] = rec;
+    }
     }
 }
 
@@ -1087,17 +1102,16 @@ void hpk_launch_score(const HpkScoreArgs& a, int cus, hipStream_t st) {
 }
 
 void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned* chunk_used,
-                        const unsigned int* fam_m,
+                        const unsigned int* fam_m, const unsigned int* fam_f,
                         unsigned int* fam_cnt, double* fam_thr, double sig, int rounds, HpkSurv* out,
                         unsigned long long* nout, int cus, hipStream_t st) {
     const int fb = (HPK_NFAM + 255) / 256;
-    // fam_cnt enters holding F(sig) (written by hpk_score)
-    hipLaunchKernelGGL(hpk_thr_init, dim3(fb), dim3(256), 0, st, fam_m, fam_cnt, fam_thr, fam_cnt, sig);
+    hipLaunchKernelGGL(hpk_thr_init, dim3(fb), dim3(256), 0, st, fam_m, fam_f, fam_thr, fam_cnt, sig);
     for (int r = 0; r < rounds; ++r) {
-        hipLaunchKernelGGL(hpk_thr_count, dim3(cus * 2), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_thr, fam_cnt);
+        hipLaunchKernelGGL(hpk_thr_count, dim3(8, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_thr, fam_cnt);
         hipLaunchKernelGGL(hpk_thr_update, dim3(fb), dim3(256), 0, st, fam_m, fam_thr, fam_cnt, sig);
     }
-    hipLaunchKernelGGL(hpk_thr_compact, dim3(cus * 2), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_thr, out, nout);
+    hipLaunchKernelGGL(hpk_thr_compact, dim3(8, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_thr, out, nout);
 }
 
 void hpk_launch_etab(const HpkDevPlan* plan, int nsteps, int D, const double* IR, int num, double* etab, hipStream_t st) {
