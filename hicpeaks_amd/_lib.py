@@ -263,25 +263,31 @@ class Context(object):
         bd.on_device = 1 if on_device else 0
         return bd
 
-    def _host_band(self, raw, IR, bias1, bias2, balanced=None, weight=None):
+    def _host_band(self, raw, IR, bias1, bias2, balanced=None, weight=None, num_hint=None):
         raw = np.ascontiguousarray(raw, dtype=np.float32)
         n, ld = raw.shape
         keep = [raw]
-        IR = np.ascontiguousarray(IR, dtype=np.float64)
-        b1 = np.ascontiguousarray(bias1, dtype=np.float64)
-        b2 = b1 if bias2 is bias1 else np.ascontiguousarray(bias2, dtype=np.float64)
-        keep += [IR, b1, b2]
+        derive = IR is None         # IR / biases derived on the device from the weights
+        if derive:
+            num = num_hint if num_hint is not None else ld
+            irp = b1p = b2p = None
+        else:
+            IR = np.ascontiguousarray(IR, dtype=np.float64)
+            b1 = np.ascontiguousarray(bias1, dtype=np.float64)
+            b2 = b1 if bias2 is bias1 else np.ascontiguousarray(bias2, dtype=np.float64)
+            keep += [IR, b1, b2]
+            num, irp, b1p, b2p = IR.size, IR.ctypes.data, b1.ctypes.data, b2.ctypes.data
         balp = wp = None
         if balanced is not None:
             balanced = np.ascontiguousarray(balanced, dtype=np.float64)
             assert balanced.shape == raw.shape
             keep.append(balanced)
             balp = balanced.ctypes.data
-        else:
+        if weight is not None:
             weight = np.ascontiguousarray(weight, dtype=np.float64)
             keep.append(weight)
             wp = weight.ctypes.data
-        bd = self._band(n, IR.size, ld, raw.ctypes.data, balp, wp, IR.ctypes.data, b1.ctypes.data, b2.ctypes.data, False)
+        bd = self._band(n, num, ld, raw.ctypes.data, balp, wp, irp, b1p, b2p, False)
         return bd, keep
 
     def score(self, band, params, n):
@@ -293,8 +299,10 @@ class Context(object):
         finally:
             self.lib.hpk_result_free(res)
 
-    def score_host(self, raw, IR, bias1, bias2, params, balanced=None, weight=None):
-        bd, keep = self._host_band(raw, IR, bias1, bias2, balanced, weight)
+    def score_host(self, raw, IR, bias1, bias2, params, balanced=None, weight=None, num=None):
+        """IR = bias1 = bias2 = None: derived on the device from `weight` (then `num` = stored diagonals, default
+        raw.shape[1])."""
+        bd, keep = self._host_band(raw, IR, bias1, bias2, balanced, weight, num_hint=num)
         return self.score(bd, params, raw.shape[0])
 
     def score_device(self, n, num, ld, raw_ptr, IR_ptr, b1_ptr, b2_ptr, params, balanced_ptr=None, weight_ptr=None):

@@ -130,7 +130,9 @@ def hiccups_band(raw, IR, B1, B2, chrom='', balanced=None, weight=None, pw=[2], 
                  sumq=0.01, double_fold=1.75, single_fold=2, maxapart=2000000, res=10000, use_raw=False,
                  min_marginal_peaks=3, onlyanchor=True, min_local_reads=25, device=0, detail=None, ctx=None):
     """`hiccups` on band inputs: raw [n, num] counts, IR [num], and either the balanced f64 band or the
-    balancing weights (balanced is then formed on chip).  Returns the reference's final_table."""
+    balancing weights (balanced is then formed on chip).  With IR = B1 = B2 = None and `weight` given, the 1-D
+    expected and the biases are derived on the device too (scripts/pyHICCUPS:149-166).  Returns the reference's
+    final_table."""
     ctx = ctx or _lib.default_context(device)
     flags = 0
     if detail is not None and detail.get('dense'):

@@ -127,8 +127,7 @@ def _score_chrom(args_dict, mode, key, device):
     if mode == 'hiccups':
         num = a['maxapart'] // res + a['maxww'] + 1
         raw, w = src.fetch(key, num, a['clr_weight_name'])
-        IR, biases = band.expected_and_biases(raw, w, min(a['ww']))
-        table = callers.hiccups_band(raw, IR, biases, biases, chrom=key.lstrip('chr'), weight=w, pw=a['pw'], ww=a['ww'],
+        table = callers.hiccups_band(raw, None, None, None, chrom=key.lstrip('chr'), weight=w, pw=a['pw'], ww=a['ww'],
                                      maxww=a['maxww'], sig=a['siglevel'], sumq=a['sumq'], double_fold=a['double_fold'],
                                      single_fold=a['single_fold'], maxapart=a['maxapart'], res=res,
                                      use_raw=a['use_raw'], min_marginal_peaks=a['min_marginal_peaks'],
@@ -136,8 +135,7 @@ def _score_chrom(args_dict, mode, key, device):
     else:
         num = a['maxapart'] // res + a['maxww'] + 1
         raw, w = src.fetch(key, num, a['clr_weight_name'])
-        IR, biases = band.expected_and_biases(raw, w, a['ww'])
-        table = callers.bhfdr_band(raw, IR, biases, biases, chrom=key.lstrip('chr'), weight=w, pw=a['pw'], ww=a['ww'],
+        table = callers.bhfdr_band(raw, None, None, None, chrom=key.lstrip('chr'), weight=w, pw=a['pw'], ww=a['ww'],
                                    sig=a['siglevel'], maxww=a['maxww'], maxapart=a['maxapart'], res=res, ctx=ctx)
     return key.lstrip('chr'), table
 

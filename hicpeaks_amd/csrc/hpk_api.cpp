@@ -60,7 +60,7 @@ struct hpk_ctx {
     DevBuf d_bounds, d_off, d_sfe, d_ptab;
     // workspaces (grow only)
     DevBuf raw, bal, weight, IR, b1, b2, plan, etab, recE, recS, recW, tilecnt, dE, dW, dS, small, gap, histpart;
-    DevBuf surv, surv2, chunkused;
+    DevBuf surv, surv2, chunkused, psum, pnan;
     // the device copy of the widening plan is reused while the parameters do not change
     hpk_params plan_key;
     bool plan_valid = false;
@@ -208,7 +208,7 @@ void hpk_destroy(hpk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf* all[] = {&c->d_bounds, &c->d_off, &c->d_sfe, &c->d_ptab, &c->raw, &c->bal, &c->weight, &c->IR, &c->b1, &c->b2,
-                     &c->plan, &c->etab, &c->recE, &c->recS, &c->recW, &c->tilecnt, &c->dE, &c->dW, &c->dS, &c->histpart, &c->small, &c->gap, &c->surv, &c->surv2, &c->chunkused, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD};
+                     &c->plan, &c->etab, &c->recE, &c->recS, &c->recW, &c->tilecnt, &c->dE, &c->dW, &c->dS, &c->histpart, &c->small, &c->gap, &c->surv, &c->surv2, &c->chunkused, &c->psum, &c->pnan, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD};
     for (DevBuf* b : all) b->release();
     for (int i = 0; i < c->nev; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -290,45 +290,63 @@ struct Staged {
     std::vector<double> hIR;
 };
 
-int stage_inputs(hpk_ctx* c, const hpk_band* band, Staged* s) {
+int stage_inputs(hpk_ctx* c, const hpk_band* band, int mw, Staged* s) {
     const size_t n = (size_t)band->n, num = (size_t)band->num, ld = (size_t)band->ld;
-    s->hIR.resize(num);
+    const bool derive = !band->IR;          // IR / biases from raw + weight on the device (scripts/pyHICCUPS:149-166)
     if (band->on_device) {
         s->raw = band->raw; s->bal = band->balanced; s->weight = band->weight; s->IR = band->IR; s->b1 = band->bias1; s->b2 = band->bias2;
-        return HPK_OK;
-    }
-    std::memcpy(s->hIR.data(), band->IR, sizeof(double) * num);
-    HIPCHK(c, c->raw.reserve(sizeof(float) * n * ld));
-    HIPCHK(c, hipMemcpyAsync(c->raw.p, band->raw, sizeof(float) * n * ld, hipMemcpyHostToDevice, c->stream));
-    s->raw = c->raw.as<float>();
-    if (band->balanced) {
-        HIPCHK(c, c->bal.reserve(sizeof(double) * n * ld));
-        HIPCHK(c, hipMemcpyAsync(c->bal.p, band->balanced, sizeof(double) * n * ld, hipMemcpyHostToDevice, c->stream));
-        s->bal = c->bal.as<double>();
     } else {
-        HIPCHK(c, c->weight.reserve(sizeof(double) * n));
-        HIPCHK(c, hipMemcpyAsync(c->weight.p, band->weight, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-        s->weight = c->weight.as<double>();
+        HIPCHK(c, c->raw.reserve(sizeof(float) * n * ld));
+        HIPCHK(c, hipMemcpyAsync(c->raw.p, band->raw, sizeof(float) * n * ld, hipMemcpyHostToDevice, c->stream));
+        s->raw = c->raw.as<float>();
+        if (band->balanced) {
+            HIPCHK(c, c->bal.reserve(sizeof(double) * n * ld));
+            HIPCHK(c, hipMemcpyAsync(c->bal.p, band->balanced, sizeof(double) * n * ld, hipMemcpyHostToDevice, c->stream));
+            s->bal = c->bal.as<double>();
+        }
+        if (band->weight) {
+            HIPCHK(c, c->weight.reserve(sizeof(double) * n));
+            HIPCHK(c, hipMemcpyAsync(c->weight.p, band->weight, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+            s->weight = c->weight.as<double>();
+        }
+        if (!derive) {
+            HIPCHK(c, c->IR.reserve(sizeof(double) * num));
+            HIPCHK(c, hipMemcpyAsync(c->IR.p, band->IR, sizeof(double) * num, hipMemcpyHostToDevice, c->stream));
+            s->IR = c->IR.as<double>();
+            HIPCHK(c, c->b1.reserve(sizeof(double) * n));
+            HIPCHK(c, hipMemcpyAsync(c->b1.p, band->bias1, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+            s->b1 = c->b1.as<double>();
+            if (band->bias2 == band->bias1) s->b2 = s->b1;
+            else {
+                HIPCHK(c, c->b2.reserve(sizeof(double) * n));
+                HIPCHK(c, hipMemcpyAsync(c->b2.p, band->bias2, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+                s->b2 = c->b2.as<double>();
+            }
+        }
     }
-    HIPCHK(c, c->IR.reserve(sizeof(double) * num));
-    HIPCHK(c, hipMemcpyAsync(c->IR.p, band->IR, sizeof(double) * num, hipMemcpyHostToDevice, c->stream));
-    s->IR = c->IR.as<double>();
-    HIPCHK(c, c->b1.reserve(sizeof(double) * n));
-    HIPCHK(c, hipMemcpyAsync(c->b1.p, band->bias1, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-    s->b1 = c->b1.as<double>();
-    if (band->bias2 == band->bias1) s->b2 = s->b1;
-    else {
-        HIPCHK(c, c->b2.reserve(sizeof(double) * n));
-        HIPCHK(c, hipMemcpyAsync(c->b2.p, band->bias2, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-        s->b2 = c->b2.as<double>();
+    if (derive) {
+        const size_t nparts = (n + 127) / 128;
+        HIPCHK(c, c->IR.reserve(sizeof(double) * num));
+        HIPCHK(c, c->b1.reserve(sizeof(double) * n));
+        HIPCHK(c, c->psum.reserve(sizeof(double) * nparts * num));
+        HIPCHK(c, c->pnan.reserve(sizeof(unsigned) * nparts * num));
+        hpk_launch_prep(s->raw, s->weight, (int)n, (int)num, (int64_t)ld, mw, c->psum.as<double>(), c->pnan.as<unsigned>(),
+                        c->IR.as<double>(), c->b1.as<double>(), c->stream);
+        HIPCHK(c, hipGetLastError());
+        s->IR = c->IR.as<double>();
+        s->b1 = c->b1.as<double>();
+        s->b2 = s->b1;
     }
     return HPK_OK;
 }
 
 int check_band(hpk_ctx* c, const hpk_band* band) {
     if (!band || band->n <= 0 || band->num <= 0 || band->ld < band->num) return fail(c, HPK_ERR_INVALID, "bad band shape");
-    if (!band->raw || !band->IR || !band->bias1 || !band->bias2) return fail(c, HPK_ERR_INVALID, "raw / IR / bias pointers required");
+    if (!band->raw) return fail(c, HPK_ERR_INVALID, "raw pointer required");
     if (!band->balanced && !band->weight) return fail(c, HPK_ERR_INVALID, "either balanced or weight must be given");
+    const bool derive = !band->IR && !band->bias1 && !band->bias2;
+    if (derive && !band->weight) return fail(c, HPK_ERR_INVALID, "IR / biases can only be derived on the device from `weight`");
+    if (!derive && (!band->IR || !band->bias1 || !band->bias2)) return fail(c, HPK_ERR_INVALID, "IR, bias1 and bias2 go together");
     return HPK_OK;
 }
 
@@ -392,7 +410,7 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     // ---- inputs
     Staged in;
     (void)hipEventRecord(c->ev[0], c->stream);
-    rc = stage_inputs(c, band, &in);
+    rc = stage_inputs(c, band, plan.mw, &in);
     if (rc != HPK_OK) return rc;
     if (!plan_hit) {
         HIPCHK(c, c->plan.reserve(sizeof(HpkDevPlan)));
@@ -697,7 +715,7 @@ int hpk_bruteforce_sums(hpk_ctx* c, const hpk_band* band, const hpk_params* prm,
     if (rc != HPK_OK) return fail(c, rc, "%s", msg);
     if (step < 0 || step >= plan.nsteps) return fail(c, HPK_ERR_INVALID, "step out of range");
     Staged in;
-    rc = stage_inputs(c, band, &in);
+    rc = stage_inputs(c, band, plan.mw, &in);
     if (rc != HPK_OK) return rc;
     c->plan_valid = false;
     HIPCHK(c, c->plan.reserve(sizeof(HpkDevPlan)));

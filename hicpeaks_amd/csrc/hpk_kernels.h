@@ -109,6 +109,8 @@ void hpk_launch_stencil(const HpkStencilArgs& a, bool balf64, bool simple, hipSt
 void hpk_launch_dense(const HpkDenseArgs& a, hipStream_t st);
 void hpk_launch_freeze(const HpkDevPlan* plan, unsigned long long* hist, const unsigned* hist_part, int nparts,
                        int32_t* frozen, int32_t* executed, int32_t* err, hipStream_t st);
+void hpk_launch_prep(const float* raw, const double* weight, int n, int num, int64_t ld, int mw, double* psum, unsigned* pnan,
+                     double* IR, double* bias, hipStream_t st);
 void hpk_launch_etab(const HpkDevPlan* plan, int nsteps, int D, const double* IR, int num, double* etab, hipStream_t st);
 void hpk_launch_gap(const float* raw, const double* bal, const double* weight, int32_t n, int32_t num,
                     int64_t ld, int32_t mw, uint8_t* gap, hipStream_t st);

@@ -577,6 +577,46 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
     }
 }
 
+// ------------------------------------------------------------------ 1-D expected IR[d] and biases (scripts/pyHICCUPS:149-166)
+// IR[d] = mean over diagonal d of the balanced values, where *stored* (non-zero) pixels in masked bins are NaN and
+// are left out of both sum and count, while unstored pixels count as 0 even in masked bins.  Deterministic
+// two-level reduction: workgroup b sums rows [b * 128, b * 128 + 128) per diagonal, hpk_ir_final adds the partials
+// in workgroup order.
+__global__ void __launch_bounds__(256) hpk_ir_partial(const float* __restrict__ raw, const double* __restrict__ weight, int n,
+                                                      int num, int64_t ld, int mw, double* __restrict__ psum,
+                                                      unsigned* __restrict__ pnan) {
+    const int rbeg = blockIdx.x * 128, rend = (rbeg + 128 < n) ? rbeg + 128 : n;
+    for (int k = mw + threadIdx.x; k < num; k += blockDim.x) {
+        double s = 0.0;
+        unsigned nn = 0u;
+        for (int r = rbeg; r < rend && r + k < n; ++r) {
+            const float cnt = raw[(int64_t)r * ld + k];
+            if (cnt != 0.f) {
+                const double b = ((double)cnt * weight[r]) * weight[r + k];
+                if (b == b) s += b; else ++nn;
+            }
+        }
+        psum[(int64_t)blockIdx.x * num + k] = s;
+        pnan[(int64_t)blockIdx.x * num + k] = nn;
+    }
+}
+__global__ void __launch_bounds__(256) hpk_ir_final(const double* __restrict__ psum, const unsigned* __restrict__ pnan, int nparts,
+                                                    int n, int num, int mw, double* __restrict__ IR) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= num) return;
+    double s = 0.0;
+    unsigned long long nn = 0ull;
+    if (k >= mw) for (int p = 0; p < nparts; ++p) { s += psum[(int64_t)p * num + k]; nn += pnan[(int64_t)p * num + k]; }
+    const long long denom = (long long)(n - k) - (long long)nn;
+    IR[k] = (k >= mw && n - k > 0) ? s / (double)denom : 0.0;       // 0/0 -> NaN like numpy's mean of an empty slice
+}
+__global__ void __launch_bounds__(256) hpk_biases(const double* __restrict__ weight, int n, double* __restrict__ bias) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double w = weight[i];
+    bias[i] = (w == 0.0 || w != w) ? 0.0 : 1.0 / w;                 // scripts/pyHICCUPS:163-166
+}
+
 // ------------------------------------------------------------------ local-expected tables (callers.py:66-72 + 175-198)
 // bE of step s / filter fl at an interior pixel depends on the diagonal only: sum over the window's diagonal offsets
 // of (cells at that offset, with multiplicity) * IR.  One thread per table entry, offsets added in ascending order.
@@ -1112,6 +1152,14 @@ void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, in
         hipLaunchKernelGGL(hpk_thr_update, dim3(fb), dim3(256), 0, st, fam_m, fam_thr, fam_cnt, sig);
     }
     hipLaunchKernelGGL(hpk_thr_compact, dim3(8, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_thr, out, nout);
+}
+
+void hpk_launch_prep(const float* raw, const double* weight, int n, int num, int64_t ld, int mw, double* psum, unsigned* pnan,
+                     double* IR, double* bias, hipStream_t st) {
+    const int nparts = (n + 127) / 128;
+    hipLaunchKernelGGL(hpk_ir_partial, dim3(nparts), dim3(256), 0, st, raw, weight, n, num, ld, mw, psum, pnan);
+    hipLaunchKernelGGL(hpk_ir_final, dim3((num + 255) / 256), dim3(256), 0, st, psum, pnan, nparts, n, num, mw, IR);
+    hipLaunchKernelGGL(hpk_biases, dim3((n + 255) / 256), dim3(256), 0, st, weight, n, bias);
 }
 
 void hpk_launch_etab(const HpkDevPlan* plan, int nsteps, int D, const double* IR, int num, double* etab, hipStream_t st) {

@@ -88,6 +88,9 @@ typedef struct {
     const double* IR;          /* [num] 1-D expected per diagonal, 0 below min(ww) (scripts/pyHICCUPS:150-156) */
     const double* bias1;       /* [n] B1 (callers.py:249) */
     const double* bias2;       /* [n] B2 */
+                               /* IR = bias1 = bias2 = NULL (needs `weight`): the library derives them on the device the
+                                  way scripts/pyHICCUPS:149-166 does - IR[d] = mean of the balanced diagonal with stored
+                                  pixels of masked bins left out, biases = 1 / weight (0 where the weight is 0 / NaN) */
     int32_t on_device;         /* non-zero: all pointers above are device pointers on the ctx's device */
     int32_t reserved;
 } hpk_band;

@@ -232,3 +232,26 @@ def test_full_size_chr1_properties(ctx):
     for s in R.sets:
         assert np.all(w[s['x'], s['y'] - s['x']] != 0)
         assert np.all(s['p'] <= s['q'] + 1e-18) and np.all(s['q'] <= 0.05)
+
+
+@pytest.mark.parametrize('name', ['hiccups_union_shallow', 'hiccups_p2w5', 'bhfdr_shallow'])
+def test_device_side_expected_and_biases(name, ctx):
+    """IR / biases derived on the device from the weights (rows A1 / F4) give the reference's final table."""
+    g = load_golden(name)
+    p = g.params
+    num = g.meta['num']
+    raw = g['raw'][:, :num].astype(np.float32)
+    if g.mode == 'hiccups':
+        final = callers.hiccups_band(raw, None, None, None, chrom='T', weight=g['weight'], pw=p['pw'], ww=p['ww'],
+                                     maxww=p['maxww'], sig=p['sig'], sumq=p['sumq'], double_fold=p['double_fold'],
+                                     single_fold=p['single_fold'], maxapart=p['maxapart'], res=p['res'],
+                                     use_raw=p['use_raw'], min_marginal_peaks=p['min_marginal_peaks'],
+                                     onlyanchor=p['onlyanchor'], min_local_reads=p['min_local_reads'], ctx=ctx)
+    else:
+        final = callers.bhfdr_band(raw, None, None, None, chrom='T', weight=g['weight'], pw=p['pw'], ww=p['ww'],
+                                   sig=p['sig'], maxww=p['maxww'], maxapart=p['maxapart'], res=p['res'],
+                                   min_marginal_peaks=p['min_marginal_peaks'], onlyanchor=p['onlyanchor'], ctx=ctx)
+    k, v = _table_arrays(final)
+    np.testing.assert_array_equal(k, g['final_keys'])
+    if k.size:
+        np.testing.assert_allclose(v, g['final_vals'], rtol=1e-9, atol=1e-9)
