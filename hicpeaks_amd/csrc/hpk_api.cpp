@@ -60,7 +60,7 @@ struct hpk_ctx {
     DevBuf d_bounds, d_off, d_sfe, d_ptab;
     // workspaces (grow only)
     DevBuf raw, bal, weight, IR, b1, b2, plan, etab, recE, recS, recW, tilecnt, dE, dW, dS, small, gap, histpart;
-    DevBuf surv, surv2, chunkused, psum, pnan;
+    DevBuf surv, surv2, chunkused, psum, pnan, eedge;
     // the device copy of the widening plan is reused while the parameters do not change
     hpk_params plan_key;
     bool plan_valid = false;
@@ -208,7 +208,7 @@ void hpk_destroy(hpk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf* all[] = {&c->d_bounds, &c->d_off, &c->d_sfe, &c->d_ptab, &c->raw, &c->bal, &c->weight, &c->IR, &c->b1, &c->b2,
-                     &c->plan, &c->etab, &c->recE, &c->recS, &c->recW, &c->tilecnt, &c->dE, &c->dW, &c->dS, &c->histpart, &c->small, &c->gap, &c->surv, &c->surv2, &c->chunkused, &c->psum, &c->pnan, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD};
+                     &c->plan, &c->etab, &c->recE, &c->recS, &c->recW, &c->tilecnt, &c->dE, &c->dW, &c->dS, &c->histpart, &c->small, &c->gap, &c->surv, &c->surv2, &c->chunkused, &c->psum, &c->pnan, &c->eedge, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD};
     for (DevBuf* b : all) b->release();
     for (int i = 0; i < c->nev; ++i) (void)hipEventDestroy(c->ev[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -419,7 +419,9 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
         c->plan_valid = true;
     }
     HIPCHK(c, c->etab.reserve(sizeof(double) * std::max<size_t>((size_t)plan.nsteps * 2 * (D + 1), 1)));
-    hpk_launch_etab(c->plan.as<HpkDevPlan>(), plan.nsteps, D, in.IR, num, c->etab.as<double>(), c->stream);
+    HIPCHK(c, c->eedge.reserve(sizeof(double) * std::max<size_t>((size_t)2 * W * plan.nsteps * 2 * (D + 1), 1)));
+    hpk_launch_etab(c->plan.as<HpkDevPlan>(), plan.nsteps, D, W, in.IR, n, num, c->etab.as<double>(), c->eedge.as<double>(),
+                    c->stream);
     HIPCHK(c, hipGetLastError());
     const int64_t ldo = ((int64_t)(D + 1) + 31) / 32 * 32;
     const size_t dense_elems = (size_t)plan.nslots * (size_t)n * (size_t)ldo;
@@ -511,7 +513,7 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
             HpkScoreArgs sc;
             std::memset(&sc, 0, sizeof(sc));
             sc.raw = in.raw; sc.bal = in.bal; sc.weight = in.weight; sc.plan = sa.plan;
-            sc.etab = c->etab.as<double>(); sc.IR = in.IR; sc.b1 = in.b1; sc.b2 = in.b2;
+            sc.etab = c->etab.as<double>(); sc.eedge = c->eedge.as<double>(); sc.IR = in.IR; sc.b1 = in.b1; sc.b2 = in.b2;
             sc.frozen = d_frozen; sc.bounds = c->d_bounds.as<double>(); sc.ptab = c->d_ptab.as<double>();
             sc.ptab_off = c->d_off.as<int32_t>(); sc.sfe = c->d_sfe.as<double>(); sc.sig = prm->sig;
             sc.n = n; sc.num = num; sc.ld = band->ld; sc.ldo = ldo; sc.mw = mw; sc.D = D;
@@ -519,6 +521,7 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
             sc.tilecap = sa.tilecap; sc.rec_stride = sa.rec_stride; sc.ntiles = sa.ntiles;
             sc.TR = TR; sc.TC = TC; sc.J = sa.J; sc.W = W;
             sc.fam_m = d_fam_m; sc.fam_f = d_fam_f; sc.emax_bits = d_emax; sc.nvalid = d_nvalid; sc.nsurv = d_nsurv;
+            { const char* e = std::getenv("HPK_DBG_SCORE"); sc.dbg = e ? std::atoi(e) : 0; }
             sc.cap = cap; sc.surv = c->surv.as<HpkSurv>(); sc.chunk_used = c->chunkused.as<unsigned>();
             hpk_launch_score(sc, c->cus, c->stream);
             HIPCHK(c, hipGetLastError());
@@ -599,7 +602,7 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
         HpkDenseArgs da;
         da.rec_ent = sa.rec_ent; da.rec_S = sa.rec_S; da.rec_W = sa.rec_W; da.tile_cnt = sa.tile_cnt;
         da.tilecap = sa.tilecap; da.rec_stride = sa.rec_stride; da.ntiles = sa.ntiles; da.TR = TR; da.TC = TC; da.J = sa.J;
-        da.plan = sa.plan; da.etab = c->etab.as<double>();
+        da.plan = sa.plan; da.etab = c->etab.as<double>(); da.eedge = c->eedge.as<double>();
         da.IR = in.IR; da.b1 = in.b1; da.b2 = in.b2; da.n = n; da.num = num; da.ldo = ldo; da.mw = mw; da.D = D;
         da.dE = c->dE.as<double2>(); da.dW = c->dW.as<uint8_t>(); da.dS = sums ? c->dS.as<double4>() : nullptr;
         hpk_launch_dense(da, c->stream);

@@ -64,6 +64,7 @@ struct HpkScoreArgs {
     int32_t ntiles, TR, TC, J, W;       // tile geometry
     const HpkDevPlan* plan;
     const double* etab;                 // [nsteps][2][D + 1]
+    const double* eedge;                // [2][W][nsteps][2][D + 1] windows clipped by the first rows / last columns
     const double* IR;
     const double* b1;
     const double* b2;
@@ -85,12 +86,14 @@ struct HpkScoreArgs {
     int64_t cap;                        // survivor capacity per region (multiple of 256)
     HpkSurv* surv;
     unsigned* chunk_used;               // [HPK_NREG * cap / 256] filled slots per 256-record chunk
+    int32_t dbg;                        // profiling ablation (HPK_DBG_SCORE): 1 no Poisson table read, 2 no expected table,
+                                        // 3 no survivor stores, 4 no counters
 };
 
 struct HpkDenseArgs {
     const unsigned* rec_ent; const double2* rec_S; const uint8_t* rec_W; const unsigned* tile_cnt;
     int32_t tilecap; int64_t rec_stride; int32_t ntiles, TR, TC, J;
-    const HpkDevPlan* plan; const double* etab;
+    const HpkDevPlan* plan; const double* etab; const double* eedge;
     const double* IR; const double* b1; const double* b2;
     int32_t n, num; int64_t ldo; int32_t mw, D;
     double2* dE; uint8_t* dW; double4* dS;
@@ -111,7 +114,8 @@ void hpk_launch_freeze(const HpkDevPlan* plan, unsigned long long* hist, const u
                        int32_t* frozen, int32_t* executed, int32_t* err, hipStream_t st);
 void hpk_launch_prep(const float* raw, const double* weight, int n, int num, int64_t ld, int mw, double* psum, unsigned* pnan,
                      double* IR, double* bias, hipStream_t st);
-void hpk_launch_etab(const HpkDevPlan* plan, int nsteps, int D, const double* IR, int num, double* etab, hipStream_t st);
+void hpk_launch_etab(const HpkDevPlan* plan, int nsteps, int D, int W, const double* IR, int n, int num, double* etab,
+                     double* eedge, hipStream_t st);
 void hpk_launch_gap(const float* raw, const double* bal, const double* weight, int32_t n, int32_t num,
                     int64_t ld, int32_t mw, uint8_t* gap, hipStream_t st);
 void hpk_launch_score(const HpkScoreArgs& a, int cus, hipStream_t st);

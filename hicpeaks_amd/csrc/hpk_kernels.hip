@@ -773,17 +773,74 @@ __global__ void __launch_bounds__(256) hpk_poisson_sf_k(const double* __restrict
 }
 
 // ------------------------------------------------------------------ scoring
-// local expected of a pixel at its resolving step: table value in the interior, explicit window where the window
-// is clipped by the matrix ends
+// local expected of a pixel at its resolving step: table value in the interior; within maxww of the first rows or the
+// last columns the window is clipped by the matrix end (callers.py:50-96 padding) and the value comes from the edge
+// tables, indexed by the distance to that end; only a pixel clipped on both sides (chromosomes shorter than the
+// band) takes the explicit loop.
+//   etab [(s * 2 + fl) * (D + 1) + d]
+//   eedge[(((side * W + e) * nsteps + s) * 2 + fl) * (D + 1) + d]    side 0: e = r < W,  side 1: e = n - 1 - c < W
 __device__ __forceinline__ void local_expected(const HpkDevPlan* __restrict__ plan, const double* __restrict__ etab,
-                                               const double* __restrict__ IR, int step, int r, int c, int d, int n,
-                                               int num, int mw, int D, int W, double& EK, double& EY) {
-    if (r >= W && c < n - W) {
+                                               const double* __restrict__ eedge, const double* __restrict__ IR, int step,
+                                               int r, int c, int d, int n, int num, int mw, int D, int W, double& EK,
+                                               double& EY) {
+    const bool top = r < W, right = c >= n - W;
+    if (!top && !right) {
         EK = etab[(int64_t)(step * 2) * (D + 1) + d];
         EY = etab[(int64_t)(step * 2 + 1) * (D + 1) + d];
+    } else if (top != right) {
+        const int side = top ? 0 : 1, e = top ? r : n - 1 - c;
+        const int64_t o = ((int64_t)((side * W + e) * plan->nsteps + step) * 2) * (D + 1) + d;
+        EK = eedge[o];
+        EY = eedge[o + (D + 1)];
     } else {
         edge_expected(plan->steps[step].m, plan->steps[step].wi, IR, r, c, n, num, mw, EK, EY);
     }
+}
+
+// Edge tables: one wave per (side, e, step) and 64 diagonals; the window cells are walked by a uniform loop (ring
+// multiplicity and clipping are wave-uniform), the IR reads are coalesced across the diagonals and independent, so
+// the loop pipelines instead of waiting for every load.
+__global__ void __launch_bounds__(64) hpk_etab_edge(const HpkDevPlan* __restrict__ plan, const double* __restrict__ IR, int n,
+                                                    int num, double* __restrict__ eedge) {
+    const int D = plan->D, W = plan->W, mw = plan->mw, ns = plan->nsteps;
+    const int d = blockIdx.x * 64 + threadIdx.x;
+    int t = blockIdx.y;
+    const int s = t % ns; t /= ns;
+    const int e = t % W, side = t / W;
+    const HpkDevStep& st = plan->steps[s];
+    const int wi = st.wi;
+    __shared__ int lm[HPK_MAX_W + 1];           // ring multiplicities of this step
+    __shared__ double lir[64 + 4 * HPK_MAX_W + 2];   // IR[d0 - 2wi .. d0 + 63 + 2wi] (0 outside [mw, num))
+    if ((int)threadIdx.x <= HPK_MAX_W) lm[threadIdx.x] = st.m[threadIdx.x];
+    const int d0 = blockIdx.x * 64, kbase = d0 - 2 * wi;
+    for (int i = threadIdx.x; i < 64 + 4 * wi + 1; i += 64) {
+        const int kk = kbase + i;
+        lir[i] = (kk >= mw && kk < num) ? IR[kk] : 0.0;
+    }
+    __syncthreads();
+    const int r = side ? (n - 1 - e) - d : e;       // per lane on the right side, uniform on the top side
+    const int c = r + d;
+    double EK = 0.0, EY = 0.0;
+    const bool live = r >= 0 && c < n && d <= D;
+    for (int di = -wi; di <= wi; ++di) {
+        if (di == 0 || (side == 0 && e + di < 0)) continue;       // centre row; rows above the matrix (uniform)
+        const int adi = di < 0 ? -di : di;
+        const bool low = di > 0;
+#pragma unroll 7
+        for (int dj = -wi; dj <= wi; ++dj) {
+            const int adj = dj < 0 ? -dj : dj;
+            const int m = dj ? lm[adi > adj ? adi : adj] : 0;
+            const int rr = r + di, cc = c + dj;
+            const bool ok = live && rr >= 0 && cc < n;
+            const double v = ok ? (double)m * lir[(int)threadIdx.x + dj - di + 2 * wi] : 0.0;
+            EK += v;
+            if (low && dj < 0) EY += v;
+        }
+    }
+    if (d > D) return;
+    const int64_t o = ((int64_t)((side * W + e) * ns + s) * 2) * (D + 1) + d;
+    eedge[o] = EK;
+    eedge[o + (D + 1)] = EY;
 }
 
 // Persistent blocks: block b walks rows b, b + gridDim.x, ...; the per-family counters live in LDS for the block's
@@ -858,8 +915,8 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                     const double2 s2 = a.rec_S[slot * a.rec_stride + ri];
                     ok = (stp != 0) && (lstepw[stp > 0 ? stp - 1 : 0] <= frozen);   // resolved at an executed step
                     if (ok) {
-                        double EK, EY;
-                        local_expected(plan, a.etab, a.IR, stp - 1, r, c, d, a.n, a.num, a.mw, a.D, W, EK, EY);
+                        double EK = 1.0, EY = 1.0;
+                        if (a.dbg != 2) local_expected(plan, a.etab, a.eedge, a.IR, stp - 1, r, c, d, a.n, a.num, a.mw, a.D, W, EK, EY);
                         // callers.py:244-249: E = ((IR[d] * (bS / bE)) * B1[x]) * B2[y] where bE != 0
                         eK = (EK != 0.0) ? ((ir * (s2.x / EK)) * b1r) * b2c : 0.0;
                         eY = (EY != 0.0) ? ((ir * (s2.y / EY)) * b1r) * b2c : 0.0;
@@ -890,16 +947,16 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                                 if (chunk <= HPK_NB_TAB) {
                                     const int base = lptoff[chunk], len = lptoff[chunk + 1] - base;
                                     const long long kO = (long long)O;
-                                    p = (kO < len) ? a.ptab[base + (int)kO] : 0.0;
+                                    p = (a.dbg == 1) ? 0.5 : ((kO < len) ? a.ptab[base + (int)kO] : 0.0);
                                 } else {
                                     p = poisson_sf(O, lbounds[chunk - 1], a.sfe);   // callers.py:268-270
                                 }
                             }
                         }
                     }
-                    const bool surv = valid && chunk != 0 && p <= a.sig;      // only these can reach q <= sig
+                    const bool surv = valid && chunk != 0 && p <= a.sig && a.dbg != 3;      // only these can reach q <= sig
                     // per-wave aggregation before touching the LDS counters
-                    const unsigned long long vm = __ballot(valid);
+                    const unsigned long long vm = (a.dbg == 4) ? 0ull : __ballot(valid);
                     if (vm != 0ull) {
                         double em = valid ? E : 0.0;
                         for (int off = 32; off > 0; off >>= 1) em = fmax(em, __shfl_xor(em, off));
@@ -1011,8 +1068,9 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkSurv* __restrict
         HpkSurv rec;
         if (i < n) {
             if ((unsigned)(i & 255) < chunk_used[(rb + i) >> 8]) {
-                rec = surv[rb + i];
-                keep = rec.p <= thr[(int)rec.set * (HPK_NB + 1) + (int)rec.chunk];
+                const HpkSurv& src = surv[rb + i];
+                keep = src.p <= thr[(int)src.set * (HPK_NB + 1) + (int)src.chunk];
+                if (keep) rec = src;                      // the other 30 bytes only for the few that stay
             }
         }
         const unsigned long long km = __ballot(keep);
@@ -1049,7 +1107,7 @@ __global__ void __launch_bounds__(256) hpk_dense(HpkDenseArgs a) {
             if (stp != 0) {
                 const double2 s2 = a.rec_S[q * a.rec_stride + ri];
                 double EK, EY;
-                local_expected(plan, a.etab, a.IR, stp - 1, r, c, d, a.n, a.num, a.mw, a.D, plan->W, EK, EY);
+                local_expected(plan, a.etab, a.eedge, a.IR, stp - 1, r, c, d, a.n, a.num, a.mw, a.D, plan->W, EK, EY);
                 const double ir = a.IR[d], b1r = a.b1[r], b2c = a.b2[c];
                 e.x = (EK != 0.0) ? ((ir * (s2.x / EK)) * b1r) * b2c : 0.0;
                 e.y = (EY != 0.0) ? ((ir * (s2.y / EY)) * b1r) * b2c : 0.0;
@@ -1162,10 +1220,12 @@ void hpk_launch_prep(const float* raw, const double* weight, int n, int num, int
     hipLaunchKernelGGL(hpk_biases, dim3((n + 255) / 256), dim3(256), 0, st, weight, n, bias);
 }
 
-void hpk_launch_etab(const HpkDevPlan* plan, int nsteps, int D, const double* IR, int num, double* etab, hipStream_t st) {
+void hpk_launch_etab(const HpkDevPlan* plan, int nsteps, int D, int W, const double* IR, int n, int num, double* etab,
+                     double* eedge, hipStream_t st) {
     const int total = nsteps * 2 * (D + 1);
     if (total <= 0) return;
     hipLaunchKernelGGL(hpk_etab, dim3((total + 255) / 256), dim3(256), 0, st, plan, IR, num, etab);
+    hipLaunchKernelGGL(hpk_etab_edge, dim3((D + 64) / 64, 2 * W * nsteps), dim3(64), 0, st, plan, IR, n, num, eedge);
 }
 
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,
