@@ -61,6 +61,8 @@ struct hpk_ctx {
     // workspaces (grow only)
     DevBuf raw, bal, weight, IR, b1, b2, plan, etab, recE, recS, recW, tilecnt, dE, dW, dS, small, gap, histpart;
     DevBuf surv, surv2, chunkused, psum, pnan, eedge;
+    void* h_head = nullptr;             // pinned landing area of the result head (counters | row flags | survivors)
+    size_t h_head_cap = 0;
     // the device copy of the widening plan is reused while the parameters do not change
     hpk_params plan_key;
     bool plan_valid = false;
@@ -146,9 +148,8 @@ static_assert(sizeof(HpkSurv) == 40, "survivor record layout");
 
 // Benjamini-Hochberg on the p <= sig subset of one family of m tests (statsmodels fdr_bh): the subset holds
 // the m' smallest p-values, so their ranks and step-up q-values are those of the full family.
-void bh_family(std::vector<Surv*>& fam, unsigned long long m, double sig, bool use_reject_mask) {
-    std::sort(fam.begin(), fam.end(), [](const Surv* a, const Surv* b) { return a->p < b->p; });
-    const size_t k = fam.size();
+// `fam` arrives sorted by p.
+void bh_family(Surv* const* fam, size_t k, unsigned long long m, double sig, bool use_reject_mask) {
     double running = INFINITY;
     long rejectmax = -1;
     for (size_t j = k; j-- > 0;) {
@@ -205,6 +206,7 @@ int hpk_create(int device, hpk_ctx** out) {
 }
 
 void hpk_destroy(hpk_ctx* c) {
+    if (c && c->h_head) { (void)hipHostFree(c->h_head); c->h_head = nullptr; }
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf* all[] = {&c->d_bounds, &c->d_off, &c->d_sfe, &c->d_ptab, &c->raw, &c->bal, &c->weight, &c->IR, &c->b1, &c->b2,
@@ -361,9 +363,8 @@ constexpr size_t OFF_EMAX = OFF_NVALID + 8 * 2 * HPK_MAX_PAIRS;                 
 constexpr size_t OFF_NOUT = OFF_EMAX + 8 * 2 * HPK_MAX_PAIRS;                    // u64
 constexpr size_t OFF_FAM_M = OFF_NOUT + 8;                                       // u32[HPK_NFAM]
 constexpr size_t OFF_FAM_F = OFF_FAM_M + 4 * HPK_NFAM;                           // u32[HPK_NFAM]
-constexpr size_t OFF_THR = OFF_FAM_F + 4 * HPK_NFAM;                             // f64[HPK_NFAM]
-constexpr size_t OFF_CNT = OFF_THR + 8 * HPK_NFAM;                                // u32[HPK_NFAM] tightening scratch
-constexpr size_t SMALL_BYTES = OFF_CNT + 4 * HPK_NFAM;
+constexpr size_t SMALL_BYTES = OFF_FAM_F + 4 * HPK_NFAM;
+constexpr size_t HEAD_INLINE = 4096;         // compacted survivors that travel to the host with the counters
 
 }  // namespace
 
@@ -430,16 +431,34 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
         HIPCHK(c, c->dW.reserve(dense_elems));
         if (sums) HIPCHK(c, c->dS.reserve(sizeof(double4) * dense_elems));
     }
-    // one zero-filled block: counters | per-workgroup histograms | per-tile record counts (sized below)
+    // One block, zero-filled by a single memset:
+    //   head (one D2H copy):  counters | row-has-signal flags [n] | first HEAD_INLINE compacted survivors
+    //   scratch:              per-workgroup histograms | per-tile record counts | tightening counters | chunk fill counts
     const int J_ = (TR + D - mw + TC - 1) / TC;
     const int ntiles_ = ((n + TR - 1) / TR) * J_;
     const int grid_ = std::max(8, std::min((c->cus / 8) * 8, ((ntiles_ + 7) / 8) * 8));
-    const size_t off_hp = (SMALL_BYTES + 255) / 256 * 256;
-    const size_t off_tc = off_hp + (sizeof(unsigned) * (size_t)grid_ * (HPK_MAX_STEPS + 1) + 255) / 256 * 256;
-    const size_t zero_bytes = off_tc + sizeof(unsigned) * (size_t)ntiles_;
+    int64_t band_px = 0;                    // pixels with mw <= d <= D inside the matrix
+    for (int d = mw; d <= std::min(D, num - 1); ++d) if (n - d > 0) band_px += n - d;
+    // survivor capacity per region; every scoring wave may hold one partly filled 256-record chunk
+    int64_t cap = (std::max<int64_t>(1 << 16, band_px * nsets / 6) + (int64_t)c->cus * 8 * 4 * 256 * 2) / HPK_NREG;
+    cap = (cap + 255) / 256 * 256;
+    auto up256 = [](size_t v) { return (v + 255) / 256 * 256; };
+    const size_t off_rowlive = up256(SMALL_BYTES);
+    const size_t off_inl = up256(off_rowlive + (size_t)n);
+    const size_t head_bytes = off_inl + sizeof(HpkSurv) * HEAD_INLINE;
+    const size_t off_hp = up256(head_bytes);
+    const size_t off_tc = up256(off_hp + sizeof(unsigned) * (size_t)grid_ * (HPK_MAX_STEPS + 1));
+    const size_t off_cnt = up256(off_tc + sizeof(unsigned) * (size_t)ntiles_);
+    const size_t off_cu = up256(off_cnt + sizeof(unsigned) * HPK_NFAM * HPK_TIGHTEN_MAX);
+    const size_t zero_bytes = (off_cu + sizeof(unsigned) * (size_t)(cap / 256 * HPK_NREG + 1) + 4095) / 4096 * 4096;
     HIPCHK(c, c->small.reserve(zero_bytes));
     HIPCHK(c, hipMemsetAsync(c->small.p, 0, zero_bytes, c->stream));
-    HIPCHK(c, c->gap.reserve((size_t)n));
+    if (c->h_head_cap < head_bytes) {
+        if (c->h_head) (void)hipHostFree(c->h_head);
+        c->h_head = nullptr; c->h_head_cap = 0;
+        HIPCHK(c, hipHostMalloc(&c->h_head, head_bytes + head_bytes / 4, hipHostMallocDefault));
+        c->h_head_cap = head_bytes + head_bytes / 4;
+    }
     if (dense) {   // pixels outside the band are never written by the kernel
         HIPCHK(c, hipMemsetAsync(c->dE.p, 0, sizeof(double2) * dense_elems, c->stream));
         HIPCHK(c, hipMemsetAsync(c->dW.p, 0, dense_elems, c->stream));
@@ -477,8 +496,7 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     HIPCHK(c, c->recW.reserve((size_t)sa.rec_stride * plan.nslots));
     sa.rec_ent = c->recE.as<unsigned>(); sa.rec_S = c->recS.as<double2>(); sa.rec_W = c->recW.as<uint8_t>();
     sa.tile_cnt = reinterpret_cast<unsigned*>(small + off_tc);
-    HIPCHK(c, hipMemsetAsync(c->gap.p, 1, (size_t)n, c->stream));
-    sa.gap = c->gap.as<uint8_t>();
+    sa.gap = small + off_rowlive;
     (void)hipEventRecord(c->ev[1], c->stream);
     hpk_launch_stencil(sa, in.bal != nullptr, plan.simple_reads != 0 && !std::getenv("HPK_GENERIC_SEARCH"), c->stream);
     HIPCHK(c, hipGetLastError());
@@ -487,9 +505,6 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     HIPCHK(c, hipGetLastError());
     (void)hipEventRecord(c->ev[3], c->stream);
 
-    // band pixel count (pixels with mw <= d <= D inside the matrix)
-    int64_t band_px = 0;
-    for (int d = mw; d <= std::min(D, num - 1); ++d) if (n - d > 0) band_px += n - d;
     R.band_px = band_px;
     R.stencil_tiles = sa.ntiles;
 
@@ -497,19 +512,20 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     unsigned long long* d_nout = reinterpret_cast<unsigned long long*>(small + OFF_NOUT);
     unsigned int* d_fam_m = reinterpret_cast<unsigned int*>(small + OFF_FAM_M);
     unsigned int* d_fam_f = reinterpret_cast<unsigned int*>(small + OFF_FAM_F);
-    double* d_thr = reinterpret_cast<double*>(small + OFF_THR);
-    std::vector<unsigned char> hsmall(SMALL_BYTES);
-    int64_t cap = 0;
+    unsigned int* d_cnt = reinterpret_cast<unsigned int*>(small + off_cnt);
+    unsigned* d_chunkused = reinterpret_cast<unsigned*>(small + off_cu);
+    const unsigned char* hsmall = static_cast<const unsigned char*>(c->h_head);
+    const int rounds = std::getenv("HPK_ROUNDS") ? std::atoi(std::getenv("HPK_ROUNDS")) : 3;
     (void)hipEventRecord(c->ev[3], c->stream);
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (do_score) {
-            // capacity per region; every scoring wave may hold one partly filled 256-record chunk
-            if (cap == 0) cap = (std::max<int64_t>(1 << 16, band_px * nsets / 6) + (int64_t)c->cus * 8 * 4 * 256 * 2) / HPK_NREG;
-            cap = (cap + 255) / 256 * 256;
             HIPCHK(c, c->surv.reserve(sizeof(HpkSurv) * (size_t)cap * HPK_NREG));
-            HIPCHK(c, c->chunkused.reserve(sizeof(unsigned) * (size_t)(cap / 256 * HPK_NREG + 1)));
-            HIPCHK(c, hipMemsetAsync(c->chunkused.p, 0, sizeof(unsigned) * (size_t)(cap / 256 * HPK_NREG + 1), c->stream));
             HIPCHK(c, c->surv2.reserve(sizeof(HpkSurv) * (size_t)cap * HPK_NREG));
+            if (attempt == 1) {      // overflow rerun: the chunk table no longer fits the zero block
+                HIPCHK(c, c->chunkused.reserve(sizeof(unsigned) * (size_t)(cap / 256 * HPK_NREG + 1)));
+                HIPCHK(c, hipMemsetAsync(c->chunkused.p, 0, sizeof(unsigned) * (size_t)(cap / 256 * HPK_NREG + 1), c->stream));
+                d_chunkused = c->chunkused.as<unsigned>();
+            }
             HpkScoreArgs sc;
             std::memset(&sc, 0, sizeof(sc));
             sc.raw = in.raw; sc.bal = in.bal; sc.weight = in.weight; sc.plan = sa.plan;
@@ -522,12 +538,12 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
             sc.TR = TR; sc.TC = TC; sc.J = sa.J; sc.W = W;
             sc.fam_m = d_fam_m; sc.fam_f = d_fam_f; sc.emax_bits = d_emax; sc.nvalid = d_nvalid; sc.nsurv = d_nsurv;
             { const char* e = std::getenv("HPK_DBG_SCORE"); sc.dbg = e ? std::atoi(e) : 0; }
-            sc.cap = cap; sc.surv = c->surv.as<HpkSurv>(); sc.chunk_used = c->chunkused.as<unsigned>();
+            sc.cap = cap; sc.surv = c->surv.as<HpkSurv>(); sc.chunk_used = d_chunkused;
             hpk_launch_score(sc, c->cus, c->stream);
             HIPCHK(c, hipGetLastError());
             (void)hipEventRecord(c->ev[4], c->stream);
-            hpk_launch_tighten(sc.surv, d_nsurv, cap, sc.chunk_used, d_fam_m, d_fam_f,
-                               reinterpret_cast<unsigned int*>(small + OFF_CNT), d_thr, prm->sig, (std::getenv("HPK_ROUNDS") ? std::atoi(std::getenv("HPK_ROUNDS")) : 3), c->surv2.as<HpkSurv>(), d_nout,
+            hpk_launch_tighten(sc.surv, d_nsurv, cap, sc.chunk_used, d_fam_m, d_fam_f, d_cnt, prm->sig, rounds,
+                               reinterpret_cast<HpkSurv*>(small + off_inl), HEAD_INLINE, c->surv2.as<HpkSurv>(), d_nout,
                                c->cus, c->stream);
             HIPCHK(c, hipGetLastError());
         } else {
@@ -536,34 +552,34 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
         (void)hipEventRecord(c->ev[5], c->stream);
         // gap rows are produced by the stencil kernel (hpk_gap remains as an independent check for the tests)
         if (attempt == 0 && std::getenv("HPK_GAP_KERNEL")) {
-            hpk_launch_gap(in.raw, in.bal, in.weight, n, num, band->ld, mw, c->gap.as<uint8_t>(), c->stream);
+            hpk_launch_gap(in.raw, in.bal, in.weight, n, num, band->ld, mw, small + off_rowlive, c->stream);
             HIPCHK(c, hipGetLastError());
         }
         (void)hipEventRecord(c->ev[6], c->stream);
-        HIPCHK(c, hipMemcpyAsync(hsmall.data(), small, SMALL_BYTES, hipMemcpyDeviceToHost, c->stream));
-        if (attempt == 0) {
-            box->gap.resize(n);
-            HIPCHK(c, hipMemcpyAsync(box->gap.data(), c->gap.p, (size_t)n, hipMemcpyDeviceToHost, c->stream));
-        }
+        // counters, row flags and the first survivors in one copy into pinned memory
+        HIPCHK(c, hipMemcpyAsync(c->h_head, small, head_bytes, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         unsigned long long ns = 0;              // fullest region
         for (int rg = 0; rg < HPK_NREG; ++rg)
-            ns = std::max(ns, reinterpret_cast<const unsigned long long*>(hsmall.data() + OFF_NSURV)[rg * HPK_REG_STRIDE]);
+            ns = std::max(ns, reinterpret_cast<const unsigned long long*>(hsmall + OFF_NSURV)[rg * HPK_REG_STRIDE]);
         if (!do_score || (int64_t)ns <= cap) break;
         if (attempt == 1) return fail(c, HPK_ERR_NOMEM, "survivor buffer overflow");
-        cap = (int64_t)ns * 2 + 1024;           // rerun the scoring with room for everything (slots are chunked)
+        cap = ((int64_t)ns * 2 + 1024 + 255) / 256 * 256;      // rerun the scoring with room for everything
         HIPCHK(c, hipMemsetAsync(small + OFF_NSURV, 0, SMALL_BYTES - OFF_NSURV, c->stream));
+        HIPCHK(c, hipMemsetAsync(small + off_cnt, 0, sizeof(unsigned) * HPK_NFAM * HPK_TIGHTEN_MAX, c->stream));
     }
+    box->gap.resize(n);
+    for (int r = 0; r < n; ++r) box->gap[r] = hsmall[off_rowlive + r] ? 0 : 1;
 
     // ---- results to host
-    const unsigned long long* h_hist = reinterpret_cast<const unsigned long long*>(hsmall.data() + OFF_HIST);
-    const int32_t h_frozen = *reinterpret_cast<const int32_t*>(hsmall.data() + OFF_FROZEN);
-    const int32_t h_err = *reinterpret_cast<const int32_t*>(hsmall.data() + OFF_ERR);
-    const int32_t* h_exec = reinterpret_cast<const int32_t*>(hsmall.data() + OFF_EXEC);
-    const unsigned long long h_nsurv = *reinterpret_cast<const unsigned long long*>(hsmall.data() + OFF_NOUT);
-    const unsigned long long* h_nvalid = reinterpret_cast<const unsigned long long*>(hsmall.data() + OFF_NVALID);
-    const unsigned long long* h_emax = reinterpret_cast<const unsigned long long*>(hsmall.data() + OFF_EMAX);
-    const unsigned int* h_chist = reinterpret_cast<const unsigned int*>(hsmall.data() + OFF_FAM_M);
+    const unsigned long long* h_hist = reinterpret_cast<const unsigned long long*>(hsmall + OFF_HIST);
+    const int32_t h_frozen = *reinterpret_cast<const int32_t*>(hsmall + OFF_FROZEN);
+    const int32_t h_err = *reinterpret_cast<const int32_t*>(hsmall + OFF_ERR);
+    const int32_t* h_exec = reinterpret_cast<const int32_t*>(hsmall + OFF_EXEC);
+    const unsigned long long h_nsurv = *reinterpret_cast<const unsigned long long*>(hsmall + OFF_NOUT);
+    const unsigned long long* h_nvalid = reinterpret_cast<const unsigned long long*>(hsmall + OFF_NVALID);
+    const unsigned long long* h_emax = reinterpret_cast<const unsigned long long*>(hsmall + OFF_EMAX);
+    const unsigned int* h_chist = reinterpret_cast<const unsigned int*>(hsmall + OFF_FAM_M);
 
     R.nsteps = plan.nsteps;
     for (int s = 0; s < plan.nsteps; ++s) {
@@ -577,7 +593,7 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     for (int q = 0; q < plan.nslots; ++q) R.slot_pi[q] = plan.slot_pi[q];
     R.ncand = (int64_t)h_hist[HPK_HIST_NCAND];
     R.nsurv_sig = 0;
-    for (int i = 0; i < HPK_NFAM; ++i) R.nsurv_sig += reinterpret_cast<const unsigned int*>(hsmall.data() + OFF_FAM_F)[i];
+    for (int i = 0; i < HPK_NFAM; ++i) R.nsurv_sig += reinterpret_cast<const unsigned int*>(hsmall + OFF_FAM_F)[i];
     R.nsurv_cut = (int64_t)h_nsurv;
     R.gap = box->gap.data();
     if (h_err != 0 && sa.dbg_stop == 0) {
@@ -590,13 +606,19 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     std::vector<Surv> sv;
     if (do_score && h_nsurv) {
         const size_t ns = (size_t)h_nsurv;
-        std::vector<HpkSurv> recs(ns);
-        HIPCHK(c, hipMemcpyAsync(recs.data(), c->surv2.p, sizeof(HpkSurv) * ns, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        const HpkSurv* head = reinterpret_cast<const HpkSurv*>(hsmall + off_inl);
+        std::vector<HpkSurv> rest;
+        if (ns > HEAD_INLINE) {
+            rest.resize(ns - HEAD_INLINE);
+            HIPCHK(c, hipMemcpyAsync(rest.data(), c->surv2.p, sizeof(HpkSurv) * (ns - HEAD_INLINE), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
+        auto rec_at = [&](size_t i) -> const HpkSurv& { return i < HEAD_INLINE ? head[i] : rest[i - HEAD_INLINE]; };
         sv.resize(ns);
-        for (size_t i = 0; i < ns; ++i)
-            sv[i] = Surv{recs[i].x, recs[i].y, recs[i].set, recs[i].chunk, recs[i].flag, 0, recs[i].O, recs[i].E, recs[i].p,
-                         recs[i].bal, 1.0};
+        for (size_t i = 0; i < ns; ++i) {
+            const HpkSurv& rc_ = rec_at(i);
+            sv[i] = Surv{rc_.x, rc_.y, rc_.set, rc_.chunk, rc_.flag, 0, rc_.O, rc_.E, rc_.p, rc_.bal, 1.0};
+        }
     }
     if (dense) {
         HpkDenseArgs da;
@@ -627,13 +649,19 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     R.nsets = do_score ? nsets : 0;
     std::vector<std::vector<Surv*>> kept(nsets);
     if (do_score) {
-        // families = (set, chunk): one sort by (set, chunk, p), then Benjamini-Hochberg on each run
+        // families = (set, chunk): one sort by (family, p) on flat 16-byte keys (p >= 0, so its bit pattern orders
+        // like its value), then Benjamini-Hochberg on each run
+        struct Key { uint32_t fam, idx; uint64_t pbits; };
+        std::vector<Key> keys(sv.size());
+        for (size_t i = 0; i < sv.size(); ++i) {
+            uint64_t b;
+            std::memcpy(&b, &sv[i].p, 8);
+            keys[i] = Key{(uint32_t)sv[i].set << 8 | sv[i].chunk, (uint32_t)i, b};
+        }
+        std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
+            return a.fam != b.fam ? a.fam < b.fam : a.pbits < b.pbits; });
         std::vector<Surv*> order(sv.size());
-        for (size_t i = 0; i < sv.size(); ++i) order[i] = &sv[i];
-        std::sort(order.begin(), order.end(), [](const Surv* a, const Surv* b) {
-            if (a->set != b->set) return a->set < b->set;
-            if (a->chunk != b->chunk) return a->chunk < b->chunk;
-            return a->p < b->p; });
+        for (size_t i = 0; i < sv.size(); ++i) order[i] = &sv[keys[i].idx];
         const double t_h1 = now_ms();
         std::vector<int> numbins(nsets, 0);
         for (int s = 0; s < nsets; ++s) {
@@ -652,15 +680,13 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
             hs.numbin = numbin;
             numbins[s] = (plan.mode == HPK_MODE_BHFDR) ? 1 : numbin;
         }
-        std::vector<Surv*> f;
         for (size_t i = 0; i < order.size();) {
             size_t j = i;
             while (j < order.size() && order[j]->set == order[i]->set && order[j]->chunk == order[i]->chunk) ++j;
             const int s = order[i]->set, ch = order[i]->chunk;
             if (s < nsets && ch >= 1 && ch <= numbins[s]) {        // chunks beyond numbin keep p = q = 1 (callers.py:259-260)
-                f.assign(order.begin() + i, order.begin() + j);
-                bh_family(f, h_chist[(size_t)s * (HPK_NB + 1) + ch], prm->sig, plan.mode == HPK_MODE_BHFDR);
-                for (Surv* p : f) if (p->keep) kept[s].push_back(p);
+                bh_family(order.data() + i, j - i, h_chist[(size_t)s * (HPK_NB + 1) + ch], prm->sig, plan.mode == HPK_MODE_BHFDR);
+                for (size_t t = i; t < j; ++t) if (order[t]->keep) kept[s].push_back(order[t]);
             }
             i = j;
         }

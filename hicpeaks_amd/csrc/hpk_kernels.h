@@ -48,6 +48,7 @@ struct HpkSurv {
     double E, p, bal;
 };
 #define HPK_NFAM (2 * HPK_MAX_PAIRS * (HPK_NB + 1))     // (set, chunk) families
+#define HPK_TIGHTEN_MAX 4                                // rounds of BH-cut tightening (one counter array each)
 #define HPK_NREG 64                     // independent survivor regions (one reservation counter each, 256 B apart)
 #define HPK_REG_STRIDE 32               // counters are u64[HPK_NREG * HPK_REG_STRIDE]
 
@@ -122,9 +123,9 @@ void hpk_launch_score(const HpkScoreArgs& a, int cus, hipStream_t st);
 // Benjamini-Hochberg cut tightening on the survivor list: thr[f] <- sig * #{p <= thr[f]} / m[f], `rounds` times,
 // then compaction of the records with p <= thr[f] into `out` (count in *nout).
 void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned* chunk_used,
-                        const unsigned int* fam_m, const unsigned int* fam_f,
-                        unsigned int* fam_cnt, double* fam_thr, double sig, int rounds, HpkSurv* out,
-                        unsigned long long* nout, int cus, hipStream_t st);
+                        const unsigned int* fam_m, const unsigned int* fam_f, unsigned int* fam_cnt, double sig, int rounds,
+                        HpkSurv* out_head, unsigned long long inl, HpkSurv* out_rest, unsigned long long* nout, int cus,
+                        hipStream_t st);
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,
                      hipStream_t st);
 void hpk_launch_poisson_sf(const double* k, const double* lam, const double* sfe, double* out, int64_t count,

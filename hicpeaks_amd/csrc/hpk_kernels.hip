@@ -337,13 +337,14 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
     const double tiny_thr = 1e-9 * S.c[LR * LC - 1];
     // Gap rows (callers.py:238: rows of the balanced upper band that sum to 0): the valid-count plane gives the exact
     // row sum of this tile's columns; the last tile of a row block also covers the maxww diagonals beyond D in its
-    // right halo.  gap[] is preset to 1, any tile that sees a non-zero balanced value in row r clears gap[r].
+    // right halo.  The flags start at 0 ("no signal seen"); any tile that sees a non-zero balanced value in row r
+    // sets rowlive[r] (plain byte stores of the same value: no atomics needed).  gap = !rowlive.
     if ((int)threadIdx.x < a.TR && r0 + (int)threadIdx.x < n) {
         const bool last = (cj == a.J - 1) || (c0 + a.TC >= n) || (mw + (cj + 1) * a.TC - (a.TR - 1)) > D;
         const int Y = (int)threadIdx.x + W + 1;
         const int xe = last ? LC - 1 : W + a.TC, xs = W;
         const unsigned rs = S.v[Y * LC + xe] - S.v[(Y - 1) * LC + xe] - S.v[Y * LC + xs] + S.v[(Y - 1) * LC + xs];
-        if (rs != 0u) a.gap[r0 + (int)threadIdx.x] = 0;
+        if (rs != 0u) a.gap[r0 + (int)threadIdx.x] = 1;
     }
 
     // ---- phase 3: candidates of the tile.  Work is proportional to the candidates (non-zero pixels), not to the
@@ -420,7 +421,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
         const bool cand = kb * 64 + lane < cnt;
         const int yi = (int)((id >> 7) & 3u), x = (int)(id & 127u);
         const int y = wave + NW * yi;
-        if (cand) a.rec_ent[rec0 + kb * 64 + lane] = id;
+        if (cand && a.dbg_stop != 7) a.rec_ent[rec0 + kb * 64 + lane] = id;
         const int r = r0 + y;
         const int d = c0 + x - r;
         const int base = (y + W + 1) * LC + W + 1 + x;       // idle lanes: id 0 -> a valid interior cell
@@ -552,7 +553,8 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
                     }
                 }
             }
-            if (cand) {
+            if (a.dbg_stop == 7) { if (SK == -1.0 && SY == -7.0 && sq == 1234) a.hist[0] = 1ull; }
+            else if (cand) {
                 const int64_t o = q * a.rec_stride + rec0 + kb * 64 + lane;
                 g_recS[o] = make_double2(act ? SK : 0.0, act ? SY : 0.0);
                 g_recW[o] = act ? (uint8_t)(sq + 1) : (uint8_t)0;
@@ -697,7 +699,7 @@ __global__ void __launch_bounds__(256) hpk_gap(const float* __restrict__ raw, co
         any = any || (b != 0.0);
     }
     const unsigned long long m = __ballot(any);
-    if (lane == 0) gap[r] = (m == 0ull) ? 1 : 0;
+    if (lane == 0) gap[r] = (m == 0ull) ? 0 : 1;        // same "row has signal" flag as the stencil kernel writes
 }
 
 // ------------------------------------------------------------------ Poisson
@@ -797,9 +799,11 @@ __device__ __forceinline__ void local_expected(const HpkDevPlan* __restrict__ pl
     }
 }
 
-// Edge tables: one wave per (side, e, step) and 64 diagonals; the window cells are walked by a uniform loop (ring
-// multiplicity and clipping are wave-uniform), the IR reads are coalesced across the diagonals and independent, so
-// the loop pipelines instead of waiting for every load.
+// Edge tables.  Clipping by one matrix end removes whole window rows (top: di < -e) or whole window columns (right:
+// dj > e) whatever the diagonal, so the clipped window is again a 1-D stencil over IR: tap t = dj - di + 2wi carries
+// the summed multiplicity of the surviving cells on that anti-diagonal.  One wave per (side, e, step) and 64
+// diagonals: the taps are formed once in LDS (<= 2wi+1 cells each), then every lane runs <= 4wi+1 multiply-adds on an
+// LDS-staged IR window.
 __global__ void __launch_bounds__(64) hpk_etab_edge(const HpkDevPlan* __restrict__ plan, const double* __restrict__ IR, int n,
                                                     int num, double* __restrict__ eedge) {
     const int D = plan->D, W = plan->W, mw = plan->mw, ns = plan->nsteps;
@@ -809,8 +813,9 @@ __global__ void __launch_bounds__(64) hpk_etab_edge(const HpkDevPlan* __restrict
     const int e = t % W, side = t / W;
     const HpkDevStep& st = plan->steps[s];
     const int wi = st.wi;
-    __shared__ int lm[HPK_MAX_W + 1];           // ring multiplicities of this step
-    __shared__ double lir[64 + 4 * HPK_MAX_W + 2];   // IR[d0 - 2wi .. d0 + 63 + 2wi] (0 outside [mw, num))
+    __shared__ int lm[HPK_MAX_W + 1];                    // ring multiplicities of this step
+    __shared__ double tapK[4 * HPK_MAX_W + 1], tapY[4 * HPK_MAX_W + 1];
+    __shared__ double lir[64 + 4 * HPK_MAX_W + 2];       // IR[d0 - 2wi .. d0 + 63 + 2wi] (0 outside [mw, num))
     if ((int)threadIdx.x <= HPK_MAX_W) lm[threadIdx.x] = st.m[threadIdx.x];
     const int d0 = blockIdx.x * 64, kbase = d0 - 2 * wi;
     for (int i = threadIdx.x; i < 64 + 4 * wi + 1; i += 64) {
@@ -818,26 +823,29 @@ __global__ void __launch_bounds__(64) hpk_etab_edge(const HpkDevPlan* __restrict
         lir[i] = (kk >= mw && kk < num) ? IR[kk] : 0.0;
     }
     __syncthreads();
-    const int r = side ? (n - 1 - e) - d : e;       // per lane on the right side, uniform on the top side
-    const int c = r + d;
-    double EK = 0.0, EY = 0.0;
-    const bool live = r >= 0 && c < n && d <= D;
-    for (int di = -wi; di <= wi; ++di) {
-        if (di == 0 || (side == 0 && e + di < 0)) continue;       // centre row; rows above the matrix (uniform)
-        const int adi = di < 0 ? -di : di;
-        const bool low = di > 0;
-#pragma unroll 7
-        for (int dj = -wi; dj <= wi; ++dj) {
-            const int adj = dj < 0 ? -dj : dj;
-            const int m = dj ? lm[adi > adj ? adi : adj] : 0;
-            const int rr = r + di, cc = c + dj;
-            const bool ok = live && rr >= 0 && cc < n;
-            const double v = ok ? (double)m * lir[(int)threadIdx.x + dj - di + 2 * wi] : 0.0;
-            EK += v;
-            if (low && dj < 0) EY += v;
+    for (int tp = threadIdx.x; tp <= 4 * wi; tp += 64) {
+        const int off = tp - 2 * wi;                     // dj - di
+        int ck = 0, cy = 0;
+        for (int di = -wi; di <= wi; ++di) {
+            const int dj = di + off;
+            if (di == 0 || dj == 0 || dj < -wi || dj > wi) continue;
+            if (side == 0 ? (e + di < 0) : (dj > e)) continue;          // rows above / columns right of the matrix
+            const int adi = di < 0 ? -di : di, adj = dj < 0 ? -dj : dj;
+            const int m = lm[adi > adj ? adi : adj];
+            ck += m;
+            if (di > 0 && dj < 0) cy += m;
         }
+        tapK[tp] = (double)ck;
+        tapY[tp] = (double)cy;
     }
+    __syncthreads();
     if (d > D) return;
+    double EK = 0.0, EY = 0.0;
+    for (int tp = 0; tp <= 4 * wi; ++tp) {
+        const double v = lir[(int)threadIdx.x + tp];
+        EK += tapK[tp] * v;
+        EY += tapY[tp] * v;
+    }
     const int64_t o = ((int64_t)((side * W + e) * ns + s) * 2) * (D + 1) + d;
     eedge[o] = EK;
     eedge[o + (D + 1)] = EY;
@@ -1016,51 +1024,62 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
 // With F(t) = #{p <= t}: k* <= F(sig), hence p_(k*) <= sig F(sig) / m =: T1 <= sig, then p_(k*) <= sig F(T1) / m, ...
 // Every p-value above the current bound is irrelevant both for the rejection set and for the q-values of the
 // rejected ones (their step-up terms exceed sig), so the list can be cut to p <= T before it leaves the device.
-__global__ void __launch_bounds__(256) hpk_thr_init(const unsigned int* fam_m, const unsigned int* fam_f, double* thr,
-                                                    unsigned int* cnt, double sig) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= HPK_NFAM) return;
-    const unsigned m = fam_m[i];
-    thr[i] = m ? fmin(sig, sig * ((double)fam_f[i] / (double)m) * (1.0 + 1e-9)) : 0.0;
-    cnt[i] = 0u;
+// Round k (k = 0 .. rounds-1) counts F(T_k) into cnt[k][.], where T_0 = sig f / m (f = #{p <= sig}, counted by the
+// scoring kernel) and T_k = sig cnt[k-1] / m.  Every workgroup derives the bounds it needs from the previous rounds'
+// counters in its prologue, so a round is one launch and the last bound is applied by the compaction itself.
+__device__ __forceinline__ void thr_table(double* lthr, const unsigned int* __restrict__ fam_m, const unsigned int* __restrict__ fam_f,
+                                          const unsigned int* __restrict__ cnt, int round, double sig) {
+    for (int i = threadIdx.x; i < HPK_NFAM; i += blockDim.x) {
+        const unsigned m = fam_m[i];
+        double t = 0.0;
+        if (m) {
+            t = fmin(sig, sig * ((double)fam_f[i] / (double)m) * (1.0 + 1e-9));
+            for (int k = 0; k < round; ++k) t = fmin(t, sig * ((double)cnt[(size_t)k * HPK_NFAM + i] / (double)m) * (1.0 + 1e-9));
+        }
+        lthr[i] = t;
+    }
 }
 __global__ void __launch_bounds__(256) hpk_thr_count(const HpkSurv* __restrict__ surv, const unsigned long long* __restrict__ nsurv,
                                                      int64_t cap, const unsigned* __restrict__ chunk_used,
-                                                     const double* __restrict__ thr, unsigned int* __restrict__ cnt) {
+                                                     const unsigned int* __restrict__ fam_m, const unsigned int* __restrict__ fam_f,
+                                                     unsigned int* __restrict__ cnt, int round, double sig) {
     __shared__ unsigned int lc[HPK_NFAM];
+    __shared__ double lthr[HPK_NFAM];
+    const int reg = blockIdx.y;             // one grid row per survivor region
+    int64_t n = (int64_t)nsurv[reg * HPK_REG_STRIDE]; if (n > cap) n = cap;
+    if ((int64_t)blockIdx.x * blockDim.x >= n) return;
     for (int i = threadIdx.x; i < HPK_NFAM; i += blockDim.x) lc[i] = 0u;
+    thr_table(lthr, fam_m, fam_f, cnt, round, sig);
     __syncthreads();
     {
-        const int reg = blockIdx.y;             // one grid row per survivor region
-        int64_t n = (int64_t)nsurv[reg * HPK_REG_STRIDE]; if (n > cap) n = cap;
         const int64_t rb = (int64_t)reg * cap;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
             if ((unsigned)(i & 255) >= chunk_used[(rb + i) >> 8]) continue;
             const HpkSurv& rec = surv[rb + i];
             const int f = (int)rec.set * (HPK_NB + 1) + (int)rec.chunk;
-            if (rec.p <= thr[f]) atomicAdd(&lc[f], 1u);
+            if (rec.p <= lthr[f]) atomicAdd(&lc[f], 1u);
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < HPK_NFAM; i += blockDim.x) if (lc[i]) atomicAdd(&cnt[i], lc[i]);
+    unsigned int* out = cnt + (size_t)round * HPK_NFAM;
+    for (int i = threadIdx.x; i < HPK_NFAM; i += blockDim.x) if (lc[i]) atomicAdd(&out[i], lc[i]);
 }
-__global__ void __launch_bounds__(256) hpk_thr_update(const unsigned int* __restrict__ fam_m, double* __restrict__ thr,
-                                                      unsigned int* __restrict__ cnt, double sig) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= HPK_NFAM) return;
-    const unsigned m = fam_m[i];
-    if (m) thr[i] = fmin(thr[i], sig * ((double)cnt[i] / (double)m) * (1.0 + 1e-9));
-    cnt[i] = 0u;
-}
+// The first `inl` survivors of the cut go to out_head (which travels to the host together with the counters), the rest
+// to out_rest.
 __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkSurv* __restrict__ surv, const unsigned long long* __restrict__ nsurv,
                                                        int64_t cap, const unsigned* __restrict__ chunk_used,
-                                                       const double* __restrict__ thr, HpkSurv* __restrict__ out,
-                                                       unsigned long long* __restrict__ nout) {
+                                                       const unsigned int* __restrict__ fam_m, const unsigned int* __restrict__ fam_f,
+                                                       const unsigned int* __restrict__ cnt, int rounds, double sig,
+                                                       HpkSurv* __restrict__ out_head, unsigned long long inl,
+                                                       HpkSurv* __restrict__ out_rest, unsigned long long* __restrict__ nout) {
+    __shared__ double lthr[HPK_NFAM];
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    {
     const int reg = blockIdx.y;
     int64_t n = (int64_t)nsurv[reg * HPK_REG_STRIDE]; if (n > cap) n = cap;
+    if ((int64_t)blockIdx.x * blockDim.x >= n) return;
+    thr_table(lthr, fam_m, fam_f, cnt, rounds, sig);
+    __syncthreads();
     const int64_t rb = (int64_t)reg * cap;
     for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
         const int64_t i = i0 + threadIdx.x;
@@ -1069,7 +1088,7 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkSurv* __restrict
         if (i < n) {
             if ((unsigned)(i & 255) < chunk_used[(rb + i) >> 8]) {
                 const HpkSurv& src = surv[rb + i];
-                keep = src.p <= thr[(int)src.set * (HPK_NB + 1) + (int)src.chunk];
+                keep = src.p <= lthr[(int)src.set * (HPK_NB + 1) + (int)src.chunk];
                 if (keep) rec = src;                      // the other 30 bytes only for the few that stay
             }
         }
@@ -1078,8 +1097,10 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkSurv* __restrict
         unsigned long long basei = 0ull;
         if (lane == 0) basei = atomicAdd(nout, (unsigned long long)__popcll(km));
         basei = __shfl(basei, 0);
-        if (keep) out[basei + (unsigned long long)__popcll(km & ((1ull << lane) - 1ull))] = rec;
-    }
+        if (keep) {
+            const unsigned long long o = basei + (unsigned long long)__popcll(km & ((1ull << lane) - 1ull));
+            if (o < inl) out_head[o] = rec; else out_rest[o - inl] = rec;
+        }
     }
 }
 
@@ -1200,16 +1221,14 @@ void hpk_launch_score(const HpkScoreArgs& a, int cus, hipStream_t st) {
 }
 
 void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned* chunk_used,
-                        const unsigned int* fam_m, const unsigned int* fam_f,
-                        unsigned int* fam_cnt, double* fam_thr, double sig, int rounds, HpkSurv* out,
-                        unsigned long long* nout, int cus, hipStream_t st) {
-    const int fb = (HPK_NFAM + 255) / 256;
-    hipLaunchKernelGGL(hpk_thr_init, dim3(fb), dim3(256), 0, st, fam_m, fam_f, fam_thr, fam_cnt, sig);
-    for (int r = 0; r < rounds; ++r) {
-        hipLaunchKernelGGL(hpk_thr_count, dim3(8, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_thr, fam_cnt);
-        hipLaunchKernelGGL(hpk_thr_update, dim3(fb), dim3(256), 0, st, fam_m, fam_thr, fam_cnt, sig);
-    }
-    hipLaunchKernelGGL(hpk_thr_compact, dim3(8, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_thr, out, nout);
+                        const unsigned int* fam_m, const unsigned int* fam_f, unsigned int* fam_cnt, double sig, int rounds,
+                        HpkSurv* out_head, unsigned long long inl, HpkSurv* out_rest, unsigned long long* nout, int cus,
+                        hipStream_t st) {
+    if (rounds > HPK_TIGHTEN_MAX) rounds = HPK_TIGHTEN_MAX;
+    for (int r = 0; r < rounds; ++r)
+        hipLaunchKernelGGL(hpk_thr_count, dim3(8, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt, r, sig);
+    hipLaunchKernelGGL(hpk_thr_compact, dim3(8, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt,
+                       rounds, sig, out_head, inl, out_rest, nout);
 }
 
 void hpk_launch_prep(const float* raw, const double* weight, int n, int num, int64_t ld, int mw, double* psum, unsigned* pnan,
