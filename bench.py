@@ -16,6 +16,7 @@ collective (weak scaling).  Rank 0 prints ONE JSON line.
                to it by fixtures) timed on a bounded row sample of the same workload, rank 0, N = 1 only.
 """
 import argparse
+import collections
 import json
 import os
 import sys
@@ -83,6 +84,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='chr1_10kb', choices=sorted(CONFIGS))
     ap.add_argument('--cpu-rows', type=int, default=12000, help='rows of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--pipeline-depth', type=int, default=2,
+                    help='chromosomes in flight per GPU (hpk_submit_band / hpk_collect); 1 = one synchronous call per step')
     ap.add_argument('--stencil-only', action='store_true', help='time the stencil kernel alone (HPK_FLAG_NO_SCORE)')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -125,12 +128,29 @@ def main():
                            MIN_READS, flags)
     px_per_step = band.band_pixels(n, num, mw, D) * len(cfg['pw'])
 
-    def step():
-        return ctx.score_device(n, num, ld, raw_d.data_ptr(), ir_d.data_ptr(), b_d.data_ptr(), b_d.data_ptr(), prm,
-                                weight_ptr=w_d.data_ptr())
+    # One step = one whole pass of the path over the chromosome (every kernel, the download and the host half).  As in
+    # a run over many chromosomes, the next pass is submitted before the previous one is collected, so the host half
+    # (Benjamini-Hochberg, result assembly) of pass i overlaps the kernels of pass i + 1; all K passes are submitted
+    # and collected inside the timed region.
+    depth = max(1, min(args.pipeline_depth, ctx.pipeline_depth))
 
-    for _ in range(args.warmup):
-        R = step()
+    def submit():
+        return ctx.submit_device(n, num, ld, raw_d.data_ptr(), ir_d.data_ptr(), b_d.data_ptr(), b_d.data_ptr(), prm,
+                                 weight_ptr=w_d.data_ptr())
+
+    def run(k):
+        pending, done = collections.deque(), []
+        for _ in range(k):
+            pending.append(submit())
+            if len(pending) >= depth:
+                done.append(pending.popleft().result())
+        while pending:
+            done.append(pending.popleft().result())
+        return done
+
+    R = None
+    for R in run(args.warmup):
+        pass
 
     def barrier():
         if dist is not None:
@@ -140,12 +160,23 @@ def main():
     barrier()
     t0 = time.perf_counter()
     stencil_ms, score_ms = [], []
-    for _ in range(args.steps):
-        R = step()
-        stencil_ms.append(R.timing['stencil'])
-        score_ms.append(R.timing['score'])
+    results = run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    for R in results:
+        stencil_ms.append(R.timing['stencil'])
+        score_ms.append(R.timing['score'])
+    # outside the timed region: latency of one synchronous call (submit + collect), then a few calls with the per-phase
+    # events switched on (they cost ~6 us of idle GPU each, so the timed passes run without them)
+    lat = []
+    for _ in range(min(5, args.steps)):
+        t1 = time.perf_counter()
+        submit().result()
+        lat.append((time.perf_counter() - t1) * 1e3)
+    prm = _lib.make_params(_lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], cfg['maxww'], SIG, cfg['maxapart'], cfg['res'],
+                           MIN_READS, flags | _lib.FLAG_PHASE_TIMING)
+    for _ in range(3):
+        R = submit().result()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -162,7 +193,8 @@ def main():
             'config': {'workload': cfg['workload'], 'name': args.config, 'band_px_per_step': px_per_step,
                        'candidates': R.ncand, 'significant_px': int(sum(s['x'].size for s in R.sets)),
                        'px_with_p_le_sig': R.nsurv_sig, 'records_copied_back': R.nsurv_cut,
-                       'parallelism': 'one chromosome per GPU, no collective',
+                       'parallelism': 'one chromosome per GPU, no collective', 'pipeline_depth': depth,
+                       'sync_call_ms': float(np.median(lat)),
                        'stencil_only': bool(args.stencil_only)},
             'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,

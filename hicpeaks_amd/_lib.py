@@ -23,12 +23,14 @@ MODE_BHFDR = 1
 FLAG_DENSE_E = 1
 FLAG_DENSE_SUMS = 2
 FLAG_NO_SCORE = 4
+FLAG_PHASE_TIMING = 8
 
 HPK_OK = 0
-ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_EMPTY_STEP, ERR_PLAN, ERR_NOMEM = -1, -2, -3, -4, -5, -6
+ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_EMPTY_STEP, ERR_PLAN, ERR_NOMEM, ERR_BUSY = -1, -2, -3, -4, -5, -6, -7
 
 # every symbol include/hpk.h declares (tests check the built library exports all of them)
 ABI_SYMBOLS = ['hpk_create', 'hpk_destroy', 'hpk_last_error', 'hpk_abi_version', 'hpk_score_band',
+               'hpk_pipeline_depth', 'hpk_submit_band', 'hpk_collect',
                'hpk_result_free', 'hpk_plan_rings', 'hpk_chunk_bounds', 'hpk_set_chunk_bounds',
                'hpk_device_info', 'hpk_poisson_sf', 'hpk_bruteforce_sums']
 
@@ -117,6 +119,11 @@ def load():
     lib.hpk_score_band.restype = C.c_int
     lib.hpk_result_free.argtypes = [C.POINTER(Result)]
     lib.hpk_result_free.restype = None
+    lib.hpk_pipeline_depth.restype = C.c_int
+    lib.hpk_submit_band.argtypes = [C.c_void_p, C.POINTER(Band), C.POINTER(Params), C.POINTER(C.c_void_p)]
+    lib.hpk_submit_band.restype = C.c_int
+    lib.hpk_collect.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.POINTER(Result))]
+    lib.hpk_collect.restype = C.c_int
     lib.hpk_plan_rings.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hpk_plan_rings.restype = C.c_int
     lib.hpk_chunk_bounds.argtypes = [C.c_void_p, C.c_int32]
@@ -218,6 +225,31 @@ class BandResult(object):
                 self.dense_sums = np.ctypeslib.as_array(r.dense_sums, shape=(k * 4,)).reshape(r.nslots, n, ld, 4).copy()
 
 
+class Job(object):
+    """A chromosome in flight on one lane of a Context (hpk_submit_band / hpk_collect)."""
+
+    def __init__(self, ctx, handle, n, keep=None):
+        self.ctx, self.handle, self.n, self._keep = ctx, handle, n, keep
+
+    def result(self):
+        if self.handle is None:
+            raise HpkError(ERR_INVALID, 'job already collected')
+        res = C.POINTER(Result)()
+        h, self.handle = self.handle, None
+        rc = self.ctx.lib.hpk_collect(self.ctx.h, h, C.byref(res))
+        self._keep = None
+        self.ctx._check(rc)
+        try:
+            return BandResult(res.contents, self.n)
+        finally:
+            self.ctx.lib.hpk_result_free(res)
+
+    def __del__(self):          # a dropped job still has to give its lane back
+        if getattr(self, 'handle', None) is not None and getattr(self.ctx, 'h', None):
+            h, self.handle = self.handle, None
+            self.ctx.lib.hpk_collect(self.ctx.h, h, None)
+
+
 class Context(object):
     """One hpk_ctx = one GPU.  Not shared between threads."""
 
@@ -301,6 +333,25 @@ class Context(object):
             return BandResult(res.contents, n)
         finally:
             self.lib.hpk_result_free(res)
+
+    # ---- one chromosome ahead: submit() enqueues everything on a free lane, Job.result() waits and finishes on the host
+    def submit(self, band, params, n, keep=None):
+        job = C.c_void_p()
+        self._check(self.lib.hpk_submit_band(self.h, C.byref(band), C.byref(params), C.byref(job)))
+        return Job(self, job, n, keep)
+
+    def submit_host(self, raw, IR, bias1, bias2, params, balanced=None, weight=None, num=None):
+        """Like score_host, but returns a Job; the arrays are kept alive until Job.result()."""
+        bd, keep = self._host_band(raw, IR, bias1, bias2, balanced, weight, num_hint=num)
+        return self.submit(bd, params, raw.shape[0], keep)
+
+    def submit_device(self, n, num, ld, raw_ptr, IR_ptr, b1_ptr, b2_ptr, params, balanced_ptr=None, weight_ptr=None):
+        bd = self._band(n, num, ld, raw_ptr, balanced_ptr, weight_ptr, IR_ptr, b1_ptr, b2_ptr, True)
+        return self.submit(bd, params, n)
+
+    @property
+    def pipeline_depth(self):
+        return int(self.lib.hpk_pipeline_depth())
 
     def score_host(self, raw, IR, bias1, bias2, params, balanced=None, weight=None, num=None):
         """IR = bias1 = bias2 = None: derived on the device from `weight` (then `num` = stored diagonals, default

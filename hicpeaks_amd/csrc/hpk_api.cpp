@@ -44,12 +44,44 @@ double now_ms() {
 
 }  // namespace
 
+// One lane = everything a chromosome in flight owns: upload stream, events, device workspaces, the pinned landing
+// area of its result head and the cached device copy of its widening plan.  Two lanes let the host half of
+// chromosome i (Benjamini-Hochberg, result assembly, the caller's Python) and the upload of chromosome i + 1 overlap
+// the kernels.  All kernels of all lanes run in submission order on the context's one compute stream: the stencil
+// fills the whole chip (one 160 KiB-LDS workgroup per CU), so running two chromosomes' kernels side by side would
+// only time-slice them - and would blur the per-kernel timings.
+#define HPK_LANES 2
+struct Lane {
+    hipStream_t up = nullptr;           // uploads of host inputs run beside the kernels of the chromosome before
+    hipEvent_t ev[8];                   // phase marks on the compute stream
+    hipEvent_t ev_up = nullptr, ev_done = nullptr;
+    int nev = 0;
+    bool busy = false;
+    // workspaces (grow only)
+    DevBuf raw, bal, weight, IR, b1, b2, plan, etab, eedge, recE, recS, recW, dE, dW, dS, small, surv, surv2, chunkused, psum, pnan;
+    void* h_head = nullptr;             // pinned: counters | row flags | first survivors
+    size_t h_head_cap = 0;
+    // the device copy of the widening plan is reused while the parameters do not change
+    hpk_params plan_key;
+    bool plan_valid = false;
+    HpkDevPlan plan_host;
+    void release() {
+        DevBuf* all[] = {&raw, &bal, &weight, &IR, &b1, &b2, &plan, &etab, &eedge, &recE, &recS, &recW, &dE, &dW, &dS, &small,
+                         &surv, &surv2, &chunkused, &psum, &pnan};
+        for (DevBuf* b : all) b->release();
+        if (h_head) { (void)hipHostFree(h_head); h_head = nullptr; h_head_cap = 0; }
+        for (int i = 0; i < nev; ++i) (void)hipEventDestroy(ev[i]);
+        nev = 0;
+        if (ev_up) { (void)hipEventDestroy(ev_up); ev_up = nullptr; }
+        if (ev_done) { (void)hipEventDestroy(ev_done); ev_done = nullptr; }
+        if (up) { (void)hipStreamDestroy(up); up = nullptr; }
+    }
+};
+
 struct hpk_ctx {
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;       // compute stream: every kernel and the result downloads
     std::string err;
-    hipEvent_t ev[10];
-    int nev = 0;
     char name[128] = {0};
     int cus = 0;
     size_t hbm = 0;
@@ -58,15 +90,7 @@ struct hpk_ctx {
     std::vector<int32_t> h_off;
     std::vector<double> h_sfe;
     DevBuf d_bounds, d_off, d_sfe, d_ptab;
-    // workspaces (grow only)
-    DevBuf raw, bal, weight, IR, b1, b2, plan, etab, recE, recS, recW, tilecnt, dE, dW, dS, small, gap, histpart;
-    DevBuf surv, surv2, chunkused, psum, pnan, eedge;
-    void* h_head = nullptr;             // pinned landing area of the result head (counters | row flags | survivors)
-    size_t h_head_cap = 0;
-    // the device copy of the widening plan is reused while the parameters do not change
-    hpk_params plan_key;
-    bool plan_valid = false;
-    HpkDevPlan plan_host;
+    Lane lane[HPK_LANES];
     DevBuf tmpA, tmpB, tmpC, tmpD;
 };
 
@@ -192,11 +216,18 @@ int hpk_create(int device, hpk_ctx** out) {
     std::snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
     c->cus = prop.multiProcessorCount;
     c->hbm = prop.totalGlobalMem;
-    if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) {
-        delete c;
-        return fail(nullptr, HPK_ERR_HIP, "hipStreamCreate -> %s", hipGetErrorName(e));
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    for (int l = 0; l < HPK_LANES && e == hipSuccess; ++l) {
+        Lane& L = c->lane[l];
+        e = hipStreamCreateWithFlags(&L.up, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&L.ev_up, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming);
+        for (int i = 0; i < 8 && e == hipSuccess; ++i) { e = hipEventCreate(&L.ev[i]); if (e == hipSuccess) L.nev++; }
     }
-    for (int i = 0; i < 10; ++i) { if (hipEventCreate(&c->ev[i]) == hipSuccess) c->nev++; }
+    if (e != hipSuccess) {
+        hpk_destroy(c);
+        return fail(nullptr, HPK_ERR_HIP, "stream / event creation -> %s", hipGetErrorName(e));
+    }
     fill_bounds(c->h_bounds);
     fill_sfe(c->h_sfe);
     int rc = upload_tables(c);
@@ -206,13 +237,12 @@ int hpk_create(int device, hpk_ctx** out) {
 }
 
 void hpk_destroy(hpk_ctx* c) {
-    if (c && c->h_head) { (void)hipHostFree(c->h_head); c->h_head = nullptr; }
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf* all[] = {&c->d_bounds, &c->d_off, &c->d_sfe, &c->d_ptab, &c->raw, &c->bal, &c->weight, &c->IR, &c->b1, &c->b2,
-                     &c->plan, &c->etab, &c->recE, &c->recS, &c->recW, &c->tilecnt, &c->dE, &c->dW, &c->dS, &c->histpart, &c->small, &c->gap, &c->surv, &c->surv2, &c->chunkused, &c->psum, &c->pnan, &c->eedge, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD};
+    (void)hipDeviceSynchronize();
+    DevBuf* all[] = {&c->d_bounds, &c->d_off, &c->d_sfe, &c->d_ptab, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD};
     for (DevBuf* b : all) b->release();
-    for (int i = 0; i < c->nev; ++i) (void)hipEventDestroy(c->ev[i]);
+    for (int l = 0; l < HPK_LANES; ++l) c->lane[l].release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -289,54 +319,57 @@ struct Staged {
     const double* IR = nullptr;
     const double* b1 = nullptr;
     const double* b2 = nullptr;
-    std::vector<double> hIR;
 };
 
-int stage_inputs(hpk_ctx* c, const hpk_band* band, int mw, Staged* s) {
+int stage_inputs(hpk_ctx* c, Lane& L, const hpk_band* band, int mw, Staged* s) {
     const size_t n = (size_t)band->n, num = (size_t)band->num, ld = (size_t)band->ld;
     const bool derive = !band->IR;          // IR / biases from raw + weight on the device (scripts/pyHICCUPS:149-166)
     if (band->on_device) {
         s->raw = band->raw; s->bal = band->balanced; s->weight = band->weight; s->IR = band->IR; s->b1 = band->bias1; s->b2 = band->bias2;
     } else {
-        HIPCHK(c, c->raw.reserve(sizeof(float) * n * ld));
-        HIPCHK(c, hipMemcpyAsync(c->raw.p, band->raw, sizeof(float) * n * ld, hipMemcpyHostToDevice, c->stream));
-        s->raw = c->raw.as<float>();
+        HIPCHK(c, L.raw.reserve(sizeof(float) * n * ld));
+        HIPCHK(c, hipMemcpyAsync(L.raw.p, band->raw, sizeof(float) * n * ld, hipMemcpyHostToDevice, L.up));
+        s->raw = L.raw.as<float>();
         if (band->balanced) {
-            HIPCHK(c, c->bal.reserve(sizeof(double) * n * ld));
-            HIPCHK(c, hipMemcpyAsync(c->bal.p, band->balanced, sizeof(double) * n * ld, hipMemcpyHostToDevice, c->stream));
-            s->bal = c->bal.as<double>();
+            HIPCHK(c, L.bal.reserve(sizeof(double) * n * ld));
+            HIPCHK(c, hipMemcpyAsync(L.bal.p, band->balanced, sizeof(double) * n * ld, hipMemcpyHostToDevice, L.up));
+            s->bal = L.bal.as<double>();
         }
         if (band->weight) {
-            HIPCHK(c, c->weight.reserve(sizeof(double) * n));
-            HIPCHK(c, hipMemcpyAsync(c->weight.p, band->weight, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-            s->weight = c->weight.as<double>();
+            HIPCHK(c, L.weight.reserve(sizeof(double) * n));
+            HIPCHK(c, hipMemcpyAsync(L.weight.p, band->weight, sizeof(double) * n, hipMemcpyHostToDevice, L.up));
+            s->weight = L.weight.as<double>();
         }
         if (!derive) {
-            HIPCHK(c, c->IR.reserve(sizeof(double) * num));
-            HIPCHK(c, hipMemcpyAsync(c->IR.p, band->IR, sizeof(double) * num, hipMemcpyHostToDevice, c->stream));
-            s->IR = c->IR.as<double>();
-            HIPCHK(c, c->b1.reserve(sizeof(double) * n));
-            HIPCHK(c, hipMemcpyAsync(c->b1.p, band->bias1, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-            s->b1 = c->b1.as<double>();
+            HIPCHK(c, L.IR.reserve(sizeof(double) * num));
+            HIPCHK(c, hipMemcpyAsync(L.IR.p, band->IR, sizeof(double) * num, hipMemcpyHostToDevice, L.up));
+            s->IR = L.IR.as<double>();
+            HIPCHK(c, L.b1.reserve(sizeof(double) * n));
+            HIPCHK(c, hipMemcpyAsync(L.b1.p, band->bias1, sizeof(double) * n, hipMemcpyHostToDevice, L.up));
+            s->b1 = L.b1.as<double>();
             if (band->bias2 == band->bias1) s->b2 = s->b1;
             else {
-                HIPCHK(c, c->b2.reserve(sizeof(double) * n));
-                HIPCHK(c, hipMemcpyAsync(c->b2.p, band->bias2, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
-                s->b2 = c->b2.as<double>();
+                HIPCHK(c, L.b2.reserve(sizeof(double) * n));
+                HIPCHK(c, hipMemcpyAsync(L.b2.p, band->bias2, sizeof(double) * n, hipMemcpyHostToDevice, L.up));
+                s->b2 = L.b2.as<double>();
             }
         }
     }
+    if (!band->on_device) {      // the kernels wait for the uploads, not the other way round
+        HIPCHK(c, hipEventRecord(L.ev_up, L.up));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, L.ev_up, 0));
+    }
     if (derive) {
         const size_t nparts = (n + 127) / 128;
-        HIPCHK(c, c->IR.reserve(sizeof(double) * num));
-        HIPCHK(c, c->b1.reserve(sizeof(double) * n));
-        HIPCHK(c, c->psum.reserve(sizeof(double) * nparts * num));
-        HIPCHK(c, c->pnan.reserve(sizeof(unsigned) * nparts * num));
-        hpk_launch_prep(s->raw, s->weight, (int)n, (int)num, (int64_t)ld, mw, c->psum.as<double>(), c->pnan.as<unsigned>(),
-                        c->IR.as<double>(), c->b1.as<double>(), c->stream);
+        HIPCHK(c, L.IR.reserve(sizeof(double) * num));
+        HIPCHK(c, L.b1.reserve(sizeof(double) * n));
+        HIPCHK(c, L.psum.reserve(sizeof(double) * nparts * num));
+        HIPCHK(c, L.pnan.reserve(sizeof(unsigned) * nparts * num));
+        hpk_launch_prep(s->raw, s->weight, (int)n, (int)num, (int64_t)ld, mw, L.psum.as<double>(), L.pnan.as<unsigned>(),
+                        L.IR.as<double>(), L.b1.as<double>(), c->stream);
         HIPCHK(c, hipGetLastError());
-        s->IR = c->IR.as<double>();
-        s->b1 = c->b1.as<double>();
+        s->IR = L.IR.as<double>();
+        s->b1 = L.b1.as<double>();
         s->b2 = s->b1;
     }
     return HPK_OK;
@@ -374,62 +407,145 @@ void hpk_result_free(hpk_result* res) {
     if (res) delete reinterpret_cast<ResultBox*>(res);
 }
 
-int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_result** out) {
-    if (!c) return HPK_ERR_INVALID;
-    if (!out || !prm) return fail(c, HPK_ERR_INVALID, "params / out is NULL");
-    *out = nullptr;
-    int rc = check_band(c, band);
-    if (rc != HPK_OK) return rc;
-    (void)hipSetDevice(c->device);
-    const double t_begin = now_ms();
+}  // extern "C"
 
+// One chromosome in flight.
+struct hpk_job {
+    hpk_ctx* ctx = nullptr;
+    int lane = -1;
+    hpk_params prm;
+    int32_t n = 0, num = 0;
+    int64_t ld = 0;
+    Staged in;
+    HpkStencilArgs sa;
+    size_t off_rowlive = 0, off_inl = 0, head_bytes = 0, off_cnt = 0, off_cu = 0, dense_elems = 0;
+    int64_t cap = 0, band_px = 0, ldo = 0;
+    int nsets = 0, TR = 0, TC = 0, rounds = 3;
+    bool sums = false, dense = false, do_score = true, phases = false;
+    double t_begin = 0.0;
+    ResultBox* box = nullptr;
+    ~hpk_job() { delete box; }
+};
+
+namespace {
+
+// scoring + BH-cut tightening + the head copy, on the job's lane (first pass and overflow rerun)
+int launch_scoring(hpk_ctx* c, hpk_job* j, int attempt) {
+    Lane& L = c->lane[j->lane];
+    const HpkDevPlan& plan = L.plan_host;
+    unsigned char* small = L.small.as<unsigned char>();
+    unsigned long long* d_nsurv = reinterpret_cast<unsigned long long*>(small + OFF_NSURV);
+    unsigned long long* d_nout = reinterpret_cast<unsigned long long*>(small + OFF_NOUT);
+    unsigned int* d_fam_m = reinterpret_cast<unsigned int*>(small + OFF_FAM_M);
+    unsigned int* d_fam_f = reinterpret_cast<unsigned int*>(small + OFF_FAM_F);
+    unsigned int* d_cnt = reinterpret_cast<unsigned int*>(small + j->off_cnt);
+    unsigned* d_chunkused = reinterpret_cast<unsigned*>(small + j->off_cu);
+    const HpkStencilArgs& sa = j->sa;
+    if (j->do_score) {
+        const int64_t cap = j->cap;
+        HIPCHK(c, L.surv.reserve(sizeof(HpkSurv) * (size_t)cap * HPK_NREG));
+        HIPCHK(c, L.surv2.reserve(sizeof(HpkSurv) * (size_t)cap * HPK_NREG));
+        if (attempt > 0) {       // overflow rerun: the chunk table no longer fits the zero block
+            const size_t cu_bytes = sizeof(unsigned) * (size_t)(cap / 256 * HPK_NREG + 1);
+            HIPCHK(c, L.chunkused.reserve(cu_bytes));
+            HIPCHK(c, hipMemsetAsync(L.chunkused.p, 0, cu_bytes, c->stream));
+            HIPCHK(c, hipMemsetAsync(small + OFF_NSURV, 0, SMALL_BYTES - OFF_NSURV, c->stream));
+            HIPCHK(c, hipMemsetAsync(small + j->off_cnt, 0, sizeof(unsigned) * HPK_NFAM * HPK_TIGHTEN_MAX, c->stream));
+            d_chunkused = L.chunkused.as<unsigned>();
+        }
+        HpkScoreArgs sc;
+        std::memset(&sc, 0, sizeof(sc));
+        sc.raw = j->in.raw; sc.bal = j->in.bal; sc.weight = j->in.weight; sc.plan = sa.plan;
+        sc.etab = L.etab.as<double>(); sc.eedge = L.eedge.as<double>(); sc.IR = j->in.IR; sc.b1 = j->in.b1; sc.b2 = j->in.b2;
+        sc.frozen = reinterpret_cast<int32_t*>(small + OFF_FROZEN);
+        sc.bounds = c->d_bounds.as<double>(); sc.ptab = c->d_ptab.as<double>();
+        sc.ptab_off = c->d_off.as<int32_t>(); sc.sfe = c->d_sfe.as<double>(); sc.sig = j->prm.sig;
+        sc.n = j->n; sc.num = j->num; sc.ld = j->ld; sc.ldo = j->ldo; sc.mw = plan.mw; sc.D = plan.D;
+        sc.rec_ent = sa.rec_ent; sc.rec_S = sa.rec_S; sc.rec_W = sa.rec_W; sc.tile_cnt = sa.tile_cnt;
+        sc.tilecap = sa.tilecap; sc.rec_stride = sa.rec_stride; sc.ntiles = sa.ntiles;
+        sc.TR = j->TR; sc.TC = j->TC; sc.J = sa.J; sc.W = plan.W;
+        sc.fam_m = d_fam_m; sc.fam_f = d_fam_f;
+        sc.emax_bits = reinterpret_cast<unsigned long long*>(small + OFF_EMAX);
+        sc.nvalid = reinterpret_cast<unsigned long long*>(small + OFF_NVALID);
+        sc.nsurv = d_nsurv;
+        { const char* e = std::getenv("HPK_DBG_SCORE"); sc.dbg = e ? std::atoi(e) : 0; }
+        sc.cap = cap; sc.surv = L.surv.as<HpkSurv>(); sc.chunk_used = d_chunkused;
+        hpk_launch_score(sc, c->cus, c->stream);
+        HIPCHK(c, hipGetLastError());
+        if (j->phases) (void)hipEventRecord(L.ev[4], c->stream);
+        hpk_launch_tighten(sc.surv, d_nsurv, cap, sc.chunk_used, d_fam_m, d_fam_f, d_cnt, j->prm.sig, j->rounds,
+                           reinterpret_cast<HpkSurv*>(small + j->off_inl), HEAD_INLINE, L.surv2.as<HpkSurv>(), d_nout,
+                           c->cus, c->stream);
+        HIPCHK(c, hipGetLastError());
+    } else {
+        if (j->phases) (void)hipEventRecord(L.ev[4], c->stream);
+    }
+    if (j->phases) (void)hipEventRecord(L.ev[5], c->stream);
+    // gap rows are produced by the stencil kernel (hpk_gap remains as an independent check for the tests)
+    if (attempt == 0 && std::getenv("HPK_GAP_KERNEL")) {
+        hpk_launch_gap(j->in.raw, j->in.bal, j->in.weight, j->n, j->num, j->ld, plan.mw, small + j->off_rowlive, c->stream);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (j->phases) (void)hipEventRecord(L.ev[6], c->stream);
+    // counters, row flags and the first survivors in one copy into pinned memory
+    HIPCHK(c, hipMemcpyAsync(L.h_head, small, j->head_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipEventRecord(L.ev_done, c->stream));
+    return HPK_OK;
+}
+
+int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* prm) {
+    Lane& L = c->lane[j->lane];
     hpk_params key = *prm;
     key.flags = 0; key.reserved = 0;
     for (int i = key.npairs > 0 ? key.npairs : 0; i < HPK_MAX_PAIRS; ++i) { key.pw[i] = 0; key.ww[i] = 0; }
-    const bool plan_hit = c->plan_valid && std::memcmp(&key, &c->plan_key, sizeof(key)) == 0;
+    const bool plan_hit = L.plan_valid && std::memcmp(&key, &L.plan_key, sizeof(key)) == 0;
+    int rc;
     if (!plan_hit) {
         char msg[256];
-        c->plan_valid = false;
-        rc = hpk_build_plan(prm, &c->plan_host, msg);
+        L.plan_valid = false;
+        rc = hpk_build_plan(prm, &L.plan_host, msg);
         if (rc != HPK_OK) return fail(c, rc, "%s", msg);
     }
-    const HpkDevPlan& plan = c->plan_host;
+    const HpkDevPlan& plan = L.plan_host;
     const int W = plan.W, mw = plan.mw, D = plan.D;
     const int n = band->n, num = band->num;
     const int TR = HPK_LR - 2 * W - 1, TC = HPK_LC - 2 * W - 1;
     if (D < mw) return fail(c, HPK_ERR_INVALID, "maxapart / res (%d) is below min(ww) (%d)", D, mw);
-    const int nsets = (plan.mode == HPK_MODE_BHFDR) ? 1 : 2 * plan.npairs;
-    const bool sums = (prm->flags & HPK_FLAG_DENSE_SUMS) != 0;
-    const bool dense = sums || (prm->flags & HPK_FLAG_DENSE_E) != 0;
-    const bool do_score = (prm->flags & HPK_FLAG_NO_SCORE) == 0;
+    j->prm = *prm; j->n = n; j->num = num; j->ld = band->ld; j->TR = TR; j->TC = TC;
+    j->nsets = (plan.mode == HPK_MODE_BHFDR) ? 1 : 2 * plan.npairs;
+    j->sums = (prm->flags & HPK_FLAG_DENSE_SUMS) != 0;
+    j->dense = j->sums || (prm->flags & HPK_FLAG_DENSE_E) != 0;
+    j->do_score = (prm->flags & HPK_FLAG_NO_SCORE) == 0;
+    j->phases = (prm->flags & HPK_FLAG_PHASE_TIMING) != 0;
+    j->rounds = std::getenv("HPK_ROUNDS") ? std::atoi(std::getenv("HPK_ROUNDS")) : 3;
+    const bool sums = j->sums, dense = j->dense;
 
-    ResultBox* box = new ResultBox();
-    std::memset(&box->pub, 0, sizeof(box->pub));
-    hpk_result& R = box->pub;
-    struct Guard { ResultBox* b; ~Guard() { delete b; } } guard{box};
+    j->box = new ResultBox();
+    std::memset(&j->box->pub, 0, sizeof(j->box->pub));
 
     // ---- inputs
-    Staged in;
-    (void)hipEventRecord(c->ev[0], c->stream);
-    rc = stage_inputs(c, band, plan.mw, &in);
+    if (j->phases) (void)hipEventRecord(L.ev[0], c->stream);
+    rc = stage_inputs(c, L, band, plan.mw, &j->in);
     if (rc != HPK_OK) return rc;
+    const Staged& in = j->in;
     if (!plan_hit) {
-        HIPCHK(c, c->plan.reserve(sizeof(HpkDevPlan)));
-        HIPCHK(c, hipMemcpyAsync(c->plan.p, &c->plan_host, sizeof(HpkDevPlan), hipMemcpyHostToDevice, c->stream));
-        c->plan_key = key;
-        c->plan_valid = true;
+        HIPCHK(c, L.plan.reserve(sizeof(HpkDevPlan)));
+        HIPCHK(c, hipMemcpyAsync(L.plan.p, &L.plan_host, sizeof(HpkDevPlan), hipMemcpyHostToDevice, c->stream));
+        L.plan_key = key;
+        L.plan_valid = true;
     }
-    HIPCHK(c, c->etab.reserve(sizeof(double) * std::max<size_t>((size_t)plan.nsteps * 2 * (D + 1), 1)));
-    HIPCHK(c, c->eedge.reserve(sizeof(double) * std::max<size_t>((size_t)2 * W * plan.nsteps * 2 * (D + 1), 1)));
-    hpk_launch_etab(c->plan.as<HpkDevPlan>(), plan.nsteps, D, W, in.IR, n, num, c->etab.as<double>(), c->eedge.as<double>(),
+    HIPCHK(c, L.etab.reserve(sizeof(double) * std::max<size_t>((size_t)plan.nsteps * 2 * (D + 1), 1)));
+    HIPCHK(c, L.eedge.reserve(sizeof(double) * std::max<size_t>((size_t)2 * W * plan.nsteps * 2 * (D + 1), 1)));
+    hpk_launch_etab(L.plan.as<HpkDevPlan>(), plan.nsteps, D, W, in.IR, n, num, L.etab.as<double>(), L.eedge.as<double>(),
                     c->stream);
     HIPCHK(c, hipGetLastError());
     const int64_t ldo = ((int64_t)(D + 1) + 31) / 32 * 32;
     const size_t dense_elems = (size_t)plan.nslots * (size_t)n * (size_t)ldo;
+    j->ldo = ldo; j->dense_elems = dense_elems;
     if (dense) {
-        HIPCHK(c, c->dE.reserve(sizeof(double2) * dense_elems));
-        HIPCHK(c, c->dW.reserve(dense_elems));
-        if (sums) HIPCHK(c, c->dS.reserve(sizeof(double4) * dense_elems));
+        HIPCHK(c, L.dE.reserve(sizeof(double2) * dense_elems));
+        HIPCHK(c, L.dW.reserve(dense_elems));
+        if (sums) HIPCHK(c, L.dS.reserve(sizeof(double4) * dense_elems));
     }
     // One block, zero-filled by a single memset:
     //   head (one D2H copy):  counters | row-has-signal flags [n] | first HEAD_INLINE compacted survivors
@@ -439,9 +555,11 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     const int grid_ = std::max(8, std::min((c->cus / 8) * 8, ((ntiles_ + 7) / 8) * 8));
     int64_t band_px = 0;                    // pixels with mw <= d <= D inside the matrix
     for (int d = mw; d <= std::min(D, num - 1); ++d) if (n - d > 0) band_px += n - d;
+    j->band_px = band_px;
     // survivor capacity per region; every scoring wave may hold one partly filled 256-record chunk
-    int64_t cap = (std::max<int64_t>(1 << 16, band_px * nsets / 6) + (int64_t)c->cus * 8 * 4 * 256 * 2) / HPK_NREG;
+    int64_t cap = (std::max<int64_t>(1 << 16, band_px * j->nsets / 6) + (int64_t)c->cus * 8 * 4 * 256 * 2) / HPK_NREG;
     cap = (cap + 255) / 256 * 256;
+    j->cap = cap;
     auto up256 = [](size_t v) { return (v + 255) / 256 * 256; };
     const size_t off_rowlive = up256(SMALL_BYTES);
     const size_t off_inl = up256(off_rowlive + (size_t)n);
@@ -451,125 +569,87 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     const size_t off_cnt = up256(off_tc + sizeof(unsigned) * (size_t)ntiles_);
     const size_t off_cu = up256(off_cnt + sizeof(unsigned) * HPK_NFAM * HPK_TIGHTEN_MAX);
     const size_t zero_bytes = (off_cu + sizeof(unsigned) * (size_t)(cap / 256 * HPK_NREG + 1) + 4095) / 4096 * 4096;
-    HIPCHK(c, c->small.reserve(zero_bytes));
-    HIPCHK(c, hipMemsetAsync(c->small.p, 0, zero_bytes, c->stream));
-    if (c->h_head_cap < head_bytes) {
-        if (c->h_head) (void)hipHostFree(c->h_head);
-        c->h_head = nullptr; c->h_head_cap = 0;
-        HIPCHK(c, hipHostMalloc(&c->h_head, head_bytes + head_bytes / 4, hipHostMallocDefault));
-        c->h_head_cap = head_bytes + head_bytes / 4;
+    j->off_rowlive = off_rowlive; j->off_inl = off_inl; j->head_bytes = head_bytes; j->off_cnt = off_cnt; j->off_cu = off_cu;
+    HIPCHK(c, L.small.reserve(zero_bytes));
+    HIPCHK(c, hipMemsetAsync(L.small.p, 0, zero_bytes, c->stream));
+    if (L.h_head_cap < head_bytes) {
+        if (L.h_head) (void)hipHostFree(L.h_head);
+        L.h_head = nullptr; L.h_head_cap = 0;
+        HIPCHK(c, hipHostMalloc(&L.h_head, head_bytes + head_bytes / 4, hipHostMallocDefault));
+        L.h_head_cap = head_bytes + head_bytes / 4;
     }
     if (dense) {   // pixels outside the band are never written by the kernel
-        HIPCHK(c, hipMemsetAsync(c->dE.p, 0, sizeof(double2) * dense_elems, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->dW.p, 0, dense_elems, c->stream));
-        if (sums) HIPCHK(c, hipMemsetAsync(c->dS.p, 0, sizeof(double4) * dense_elems, c->stream));
+        HIPCHK(c, hipMemsetAsync(L.dE.p, 0, sizeof(double2) * dense_elems, c->stream));
+        HIPCHK(c, hipMemsetAsync(L.dW.p, 0, dense_elems, c->stream));
+        if (sums) HIPCHK(c, hipMemsetAsync(L.dS.p, 0, sizeof(double4) * dense_elems, c->stream));
     }
-    (void)hipEventRecord(c->ev[1], c->stream);
 
-    unsigned char* small = c->small.as<unsigned char>();
+    unsigned char* small = L.small.as<unsigned char>();
     unsigned long long* d_hist = reinterpret_cast<unsigned long long*>(small + OFF_HIST);
     int32_t* d_frozen = reinterpret_cast<int32_t*>(small + OFF_FROZEN);
     int32_t* d_err = reinterpret_cast<int32_t*>(small + OFF_ERR);
     int32_t* d_exec = reinterpret_cast<int32_t*>(small + OFF_EXEC);
-    unsigned long long* d_nsurv = reinterpret_cast<unsigned long long*>(small + OFF_NSURV);
-    unsigned long long* d_nvalid = reinterpret_cast<unsigned long long*>(small + OFF_NVALID);
-    unsigned long long* d_emax = reinterpret_cast<unsigned long long*>(small + OFF_EMAX);
 
     // ---- stencil
-    HpkStencilArgs sa;
+    HpkStencilArgs& sa = j->sa;
     std::memset(&sa, 0, sizeof(sa));
     sa.raw = in.raw; sa.bal = in.bal; sa.weight = in.weight;
-    sa.plan = c->plan.as<HpkDevPlan>();
+    sa.plan = L.plan.as<HpkDevPlan>();
     sa.hist = d_hist;
     sa.n = n; sa.num = num; sa.ld = band->ld; sa.ldo = ldo; sa.W = W; sa.mw = mw; sa.D = D; sa.TR = TR; sa.TC = TC;
-    sa.J = (TR + D - mw + TC - 1) / TC;
-    const int RB = (n + TR - 1) / TR;
-    sa.ntiles = RB * sa.J;
+    sa.J = J_;
+    sa.ntiles = ntiles_;
     sa.chunk = (sa.ntiles + 7) / 8;
     { const char* e = std::getenv("HPK_DBG_STOP"); sa.dbg_stop = e ? std::atoi(e) : 0; }
     sa.grid = std::max(8, std::min((c->cus / 8) * 8, ((sa.chunk + 0) * 8)));
     sa.hist_part = reinterpret_cast<unsigned*>(small + off_hp);
     sa.tilecap = TR * TC;
     sa.rec_stride = (int64_t)sa.ntiles * sa.tilecap;
-    HIPCHK(c, c->recE.reserve(sizeof(unsigned) * (size_t)sa.rec_stride));
-    HIPCHK(c, c->recS.reserve(sizeof(double2) * (size_t)sa.rec_stride * plan.nslots));
-    HIPCHK(c, c->recW.reserve((size_t)sa.rec_stride * plan.nslots));
-    sa.rec_ent = c->recE.as<unsigned>(); sa.rec_S = c->recS.as<double2>(); sa.rec_W = c->recW.as<uint8_t>();
+    HIPCHK(c, L.recE.reserve(sizeof(unsigned) * (size_t)sa.rec_stride));
+    HIPCHK(c, L.recS.reserve(sizeof(double2) * (size_t)sa.rec_stride * plan.nslots));
+    HIPCHK(c, L.recW.reserve((size_t)sa.rec_stride * plan.nslots));
+    sa.rec_ent = L.recE.as<unsigned>(); sa.rec_S = L.recS.as<double2>(); sa.rec_W = L.recW.as<uint8_t>();
     sa.tile_cnt = reinterpret_cast<unsigned*>(small + off_tc);
     sa.gap = small + off_rowlive;
-    (void)hipEventRecord(c->ev[1], c->stream);
+    (void)hipEventRecord(L.ev[1], c->stream);
     hpk_launch_stencil(sa, in.bal != nullptr, plan.simple_reads != 0 && !std::getenv("HPK_GENERIC_SEARCH"), c->stream);
     HIPCHK(c, hipGetLastError());
-    (void)hipEventRecord(c->ev[2], c->stream);
+    (void)hipEventRecord(L.ev[2], c->stream);
     hpk_launch_freeze(sa.plan, d_hist, sa.hist_part, sa.grid, d_frozen, d_exec, d_err, c->stream);
     HIPCHK(c, hipGetLastError());
-    (void)hipEventRecord(c->ev[3], c->stream);
+    if (j->phases) (void)hipEventRecord(L.ev[3], c->stream);
+    return launch_scoring(c, j, 0);
+}
 
-    R.band_px = band_px;
-    R.stencil_tiles = sa.ntiles;
-
-    // ---- scoring + BH cut tightening
-    unsigned long long* d_nout = reinterpret_cast<unsigned long long*>(small + OFF_NOUT);
-    unsigned int* d_fam_m = reinterpret_cast<unsigned int*>(small + OFF_FAM_M);
-    unsigned int* d_fam_f = reinterpret_cast<unsigned int*>(small + OFF_FAM_F);
-    unsigned int* d_cnt = reinterpret_cast<unsigned int*>(small + off_cnt);
-    unsigned* d_chunkused = reinterpret_cast<unsigned*>(small + off_cu);
-    const unsigned char* hsmall = static_cast<const unsigned char*>(c->h_head);
-    const int rounds = std::getenv("HPK_ROUNDS") ? std::atoi(std::getenv("HPK_ROUNDS")) : 3;
-    (void)hipEventRecord(c->ev[3], c->stream);
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        if (do_score) {
-            HIPCHK(c, c->surv.reserve(sizeof(HpkSurv) * (size_t)cap * HPK_NREG));
-            HIPCHK(c, c->surv2.reserve(sizeof(HpkSurv) * (size_t)cap * HPK_NREG));
-            if (attempt == 1) {      // overflow rerun: the chunk table no longer fits the zero block
-                HIPCHK(c, c->chunkused.reserve(sizeof(unsigned) * (size_t)(cap / 256 * HPK_NREG + 1)));
-                HIPCHK(c, hipMemsetAsync(c->chunkused.p, 0, sizeof(unsigned) * (size_t)(cap / 256 * HPK_NREG + 1), c->stream));
-                d_chunkused = c->chunkused.as<unsigned>();
-            }
-            HpkScoreArgs sc;
-            std::memset(&sc, 0, sizeof(sc));
-            sc.raw = in.raw; sc.bal = in.bal; sc.weight = in.weight; sc.plan = sa.plan;
-            sc.etab = c->etab.as<double>(); sc.eedge = c->eedge.as<double>(); sc.IR = in.IR; sc.b1 = in.b1; sc.b2 = in.b2;
-            sc.frozen = d_frozen; sc.bounds = c->d_bounds.as<double>(); sc.ptab = c->d_ptab.as<double>();
-            sc.ptab_off = c->d_off.as<int32_t>(); sc.sfe = c->d_sfe.as<double>(); sc.sig = prm->sig;
-            sc.n = n; sc.num = num; sc.ld = band->ld; sc.ldo = ldo; sc.mw = mw; sc.D = D;
-            sc.rec_ent = sa.rec_ent; sc.rec_S = sa.rec_S; sc.rec_W = sa.rec_W; sc.tile_cnt = sa.tile_cnt;
-            sc.tilecap = sa.tilecap; sc.rec_stride = sa.rec_stride; sc.ntiles = sa.ntiles;
-            sc.TR = TR; sc.TC = TC; sc.J = sa.J; sc.W = W;
-            sc.fam_m = d_fam_m; sc.fam_f = d_fam_f; sc.emax_bits = d_emax; sc.nvalid = d_nvalid; sc.nsurv = d_nsurv;
-            { const char* e = std::getenv("HPK_DBG_SCORE"); sc.dbg = e ? std::atoi(e) : 0; }
-            sc.cap = cap; sc.surv = c->surv.as<HpkSurv>(); sc.chunk_used = d_chunkused;
-            hpk_launch_score(sc, c->cus, c->stream);
-            HIPCHK(c, hipGetLastError());
-            (void)hipEventRecord(c->ev[4], c->stream);
-            hpk_launch_tighten(sc.surv, d_nsurv, cap, sc.chunk_used, d_fam_m, d_fam_f, d_cnt, prm->sig, rounds,
-                               reinterpret_cast<HpkSurv*>(small + off_inl), HEAD_INLINE, c->surv2.as<HpkSurv>(), d_nout,
-                               c->cus, c->stream);
-            HIPCHK(c, hipGetLastError());
-        } else {
-            (void)hipEventRecord(c->ev[4], c->stream);
-        }
-        (void)hipEventRecord(c->ev[5], c->stream);
-        // gap rows are produced by the stencil kernel (hpk_gap remains as an independent check for the tests)
-        if (attempt == 0 && std::getenv("HPK_GAP_KERNEL")) {
-            hpk_launch_gap(in.raw, in.bal, in.weight, n, num, band->ld, mw, small + off_rowlive, c->stream);
-            HIPCHK(c, hipGetLastError());
-        }
-        (void)hipEventRecord(c->ev[6], c->stream);
-        // counters, row flags and the first survivors in one copy into pinned memory
-        HIPCHK(c, hipMemcpyAsync(c->h_head, small, head_bytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+int collect_impl(hpk_ctx* c, hpk_job* j, hpk_result** out) {
+    Lane& L = c->lane[j->lane];
+    const HpkDevPlan& plan = L.plan_host;
+    const hpk_params* prm = &j->prm;
+    const int n = j->n, num = j->num, nsets = j->nsets, mw = plan.mw, D = plan.D, TR = j->TR, TC = j->TC;
+    const bool sums = j->sums, dense = j->dense, do_score = j->do_score;
+    const size_t off_rowlive = j->off_rowlive, off_inl = j->off_inl, dense_elems = j->dense_elems;
+    const int64_t ldo = j->ldo;
+    const HpkStencilArgs& sa = j->sa;
+    const Staged& in = j->in;
+    ResultBox* box = j->box;
+    hpk_result& R = box->pub;
+    (void)num; (void)mw;
+    const unsigned char* hsmall = static_cast<const unsigned char*>(L.h_head);
+    for (int attempt = 0;; ++attempt) {
+        HIPCHK(c, hipEventSynchronize(L.ev_done));       // this chromosome only; the next one keeps running
         unsigned long long ns = 0;              // fullest region
         for (int rg = 0; rg < HPK_NREG; ++rg)
             ns = std::max(ns, reinterpret_cast<const unsigned long long*>(hsmall + OFF_NSURV)[rg * HPK_REG_STRIDE]);
-        if (!do_score || (int64_t)ns <= cap) break;
+        if (!do_score || (int64_t)ns <= j->cap) break;
         if (attempt == 1) return fail(c, HPK_ERR_NOMEM, "survivor buffer overflow");
-        cap = ((int64_t)ns * 2 + 1024 + 255) / 256 * 256;      // rerun the scoring with room for everything
-        HIPCHK(c, hipMemsetAsync(small + OFF_NSURV, 0, SMALL_BYTES - OFF_NSURV, c->stream));
-        HIPCHK(c, hipMemsetAsync(small + off_cnt, 0, sizeof(unsigned) * HPK_NFAM * HPK_TIGHTEN_MAX, c->stream));
+        j->cap = ((int64_t)ns * 2 + 1024 + 255) / 256 * 256;      // rerun the scoring with room for everything
+        int rc = launch_scoring(c, j, 1);
+        if (rc != HPK_OK) return rc;
     }
     box->gap.resize(n);
     for (int r = 0; r < n; ++r) box->gap[r] = hsmall[off_rowlive + r] ? 0 : 1;
+    R.band_px = j->band_px;
+    R.stencil_tiles = sa.ntiles;
 
     // ---- results to host
     const unsigned long long* h_hist = reinterpret_cast<const unsigned long long*>(hsmall + OFF_HIST);
@@ -610,8 +690,10 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
         std::vector<HpkSurv> rest;
         if (ns > HEAD_INLINE) {
             rest.resize(ns - HEAD_INLINE);
-            HIPCHK(c, hipMemcpyAsync(rest.data(), c->surv2.p, sizeof(HpkSurv) * (ns - HEAD_INLINE), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipStreamSynchronize(c->stream));
+            // beyond the inlined head: fetched on the lane's own (idle) copy stream, so the next chromosome's kernels
+            // on the compute stream are not waited for
+            HIPCHK(c, hipMemcpyAsync(rest.data(), L.surv2.p, sizeof(HpkSurv) * (ns - HEAD_INLINE), hipMemcpyDeviceToHost, L.up));
+            HIPCHK(c, hipStreamSynchronize(L.up));
         }
         auto rec_at = [&](size_t i) -> const HpkSurv& { return i < HEAD_INLINE ? head[i] : rest[i - HEAD_INLINE]; };
         sv.resize(ns);
@@ -624,18 +706,18 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
         HpkDenseArgs da;
         da.rec_ent = sa.rec_ent; da.rec_S = sa.rec_S; da.rec_W = sa.rec_W; da.tile_cnt = sa.tile_cnt;
         da.tilecap = sa.tilecap; da.rec_stride = sa.rec_stride; da.ntiles = sa.ntiles; da.TR = TR; da.TC = TC; da.J = sa.J;
-        da.plan = sa.plan; da.etab = c->etab.as<double>(); da.eedge = c->eedge.as<double>();
+        da.plan = sa.plan; da.etab = L.etab.as<double>(); da.eedge = L.eedge.as<double>();
         da.IR = in.IR; da.b1 = in.b1; da.b2 = in.b2; da.n = n; da.num = num; da.ldo = ldo; da.mw = mw; da.D = D;
-        da.dE = c->dE.as<double2>(); da.dW = c->dW.as<uint8_t>(); da.dS = sums ? c->dS.as<double4>() : nullptr;
+        da.dE = L.dE.as<double2>(); da.dW = L.dW.as<uint8_t>(); da.dS = sums ? L.dS.as<double4>() : nullptr;
         hpk_launch_dense(da, c->stream);
         HIPCHK(c, hipGetLastError());
         box->denseE.resize(dense_elems * 2);
         box->denseW.resize(dense_elems);
-        HIPCHK(c, hipMemcpyAsync(box->denseE.data(), c->dE.p, sizeof(double2) * dense_elems, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(box->denseW.data(), c->dW.p, dense_elems, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(box->denseE.data(), L.dE.p, sizeof(double2) * dense_elems, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(box->denseW.data(), L.dW.p, dense_elems, hipMemcpyDeviceToHost, c->stream));
         if (sums) {
             box->denseS.resize(dense_elems * 4);
-            HIPCHK(c, hipMemcpyAsync(box->denseS.data(), c->dS.p, sizeof(double4) * dense_elems, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(box->denseS.data(), L.dS.p, sizeof(double4) * dense_elems, hipMemcpyDeviceToHost, c->stream));
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
         R.dense_ld = ldo;
@@ -715,19 +797,78 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     if (std::getenv("HPK_HOST_PROF")) std::fprintf(stderr, "[hpk host] total host_bh=%.3f d2h=%.3f\n", t_end - t_d2h1, t_d2h1 - t_d2h0);
 
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) == hipSuccess) R.ms_h2d = ms;
-    if (hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) R.ms_stencil = ms;
-    if (hipEventElapsedTime(&ms, c->ev[2], c->ev[3]) == hipSuccess) R.ms_freeze = ms;
-    if (hipEventElapsedTime(&ms, c->ev[3], c->ev[4]) == hipSuccess) R.ms_score = ms;
-    if (hipEventElapsedTime(&ms, c->ev[4], c->ev[5]) == hipSuccess) R.ms_tighten = ms;
-    if (hipEventElapsedTime(&ms, c->ev[5], c->ev[6]) == hipSuccess) R.ms_gap = ms;
+    if (hipEventElapsedTime(&ms, L.ev[1], L.ev[2]) == hipSuccess) R.ms_stencil = ms;
+    if (j->phases) {
+        if (hipEventElapsedTime(&ms, L.ev[0], L.ev[1]) == hipSuccess) R.ms_h2d = ms;
+        if (hipEventElapsedTime(&ms, L.ev[2], L.ev[3]) == hipSuccess) R.ms_freeze = ms;
+        if (hipEventElapsedTime(&ms, L.ev[3], L.ev[4]) == hipSuccess) R.ms_score = ms;
+        if (hipEventElapsedTime(&ms, L.ev[4], L.ev[5]) == hipSuccess) R.ms_tighten = ms;
+        if (hipEventElapsedTime(&ms, L.ev[5], L.ev[6]) == hipSuccess) R.ms_gap = ms;
+    }
     R.ms_d2h = (float)(t_d2h1 - t_d2h0);
     R.ms_host_bh = (float)(t_end - t_d2h1);
-    R.ms_total = (float)(t_end - t_begin);
 
-    guard.b = nullptr;
+    R.ms_total = (float)(t_end - j->t_begin);
+    j->box = nullptr;
     *out = &box->pub;
     return HPK_OK;
+}
+
+int acquire_lane(hpk_ctx* c) {
+    for (int l = 0; l < HPK_LANES; ++l) if (!c->lane[l].busy) return l;
+    return -1;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hpk_pipeline_depth(void) { return HPK_LANES; }
+
+int hpk_submit_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_job** job) {
+    if (!c) return HPK_ERR_INVALID;
+    if (!job || !prm) return fail(c, HPK_ERR_INVALID, "params / job is NULL");
+    *job = nullptr;
+    int rc = check_band(c, band);
+    if (rc != HPK_OK) return rc;
+    const int lane = acquire_lane(c);
+    if (lane < 0) return fail(c, HPK_ERR_BUSY, "all %d lanes hold a chromosome in flight: collect one first", HPK_LANES);
+    (void)hipSetDevice(c->device);
+    hpk_job* j = new hpk_job();
+    j->ctx = c; j->lane = lane; j->t_begin = now_ms();
+    rc = submit_impl(c, j, band, prm);
+    if (rc != HPK_OK) {
+        (void)hipStreamSynchronize(c->stream);
+        delete j;
+        return rc;
+    }
+    c->lane[lane].busy = true;
+    *job = j;
+    return HPK_OK;
+}
+
+int hpk_collect(hpk_ctx* c, hpk_job* job, hpk_result** out) {
+    if (!c || !job || job->ctx != c) return c ? fail(c, HPK_ERR_INVALID, "job does not belong to this context") : HPK_ERR_INVALID;
+    if (out) *out = nullptr;
+    (void)hipSetDevice(c->device);
+    hpk_result* res = nullptr;
+    int rc = collect_impl(c, job, &res);
+    if (rc != HPK_OK) (void)hipStreamSynchronize(c->stream);
+    c->lane[job->lane].busy = false;
+    delete job;
+    if (rc != HPK_OK) return rc;
+    if (out) *out = res; else hpk_result_free(res);
+    return HPK_OK;
+}
+
+int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_result** out) {
+    if (!c) return HPK_ERR_INVALID;
+    if (!out || !prm) return fail(c, HPK_ERR_INVALID, "params / out is NULL");
+    *out = nullptr;
+    hpk_job* job = nullptr;
+    int rc = hpk_submit_band(c, band, prm, &job);
+    if (rc != HPK_OK) return rc;
+    return hpk_collect(c, job, out);
 }
 
 int hpk_bruteforce_sums(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, int32_t step, const int32_t* rows,
@@ -743,19 +884,21 @@ int hpk_bruteforce_sums(hpk_ctx* c, const hpk_band* band, const hpk_params* prm,
     rc = hpk_build_plan(prm, &plan, msg);
     if (rc != HPK_OK) return fail(c, rc, "%s", msg);
     if (step < 0 || step >= plan.nsteps) return fail(c, HPK_ERR_INVALID, "step out of range");
+    if (c->lane[0].busy) return fail(c, HPK_ERR_BUSY, "lane 0 holds a chromosome in flight");
+    Lane& L = c->lane[0];
     Staged in;
-    rc = stage_inputs(c, band, plan.mw, &in);
+    rc = stage_inputs(c, L, band, plan.mw, &in);
     if (rc != HPK_OK) return rc;
-    c->plan_valid = false;
-    HIPCHK(c, c->plan.reserve(sizeof(HpkDevPlan)));
-    HIPCHK(c, hipMemcpyAsync(c->plan.p, &plan, sizeof(plan), hipMemcpyHostToDevice, c->stream));
+    L.plan_valid = false;
+    HIPCHK(c, L.plan.reserve(sizeof(HpkDevPlan)));
+    HIPCHK(c, hipMemcpyAsync(L.plan.p, &plan, sizeof(plan), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, c->tmpA.reserve(4 * (size_t)count));
     HIPCHK(c, c->tmpB.reserve(4 * (size_t)count));
     HIPCHK(c, c->tmpC.reserve(8 * 5 * (size_t)count));
     HIPCHK(c, hipMemcpyAsync(c->tmpA.p, rows, 4 * (size_t)count, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->tmpB.p, cols, 4 * (size_t)count, hipMemcpyHostToDevice, c->stream));
     HpkBruteArgs a;
-    a.raw = in.raw; a.bal = in.bal; a.weight = in.weight; a.IR = in.IR; a.plan = c->plan.as<HpkDevPlan>();
+    a.raw = in.raw; a.bal = in.bal; a.weight = in.weight; a.IR = in.IR; a.plan = L.plan.as<HpkDevPlan>();
     a.n = band->n; a.num = band->num; a.ld = band->ld; a.step = step;
     a.rows = c->tmpA.as<int32_t>(); a.cols = c->tmpB.as<int32_t>(); a.count = count; a.out = c->tmpC.as<double>();
     hpk_launch_brute(a, c->stream);

@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
 
     // Resolve histogram: 40k same-address atomics (one per wave and tile) serialise at ~90 per microsecond in L2 -
     // 0.46 ms, several times the kernel itself.  Instead the waves of the workgroup meet in LDS (the SAT is dead now)
-    // and the workgroup writes its partial counts with plain stores; hpk_hist_reduce sums the partials.
+    // and the workgroup writes its partial counts with plain stores; hpk_freeze sums the partials.
     unsigned* red = reinterpret_cast<unsigned*>(smem);
     red[wave * (HPK_MAX_STEPS + 1) + lane] = myhist;
     if (lane == 0) red[wave * (HPK_MAX_STEPS + 1) + HPK_MAX_STEPS] = mycand;
@@ -620,46 +620,22 @@ __global__ void __launch_bounds__(256) hpk_biases(const double* __restrict__ wei
 }
 
 // ------------------------------------------------------------------ local-expected tables (callers.py:66-72 + 175-198)
-// bE of step s / filter fl at an interior pixel depends on the diagonal only: sum over the window's diagonal offsets
-// of (cells at that offset, with multiplicity) * IR.  One thread per table entry, offsets added in ascending order.
-__global__ void __launch_bounds__(256) hpk_etab(const HpkDevPlan* __restrict__ plan, const double* __restrict__ IR, int num,
-                                                double* __restrict__ etab) {
-    const int D = plan->D, W = plan->W, mw = plan->mw;
-    const int total = plan->nsteps * 2 * (D + 1);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int d = i % (D + 1), sf = i / (D + 1);
-    const int16_t* cf = plan->ecoef[sf >> 1][sf & 1];
-    double acc = 0.0;
-    for (int k = 0; k <= 4 * W; ++k) {
-        const int kk = d + k - 2 * W;
-        const int c = cf[k];
-        if (c == 0 || kk < mw || kk >= num) continue;
-        acc += (double)c * IR[kk];
+// ------------------------------------------------------------------ freeze (one workgroup)
+// Column sums of the per-workgroup resolve histograms (wave w sums columns w, w + 16, ...; lanes stride over the
+// partials), then one thread replays the reference's frozen_w / break logic on the totals.
+__global__ void __launch_bounds__(1024) hpk_freeze(const HpkDevPlan* __restrict__ plan, const unsigned* __restrict__ hist_part,
+                                                   int nparts, unsigned long long* __restrict__ hist_out,
+                                                   int32_t* frozen, int32_t* executed, int32_t* err) {
+    __shared__ unsigned long long hist[HPK_MAX_STEPS + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k <= HPK_MAX_STEPS; k += 16) {
+        unsigned long long t = 0ull;
+        for (int p = lane; p < nparts; p += 64) t += hist_part[(int64_t)p * (HPK_MAX_STEPS + 1) + k];
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
+        if (lane == 0) { hist[k] = t; hist_out[k] = t; }
     }
-    etab[i] = acc;
-}
-
-// ------------------------------------------------------------------ resolve histogram: column sums of the per-tile partials
-__global__ void __launch_bounds__(256) hpk_hist_reduce(const unsigned* __restrict__ hist_part, int nparts,
-                                                       unsigned long long* __restrict__ hist) {
-    __shared__ unsigned long long red[256];
-    const int k = blockIdx.x;
-    unsigned long long t = 0ull;
-    for (int p = threadIdx.x; p < nparts; p += 256) t += hist_part[(int64_t)p * (HPK_MAX_STEPS + 1) + k];
-    red[threadIdx.x] = t;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) hist[k] = red[0];
-}
-
-// ------------------------------------------------------------------ freeze (one thread)
-__global__ void hpk_freeze(const HpkDevPlan* __restrict__ plan, const unsigned long long* __restrict__ hist,
-                           int32_t* frozen, int32_t* executed, int32_t* err) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (threadIdx.x != 0) return;
     const long long total = (long long)hist[HPK_HIST_NCAND];
     long long unres[HPK_KSLOTS];
     for (int q = 0; q < HPK_KSLOTS; ++q) unres[q] = total;
@@ -804,13 +780,16 @@ __device__ __forceinline__ void local_expected(const HpkDevPlan* __restrict__ pl
 // the summed multiplicity of the surviving cells on that anti-diagonal.  One wave per (side, e, step) and 64
 // diagonals: the taps are formed once in LDS (<= 2wi+1 cells each), then every lane runs <= 4wi+1 multiply-adds on an
 // LDS-staged IR window.
+// blockIdx.y >= 2 W nsteps: the unclipped (interior) table of step y - 2 W nsteps, same taps without clipping.
 __global__ void __launch_bounds__(64) hpk_etab_edge(const HpkDevPlan* __restrict__ plan, const double* __restrict__ IR, int n,
-                                                    int num, double* __restrict__ eedge) {
+                                                    int num, double* __restrict__ etab, double* __restrict__ eedge) {
     const int D = plan->D, W = plan->W, mw = plan->mw, ns = plan->nsteps;
     const int d = blockIdx.x * 64 + threadIdx.x;
     int t = blockIdx.y;
+    const bool interior = t >= 2 * W * ns;
+    if (interior) t -= 2 * W * ns;
     const int s = t % ns; t /= ns;
-    const int e = t % W, side = t / W;
+    const int e = interior ? 0 : t % W, side = interior ? 2 : t / W;
     const HpkDevStep& st = plan->steps[s];
     const int wi = st.wi;
     __shared__ int lm[HPK_MAX_W + 1];                    // ring multiplicities of this step
@@ -829,7 +808,7 @@ __global__ void __launch_bounds__(64) hpk_etab_edge(const HpkDevPlan* __restrict
         for (int di = -wi; di <= wi; ++di) {
             const int dj = di + off;
             if (di == 0 || dj == 0 || dj < -wi || dj > wi) continue;
-            if (side == 0 ? (e + di < 0) : (dj > e)) continue;          // rows above / columns right of the matrix
+            if (side == 0 ? (e + di < 0) : (side == 1 && dj > e)) continue;   // rows above / columns right of the matrix
             const int adi = di < 0 ? -di : di, adj = dj < 0 ? -dj : dj;
             const int m = lm[adi > adj ? adi : adj];
             ck += m;
@@ -845,6 +824,11 @@ __global__ void __launch_bounds__(64) hpk_etab_edge(const HpkDevPlan* __restrict
         const double v = lir[(int)threadIdx.x + tp];
         EK += tapK[tp] * v;
         EY += tapY[tp] * v;
+    }
+    if (interior) {
+        etab[(int64_t)(s * 2) * (D + 1) + d] = EK;
+        etab[(int64_t)(s * 2 + 1) * (D + 1) + d] = EY;
+        return;
     }
     const int64_t o = ((int64_t)((side * W + e) * ns + s) * 2) * (D + 1) + d;
     eedge[o] = EK;
@@ -1205,8 +1189,7 @@ void hpk_launch_dense(const HpkDenseArgs& a, hipStream_t st) {
 
 void hpk_launch_freeze(const HpkDevPlan* plan, unsigned long long* hist, const unsigned* hist_part, int nparts,
                        int32_t* frozen, int32_t* executed, int32_t* err, hipStream_t st) {
-    hipLaunchKernelGGL(hpk_hist_reduce, dim3(HPK_MAX_STEPS + 1), dim3(256), 0, st, hist_part, nparts, hist);
-    hipLaunchKernelGGL(hpk_freeze, dim3(1), dim3(64), 0, st, plan, hist, frozen, executed, err);
+    hipLaunchKernelGGL(hpk_freeze, dim3(1), dim3(1024), 0, st, plan, hist_part, nparts, hist, frozen, executed, err);
 }
 
 void hpk_launch_gap(const float* raw, const double* bal, const double* weight, int32_t n, int32_t num, int64_t ld,
@@ -1243,8 +1226,7 @@ void hpk_launch_etab(const HpkDevPlan* plan, int nsteps, int D, int W, const dou
                      double* eedge, hipStream_t st) {
     const int total = nsteps * 2 * (D + 1);
     if (total <= 0) return;
-    hipLaunchKernelGGL(hpk_etab, dim3((total + 255) / 256), dim3(256), 0, st, plan, IR, num, etab);
-    hipLaunchKernelGGL(hpk_etab_edge, dim3((D + 64) / 64, 2 * W * nsteps), dim3(64), 0, st, plan, IR, n, num, eedge);
+    hipLaunchKernelGGL(hpk_etab_edge, dim3((D + 64) / 64, 2 * W * nsteps + nsteps), dim3(64), 0, st, plan, IR, n, num, etab, eedge);
 }
 
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,

@@ -45,7 +45,8 @@ typedef enum {
     HPK_ERR_EMPTY_STEP = -4,   /* a widening step was entered with no unresolved candidate for its peak
                                   width - the reference raises here (callers.py:203-208, 487-492) */
     HPK_ERR_PLAN = -5,         /* (pw, ww, maxww) give a negative ring multiplicity; not representable */
-    HPK_ERR_NOMEM = -6
+    HPK_ERR_NOMEM = -6,
+    HPK_ERR_BUSY = -7          /* every lane of the context holds a chromosome in flight */
 } hpk_status;
 
 typedef enum {
@@ -56,7 +57,9 @@ typedef enum {
 enum {
     HPK_FLAG_DENSE_E = 1,      /* copy the dense per-slot local expected (E_K, E_Y) and resolving width back */
     HPK_FLAG_DENSE_SUMS = 2,   /* debug: also the four raw sums (bS_K, bE_K, bS_Y, bE_Y) at every candidate */
-    HPK_FLAG_NO_SCORE = 4      /* stop after the stencil (bench: time the donut kernel alone) */
+    HPK_FLAG_NO_SCORE = 4,     /* stop after the stencil (bench: time the donut kernel alone) */
+    HPK_FLAG_PHASE_TIMING = 8  /* also time upload / freeze / scoring / tightening (five more events on the compute
+                                  stream, ~6 us of idle each); ms_stencil, ms_d2h, ms_host_bh, ms_total are always filled */
 };
 
 /* hiccups(): pw/ww lists, maxww, sig, maxapart, res, min_local_reads (callers.py:44-46);
@@ -160,6 +163,19 @@ int  hpk_abi_version(void);
 /* The whole path for one chromosome.  *out is allocated by the library. */
 int  hpk_score_band(hpk_ctx* ctx, const hpk_band* band, const hpk_params* params, hpk_result** out);
 void hpk_result_free(hpk_result* res);
+
+/* The same path split in two, so that the caller's loop over chromosomes (scripts/pyHICCUPS:192-198 maps worker()
+ * over the chromosomes one after the other) can keep the GPU busy: hpk_submit_band enqueues the uploads, every
+ * kernel and the download of the result head on one of the context's hpk_pipeline_depth() lanes (each with its own
+ * HIP stream and workspaces) and returns at once; hpk_collect waits for that lane, runs the Benjamini-Hochberg step
+ * on the host and hands out the result.  With one chromosome submitted ahead, the host half of chromosome i and the
+ * upload of chromosome i + 1 overlap the kernels.  hpk_score_band == submit + collect.
+ * Host input arrays (band->on_device == 0) must stay valid until the job is collected.  hpk_collect always
+ * consumes the job, also on error.  HPK_ERR_BUSY: no free lane. */
+typedef struct hpk_job hpk_job;
+int  hpk_pipeline_depth(void);
+int  hpk_submit_band(hpk_ctx* ctx, const hpk_band* band, const hpk_params* params, hpk_job** job);
+int  hpk_collect(hpk_ctx* ctx, hpk_job* job, hpk_result** out);
 
 /* Host-only helpers (no device needed): the widening plan of callers.py:15-23 + 132-201 as ring
  * multiplicities.  mult is [HPK_MAX_STEPS][HPK_MAX_W + 1]; returns the number of steps or a status. */
