@@ -126,13 +126,21 @@ def _finish_hiccups(R, n, chrom, pw, ww, sig, sumq, double_fold, single_fold, re
     return final_table, pixel_table
 
 
-def hiccups_band(raw, IR, B1, B2, chrom='', balanced=None, weight=None, pw=[2], ww=[5], maxww=20, sig=0.1,
-                 sumq=0.01, double_fold=1.75, single_fold=2, maxapart=2000000, res=10000, use_raw=False,
-                 min_marginal_peaks=3, onlyanchor=True, min_local_reads=25, device=0, detail=None, ctx=None):
-    """`hiccups` on band inputs: raw [n, num] counts, IR [num], and either the balanced f64 band or the
-    balancing weights (balanced is then formed on chip).  With IR = B1 = B2 = None and `weight` given, the 1-D
-    expected and the biases are derived on the device too (scripts/pyHICCUPS:149-166).  Returns the reference's
-    final_table."""
+class PendingCall(object):
+    """A chromosome whose kernels are in flight (hpk_submit_band); result() waits for it and runs the host half
+    (gap filter, donut / lower-left combine, clustering).  Lets a loop over chromosomes stay one ahead."""
+
+    def __init__(self, job, finish):
+        self._job, self._finish = job, finish
+
+    def result(self):
+        return self._finish(self._job.result())
+
+
+def hiccups_band_submit(raw, IR, B1, B2, chrom='', balanced=None, weight=None, pw=[2], ww=[5], maxww=20, sig=0.1,
+                        sumq=0.01, double_fold=1.75, single_fold=2, maxapart=2000000, res=10000, use_raw=False,
+                        min_marginal_peaks=3, onlyanchor=True, min_local_reads=25, device=0, detail=None, ctx=None):
+    """Arguments of `hiccups_band`; returns a PendingCall."""
     ctx = ctx or _lib.default_context(device)
     flags = 0
     if detail is not None and detail.get('dense'):
@@ -140,15 +148,32 @@ def hiccups_band(raw, IR, B1, B2, chrom='', balanced=None, weight=None, pw=[2], 
     prm = _lib.make_params(_lib.MODE_HICCUPS, pw, ww, maxww, sig, maxapart, res, min_local_reads, flags)
     n = raw.shape[0]
     logger.info('Chrom:{0}, Two local neighborhoods, two expected matrices ...'.format(chrom))
-    R = ctx.score_host(raw, IR, B1, B2, prm, balanced=balanced, weight=weight)
-    logger.info('Chrom:{0}, Observed Contact Number: {1}'.format(chrom, R.ncand))
-    npairs = prm.npairs
-    final, table = _finish_hiccups(R, n, chrom, list(pw)[:npairs], list(ww)[:npairs], sig, sumq, double_fold,
-                                   single_fold, res, use_raw, min_marginal_peaks, onlyanchor)
-    if detail is not None:
-        detail['result'] = R
-        detail['pixel_table'] = table
-    return final
+    job = ctx.submit_host(raw, IR, B1, B2, prm, balanced=balanced, weight=weight)
+    pw, ww = list(pw), list(ww)
+
+    def finish(R):
+        logger.info('Chrom:{0}, Observed Contact Number: {1}'.format(chrom, R.ncand))
+        npairs = prm.npairs
+        final, table = _finish_hiccups(R, n, chrom, pw[:npairs], ww[:npairs], sig, sumq, double_fold,
+                                       single_fold, res, use_raw, min_marginal_peaks, onlyanchor)
+        if detail is not None:
+            detail['result'] = R
+            detail['pixel_table'] = table
+        return final
+    return PendingCall(job, finish)
+
+
+def hiccups_band(raw, IR, B1, B2, chrom='', balanced=None, weight=None, pw=[2], ww=[5], maxww=20, sig=0.1,
+                 sumq=0.01, double_fold=1.75, single_fold=2, maxapart=2000000, res=10000, use_raw=False,
+                 min_marginal_peaks=3, onlyanchor=True, min_local_reads=25, device=0, detail=None, ctx=None):
+    """`hiccups` on band inputs: raw [n, num] counts, IR [num], and either the balanced f64 band or the
+    balancing weights (balanced is then formed on chip).  With IR = B1 = B2 = None and `weight` given, the 1-D
+    expected and the biases are derived on the device too (scripts/pyHICCUPS:149-166).  Returns the reference's
+    final_table."""
+    return hiccups_band_submit(raw, IR, B1, B2, chrom=chrom, balanced=balanced, weight=weight, pw=pw, ww=ww, maxww=maxww,
+                               sig=sig, sumq=sumq, double_fold=double_fold, single_fold=single_fold, maxapart=maxapart,
+                               res=res, use_raw=use_raw, min_marginal_peaks=min_marginal_peaks, onlyanchor=onlyanchor,
+                               min_local_reads=min_local_reads, device=device, detail=detail, ctx=ctx).result()
 
 
 def hiccups(M, cM, B1, B2, IR, chromLen, Diags, cDiags, num, chrom, pw=[2], ww=[5],
@@ -166,8 +191,9 @@ def hiccups(M, cM, B1, B2, IR, chromLen, Diags, cDiags, num, chrom, pw=[2], ww=[
 
 
 # ----------------------------------------------------------------------------- bhfdr
-def bhfdr_band(raw, IR, B1, B2, chrom='', balanced=None, weight=None, pw=2, ww=5, sig=0.05, maxww=20,
-               maxapart=2000000, res=10000, min_marginal_peaks=3, onlyanchor=False, device=0, detail=None, ctx=None):
+def bhfdr_band_submit(raw, IR, B1, B2, chrom='', balanced=None, weight=None, pw=2, ww=5, sig=0.05, maxww=20,
+                      maxapart=2000000, res=10000, min_marginal_peaks=3, onlyanchor=False, device=0, detail=None, ctx=None):
+    """Arguments of `bhfdr_band`; returns a PendingCall."""
     ctx = ctx or _lib.default_context(device)
     flags = 0
     if detail is not None and detail.get('dense'):
@@ -175,28 +201,38 @@ def bhfdr_band(raw, IR, B1, B2, chrom='', balanced=None, weight=None, pw=2, ww=5
     prm = _lib.make_params(_lib.MODE_BHFDR, [pw], [ww], maxww, sig, maxapart, res, 16, flags)
     n = raw.shape[0]
     logger.info('Chrom:{0}, Calculate the expected matrix ...'.format(chrom))
-    R = ctx.score_host(raw, IR, B1, B2, prm, balanced=balanced, weight=weight)
-    logger.info('Chrom:{0}, Observed Contact Number: {1}'.format(chrom, R.ncand))
-    s = R.sets[0]
-    logger.info('Chrom:{0}, Number of Poisson Models: {1}'.format(chrom, s['nvalid']))
-    if s['nvalid'] == 0:
-        # statsmodels' multipletests fails on an empty p-value array (callers.py:545)
-        raise _lib.EmptyStepError(_lib.ERR_EMPTY_STEP, 'no pixel with a positive expected value; the reference '
-                                  'fails in multipletests (hicpeaks/callers.py:545)')
-    keep = _gap_keep(s['x'], s['y'], R.gap, ww, n)                               # callers.py:557-577
-    x, y, O, E, p, q = s['x'][keep], s['y'][keep], s['O'][keep], s['E'][keep], s['p'][keep], s['q'][keep]
-    fold = O / E
-    Donuts = dict(zip(zip(x.tolist(), y.tolist()), zip(O.tolist(), fold.tolist(), p.tolist(), q.tolist())))
-    pixel_list = local_clustering(Donuts, None, res, min_count=min_marginal_peaks, r=2 * res, onlysummit=onlyanchor)
-    pixel_table = {}
-    for pixel, cen, radius in pixel_list:
-        donut = Donuts[pixel]
-        if donut[1] > 2:                                                         # callers.py:587
-            pixel_table[(pixel[0] * res, pixel[1] * res)] = (cen[0] * res, cen[1] * res) + (radius * res,) + donut
-    if detail is not None:
-        detail['result'] = R
-        detail['Donuts'] = Donuts
-    return pixel_table
+    job = ctx.submit_host(raw, IR, B1, B2, prm, balanced=balanced, weight=weight)
+
+    def finish(R):
+        logger.info('Chrom:{0}, Observed Contact Number: {1}'.format(chrom, R.ncand))
+        s = R.sets[0]
+        logger.info('Chrom:{0}, Number of Poisson Models: {1}'.format(chrom, s['nvalid']))
+        if s['nvalid'] == 0:
+            # statsmodels' multipletests fails on an empty p-value array (callers.py:545)
+            raise _lib.EmptyStepError(_lib.ERR_EMPTY_STEP, 'no pixel with a positive expected value; the reference '
+                                      'fails in multipletests (hicpeaks/callers.py:545)')
+        keep = _gap_keep(s['x'], s['y'], R.gap, ww, n)                               # callers.py:557-577
+        x, y, O, E, p, q = s['x'][keep], s['y'][keep], s['O'][keep], s['E'][keep], s['p'][keep], s['q'][keep]
+        fold = O / E
+        Donuts = dict(zip(zip(x.tolist(), y.tolist()), zip(O.tolist(), fold.tolist(), p.tolist(), q.tolist())))
+        pixel_list = local_clustering(Donuts, None, res, min_count=min_marginal_peaks, r=2 * res, onlysummit=onlyanchor)
+        pixel_table = {}
+        for pixel, cen, radius in pixel_list:
+            donut = Donuts[pixel]
+            if donut[1] > 2:                                                         # callers.py:587
+                pixel_table[(pixel[0] * res, pixel[1] * res)] = (cen[0] * res, cen[1] * res) + (radius * res,) + donut
+        if detail is not None:
+            detail['result'] = R
+            detail['Donuts'] = Donuts
+        return pixel_table
+    return PendingCall(job, finish)
+
+
+def bhfdr_band(raw, IR, B1, B2, chrom='', balanced=None, weight=None, pw=2, ww=5, sig=0.05, maxww=20,
+               maxapart=2000000, res=10000, min_marginal_peaks=3, onlyanchor=False, device=0, detail=None, ctx=None):
+    return bhfdr_band_submit(raw, IR, B1, B2, chrom=chrom, balanced=balanced, weight=weight, pw=pw, ww=ww, sig=sig,
+                             maxww=maxww, maxapart=maxapart, res=res, min_marginal_peaks=min_marginal_peaks,
+                             onlyanchor=onlyanchor, device=device, detail=detail, ctx=ctx).result()
 
 
 def bhfdr(M, cM, B1, B2, IR, chromLen, Diags, cDiags, num, chrom, pw=2, ww=5, sig=0.05, maxww=20,

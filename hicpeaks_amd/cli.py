@@ -117,32 +117,54 @@ def select_chroms(chromnames, chroms):
     return out
 
 
-def _score_chrom(args_dict, mode, key, device):
-    """One work item = one chromosome (the body of worker(), scripts/pyHICCUPS:139-175)."""
-    from . import band, callers, io, _lib
+def _submit_chrom(args_dict, mode, key, device, src=None):
+    """Read one chromosome's band and put it on the GPU's queue (the first half of worker(), scripts/pyHICCUPS:139-175);
+    returns a PendingCall."""
+    from . import callers, io, _lib
     a = args_dict
-    src = io.open_source(a['path'])
+    src = src or io.open_source(a['path'])
     res = src.binsize
     ctx = _lib.default_context(device)
+    num = a['maxapart'] // res + a['maxww'] + 1
+    raw, w = src.fetch(key, num, a['clr_weight_name'])
     if mode == 'hiccups':
-        num = a['maxapart'] // res + a['maxww'] + 1
-        raw, w = src.fetch(key, num, a['clr_weight_name'])
-        table = callers.hiccups_band(raw, None, None, None, chrom=key.lstrip('chr'), weight=w, pw=a['pw'], ww=a['ww'],
-                                     maxww=a['maxww'], sig=a['siglevel'], sumq=a['sumq'], double_fold=a['double_fold'],
-                                     single_fold=a['single_fold'], maxapart=a['maxapart'], res=res,
-                                     use_raw=a['use_raw'], min_marginal_peaks=a['min_marginal_peaks'],
-                                     onlyanchor=a['only_anchors'], min_local_reads=a['min_local_reads'], ctx=ctx)
-    else:
-        num = a['maxapart'] // res + a['maxww'] + 1
-        raw, w = src.fetch(key, num, a['clr_weight_name'])
-        table = callers.bhfdr_band(raw, None, None, None, chrom=key.lstrip('chr'), weight=w, pw=a['pw'], ww=a['ww'],
-                                   sig=a['siglevel'], maxww=a['maxww'], maxapart=a['maxapart'], res=res, ctx=ctx)
-    return key.lstrip('chr'), table
+        return callers.hiccups_band_submit(raw, None, None, None, chrom=key.lstrip('chr'), weight=w, pw=a['pw'],
+                                           ww=a['ww'], maxww=a['maxww'], sig=a['siglevel'], sumq=a['sumq'],
+                                           double_fold=a['double_fold'], single_fold=a['single_fold'],
+                                           maxapart=a['maxapart'], res=res, use_raw=a['use_raw'],
+                                           min_marginal_peaks=a['min_marginal_peaks'], onlyanchor=a['only_anchors'],
+                                           min_local_reads=a['min_local_reads'], ctx=ctx)
+    return callers.bhfdr_band_submit(raw, None, None, None, chrom=key.lstrip('chr'), weight=w, pw=a['pw'], ww=a['ww'],
+                                     sig=a['siglevel'], maxww=a['maxww'], maxapart=a['maxapart'], res=res, ctx=ctx)
+
+
+def _score_chrom(args_dict, mode, key, device):
+    """One work item = one chromosome."""
+    return key.lstrip('chr'), _submit_chrom(args_dict, mode, key, device).result()
+
+
+def _score_chroms(args_dict, mode, keys, device):
+    """The chromosomes of one GPU, one ahead: while chromosome i is on the GPU, chromosome i + 1 is read and uploaded
+    and chromosome i - 1 goes through clustering on the host (hpk_submit_band / hpk_collect)."""
+    from . import io, _lib
+    import collections
+    src = io.open_source(args_dict['path'])
+    depth = _lib.default_context(device).pipeline_depth
+    pending, out = collections.deque(), []
+    for key in keys:
+        pending.append((key, _submit_chrom(args_dict, mode, key, device, src)))
+        if len(pending) >= depth:
+            k, call = pending.popleft()
+            out.append((k.lstrip('chr'), call.result()))
+    while pending:
+        k, call = pending.popleft()
+        out.append((k.lstrip('chr'), call.result()))
+    return out
 
 
 def _pool_worker(job):
     args_dict, mode, keys, device = job
-    return [_score_chrom(args_dict, mode, k, device) for k in keys]
+    return _score_chroms(args_dict, mode, keys, device)
 
 
 def _run(mode, argv):
@@ -169,7 +191,8 @@ def _run(mode, argv):
         import torch.distributed as dist
         dist.init_process_group('gloo')              # only Python objects travel
         dev = local if args.device is None else args.device
-        tables = parallel.run_sharded(sizes, lambda k: _score_chrom(a, mode, k, dev)[1], rank, world)
+        tables = parallel.run_sharded(sizes, None, rank, world,
+                                      batch_fn=lambda ks: [t for _, t in _score_chroms(a, mode, ks, dev)])
         dist.destroy_process_group()
         if rank != 0:
             return 0
@@ -183,7 +206,7 @@ def _run(mode, argv):
         results = [(k.lstrip('chr'), done[k.lstrip('chr')]) for k in keys]
     else:
         dev = 0 if args.device is None else args.device
-        results = [_score_chrom(a, mode, k, dev) for k in keys]
+        results = _score_chroms(a, mode, keys, dev)
     with open(args.output, 'w') as out:
         for key, table in results:
             out.write(format_hiccups(key, table, res) if mode == 'hiccups' else format_bhfdr(key, table, res))

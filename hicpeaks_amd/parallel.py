@@ -25,12 +25,16 @@ def dist_env():
             int(os.environ.get('LOCAL_RANK', '0')))
 
 
-def run_sharded(sizes, score_fn, rank=0, world=1, group=None):
-    """Score this rank's share of the chromosomes with `score_fn(chrom) -> table` and gather {chrom: table} on
-    rank 0 (None elsewhere).  `group` is a torch.distributed process group when world > 1 (backend nccl on the GPU
-    box, gloo in the CPU tests); only Python objects travel."""
+def run_sharded(sizes, score_fn, rank=0, world=1, group=None, batch_fn=None):
+    """Score this rank's share of the chromosomes with `score_fn(chrom) -> table` (or, one chromosome ahead,
+    `batch_fn(chroms) -> [table, ...]`) and gather {chrom: table} on rank 0 (None elsewhere).  `group` is a
+    torch.distributed process group when world > 1 (backend nccl on the GPU box, gloo in the CPU tests); only Python
+    objects travel."""
     mine = lpt_partition(sizes, world)[rank]
-    local = {c: score_fn(c) for c in mine}
+    if batch_fn is not None:
+        local = dict(zip(mine, batch_fn(mine)))
+    else:
+        local = {c: score_fn(c) for c in mine}
     if world == 1:
         return local
     import torch.distributed as dist

@@ -50,3 +50,29 @@ def test_pybhfdr_cli(tmp_path):
     assert cli.main_bhfdr(argv) == 0
     # pyBHFDR calls bhfdr() with its keyword defaults for clustering (min_marginal_peaks=3, onlyanchor=False)
     _numeric_equal(_lines(out), sorted(g.meta['lines'].splitlines()))
+
+
+def test_pyhiccups_cli_several_chromosomes_one_ahead(tmp_path):
+    """Three chromosomes through the one-ahead loop of the command line (hpk_submit_band / hpk_collect): every
+    chromosome's lines equal the reference's lines for that band, in the order of --chroms."""
+    ga, gb = load_golden('hiccups_p2w5'), load_golden('hiccups_p2w5_shallow')
+    pa, pb = ga.params, gb.params
+    same = all(pa[k] == pb[k] for k in ('pw', 'ww', 'maxww', 'sig', 'sumq', 'maxapart', 'res', 'min_local_reads',
+                                        'min_marginal_peaks'))
+    if not same:
+        gb = ga
+    arc = str(tmp_path / 'in.npz')
+    io.save_band_archive(arc, pa['res'], {'chr1': (ga['raw'], ga['weight']), 'chr2': (gb['raw'], gb['weight']),
+                                          'chr3': (ga['raw'], ga['weight'])})
+    out = str(tmp_path / 'out.bedpe')
+    argv = ['-O', out, '-p', arc, '-C', '1', '2', '3', '--pw'] + [str(v) for v in pa['pw']] + ['--ww'] + [
+        str(v) for v in pa['ww']] + ['--maxww', str(pa['maxww']), '--siglevel', str(pa['sig']), '--sumq', str(pa['sumq']),
+        '--maxapart', str(pa['maxapart']), '--min-marginal-peaks', str(pa['min_marginal_peaks']),
+        '--min-local-reads', str(pa['min_local_reads']), '--logFile', str(tmp_path / 'log.txt')]
+    assert cli.main_hiccups(argv) == 0
+    got = open(out).read().splitlines()
+    order = [l.split('\t')[0] for l in got]
+    assert order == sorted(order, key=lambda c: int(c[3:]))            # chromosomes stay in --chroms order
+    for name, g in (('chr1', ga), ('chr2', gb), ('chr3', ga)):
+        want = sorted(l.replace('chrT', name) for l in g.meta['lines'].splitlines())
+        _numeric_equal(sorted(l for l in got if l.startswith(name + '\t')), want)
