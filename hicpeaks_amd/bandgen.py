@@ -7,7 +7,8 @@ Returns torch tensors on `device`: raw f32 [n, ld], weight f64 [n], IR f64 [num]
 import numpy as np
 
 
-def device_band(n, num, ld, mw, depth=60.0, alpha=1.0, nloops=200, seed=0, nan_frac=0.025, enrich=8.0, device='cuda'):
+def device_band(n, num, ld, mw, depth=60.0, alpha=1.0, nloops=200, seed=0, nan_frac=0.025, enrich=8.0, device='cuda',
+                want_expected=True):
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(int(seed))
@@ -50,6 +51,8 @@ def device_band(n, num, ld, mw, depth=60.0, alpha=1.0, nloops=200, seed=0, nan_f
         if nbad - run > 0:
             idx = torch.from_numpy(rng.choice(n, size=nbad - run, replace=False)).to(device)
             weight[idx] = float('nan')
+    if not want_expected:        # the library derives IR and the biases on the device (hpk_band.IR = NULL)
+        return raw, weight, None, None
     # IR[d] = mean over the diagonal of the balanced values, stored pixels in masked bins left out (pyHICCUPS:150-156)
     IR = torch.zeros(num, dtype=torch.float64, device=device)
     for d in range(mw, min(num, n)):

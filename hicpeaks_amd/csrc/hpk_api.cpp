@@ -360,7 +360,7 @@ int stage_inputs(hpk_ctx* c, Lane& L, const hpk_band* band, int mw, Staged* s) {
         HIPCHK(c, hipStreamWaitEvent(c->stream, L.ev_up, 0));
     }
     if (derive) {
-        const size_t nparts = (n + 127) / 128;
+        const size_t nparts = (n + 31) / 32;        // HPK_IR_ROWS rows per partial (hpk_launch_prep)
         HIPCHK(c, L.IR.reserve(sizeof(double) * num));
         HIPCHK(c, L.b1.reserve(sizeof(double) * n));
         HIPCHK(c, L.psum.reserve(sizeof(double) * nparts * num));
@@ -473,7 +473,7 @@ int launch_scoring(hpk_ctx* c, hpk_job* j, int attempt) {
         hpk_launch_score(sc, c->cus, c->stream);
         HIPCHK(c, hipGetLastError());
         if (j->phases) (void)hipEventRecord(L.ev[4], c->stream);
-        hpk_launch_tighten(sc.surv, d_nsurv, cap, sc.chunk_used, d_fam_m, d_fam_f, d_cnt, j->prm.sig, j->rounds,
+        hpk_launch_tighten(sc.surv, d_nsurv, cap, sc.chunk_used, d_fam_m, d_fam_f, d_cnt, j->prm.sig, j->rounds, j->nsets,
                            reinterpret_cast<HpkSurv*>(small + j->off_inl), HEAD_INLINE, L.surv2.as<HpkSurv>(), d_nout,
                            c->cus, c->stream);
         HIPCHK(c, hipGetLastError());

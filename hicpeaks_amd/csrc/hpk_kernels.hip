@@ -582,33 +582,44 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
 // ------------------------------------------------------------------ 1-D expected IR[d] and biases (scripts/pyHICCUPS:149-166)
 // IR[d] = mean over diagonal d of the balanced values, where *stored* (non-zero) pixels in masked bins are NaN and
 // are left out of both sum and count, while unstored pixels count as 0 even in masked bins.  Deterministic
-// two-level reduction: workgroup b sums rows [b * 128, b * 128 + 128) per diagonal, hpk_ir_final adds the partials
-// in workgroup order.
+// two-level reduction: workgroup b sums rows [b * HPK_IR_ROWS, ...) per diagonal (lanes = diagonals, coalesced),
+// hpk_ir_final adds the partials of one diagonal with 64 lanes in a fixed order.
+#define HPK_IR_ROWS 32
 __global__ void __launch_bounds__(256) hpk_ir_partial(const float* __restrict__ raw, const double* __restrict__ weight, int n,
                                                       int num, int64_t ld, int mw, double* __restrict__ psum,
                                                       unsigned* __restrict__ pnan) {
-    const int rbeg = blockIdx.x * 128, rend = (rbeg + 128 < n) ? rbeg + 128 : n;
+    __shared__ double wrow[HPK_IR_ROWS];
+    const int rbeg = blockIdx.x * HPK_IR_ROWS;
+    if ((int)threadIdx.x < HPK_IR_ROWS) wrow[threadIdx.x] = (rbeg + (int)threadIdx.x < n) ? weight[rbeg + threadIdx.x] : 0.0;
+    __syncthreads();
     for (int k = mw + threadIdx.x; k < num; k += blockDim.x) {
         double s = 0.0;
         unsigned nn = 0u;
-        for (int r = rbeg; r < rend && r + k < n; ++r) {
-            const float cnt = raw[(int64_t)r * ld + k];
-            if (cnt != 0.f) {
-                const double b = ((double)cnt * weight[r]) * weight[r + k];
-                if (b == b) s += b; else ++nn;
-            }
+        int rows = n - k - rbeg;                    // rows of this group that still have column r + k inside the matrix
+        rows = rows > HPK_IR_ROWS ? HPK_IR_ROWS : rows;
+        const float* __restrict__ src = raw + (int64_t)rbeg * ld + k;
+        const double* __restrict__ wc = weight + rbeg + k;
+#pragma unroll 8
+        for (int j = 0; j < rows; ++j) {
+            const float cnt = src[(int64_t)j * ld];
+            const double b = ((double)cnt * wrow[j]) * wc[j];
+            if (cnt != 0.f) { if (b == b) s += b; else ++nn; }
         }
         psum[(int64_t)blockIdx.x * num + k] = s;
         pnan[(int64_t)blockIdx.x * num + k] = nn;
     }
 }
+// one wave per diagonal, four diagonals per workgroup
 __global__ void __launch_bounds__(256) hpk_ir_final(const double* __restrict__ psum, const unsigned* __restrict__ pnan, int nparts,
                                                     int n, int num, int mw, double* __restrict__ IR) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= num) return;
     double s = 0.0;
     unsigned long long nn = 0ull;
-    if (k >= mw) for (int p = 0; p < nparts; ++p) { s += psum[(int64_t)p * num + k]; nn += pnan[(int64_t)p * num + k]; }
+    if (k >= mw) for (int p = lane; p < nparts; p += 64) { s += psum[(int64_t)p * num + k]; nn += pnan[(int64_t)p * num + k]; }
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off); nn += __shfl_down(nn, off); }
+    if (lane != 0) return;
     const long long denom = (long long)(n - k) - (long long)nn;
     IR[k] = (k >= mw && n - k > 0) ? s / (double)denom : 0.0;       // 0/0 -> NaN like numpy's mean of an empty slice
 }
@@ -627,7 +638,9 @@ __global__ void __launch_bounds__(1024) hpk_freeze(const HpkDevPlan* __restrict_
                                                    int nparts, unsigned long long* __restrict__ hist_out,
                                                    int32_t* frozen, int32_t* executed, int32_t* err) {
     __shared__ unsigned long long hist[HPK_MAX_STEPS + 1];
+    __shared__ int swi[HPK_MAX_STEPS], sslot[HPK_MAX_STEPS];        // the serial part below reads LDS only
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((int)threadIdx.x < plan->nsteps) { swi[threadIdx.x] = plan->steps[threadIdx.x].wi; sslot[threadIdx.x] = plan->steps[threadIdx.x].slot; }
     for (int k = wave; k <= HPK_MAX_STEPS; k += 16) {
         unsigned long long t = 0ull;
         for (int p = lane; p < nparts; p += 64) t += hist_part[(int64_t)p * (HPK_MAX_STEPS + 1) + k];
@@ -641,8 +654,10 @@ __global__ void __launch_bounds__(1024) hpk_freeze(const HpkDevPlan* __restrict_
     for (int q = 0; q < HPK_KSLOTS; ++q) unres[q] = total;
     int fw = plan->W;
     int e = 0;
-    for (int s = 0; s < plan->nsteps; ++s) {
-        const HpkDevStep& st = plan->steps[s];
+    const int nsteps = plan->nsteps, maxw = plan->maxw;
+    const bool bh = plan->mode == HPK_MODE_BHFDR;
+    for (int s = 0; s < nsteps; ++s) {
+        struct { int wi, slot; } st = {swi[s], sslot[s]};
         if (st.wi > fw) { executed[s] = 0; continue; }                 // callers.py:133-134 / break at 505-511
         executed[s] = 1;
         const long long before = unres[st.slot];
@@ -651,7 +666,7 @@ __global__ void __launch_bounds__(1024) hpk_freeze(const HpkDevPlan* __restrict_
         const double vr = before ? (double)now / (double)before : 0.0;  // callers.py:208 / 492
         unres[st.slot] = before - now;
         const double lr = total ? (double)unres[st.slot] / (double)total : 0.0;   // callers.py:219 / 501
-        const bool widest = (plan->mode == HPK_MODE_BHFDR) || (st.wi >= plan->maxw);
+        const bool widest = bh || (st.wi >= maxw);
         if (widest && (vr < 0.3 || lr < 0.03)) fw = st.wi;              // callers.py:223-229
     }
     *frozen = fw;
@@ -885,35 +900,49 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
         const int iend = (ub * 256 + 256 < cnt) ? ub * 256 + 256 : cnt;
         for (int i0 = ub * 256; i0 < iend; i0 += 64) {
             const bool cand = i0 + lane < cnt;
-            const int64_t ri = (int64_t)tile * a.tilecap + i0 + lane;
-            unsigned ent = 0u;
-            if (cand) ent = a.rec_ent[ri];
+            // Three dependent rounds of loads per batch instead of five: (1) entry + first slot's step and sums (idle
+            // lanes read the tile's first record: always allocated, never used), (2) IR, biases and the local-expected
+            // table entries, all addressed from the entry, (3) the Poisson table.
+            const int64_t ri = (int64_t)tile * a.tilecap + (cand ? i0 + lane : 0);
+            unsigned ent = a.rec_ent[ri];
+            int slot = lpair_slot[0];
+            int stp_n = (int)a.rec_W[slot * a.rec_stride + ri];
+            double2 s2_n = a.rec_S[slot * a.rec_stride + ri];
+            if (!cand) ent = 0u;
             const int r = r0 + (int)((ent >> 9) & 15u) + HPK_NWAVES * (int)((ent >> 7) & 3u);
             const int c = c0 + (int)(ent & 127u);
             const int d = c - r;
             float rawpix = (float)(ent >> 13);
             if (cand && (ent >> 13) == HPK_RAWCAP) rawpix = a.raw[(int64_t)r * a.ld + d];     // count too large for the entry
             const double O = (double)rawpix;
-            double ir = 0.0, b2c = 0.0, b1r = 0.0;
-            if (cand) { ir = a.IR[d]; b2c = a.b2[c]; b1r = a.b1[r]; }
+            const double ir = a.IR[cand ? d : 0], b2c = a.b2[cand ? c : 0], b1r = a.b1[cand ? r : 0];
+            // which local-expected table serves this pixel (interior / clipped by one matrix end / both: explicit)
+            const bool top = cand && r < W, right = cand && c >= a.n - W;
+            const bool both = top && right;
+            const double* __restrict__ tab = (top != right) ? a.eedge : a.etab;
+            const int64_t tstride = (int64_t)2 * (a.D + 1);
+            const int64_t tbase = (top != right) ? (int64_t)(((top ? 0 : 1) * W + (top ? r : a.n - 1 - c)) * plan->nsteps) * tstride : 0;
 
             for (int pj = 0; pj < npairs; ++pj) {
-                const int slot = lpair_slot[pj];
                 const int wi0 = lpair_wi[pj];
-                bool ok = cand && d >= wi0;                                   // callers.py:244
-                double eK = 0.0, eY = 0.0;
-                if (ok) {
-                    const int stp = (int)a.rec_W[slot * a.rec_stride + ri];   // step and sums travel together
-                    const double2 s2 = a.rec_S[slot * a.rec_stride + ri];
-                    ok = (stp != 0) && (lstepw[stp > 0 ? stp - 1 : 0] <= frozen);   // resolved at an executed step
-                    if (ok) {
-                        double EK = 1.0, EY = 1.0;
-                        if (a.dbg != 2) local_expected(plan, a.etab, a.eedge, a.IR, stp - 1, r, c, d, a.n, a.num, a.mw, a.D, W, EK, EY);
-                        // callers.py:244-249: E = ((IR[d] * (bS / bE)) * B1[x]) * B2[y] where bE != 0
-                        eK = (EK != 0.0) ? ((ir * (s2.x / EK)) * b1r) * b2c : 0.0;
-                        eY = (EY != 0.0) ? ((ir * (s2.y / EY)) * b1r) * b2c : 0.0;
-                    }
+                const int stp = stp_n;
+                const double2 s2 = s2_n;
+                if (pj + 1 < npairs) {                  // next slot's record is on its way while this one is scored
+                    slot = lpair_slot[pj + 1];
+                    stp_n = (int)a.rec_W[slot * a.rec_stride + ri];
+                    s2_n = a.rec_S[slot * a.rec_stride + ri];
                 }
+                // resolved at an executed step (callers.py:133-134), far enough from the diagonal (callers.py:244)
+                const bool ok = cand && d >= wi0 && stp != 0 && lstepw[stp > 0 ? stp - 1 : 0] <= frozen;
+                const int64_t to = tbase + (int64_t)(ok ? stp - 1 : 0) * tstride + (cand ? d : 0);
+                double EK = tab[to], EY = tab[to + (a.D + 1)];
+                if (__ballot(both && ok) != 0ull) {
+                    if (both && ok) edge_expected(plan->steps[stp - 1].m, plan->steps[stp - 1].wi, a.IR, r, c, a.n, a.num, a.mw, EK, EY);
+                }
+                if (a.dbg == 2) { EK = 1.0; EY = 1.0; }
+                // callers.py:244-249: E = ((IR[d] * (bS / bE)) * B1[x]) * B2[y] where bE != 0
+                const double eK = (ok && EK != 0.0) ? ((ir * (s2.x / EK)) * b1r) * b2c : 0.0;
+                const double eY = (ok && EY != 0.0) ? ((ir * (s2.y / EY)) * b1r) * b2c : 0.0;
                 const int nfl = (mode == HPK_MODE_BHFDR) ? 1 : 2;
                 for (int fl = 0; fl < nfl; ++fl) {
                     const int set = (mode == HPK_MODE_BHFDR) ? 0 : pj * 2 + fl;
@@ -949,6 +978,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                     const bool surv = valid && chunk != 0 && p <= a.sig && a.dbg != 3;      // only these can reach q <= sig
                     // per-wave aggregation before touching the LDS counters
                     const unsigned long long vm = (a.dbg == 4) ? 0ull : __ballot(valid);
+                    const unsigned long long sm = __ballot(surv);
                     if (vm != 0ull) {
                         double em = valid ? E : 0.0;
                         for (int off = 32; off > 0; off >>= 1) em = fmax(em, __shfl_xor(em, off));
@@ -959,7 +989,6 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                         if (valid && chunk) atomicAdd(&lm[set][chunk], 1u);
                         if (surv) atomicAdd(&lf[set][chunk], 1u);
                     }
-                    const unsigned long long sm = __ballot(surv);
                     if (sm != 0ull) {
                         const unsigned scnt = (unsigned)__popcll(sm);
                         if (wused + scnt > HPK_SCH) {            // wave-uniform: retire the chunk, take a new one
@@ -1012,8 +1041,8 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
 // scoring kernel) and T_k = sig cnt[k-1] / m.  Every workgroup derives the bounds it needs from the previous rounds'
 // counters in its prologue, so a round is one launch and the last bound is applied by the compaction itself.
 __device__ __forceinline__ void thr_table(double* lthr, const unsigned int* __restrict__ fam_m, const unsigned int* __restrict__ fam_f,
-                                          const unsigned int* __restrict__ cnt, int round, double sig) {
-    for (int i = threadIdx.x; i < HPK_NFAM; i += blockDim.x) {
+                                          const unsigned int* __restrict__ cnt, int round, double sig, int nfam) {
+    for (int i = threadIdx.x; i < nfam; i += blockDim.x) {
         const unsigned m = fam_m[i];
         double t = 0.0;
         if (m) {
@@ -1026,14 +1055,14 @@ __device__ __forceinline__ void thr_table(double* lthr, const unsigned int* __re
 __global__ void __launch_bounds__(256) hpk_thr_count(const HpkSurv* __restrict__ surv, const unsigned long long* __restrict__ nsurv,
                                                      int64_t cap, const unsigned* __restrict__ chunk_used,
                                                      const unsigned int* __restrict__ fam_m, const unsigned int* __restrict__ fam_f,
-                                                     unsigned int* __restrict__ cnt, int round, double sig) {
+                                                     unsigned int* __restrict__ cnt, int round, double sig, int nfam) {
     __shared__ unsigned int lc[HPK_NFAM];
     __shared__ double lthr[HPK_NFAM];
     const int reg = blockIdx.y;             // one grid row per survivor region
     int64_t n = (int64_t)nsurv[reg * HPK_REG_STRIDE]; if (n > cap) n = cap;
     if ((int64_t)blockIdx.x * blockDim.x >= n) return;
-    for (int i = threadIdx.x; i < HPK_NFAM; i += blockDim.x) lc[i] = 0u;
-    thr_table(lthr, fam_m, fam_f, cnt, round, sig);
+    for (int i = threadIdx.x; i < nfam; i += blockDim.x) lc[i] = 0u;
+    thr_table(lthr, fam_m, fam_f, cnt, round, sig, nfam);
     __syncthreads();
     {
         const int64_t rb = (int64_t)reg * cap;
@@ -1046,14 +1075,14 @@ __global__ void __launch_bounds__(256) hpk_thr_count(const HpkSurv* __restrict__
     }
     __syncthreads();
     unsigned int* out = cnt + (size_t)round * HPK_NFAM;
-    for (int i = threadIdx.x; i < HPK_NFAM; i += blockDim.x) if (lc[i]) atomicAdd(&out[i], lc[i]);
+    for (int i = threadIdx.x; i < nfam; i += blockDim.x) if (lc[i]) atomicAdd(&out[i], lc[i]);
 }
 // The first `inl` survivors of the cut go to out_head (which travels to the host together with the counters), the rest
 // to out_rest.
 __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkSurv* __restrict__ surv, const unsigned long long* __restrict__ nsurv,
                                                        int64_t cap, const unsigned* __restrict__ chunk_used,
                                                        const unsigned int* __restrict__ fam_m, const unsigned int* __restrict__ fam_f,
-                                                       const unsigned int* __restrict__ cnt, int rounds, double sig,
+                                                       const unsigned int* __restrict__ cnt, int rounds, double sig, int nfam,
                                                        HpkSurv* __restrict__ out_head, unsigned long long inl,
                                                        HpkSurv* __restrict__ out_rest, unsigned long long* __restrict__ nout) {
     __shared__ double lthr[HPK_NFAM];
@@ -1062,7 +1091,7 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkSurv* __restrict
     const int reg = blockIdx.y;
     int64_t n = (int64_t)nsurv[reg * HPK_REG_STRIDE]; if (n > cap) n = cap;
     if ((int64_t)blockIdx.x * blockDim.x >= n) return;
-    thr_table(lthr, fam_m, fam_f, cnt, rounds, sig);
+    thr_table(lthr, fam_m, fam_f, cnt, rounds, sig, nfam);
     __syncthreads();
     const int64_t rb = (int64_t)reg * cap;
     for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
@@ -1205,20 +1234,21 @@ void hpk_launch_score(const HpkScoreArgs& a, int cus, hipStream_t st) {
 
 void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned* chunk_used,
                         const unsigned int* fam_m, const unsigned int* fam_f, unsigned int* fam_cnt, double sig, int rounds,
-                        HpkSurv* out_head, unsigned long long inl, HpkSurv* out_rest, unsigned long long* nout, int cus,
-                        hipStream_t st) {
+                        int nsets, HpkSurv* out_head, unsigned long long inl, HpkSurv* out_rest, unsigned long long* nout,
+                        int cus, hipStream_t st) {
     if (rounds > HPK_TIGHTEN_MAX) rounds = HPK_TIGHTEN_MAX;
+    const int nfam = nsets * (HPK_NB + 1);          // families in use: (set, chunk)
     for (int r = 0; r < rounds; ++r)
-        hipLaunchKernelGGL(hpk_thr_count, dim3(8, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt, r, sig);
+        hipLaunchKernelGGL(hpk_thr_count, dim3(8, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt, r, sig, nfam);
     hipLaunchKernelGGL(hpk_thr_compact, dim3(8, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt,
-                       rounds, sig, out_head, inl, out_rest, nout);
+                       rounds, sig, nfam, out_head, inl, out_rest, nout);
 }
 
 void hpk_launch_prep(const float* raw, const double* weight, int n, int num, int64_t ld, int mw, double* psum, unsigned* pnan,
                      double* IR, double* bias, hipStream_t st) {
-    const int nparts = (n + 127) / 128;
+    const int nparts = (n + HPK_IR_ROWS - 1) / HPK_IR_ROWS;        // hpk_api.cpp sizes psum / pnan with the same constant
     hipLaunchKernelGGL(hpk_ir_partial, dim3(nparts), dim3(256), 0, st, raw, weight, n, num, ld, mw, psum, pnan);
-    hipLaunchKernelGGL(hpk_ir_final, dim3((num + 255) / 256), dim3(256), 0, st, psum, pnan, nparts, n, num, mw, IR);
+    hipLaunchKernelGGL(hpk_ir_final, dim3((num + 3) / 4), dim3(256), 0, st, psum, pnan, nparts, n, num, mw, IR);
     hipLaunchKernelGGL(hpk_biases, dim3((n + 255) / 256), dim3(256), 0, st, weight, n, bias);
 }
 

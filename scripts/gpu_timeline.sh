@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/timeline
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --memory-copy-trace -d $OUT/t -o k --output-format csv -- python $R/bench.py --config ${CFG:-chr1_10kb} --steps 6 --warmup 2 --cpu-rows 0 > $OUT/log 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace -d $OUT/t -o k --output-format csv -- python $R/bench.py --config ${CFG:-chr1_10kb} --steps ${STEPS:-6} --warmup ${WARM:-2} --cpu-rows 0 > $OUT/log 2>&1
 python - <<PY
 import csv, glob
 ks = []
