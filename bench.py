@@ -167,7 +167,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='chr1_10kb', choices=sorted(CONFIGS))
-    ap.add_argument('--cpu-rows', type=int, default=12000, help='rows of the CPU-baseline sample (0 = skip)')
+    ap.add_argument('--cpu-rows', type=int, default=1 << 30,
+                    help='rows of the CPU-baseline sample (default: the whole workload, ~8 s on one core; 0 = skip)')
     ap.add_argument('--pipeline-depth', type=int, default=2,
                     help='chromosomes in flight per GPU (hpk_submit_band / hpk_collect); 1 = one synchronous call per step')
     ap.add_argument('--stencil-only', action='store_true', help='time the stencil kernel alone (HPK_FLAG_NO_SCORE)')
