@@ -5,10 +5,10 @@
 #include "hpk_plan.h"
 
 #define HPK_LC 128                      // SAT columns per tile (two cells per lane)
-#define HPK_LR 80                       // SAT rows per tile: 80 * 128 * 16 B = 160 KiB, the whole LDS of one CU
+#define HPK_LR 80                       // SAT rows per tile: 80 * 128 * 12 B = 120 KiB + 32 KiB of candidate lists
 #define HPK_HIST_NCAND HPK_MAX_STEPS    // hist[HPK_MAX_STEPS] counts the candidates
 #define HPK_NWAVES 16                   // waves per stencil workgroup
-#define HPK_RAWCAP 0x7ffffu              // largest count that fits a record entry; larger ones are re-read from the band
+#define HPK_LISTCAP 512                 // candidate ids per wave and tile (4 rows x <= 127 columns)
 
 struct HpkStencilArgs {
     const float*  raw;
@@ -17,7 +17,7 @@ struct HpkStencilArgs {
     const HpkDevPlan* plan;
     // Output: compact candidate records, one region of `tilecap` records per tile.  Waves reserve their share of a
     // region with one atomicAdd on tile_cnt[tile] (distinct addresses per tile: no serialisation).
-    //   rec_ent[tile * tilecap + i]                    x | row slot << 7 | stencil wave << 9 | min(raw, 2^19 - 1) << 13
+    //   rec_ent[tile * tilecap + i]                    x | row slot << 7 | stencil wave << 9 | min(raw, HPK_PK_CAP) << 13
     //   rec_S[slot * rec_stride + tile * tilecap + i]  (bS_K, bS_Y) at the resolving step
     //   rec_W[slot * rec_stride + tile * tilecap + i]  resolving step + 1, 0 = unresolved
     unsigned* rec_ent;
@@ -26,7 +26,7 @@ struct HpkStencilArgs {
     unsigned* tile_cnt;
     int32_t tilecap;
     int64_t rec_stride;
-    uint8_t* gap;                       // [n] preset to 1; cleared for rows with a non-zero balanced value
+    uint8_t* gap;                       // [n] preset to 0; set for rows with a non-zero balanced value (gap = !flag)
     unsigned long long* hist;           // [HPK_MAX_STEPS + 1] totals, written by hpk_freeze
     unsigned* hist_part;                // [grid][HPK_MAX_STEPS + 1] per-workgroup resolve counts, [..][HPK_MAX_STEPS] = candidates
     int32_t n, num;

@@ -11,13 +11,13 @@
 // Stencil design.  The tile is built in true matrix coordinates (r, c): an output tile of TR x TC pixels
 // plus a halo of maxww (+1 row/column for the prefix origin) is read from band storage - rows are
 // contiguous in c, so every wave reads 128 consecutive floats of one band row - and turned into a
-// summed-area table (SAT) of 16-byte cells {f64 balanced, u32 raw, u32 valid-raw} in LDS.  Each wave owns
+// summed-area table (SAT) of 12-byte cells {f64 balanced, u32 capped raw count | valid flag << 21} in LDS.  Each wave owns
 // RPW consecutive rows x 128 columns (two cells per lane): the prefix along a row is an in-register DPP
 // scan, the prefix down the columns is a running sum in registers, so the SAT is written to LDS exactly
 // once and never read back during construction.  With the SAT every quadrant box of the (p, w) window is
-// four cell reads (one ds_read_b128 each), independent of w.  u32 sums wrap but their differences are
-// exact; the valid-raw sum tells an all-zero balanced box (exact 0, as the reference's CSR adds give)
-// from floating-point residue of the f64 SAT.
+// four cell reads, independent of w.  u32 sums wrap but their differences are exact; the valid count
+// tells an all-zero balanced box (exact 0, as the reference's CSR adds give) from floating-point residue
+// of the f64 SAT.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <float.h>
@@ -29,14 +29,26 @@ namespace {
 constexpr int LC = HPK_LC;
 constexpr int LR = HPK_LR;
 
-// The SAT is kept as three planes so that every access pattern of the evaluation phase is bank-conflict free
-// (lanes walk along x): f64 balanced (8-byte stride, ds_read_b64), u32 raw and u32 valid-raw (4-byte stride,
-// ds_read_b32).  Sizes: 80 KiB + 40 KiB + 40 KiB = 160 KiB.
+// The SAT is kept as two planes so that every access pattern of the evaluation phase is bank-conflict free
+// (lanes walk along x): f64 balanced (8-byte stride, ds_read_b64) and one u32 plane (ds_read_b32) that carries two
+// exact integer sums side by side:
+//   bits  0..20  raw count capped at HPK_PK_CAP.  Only "Reads >= min_local_reads" is ever asked of it: with
+//                min_local_reads <= HPK_PK_CAP a capped cell decides the comparison the same way the true count
+//                does, and a box of (2 maxww + 1)^2 <= 1681 cells stays below 2^21;
+//   bits 21..31  number of cells with a non-zero balanced value (a box holds < 2^11 of them).
+// Sums wrap mod 2^32, box differences are exact in both fields.  Sizes: 80 KiB + 40 KiB; the rest of the LDS holds
+// the per-wave candidate lists.
+constexpr unsigned PK_SHIFT = 21u, PK_MASK = (1u << PK_SHIFT) - 1u;
+static_assert((2 * HPK_MAX_W + 1) * (2 * HPK_MAX_W + 1) * HPK_PK_CAP < (1u << PK_SHIFT), "capped raw box sum must fit its field");
+static_assert((2 * HPK_MAX_W + 1) * (2 * HPK_MAX_W + 1) < (1u << (32 - PK_SHIFT)), "valid count of a box must fit its field");
 struct Sat {
-    double* c;       // balanced
-    unsigned* r;     // raw count
-    unsigned* v;     // raw count where balanced != 0
+    double* c;          // balanced
+    unsigned* p;        // capped raw | valid << 21
+    unsigned* l;        // candidate lists: HPK_LISTCAP entries per wave
 };
+__device__ __forceinline__ unsigned pack_cell(unsigned ru, bool valid) {
+    return (ru < HPK_PK_CAP ? ru : HPK_PK_CAP) | (valid ? 1u << PK_SHIFT : 0u);
+}
 
 // ------------------------------------------------------------------ wave64 DPP scan (gfx9 DPP controls)
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
@@ -54,22 +66,20 @@ __device__ __forceinline__ double dpp_f64(double x) {
     return __hiloint2double(hi, lo);
 }
 template <int CTRL, int ROWMASK>
-__device__ __forceinline__ void scan_step(double& c, unsigned& r, unsigned& v) {
+__device__ __forceinline__ void scan_step(double& c, unsigned& r) {
     c += dpp_f64<CTRL, ROWMASK>(c);
     r += dpp_u32<CTRL, ROWMASK>(r);
-    v += dpp_u32<CTRL, ROWMASK>(v);
 }
 // inclusive prefix over the 64 lanes, then shifted right by one lane (= exclusive prefix)
-__device__ __forceinline__ void wave_exclusive_scan(double& c, unsigned& r, unsigned& v) {
-    scan_step<DPP_ROW_SHR1, 0xf>(c, r, v);
-    scan_step<DPP_ROW_SHR2, 0xf>(c, r, v);
-    scan_step<DPP_ROW_SHR4, 0xf>(c, r, v);
-    scan_step<DPP_ROW_SHR8, 0xf>(c, r, v);
-    scan_step<DPP_ROW_BCAST15, 0xa>(c, r, v);
-    scan_step<DPP_ROW_BCAST31, 0xc>(c, r, v);
+__device__ __forceinline__ void wave_exclusive_scan(double& c, unsigned& r) {
+    scan_step<DPP_ROW_SHR1, 0xf>(c, r);
+    scan_step<DPP_ROW_SHR2, 0xf>(c, r);
+    scan_step<DPP_ROW_SHR4, 0xf>(c, r);
+    scan_step<DPP_ROW_SHR8, 0xf>(c, r);
+    scan_step<DPP_ROW_BCAST15, 0xa>(c, r);
+    scan_step<DPP_ROW_BCAST31, 0xc>(c, r);
     c = dpp_f64<DPP_WAVE_SHR1, 0xf>(c);
     r = dpp_u32<DPP_WAVE_SHR1, 0xf>(r);
-    v = dpp_u32<DPP_WAVE_SHR1, 0xf>(v);
 }
 
 // ------------------------------------------------------------------ box sums on the SAT
@@ -88,8 +98,8 @@ __device__ __forceinline__ void box_ky(const double* __restrict__ Sc, int base, 
     kc = ((top + bot) + mid) + pixc;
     yc = (bm1 - bl) - (sc - ml1);
 }
-// the same two boxes on the u32 valid-raw plane (exact, wrapping): decides whether a tiny f64 box sum is an
-// exact zero (every contributing balanced value is 0) or just small
+// the same two boxes on the valid-count field of the packed plane (exact, wrapping): decides whether a tiny f64 box
+// sum is an exact zero (every contributing balanced value is 0) or just small.  Returns the two counts.
 __device__ __noinline__ unsigned long long box_ky_valid(const unsigned* __restrict__ Sv, int base, int rho, unsigned pixv,
                                                         unsigned sv) {
     const int t = base - (rho + 1) * LC, b = base + rho * LC, m0 = base - LC;
@@ -99,12 +109,13 @@ __device__ __noinline__ unsigned long long box_ky_valid(const unsigned* __restri
     const unsigned vml0 = Sv[m0 + xl], vml1 = Sv[base + xl], vmr0 = Sv[m0 + xr], vmr1 = Sv[base + xr];
     const unsigned kv = vtl - vtm1 + vtm - vtr + vbr - vbm + vbm1 - vbl + vml1 - vml0 + vmr0 - vmr1 + pixv;
     const unsigned yv = vbm1 - vbl - sv + vml1;
-    return (unsigned long long)kv | (unsigned long long)yv << 32;      // in registers: no scratch round trip
+    return (unsigned long long)(kv >> PK_SHIFT) | (unsigned long long)(yv >> PK_SHIFT) << 32;   // in registers: no scratch
 }
 
+// lower-left box of capped raw counts (radius rho) on the packed plane; sr = S(Y, X-1)
 __device__ __forceinline__ unsigned reads_box(const unsigned* __restrict__ Sr, int base, int rho, unsigned sr) {
     const int b = base + rho * LC, xl = -(rho + 1);
-    return Sr[b - 1] - sr - Sr[b + xl] + Sr[base + xl];
+    return (Sr[b - 1] - sr - Sr[b + xl] + Sr[base + xl]) & PK_MASK;
 }
 
 // balanced value of pixel (rr, cc) on diagonal k (formed on chip in weight mode): (raw * w_r) * w_c, NaN -> 0
@@ -200,8 +211,8 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Sat S;
     S.c = reinterpret_cast<double*>(smem);
-    S.r = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 8);
-    S.v = S.r + LR * LC;
+    S.p = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 8);
+    S.l = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 12);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -261,10 +272,10 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
     const int xx0 = 2 * lane;
     const int cc0 = c0 - W - 1 + xx0;
     const int rr0 = r0 - W - 1 + wave * RPW;
-    float rawv[RPW][2];
     double balv[RPW][2];
     double tc[2] = {0.0, 0.0};
-    unsigned tr[2] = {0u, 0u}, tv[2] = {0u, 0u};
+    unsigned tp[2] = {0u, 0u};
+    unsigned pkv[RPW][2];
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
 #pragma unroll
@@ -274,56 +285,50 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
             double bv = 0.0;
             if (BALF64) { bv = nxt.bal[j][e]; bv = (bv == bv) ? bv : 0.0; }
             else if (k >= mw) bv = balanced_of(rv, nxt.wrow[BALF64 ? 0 : j], nxt.wc[e]);
-            rawv[j][e] = rv;
             balv[j][e] = bv;
-            const unsigned ru = (unsigned)rv;
+            pkv[j][e] = pack_cell((unsigned)rv, bv != 0.0);
             tc[e] += bv;
-            tr[e] += ru;
-            tv[e] += (bv != 0.0) ? (ru ? ru : 1u) : 0u;
+            tp[e] += pkv[j][e];
         }
     }
     if (a.dbg_stop == 1) {
-        if (tc[0] + tc[1] == -1.0 && tr[0] + tv[1] == 77u) a.hist[0] = 1ull;     // keep the loads live
+        if (tc[0] + tc[1] == -1.0 && tp[0] + tp[1] == 77u) a.hist[0] = 1ull;     // keep the loads live
         if (tid_next >= 0) tile_load<RPW, BALF64>(a, g_raw, g_bal, g_w, tid_next, wave, lane, nxt);
         tid = tid_next;
         continue;
     }
     // column totals of this wave's row segment -> LDS (aliases the SAT; consumed before the SAT is written)
     *reinterpret_cast<double2*>(&S.c[wave * LC + xx0]) = make_double2(tc[0], tc[1]);
-    *reinterpret_cast<uint2*>(&S.r[wave * LC + xx0]) = make_uint2(tr[0], tr[1]);
-    *reinterpret_cast<uint2*>(&S.v[wave * LC + xx0]) = make_uint2(tv[0], tv[1]);
+    *reinterpret_cast<uint2*>(&S.p[wave * LC + xx0]) = make_uint2(tp[0], tp[1]);
     __syncthreads();
     double ac[2] = {0.0, 0.0};           // running column sums of row-prefixed values = SAT of the rows above
-    unsigned ar[2] = {0u, 0u}, av[2] = {0u, 0u};
+    unsigned ar[2] = {0u, 0u};
     for (int w2 = 0; w2 < wave; ++w2) {
         const double2 t = *reinterpret_cast<const double2*>(&S.c[w2 * LC + xx0]);
-        const uint2 u = *reinterpret_cast<const uint2*>(&S.r[w2 * LC + xx0]);
-        const uint2 q = *reinterpret_cast<const uint2*>(&S.v[w2 * LC + xx0]);
-        ac[0] += t.x; ac[1] += t.y; ar[0] += u.x; ar[1] += u.y; av[0] += q.x; av[1] += q.y;
+        const uint2 u = *reinterpret_cast<const uint2*>(&S.p[w2 * LC + xx0]);
+        ac[0] += t.x; ac[1] += t.y; ar[0] += u.x; ar[1] += u.y;
     }
     __syncthreads();
     {   // prefix of the segment base along the row
-        double pc = ac[0] + ac[1]; unsigned pr = ar[0] + ar[1], pv = av[0] + av[1];
-        const double l1c = pc; const unsigned l1r = pr, l1v = pv;
-        wave_exclusive_scan(pc, pr, pv);
-        ac[0] = pc + ac[0]; ar[0] = pr + ar[0]; av[0] = pv + av[0];
-        ac[1] = pc + l1c;   ar[1] = pr + l1r;   av[1] = pv + l1v;
+        double pc = ac[0] + ac[1]; unsigned pr = ar[0] + ar[1];
+        const double l1c = pc; const unsigned l1r = pr;
+        wave_exclusive_scan(pc, pr);
+        ac[0] = pc + ac[0]; ar[0] = pr + ar[0];
+        ac[1] = pc + l1c;   ar[1] = pr + l1r;
     }
     // ---- phase 2: row prefix by DPP scan, column prefix by running sums, one LDS write per cell
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
-        const unsigned r0u = (unsigned)rawv[j][0], r1u = (unsigned)rawv[j][1];
+        const unsigned r0u = pkv[j][0], r1u = pkv[j][1];
         const double c0v = balv[j][0], c1v = balv[j][1];
-        const unsigned v0 = (c0v != 0.0) ? (r0u ? r0u : 1u) : 0u, v1 = (c1v != 0.0) ? (r1u ? r1u : 1u) : 0u;
-        const double l1c = c0v + c1v; const unsigned l1r = r0u + r1u, l1v = v0 + v1;
-        double pc = l1c; unsigned pr = l1r, pv = l1v;
-        wave_exclusive_scan(pc, pr, pv);
-        ac[0] += pc + c0v; ar[0] += pr + r0u; av[0] += pv + v0;
-        ac[1] += pc + l1c; ar[1] += pr + l1r; av[1] += pv + l1v;
+        const double l1c = c0v + c1v; const unsigned l1r = r0u + r1u;
+        double pc = l1c; unsigned pr = l1r;
+        wave_exclusive_scan(pc, pr);
+        ac[0] += pc + c0v; ar[0] += pr + r0u;
+        ac[1] += pc + l1c; ar[1] += pr + l1r;
         const int o = (wave * RPW + j) * LC + xx0;
         *reinterpret_cast<double2*>(&S.c[o]) = make_double2(ac[0], ac[1]);
-        *reinterpret_cast<uint2*>(&S.r[o]) = make_uint2(ar[0], ar[1]);
-        *reinterpret_cast<uint2*>(&S.v[o]) = make_uint2(av[0], av[1]);
+        *reinterpret_cast<uint2*>(&S.p[o]) = make_uint2(ar[0], ar[1]);
     }
     __syncthreads();
     // the next tile's rows start moving now; nothing below waits for them
@@ -343,26 +348,21 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
         const bool last = (cj == a.J - 1) || (c0 + a.TC >= n) || (mw + (cj + 1) * a.TC - (a.TR - 1)) > D;
         const int Y = (int)threadIdx.x + W + 1;
         const int xe = last ? LC - 1 : W + a.TC, xs = W;
-        const unsigned rs = S.v[Y * LC + xe] - S.v[(Y - 1) * LC + xe] - S.v[Y * LC + xs] + S.v[(Y - 1) * LC + xs];
-        if (rs != 0u) a.gap[r0 + (int)threadIdx.x] = 1;
+        const unsigned rs = S.p[Y * LC + xe] - S.p[(Y - 1) * LC + xe] - S.p[Y * LC + xs] + S.p[(Y - 1) * LC + xs];
+        if ((rs >> PK_SHIFT) != 0u) a.gap[r0 + (int)threadIdx.x] = 1;
     }
 
     // ---- phase 3: candidates of the tile.  Work is proportional to the candidates (non-zero pixels), not to the
     // band pixels:
-    //   (L) each wave walks its rows (y = wave, wave + NW, ...), takes every pixel's count out of the u32 SAT and
-    //       compacts the candidates' ids (row slot << 7 | x) into a register list - one ds_permute per 64 pixels
-    //       (candidates rotate to the free lanes of the current list register, the rest to the remaining lanes);
+    //   (L) each wave walks its rows (y = wave, wave + NW, ...), takes every pixel's (capped) count out of the packed
+    //       SAT and appends the candidates' ids (row slot << 7 | x) to its list in LDS (ballot + mbcnt offsets);
     //   (A) per batch of 64 candidates: first step whose Reads reach min_local_reads - three u32 SAT reads per
     //       radius, for "simple" plans without a step loop;
     //   (B) donut / lower-left sums once per slot with per-lane radii (each lane fetches its own step's box terms
     //       with ds_bpermute), scattered 17-byte stores for the candidates only.
     // Output per slot and candidate pixel: (bS_K, bS_Y) f64 + resolving step + 1 (u8); pixels with a zero count are
     // never written (nothing reads them).  The local expected, biases and division belong to the scoring kernel.
-    constexpr int NLIST = (LR + NW - 1) / NW * 2;       // 64-lane list registers: rows per wave x 2 column blocks
-    unsigned L[NLIST];
-#pragma unroll
-    for (int k = 0; k < NLIST; ++k) L[k] = 0u;
-    unsigned curL = 0u;                 // the list register being filled; committed to L[] when it is full
+    unsigned* __restrict__ lst = S.l + wave * HPK_LISTCAP;            // this wave's list: at most 4 rows x TC entries
     int cnt = 0;
 #pragma unroll 1
     for (int yi = 0; wave + NW * yi < a.TR; ++yi) {
@@ -377,31 +377,14 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
             const int d = c - r;
             const bool inb = x < a.TC && c < n && d >= mw && d <= D && d < num;
             const int base = Yb + (x < a.TC ? x : a.TC - 1);          // clamped: every lane reads inside the tile
-            const unsigned rawu = S.r[base] - S.r[base - LC] - S.r[base - 1] + S.r[base - LC - 1];
-            const bool cnd = inb && rawu != 0u && a.dbg_stop != 4;
+            const unsigned pix = S.p[base] - S.p[base - LC] - S.p[base - 1] + S.p[base - LC - 1];
+            const bool cnd = inb && (pix & PK_MASK) != 0u && a.dbg_stop != 4;
             const unsigned long long M = __ballot(cnd);
             if (M == 0ull) continue;
-            const int pc = __popcll(M);
             const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(M >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M, 0u));
-            const int a0 = cnt & 63;
-            // a bijection of the 64 lanes: candidates -> a0, a0+1, ... (mod 64), the others -> the lanes that remain
-            const int tgt = cnd ? a0 + below : a0 + pc + (lane - below);
-            const unsigned id = (unsigned)x | ((unsigned)yi << 7) | ((unsigned)wave << 9) | ((rawu < HPK_RAWCAP ? rawu : HPK_RAWCAP) << 13);
-            const unsigned R = (unsigned)__builtin_amdgcn_ds_permute((tgt & 63) << 2, (int)id);
-            if (lane >= a0 && lane < a0 + pc) curL = R;
-            if (a0 + pc >= 64) {                 // register full: commit, the wrapped part starts the next one
-                const int kf = cnt >> 6;
-#pragma unroll
-                for (int k = 0; k < NLIST; ++k) if (k == kf) L[k] = curL;
-                curL = (lane < a0 + pc - 64) ? R : 0u;
-            }
-            cnt += pc;
+            if (cnd) lst[cnt + below] = (unsigned)x | ((unsigned)yi << 7) | ((unsigned)wave << 9) | ((pix & PK_MASK) << 13);
+            cnt += __popcll(M);
         }
-    }
-    {
-        const int kf = cnt >> 6;            // partially filled last register
-#pragma unroll
-        for (int k = 0; k < NLIST; ++k) if (k == kf) L[k] = curL;
     }
     // this wave's share of the tile's record region
     unsigned woff = 0u;
@@ -415,10 +398,8 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
     const int nbatch = (cnt + 63) >> 6;
 #pragma unroll 1
     for (int kb = 0; kb < nbatch; ++kb) {
-        unsigned id = 0u;
-#pragma unroll
-        for (int k = 0; k < NLIST; ++k) if (k == kb) id = L[k];
         const bool cand = kb * 64 + lane < cnt;
+        const unsigned id = cand ? lst[kb * 64 + lane] : 0u;
         const int yi = (int)((id >> 7) & 3u), x = (int)(id & 127u);
         const int y = wave + NW * yi;
         if (cand && a.dbg_stop != 7) a.rec_ent[rec0 + kb * 64 + lane] = id;
@@ -426,7 +407,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
         const int d = c0 + x - r;
         const int base = (y + W + 1) * LC + W + 1 + x;       // idle lanes: id 0 -> a valid interior cell
         // S(Y, X-1) of the planes, the pixel's own balanced value, and the first Reads boxes: one batch of reads
-        const unsigned sr = S.r[base - 1];
+        const unsigned sr = S.p[base - 1];
         const double sc = S.c[base - 1];
         const double pixc = cand ? (S.c[base] - S.c[base - LC]) - (sc - S.c[base - LC - 1]) : 0.0;
         unsigned sstar = 0xffffffffu;           // resolving step index, 8 bits per slot (0xff = none)
@@ -435,9 +416,9 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
             // first width w* whose lower-left rings p0+1 .. w hold >= min_local_reads counts.  Rings are only ever
             // added, so Reads is monotone in w: the narrowest and the widest box are read together (most candidates
             // pass the first, far-from-diagonal ones often fail even the last), the lanes in between bisect.
-            const unsigned b0 = (p0_p > 0) ? reads_box(S.r, base, p0_p, sr) : 0u;
-            const unsigned bf = reads_box(S.r, base, wmin_p, sr);
-            const unsigned bl = reads_box(S.r, base, W, sr);
+            const unsigned b0 = (p0_p > 0) ? reads_box(S.p, base, p0_p, sr) : 0u;
+            const unsigned bf = reads_box(S.p, base, wmin_p, sr);
+            const unsigned bl = reads_box(S.p, base, W, sr);
             int wstar = 255;
             if (cand && bf - b0 >= (unsigned)minr_p) wstar = wmin_p;
             else if (cand && bl - b0 >= (unsigned)minr_p) wstar = W;
@@ -445,7 +426,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
             bool bis = cand && wstar == W && hi - lo > 1;
             while (__ballot(bis) != 0ull) {
                 const int mid = (lo + hi) >> 1;
-                const unsigned bm = reads_box(S.r, base, bis ? mid : wmin_p, sr);
+                const unsigned bm = reads_box(S.p, base, bis ? mid : wmin_p, sr);
                 if (bis) {
                     if (bm - b0 >= (unsigned)minr_p) hi = mid; else lo = mid;
                     wstar = hi;
@@ -488,7 +469,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
                     unsigned acc = 0u;
                     for (int j = 0; j < nrt; ++j) {
                         const unsigned t = (unsigned)(rt >> (16 * j)) & 0xffffu;
-                        acc += (unsigned)(int)(signed char)(t >> 8) * reads_box(S.r, base, (int)(t & 0xffu), sr);
+                        acc += (unsigned)(int)(signed char)(t >> 8) * reads_box(S.p, base, (int)(t & 0xffu), sr);
                     }
                     reads = acc;
                 }
@@ -537,14 +518,14 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
                 const bool tiny = act && (SK <= tiny_thr || (SY <= tiny_thr && SY != 0.0));
                 if (__ballot(tiny) != 0ull) {
                     if (tiny) {
-                        const unsigned sv = S.v[base - 1];
-                        const unsigned pv = S.v[base] - S.v[base - LC] - sv + S.v[base - LC - 1];
+                        const unsigned sv = sr;
+                        const unsigned pv = S.p[base] - S.p[base - LC] - sv + S.p[base - LC - 1];
                         unsigned VK = 0u, VY = 0u;
 #pragma unroll 1
                         for (int j = 0; j < nkt; ++j) {
                             const unsigned kw = (j < 2) ? k0 : (j < 4) ? k1 : (j < 6) ? k2 : k3;
                             const unsigned t = (kw >> (16 * (j & 1))) & 0xffffu;
-                            const unsigned long long kyv = box_ky_valid(S.v, base, (int)(t & 0xffu), pv, sv);
+                            const unsigned long long kyv = box_ky_valid(S.p, base, (int)(t & 0xffu), pv, sv);
                             VK += (unsigned)(int)(signed char)(t >> 8) * (unsigned)kyv;
                             VY += (unsigned)(int)(signed char)(t >> 8) * (unsigned)(kyv >> 32);
                         }
@@ -912,8 +893,8 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
             const int r = r0 + (int)((ent >> 9) & 15u) + HPK_NWAVES * (int)((ent >> 7) & 3u);
             const int c = c0 + (int)(ent & 127u);
             const int d = c - r;
-            float rawpix = (float)(ent >> 13);
-            if (cand && (ent >> 13) == HPK_RAWCAP) rawpix = a.raw[(int64_t)r * a.ld + d];     // count too large for the entry
+            float rawpix = (float)(ent >> 13);          // the SAT holds counts capped at HPK_PK_CAP: those are re-read
+            if (cand && (ent >> 13) >= HPK_PK_CAP) rawpix = a.raw[(int64_t)r * a.ld + d];
             const double O = (double)rawpix;
             const double ir = a.IR[cand ? d : 0], b2c = a.b2[cand ? c : 0], b1r = a.b1[cand ? r : 0];
             // which local-expected table serves this pixel (interior / clipped by one matrix end / both: explicit)
@@ -1191,7 +1172,7 @@ __global__ void __launch_bounds__(64) hpk_brute(HpkBruteArgs a) {
 }  // namespace
 
 // ------------------------------------------------------------------ launchers
-int hpk_stencil_lds_bytes() { return LR * LC * 16; }
+int hpk_stencil_lds_bytes() { return LR * LC * 12 + HPK_NWAVES * HPK_LISTCAP * 4; }
 
 template <int NW, bool BALF64, bool SIMPLE>
 static void launch_stencil_t(const HpkStencilArgs& a, hipStream_t st) {

@@ -52,6 +52,11 @@ int hpk_build_plan(const hpk_params* prm, HpkDevPlan* plan, char* msg) {
     plan->maxw = maxw;
     plan->D = (int32_t)(prm->maxapart / prm->res);
     plan->min_reads = (prm->mode == HPK_MODE_BHFDR) ? 16 : prm->min_local_reads;   // callers.py:490
+    if (plan->min_reads > (int32_t)HPK_PK_CAP) {
+        std::snprintf(msg, 256, "min_local_reads = %d: the stencil compares Reads on counts capped at %u, larger thresholds are not supported",
+                      plan->min_reads, HPK_PK_CAP);
+        return HPK_ERR_INVALID;
+    }
     plan->npairs = prm->npairs;
 
     // output slots: distinct peak widths in order of appearance (the bSV / bEV / RefIdx dict keys, callers.py:107-119)

@@ -8,6 +8,7 @@
 #define HPK_KSLOTS 4            // distinct peak widths the stencil kernel keeps in registers
 #define HPK_NB     128          // lambda-chunk boundaries 2^((i-1)/3), i = 1..HPK_NB
 #define HPK_NB_TAB 46           // chunks served from the device-built Poisson table (rv <= 2^15)
+#define HPK_PK_CAP 1023u        // raw counts enter the stencil's packed SAT plane capped here: min_local_reads may not exceed it
 
 struct HpkDevStep {
     int32_t slot;               // output slot = index of pi among the distinct peak widths

@@ -306,3 +306,38 @@ def test_submit_collect_matches_synchronous_call(ctx):
     b = ctx.submit_host(args[1][0], args[1][1], args[1][2], args[1][2], args[1][3], weight=args[1][4])
     _same_result(b.result(), sync[1])
     _same_result(a.result(), sync[0])
+
+
+@pytest.mark.parametrize('depth,min_reads', [(30000.0, 16), (3000.0, 900), (3000.0, 1023)])
+def test_deep_counts_beyond_the_sat_cap(depth, min_reads, ctx):
+    """Counts far above HPK_PK_CAP = 1023 (the stencil's packed SAT plane holds capped counts): the widening decisions,
+    the sums, O and the final table still equal the oracle's, also with a threshold close to the cap; a threshold above
+    the cap is refused."""
+    from hicpeaks_amd import synthetic
+    n, res, maxapart, maxww = 700, 10000, 900000, 10
+    num = maxapart // res + maxww + 1
+    raw, weight, _ = synthetic.synth_band(n, num, depth=depth, nloops=12, seed=7)
+    assert (raw > 1023).sum() > 500
+    pw, ww, sig = [2], [5], 0.05
+    IR, cband, biases = orc.prep_from_band(raw, weight, min(ww))
+    loc = orc.hiccups_local_sums(raw, cband, IR, n, num, pw, ww, maxww, maxapart, res, min_reads)
+    want = orc.hiccups(raw, cband, biases, biases, IR, n, num, pw=pw, ww=ww, maxww=maxww, sig=sig, maxapart=maxapart,
+                       res=res, min_local_reads=min_reads, min_marginal_peaks=2, onlyanchor=False)
+    detail = dict(dense=True)
+    got = callers.hiccups_band(raw.astype(np.float32), IR, biases, biases, chrom='T', weight=weight, pw=pw, ww=ww,
+                               maxww=maxww, sig=sig, maxapart=maxapart, res=res, min_local_reads=min_reads,
+                               min_marginal_peaks=2, onlyanchor=False, ctx=ctx, detail=detail)
+    R = detail['result']
+    vx, vy = loc['vx'], loc['vy']
+    w = R.dense_w[0][vx, vy - vx].astype(np.int64)
+    np.testing.assert_array_equal(np.where(w > R.frozen_w, 0, w), loc['wres'][pw[0]])
+    for s in R.sets:                                   # O of the survivors is the true count, not the capped one
+        np.testing.assert_array_equal(s['O'], raw[s['x'], s['y'] - s['x']])
+    k, v = _table_arrays(got)
+    kw, vw = _table_arrays(want)
+    np.testing.assert_array_equal(k, kw)
+    if k.size:
+        np.testing.assert_allclose(v, vw, rtol=1e-9, atol=1e-9)
+    with pytest.raises(_lib.HpkError):
+        callers.hiccups_band(raw.astype(np.float32), IR, biases, biases, chrom='T', weight=weight, pw=pw, ww=ww,
+                             maxww=maxww, sig=sig, maxapart=maxapart, res=res, min_local_reads=1024, ctx=ctx)
