@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
             if (cand && bf - b0 >= (unsigned)minr_p) wstar = wmin_p;
             else if (cand && bl - b0 >= (unsigned)minr_p) wstar = W;
             int lo = wmin_p, hi = W;            // invariant for bisecting lanes: Reads(lo) < min <= Reads(hi)
-            bool bis = cand && wstar == W && hi - lo > 1;
+            bool bis = cand && wstar == W && hi - lo > 1 && !(a.dbg_stop & 32);
             while (__ballot(bis) != 0ull) {
                 const int mid = (lo + hi) >> 1;
                 const unsigned bm = reads_box(S.p, base, bis ? mid : wmin_p, sr);
@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
                 if (!cand || wstar == 255) sq = 0xff;
                 sstar = (sstar & ~(0xffu << (8 * q))) | ((unsigned)(sq & 0xff) << (8 * q));
                 // histogram: one ballot per distinct resolving step present in the wave
-                unsigned long long left = __ballot(sq != 0xff);
+                unsigned long long left = (a.dbg_stop & 16) ? 0ull : __ballot(sq != 0xff);
                 while (left != 0ull) {
                     const int ln = __ffsll((long long)left) - 1;
                     const int sv0 = __builtin_amdgcn_readlane(sq, ln);
@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
                     }
                 }
             }
-            if (a.dbg_stop == 7) { if (SK == -1.0 && SY == -7.0 && sq == 1234) a.hist[0] = 1ull; }
+            if (a.dbg_stop == 7 || (a.dbg_stop & 64)) { if (SK == -1.0 && SY == -7.0 && sq == 1234) a.hist[0] = 1ull; }
             else if (cand) {
                 const int64_t o = q * a.rec_stride + rec0 + kb * 64 + lane;
                 g_recS[o] = make_double2(act ? SK : 0.0, act ? SY : 0.0);

@@ -341,3 +341,37 @@ def test_deep_counts_beyond_the_sat_cap(depth, min_reads, ctx):
     with pytest.raises(_lib.HpkError):
         callers.hiccups_band(raw.astype(np.float32), IR, biases, biases, chrom='T', weight=weight, pw=pw, ww=ww,
                              maxww=maxww, sig=sig, maxapart=maxapart, res=res, min_local_reads=1024, ctx=ctx)
+
+
+@pytest.mark.parametrize('maxww,pw,ww', [(3, [1], [3]), (5, [2], [4]), (6, [1, 2], [3, 5]), (7, [2], [5])])
+def test_small_maxww_tiles(maxww, pw, ww, ctx):
+    """maxww < 8 leaves more than 64 of the 80 SAT rows to the output tile; the tile is capped at four rows per wave.
+    Resolving widths, sums and the final table against the oracle."""
+    from hicpeaks_amd import synthetic
+    n, res, maxapart = 900, 10000, 1200000
+    num = maxapart // res + maxww + 1
+    raw, weight, _ = synthetic.synth_band(n, num, depth=25.0, nloops=15, seed=11)
+    IR, cband, biases = orc.prep_from_band(raw, weight, min(ww))
+    loc = orc.hiccups_local_sums(raw, cband, IR, n, num, pw, ww, maxww, maxapart, res, 16)
+    want = orc.hiccups(raw, cband, biases, biases, IR, n, num, pw=pw, ww=ww, maxww=maxww, sig=0.1, maxapart=maxapart,
+                       res=res, min_local_reads=16, min_marginal_peaks=2, onlyanchor=False)
+    detail = dict(dense=True)
+    got = callers.hiccups_band(raw.astype(np.float32), IR, biases, biases, chrom='T', weight=weight, pw=pw, ww=ww,
+                               maxww=maxww, sig=0.1, maxapart=maxapart, res=res, min_local_reads=16,
+                               min_marginal_peaks=2, onlyanchor=False, ctx=ctx, detail=detail)
+    R = detail['result']
+    vx, vy = loc['vx'], loc['vy']
+    assert R.ncand == vx.size
+    for slot, pi in enumerate(R.slot_pi):
+        w = R.dense_w[slot][vx, vy - vx].astype(np.int64)
+        w = np.where(w > R.frozen_w, 0, w)
+        np.testing.assert_array_equal(w, loc['wres'][pi])
+        sums = R.dense_sums[slot][vx, vy - vx]
+        ok = w > 0
+        for col, (fl, arr) in enumerate([('K', 'bSV'), ('K', 'bEV'), ('Y', 'bSV'), ('Y', 'bEV')]):
+            np.testing.assert_allclose(sums[ok, col], loc[arr][pi][fl][ok], rtol=1e-11, atol=0)
+    k, v = _table_arrays(got)
+    kw, vw = _table_arrays(want)
+    np.testing.assert_array_equal(k, kw)
+    if k.size:
+        np.testing.assert_allclose(v, vw, rtol=1e-9, atol=1e-9)
