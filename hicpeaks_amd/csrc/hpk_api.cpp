@@ -420,7 +420,7 @@ struct hpk_job {
     HpkStencilArgs sa;
     size_t off_rowlive = 0, off_inl = 0, head_bytes = 0, off_cnt = 0, off_cu = 0, dense_elems = 0;
     int64_t cap = 0, band_px = 0, ldo = 0;
-    int nsets = 0, TR = 0, TC = 0, rounds = 3;
+    int nsets = 0, TR = 0, TC = 0, rounds = 2;
     bool sums = false, dense = false, do_score = true, phases = false;
     double t_begin = 0.0;
     ResultBox* box = nullptr;
@@ -520,7 +520,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     j->dense = j->sums || (prm->flags & HPK_FLAG_DENSE_E) != 0;
     j->do_score = (prm->flags & HPK_FLAG_NO_SCORE) == 0;
     j->phases = (prm->flags & HPK_FLAG_PHASE_TIMING) != 0;
-    j->rounds = std::getenv("HPK_ROUNDS") ? std::atoi(std::getenv("HPK_ROUNDS")) : 3;
+    j->rounds = std::getenv("HPK_ROUNDS") ? std::atoi(std::getenv("HPK_ROUNDS")) : 2;
     const bool sums = j->sums, dense = j->dense;
 
     j->box = new ResultBox();

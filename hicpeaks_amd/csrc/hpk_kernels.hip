@@ -423,7 +423,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
             if (cand && bf - b0 >= (unsigned)minr_p) wstar = wmin_p;
             else if (cand && bl - b0 >= (unsigned)minr_p) wstar = W;
             int lo = wmin_p, hi = W;            // invariant for bisecting lanes: Reads(lo) < min <= Reads(hi)
-            bool bis = cand && wstar == W && hi - lo > 1 && !(a.dbg_stop & 32);
+            bool bis = cand && wstar == W && hi - lo > 1;
             while (__ballot(bis) != 0ull) {
                 const int mid = (lo + hi) >> 1;
                 const unsigned bm = reads_box(S.p, base, bis ? mid : wmin_p, sr);
@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
                 if (!cand || wstar == 255) sq = 0xff;
                 sstar = (sstar & ~(0xffu << (8 * q))) | ((unsigned)(sq & 0xff) << (8 * q));
                 // histogram: one ballot per distinct resolving step present in the wave
-                unsigned long long left = (a.dbg_stop & 16) ? 0ull : __ballot(sq != 0xff);
+                unsigned long long left = __ballot(sq != 0xff);
                 while (left != 0ull) {
                     const int ln = __ffsll((long long)left) - 1;
                     const int sv0 = __builtin_amdgcn_readlane(sq, ln);
@@ -534,7 +534,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
                     }
                 }
             }
-            if (a.dbg_stop == 7 || (a.dbg_stop & 64)) { if (SK == -1.0 && SY == -7.0 && sq == 1234) a.hist[0] = 1ull; }
+            if (a.dbg_stop == 7) { if (SK == -1.0 && SY == -7.0 && sq == 1234) a.hist[0] = 1ull; }
             else if (cand) {
                 const int64_t o = q * a.rec_stride + rec0 + kb * 64 + lane;
                 g_recS[o] = make_double2(act ? SK : 0.0, act ? SY : 0.0);
@@ -961,12 +961,12 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                     const unsigned long long vm = (a.dbg == 4) ? 0ull : __ballot(valid);
                     const unsigned long long sm = __ballot(surv);
                     if (vm != 0ull) {
-                        double em = valid ? E : 0.0;
-                        for (int off = 32; off > 0; off >>= 1) em = fmax(em, __shfl_xor(em, off));
-                        if (lane == 0) {
-                            atomicAdd(&lvalid[set], (unsigned)__popcll(vm));
-                            atomicMax(&lemax[set], (unsigned long long)__double_as_longlong(em));
-                        }
+                        if (lane == 0) atomicAdd(&lvalid[set], (unsigned)__popcll(vm));
+                        // Emax of the set: E > 0, so its bit pattern orders like its value.  The block's running maximum
+                        // settles after a few batches; only lanes that beat it touch the LDS atomic.
+                        const unsigned long long ebits = (unsigned long long)__double_as_longlong(E);
+                        const bool beats = valid && ebits > lemax[set];
+                        if (__ballot(beats) != 0ull) { if (beats) atomicMax(&lemax[set], ebits); }
                         if (valid && chunk) atomicAdd(&lm[set][chunk], 1u);
                         if (surv) atomicAdd(&lf[set][chunk], 1u);
                     }
