@@ -291,9 +291,11 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
             tp[e] += pkv[j][e];
         }
     }
+    // the prefetch registers are free again: the next tile's rows start moving now, beside this tile's SAT build and
+    // candidate work (nothing below waits for them)
+    if (tid_next >= 0) tile_load<RPW, BALF64>(a, g_raw, g_bal, g_w, tid_next, wave, lane, nxt);
     if (a.dbg_stop == 1) {
         if (tc[0] + tc[1] == -1.0 && tp[0] + tp[1] == 77u) a.hist[0] = 1ull;     // keep the loads live
-        if (tid_next >= 0) tile_load<RPW, BALF64>(a, g_raw, g_bal, g_w, tid_next, wave, lane, nxt);
         tid = tid_next;
         continue;
     }
@@ -331,8 +333,6 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
         *reinterpret_cast<uint2*>(&S.p[o]) = make_uint2(ar[0], ar[1]);
     }
     __syncthreads();
-    // the next tile's rows start moving now; nothing below waits for them
-    if (tid_next >= 0) tile_load<RPW, BALF64>(a, g_raw, g_bal, g_w, tid_next, wave, lane, nxt);
     if (a.dbg_stop == 2) {
         if (S.c[threadIdx.x] == -1.0) a.hist[0] = 1ull;
         __syncthreads();
