@@ -183,7 +183,7 @@ def main():
         raise SystemExit('bench.py needs an MI355X: there is no CPU path')
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get('HPK_BENCH_FORCE_DIST'):     # the env knob exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')

@@ -1,5 +1,5 @@
-// HIP kernels for gfx950 (MI355X / CDNA4).  Wave = 64 lanes; one stencil workgroup owns the whole 160 KiB
-// LDS of a CU.
+// HIP kernels for gfx950 (MI355X / CDNA4).  Wave = 64 lanes; one stencil workgroup owns the LDS of a CU
+// (152 of 160 KiB).
 //
 //   hpk_stencil   donut (K) + lower-left (Y) local sums and adaptive widening   callers.py:132-232, 440-513
 //   hpk_freeze    frozen_w / break decision from the resolve histogram            callers.py:208-229, 505-511
@@ -219,7 +219,8 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
     const int W = a.W, n = a.n, num = a.num, mw = a.mw, D = a.D;
 
     // ---- per-workgroup constants.  The widening plan lives in registers: lane s holds step s (HpkDevPlan::packed),
-    // v_readlane / ds_bpermute hand the fields out, so the pixel loops touch memory only for the SAT and the stores.
+    // v_readlane / ds_bpermute hand the fields out, so the pixel loops touch memory only for the SAT, the lists and the
+    // stores.  (Keeping it in LDS instead was measured 5 % slower.)
     const HpkDevPlan* __restrict__ plan = a.plan;
     const int nsteps = plan->nsteps, nslots = plan->nslots, min_reads = plan->min_reads;
     int pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, pk6 = 0;
@@ -340,7 +341,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
         continue;
     }
     const double tiny_thr = 1e-9 * S.c[LR * LC - 1];
-    // Gap rows (callers.py:238: rows of the balanced upper band that sum to 0): the valid-count plane gives the exact
+    // Gap rows (callers.py:238: rows of the balanced upper band that sum to 0): the valid-count field gives the exact
     // row sum of this tile's columns; the last tile of a row block also covers the maxww diagonals beyond D in its
     // right halo.  The flags start at 0 ("no signal seen"); any tile that sees a non-zero balanced value in row r
     // sets rowlive[r] (plain byte stores of the same value: no atomics needed).  gap = !rowlive.
@@ -514,7 +515,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
                 if (d - (int)((w0 >> 24) & 31u) - 1 < mw) SY = 0.0;
                 // A box whose balanced values are all 0 must come out as exact 0 (as the reference's CSR adds do);
                 // the f64 SAT leaves rounding residue of at most ~1e-13 of the tile total there.  Sums below 1e-9
-                // of the tile total are re-examined on the exact u32 valid-raw plane.
+                // of the tile total are re-examined on the exact valid-count field of the packed plane.
                 const bool tiny = act && (SK <= tiny_thr || (SY <= tiny_thr && SY != 0.0));
                 if (__ballot(tiny) != 0ull) {
                     if (tiny) {

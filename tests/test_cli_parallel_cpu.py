@@ -92,3 +92,17 @@ def test_run_sharded_world2_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert 'GATHER_OK 7' in outs[0]
+
+
+def test_run_sharded_batch_fn_single_rank():
+    """batch_fn path of run_sharded (the one-ahead loop hands back tables in the order of the chromosomes it got)."""
+    from hicpeaks_amd import parallel
+    sizes = {'1': 100, '2': 80, 'X': 60}
+    seen = []
+
+    def batch(chroms):
+        seen.append(list(chroms))
+        return [{'chrom': c} for c in chroms]
+    out = parallel.run_sharded(sizes, None, 0, 1, batch_fn=batch)
+    assert seen == [parallel.lpt_partition(sizes, 1)[0]]
+    assert out == {c: {'chrom': c} for c in sizes}
