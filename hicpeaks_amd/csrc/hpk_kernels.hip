@@ -880,16 +880,28 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
         const int rb = tile / a.J, cj = tile - rb * a.J;
         const int r0 = rb * a.TR, c0 = r0 + a.mw + cj * a.TC;
         const int iend = (ub * 256 + 256 < cnt) ? ub * 256 + 256 : cnt;
+        // Dependent rounds of loads per batch: (1) entry + first slot's step and sums - requested one batch ahead (idle
+        // lanes read the tile's first record: always allocated, never used), (2) IR, biases and the local-expected
+        // table entries, all addressed from the entry, (3) the Poisson table.
+        const int slot0 = lpair_slot[0];
+        const int64_t tbase0 = (int64_t)tile * a.tilecap;
+        int64_t ri_b = tbase0 + ((ub * 256 + lane < cnt) ? ub * 256 + lane : 0);
+        unsigned ent_b = a.rec_ent[ri_b];
+        int stp_b = (int)a.rec_W[slot0 * a.rec_stride + ri_b];
+        double2 s2_b = a.rec_S[slot0 * a.rec_stride + ri_b];
         for (int i0 = ub * 256; i0 < iend; i0 += 64) {
             const bool cand = i0 + lane < cnt;
-            // Three dependent rounds of loads per batch instead of five: (1) entry + first slot's step and sums (idle
-            // lanes read the tile's first record: always allocated, never used), (2) IR, biases and the local-expected
-            // table entries, all addressed from the entry, (3) the Poisson table.
-            const int64_t ri = (int64_t)tile * a.tilecap + (cand ? i0 + lane : 0);
-            unsigned ent = a.rec_ent[ri];
-            int slot = lpair_slot[0];
-            int stp_n = (int)a.rec_W[slot * a.rec_stride + ri];
-            double2 s2_n = a.rec_S[slot * a.rec_stride + ri];
+            const int64_t ri = ri_b;
+            unsigned ent = ent_b;
+            int slot = slot0;
+            int stp_n = stp_b;
+            double2 s2_n = s2_b;
+            if (i0 + 64 < iend) {
+                ri_b = tbase0 + ((i0 + 64 + lane < cnt) ? i0 + 64 + lane : 0);
+                ent_b = a.rec_ent[ri_b];
+                stp_b = (int)a.rec_W[slot0 * a.rec_stride + ri_b];
+                s2_b = a.rec_S[slot0 * a.rec_stride + ri_b];
+            }
             if (!cand) ent = 0u;
             const int r = r0 + (int)((ent >> 9) & 15u) + HPK_NWAVES * (int)((ent >> 7) & 3u);
             const int c = c0 + (int)(ent & 127u);
