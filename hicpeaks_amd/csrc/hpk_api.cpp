@@ -475,7 +475,7 @@ int launch_scoring(hpk_ctx* c, hpk_job* j, int attempt) {
         if (j->phases) (void)hipEventRecord(L.ev[4], c->stream);
         hpk_launch_tighten(sc.surv, d_nsurv, cap, sc.chunk_used, d_fam_m, d_fam_f, d_cnt, j->prm.sig, j->rounds, j->nsets,
                            reinterpret_cast<HpkSurv*>(small + j->off_inl), HEAD_INLINE, L.surv2.as<HpkSurv>(), d_nout,
-                           c->cus, c->stream);
+                           j->in.bal, j->in.weight, j->ld, c->cus, c->stream);
         HIPCHK(c, hipGetLastError());
     } else {
         if (j->phases) (void)hipEventRecord(L.ev[4], c->stream);

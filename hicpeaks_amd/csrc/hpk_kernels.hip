@@ -845,6 +845,11 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     __shared__ int lpair_slot[HPK_MAX_PAIRS], lpair_wi[HPK_MAX_PAIRS];
     __shared__ int lptoff[HPK_NB_TAB + 2];
     const HpkDevPlan* __restrict__ plan = a.plan;
+    // Arguments that only rare paths need (re-read of a capped count, Poisson beyond the table, chunk bookkeeping) are
+    // fetched from the kernel-argument segment where they are used instead of being held in SGPRs for the whole
+    // kernel: with ~45 scalars live the compiler spilled ~80 of them to VGPR lanes, and the spill traffic
+    // (v_readlane / v_writelane / s_nop) was 15 % of the instruction stream of this issue-bound kernel.
+    const volatile HpkScoreArgs* ka = (const volatile HpkScoreArgs*)(const void*)__builtin_amdgcn_kernarg_segment_ptr();
     const int mode = plan->mode;
     const int npairs = plan->npairs;
     const int W = plan->W;
@@ -907,7 +912,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
             const int c = c0 + (int)(ent & 127u);
             const int d = c - r;
             float rawpix = (float)(ent >> 13);          // the SAT holds counts capped at HPK_PK_CAP: those are re-read
-            if (cand && (ent >> 13) >= HPK_PK_CAP) rawpix = a.raw[(int64_t)r * a.ld + d];
+            if (cand && (ent >> 13) >= HPK_PK_CAP) rawpix = ka->raw[(int64_t)r * ka->ld + d];
             const double O = (double)rawpix;
             const double ir = a.IR[cand ? d : 0], b2c = a.b2[cand ? c : 0], b1r = a.b1[cand ? r : 0];
             // which local-expected table serves this pixel (interior / clipped by one matrix end / both: explicit)
@@ -947,7 +952,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                     if (valid) {
                         if (mode == HPK_MODE_BHFDR) {
                             chunk = 1;
-                            p = poisson_sf(O, E, a.sfe);                      // callers.py:536-540
+                            p = poisson_sf(O, E, const_cast<const double*>(ka->sfe));      // callers.py:536-540
                         } else {
                             // lo = number of boundaries <= E (boundaries are 2^(i/3), i = 0..); membership is strict on
                             // both sides (callers.py:38), so E sitting on a boundary belongs to no chunk
@@ -964,7 +969,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                                     const long long kO = (long long)O;
                                     p = (a.dbg == 1) ? 0.5 : ((kO < len) ? a.ptab[base + (int)kO] : 0.0);
                                 } else {
-                                    p = poisson_sf(O, lbounds[chunk - 1], a.sfe);   // callers.py:268-270
+                                    p = poisson_sf(O, lbounds[chunk - 1], const_cast<const double*>(ka->sfe));   // callers.py:268-270
                                 }
                             }
                         }
@@ -986,7 +991,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                     if (sm != 0ull) {
                         const unsigned scnt = (unsigned)__popcll(sm);
                         if (wused + scnt > HPK_SCH) {            // wave-uniform: retire the chunk, take a new one
-                            if (have_chunk && lane == 0 && (int64_t)wbase < a.cap) a.chunk_used[(rbase + (int64_t)wbase) / HPK_SCH] = wused;
+                            if (have_chunk && lane == 0 && (int64_t)wbase < a.cap) const_cast<unsigned*>(ka->chunk_used)[(rbase + (int64_t)wbase) / HPK_SCH] = wused;
                             have_chunk = true;
                             unsigned long long nb = 0ull;
                             if (lane == 0) nb = atomicAdd(&a.nsurv[region * HPK_REG_STRIDE], (unsigned long long)HPK_SCH);
@@ -998,13 +1003,10 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                         if (surv) {
                             const unsigned long long idx = basei + (unsigned long long)__popcll(sm & ((1ull << lane) - 1ull));
                             if ((int64_t)idx < a.cap) {
-                                double b;
-                                if (a.bal) { b = a.bal[(int64_t)r * a.ld + d]; b = (b == b) ? b : 0.0; }
-                                else b = balanced_of(rawpix, a.weight[r], a.weight[c]);
                                 HpkSurv rec;
                                 rec.x = r; rec.y = c; rec.O = rawpix; rec.set = (uint8_t)set; rec.chunk = (uint8_t)chunk;
                                 rec.flag = (fl == 0 && eY == 0.0) ? 1 : 0;           // callers.py:330
-                                rec.pad = 0; rec.E = E; rec.p = p; rec.bal = b;
+                                rec.pad = 0; rec.E = E; rec.p = p; rec.bal = 0.0;       // balanced value: filled by hpk_thr_compact
                                 a.surv[rbase + (int64_t)idx] = rec;
                             }
                         }
@@ -1013,7 +1015,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
             }
         }
     }
-    if (have_chunk && lane == 0 && (int64_t)wbase < a.cap) a.chunk_used[(rbase + (int64_t)wbase) / HPK_SCH] = wused;
+    if (have_chunk && lane == 0 && (int64_t)wbase < a.cap) const_cast<unsigned*>(ka->chunk_used)[(rbase + (int64_t)wbase) / HPK_SCH] = wused;
     __syncthreads();
     for (int i = threadIdx.x; i < nsets * (HPK_NB + 1); i += blockDim.x) {
         const unsigned v = (&lm[0][0])[i], f = (&lf[0][0])[i];
@@ -1078,7 +1080,8 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkSurv* __restrict
                                                        const unsigned int* __restrict__ fam_m, const unsigned int* __restrict__ fam_f,
                                                        const unsigned int* __restrict__ cnt, int rounds, double sig, int nfam,
                                                        HpkSurv* __restrict__ out_head, unsigned long long inl,
-                                                       HpkSurv* __restrict__ out_rest, unsigned long long* __restrict__ nout) {
+                                                       HpkSurv* __restrict__ out_rest, unsigned long long* __restrict__ nout,
+                                                       const double* __restrict__ bal, const double* __restrict__ weight, int64_t ld) {
     __shared__ double lthr[HPK_NFAM];
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1096,7 +1099,14 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkSurv* __restrict
             if ((unsigned)(i & 255) < chunk_used[(rb + i) >> 8]) {
                 const HpkSurv& src = surv[rb + i];
                 keep = src.p <= lthr[(int)src.set * (HPK_NB + 1) + (int)src.chunk];
-                if (keep) rec = src;                      // the other 30 bytes only for the few that stay
+                if (keep) {                               // the other 30 bytes only for the few that stay
+                    rec = src;
+                    // the pixel's balanced value (reported with the call, callers.py:254-256), for these few only
+                    double b;
+                    if (bal) { b = bal[(int64_t)rec.x * ld + (rec.y - rec.x)]; b = (b == b) ? b : 0.0; }
+                    else b = balanced_of(rec.O, weight[rec.x], weight[rec.y]);
+                    rec.bal = b;
+                }
             }
         }
         const unsigned long long km = __ballot(keep);
@@ -1229,13 +1239,13 @@ void hpk_launch_score(const HpkScoreArgs& a, int cus, hipStream_t st) {
 void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned* chunk_used,
                         const unsigned int* fam_m, const unsigned int* fam_f, unsigned int* fam_cnt, double sig, int rounds,
                         int nsets, HpkSurv* out_head, unsigned long long inl, HpkSurv* out_rest, unsigned long long* nout,
-                        int cus, hipStream_t st) {
+                        const double* bal, const double* weight, int64_t ld, int cus, hipStream_t st) {
     if (rounds > HPK_TIGHTEN_MAX) rounds = HPK_TIGHTEN_MAX;
     const int nfam = nsets * (HPK_NB + 1);          // families in use: (set, chunk)
     for (int r = 0; r < rounds; ++r)
         hipLaunchKernelGGL(hpk_thr_count, dim3(8, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt, r, sig, nfam);
     hipLaunchKernelGGL(hpk_thr_compact, dim3(8, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt,
-                       rounds, sig, nfam, out_head, inl, out_rest, nout);
+                       rounds, sig, nfam, out_head, inl, out_rest, nout, bal, weight, ld);
 }
 
 void hpk_launch_prep(const float* raw, const double* weight, int n, int num, int64_t ld, int mw, double* psum, unsigned* pnan,
