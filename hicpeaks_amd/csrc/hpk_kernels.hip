@@ -855,15 +855,16 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     const int W = plan->W;
     const int nsets = (mode == HPK_MODE_BHFDR) ? 1 : 2 * npairs;
     for (int i = threadIdx.x; i < nsets * (HPK_NB + 1); i += blockDim.x) { (&lm[0][0])[i] = 0u; (&lf[0][0])[i] = 0u; }
-    if (threadIdx.x < HPK_NB) lbounds[threadIdx.x] = a.bounds[threadIdx.x];
+    if (threadIdx.x < HPK_NB) lbounds[threadIdx.x] = const_cast<const double*>(ka->bounds)[threadIdx.x];
     if (threadIdx.x < 2 * HPK_MAX_PAIRS) { lemax[threadIdx.x] = 0ull; lvalid[threadIdx.x] = 0u; }
     if (threadIdx.x < HPK_MAX_STEPS) lstepw[threadIdx.x] = (threadIdx.x < plan->nsteps) ? plan->steps[threadIdx.x].wi : 0;
     if (threadIdx.x < HPK_MAX_PAIRS) { lpair_slot[threadIdx.x] = plan->pair_slot[threadIdx.x]; lpair_wi[threadIdx.x] = plan->pair_wi[threadIdx.x]; }
-    if (threadIdx.x < HPK_NB_TAB + 2) lptoff[threadIdx.x] = a.ptab_off[threadIdx.x];
+    if (threadIdx.x < HPK_NB_TAB + 2) lptoff[threadIdx.x] = const_cast<const int32_t*>(ka->ptab_off)[threadIdx.x];
     __syncthreads();
 
     const int lane = threadIdx.x & 63;
-    const int frozen = *a.frozen;
+    const int nsteps_u = plan->nsteps;
+    const int frozen = *const_cast<const int32_t*>(ka->frozen);
     // Survivor slots are reserved from the global counter HPK_SCH records at a time per wave (same-address atomics
     // run at ~90 per microsecond device-wide); how many slots of a chunk were filled goes to chunk_used[].
     constexpr unsigned HPK_SCH = 256;
@@ -888,24 +889,29 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
         // Dependent rounds of loads per batch: (1) entry + first slot's step and sums - requested one batch ahead (idle
         // lanes read the tile's first record: always allocated, never used), (2) IR, biases and the local-expected
         // table entries, all addressed from the entry, (3) the Poisson table.
+        // wave-uniform bases of the tile's record region (scalar arithmetic), 32-bit lane offsets
         const int slot0 = lpair_slot[0];
         const int64_t tbase0 = (int64_t)tile * a.tilecap;
-        int64_t ri_b = tbase0 + ((ub * 256 + lane < cnt) ? ub * 256 + lane : 0);
-        unsigned ent_b = a.rec_ent[ri_b];
-        int stp_b = (int)a.rec_W[slot0 * a.rec_stride + ri_b];
-        double2 s2_b = a.rec_S[slot0 * a.rec_stride + ri_b];
+        const unsigned* __restrict__ ent_t = a.rec_ent + tbase0;
+        const uint8_t* __restrict__ recW_t = a.rec_W + tbase0;
+        const double2* __restrict__ recS_t = a.rec_S + tbase0;
+        const int64_t sl0 = slot0 * a.rec_stride;
+        unsigned ri_b = (ub * 256 + lane < cnt) ? (unsigned)(ub * 256 + lane) : 0u;
+        unsigned ent_b = ent_t[ri_b];
+        int stp_b = (int)(recW_t + sl0)[ri_b];
+        double2 s2_b = (recS_t + sl0)[ri_b];
         for (int i0 = ub * 256; i0 < iend; i0 += 64) {
             const bool cand = i0 + lane < cnt;
-            const int64_t ri = ri_b;
+            const unsigned ri = ri_b;
             unsigned ent = ent_b;
             int slot = slot0;
             int stp_n = stp_b;
             double2 s2_n = s2_b;
             if (i0 + 64 < iend) {
-                ri_b = tbase0 + ((i0 + 64 + lane < cnt) ? i0 + 64 + lane : 0);
-                ent_b = a.rec_ent[ri_b];
-                stp_b = (int)a.rec_W[slot0 * a.rec_stride + ri_b];
-                s2_b = a.rec_S[slot0 * a.rec_stride + ri_b];
+                ri_b = (i0 + 64 + lane < cnt) ? (unsigned)(i0 + 64 + lane) : 0u;
+                ent_b = ent_t[ri_b];
+                stp_b = (int)(recW_t + sl0)[ri_b];
+                s2_b = (recS_t + sl0)[ri_b];
             }
             if (!cand) ent = 0u;
             const int r = r0 + (int)((ent >> 9) & 15u) + HPK_NWAVES * (int)((ent >> 7) & 3u);
@@ -914,13 +920,13 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
             float rawpix = (float)(ent >> 13);          // the SAT holds counts capped at HPK_PK_CAP: those are re-read
             if (cand && (ent >> 13) >= HPK_PK_CAP) rawpix = ka->raw[(int64_t)r * ka->ld + d];
             const double O = (double)rawpix;
-            const double ir = a.IR[cand ? d : 0], b2c = a.b2[cand ? c : 0], b1r = a.b1[cand ? r : 0];
+            const double ir = a.IR[cand ? (unsigned)d : 0u], b2c = a.b2[cand ? (unsigned)c : 0u], b1r = a.b1[cand ? (unsigned)r : 0u];
             // which local-expected table serves this pixel (interior / clipped by one matrix end / both: explicit)
             const bool top = cand && r < W, right = cand && c >= a.n - W;
             const bool both = top && right;
             const double* __restrict__ tab = (top != right) ? a.eedge : a.etab;
-            const int64_t tstride = (int64_t)2 * (a.D + 1);
-            const int64_t tbase = (top != right) ? (int64_t)(((top ? 0 : 1) * W + (top ? r : a.n - 1 - c)) * plan->nsteps) * tstride : 0;
+            const unsigned tstride = 2u * (unsigned)(a.D + 1);          // table offsets fit 32 bits: <= 2 * 20 * 64 * 2 * (D + 1) entries
+            const unsigned tbase = (top != right) ? (unsigned)(((top ? 0 : 1) * W + (top ? r : a.n - 1 - c)) * nsteps_u) * tstride : 0u;
 
             for (int pj = 0; pj < npairs; ++pj) {
                 const int wi0 = lpair_wi[pj];
@@ -928,13 +934,14 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                 const double2 s2 = s2_n;
                 if (pj + 1 < npairs) {                  // next slot's record is on its way while this one is scored
                     slot = lpair_slot[pj + 1];
-                    stp_n = (int)a.rec_W[slot * a.rec_stride + ri];
-                    s2_n = a.rec_S[slot * a.rec_stride + ri];
+                    const int64_t sl = slot * a.rec_stride;
+                    stp_n = (int)(recW_t + sl)[ri];
+                    s2_n = (recS_t + sl)[ri];
                 }
                 // resolved at an executed step (callers.py:133-134), far enough from the diagonal (callers.py:244)
                 const bool ok = cand && d >= wi0 && stp != 0 && lstepw[stp > 0 ? stp - 1 : 0] <= frozen;
-                const int64_t to = tbase + (int64_t)(ok ? stp - 1 : 0) * tstride + (cand ? d : 0);
-                double EK = tab[to], EY = tab[to + (a.D + 1)];
+                const unsigned to = tbase + (unsigned)(ok ? stp - 1 : 0) * tstride + (cand ? (unsigned)d : 0u);
+                double EK = tab[to], EY = tab[to + (unsigned)(a.D + 1)];
                 if (__ballot(both && ok) != 0ull) {
                     if (both && ok) edge_expected(plan->steps[stp - 1].m, plan->steps[stp - 1].wi, a.IR, r, c, a.n, a.num, a.mw, EK, EY);
                 }
@@ -967,7 +974,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                                 if (chunk <= HPK_NB_TAB) {
                                     const int base = lptoff[chunk], len = lptoff[chunk + 1] - base;
                                     const long long kO = (long long)O;
-                                    p = (a.dbg == 1) ? 0.5 : ((kO < len) ? a.ptab[base + (int)kO] : 0.0);
+                                    p = (a.dbg == 1) ? 0.5 : ((kO < len) ? a.ptab[(unsigned)(base + (int)kO)] : 0.0);
                                 } else {
                                     p = poisson_sf(O, lbounds[chunk - 1], const_cast<const double*>(ka->sfe));   // callers.py:268-270
                                 }
@@ -1019,12 +1026,12 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     __syncthreads();
     for (int i = threadIdx.x; i < nsets * (HPK_NB + 1); i += blockDim.x) {
         const unsigned v = (&lm[0][0])[i], f = (&lf[0][0])[i];
-        if (v) atomicAdd(&a.fam_m[i], v);
-        if (f) atomicAdd(&a.fam_f[i], f);
+        if (v) atomicAdd(&const_cast<unsigned int*>(ka->fam_m)[i], v);
+        if (f) atomicAdd(&const_cast<unsigned int*>(ka->fam_f)[i], f);
     }
     if (threadIdx.x < nsets) {
-        if (lvalid[threadIdx.x]) atomicAdd(&a.nvalid[threadIdx.x], (unsigned long long)lvalid[threadIdx.x]);
-        if (lemax[threadIdx.x]) atomicMax(&a.emax_bits[threadIdx.x], lemax[threadIdx.x]);
+        if (lvalid[threadIdx.x]) atomicAdd(&const_cast<unsigned long long*>(ka->nvalid)[threadIdx.x], (unsigned long long)lvalid[threadIdx.x]);
+        if (lemax[threadIdx.x]) atomicMax(&const_cast<unsigned long long*>(ka->emax_bits)[threadIdx.x], lemax[threadIdx.x]);
     }
 }
 
