@@ -561,6 +561,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     j->band_px = band_px;
     // survivor capacity per region; every scoring wave may hold one partly filled 256-record chunk
     int64_t cap = (std::max<int64_t>(1 << 16, band_px * j->nsets / 6) + (int64_t)c->cus * 8 * 4 * 256 * 2) / HPK_NREG;
+    if (const char* e = std::getenv("HPK_SURV_CAP")) cap = std::max<int64_t>(256, std::atoll(e));     // tests: force the overflow rerun
     cap = (cap + 255) / 256 * 256;
     j->cap = cap;
     auto up256 = [](size_t v) { return (v + 255) / 256 * 256; };

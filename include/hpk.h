@@ -70,7 +70,8 @@ typedef struct {
     int32_t pw[HPK_MAX_PAIRS];
     int32_t ww[HPK_MAX_PAIRS];
     int32_t maxww;
-    int32_t min_local_reads;
+    int32_t min_local_reads;   /* <= 1023: the stencil compares Reads on counts capped there (exact for any such threshold);
+                                  larger values return HPK_ERR_INVALID.  The reference's defaults are 25 / 16 */
     int64_t maxapart;
     int64_t res;
     double  sig;

@@ -375,3 +375,23 @@ def test_small_maxww_tiles(maxww, pw, ww, ctx):
     np.testing.assert_array_equal(k, kw)
     if k.size:
         np.testing.assert_allclose(v, vw, rtol=1e-9, atol=1e-9)
+
+
+def test_survivor_overflow_rerun(ctx, monkeypatch):
+    """The survivor regions are sized from the band; when they overflow, hpk_collect reruns the scoring with room for
+    everything.  Forced here with a one-chunk capacity: results must not change."""
+    from hicpeaks_amd import synthetic
+    n, res, maxapart, maxww = 3000, 10000, 2000000, 10
+    num = maxapart // res + maxww + 1
+    raw, weight, _ = synthetic.synth_band(n, num, depth=60.0, nloops=40, seed=3)
+    raw = raw.astype(np.float32)
+    prm = _lib.make_params(_lib.MODE_HICCUPS, [1, 2], [3, 5], maxww, 0.1, maxapart, res, 16, 0)
+    want = ctx.score_host(raw, None, None, None, prm, weight=weight)
+    # every scoring wave with a survivor takes a whole 256-record chunk: hundreds of waves against 64 regions x 1 chunk
+    assert want.nsurv_sig > 64 * 256 and want.ncand > 100000
+    monkeypatch.setenv('HPK_SURV_CAP', '256')
+    got = ctx.score_host(raw, None, None, None, prm, weight=weight)
+    _same_result(got, want)
+    jobs = [ctx.submit_host(raw, None, None, None, prm, weight=weight) for _ in range(2)]
+    for j in jobs:                            # also with two chromosomes in flight
+        _same_result(j.result(), want)
