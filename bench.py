@@ -171,6 +171,8 @@ def main():
                     help='rows of the CPU-baseline sample (default: the whole workload, ~8 s on one core; 0 = skip)')
     ap.add_argument('--pipeline-depth', type=int, default=2,
                     help='chromosomes in flight per GPU (hpk_submit_band / hpk_collect); 1 = one synchronous call per step')
+    ap.add_argument('--host-inputs', action='store_true',
+                    help='hand the band over as host (numpy) arrays every step: the PCIe-inclusive rate of DESIGN.md, never `value`')
     ap.add_argument('--stencil-only', action='store_true', help='time the stencil kernel alone (HPK_FLAG_NO_SCORE)')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -221,7 +223,13 @@ def main():
     # and collected inside the timed region.
     depth = max(1, min(args.pipeline_depth, ctx.pipeline_depth))
 
+    if args.host_inputs:
+        raw_h = np.ascontiguousarray(raw_d[:, :num].cpu().numpy())
+        w_h, ir_h, b_h = w_d.cpu().numpy(), ir_d.cpu().numpy(), b_d.cpu().numpy()
+
     def submit():
+        if args.host_inputs:
+            return ctx.submit_host(raw_h, ir_h, b_h, b_h, prm, weight=w_h)
         return ctx.submit_device(n, num, ld, raw_d.data_ptr(), ir_d.data_ptr(), b_d.data_ptr(), b_d.data_ptr(), prm,
                                  weight_ptr=w_d.data_ptr())
 
@@ -282,7 +290,7 @@ def main():
                        'px_with_p_le_sig': R.nsurv_sig, 'records_copied_back': R.nsurv_cut,
                        'parallelism': 'one chromosome per GPU, no collective', 'pipeline_depth': depth,
                        'sync_call_ms': float(np.median(lat)),
-                       'stencil_only': bool(args.stencil_only)},
+                       'stencil_only': bool(args.stencil_only), 'host_inputs': bool(args.host_inputs)},
             'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                          'kernel_ms': st, 'algorithmic_bytes_per_launch': BYTES_PER_PX * px_per_step},
