@@ -511,8 +511,8 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     const int n = band->n, num = band->num;
     // output tile: what the halo leaves of the SAT tile, at most 4 rows per stencil wave (row slot = 2 bits of the record
     // entry, HPK_LISTCAP ids per wave)
-    const int TR = std::min(HPK_LR - 2 * W - 1, 4 * HPK_NWAVES), TC = HPK_LC - 2 * W - 1;
-    static_assert(4 * (HPK_LC - 1) <= HPK_LISTCAP, "a wave's candidate list must hold four tile rows");
+    const int TR = std::min(HPK_LR - 2 * W - 1, HPK_ROWS_PER_WAVE * HPK_NWAVES), TC = HPK_LC - 2 * W - 1;
+    static_assert(HPK_ROWS_PER_WAVE * (HPK_LC - 1) <= HPK_LISTCAP, "a wave's candidate list must hold its tile rows");
     if (D < mw) return fail(c, HPK_ERR_INVALID, "maxapart / res (%d) is below min(ww) (%d)", D, mw);
     j->prm = *prm; j->n = n; j->num = num; j->ld = band->ld; j->TR = TR; j->TC = TC;
     j->nsets = (plan.mode == HPK_MODE_BHFDR) ? 1 : 2 * plan.npairs;

@@ -7,8 +7,13 @@
 #define HPK_LC 128                      // SAT columns per tile (two cells per lane)
 #define HPK_LR 80                       // SAT rows per tile: 80 * 128 * 12 B = 120 KiB + 32 KiB of candidate lists
 #define HPK_HIST_NCAND HPK_MAX_STEPS    // hist[HPK_MAX_STEPS] counts the candidates
-#define HPK_NWAVES 16                   // waves per stencil workgroup
-#define HPK_LISTCAP 512                 // candidate ids per wave and tile (4 rows x <= 127 columns)
+#ifndef HPK_NWAVES
+#define HPK_NWAVES 16                   // waves per stencil workgroup (16 or 8)
+#endif
+#define HPK_ROWS_PER_WAVE (64 / HPK_NWAVES)                  // output-tile rows a wave walks in phase 3 (tile rows <= 64)
+#define HPK_YI_BITS (HPK_NWAVES == 16 ? 2 : 3)              // record entry: x (7 bits) | row slot | wave | capped count << 13
+#define HPK_WV_BITS (HPK_NWAVES == 16 ? 4 : 3)
+#define HPK_LISTCAP (HPK_ROWS_PER_WAVE * 128)               // candidate ids per wave and tile
 
 struct HpkStencilArgs {
     const float*  raw;

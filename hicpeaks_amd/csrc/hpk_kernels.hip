@@ -383,7 +383,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
             const unsigned long long M = __ballot(cnd);
             if (M == 0ull) continue;
             const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(M >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M, 0u));
-            if (cnd) lst[cnt + below] = (unsigned)x | ((unsigned)yi << 7) | ((unsigned)wave << 9) | ((pix & PK_MASK) << 13);
+            if (cnd) lst[cnt + below] = (unsigned)x | ((unsigned)yi << 7) | ((unsigned)wave << (7 + HPK_YI_BITS)) | ((pix & PK_MASK) << 13);
             cnt += __popcll(M);
         }
     }
@@ -401,7 +401,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
     for (int kb = 0; kb < nbatch; ++kb) {
         const bool cand = kb * 64 + lane < cnt;
         const unsigned id = cand ? lst[kb * 64 + lane] : 0u;
-        const int yi = (int)((id >> 7) & 3u), x = (int)(id & 127u);
+        const int yi = (int)((id >> 7) & ((1u << HPK_YI_BITS) - 1u)), x = (int)(id & 127u);
         const int y = wave + NW * yi;
         if (cand && a.dbg_stop != 7) a.rec_ent[rec0 + kb * 64 + lane] = id;
         const int r = r0 + y;
@@ -914,7 +914,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                 s2_b = (recS_t + sl0)[ri_b];
             }
             if (!cand) ent = 0u;
-            const int r = r0 + (int)((ent >> 9) & 15u) + HPK_NWAVES * (int)((ent >> 7) & 3u);
+            const int r = r0 + (int)((ent >> (7 + HPK_YI_BITS)) & ((1u << HPK_WV_BITS) - 1u)) + HPK_NWAVES * (int)((ent >> 7) & ((1u << HPK_YI_BITS) - 1u));
             const int c = c0 + (int)(ent & 127u);
             const int d = c - r;
             float rawpix = (float)(ent >> 13);          // the SAT holds counts capped at HPK_PK_CAP: those are re-read
@@ -1140,7 +1140,7 @@ __global__ void __launch_bounds__(256) hpk_dense(HpkDenseArgs a) {
     for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
         const int64_t ri = (int64_t)tile * a.tilecap + i;
         const unsigned ent = a.rec_ent[ri];
-        const int r = r0 + (int)((ent >> 9) & 15u) + HPK_NWAVES * (int)((ent >> 7) & 3u);
+        const int r = r0 + (int)((ent >> (7 + HPK_YI_BITS)) & ((1u << HPK_WV_BITS) - 1u)) + HPK_NWAVES * (int)((ent >> 7) & ((1u << HPK_YI_BITS) - 1u));
         const int c = c0 + (int)(ent & 127u);
         const int d = c - r;
         const int64_t o = (int64_t)r * a.ldo + d;
