@@ -539,9 +539,6 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     }
     HIPCHK(c, L.etab.reserve(sizeof(double) * std::max<size_t>((size_t)plan.nsteps * 2 * (D + 1), 1)));
     HIPCHK(c, L.eedge.reserve(sizeof(double) * std::max<size_t>((size_t)2 * W * plan.nsteps * 2 * (D + 1), 1)));
-    hpk_launch_etab(L.plan.as<HpkDevPlan>(), plan.nsteps, D, W, in.IR, n, num, L.etab.as<double>(), L.eedge.as<double>(),
-                    c->stream);
-    HIPCHK(c, hipGetLastError());
     const int64_t ldo = ((int64_t)(D + 1) + 31) / 32 * 32;
     const size_t dense_elems = (size_t)plan.nslots * (size_t)n * (size_t)ldo;
     j->ldo = ldo; j->dense_elems = dense_elems;
@@ -575,7 +572,10 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     const size_t zero_bytes = (off_cu + sizeof(unsigned) * (size_t)(cap / 256 * HPK_NREG + 1) + 4095) / 4096 * 4096;
     j->off_rowlive = off_rowlive; j->off_inl = off_inl; j->head_bytes = head_bytes; j->off_cnt = off_cnt; j->off_cu = off_cu;
     HIPCHK(c, L.small.reserve(zero_bytes));
-    HIPCHK(c, hipMemsetAsync(L.small.p, 0, zero_bytes, c->stream));
+    // expected tables of this chromosome; the same launch zero-fills the block (extra workgroups)
+    hpk_launch_etab(L.plan.as<HpkDevPlan>(), plan.nsteps, D, W, in.IR, n, num, L.etab.as<double>(), L.eedge.as<double>(),
+                    L.small.p, zero_bytes, c->stream);
+    HIPCHK(c, hipGetLastError());
     if (L.h_head_cap < head_bytes) {
         if (L.h_head) (void)hipHostFree(L.h_head);
         L.h_head = nullptr; L.h_head_cap = 0;

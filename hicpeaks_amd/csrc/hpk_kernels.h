@@ -121,7 +121,7 @@ void hpk_launch_freeze(const HpkDevPlan* plan, unsigned long long* hist, const u
 void hpk_launch_prep(const float* raw, const double* weight, int n, int num, int64_t ld, int mw, double* psum, unsigned* pnan,
                      double* IR, double* bias, hipStream_t st);
 void hpk_launch_etab(const HpkDevPlan* plan, int nsteps, int D, int W, const double* IR, int n, int num, double* etab,
-                     double* eedge, hipStream_t st);
+                     double* eedge, void* zero, size_t zero_bytes, hipStream_t st);
 void hpk_launch_gap(const float* raw, const double* bal, const double* weight, int32_t n, int32_t num,
                     int64_t ld, int32_t mw, uint8_t* gap, hipStream_t st);
 void hpk_launch_score(const HpkScoreArgs& a, int cus, hipStream_t st);

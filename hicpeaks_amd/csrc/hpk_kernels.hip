@@ -623,13 +623,20 @@ __global__ void __launch_bounds__(1024) hpk_freeze(const HpkDevPlan* __restrict_
     __shared__ int swi[HPK_MAX_STEPS], sslot[HPK_MAX_STEPS];        // the serial part below reads LDS only
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if ((int)threadIdx.x < plan->nsteps) { swi[threadIdx.x] = plan->steps[threadIdx.x].wi; sslot[threadIdx.x] = plan->steps[threadIdx.x].slot; }
-    for (int k = wave; k <= HPK_MAX_STEPS; k += 16) {
-        unsigned long long t = 0ull;
-        for (int p = lane; p < nparts; p += 64) t += hist_part[(int64_t)p * (HPK_MAX_STEPS + 1) + k];
-        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off);
-        if (lane == 0) { hist[k] = t; hist_out[k] = t; }
+    // thread t sums column t % 65 over the partials t / 65, t / 65 + 15, ... (independent loads), LDS atomics finish
+    if (threadIdx.x <= HPK_MAX_STEPS) hist[threadIdx.x] = 0ull;
+    __syncthreads();
+    {
+        const int k = threadIdx.x % (HPK_MAX_STEPS + 1), g = threadIdx.x / (HPK_MAX_STEPS + 1), ng = 1024 / (HPK_MAX_STEPS + 1);
+        if (g < ng) {
+            unsigned long long t = 0ull;
+            for (int p = g; p < nparts; p += ng) t += hist_part[(int64_t)p * (HPK_MAX_STEPS + 1) + k];
+            if (t) atomicAdd(&hist[k], t);
+        }
     }
     __syncthreads();
+    if (threadIdx.x <= HPK_MAX_STEPS) hist_out[threadIdx.x] = hist[threadIdx.x];
+    (void)lane; (void)wave;
     if (threadIdx.x != 0) return;
     const long long total = (long long)hist[HPK_HIST_NCAND];
     long long unres[HPK_KSLOTS];
@@ -778,8 +785,15 @@ __device__ __forceinline__ void local_expected(const HpkDevPlan* __restrict__ pl
 // diagonals: the taps are formed once in LDS (<= 2wi+1 cells each), then every lane runs <= 4wi+1 multiply-adds on an
 // LDS-staged IR window.
 // blockIdx.y >= 2 W nsteps: the unclipped (interior) table of step y - 2 W nsteps, same taps without clipping.
+// blockIdx.y >= ntab: zero-fill duty (the per-chromosome counter block; saves a memset launch).
 __global__ void __launch_bounds__(64) hpk_etab_edge(const HpkDevPlan* __restrict__ plan, const double* __restrict__ IR, int n,
-                                                    int num, double* __restrict__ etab, double* __restrict__ eedge) {
+                                                    int num, double* __restrict__ etab, double* __restrict__ eedge,
+                                                    uint4* __restrict__ zero, unsigned long long nzero16, int ntab) {
+    if ((int)blockIdx.y >= ntab) {
+        const unsigned long long i = ((unsigned long long)(blockIdx.y - ntab) * gridDim.x + blockIdx.x) * 64ull + threadIdx.x;
+        if (i < nzero16) zero[i] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
     const int D = plan->D, W = plan->W, mw = plan->mw, ns = plan->nsteps;
     const int d = blockIdx.x * 64 + threadIdx.x;
     int t = blockIdx.y;
@@ -1264,10 +1278,13 @@ void hpk_launch_prep(const float* raw, const double* weight, int n, int num, int
 }
 
 void hpk_launch_etab(const HpkDevPlan* plan, int nsteps, int D, int W, const double* IR, int n, int num, double* etab,
-                     double* eedge, hipStream_t st) {
-    const int total = nsteps * 2 * (D + 1);
-    if (total <= 0) return;
-    hipLaunchKernelGGL(hpk_etab_edge, dim3((D + 64) / 64, 2 * W * nsteps + nsteps), dim3(64), 0, st, plan, IR, n, num, etab, eedge);
+                     double* eedge, void* zero, size_t zero_bytes, hipStream_t st) {
+    const int gx = (D + 64) / 64;
+    const int ntab = 2 * W * nsteps + nsteps;
+    // rows of workgroups beyond the tables zero-fill `zero` (multiple of 16 bytes): gx * 64 lanes x 16 B per row
+    const int nzero = (int)((zero_bytes / 16 + (size_t)gx * 64 - 1) / ((size_t)gx * 64));
+    hipLaunchKernelGGL(hpk_etab_edge, dim3(gx, ntab + nzero), dim3(64), 0, st, plan, IR, n, num, etab, eedge,
+                       reinterpret_cast<uint4*>(zero), (unsigned long long)(zero_bytes / 16), ntab);
 }
 
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,
