@@ -488,7 +488,12 @@ int launch_scoring(hpk_ctx* c, hpk_job* j, int attempt) {
     }
     if (j->phases) (void)hipEventRecord(L.ev[6], c->stream);
     // counters, row flags and the first survivors in one copy into pinned memory
-    HIPCHK(c, hipMemcpyAsync(L.h_head, small, j->head_bytes, hipMemcpyDeviceToHost, c->stream));
+    if (std::getenv("HPK_HEAD_COPY")) {
+        HIPCHK(c, hipMemcpyAsync(L.h_head, small, j->head_bytes, hipMemcpyDeviceToHost, c->stream));
+    } else {        // pinned memory is device-visible: a small kernel writes it (head_bytes is a multiple of 16)
+        hpk_launch_publish(small, L.h_head, j->head_bytes, c->stream);
+        HIPCHK(c, hipGetLastError());
+    }
     HIPCHK(c, hipEventRecord(L.ev_done, c->stream));
     return HPK_OK;
 }
@@ -579,7 +584,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     if (L.h_head_cap < head_bytes) {
         if (L.h_head) (void)hipHostFree(L.h_head);
         L.h_head = nullptr; L.h_head_cap = 0;
-        HIPCHK(c, hipHostMalloc(&L.h_head, head_bytes + head_bytes / 4, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc(&L.h_head, head_bytes + head_bytes / 4, hipHostMallocMapped));
         L.h_head_cap = head_bytes + head_bytes / 4;
     }
     if (dense) {   // pixels outside the band are never written by the kernel

@@ -131,6 +131,7 @@ void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, in
                         const unsigned int* fam_m, const unsigned int* fam_f, unsigned int* fam_cnt, double sig, int rounds,
                         int nsets, HpkSurv* out_head, unsigned long long inl, HpkSurv* out_rest, unsigned long long* nout,
                         const double* bal, const double* weight, int64_t ld, int cus, hipStream_t st);
+void hpk_launch_publish(const void* src, void* dst_host_mapped, size_t bytes, hipStream_t st);
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,
                      hipStream_t st);
 void hpk_launch_poisson_sf(const double* k, const double* lam, const double* sfe, double* out, int64_t count,

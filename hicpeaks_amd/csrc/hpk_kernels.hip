@@ -1287,6 +1287,17 @@ void hpk_launch_etab(const HpkDevPlan* plan, int nsteps, int D, int W, const dou
                        reinterpret_cast<uint4*>(zero), (unsigned long long)(zero_bytes / 16), ntab);
 }
 
+// result head -> pinned host memory by a kernel (the copy engine costs ~15 us of start-up latency per chromosome)
+__global__ void __launch_bounds__(256) hpk_publish(const uint4* __restrict__ src, uint4* __restrict__ dst, unsigned n16) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+void hpk_launch_publish(const void* src, void* dst_host_mapped, size_t bytes, hipStream_t st) {
+    const unsigned n16 = (unsigned)((bytes + 15) / 16);
+    hipLaunchKernelGGL(hpk_publish, dim3((n16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4*>(src),
+                       reinterpret_cast<uint4*>(dst_host_mapped), n16);
+}
+
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,
                      hipStream_t st) {
     hipLaunchKernelGGL(hpk_ptab, dim3((total + 255) / 256), dim3(256), 0, st, bounds, off, sfe, ptab, total);
