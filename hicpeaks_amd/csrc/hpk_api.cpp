@@ -470,7 +470,7 @@ int launch_scoring(hpk_ctx* c, hpk_job* j, int attempt) {
         sc.nsurv = d_nsurv;
         { const char* e = std::getenv("HPK_DBG_SCORE"); sc.dbg = e ? std::atoi(e) : 0; }
         sc.cap = cap; sc.surv = L.surv.as<HpkSurv>(); sc.chunk_used = d_chunkused;
-        hpk_launch_score(sc, c->cus, c->stream);
+        hpk_launch_score(sc, plan.mode == HPK_MODE_BHFDR, c->cus, c->stream);
         HIPCHK(c, hipGetLastError());
         if (j->phases) (void)hipEventRecord(L.ev[4], c->stream);
         hpk_launch_tighten(sc.surv, d_nsurv, cap, sc.chunk_used, d_fam_m, d_fam_f, d_cnt, j->prm.sig, j->rounds, j->nsets,

@@ -124,7 +124,7 @@ void hpk_launch_etab(const HpkDevPlan* plan, int nsteps, int D, int W, const dou
                      double* eedge, void* zero, size_t zero_bytes, hipStream_t st);
 void hpk_launch_gap(const float* raw, const double* bal, const double* weight, int32_t n, int32_t num,
                     int64_t ld, int32_t mw, uint8_t* gap, hipStream_t st);
-void hpk_launch_score(const HpkScoreArgs& a, int cus, hipStream_t st);
+void hpk_launch_score(const HpkScoreArgs& a, bool bhfdr, int cus, hipStream_t st);
 // Benjamini-Hochberg cut tightening on the survivor list: thr[f] <- sig * #{p <= thr[f]} / m[f], `rounds` times,
 // then compaction of the records with p <= thr[f] into `out` (count in *nout).
 void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned* chunk_used,

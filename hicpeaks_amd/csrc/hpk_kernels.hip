@@ -849,6 +849,7 @@ __global__ void __launch_bounds__(64) hpk_etab_edge(const HpkDevPlan* __restrict
 // Persistent blocks: block b walks rows b, b + gridDim.x, ...; the per-family counters live in LDS for the block's
 // whole life and are flushed once.  Chunk boundaries sit in LDS; the chunk of E is 3 * exponent(E) plus two
 // comparisons against the reference's own boundary values.
+template <bool BH>            // BH: bhfdr (one set, per-pixel lambda = E); otherwise hiccups (lambda chunks)
 __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     __shared__ unsigned int lm[2 * HPK_MAX_PAIRS][HPK_NB + 1];
     __shared__ unsigned int lf[2 * HPK_MAX_PAIRS][HPK_NB + 1];
@@ -864,10 +865,9 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     // kernel: with ~45 scalars live the compiler spilled ~80 of them to VGPR lanes, and the spill traffic
     // (v_readlane / v_writelane / s_nop) was 15 % of the instruction stream of this issue-bound kernel.
     const volatile HpkScoreArgs* ka = (const volatile HpkScoreArgs*)(const void*)__builtin_amdgcn_kernarg_segment_ptr();
-    const int mode = plan->mode;
     const int npairs = plan->npairs;
     const int W = plan->W;
-    const int nsets = (mode == HPK_MODE_BHFDR) ? 1 : 2 * npairs;
+    const int nsets = BH ? 1 : 2 * npairs;
     for (int i = threadIdx.x; i < nsets * (HPK_NB + 1); i += blockDim.x) { (&lm[0][0])[i] = 0u; (&lf[0][0])[i] = 0u; }
     if (threadIdx.x < HPK_NB) lbounds[threadIdx.x] = const_cast<const double*>(ka->bounds)[threadIdx.x];
     if (threadIdx.x < 2 * HPK_MAX_PAIRS) { lemax[threadIdx.x] = 0ull; lvalid[threadIdx.x] = 0u; }
@@ -963,36 +963,41 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                 // callers.py:244-249: E = ((IR[d] * (bS / bE)) * B1[x]) * B2[y] where bE != 0
                 const double eK = (ok && EK != 0.0) ? ((ir * (s2.x / EK)) * b1r) * b2c : 0.0;
                 const double eY = (ok && EY != 0.0) ? ((ir * (s2.y / EY)) * b1r) * b2c : 0.0;
-                const int nfl = (mode == HPK_MODE_BHFDR) ? 1 : 2;
+                constexpr int nfl = BH ? 1 : 2;
+#pragma unroll
                 for (int fl = 0; fl < nfl; ++fl) {
-                    const int set = (mode == HPK_MODE_BHFDR) ? 0 : pj * 2 + fl;
+                    const int set = BH ? 0 : pj * 2 + fl;
                     const double E = fl ? eY : eK;
                     const bool valid = ok && (E > 0.0);                       // callers.py:250
                     int chunk = 0;
                     double p = 1.0;
-                    if (valid) {
-                        if (mode == HPK_MODE_BHFDR) {
+                    if (BH) {
+                        if (valid) {
                             chunk = 1;
                             p = poisson_sf(O, E, const_cast<const double*>(ka->sfe));      // callers.py:536-540
-                        } else {
-                            // lo = number of boundaries <= E (boundaries are 2^(i/3), i = 0..); membership is strict on
-                            // both sides (callers.py:38), so E sitting on a boundary belongs to no chunk
-                            int lo = 0;
-                            if (E >= 1.0) {
-                                const int e3 = 3 * (((int)(__double_as_longlong(E) >> 52) & 0x7ff) - 1023);
-                                if (e3 + 2 < HPK_NB) lo = e3 + 1 + (E >= lbounds[e3 + 1] ? 1 : 0) + (E >= lbounds[e3 + 2] ? 1 : 0);
-                                else lo = HPK_NB;
-                            }
-                            if (lo < HPK_NB && !(lo > 0 && E == lbounds[lo - 1])) {
-                                chunk = lo + 1;
-                                if (chunk <= HPK_NB_TAB) {
-                                    const int base = lptoff[chunk], len = lptoff[chunk + 1] - base;
-                                    const long long kO = (long long)O;
-                                    p = (a.dbg == 1) ? 0.5 : ((kO < len) ? a.ptab[(unsigned)(base + (int)kO)] : 0.0);
-                                } else {
-                                    p = poisson_sf(O, lbounds[chunk - 1], const_cast<const double*>(ka->sfe));   // callers.py:268-270
-                                }
-                            }
+                        }
+                    } else {
+                        // lo = number of boundaries <= E (boundaries lbounds[i] = 2^(i/3), i = 0..); membership is strict
+                        // on both sides (callers.py:38), so E sitting on a boundary belongs to no chunk.  E in
+                        // [2^k, 2^(k+1)) has the three boundaries lbounds[3k .. 3k+2] at or below it to compare with.
+                        // Written with selects: this kernel is issue-bound and divergent ifs cost scalar work.
+                        const int e3 = 3 * (((int)(__double_as_longlong(E) >> 52) & 0x7ff) - 1023);
+                        const bool ge1 = valid && E >= 1.0;
+                        const bool big = e3 + 2 >= HPK_NB;
+                        const int i0b = (ge1 && !big) ? e3 : 0;                // clamped: every lane reads inside the table
+                        const double bq = lbounds[i0b], bA = lbounds[i0b + 1], bB = lbounds[i0b + 2];
+                        const int lo = ge1 ? (big ? HPK_NB : e3 + 1 + (E >= bA ? 1 : 0) + (E >= bB ? 1 : 0)) : 0;
+                        const bool onb = ge1 && !big && (E == bq || E == bA || E == bB);
+                        const bool inch = valid && lo < HPK_NB && !onb;
+                        chunk = inch ? lo + 1 : 0;
+                        const bool tabd = inch && chunk <= HPK_NB_TAB;
+                        const int ct = tabd ? chunk : 1;
+                        const int base = lptoff[ct], len = lptoff[ct + 1] - base;
+                        const int kO = (int)O;
+                        if (tabd) p = (a.dbg == 1) ? 0.5 : ((kO < len) ? a.ptab[(unsigned)(base + kO)] : 0.0);
+                        const bool rare = inch && !tabd;                      // lambda > 2^15: beyond the table
+                        if (__ballot(rare) != 0ull) {
+                            if (rare) p = poisson_sf(O, lbounds[chunk - 1], const_cast<const double*>(ka->sfe));   // callers.py:268-270
                         }
                     }
                     const bool surv = valid && chunk != 0 && p <= a.sig && a.dbg != 3;      // only these can reach q <= sig
@@ -1251,10 +1256,11 @@ void hpk_launch_gap(const float* raw, const double* bal, const double* weight, i
     hipLaunchKernelGGL(hpk_gap, dim3((n + 3) / 4), dim3(256), 0, st, raw, bal, weight, n, num, ld, mw, gap);
 }
 
-void hpk_launch_score(const HpkScoreArgs& a, int cus, hipStream_t st) {
+void hpk_launch_score(const HpkScoreArgs& a, bool bhfdr, int cus, hipStream_t st) {
     if (a.ntiles <= 0 || a.n <= 0) return;
     const int grid = cus * 8;
-    hipLaunchKernelGGL(hpk_score, dim3(grid), dim3(256), 0, st, a);
+    if (bhfdr) hipLaunchKernelGGL(hpk_score<true>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(hpk_score<false>, dim3(grid), dim3(256), 0, st, a);
 }
 
 void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned* chunk_used,
