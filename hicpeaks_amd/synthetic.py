@@ -49,7 +49,7 @@ def synth_band(n, num, depth=60.0, alpha=1.0, nloops=20, seed=0,
     # marginal sums of the symmetric matrix restricted to the band
     rowsum = raw.sum(axis=1).astype(np.float64)
     colsum = np.zeros(n)
-    for kk in range(1, num):
+    for kk in range(1, min(num, n)):          # diagonals beyond the matrix (num > n) hold nothing
         colsum[kk:] += raw[: n - kk, kk]
     weight = 1.0 / np.sqrt(rowsum + colsum + 1.0)
 

@@ -1,0 +1,110 @@
+#!/usr/bin/env python
+"""Randomised parity run: HIP path (through the C ABI) against the numpy oracle on random small chromosomes and random
+parameter sets (maxww 3..20, one to three pairs in any order, thresholds, band widths, NaN runs).  Test infrastructure.
+usage: gpu_fuzz.py [ncases] [first_seed]"""
+import os, sys, time, traceback
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from hicpeaks_amd import _lib, callers, synthetic
+from oracle import hiccups_oracle as orc
+
+
+def table_arrays(t):
+    k = sorted(t)
+    return np.array(k, dtype=np.int64).reshape(-1, 2), np.array([[float(v) for v in t[x]] for x in k])
+
+
+def one_case(seed, ctx):
+    rng = np.random.default_rng(seed)
+    maxww = int(rng.integers(3, 21))
+    npairs = int(rng.integers(1, 4))
+    ww = sorted(set(int(v) for v in rng.integers(2, maxww + 3, npairs)))     # a pair may be wider than maxww
+    pw = [int(rng.integers(0, max(1, w))) for w in ww]
+    if rng.random() < 0.25:
+        order = rng.permutation(len(ww))
+        pw, ww = [pw[i] for i in order], [ww[i] for i in order]
+    res = 10000
+    n = int(rng.integers(150, 1400)) if rng.random() < 0.8 else int(rng.integers(25, 150))     # some shorter than the band
+    D = int(rng.integers(max(ww) + 2, 160))
+    maxapart = D * res
+    num = D + maxww + 1
+    depth = float(rng.choice([2.0, 8.0, 25.0, 60.0, 400.0, 5000.0]))
+    min_reads = int(rng.choice([1, 8, 16, 25, 200, 1000]))
+    sig = float(rng.choice([0.01, 0.05, 0.1, 0.3]))
+    raw, weight, _ = synthetic.synth_band(n, num, depth=depth, nloops=int(rng.integers(0, 25)), seed=seed)
+    mode = 'bhfdr' if rng.random() < 0.2 else 'hiccups'
+    desc = dict(seed=seed, mode=mode, n=n, D=D, maxww=maxww, pw=pw, ww=ww, depth=depth, min_reads=min_reads, sig=sig)
+    mw = min(ww) if mode == 'hiccups' else ww[0]
+    try:
+        IR, cband, biases = orc.prep_from_band(raw, weight, mw)
+    except ValueError as e:          # chromosome shorter than the band: the reference's own prep fails (pyHICCUPS:148)
+        return 'reference-prep-raises', desc, str(e)[:60]
+    rawf = raw.astype(np.float32)
+    want = werr = None
+    try:
+        if mode == 'hiccups':
+            want = orc.hiccups(raw, cband, biases, biases, IR, n, num, pw=pw, ww=ww, maxww=maxww, sig=sig, maxapart=maxapart,
+                               res=res, min_local_reads=min_reads, min_marginal_peaks=2, onlyanchor=False)
+        else:
+            want = orc.bhfdr(raw, cband, biases, biases, IR, n, num, pw=pw[0], ww=ww[0], sig=sig, maxww=maxww,
+                             maxapart=maxapart, res=res, min_marginal_peaks=2, onlyanchor=False)
+    except (ValueError, ZeroDivisionError, IndexError) as e:
+        werr = e
+    got = gerr = None
+    detail = dict(dense=True)
+    try:
+        if mode == 'hiccups':
+            got = callers.hiccups_band(rawf, IR, biases, biases, chrom='T', weight=weight, pw=pw, ww=ww, maxww=maxww, sig=sig,
+                                       maxapart=maxapart, res=res, min_local_reads=min_reads, min_marginal_peaks=2,
+                                       onlyanchor=False, ctx=ctx, detail=detail)
+        else:
+            got = callers.bhfdr_band(rawf, IR, biases, biases, chrom='T', weight=weight, pw=pw[0], ww=ww[0], sig=sig,
+                                     maxww=maxww, maxapart=maxapart, res=res, min_marginal_peaks=2, onlyanchor=False,
+                                     ctx=ctx, detail=detail)
+    except (ValueError, ZeroDivisionError, _lib.HpkError) as e:
+        gerr = e
+    if werr is not None or gerr is not None:
+        unsupported = isinstance(gerr, _lib.HpkError) and not isinstance(gerr, _lib.EmptyStepError)
+        if unsupported:
+            return 'unsupported', desc, str(gerr)[:100]
+        if (werr is None) != (gerr is None):
+            return 'MISMATCH-exception', desc, 'oracle %r vs hip %r' % (werr, gerr)
+        return 'both-raise', desc, ''
+    k, v = table_arrays(got)
+    kw, vw = table_arrays(want)
+    if k.shape != kw.shape or not np.array_equal(k, kw):
+        return 'MISMATCH-keys', desc, '%d vs %d pixels' % (len(k), len(kw))
+    if k.size and not np.allclose(v, vw, rtol=1e-9, atol=1e-9):
+        return 'MISMATCH-values', desc, 'max abs diff %g' % np.abs(v - vw).max()
+    if mode == 'hiccups':          # resolving widths of every candidate
+        loc = orc.hiccups_local_sums(raw, cband, IR, n, num, pw, ww, maxww, maxapart, res, min_reads)
+        R = detail['result']
+        vx, vy = loc['vx'], loc['vy']
+        for slot, pi in enumerate(R.slot_pi):
+            w = R.dense_w[slot][vx, vy - vx].astype(np.int64)
+            w = np.where(w > R.frozen_w, 0, w)
+            if not np.array_equal(w, loc['wres'][pi]):
+                return 'MISMATCH-widths', desc, 'slot %d: %d differ' % (slot, int((w != loc['wres'][pi]).sum()))
+    return 'ok', desc, '%d pixels' % len(k)
+
+
+def main():
+    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    ctx = _lib.Context(0)
+    tally = {}
+    t0 = time.time()
+    for seed in range(first, first + ncases):
+        try:
+            status, desc, note = one_case(seed, ctx)
+        except Exception:
+            status, desc, note = 'CRASH', dict(seed=seed), traceback.format_exc()[-600:]
+        tally[status] = tally.get(status, 0) + 1
+        if status.startswith('MISMATCH') or status == 'CRASH' or os.environ.get('HPK_FUZZ_VERBOSE'):
+            print(status, desc, note, flush=True)
+    print('fuzz: %d cases in %.0f s: %s' % (ncases, time.time() - t0, tally))
+    return 1 if any(k.startswith('MISMATCH') or k == 'CRASH' for k in tally) else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
