@@ -33,7 +33,8 @@ def one_case(seed, ctx):
     sig = float(rng.choice([0.01, 0.05, 0.1, 0.3]))
     raw, weight, _ = synthetic.synth_band(n, num, depth=depth, nloops=int(rng.integers(0, 25)), seed=seed)
     mode = 'bhfdr' if rng.random() < 0.2 else 'hiccups'
-    desc = dict(seed=seed, mode=mode, n=n, D=D, maxww=maxww, pw=pw, ww=ww, depth=depth, min_reads=min_reads, sig=sig)
+    inp = str(rng.choice(['weight', 'balanced', 'derive']))       # weights + IR | f64 balanced band + IR | weights only
+    desc = dict(seed=seed, mode=mode, inp=inp, n=n, D=D, maxww=maxww, pw=pw, ww=ww, depth=depth, min_reads=min_reads, sig=sig)
     mw = min(ww) if mode == 'hiccups' else ww[0]
     try:
         IR, cband, biases = orc.prep_from_band(raw, weight, mw)
@@ -52,15 +53,17 @@ def one_case(seed, ctx):
         werr = e
     got = gerr = None
     detail = dict(dense=True)
+    kw = dict(balanced=cband) if inp == 'balanced' else dict(weight=weight)
+    gIR, gb = (None, None) if inp == 'derive' else (IR, biases)
     try:
         if mode == 'hiccups':
-            got = callers.hiccups_band(rawf, IR, biases, biases, chrom='T', weight=weight, pw=pw, ww=ww, maxww=maxww, sig=sig,
+            got = callers.hiccups_band(rawf, gIR, gb, gb, chrom='T', pw=pw, ww=ww, maxww=maxww, sig=sig,
                                        maxapart=maxapart, res=res, min_local_reads=min_reads, min_marginal_peaks=2,
-                                       onlyanchor=False, ctx=ctx, detail=detail)
+                                       onlyanchor=False, ctx=ctx, detail=detail, **kw)
         else:
-            got = callers.bhfdr_band(rawf, IR, biases, biases, chrom='T', weight=weight, pw=pw[0], ww=ww[0], sig=sig,
+            got = callers.bhfdr_band(rawf, gIR, gb, gb, chrom='T', pw=pw[0], ww=ww[0], sig=sig,
                                      maxww=maxww, maxapart=maxapart, res=res, min_marginal_peaks=2, onlyanchor=False,
-                                     ctx=ctx, detail=detail)
+                                     ctx=ctx, detail=detail, **kw)
     except (ValueError, ZeroDivisionError, _lib.HpkError) as e:
         gerr = e
     if werr is not None or gerr is not None:
