@@ -107,14 +107,17 @@ def run_genome(args, cfg, ctx, rank, world, local, dist):
     px_genome = sum(band.band_pixels(n, num, mw, D) for n in sizes.values()) * len(cfg['pw'])
     depth = max(1, min(args.pipeline_depth, ctx.pipeline_depth))
 
+    def light(R):         # what the report needs; holding every BandResult makes Python's cyclic GC slower pass after pass
+        return (R.timing['stencil'], R.band_px, R.ncand, int(sum(s['x'].size for s in R.sets)))
+
     def one_pass():
         pending, done = collections.deque(), []
         for c, n, raw_d, w_d in bands:
             pending.append(ctx.submit_device(n, num, ld, raw_d.data_ptr(), None, None, None, prm, weight_ptr=w_d.data_ptr()))
             if len(pending) >= depth:
-                done.append(pending.popleft().result())
+                done.append(light(pending.popleft().result()))
         while pending:
-            done.append(pending.popleft().result())
+            done.append(light(pending.popleft().result()))
         return done
 
     def barrier():
@@ -137,8 +140,8 @@ def run_genome(args, cfg, ctx, rank, world, local, dist):
         elapsed = float(t.item())
     if rank == 0:
         # dominant kernel: all stencil launches of this rank; achieved = algorithmic bytes / kernel time, per launch
-        st_ms = sum(R.timing['stencil'] for rs in results for R in rs)
-        st_px = sum(R.band_px for rs in results for R in rs) * len(cfg['pw'])
+        st_ms = sum(t[0] for rs in results for t in rs)
+        st_px = sum(t[1] for rs in results for t in rs) * len(cfg['pw'])
         nlaunch = sum(len(rs) for rs in results)
         achieved = BYTES_PER_PX * st_px / (st_ms * 1e-3) / 1e9
         last = results[-1]
@@ -148,8 +151,8 @@ def run_genome(args, cfg, ctx, rank, world, local, dist):
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': cfg['workload'], 'name': args.config, 'band_px_per_step': px_genome,
                        'chromosomes': len(sizes), 'chromosomes_rank0': len(mine), 'pipeline_depth': depth,
-                       'candidates_rank0': int(sum(R.ncand for R in last)),
-                       'significant_px_rank0': int(sum(s['x'].size for R in last for s in R.sets)),
+                       'candidates_rank0': int(sum(t[2] for t in last)),
+                       'significant_px_rank0': int(sum(t[3] for t in last)),
                        'parallelism': 'chromosomes dealt largest-first to the GPUs, no collective',
                        'whole_genome_wall_ms': elapsed / args.steps * 1e3},
             'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -239,10 +242,15 @@ def main():
             pending.append(submit())
             if len(pending) >= depth:
                 done.append(pending.popleft().result())
+                del done[:-1]           # the report needs the kernel times (below) and one result, not K of them
+                stencil_ms.append(done[-1].timing['stencil'])
         while pending:
             done.append(pending.popleft().result())
+            del done[:-1]
+            stencil_ms.append(done[-1].timing['stencil'])
         return done
 
+    stencil_ms = []
     R = None
     for R in run(args.warmup):
         pass
@@ -253,14 +261,14 @@ def main():
         torch.cuda.synchronize()
 
     barrier()
+    del stencil_ms[:]
     t0 = time.perf_counter()
-    stencil_ms, score_ms = [], []
     results = run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    for R in results:
-        stencil_ms.append(R.timing['stencil'])
-        score_ms.append(R.timing['score'])
+    assert len(stencil_ms) == args.steps
+    stencil_ms = list(stencil_ms)
+    R = results[-1]
     # outside the timed region: latency of one synchronous call (submit + collect), then a few calls with the per-phase
     # events switched on (they cost ~6 us of idle GPU each, so the timed passes run without them)
     lat = []
