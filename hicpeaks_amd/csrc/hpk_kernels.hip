@@ -574,7 +574,9 @@ __global__ void __launch_bounds__(256) hpk_ir_partial(const float* __restrict__ 
     const int rbeg = blockIdx.x * HPK_IR_ROWS;
     if ((int)threadIdx.x < HPK_IR_ROWS) wrow[threadIdx.x] = (rbeg + (int)threadIdx.x < n) ? weight[rbeg + threadIdx.x] : 0.0;
     __syncthreads();
-    for (int k = mw + threadIdx.x; k < num; k += blockDim.x) {
+    // one diagonal per thread: blockIdx.y walks the diagonals in chunks of 256 (wide bands would otherwise leave one
+    // wave per SIMD looping over eight diagonals each)
+    for (int k = mw + blockIdx.y * blockDim.x + threadIdx.x; k < num; k += gridDim.y * blockDim.x) {
         double s = 0.0;
         unsigned nn = 0u;
         int rows = n - k - rbeg;                    // rows of this group that still have column r + k inside the matrix
@@ -592,8 +594,19 @@ __global__ void __launch_bounds__(256) hpk_ir_partial(const float* __restrict__ 
     }
 }
 // one wave per diagonal, four diagonals per workgroup
+// Workgroups beyond the diagonals turn the weights into biases (scripts/pyHICCUPS:163-166) - one launch less.
 __global__ void __launch_bounds__(256) hpk_ir_final(const double* __restrict__ psum, const unsigned* __restrict__ pnan, int nparts,
-                                                    int n, int num, int mw, double* __restrict__ IR) {
+                                                    int n, int num, int mw, double* __restrict__ IR,
+                                                    const double* __restrict__ weight, double* __restrict__ bias) {
+    const int nirb = (num + 3) / 4;
+    if ((int)blockIdx.x >= nirb) {
+        const int i = ((int)blockIdx.x - nirb) * 256 + threadIdx.x;
+        if (i < n) {
+            const double w = weight[i];
+            bias[i] = (w == 0.0 || w != w) ? 0.0 : 1.0 / w;
+        }
+        return;
+    }
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= num) return;
@@ -605,13 +618,6 @@ __global__ void __launch_bounds__(256) hpk_ir_final(const double* __restrict__ p
     const long long denom = (long long)(n - k) - (long long)nn;
     IR[k] = (k >= mw && n - k > 0) ? s / (double)denom : 0.0;       // 0/0 -> NaN like numpy's mean of an empty slice
 }
-__global__ void __launch_bounds__(256) hpk_biases(const double* __restrict__ weight, int n, double* __restrict__ bias) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double w = weight[i];
-    bias[i] = (w == 0.0 || w != w) ? 0.0 : 1.0 / w;                 // scripts/pyHICCUPS:163-166
-}
-
 // ------------------------------------------------------------------ local-expected tables (callers.py:66-72 + 175-198)
 // ------------------------------------------------------------------ freeze (one workgroup)
 // Column sums of the per-workgroup resolve histograms (wave w sums columns w, w + 16, ...; lanes stride over the
@@ -1278,9 +1284,9 @@ void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, in
 void hpk_launch_prep(const float* raw, const double* weight, int n, int num, int64_t ld, int mw, double* psum, unsigned* pnan,
                      double* IR, double* bias, hipStream_t st) {
     const int nparts = (n + HPK_IR_ROWS - 1) / HPK_IR_ROWS;        // hpk_api.cpp sizes psum / pnan with the same constant
-    hipLaunchKernelGGL(hpk_ir_partial, dim3(nparts), dim3(256), 0, st, raw, weight, n, num, ld, mw, psum, pnan);
-    hipLaunchKernelGGL(hpk_ir_final, dim3((num + 3) / 4), dim3(256), 0, st, psum, pnan, nparts, n, num, mw, IR);
-    hipLaunchKernelGGL(hpk_biases, dim3((n + 255) / 256), dim3(256), 0, st, weight, n, bias);
+    hipLaunchKernelGGL(hpk_ir_partial, dim3(nparts, (num - mw + 255) / 256), dim3(256), 0, st, raw, weight, n, num, ld, mw, psum, pnan);
+    hipLaunchKernelGGL(hpk_ir_final, dim3((num + 3) / 4 + (n + 255) / 256), dim3(256), 0, st, psum, pnan, nparts, n, num, mw, IR,
+                       weight, bias);
 }
 
 void hpk_launch_etab(const HpkDevPlan* plan, int nsteps, int D, int W, const double* IR, int n, int num, double* etab,
