@@ -355,22 +355,25 @@ int stage_inputs(hpk_ctx* c, Lane& L, const hpk_band* band, int mw, Staged* s) {
             }
         }
     }
-    if (!band->on_device) {      // the kernels wait for the uploads, not the other way round
-        HIPCHK(c, hipEventRecord(L.ev_up, L.up));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, L.ev_up, 0));
-    }
     if (derive) {
+        // The derivation runs on the lane's side stream too: it only needs the inputs, so for the chromosome submitted
+        // one ahead it executes beside the scoring / cut kernels of the chromosome before (those leave registers and
+        // LDS free; the stencil does not).
         const size_t nparts = (n + 31) / 32;        // HPK_IR_ROWS rows per partial (hpk_launch_prep)
         HIPCHK(c, L.IR.reserve(sizeof(double) * num));
         HIPCHK(c, L.b1.reserve(sizeof(double) * n));
         HIPCHK(c, L.psum.reserve(sizeof(double) * nparts * num));
         HIPCHK(c, L.pnan.reserve(sizeof(unsigned) * nparts * num));
         hpk_launch_prep(s->raw, s->weight, (int)n, (int)num, (int64_t)ld, mw, L.psum.as<double>(), L.pnan.as<unsigned>(),
-                        L.IR.as<double>(), L.b1.as<double>(), c->stream);
+                        L.IR.as<double>(), L.b1.as<double>(), L.up);
         HIPCHK(c, hipGetLastError());
         s->IR = L.IR.as<double>();
         s->b1 = L.b1.as<double>();
         s->b2 = s->b1;
+    }
+    if (!band->on_device || derive) {      // the kernels wait for the uploads / the derivation, not the other way round
+        HIPCHK(c, hipEventRecord(L.ev_up, L.up));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, L.ev_up, 0));
     }
     return HPK_OK;
 }
