@@ -26,6 +26,8 @@ def one_case(seed, ctx):
     res = 10000
     n = int(rng.integers(150, 1400)) if rng.random() < 0.8 else int(rng.integers(25, 150))     # some shorter than the band
     D = int(rng.integers(max(ww) + 2, 160))
+    if os.environ.get('HPK_FUZZ_BIG'):          # many tiles: several row blocks per XCD chunk, 3-5 column chunks
+        n, D = int(rng.integers(2000, 5000)), int(rng.integers(200, 520))
     maxapart = D * res
     num = D + maxww + 1
     depth = float(rng.choice([2.0, 8.0, 25.0, 60.0, 400.0, 5000.0]))
