@@ -62,7 +62,8 @@ class Band(C.Structure):
 
 class Set(C.Structure):
     _fields_ = [('pair', C.c_int32), ('fl', C.c_int32), ('nvalid', C.c_int64), ('numbin', C.c_int32),
-                ('reserved', C.c_int32), ('emax', C.c_double), ('begin', C.c_int64), ('end', C.c_int64)]
+                ('reserved', C.c_int32), ('emax', C.c_double), ('begin', C.c_int64), ('end', C.c_int64),
+                ('chunk_tests', C.POINTER(C.c_uint32)), ('chunk_below', C.POINTER(C.c_uint32))]
 
 
 class Result(C.Structure):
@@ -209,7 +210,9 @@ class BandResult(object):
             sl = slice(int(s.begin), int(s.end))
             self.sets.append(dict(pair=s.pair, fl='KY'[s.fl], nvalid=int(s.nvalid), numbin=s.numbin, emax=s.emax,
                                   x=x[sl], y=y[sl], O=O[sl], bal=bal[sl], E=E[sl], p=p[sl], q=q[sl],
-                                  other_zero=oz[sl].astype(bool)))
+                                  other_zero=oz[sl].astype(bool),
+                                  chunk_tests=_arr(s.chunk_tests, HPK_NB + 1, np.int64),
+                                  chunk_below=_arr(s.chunk_below, HPK_NB + 1, np.int64)))
         self.gap = _arr(r.gap, n, np.uint8).astype(bool)
         self.nsurv_sig, self.nsurv_cut = int(r.nsurv_sig), int(r.nsurv_cut)
         self.timing = dict(h2d=r.ms_h2d, stencil=r.ms_stencil, freeze=r.ms_freeze, score=r.ms_score, tighten=r.ms_tighten,

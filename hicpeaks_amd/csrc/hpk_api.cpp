@@ -165,6 +165,7 @@ struct ResultBox {
     std::vector<double> O, bal, E, p, q;
     std::vector<uint8_t> oz, gap, denseW;
     std::vector<double> denseE, denseS;
+    std::vector<uint32_t> fam;      // [2][nsets][HPK_NB + 1]: tests per chunk, of those p <= sig
 };
 
 struct Surv { int32_t x, y; uint8_t set, chunk, flag, keep; float O; double E, p, bal, q; };
@@ -758,6 +759,9 @@ int collect_impl(hpk_ctx* c, hpk_job* j, hpk_result** out) {
         for (size_t i = 0; i < sv.size(); ++i) order[i] = &sv[keys[i].idx];
         const double t_h1 = now_ms();
         std::vector<int> numbins(nsets, 0);
+        box->fam.resize((size_t)2 * nsets * (HPK_NB + 1));
+        std::memcpy(box->fam.data(), h_chist, sizeof(uint32_t) * (size_t)nsets * (HPK_NB + 1));
+        std::memcpy(box->fam.data() + (size_t)nsets * (HPK_NB + 1), hsmall + OFF_FAM_F, sizeof(uint32_t) * (size_t)nsets * (HPK_NB + 1));
         for (int s = 0; s < nsets; ++s) {
             hpk_set& hs = R.sets[s];
             hs.pair = (plan.mode == HPK_MODE_BHFDR) ? 0 : s / 2;
@@ -772,6 +776,13 @@ int collect_impl(hpk_ctx* c, hpk_job* j, hpk_result** out) {
                 numbin = nb < 0 ? 0 : (nb > HPK_NB ? HPK_NB : (int)nb);
             }
             hs.numbin = numbin;
+            hs.chunk_tests = box->fam.data() + (size_t)s * (HPK_NB + 1);
+            hs.chunk_below = box->fam.data() + (size_t)(nsets + s) * (HPK_NB + 1);
+            // chunks beyond numbin do not exist for the reference (their pixels keep p = q = 1, callers.py:259-260)
+            for (int ch = ((plan.mode == HPK_MODE_BHFDR) ? 1 : numbin) + 1; ch <= HPK_NB; ++ch) {
+                box->fam[(size_t)s * (HPK_NB + 1) + ch] = 0u;
+                box->fam[(size_t)(nsets + s) * (HPK_NB + 1) + ch] = 0u;
+            }
             numbins[s] = (plan.mode == HPK_MODE_BHFDR) ? 1 : numbin;
         }
         for (size_t i = 0; i < order.size();) {

@@ -108,6 +108,9 @@ typedef struct {
     int32_t reserved;
     double  emax;
     int64_t begin, end;        /* slice of the survivor arrays: pixels with q <= sig (callers.py:279) */
+    const uint32_t* chunk_tests;   /* [129] Poisson models per lambda chunk i = 1..numbin (family sizes of the BH step,
+                                      callers.py:266); entry 0 unused; bhfdr: entry 1 = all of them */
+    const uint32_t* chunk_below;   /* [129] of those, p <= sig */
 } hpk_set;
 
 typedef struct {

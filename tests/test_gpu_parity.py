@@ -100,9 +100,17 @@ def test_golden_parity(name, mode, ctx):
                        g['s%d_p' % t], g['s%d_q' % t], sig)
             if E.size:
                 assert s['numbin'] == int(np.ceil(np.log(E.max()) / np.log(2) * 3 + 1))
+                # family sizes of the BH step = the reference's chunk memberships (callers.py:33-38, strict on both sides)
+                want = [idx.size for _, _, idx in orc.lambdachunk(E)]
+                np.testing.assert_array_equal(s['chunk_tests'][1:len(want) + 1], want)
+                assert s['chunk_tests'][len(want) + 1:].sum() == 0 and s['chunk_tests'][0] == 0
+                pv = g['s%d_p' % t]
+                below = [int((pv[idx] <= sig).sum()) for _, _, idx in orc.lambdachunk(E)]
+                np.testing.assert_array_equal(s['chunk_below'][1:len(want) + 1], below)
     else:
         _check_set(R.sets[0], g['s0_vx'].astype(np.int64), g['s0_vy'].astype(np.int64), g['s0_E'], g['s0_O'],
                    g['s0_p'], g['s0_q'], sig, reject=g['s0_reject'])
+        assert R.sets[0]['chunk_tests'][1] == g['s0_E'].size
 
     # gap rows
     np.testing.assert_array_equal(R.gap, g['cband'].sum(axis=1) == 0)
