@@ -175,6 +175,9 @@ def main():
                     help='rows of the CPU-baseline sample (default: the whole workload, ~8 s on one core; 0 = skip)')
     ap.add_argument('--pipeline-depth', type=int, default=2,
                     help='chromosomes in flight per GPU (hpk_submit_band / hpk_collect); 1 = one synchronous call per step')
+    ap.add_argument('--balanced-f64', action='store_true',
+                    help='hand over the balanced band as f64 [n][ld] (what the drop-in hiccups() receives as cDiags) instead of '
+                         'the weights: 12 B/px read instead of 4')
     ap.add_argument('--host-inputs', action='store_true',
                     help='hand the band over as host (numpy) arrays every step: the PCIe-inclusive rate of DESIGN.md, never `value`')
     ap.add_argument('--stencil-only', action='store_true', help='time the stencil kernel alone (HPK_FLAG_NO_SCORE)')
@@ -231,7 +234,22 @@ def main():
         raw_h = np.ascontiguousarray(raw_d[:, :num].cpu().numpy())
         w_h, ir_h, b_h = w_d.cpu().numpy(), ir_d.cpu().numpy(), b_d.cpu().numpy()
 
+    bal_d = None
+    if args.balanced_f64:       # balanced = (raw * w_r) * w_c on diagonals >= min(ww), NaN -> 0 (scripts/pyHICCUPS:150-158)
+        kk = torch.arange(ld, device=dev)
+        rr = torch.arange(n, device=dev)
+        cc = (rr[:, None] + kk[None, :]).clamp(max=n - 1)
+        bal_d = (raw_d.to(torch.float64) * w_d[:, None]) * w_d[cc]
+        bal_d = torch.nan_to_num(bal_d, nan=0.0)
+        bal_d[:, :mw] = 0
+        bal_d[(rr[:, None] + kk[None, :]) >= n] = 0
+        del kk, rr, cc
+        torch.cuda.synchronize()
+
     def submit():
+        if bal_d is not None:
+            return ctx.submit_device(n, num, ld, raw_d.data_ptr(), ir_d.data_ptr(), b_d.data_ptr(), b_d.data_ptr(), prm,
+                                     balanced_ptr=bal_d.data_ptr())
         if args.host_inputs:
             return ctx.submit_host(raw_h, ir_h, b_h, b_h, prm, weight=w_h)
         return ctx.submit_device(n, num, ld, raw_d.data_ptr(), ir_d.data_ptr(), b_d.data_ptr(), b_d.data_ptr(), prm,
@@ -300,7 +318,7 @@ def main():
                        'px_with_p_le_sig': R.nsurv_sig, 'records_copied_back': R.nsurv_cut,
                        'parallelism': 'one chromosome per GPU, no collective', 'pipeline_depth': depth,
                        'sync_call_ms': float(np.median(lat)),
-                       'stencil_only': bool(args.stencil_only), 'host_inputs': bool(args.host_inputs)},
+                       'stencil_only': bool(args.stencil_only), 'host_inputs': bool(args.host_inputs), 'balanced_f64': bool(args.balanced_f64)},
             'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                          'kernel_ms': st, 'algorithmic_bytes_per_launch': BYTES_PER_PX * px_per_step},
