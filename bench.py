@@ -100,7 +100,11 @@ def run_genome(args, cfg, ctx, rank, world, local, dist):
         n = sizes[c]
         raw_d, w_d, _, _ = bandgen.device_band(n, num, ld, mw, depth=cfg['depth'], nloops=max(1, cfg['nloops'] * n // cfg['n']),
                                                seed=1000 * rank + i, device=dev, want_expected=False)
-        bands.append((c, n, raw_d, w_d))
+        if args.host_inputs:       # PCIe-inclusive variant: the bands live in host memory (pageable numpy), as after cooler I/O
+            bands.append((c, n, np.ascontiguousarray(raw_d[:, :num].cpu().numpy()), w_d.cpu().numpy()))
+            del raw_d, w_d
+        else:
+            bands.append((c, n, raw_d, w_d))
     torch.cuda.synchronize()
     prm = _lib.make_params(_lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], cfg['maxww'], SIG, cfg['maxapart'], cfg['res'],
                            MIN_READS, 0)
@@ -113,7 +117,10 @@ def run_genome(args, cfg, ctx, rank, world, local, dist):
     def one_pass():
         pending, done = collections.deque(), []
         for c, n, raw_d, w_d in bands:
-            pending.append(ctx.submit_device(n, num, ld, raw_d.data_ptr(), None, None, None, prm, weight_ptr=w_d.data_ptr()))
+            if args.host_inputs:
+                pending.append(ctx.submit_host(raw_d, None, None, None, prm, weight=w_d, num=num))
+            else:
+                pending.append(ctx.submit_device(n, num, ld, raw_d.data_ptr(), None, None, None, prm, weight_ptr=w_d.data_ptr()))
             if len(pending) >= depth:
                 done.append(light(pending.popleft().result()))
         while pending:
@@ -155,7 +162,7 @@ def run_genome(args, cfg, ctx, rank, world, local, dist):
                        'candidates_rank0': int(sum(t[2] for t in last)),
                        'significant_px_rank0': int(sum(t[3] for t in last)),
                        'parallelism': 'chromosomes dealt largest-first to the GPUs, no collective',
-                       'whole_genome_wall_ms': elapsed / args.steps * 1e3},
+                       'whole_genome_wall_ms': elapsed / args.steps * 1e3, 'host_inputs': bool(args.host_inputs)},
             'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel_ms': st_ms / nlaunch,
                          'algorithmic_bytes_per_launch': BYTES_PER_PX * st_px / nlaunch},
