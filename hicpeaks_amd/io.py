@@ -42,13 +42,13 @@ class NpzSource(BandSource):
         return out, np.asarray(self.z[weight_name + '_' + chrom], dtype=np.float64)
 
 
-def save_band_archive(path, res, bands):
+def save_band_archive(path, res, bands, compressed=True):
     """bands: {chrom: (raw [n, num], weight [n])}"""
     d = dict(res=np.int64(res), chroms=np.array(list(bands), dtype='U32'))
     for c, (raw, w) in bands.items():
         d['raw_' + c] = np.asarray(raw)
         d['weight_' + c] = np.asarray(w, dtype=np.float64)
-    np.savez_compressed(path, **d)
+    (np.savez_compressed if compressed else np.savez)(path, **d)
 
 
 class CoolerSource(BandSource):
