@@ -36,10 +36,13 @@ class NpzSource(BandSource):
     def fetch(self, chrom, num, weight_name='weight'):
         raw = self.z['raw_' + chrom]
         n = raw.shape[0]
+        w = np.asarray(self.z[weight_name + '_' + chrom], dtype=np.float64)
+        if raw.shape[1] == num and raw.dtype == np.float32 and raw.flags.c_contiguous:
+            return raw, w                       # stored exactly as the library wants it: no second copy
         out = np.zeros((n, num), dtype=np.float32)
         k = min(num, raw.shape[1])
         out[:, :k] = raw[:, :k]
-        return out, np.asarray(self.z[weight_name + '_' + chrom], dtype=np.float64)
+        return out, w
 
 
 def save_band_archive(path, res, bands, compressed=True):
