@@ -213,6 +213,11 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
     S.c = reinterpret_cast<double*>(smem);
     S.p = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 8);
     S.l = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 12);
+    // records written into the current tile's region so far: the tile belongs to this workgroup alone, so its waves
+    // reserve their share with an LDS atomic (a global one costs every wave an L2 round trip per tile and a vmcnt(0)
+    // that also waits for the prefetch)
+    unsigned* __restrict__ ltc = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 12 + (size_t)NW * HPK_LISTCAP * 4);
+    if (threadIdx.x == 0) ltc[0] = 0u;
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -390,7 +395,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
     // this wave's share of the tile's record region
     unsigned woff = 0u;
     if (cnt > 0) {
-        if (lane == 0) woff = atomicAdd(&a.tile_cnt[tid], (unsigned)cnt);
+        if (lane == 0) woff = atomicAdd(ltc, (unsigned)cnt);
         woff = (unsigned)__builtin_amdgcn_readfirstlane((int)woff);
     }
     const int64_t rec0 = (int64_t)tid * a.tilecap + woff;
@@ -544,6 +549,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
         }
     }
     __syncthreads();                 // every wave is done with this tile's SAT
+    if (threadIdx.x == 0) { a.tile_cnt[tid] = ltc[0]; ltc[0] = 0u; }     // next use of ltc is two barriers away
     tid = tid_next;
     }   // tile loop
 
@@ -1227,7 +1233,7 @@ __global__ void __launch_bounds__(64) hpk_brute(HpkBruteArgs a) {
 }  // namespace
 
 // ------------------------------------------------------------------ launchers
-int hpk_stencil_lds_bytes() { return LR * LC * 12 + HPK_NWAVES * HPK_LISTCAP * 4; }
+int hpk_stencil_lds_bytes() { return LR * LC * 12 + HPK_NWAVES * HPK_LISTCAP * 4 + 16; }
 
 template <int NW, bool BALF64, bool SIMPLE>
 static void launch_stencil_t(const HpkStencilArgs& a, hipStream_t st) {
