@@ -450,7 +450,7 @@ int launch_scoring(hpk_ctx* c, hpk_job* j, int attempt) {
         HIPCHK(c, L.surv.reserve(sizeof(HpkSurv) * (size_t)cap * HPK_NREG));
         HIPCHK(c, L.surv2.reserve(sizeof(HpkSurv) * (size_t)cap * HPK_NREG));
         if (attempt > 0) {       // overflow rerun: the chunk table no longer fits the zero block
-            const size_t cu_bytes = sizeof(unsigned) * (size_t)(cap / 256 * HPK_NREG + 1);
+            const size_t cu_bytes = sizeof(unsigned) * (size_t)(cap / HPK_SCH * HPK_NREG + 1);
             HIPCHK(c, L.chunkused.reserve(cu_bytes));
             HIPCHK(c, hipMemsetAsync(L.chunkused.p, 0, cu_bytes, c->stream));
             HIPCHK(c, hipMemsetAsync(small + OFF_NSURV, 0, SMALL_BYTES - OFF_NSURV, c->stream));
@@ -565,8 +565,8 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     int64_t band_px = 0;                    // pixels with mw <= d <= D inside the matrix
     for (int d = mw; d <= std::min(D, num - 1); ++d) if (n - d > 0) band_px += n - d;
     j->band_px = band_px;
-    // survivor capacity per region; every scoring wave may hold one partly filled 256-record chunk
-    int64_t cap = (std::max<int64_t>(1 << 16, band_px * j->nsets / 6) + (int64_t)c->cus * 8 * 4 * 256 * 2) / HPK_NREG;
+    // survivor capacity per region; every scoring wave may hold one partly filled chunk of HPK_SCH records
+    int64_t cap = (std::max<int64_t>(1 << 16, band_px * j->nsets / 6) + (int64_t)c->cus * 8 * 4 * HPK_SCH * 2) / HPK_NREG;
     if (const char* e = std::getenv("HPK_SURV_CAP")) cap = std::max<int64_t>(256, std::atoll(e));     // tests: force the overflow rerun
     cap = (cap + 255) / 256 * 256;
     j->cap = cap;
@@ -578,7 +578,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     const size_t off_tc = up256(off_hp + sizeof(unsigned) * (size_t)grid_ * (HPK_MAX_STEPS + 1));
     const size_t off_cnt = up256(off_tc + sizeof(unsigned) * (size_t)ntiles_);
     const size_t off_cu = up256(off_cnt + sizeof(unsigned) * HPK_NFAM * HPK_TIGHTEN_MAX);
-    const size_t zero_bytes = (off_cu + sizeof(unsigned) * (size_t)(cap / 256 * HPK_NREG + 1) + 4095) / 4096 * 4096;
+    const size_t zero_bytes = (off_cu + sizeof(unsigned) * (size_t)(cap / HPK_SCH * HPK_NREG + 1) + 4095) / 4096 * 4096;
     j->off_rowlive = off_rowlive; j->off_inl = off_inl; j->head_bytes = head_bytes; j->off_cnt = off_cnt; j->off_cu = off_cu;
     HIPCHK(c, L.small.reserve(zero_bytes));
     // expected tables of this chromosome; the same launch zero-fills the block (extra workgroups)

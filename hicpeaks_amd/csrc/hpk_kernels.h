@@ -6,6 +6,8 @@
 
 #define HPK_LC 128                      // SAT columns per tile (two cells per lane)
 #define HPK_LR 80                       // SAT rows per tile: 80 * 128 * 12 B = 120 KiB + 32 KiB of candidate lists
+#define HPK_SCH 64                      // survivor slots a scoring wave reserves at a time (one batch always fits)
+#define HPK_SCH_LOG2 6
 #define HPK_HIST_NCAND HPK_MAX_STEPS    // hist[HPK_MAX_STEPS] counts the candidates
 #ifndef HPK_NWAVES
 #define HPK_NWAVES 16                   // waves per stencil workgroup (16 or 8)
@@ -91,7 +93,7 @@ struct HpkScoreArgs {
     unsigned long long* nsurv;          // [HPK_NREG * HPK_REG_STRIDE] reserved slots per region
     int64_t cap;                        // survivor capacity per region (multiple of 256)
     HpkSurv* surv;
-    unsigned* chunk_used;               // [HPK_NREG * cap / 256] filled slots per 256-record chunk
+    unsigned* chunk_used;               // [HPK_NREG * cap / HPK_SCH] filled slots per chunk
     int32_t dbg;                        // profiling ablation (HPK_DBG_SCORE): 1 no Poisson table read, 2 no expected table,
                                         // 3 no survivor stores, 4 no counters
 };

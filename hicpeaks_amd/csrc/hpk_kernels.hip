@@ -893,7 +893,6 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     const int frozen = *const_cast<const int32_t*>(ka->frozen);
     // Survivor slots are reserved from the global counter HPK_SCH records at a time per wave (same-address atomics
     // run at ~90 per microsecond device-wide); how many slots of a chunk were filled goes to chunk_used[].
-    constexpr unsigned HPK_SCH = 256;
     unsigned long long wbase = 0ull;
     unsigned wused = HPK_SCH;               // "no chunk yet"
     bool have_chunk = false;
@@ -1101,7 +1100,7 @@ __global__ void __launch_bounds__(256) hpk_thr_count(const HpkSurv* __restrict__
     {
         const int64_t rb = (int64_t)reg * cap;
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-            if ((unsigned)(i & 255) >= chunk_used[(rb + i) >> 8]) continue;
+            if ((unsigned)(i & (HPK_SCH - 1)) >= chunk_used[(rb + i) >> HPK_SCH_LOG2]) continue;
             const HpkSurv& rec = surv[rb + i];
             const int f = (int)rec.set * (HPK_NB + 1) + (int)rec.chunk;
             if (rec.p <= lthr[f]) atomicAdd(&lc[f], 1u);
@@ -1134,7 +1133,7 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkSurv* __restrict
         bool keep = false;
         HpkSurv rec;
         if (i < n) {
-            if ((unsigned)(i & 255) < chunk_used[(rb + i) >> 8]) {
+            if ((unsigned)(i & (HPK_SCH - 1)) < chunk_used[(rb + i) >> HPK_SCH_LOG2]) {
                 const HpkSurv& src = surv[rb + i];
                 keep = src.p <= lthr[(int)src.set * (HPK_NB + 1) + (int)src.chunk];
                 if (keep) {                               // the other 30 bytes only for the few that stay

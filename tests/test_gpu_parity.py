@@ -395,7 +395,7 @@ def test_survivor_overflow_rerun(ctx, monkeypatch):
     raw = raw.astype(np.float32)
     prm = _lib.make_params(_lib.MODE_HICCUPS, [1, 2], [3, 5], maxww, 0.1, maxapart, res, 16, 0)
     want = ctx.score_host(raw, None, None, None, prm, weight=weight)
-    # every scoring wave with a survivor takes a whole 256-record chunk: hundreds of waves against 64 regions x 1 chunk
+    # every scoring wave with a survivor takes a whole 64-record chunk: hundreds of waves against 64 regions x 4 chunks
     assert want.nsurv_sig > 64 * 256 and want.ncand > 100000
     monkeypatch.setenv('HPK_SURV_CAP', '256')
     got = ctx.score_host(raw, None, None, None, prm, weight=weight)
