@@ -1280,9 +1280,10 @@ void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, in
                         const double* bal, const double* weight, int64_t ld, int cus, hipStream_t st) {
     if (rounds > HPK_TIGHTEN_MAX) rounds = HPK_TIGHTEN_MAX;
     const int nfam = nsets * (HPK_NB + 1);          // families in use: (set, chunk)
+    static const int gx = std::getenv("HPK_THR_GX") ? std::atoi(std::getenv("HPK_THR_GX")) : 8;
     for (int r = 0; r < rounds; ++r)
-        hipLaunchKernelGGL(hpk_thr_count, dim3(8, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt, r, sig, nfam);
-    hipLaunchKernelGGL(hpk_thr_compact, dim3(8, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt,
+        hipLaunchKernelGGL(hpk_thr_count, dim3(gx, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt, r, sig, nfam);
+    hipLaunchKernelGGL(hpk_thr_compact, dim3(gx, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt,
                        rounds, sig, nfam, out_head, inl, out_rest, nout, bal, weight, ld);
 }
 
