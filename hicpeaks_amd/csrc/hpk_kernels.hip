@@ -1267,11 +1267,23 @@ void hpk_launch_gap(const float* raw, const double* bal, const double* weight, i
     hipLaunchKernelGGL(hpk_gap, dim3((n + 3) / 4), dim3(256), 0, st, raw, bal, weight, n, num, ld, mw, gap);
 }
 
+// Persistent grid: exactly the workgroups that are resident at once (occupancy x CUs), so that no second round of
+// workgroups pays the prologue again (measured: 0.105 -> 0.095 ms against twice as many).
+template <bool BH>
+static int score_grid(int cus) {
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hpk_score<BH>, 256, 0) != hipSuccess || nb <= 0) nb = 4;
+        per_cu = nb;
+    }
+    static const int gm = std::getenv("HPK_SCORE_GM") ? std::atoi(std::getenv("HPK_SCORE_GM")) : 0;
+    return cus * (gm > 0 ? gm : per_cu);
+}
 void hpk_launch_score(const HpkScoreArgs& a, bool bhfdr, int cus, hipStream_t st) {
     if (a.ntiles <= 0 || a.n <= 0) return;
-    const int grid = cus * 8;
-    if (bhfdr) hipLaunchKernelGGL(hpk_score<true>, dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(hpk_score<false>, dim3(grid), dim3(256), 0, st, a);
+    if (bhfdr) hipLaunchKernelGGL(hpk_score<true>, dim3(score_grid<true>(cus)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(hpk_score<false>, dim3(score_grid<false>(cus)), dim3(256), 0, st, a);
 }
 
 void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned* chunk_used,
