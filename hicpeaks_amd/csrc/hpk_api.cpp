@@ -58,7 +58,7 @@ struct Lane {
     int nev = 0;
     bool busy = false;
     // workspaces (grow only)
-    DevBuf raw, bal, weight, IR, b1, b2, plan, etab, eedge, recE, recS, recW, dE, dW, dS, small, surv, surv2, chunkused, psum, pnan;
+    DevBuf raw, bal, weight, IR, b1, b2, plan, etab, eedge, recE, recS, recW, dE, dW, dS, small, surv, surv2, chunkused, psum, pnan, units;
     void* h_head = nullptr;             // pinned: counters | row flags | first survivors
     size_t h_head_cap = 0;
     // the device copy of the widening plan is reused while the parameters do not change
@@ -67,7 +67,7 @@ struct Lane {
     HpkDevPlan plan_host;
     void release() {
         DevBuf* all[] = {&raw, &bal, &weight, &IR, &b1, &b2, &plan, &etab, &eedge, &recE, &recS, &recW, &dE, &dW, &dS, &small,
-                         &surv, &surv2, &chunkused, &psum, &pnan};
+                         &surv, &surv2, &chunkused, &psum, &pnan, &units};
         for (DevBuf* b : all) b->release();
         if (h_head) { (void)hipHostFree(h_head); h_head = nullptr; h_head_cap = 0; }
         for (int i = 0; i < nev; ++i) (void)hipEventDestroy(ev[i]);
@@ -394,7 +394,8 @@ constexpr size_t OFF_HIST = 0;                                                  
 constexpr size_t OFF_FROZEN = OFF_HIST + 8 * (HPK_MAX_STEPS + 1);               // i32
 constexpr size_t OFF_ERR = OFF_FROZEN + 8;                                       // i32
 constexpr size_t OFF_EXEC = OFF_ERR + 8;                                         // i32[64]
-constexpr size_t OFF_NSURV = OFF_EXEC + 4 * HPK_MAX_STEPS;                       // u64
+constexpr size_t OFF_NUNITS = OFF_EXEC + 4 * HPK_MAX_STEPS;                      // u32 (+ pad): survives the overflow rerun
+constexpr size_t OFF_NSURV = OFF_NUNITS + 8;                                     // u64 ... everything from here is reset by the rerun
 constexpr size_t OFF_NVALID = OFF_NSURV + 8 * HPK_NREG * HPK_REG_STRIDE;          // u64[16]
 constexpr size_t OFF_EMAX = OFF_NVALID + 8 * 2 * HPK_MAX_PAIRS;                  // u64[16]
 constexpr size_t OFF_NOUT = OFF_EMAX + 8 * 2 * HPK_MAX_PAIRS;                    // u64
@@ -466,6 +467,7 @@ int launch_scoring(hpk_ctx* c, hpk_job* j, int attempt) {
         sc.ptab_off = c->d_off.as<int32_t>(); sc.sfe = c->d_sfe.as<double>(); sc.sig = j->prm.sig;
         sc.n = j->n; sc.num = j->num; sc.ld = j->ld; sc.ldo = j->ldo; sc.mw = plan.mw; sc.D = plan.D;
         sc.rec_ent = sa.rec_ent; sc.rec_S = sa.rec_S; sc.rec_W = sa.rec_W; sc.tile_cnt = sa.tile_cnt;
+        sc.units = L.units.as<uint2>(); sc.nunits = reinterpret_cast<const unsigned*>(small + OFF_NUNITS);
         sc.tilecap = sa.tilecap; sc.rec_stride = sa.rec_stride; sc.ntiles = sa.ntiles;
         sc.TR = j->TR; sc.TC = j->TC; sc.J = sa.J; sc.W = plan.W;
         sc.fam_m = d_fam_m; sc.fam_f = d_fam_f;
@@ -628,7 +630,12 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     hpk_launch_stencil(sa, in.bal != nullptr, plan.simple_reads != 0 && !std::getenv("HPK_GENERIC_SEARCH"), c->stream);
     HIPCHK(c, hipGetLastError());
     (void)hipEventRecord(L.ev[2], c->stream);
-    hpk_launch_freeze(sa.plan, d_hist, sa.hist_part, sa.grid, d_frozen, d_exec, d_err, c->stream);
+    {   // at most ceil(tilecap / 256) units per tile
+        const size_t upt = ((size_t)sa.tilecap + 255) / 256;
+        HIPCHK(c, L.units.reserve(sizeof(uint2) * (size_t)sa.ntiles * upt + 16));
+    }
+    hpk_launch_freeze(sa.plan, d_hist, sa.hist_part, sa.grid, d_frozen, d_exec, d_err, sa.tile_cnt, sa.ntiles,
+                      L.units.as<uint2>(), reinterpret_cast<unsigned*>(small + OFF_NUNITS), c->stream);
     HIPCHK(c, hipGetLastError());
     if (j->phases) (void)hipEventRecord(L.ev[3], c->stream);
     return launch_scoring(c, j, 0);
