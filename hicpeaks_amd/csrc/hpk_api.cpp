@@ -625,17 +625,18 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     HIPCHK(c, L.recW.reserve((size_t)sa.rec_stride * plan.nslots));
     sa.rec_ent = L.recE.as<unsigned>(); sa.rec_S = L.recS.as<double2>(); sa.rec_W = L.recW.as<uint8_t>();
     sa.tile_cnt = reinterpret_cast<unsigned*>(small + off_tc);
+    {   // at most ceil(tilecap / 256) units per tile
+        const size_t upt = ((size_t)sa.tilecap + 255) / 256;
+        HIPCHK(c, L.units.reserve(sizeof(uint2) * (size_t)sa.ntiles * upt + 16));
+        sa.units = L.units.as<uint2>();
+        sa.nunits = reinterpret_cast<unsigned*>(small + OFF_NUNITS);
+    }
     sa.gap = small + off_rowlive;
     (void)hipEventRecord(L.ev[1], c->stream);
     hpk_launch_stencil(sa, in.bal != nullptr, plan.simple_reads != 0 && !std::getenv("HPK_GENERIC_SEARCH"), c->stream);
     HIPCHK(c, hipGetLastError());
     (void)hipEventRecord(L.ev[2], c->stream);
-    {   // at most ceil(tilecap / 256) units per tile
-        const size_t upt = ((size_t)sa.tilecap + 255) / 256;
-        HIPCHK(c, L.units.reserve(sizeof(uint2) * (size_t)sa.ntiles * upt + 16));
-    }
-    hpk_launch_freeze(sa.plan, d_hist, sa.hist_part, sa.grid, d_frozen, d_exec, d_err, sa.tile_cnt, sa.ntiles,
-                      L.units.as<uint2>(), reinterpret_cast<unsigned*>(small + OFF_NUNITS), c->stream);
+    hpk_launch_freeze(sa.plan, d_hist, sa.hist_part, sa.grid, d_frozen, d_exec, d_err, c->stream);
     HIPCHK(c, hipGetLastError());
     if (j->phases) (void)hipEventRecord(L.ev[3], c->stream);
     return launch_scoring(c, j, 0);

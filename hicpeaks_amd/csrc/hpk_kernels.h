@@ -31,6 +31,8 @@ struct HpkStencilArgs {
     double2* rec_S;
     uint8_t* rec_W;
     unsigned* tile_cnt;
+    uint2* units;                       // scoring work list: one entry per 256 records of a tile (appended at tile end)
+    unsigned* nunits;
     int32_t tilecap;
     int64_t rec_stride;
     uint8_t* gap;                       // [n] preset to 0; set for rows with a non-zero balanced value (gap = !flag)
@@ -67,7 +69,7 @@ struct HpkScoreArgs {
     const double2* rec_S;
     const uint8_t* rec_W;
     const unsigned* tile_cnt;
-    const uint2* units;                 // work list {tile, unit | records of the tile << 8}, built by hpk_freeze
+    const uint2* units;                 // work list {tile, unit | records of the tile << 8}, appended by hpk_stencil
     const unsigned* nunits;
     int32_t tilecap;
     int64_t rec_stride;
@@ -121,8 +123,7 @@ int  hpk_stencil_lds_bytes();
 void hpk_launch_stencil(const HpkStencilArgs& a, bool balf64, bool simple, hipStream_t st);
 void hpk_launch_dense(const HpkDenseArgs& a, hipStream_t st);
 void hpk_launch_freeze(const HpkDevPlan* plan, unsigned long long* hist, const unsigned* hist_part, int nparts,
-                       int32_t* frozen, int32_t* executed, int32_t* err, const unsigned* tile_cnt, int ntiles, uint2* units,
-                       unsigned* nunits, hipStream_t st);
+                       int32_t* frozen, int32_t* executed, int32_t* err, hipStream_t st);
 void hpk_launch_prep(const float* raw, const double* weight, int n, int num, int64_t ld, int mw, double* psum, unsigned* pnan,
                      double* IR, double* bias, hipStream_t st);
 void hpk_launch_etab(const HpkDevPlan* plan, int nsteps, int D, int W, const double* IR, int n, int num, double* etab,

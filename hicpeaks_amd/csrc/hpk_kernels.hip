@@ -549,7 +549,21 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
         }
     }
     __syncthreads();                 // every wave is done with this tile's SAT
-    if (threadIdx.x == 0) { a.tile_cnt[tid] = ltc[0]; ltc[0] = 0u; }     // next use of ltc is two barriers away
+    if (wave == 0) {
+        // The tile's records become work for the scoring kernel: one entry per 256 records, appended to the global
+        // list with one atomic per tile (tiles finish at ~15-25 per microsecond, well under the same-address rate).
+        // ltc is next touched two barriers from here.
+        const volatile HpkStencilArgs* ka = (const volatile HpkStencilArgs*)(const void*)__builtin_amdgcn_kernarg_segment_ptr();
+        const unsigned c = ltc[0];
+        const unsigned nu = (c + 255u) >> 8;
+        if (nu != 0u) {
+            unsigned off = 0u;
+            if (lane == 0) off = atomicAdd(const_cast<unsigned*>(ka->nunits), nu);
+            off = (unsigned)__builtin_amdgcn_readfirstlane((int)off);
+            if ((unsigned)lane < nu) const_cast<uint2*>(ka->units)[off + lane] = make_uint2((unsigned)tid, (unsigned)lane | (c << 8));
+        }
+        if (lane == 0) { a.tile_cnt[tid] = c; ltc[0] = 0u; }
+    }
     tid = tid_next;
     }   // tile loop
 
@@ -630,9 +644,7 @@ __global__ void __launch_bounds__(256) hpk_ir_final(const double* __restrict__ p
 // partials), then one thread replays the reference's frozen_w / break logic on the totals.
 __global__ void __launch_bounds__(1024) hpk_freeze(const HpkDevPlan* __restrict__ plan, const unsigned* __restrict__ hist_part,
                                                    int nparts, unsigned long long* __restrict__ hist_out,
-                                                   int32_t* frozen, int32_t* executed, int32_t* err,
-                                                   const unsigned* __restrict__ tile_cnt, int ntiles,
-                                                   uint2* __restrict__ units, unsigned* __restrict__ nunits) {
+                                                   int32_t* frozen, int32_t* executed, int32_t* err) {
     __shared__ unsigned long long hist[HPK_MAX_STEPS + 1];
     __shared__ int swi[HPK_MAX_STEPS], sslot[HPK_MAX_STEPS];        // the serial part below reads LDS only
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -651,30 +663,6 @@ __global__ void __launch_bounds__(1024) hpk_freeze(const HpkDevPlan* __restrict_
     __syncthreads();
     if (threadIdx.x <= HPK_MAX_STEPS) hist_out[threadIdx.x] = hist[threadIdx.x];
     (void)lane; (void)wave;
-    // Work list of the scoring kernel: one entry per 256 records of a tile, {tile, unit | records of the tile << 8}.
-    // (Dealing out every possible unit of every tile made each scoring wave chase ~10 empty ones, one dependent
-    // tile_cnt load each.)  Thread t takes a contiguous run of tiles; a block scan places its entries.
-    {
-        __shared__ unsigned part[1024];
-        const int per = (ntiles + 1023) / 1024;
-        const int t0 = (int)threadIdx.x * per, t1 = (t0 + per < ntiles) ? t0 + per : ntiles;
-        unsigned mine = 0u;
-        for (int t = t0; t < t1; ++t) mine += (tile_cnt[t] + 255u) >> 8;
-        part[threadIdx.x] = mine;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            const unsigned v = ((int)threadIdx.x >= off) ? part[threadIdx.x - off] : 0u;
-            __syncthreads();
-            part[threadIdx.x] += v;
-            __syncthreads();
-        }
-        unsigned o = part[threadIdx.x] - mine;
-        for (int t = t0; t < t1; ++t) {
-            const unsigned c = tile_cnt[t], nu = (c + 255u) >> 8;
-            for (unsigned k = 0; k < nu; ++k) units[o++] = make_uint2((unsigned)t, k | (c << 8));
-        }
-        if (threadIdx.x == 1023) *nunits = part[1023];
-    }
     if (threadIdx.x != 0) return;
     const long long total = (long long)hist[HPK_HIST_NCAND];
     long long unres[HPK_KSLOTS];
@@ -926,7 +914,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     const int64_t rbase = (int64_t)region * a.cap;      // this wave's survivor region
     // Work unit = 4 consecutive 64-record batches of one tile's record region; units are dealt round-robin to all
     // waves of the grid (tiles differ a lot in candidate count), reads are coalesced.
-    const unsigned nunits = *a.nunits;                      // work list built by hpk_freeze: non-empty units only
+    const unsigned nunits = *a.nunits;                      // work list appended by hpk_stencil: non-empty units only
     const unsigned gw = (unsigned)((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const unsigned nwv = (unsigned)(((int64_t)gridDim.x * blockDim.x) >> 6);
     for (unsigned u = gw; u < nunits; u += nwv) {
@@ -1283,10 +1271,8 @@ void hpk_launch_dense(const HpkDenseArgs& a, hipStream_t st) {
 }
 
 void hpk_launch_freeze(const HpkDevPlan* plan, unsigned long long* hist, const unsigned* hist_part, int nparts,
-                       int32_t* frozen, int32_t* executed, int32_t* err, const unsigned* tile_cnt, int ntiles, uint2* units,
-                       unsigned* nunits, hipStream_t st) {
-    hipLaunchKernelGGL(hpk_freeze, dim3(1), dim3(1024), 0, st, plan, hist_part, nparts, hist, frozen, executed, err, tile_cnt,
-                       ntiles, units, nunits);
+                       int32_t* frozen, int32_t* executed, int32_t* err, hipStream_t st) {
+    hipLaunchKernelGGL(hpk_freeze, dim3(1), dim3(1024), 0, st, plan, hist_part, nparts, hist, frozen, executed, err);
 }
 
 void hpk_launch_gap(const float* raw, const double* bal, const double* weight, int32_t n, int32_t num, int64_t ld,
