@@ -625,8 +625,8 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     HIPCHK(c, L.recW.reserve((size_t)sa.rec_stride * plan.nslots));
     sa.rec_ent = L.recE.as<unsigned>(); sa.rec_S = L.recS.as<double2>(); sa.rec_W = L.recW.as<uint8_t>();
     sa.tile_cnt = reinterpret_cast<unsigned*>(small + off_tc);
-    {   // at most ceil(tilecap / 256) units per tile
-        const size_t upt = ((size_t)sa.tilecap + 255) / 256;
+    {   // at most ceil(tilecap / HPK_UNIT) units per tile
+        const size_t upt = ((size_t)sa.tilecap + HPK_UNIT - 1) / HPK_UNIT;
         HIPCHK(c, L.units.reserve(sizeof(uint2) * (size_t)sa.ntiles * upt + 16));
         sa.units = L.units.as<uint2>();
         sa.nunits = reinterpret_cast<unsigned*>(small + OFF_NUNITS);

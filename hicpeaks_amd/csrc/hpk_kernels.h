@@ -6,6 +6,9 @@
 
 #define HPK_LC 128                      // SAT columns per tile (two cells per lane)
 #define HPK_LR 80                       // SAT rows per tile: 80 * 128 * 12 B = 120 KiB + 32 KiB of candidate lists
+#ifndef HPK_UNIT
+#define HPK_UNIT 128                    // records per scoring work unit (128 measured best of 128 | 256 | 512) (a tile has at most 64 x 127 records: <= 61 units of 128)
+#endif
 #define HPK_SCH 64                      // survivor slots a scoring wave reserves at a time (one batch always fits)
 #define HPK_SCH_LOG2 6
 #define HPK_HIST_NCAND HPK_MAX_STEPS    // hist[HPK_MAX_STEPS] counts the candidates

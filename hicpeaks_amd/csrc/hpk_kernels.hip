@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
         // ltc is next touched two barriers from here.
         const volatile HpkStencilArgs* ka = (const volatile HpkStencilArgs*)(const void*)__builtin_amdgcn_kernarg_segment_ptr();
         const unsigned c = ltc[0];
-        const unsigned nu = (c + 255u) >> 8;
+        const unsigned nu = (c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT;
         if (nu != 0u) {
             unsigned off = 0u;
             if (lane == 0) off = atomicAdd(const_cast<unsigned*>(ka->nunits), nu);
@@ -923,7 +923,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
         const int cnt = (int)(un.y >> 8);
         const int rb = tile / a.J, cj = tile - rb * a.J;
         const int r0 = rb * a.TR, c0 = r0 + a.mw + cj * a.TC;
-        const int iend = (ub * 256 + 256 < cnt) ? ub * 256 + 256 : cnt;
+        const int iend = (ub * HPK_UNIT + HPK_UNIT < cnt) ? ub * HPK_UNIT + HPK_UNIT : cnt;
         // Dependent rounds of loads per batch: (1) entry + first slot's step and sums - requested one batch ahead (idle
         // lanes read the tile's first record: always allocated, never used), (2) IR, biases and the local-expected
         // table entries, all addressed from the entry, (3) the Poisson table.
@@ -934,11 +934,11 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
         const uint8_t* __restrict__ recW_t = a.rec_W + tbase0;
         const double2* __restrict__ recS_t = a.rec_S + tbase0;
         const int64_t sl0 = slot0 * a.rec_stride;
-        unsigned ri_b = (ub * 256 + lane < cnt) ? (unsigned)(ub * 256 + lane) : 0u;
+        unsigned ri_b = (ub * HPK_UNIT + lane < cnt) ? (unsigned)(ub * HPK_UNIT + lane) : 0u;
         unsigned ent_b = ent_t[ri_b];
         int stp_b = (int)(recW_t + sl0)[ri_b];
         double2 s2_b = (recS_t + sl0)[ri_b];
-        for (int i0 = ub * 256; i0 < iend; i0 += 64) {
+        for (int i0 = ub * HPK_UNIT; i0 < iend; i0 += 64) {
             const bool cand = i0 + lane < cnt;
             const unsigned ri = ri_b;
             unsigned ent = ent_b;
