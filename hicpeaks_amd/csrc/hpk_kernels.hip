@@ -917,8 +917,10 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     const unsigned nunits = *a.nunits;                      // work list appended by hpk_stencil: non-empty units only
     const unsigned gw = (unsigned)((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const unsigned nwv = (unsigned)(((int64_t)gridDim.x * blockDim.x) >> 6);
+    uint2 un_next = (gw < nunits) ? a.units[gw] : make_uint2(0u, 0u);
     for (unsigned u = gw; u < nunits; u += nwv) {
-        const uint2 un = a.units[u];
+        const uint2 un = un_next;
+        if (u + nwv < nunits) un_next = a.units[u + nwv];       // the next unit's entry is on its way
         const int tile = (int)un.x, ub = (int)(un.y & 255u);
         const int cnt = (int)(un.y >> 8);
         const int rb = tile / a.J, cj = tile - rb * a.J;
