@@ -1,12 +1,16 @@
 // HIP kernels for gfx950 (MI355X / CDNA4).  Wave = 64 lanes; one stencil workgroup owns the LDS of a CU
 // (152 of 160 KiB).
 //
-//   hpk_stencil   donut (K) + lower-left (Y) local sums and adaptive widening   callers.py:132-232, 440-513
-//   hpk_freeze    frozen_w / break decision from the resolve histogram            callers.py:208-229, 505-511
-//   hpk_score     corrected expected -> lambda chunk -> Poisson p -> survivors    callers.py:238-271, 517-540
-//   hpk_gap       zero rows of the balanced band                                  callers.py:238, 557
-//   hpk_ptab      Poisson survival table for the chunk bounds                     callers.py:268-270
-//   hpk_brute     independent explicit-window check (tests)
+//   hpk_ir_partial / hpk_ir_final   1-D expected IR[d] and biases from raw + weights   scripts/pyHICCUPS:149-166
+//   hpk_etab_edge   local-expected tables (interior + clipped windows), zero-fill duty     callers.py:66-72, 175-198
+//   hpk_stencil     donut (K) + lower-left (Y) local sums, adaptive widening, gap rows,    callers.py:132-232, 440-513,
+//                   scoring work list                                                      238
+//   hpk_freeze      frozen_w / break decision from the resolve histogram                   callers.py:208-229, 505-511
+//   hpk_score       corrected expected -> lambda chunk -> Poisson p -> survivors           callers.py:238-271, 517-540
+//   hpk_thr_count / hpk_thr_compact   Benjamini-Hochberg cut on the survivor list          callers.py:273-279, 545-553
+//   hpk_publish     result head -> mapped pinned host memory
+//   hpk_ptab        Poisson survival table for the chunk bounds                            callers.py:268-270
+//   hpk_gap, hpk_brute, hpk_dense, hpk_poisson_sf_k   independent checks / dense debug outputs (tests)
 //
 // Stencil design.  The tile is built in true matrix coordinates (r, c): an output tile of TR x TC pixels
 // plus a halo of maxww (+1 row/column for the prefix origin) is read from band storage - rows are
