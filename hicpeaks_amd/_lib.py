@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libhpk.so')
+LIB_PATH = os.environ.get('HPK_LIB') or os.path.join(HERE, 'libhpk.so')      # HPK_LIB: profiling builds (scripts/)
 CSRC = os.path.join(HERE, 'csrc')
 
 HPK_MAX_PAIRS = 8
@@ -39,6 +39,10 @@ class HpkError(RuntimeError):
     def __init__(self, status, msg):
         RuntimeError.__init__(self, 'libhpk status %d: %s' % (status, msg))
         self.status = status
+        self.msg = msg
+
+    def __reduce__(self):       # picklable: a Pool worker that raises must not hang the parent's result handler
+        return (type(self), (self.status, self.msg))
 
 
 class EmptyStepError(HpkError, ValueError, ZeroDivisionError):
@@ -146,7 +150,13 @@ def make_params(mode, pw, ww, maxww, sig, maxapart, res, min_local_reads=16, fla
     pw = [int(v) for v in (pw if np.ndim(pw) else [pw])]
     ww = [int(v) for v in (ww if np.ndim(ww) else [ww])]
     if len(pw) != len(ww):
-        npairs = min(len(pw), len(ww))      # zip(pw, ww) truncates (callers.py:18, 239)
+        # The reference zips the lists for the pairs (callers.py:18, 239) but takes min(ww) / min(pw) over the full
+        # lists (callers.py:58, 102, 197, 294); the two readings differ when the surplus entries hold the minimum.
+        # Rather than guess, refuse what cannot be reproduced.
+        npairs = min(len(pw), len(ww))
+        if npairs and (min(ww) != min(ww[:npairs]) or min(pw) != min(pw[:npairs])):
+            raise HpkError(ERR_INVALID, 'pw and ww have different lengths and the unpaired entries hold the minimum '
+                           '(pw=%r, ww=%r): not supported' % (pw, ww))
         pw, ww = pw[:npairs], ww[:npairs]
     if not pw:
         raise ValueError('pw / ww are empty')

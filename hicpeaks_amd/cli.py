@@ -58,10 +58,10 @@ def _hiccups_parser():
     g2.add_argument('--clr-weight-name', default='weight', help='Name of the weight column.')
     g2.add_argument('--use-raw', action='store_true', help='Sort peak pixels by raw signals during local clustering.')
     g2.add_argument('--min-marginal-peaks', type=int, default=2, help='Minimum marginal number of peaks of an anchor.')
-    g2.add_argument('--min-local-reads', type=int, default=16, help='Minimum sum of contacts in the vicinity of a loop.')
+    g2.add_argument('--min-local-reads', type=int, default=16, help='Minimum sum of contacts in the vicinity of a loop (at most 1023).')
     g2.add_argument('--only-anchors', action='store_true', help='Either of the peak loci must be an anchor.')
     g2.add_argument('--maxapart', type=int, default=10000000, help='Maximum genomic distance between two loci.')
-    g2.add_argument('--nproc', type=int, default=1, help='Number of worker processes (one per GPU).')
+    g2.add_argument('--nproc', type=int, default=1, help='Number of worker processes (one per GPU; clamped to the GPUs present).')
     g2.add_argument('--device', type=int, default=None, help='GPU ordinal (default: local rank / worker index).')
     return p
 
@@ -85,7 +85,7 @@ def _bhfdr_parser():
     g2.add_argument('--siglevel', type=float, default=0.05, help='Significant Level.')
     g2.add_argument('--maxapart', type=int, default=2000000, help='Maximum genomic distance between two loci.')
     g2.add_argument('--clr-weight-name', default='weight', help='Name of the weight column.')
-    g2.add_argument('--nproc', type=int, default=1, help='Number of worker processes (one per GPU).')
+    g2.add_argument('--nproc', type=int, default=1, help='Number of worker processes (one per GPU; clamped to the GPUs present).')
     g2.add_argument('--device', type=int, default=None, help='GPU ordinal.')
     return p
 
@@ -162,6 +162,27 @@ def _score_chroms(args_dict, mode, keys, device):
     return out
 
 
+def _gpu_count():
+    """Visible GPUs (no torch needed: the ROCm runtime answers through libhpk's own dependency)."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL('libamdhip64.so')
+        n = ctypes.c_int(0)
+        return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+    except OSError:
+        return 0
+
+
+def worker_devices(nproc, device, ngpus):
+    """The reference's --nproc counts CPU processes (scripts/pyHICCUPS:192-198); here a worker needs a GPU.  With
+    --device every chromosome goes to that one GPU (one worker: a second process on the same GPU only time-slices);
+    otherwise min(nproc, GPUs) workers, worker w on GPU w.  -> (workers, [device per worker])"""
+    if device is not None:
+        return 1, [device]
+    n = max(1, min(nproc, ngpus)) if ngpus > 0 else nproc      # no GPU visible: let hpk_create report it
+    return n, list(range(n))
+
+
 def _pool_worker(job):
     args_dict, mode, keys, device = job
     return _score_chroms(args_dict, mode, keys, device)
@@ -197,16 +218,20 @@ def _run(mode, argv):
         if rank != 0:
             return 0
         results = [(k.lstrip('chr'), tables[k]) for k in keys]
-    elif args.nproc > 1:                             # Pool.map over GPU workers (scripts/pyHICCUPS:195-198)
-        import multiprocessing as mp
-        parts = parallel.lpt_partition(sizes, args.nproc)
-        jobs = [(a, mode, part, (w if args.device is None else args.device)) for w, part in enumerate(parts)]
-        with mp.get_context('spawn').Pool(args.nproc) as pool:
-            done = dict(kv for part in pool.map(_pool_worker, jobs) for kv in part)
-        results = [(k.lstrip('chr'), done[k.lstrip('chr')]) for k in keys]
     else:
-        dev = 0 if args.device is None else args.device
-        results = _score_chroms(a, mode, keys, dev)
+        # Pool.map over GPU workers (scripts/pyHICCUPS:192-198); one worker runs in this process
+        nworkers, devices = worker_devices(args.nproc, args.device, _gpu_count() if args.nproc > 1 else 0)
+        if args.nproc > 1:
+            logger.info('--nproc {0}: {1} worker(s) on GPU(s) {2}'.format(args.nproc, nworkers, devices))
+        if nworkers > 1:
+            import multiprocessing as mp
+            parts = parallel.lpt_partition(sizes, nworkers)
+            jobs = [(a, mode, part, devices[w]) for w, part in enumerate(parts)]
+            with mp.get_context('spawn').Pool(nworkers) as pool:
+                done = dict(kv for part in pool.map(_pool_worker, jobs) for kv in part)
+            results = [(k.lstrip('chr'), done[k.lstrip('chr')]) for k in keys]
+        else:
+            results = _score_chroms(a, mode, keys, devices[0] if args.device is not None else 0)
     with open(args.output, 'w') as out:
         for key, table in results:
             out.write(format_hiccups(key, table, res) if mode == 'hiccups' else format_bhfdr(key, table, res))

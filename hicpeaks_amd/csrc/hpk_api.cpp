@@ -488,7 +488,10 @@ int launch_scoring(hpk_ctx* c, hpk_job* j, int attempt) {
     }
     if (j->phases) (void)hipEventRecord(L.ev[5], c->stream);
     // gap rows are produced by the stencil kernel (hpk_gap remains as an independent check for the tests)
-    if (attempt == 0 && std::getenv("HPK_GAP_KERNEL")) {
+    // ... as long as the band stops where the command lines stop it (num = D + maxww + 1, scripts/pyHICCUPS:146): the
+    // tiles see the diagonals up to about D + maxww.  A caller of the drop-in hiccups() / bhfdr() may hand over more
+    // diagonals, and callers.py:238 sums all of them: then the row kernel, which reads every stored diagonal, decides.
+    if (attempt == 0 && (std::getenv("HPK_GAP_KERNEL") || j->num > plan.D + plan.W + 1)) {
         hpk_launch_gap(j->in.raw, j->in.bal, j->in.weight, j->n, j->num, j->ld, plan.mw, small + j->off_rowlive, c->stream);
         HIPCHK(c, hipGetLastError());
     }
@@ -616,6 +619,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     sa.ntiles = ntiles_;
     sa.chunk = (sa.ntiles + 7) / 8;
     { const char* e = std::getenv("HPK_DBG_STOP"); sa.dbg_stop = e ? std::atoi(e) : 0; }
+    { const char* e = std::getenv("HPK_TILE_ORDER"); sa.order = e ? std::atoi(e) : 1; }
     sa.grid = std::max(8, std::min((c->cus / 8) * 8, ((sa.chunk + 0) * 8)));
     sa.hist_part = reinterpret_cast<unsigned*>(small + off_hp);
     sa.tilecap = TR * TC;
@@ -632,6 +636,14 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
         sa.nunits = reinterpret_cast<unsigned*>(small + OFF_NUNITS);
     }
     sa.gap = small + off_rowlive;
+    sa.clk = nullptr;
+#ifdef HPK_PHASE_CLOCK
+    if (std::getenv("HPK_CLK_DUMP")) {
+        HIPCHK(c, c->tmpD.reserve(sizeof(unsigned long long) * 8 * HPK_NWAVES * 1024));
+        HIPCHK(c, hipMemsetAsync(c->tmpD.p, 0, sizeof(unsigned long long) * 8 * HPK_NWAVES * 1024, c->stream));
+        sa.clk = c->tmpD.as<unsigned long long>();
+    }
+#endif
     (void)hipEventRecord(L.ev[1], c->stream);
     hpk_launch_stencil(sa, in.bal != nullptr, plan.simple_reads != 0 && !std::getenv("HPK_GENERIC_SEARCH"), c->stream);
     HIPCHK(c, hipGetLastError());
@@ -667,6 +679,13 @@ int collect_impl(hpk_ctx* c, hpk_job* j, hpk_result** out) {
         int rc = launch_scoring(c, j, 1);
         if (rc != HPK_OK) return rc;
     }
+#ifdef HPK_PHASE_CLOCK
+    if (const char* path = std::getenv("HPK_CLK_DUMP")) {       // [grid][waves][8] u64, overwritten by every chromosome
+        std::vector<unsigned long long> h((size_t)8 * HPK_NWAVES * sa.grid);
+        HIPCHK(c, hipMemcpy(h.data(), c->tmpD.p, h.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
+    }
+#endif
     box->gap.resize(n);
     for (int r = 0; r < n; ++r) box->gap[r] = hsmall[off_rowlive + r] ? 0 : 1;
     R.band_px = j->band_px;

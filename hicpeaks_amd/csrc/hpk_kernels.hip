@@ -203,8 +203,27 @@ __device__ __forceinline__ void tile_load(const HpkStencilArgs& a, const float* 
 __device__ __forceinline__ int tile_of(const HpkStencilArgs& a, int it) {
     const int xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3), per = (int)(gridDim.x >> 3);
     const int k = j + it * per;
-    return (k < a.chunk && xcd * a.chunk + k < a.ntiles) ? xcd * a.chunk + k : -1;
+    if (!(k < a.chunk && xcd * a.chunk + k < a.ntiles)) return -1;
+    const int t = xcd * a.chunk + k;
+    if (a.order == 0) return t;
+    // Column chunk 0 holds the near-diagonal pixels (every one a candidate), the last chunks almost none: with the
+    // plain order a workgroup's stride (32) visits only every other column class and half of the workgroups get all
+    // the dense tiles.  Rotating the column chunk by the row block gives every workgroup every class in turn.
+    const int rb = t / a.J, c = t - rb * a.J;
+    int cj = c + rb % a.J;
+    if (cj >= a.J) cj -= a.J;
+    return rb * a.J + cj;
 }
+
+// Per-phase cycle accounting (-DHPK_PHASE_CLOCK builds only; scripts/gpu_phase_clock.sh): every wave sums s_memtime
+// deltas per phase of the tile loop and leaves them in a.clk[(workgroup * NW + wave) * 8 + phase].
+#ifdef HPK_PHASE_CLOCK
+#define HPK_CLK_DECL unsigned long long ck0 = 0, ck1 = 0, ck2 = 0, ck3 = 0, ck4 = 0, ck5 = 0, ck6 = 0, ck7 = 0, ckt = __builtin_readcyclecounter();
+#define HPK_CLK(v) { const unsigned long long t__ = __builtin_readcyclecounter(); v += t__ - ckt; ckt = t__; }
+#else
+#define HPK_CLK_DECL
+#define HPK_CLK(v)
+#endif
 
 template <int NW, bool BALF64, bool SIMPLE>
 __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const float* __restrict__ g_raw,
@@ -262,6 +281,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
 
     // ---- persistent tile loop with register prefetch: while tile `cur` is evaluated out of LDS, the band rows of
     // the next tile are already on their way into `nxt` (the evaluation itself issues no loads).
+    HPK_CLK_DECL
     TileRegs<RPW, BALF64> nxt;
     int tid = tile_of(a, 0);
     if (tid >= 0) tile_load<RPW, BALF64>(a, g_raw, g_bal, g_w, tid, wave, lane, nxt);
@@ -301,6 +321,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
             tp[e] += pkv[j][e];
         }
     }
+    HPK_CLK(ck0)
     // the prefetch registers are free again: the next tile's rows start moving now, beside this tile's SAT build and
     // candidate work (nothing below waits for them)
     if (tid_next >= 0) tile_load<RPW, BALF64>(a, g_raw, g_bal, g_w, tid_next, wave, lane, nxt);
@@ -321,6 +342,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
         ac[0] += t.x; ac[1] += t.y; ar[0] += u.x; ar[1] += u.y;
     }
     __syncthreads();
+    HPK_CLK(ck1)
     {   // prefix of the segment base along the row
         double pc = ac[0] + ac[1]; unsigned pr = ar[0] + ar[1];
         const double l1c = pc; const unsigned l1r = pr;
@@ -342,7 +364,9 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
         *reinterpret_cast<double2*>(&S.c[o]) = make_double2(ac[0], ac[1]);
         *reinterpret_cast<uint2*>(&S.p[o]) = make_uint2(ar[0], ar[1]);
     }
+    HPK_CLK(ck2)
     __syncthreads();
+    HPK_CLK(ck3)
     if (a.dbg_stop == 2) {
         if (S.c[threadIdx.x] == -1.0) a.hist[0] = 1ull;
         __syncthreads();
@@ -406,6 +430,10 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
     if (lane == 0) mycand += (unsigned)cnt;
 
     const int nbatch = (cnt + 63) >> 6;
+    HPK_CLK(ck4)
+#ifdef HPK_PHASE_CLOCK
+    ck7 += (unsigned long long)nbatch;
+#endif
 #pragma unroll 1
     for (int kb = 0; kb < nbatch; ++kb) {
         const bool cand = kb * 64 + lane < cnt;
@@ -552,7 +580,9 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
             }
         }
     }
+    HPK_CLK(ck5)
     __syncthreads();                 // every wave is done with this tile's SAT
+    HPK_CLK(ck6)
     if (wave == 0) {
         // The tile's records become work for the scoring kernel: one entry per 256 records, appended to the global
         // list with one atomic per tile (tiles finish at ~15-25 per microsecond, well under the same-address rate).
@@ -574,6 +604,12 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
     // Resolve histogram: 40k same-address atomics (one per wave and tile) serialise at ~90 per microsecond in L2 -
     // 0.46 ms, several times the kernel itself.  Instead the waves of the workgroup meet in LDS (the SAT is dead now)
     // and the workgroup writes its partial counts with plain stores; hpk_freeze sums the partials.
+#ifdef HPK_PHASE_CLOCK
+    if (a.clk && lane == 0) {
+        unsigned long long* o = a.clk + ((size_t)blockIdx.x * NW + wave) * 8;
+        o[0] = ck0; o[1] = ck1; o[2] = ck2; o[3] = ck3; o[4] = ck4; o[5] = ck5; o[6] = ck6; o[7] = ck7;
+    }
+#endif
     unsigned* red = reinterpret_cast<unsigned*>(smem);
     red[wave * (HPK_MAX_STEPS + 1) + lane] = myhist;
     if (lane == 0) red[wave * (HPK_MAX_STEPS + 1) + HPK_MAX_STEPS] = mycand;

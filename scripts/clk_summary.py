@@ -1,0 +1,21 @@
+#!/usr/bin/env python
+"""Summarise a phase-clock dump of hpk_stencil (libhpk built with -DHPK_PHASE_CLOCK, HPK_CLK_DUMP=<file>):
+u64 [workgroups][16 waves][8] = cycles in (0) wait for the prefetched rows + phase 1, (1) prefetch issue + column
+totals + two barriers, (2) scans + SAT stores, (3) barrier, (4) gap rows + candidate lists, (5) candidate batches,
+(6) end-of-tile barrier, and (7) the number of batches.  s_memtime ticks at 100 MHz on gfx950."""
+import sys
+import numpy as np
+a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 16, 8).astype(np.float64)
+names = ['wait+phase1', 'prefetch+coltot', 'scan+write', 'barrier(SAT)', 'gap+lists', 'batches', 'barrier(end)']
+tot = a[:, :, :7].sum(axis=2)
+print('workgroups %d; ticks per wave: mean %.0f  min %.0f  max %.0f' % (a.shape[0], tot.mean(), tot.min(), tot.max()))
+for i, nm in enumerate(names):
+    v = a[:, :, i]
+    print('%-16s mean %8.0f (%4.1f%%)   per-WG mean min %8.0f max %8.0f' % (nm, v.mean(), 100 * v.mean() / tot.mean(),
+                                                                         v.mean(axis=1).min(), v.mean(axis=1).max()))
+nb = a[:, :, 7]
+print('batches per wave: mean %.1f; per-WG sum min %d max %d mean %.0f' % (nb.mean(), nb.sum(axis=1).min(), nb.sum(axis=1).max(),
+                                                                          nb.sum(axis=1).mean()))
+wg = a[:, :, 5].mean(axis=1)
+print('batch-phase ticks per WG, deciles:', np.percentile(wg, [0, 10, 25, 50, 75, 90, 100]).round(0).tolist())
+print('ticks per batch (sum batches-phase / sum batches): %.1f' % (a[:, :, 5].sum() / max(nb.sum(), 1)))
