@@ -32,7 +32,7 @@ ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_EMPTY_STEP, ERR_PLAN, ERR_NOMEM, ERR_BU
 ABI_SYMBOLS = ['hpk_create', 'hpk_destroy', 'hpk_last_error', 'hpk_abi_version', 'hpk_score_band',
                'hpk_pipeline_depth', 'hpk_submit_band', 'hpk_collect',
                'hpk_result_free', 'hpk_plan_rings', 'hpk_chunk_bounds', 'hpk_set_chunk_bounds',
-               'hpk_device_info', 'hpk_poisson_sf', 'hpk_bruteforce_sums']
+               'hpk_device_info', 'hpk_poisson_sf', 'hpk_bruteforce_sums', 'hpk_probe_sums']
 
 
 class HpkError(RuntimeError):
@@ -142,6 +142,9 @@ def load():
     lib.hpk_bruteforce_sums.argtypes = [C.c_void_p, C.POINTER(Band), C.POINTER(Params), C.c_int32, C.c_void_p,
                                         C.c_void_p, C.c_int64, C.c_void_p]
     lib.hpk_bruteforce_sums.restype = C.c_int
+    lib.hpk_probe_sums.argtypes = [C.c_void_p, C.POINTER(Band), C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_int64,
+                                   C.c_void_p]
+    lib.hpk_probe_sums.restype = C.c_int
     _lib = lib
     return lib
 
@@ -389,6 +392,26 @@ class Context(object):
         cols = np.ascontiguousarray(cols, dtype=np.int32)
         out = np.empty((rows.size, 5), dtype=np.float64)
         self._check(self.lib.hpk_bruteforce_sums(self.h, C.byref(bd), C.byref(params), int(step), rows.ctypes.data,
+                                                 cols.ctypes.data, rows.size, out.ctypes.data))
+        return out
+
+
+    def probe_sums(self, band, params, rows, cols, nslots):
+        """(bS_K, bE_K, bS_Y, bE_Y, width) per pixel and slot from the production kernels' records; `band` from
+        `_band` / `_host_band`.  -> [count, nslots, 5]"""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        out = np.empty((rows.size, nslots, 5), dtype=np.float64)
+        self._check(self.lib.hpk_probe_sums(self.h, C.byref(band), C.byref(params), rows.ctypes.data, cols.ctypes.data,
+                                            rows.size, out.ctypes.data))
+        return out
+
+    def bruteforce_band(self, band, params, step, rows, cols):
+        """`bruteforce_sums` on a prepared band (device pointers allowed)."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        out = np.empty((rows.size, 5), dtype=np.float64)
+        self._check(self.lib.hpk_bruteforce_sums(self.h, C.byref(band), C.byref(params), int(step), rows.ctypes.data,
                                                  cols.ctypes.data, rows.size, out.ctypes.data))
         return out
 

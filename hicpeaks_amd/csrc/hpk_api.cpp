@@ -921,6 +921,45 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     return hpk_collect(c, job, out);
 }
 
+int hpk_probe_sums(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, const int32_t* rows, const int32_t* cols,
+                   int64_t count, double* out) {
+    if (!c) return HPK_ERR_INVALID;
+    if (!prm || !rows || !cols || !out || count < 0) return fail(c, HPK_ERR_INVALID, "bad arguments");
+    hpk_params p2 = *prm;
+    p2.flags = HPK_FLAG_NO_SCORE;               // stencil + freeze only; the records stay in the lane's workspaces
+    hpk_job* job = nullptr;
+    int rc = hpk_submit_band(c, band, &p2, &job);
+    if (rc != HPK_OK) return rc;
+    Lane& L = c->lane[job->lane];
+    const HpkStencilArgs& sa = job->sa;
+    const HpkDevPlan& plan = L.plan_host;
+    auto run = [&]() -> int {
+        if (count == 0) return HPK_OK;
+        HIPCHK(c, c->tmpA.reserve(4 * (size_t)count));
+        HIPCHK(c, c->tmpB.reserve(4 * (size_t)count));
+        HIPCHK(c, c->tmpC.reserve(8 * 5 * (size_t)count * plan.nslots));
+        HIPCHK(c, hipMemcpyAsync(c->tmpA.p, rows, 4 * (size_t)count, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->tmpB.p, cols, 4 * (size_t)count, hipMemcpyHostToDevice, c->stream));
+        HpkDenseArgs da;
+        std::memset(&da, 0, sizeof(da));
+        da.rec_ent = sa.rec_ent; da.rec_S = sa.rec_S; da.rec_W = sa.rec_W; da.tile_cnt = sa.tile_cnt;
+        da.tilecap = sa.tilecap; da.rec_stride = sa.rec_stride; da.ntiles = sa.ntiles; da.TR = job->TR; da.TC = job->TC; da.J = sa.J;
+        da.plan = sa.plan; da.etab = L.etab.as<double>(); da.eedge = L.eedge.as<double>();
+        da.IR = job->in.IR; da.b1 = job->in.b1; da.b2 = job->in.b2; da.n = job->n; da.num = job->num; da.ldo = job->ldo;
+        da.mw = plan.mw; da.D = plan.D;
+        hpk_launch_probe(da, c->tmpA.as<int32_t>(), c->tmpB.as<int32_t>(), count, c->tmpC.as<double>(), c->stream);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(out, c->tmpC.p, 8 * 5 * (size_t)count * plan.nslots, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return HPK_OK;
+    };
+    rc = run();
+    const std::string keep = c->err;
+    (void)hpk_collect(c, job, nullptr);          // gives the lane back (an "empty step" verdict is not this call's business)
+    if (rc != HPK_OK) c->err = keep;
+    return rc;
+}
+
 int hpk_bruteforce_sums(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, int32_t step, const int32_t* rows,
                         const int32_t* cols, int64_t count, double* out) {
     if (!c) return HPK_ERR_INVALID;

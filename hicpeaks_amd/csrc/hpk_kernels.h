@@ -127,6 +127,7 @@ struct HpkBruteArgs {
 int  hpk_stencil_lds_bytes();
 void hpk_launch_stencil(const HpkStencilArgs& a, bool balf64, bool simple, hipStream_t st);
 void hpk_launch_dense(const HpkDenseArgs& a, hipStream_t st);
+void hpk_launch_probe(const HpkDenseArgs& a, const int32_t* rows, const int32_t* cols, int64_t count, double* out, hipStream_t st);
 void hpk_launch_freeze(const HpkDevPlan* plan, unsigned long long* hist, const unsigned* hist_part, int nparts,
                        int32_t* frozen, int32_t* executed, int32_t* err, hipStream_t st);
 void hpk_launch_prep(const float* raw, const double* weight, int n, int num, int64_t ld, int mw, double* psum, unsigned* pnan,

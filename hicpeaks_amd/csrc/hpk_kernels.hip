@@ -621,6 +621,499 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
     }
 }
 
+// ------------------------------------------------------------------ stencil for "simple Reads" plans
+// Second-generation stencil kernel (same tile geometry, SAT planes and record output as hpk_stencil above, which
+// stays for plans whose Reads matrix is not monotone in the width).  What the phase clocks of the first kernel showed
+// (profiles/r02_phase_clock.txt) and what is different here:
+//   * the band rows of the next tile were fetched by five *serialised* scalar weight loads and ten branch-wrapped
+//     loads, a quarter of the kernel: here every prefetch load is a bounds-checked buffer load (out-of-range cells
+//     return 0: no branches), the row weights arrive in one vector load and are handed out with v_readlane;
+//   * the candidate lists were built after the SAT from four LDS reads per pixel, one dependent round trip per half
+//     row: here they come out of the registers of phase 1 (ballot + mbcnt), into ONE tile-wide list whose batches are
+//     dealt round-robin to the sixteen waves (no idle waves on tiles whose candidates sit in a few rows);
+//   * the column totals of the waves above were summed by a serial loop of up to fifteen dependent LDS reads: here
+//     the sixteen waves form all prefixes in parallel (eight columns per wave, four shuffle steps);
+//   * a batch of 64 candidates went through ~12 dependent LDS round trips: here the Reads boxes of all widths are
+//     read together, the box terms two at a time, and the resolve histogram is kept per *width* with one ballot per
+//     width (converted to steps once per workgroup at the end);
+//   * the scoring work list was appended with a returning global atomic that the tile's first wave waited for before
+//     the next tile could pass its first barrier: here the append of tile i is finished while tile i + 1 ends.
+#define HPK_SLIST 8000                      // tile-wide candidate list: TR * TC <= 64 * 125 entries
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+constexpr unsigned OOB_OFF = 0x7ffffff0u;   // beyond every buffer's num_records (all < 2^31): the load returns 0
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float ldbuf_f32(rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ double ldbuf_f64(rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0));
+}
+
+template <bool BALF64>
+struct TileRegsS {
+    float raw[5][2];
+    double bal[BALF64 ? 5 : 1][2];      // f64 input mode: balanced values as given
+    double wc[2];                       // weight mode: column weights of the lane's two cells
+    double wrow;                        // weight mode: lane j (j < 5) holds the weight of the wave's row j
+};
+
+template <bool BALF64>
+__device__ __forceinline__ void tile_load_s(const HpkStencilArgs& a, int tid, int wave, int lane, TileRegsS<BALF64>& t) {
+    const int rb = tid / a.J, cj = tid - rb * a.J;
+    const int r0 = rb * a.TR;
+    const int c0 = r0 + a.mw + cj * a.TC;
+    const int rt0 = r0 - a.W - 1;                          // matrix row of SAT row 0 (negative in the first row block)
+    const int rb0 = rt0 > 0 ? rt0 : 0;                     // the buffer of this tile starts at this matrix row
+    int rows = a.n - rb0;
+    rows = rows > 96 ? 96 : rows;                          // rows at or beyond n fall outside the buffer: they read 0
+    const int rr0 = rt0 + wave * 5;
+    const int cc0 = c0 - a.W - 1 + 2 * lane;
+    const int kb = cc0 - rr0;                              // diagonal of cell (row 0 of the wave, e = 0)
+    const unsigned ldu = (unsigned)a.ld;
+    // byte offset of cell (j = 0, e = 0) in the tile's buffer; negative rows wrap to offsets >= 2^31: out of range
+    const unsigned voff0 = ((unsigned)(rr0 - rb0) * ldu + (unsigned)kb) * 4u;
+    const unsigned rstep = (ldu - 1u) * 4u;                // one row down, same column: one diagonal less
+    const rsrc_t rraw = make_rsrc(a.raw + (int64_t)rb0 * a.ld, (unsigned)rows * ldu * 4u);
+    bool cok[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) cok[e] = (unsigned)(cc0 + e) < (unsigned)a.n;
+    if (!BALF64) {
+        const rsrc_t rw = make_rsrc(a.weight, (unsigned)a.n * 8u);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) t.wc[e] = ldbuf_f64(rw, (unsigned)(cc0 + e) * 8u);    // columns < 0 or >= n read 0
+        t.wrow = ldbuf_f64(rw, (unsigned)(rr0 + (lane & 7)) * 8u);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const bool ok = cok[e] && (unsigned)(kb + e - j) < (unsigned)a.num;
+                t.raw[j][e] = ldbuf_f32(rraw, ok ? voff0 + (unsigned)e * 4u + (unsigned)j * rstep : OOB_OFF);
+            }
+        }
+    } else {
+        const rsrc_t rbal = make_rsrc(a.bal + (int64_t)rb0 * a.ld, (unsigned)rows * ldu * 8u);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = kb + e - j;
+                const bool ok = cok[e] && (unsigned)k < (unsigned)a.num;
+                const unsigned off = voff0 + (unsigned)e * 4u + (unsigned)j * rstep;
+                t.raw[j][e] = ldbuf_f32(rraw, ok ? off : OOB_OFF);
+                t.bal[j][e] = ldbuf_f64(rbal, (ok && k >= a.mw) ? off * 2u : OOB_OFF);
+            }
+        }
+    }
+}
+
+// Explicit window sums of one pixel at one step (rare path of both stencil kernels): taken when the summed-area table
+// cannot deliver ~1e-11 - the box sum is a difference of f64 prefix sums, so its absolute error is that of the
+// largest corner; a window of small values in a tile that also holds values thousands of times larger (a badly
+// balanced bin, a count outlier) would come out with the large values' rounding noise.  The reference adds the
+// window cells themselves (callers.py:175-198) and has no such failure mode.
+__device__ __noinline__ double2 explicit_sums(const float* __restrict__ raw, const double* __restrict__ bal,
+                                              const double* __restrict__ weight, const int32_t* __restrict__ m, int W, int r, int c,
+                                              int n, int num, int64_t ld, int mw) {
+    double sk = 0.0, sy = 0.0;
+    for (int di = -W; di <= W; ++di) {
+        const int rr = r + di;
+        if (di == 0 || rr < 0 || rr >= n) continue;
+        const double wr = weight ? weight[rr] : 0.0;
+        for (int dj = -W; dj <= W; ++dj) {
+            if (dj == 0) continue;
+            const int adi = di < 0 ? -di : di, adj = dj < 0 ? -dj : dj;
+            const int mm = m[adi > adj ? adi : adj];
+            const int cc = c + dj, kk = cc - rr;
+            if (mm == 0 || cc < 0 || cc >= n || kk < mw || kk >= num) continue;
+            double b;
+            if (bal) { b = bal[(int64_t)rr * ld + kk]; b = (b == b) ? b : 0.0; }
+            else b = balanced_of(raw[(int64_t)rr * ld + kk], wr, weight[cc]);
+            const double v = (double)mm * b;
+            sk += v;
+            if (di > 0 && dj < 0) sy += v;
+        }
+    }
+    return make_double2(sk, sy);
+}
+
+template <bool BALF64>
+__global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
+    constexpr int NW = 16, RPW = 5;
+    static_assert(LR == NW * RPW && LC == 128, "tile geometry of the simple-plan kernel");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* __restrict__ Sc = reinterpret_cast<double*>(smem);
+    unsigned* __restrict__ Sp = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 8);
+    unsigned* __restrict__ lst = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 12);
+    unsigned* __restrict__ wcnt = lst + HPK_SLIST;          // [16] candidates of each wave's rows in the current tile
+    // the widening plan as the batches read it: per step 8 words {w0 (HpkDevPlan::packed[0]), four words of box terms},
+    // then step_of[slot][width] as bytes and the slots' first widths
+    unsigned* __restrict__ pl = wcnt + 64;                    // [HPK_MAX_STEPS][8]
+    unsigned char* __restrict__ stepof = reinterpret_cast<unsigned char*>(pl + HPK_MAX_STEPS * 8);   // [HPK_KSLOTS][32]
+
+    const int lane_k = threadIdx.x & 63;
+    const int wave_k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = lane_k, wave = wave_k;
+    const int W = a.W, n = a.n, mw = a.mw, TR = a.TR, TC = a.TC;
+    const int Dm = a.D < a.num - 1 ? a.D : a.num - 1;      // last diagonal that holds band pixels
+
+    // ---- plan in registers: lane s holds step s
+    const HpkDevPlan* __restrict__ plan = a.plan;
+    const int nsteps = plan->nsteps, nslots = plan->nslots;
+    int maxnkt = 0;
+    {
+        int pk0 = 0;
+        if (lane < nsteps) pk0 = (int)plan->packed[lane][0];
+        if (wave == 0) {
+            if (lane < nsteps) {
+                const uint32_t* pk = plan->packed[lane];
+                pl[lane * 8 + 0] = pk[0]; pl[lane * 8 + 1] = pk[3]; pl[lane * 8 + 2] = pk[4]; pl[lane * 8 + 3] = pk[5];
+                pl[lane * 8 + 4] = pk[6];
+            }
+            stepof[lane] = plan->step_of[lane >> 5][lane & 31];
+            stepof[64 + lane] = plan->step_of[2 + (lane >> 5)][lane & 31];
+        }
+        for (int s = 0; s < nsteps; ++s) {
+            const int k = (__builtin_amdgcn_readlane(pk0, s) >> 20) & 15;
+            maxnkt = k > maxnkt ? k : maxnkt;
+        }
+    }
+    int wf_q[HPK_KSLOTS];
+#pragma unroll
+    for (int q = 0; q < HPK_KSLOTS; ++q) wf_q[q] = __builtin_amdgcn_readfirstlane(plan->slot_wfirst[q]);
+    const int nslots_p = __builtin_amdgcn_readfirstlane(nslots);
+    const int minr_p = __builtin_amdgcn_readfirstlane(plan->min_reads), p0_p = __builtin_amdgcn_readfirstlane(plan->reads_p0);
+    const int wmin_p = __builtin_amdgcn_readfirstlane(plan->wmin);
+    unsigned myhist = 0u;                 // lane w: candidates whose first sufficient width is w
+    unsigned mycand = 0u;
+    // scoring work list: the append of a tile is completed one tile later (the atomic's return is not waited for)
+    int pend_tid = -1;
+    unsigned pend_c = 0u, pend_off = 0u;
+
+    HPK_CLK_DECL
+    TileRegsS<BALF64> nxt;
+    int tid = tile_of(a, 0);
+    if (tid >= 0) tile_load_s<BALF64>(a, tid, wave, lane, nxt);
+#pragma unroll 1
+    for (int it = 0; tid >= 0; ++it) {
+    // Everything below that depends only on (wave, lane) is the same for every tile, and the compiler would hoist it
+    // out of the tile loop - ten list-entry templates, row flags, compare constants: 100+ SGPRs and a dozen VGPRs
+    // that then spill to scratch, whose reloads (vmcnt(0)) also wait for the prefetch.  Opaque copies keep it in here.
+    int wave = wave_k, lane = lane_k;
+    asm volatile("" : "+s"(wave));
+    asm volatile("" : "+v"(lane));
+    const int rb = tid / a.J, cj = tid - rb * a.J;
+    const int r0 = rb * TR;
+    const int c0 = r0 + mw + cj * TC;
+    const bool empty_tile = c0 >= n || (mw + cj * TC - (TR - 1)) > a.D;       // no band pixel inside the matrix
+    const int tid_next = tile_of(a, it + 1);
+    if (empty_tile) {
+        if (tid_next >= 0) tile_load_s<BALF64>(a, tid_next, wave, lane, nxt);
+        tid = tid_next;
+        continue;
+    }
+    // ---- phase 1: balanced values, packed cells, column totals of this wave's five rows; candidate masks
+    const int xx0 = 2 * lane;
+    const int kb = (c0 - W - 1 + xx0) - (r0 - W - 1 + wave * RPW);      // diagonal of cell (j = 0, e = 0)
+    const int xo = xx0 - (W + 1);                                       // output column of cell e = 0
+    double balv[RPW][2];
+    unsigned pkv[RPW][2];
+    double tc[2] = {0.0, 0.0};
+    unsigned tp[2] = {0u, 0u};
+    int cnt = 0;                                                        // candidates in this wave's rows (uniform)
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        double wr = 0.0;
+        if (!BALF64) wr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(nxt.wrow), j),
+                                           __builtin_amdgcn_readlane(__double2loint(nxt.wrow), j));
+        const int y = wave * RPW + j - (W + 1);
+        const bool rowout = (unsigned)y < (unsigned)TR && r0 + y < n;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float rv = nxt.raw[j][e];
+            const int k = kb + e - j;
+            double bv = 0.0;
+            if (BALF64) { bv = nxt.bal[j][e]; bv = (bv == bv) ? bv : 0.0; }
+            else if (k >= mw) bv = balanced_of(rv, wr, nxt.wc[e]);
+            balv[j][e] = bv;
+            pkv[j][e] = pack_cell((unsigned)rv, bv != 0.0);
+            tc[e] += bv;
+            tp[e] += pkv[j][e];
+            const bool cd = rowout && (pkv[j][e] & PK_MASK) != 0u && (unsigned)(xo + e) < (unsigned)TC && (unsigned)(k - mw) <= (unsigned)(Dm - mw);
+            cnt += __popcll(__ballot(cd));
+        }
+    }
+    HPK_CLK(ck0)
+    if (tid_next >= 0) tile_load_s<BALF64>(a, tid_next, wave, lane, nxt);
+    // column totals of this wave's rows -> LDS row 5 wave + 1 (inside the SAT rows this wave owns: nothing else lives there now)
+    *reinterpret_cast<double2*>(&Sc[(wave * RPW + 1) * LC + xx0]) = make_double2(tc[0], tc[1]);
+    *reinterpret_cast<uint2*>(&Sp[(wave * RPW + 1) * LC + xx0]) = make_uint2(tp[0], tp[1]);
+    if (lane == 0) wcnt[wave] = (unsigned)cnt;
+    __syncthreads();
+    HPK_CLK(ck1)
+    // ---- prefixes over the waves, all columns in parallel: this wave takes columns 8 wave .. 8 wave + 7, lane (g, c)
+    // the totals of waves 2g and 2g + 1; inclusive scan over g by shuffles, results to row 5 w of every wave w
+    {
+        const int c = lane & 7, g = lane >> 3, col = 8 * wave + c;
+        const double a0 = Sc[(10 * g + 1) * LC + col], a1 = Sc[(10 * g + 6) * LC + col];
+        const unsigned u0 = Sp[(10 * g + 1) * LC + col], u1 = Sp[(10 * g + 6) * LC + col];
+        double s = a0 + a1;
+        unsigned us = u0 + u1;
+#pragma unroll
+        for (int st = 1; st <= 4; st <<= 1) {
+            const double t = __shfl_up(s, 8 * st);
+            const unsigned ut = __shfl_up(us, 8 * st);
+            if (g >= st) { s += t; us += ut; }
+        }
+        double ex = __shfl_up(s, 8);
+        unsigned uex = __shfl_up(us, 8);
+        if (g == 0) { ex = 0.0; uex = 0u; }
+        Sc[(10 * g) * LC + col] = ex;          Sp[(10 * g) * LC + col] = uex;
+        Sc[(10 * g + 5) * LC + col] = ex + a0;  Sp[(10 * g + 5) * LC + col] = uex + u0;
+    }
+    // ---- this wave's slice of the tile-wide candidate list: base = candidates of the waves before it
+    int lbase, total;
+    {
+        unsigned v = (lane < NW) ? wcnt[lane] : 0u;
+        v += dpp_u32<DPP_ROW_SHR1, 0xf>(v);
+        v += dpp_u32<DPP_ROW_SHR2, 0xf>(v);
+        v += dpp_u32<DPP_ROW_SHR4, 0xf>(v);
+        v += dpp_u32<DPP_ROW_SHR8, 0xf>(v);
+        total = __builtin_amdgcn_readlane((int)v, NW - 1);
+        lbase = wave > 0 ? __builtin_amdgcn_readlane((int)v, wave > 0 ? wave - 1 : 0) : 0;
+    }
+    if (cnt > 0) {
+        int pos = lbase;
+#pragma unroll
+        for (int j = 0; j < RPW; ++j) {
+            const int y = wave * RPW + j - (W + 1);
+            const bool rowout = (unsigned)y < (unsigned)TR && r0 + y < n;
+            if (!rowout) continue;
+            bool cd[2];
+            unsigned long long M[2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int k = kb + e - j;
+                cd[e] = (pkv[j][e] & PK_MASK) != 0u && (unsigned)(xo + e) < (unsigned)TC && (unsigned)(k - mw) <= (unsigned)(Dm - mw);
+                M[e] = __ballot(cd[e]);
+            }
+            if ((M[0] | M[1]) == 0ull) continue;
+            // entries in column order: even columns (e = 0) and odd columns (e = 1) of the row interleave
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(M[0] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M[0], 0u)) +
+                              (int)__builtin_amdgcn_mbcnt_hi((unsigned)(M[1] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M[1], 0u));
+            const unsigned yy = ((unsigned)(y >> 4) << 7) | ((unsigned)(y & 15) << (7 + HPK_YI_BITS));
+            if (cd[0]) lst[pos + below] = (unsigned)xo | yy | ((pkv[j][0] & PK_MASK) << 13);
+            if (cd[1]) lst[pos + below + (cd[0] ? 1 : 0)] = (unsigned)(xo + 1) | yy | ((pkv[j][1] & PK_MASK) << 13);
+            pos += __popcll(M[0]) + __popcll(M[1]);
+        }
+    }
+    __syncthreads();
+    HPK_CLK(ck2)
+    // ---- phase 2: SAT of the rows above (row 5 wave), prefixed along the row, then the wave's own rows
+    double ac[2];
+    unsigned ar[2];
+    {
+        const double2 t = *reinterpret_cast<const double2*>(&Sc[(wave * RPW) * LC + xx0]);
+        const uint2 u = *reinterpret_cast<const uint2*>(&Sp[(wave * RPW) * LC + xx0]);
+        double pc = t.x + t.y; unsigned pr = u.x + u.y;
+        const double l1c = pc; const unsigned l1r = pr;
+        wave_exclusive_scan(pc, pr);
+        ac[0] = pc + t.x; ar[0] = pr + u.x;
+        ac[1] = pc + l1c; ar[1] = pr + l1r;
+    }
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const unsigned r0u = pkv[j][0], r1u = pkv[j][1];
+        const double c0v = balv[j][0], c1v = balv[j][1];
+        const double l1c = c0v + c1v; const unsigned l1r = r0u + r1u;
+        double pc = l1c; unsigned pr = l1r;
+        wave_exclusive_scan(pc, pr);
+        ac[0] += pc + c0v; ar[0] += pr + r0u;
+        ac[1] += pc + l1c; ar[1] += pr + l1r;
+        const int o = (wave * RPW + j) * LC + xx0;
+        *reinterpret_cast<double2*>(&Sc[o]) = make_double2(ac[0], ac[1]);
+        *reinterpret_cast<uint2*>(&Sp[o]) = make_uint2(ar[0], ar[1]);
+    }
+    __syncthreads();
+    HPK_CLK(ck3)
+    // gap rows (callers.py:238), as in hpk_stencil
+    if ((int)threadIdx.x < TR && r0 + (int)threadIdx.x < n) {
+        const bool last = (cj == a.J - 1) || (c0 + TC >= n) || (mw + (cj + 1) * TC - (TR - 1)) > a.D;
+        const int Y = (int)threadIdx.x + W + 1;
+        const int xe = last ? LC - 1 : W + TC, xs = W;
+        const unsigned rs = Sp[Y * LC + xe] - Sp[(Y - 1) * LC + xe] - Sp[Y * LC + xs] + Sp[(Y - 1) * LC + xs];
+        if ((rs >> PK_SHIFT) != 0u) a.gap[r0 + (int)threadIdx.x] = 1;
+    }
+    // ---- phase 3: batches of 64 candidates, dealt round-robin to the waves
+    const int64_t tbase = (int64_t)tid * a.tilecap;
+    unsigned* __restrict__ ent_t = a.rec_ent + tbase;
+    HPK_CLK(ck4)
+#pragma unroll 1
+    for (int b = wave; b * 64 < total; b += NW) {
+#ifdef HPK_PHASE_CLOCK
+        ck7 += 1ull;
+#endif
+        const int i = b * 64 + lane;
+        const bool cand = i < total;
+        const unsigned id = lst[cand ? i : 0];
+        const int x = (int)(id & 127u);
+        const int y = (int)((id >> (7 + HPK_YI_BITS)) & 15u) + 16 * (int)((id >> 7) & ((1u << HPK_YI_BITS) - 1u));
+        const int base = (y + W + 1) * LC + W + 1 + x;
+        if (cand) ent_t[i] = id;
+        // one round of reads: S(Y, X-1) of both planes, the pixel's own value, the three Reads boxes that decide most
+        // candidates (p0: subtracted from all, narrowest, widest), the far corner of the widest window
+        const unsigned sr = Sp[base - 1];
+        const double sc = Sc[base - 1];
+        const double pixc = (Sc[base] - Sc[base - LC]) - (sc - Sc[base - LC - 1]);
+        const double amax = Sc[base + W * LC + W];
+        const unsigned b0 = (p0_p > 0) ? reads_box(Sp, base, p0_p, sr) : 0u;
+        const unsigned bf = reads_box(Sp, base, wmin_p, sr);
+        const unsigned bl = reads_box(Sp, base, W, sr);
+        int wstar = 255;
+        if (cand && bf - b0 >= (unsigned)minr_p) wstar = wmin_p;
+        else if (cand && bl - b0 >= (unsigned)minr_p) wstar = W;
+        // lanes that pass the widest but not the narrowest box: all widths in between, four at a time (Reads is monotone)
+        if (W - wmin_p > 1 && __ballot(wstar == W) != 0ull) {
+#pragma unroll 1
+            for (int wa = wmin_p + 1; wa < W; wa += 4) {
+                unsigned rd[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) rd[t] = reads_box(Sp, base, (wa + t < W) ? wa + t : W - 1, sr);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (wa + t < W && wstar == W && rd[t] - b0 >= (unsigned)minr_p) wstar = wa + t;
+            }
+        }
+        // resolve histogram by width: one ballot per width
+#pragma unroll 1
+        for (int w = wmin_p; w <= W; ++w) {
+            const unsigned c = (unsigned)__popcll(__ballot(wstar == w));
+            if (lane == w) myhist += c;
+        }
+        // ---- sums at the resolving step, once per slot
+#pragma unroll 1
+        for (int q = 0; q < nslots_p; ++q) {
+            const int wf = (q == 0) ? wf_q[0] : (q == 1) ? wf_q[1] : (q == 2) ? wf_q[2] : wf_q[3];
+            const int wq = wstar > wf ? wstar : wf;
+            int sq = (int)stepof[q * 32 + (wq & 31)];
+            if (wstar == 255) sq = 0xff;
+            const bool act = sq != 0xff;
+            double SK = 0.0, SY = 0.0;
+            if (__ballot(act) != 0ull) {
+                const int src = act ? sq : 0;
+                const uint4 pw4 = *reinterpret_cast<const uint4*>(&pl[src * 8]);
+                const unsigned w0 = pw4.x, k0 = pw4.y, k1 = pw4.z, k2 = pw4.w;
+                unsigned k3 = 0u;
+                if (maxnkt > 6) k3 = pl[src * 8 + 4];
+                const int nkt = act ? (int)((w0 >> 20) & 15u) : 0;
+#pragma unroll 1
+                for (int j = 0; j < maxnkt; ++j) {
+                    const bool on = j < nkt;
+                    if (__ballot(on) == 0ull) break;
+                    const unsigned kw = (j < 2) ? k0 : (j < 4) ? k1 : (j < 6) ? k2 : k3;
+                    const unsigned t = (kw >> (16 * (j & 1))) & 0xffffu;
+                    const int rho = on ? (int)(t & 0xffu) : 1;      // idle lanes read a harmless box
+                    const double cf = on ? (double)(int)(signed char)(t >> 8) : 0.0;
+                    double kc, yc;
+                    box_ky(Sc, base, rho, pixc, sc, kc, yc);
+                    SK += cf * kc; SY += cf * yc;
+                }
+                // lower-left support off the band: exact 0 (see hpk_stencil)
+                const int d = c0 + x - (r0 + y);
+                if (d - (int)((w0 >> 24) & 31u) - 1 < mw) SY = 0.0;
+                // Sums that are small against the largest corner of the window's table entries carry that corner's
+                // rounding noise: below 2^-13 of it they are redone exactly - 0 when no contributing cell is non-zero
+                // (valid-count plane), otherwise by adding the window cells themselves.
+                const double thr = amax * 0x1p-13;
+                const bool risky = act && (SK < thr || (SY < thr && SY != 0.0));
+                if (__ballot(risky) != 0ull) {
+                    if (risky) {
+                        const unsigned pv = Sp[base] - Sp[base - LC] - sr + Sp[base - LC - 1];
+                        unsigned VK = 0u, VY = 0u;
+#pragma unroll 1
+                        for (int j = 0; j < nkt; ++j) {
+                            const unsigned kw = (j < 2) ? k0 : (j < 4) ? k1 : (j < 6) ? k2 : k3;
+                            const unsigned t = (kw >> (16 * (j & 1))) & 0xffffu;
+                            const unsigned long long kyv = box_ky_valid(Sp, base, (int)(t & 0xffu), pv, sr);
+                            VK += (unsigned)(int)(signed char)(t >> 8) * (unsigned)kyv;
+                            VY += (unsigned)(int)(signed char)(t >> 8) * (unsigned)(kyv >> 32);
+                        }
+                        if (VK != 0u) {
+                            const bool keepy = SY == 0.0;           // exact by construction (support off the band)
+                            const double2 ex = explicit_sums(a.raw, a.bal, a.weight, plan->steps[sq].m, W, r0 + y, c0 + x, n, a.num, a.ld, mw);
+                            SK = ex.x;
+                            if (!keepy) SY = (VY == 0u) ? 0.0 : ex.y;
+                        } else { SK = 0.0; SY = 0.0; }
+                    }
+                }
+            }
+            if (cand) {
+                const int64_t o = q * a.rec_stride + tbase + i;
+                a.rec_S[o] = make_double2(act ? SK : 0.0, act ? SY : 0.0);
+                a.rec_W[o] = act ? (uint8_t)(sq + 1) : (uint8_t)0;
+            }
+        }
+    }
+    HPK_CLK(ck5)
+    __syncthreads();                 // every wave is done with this tile's SAT and list
+    HPK_CLK(ck6)
+    if (wave == 0) {
+        // scoring work list: one entry per HPK_UNIT records.  The slot reservation (a returning atomic on one global
+        // counter) of this tile is only consumed when the next tile ends.
+        if (pend_tid >= 0) {
+            const unsigned nu = (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT;
+            const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)pend_off);
+            if ((unsigned)lane < nu) a.units[off + lane] = make_uint2((unsigned)pend_tid, (unsigned)lane | (pend_c << 8));
+        }
+        pend_tid = -1;
+        if (total > 0) {
+            pend_tid = tid;
+            pend_c = (unsigned)total;
+            if (lane == 0) pend_off = atomicAdd(a.nunits, (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT);
+        }
+        if (lane == 0) { a.tile_cnt[tid] = (unsigned)total; mycand += (unsigned)total; }
+    }
+    tid = tid_next;
+    }   // tile loop
+    if (wave == 0 && pend_tid >= 0) {
+        const unsigned nu = (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT;
+        const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)pend_off);
+        if ((unsigned)lane < nu) a.units[off + lane] = make_uint2((unsigned)pend_tid, (unsigned)lane | (pend_c << 8));
+    }
+#ifdef HPK_PHASE_CLOCK
+    if (a.clk && lane == 0) {
+        unsigned long long* o = a.clk + ((size_t)blockIdx.x * NW + wave) * 8;
+        o[0] = ck0; o[1] = ck1; o[2] = ck2; o[3] = ck3; o[4] = ck4; o[5] = ck5; o[6] = ck6; o[7] = ck7;
+    }
+#endif
+    // ---- resolve histogram of the workgroup: widths summed over the waves in LDS, then per step s of slot q and width
+    // w: the candidates whose first sufficient width is w (w above the slot's first width) or at most w (at it)
+    unsigned* red = reinterpret_cast<unsigned*>(smem);
+    __syncthreads();
+    red[wave * 64 + lane] = myhist;
+    if (lane == 0) red[NW * 64 + wave] = mycand;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        unsigned tot = 0u;
+        for (int w2 = 0; w2 < NW; ++w2) tot += red[w2 * 64 + threadIdx.x];
+        red[(NW + 1) * 64 + threadIdx.x] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x <= HPK_MAX_STEPS) {
+        unsigned out = 0u;
+        const unsigned* hw = red + (NW + 1) * 64;
+        if ((int)threadIdx.x < nsteps) {
+            const HpkDevStep& st = plan->steps[threadIdx.x];
+            const int wf = plan->slot_wfirst[st.slot];
+            if (st.wi > wf) out = hw[st.wi];
+            else for (int w = 0; w <= wf && w < 64; ++w) out += hw[w];
+        } else if (threadIdx.x == HPK_MAX_STEPS) out = red[NW * 64];
+        a.hist_part[(int64_t)blockIdx.x * (HPK_MAX_STEPS + 1) + threadIdx.x] = out;
+    }
+}
+
 // ------------------------------------------------------------------ 1-D expected IR[d] and biases (scripts/pyHICCUPS:149-166)
 // IR[d] = mean over diagonal d of the balanced values, where *stored* (non-zero) pixels in masked bins are NaN and
 // are left out of both sum and count, while unstored pixels count as 0 even in masked bins.  Deterministic
@@ -1251,6 +1744,47 @@ __global__ void __launch_bounds__(256) hpk_dense(HpkDenseArgs a) {
     }
 }
 
+// ------------------------------------------------------------------ record look-up at sampled pixels (tests)
+// One wave per query pixel: finds the pixel's record in its tile's region (scan of the entries), then reports per
+// slot (bS_K, bE_K, bS_Y, bE_Y, resolving width); width -1: the pixel is not a candidate (zero count or off the band).
+__global__ void __launch_bounds__(64) hpk_probe(HpkDenseArgs a, const int32_t* __restrict__ rows, const int32_t* __restrict__ cols,
+                                                int64_t count, double* __restrict__ out) {
+    const HpkDevPlan* __restrict__ plan = a.plan;
+    const int64_t qi = blockIdx.x;
+    if (qi >= count) return;
+    const int lane = threadIdx.x;
+    const int r = rows[qi], c = cols[qi], d = c - r;
+    const int nslots = plan->nslots;
+    double* o = out + qi * (int64_t)nslots * 5;
+    long long found = -1;
+    if (r >= 0 && r < a.n && c < a.n && d >= a.mw && d <= a.D) {
+        const int rb = r / a.TR, r0 = rb * a.TR, cj = (c - r0 - a.mw) / a.TC;
+        const int tile = rb * a.J + cj;
+        const int x = c - (r0 + a.mw + cj * a.TC), y = r - r0;
+        const unsigned key = (unsigned)x | ((unsigned)(y >> 4) << 7) | ((unsigned)(y & 15) << (7 + HPK_YI_BITS));
+        const int cnt = (int)a.tile_cnt[tile];
+        for (int i0 = 0; i0 < cnt; i0 += 64) {
+            const int i = i0 + lane;
+            const bool hit = i < cnt && (a.rec_ent[(int64_t)tile * a.tilecap + i] & 0x1fffu) == key;
+            const unsigned long long m = __ballot(hit);
+            if (m) { found = (long long)tile * a.tilecap + i0 + (__ffsll((long long)m) - 1); break; }
+        }
+    }
+    if (lane != 0) return;
+    for (int q = 0; q < nslots; ++q) {
+        double* oq = o + q * 5;
+        oq[0] = oq[1] = oq[2] = oq[3] = 0.0;
+        oq[4] = found < 0 ? -1.0 : 0.0;
+        if (found < 0) continue;
+        const int stp = (int)a.rec_W[q * a.rec_stride + found];
+        if (stp == 0) continue;
+        const double2 s2 = a.rec_S[q * a.rec_stride + found];
+        double EK, EY;
+        local_expected(plan, a.etab, a.eedge, a.IR, stp - 1, r, c, d, a.n, a.num, a.mw, a.D, plan->W, EK, EY);
+        oq[0] = s2.x; oq[1] = EK; oq[2] = s2.y; oq[3] = EY; oq[4] = (double)plan->steps[stp - 1].wi;
+    }
+}
+
 // ------------------------------------------------------------------ brute-force check (tests only)
 __global__ void __launch_bounds__(64) hpk_brute(HpkBruteArgs a) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1301,7 +1835,32 @@ static void launch_stencil_t(const HpkStencilArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(a.grid), dim3(NW * 64), hpk_stencil_lds_bytes(), st, a, a.raw, a.bal, a.weight, a.rec_S, a.rec_W);
 }
 
+int hpk_stencil_s_lds_bytes() { return LR * LC * 12 + HPK_SLIST * 4 + 256 + HPK_MAX_STEPS * 32 + HPK_KSLOTS * 32; }
+
+template <bool BALF64>
+static void launch_stencil_s_t(const HpkStencilArgs& a, hipStream_t st) {
+    auto kern = hpk_stencil_s<BALF64>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  hpk_stencil_s_lds_bytes());
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.grid), dim3(1024), hpk_stencil_s_lds_bytes(), st, a);
+}
+
+// Simple-Reads plans within the buffer-addressing limits of hpk_stencil_s (32-bit byte offsets inside one tile's rows,
+// weights addressed from element 0) go to the second-generation kernel; everything else to hpk_stencil.
+bool hpk_stencil_s_applies(const HpkStencilArgs& a, bool simple) {
+    static const bool off = std::getenv("HPK_OLD_STENCIL") != nullptr || std::getenv("HPK_NEW_STENCIL") == nullptr;
+    return simple && !off && HPK_NWAVES == 16 && a.ld <= (int64_t)(1 << 21) && a.n < (1 << 27) && a.TR * a.TC <= HPK_SLIST;
+}
+
 void hpk_launch_stencil(const HpkStencilArgs& a, bool balf64, bool simple, hipStream_t st) {
+    if (hpk_stencil_s_applies(a, simple)) {
+        if (balf64) launch_stencil_s_t<true>(a, st); else launch_stencil_s_t<false>(a, st);
+        return;
+    }
     constexpr int NW = HPK_NWAVES;
     if (balf64) { if (simple) launch_stencil_t<NW, true, true>(a, st); else launch_stencil_t<NW, true, false>(a, st); }
     else        { if (simple) launch_stencil_t<NW, false, true>(a, st); else launch_stencil_t<NW, false, false>(a, st); }
@@ -1310,6 +1869,11 @@ void hpk_launch_stencil(const HpkStencilArgs& a, bool balf64, bool simple, hipSt
 void hpk_launch_dense(const HpkDenseArgs& a, hipStream_t st) {
     if (a.ntiles <= 0) return;
     hipLaunchKernelGGL(hpk_dense, dim3(a.ntiles), dim3(256), 0, st, a);
+}
+
+void hpk_launch_probe(const HpkDenseArgs& a, const int32_t* rows, const int32_t* cols, int64_t count, double* out, hipStream_t st) {
+    if (count <= 0) return;
+    hipLaunchKernelGGL(hpk_probe, dim3((unsigned)count), dim3(64), 0, st, a, rows, cols, count, out);
 }
 
 void hpk_launch_freeze(const HpkDevPlan* plan, unsigned long long* hist, const unsigned* hist_part, int nparts,

@@ -200,6 +200,13 @@ int  hpk_poisson_sf(hpk_ctx* ctx, const double* k, const double* lam, double* ou
 int  hpk_bruteforce_sums(hpk_ctx* ctx, const hpk_band* band, const hpk_params* params, int32_t step,
                          const int32_t* rows, const int32_t* cols, int64_t count, double* out);
 
+/* The production kernels' own sums at `count` sampled pixels without the dense debug outputs (which need
+ * [nslots][n][D+1] arrays - gigabytes at 5 kb / 1 kb resolution): runs the stencil, looks the pixels up in the
+ * candidate records; out is [count][nslots][5] = (bS_K, bE_K, bS_Y, bE_Y, resolving width); width 0 = never
+ * resolved, -1 = not a candidate (zero count or outside min(ww) <= d <= maxapart/res). */
+int  hpk_probe_sums(hpk_ctx* ctx, const hpk_band* band, const hpk_params* params, const int32_t* rows,
+                    const int32_t* cols, int64_t count, double* out);
+
 #ifdef __cplusplus
 }
 #endif

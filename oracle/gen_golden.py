@@ -96,6 +96,7 @@ class Tap(object):
         self.bh = []         # (p, q)
         self.pre = None      # (Donuts, LL) handed to local_clustering
         self.log = []
+        self.gets = []       # (rows, cols, values) of every M[rows, cols] read of a CSR matrix, in call order (G3)
 
 
 def install(tap):
@@ -141,6 +142,19 @@ def install(tap):
         tap.pre = (dict(Donuts), None if LL is None else dict(LL))
         return real_clu(Donuts, LL, res, **kw)
 
+    # G3: the widening loop reads its accumulators only through fancy indexing of CSR matrices
+    # (Reads[Txi, Tyi], bS[fl][Exi, Eyi], bE[fl][Exi, Eyi]; callers.py:205, 212-213) - observe those reads
+    real_getitem = sparse.csr_matrix.__getitem__
+
+    def getitem(self, key):
+        out = real_getitem(self, key)
+        if tap.capture_gets and isinstance(key, tuple) and len(key) == 2 and isinstance(key[0], np.ndarray) \
+                and isinstance(key[1], np.ndarray):
+            tap.gets.append((np.array(key[0]), np.array(key[1]), np.array(out, dtype=np.float64).ravel()))
+        return out
+    sparse.csr_matrix.__getitem__ = getitem
+    saved['__csr_getitem__'] = real_getitem
+
     ref.lambdachunk = lambdachunk
     ref.poisson = PoisProxy
     ref.multipletests = multipletests
@@ -157,6 +171,7 @@ def install(tap):
 
 
 def uninstall(saved, h):
+    sparse.csr_matrix.__getitem__ = saved.pop('__csr_getitem__')
     for k, v in saved.items():
         setattr(ref, k, v)
     ref.logger.removeHandler(h)
@@ -199,7 +214,7 @@ def table_to_array(table):
 
 
 # ---------------------------------------------------------------- cases
-def run_case(name, mode, gen, params, plant=None, mutate=None):
+def run_case(name, mode, gen, params, plant=None, mutate=None, g3=False):
     raw, weight, loops = synthetic.synth_band(**gen)
     if plant is not None:
         raw = plant(raw)
@@ -236,6 +251,7 @@ def run_case(name, mode, gen, params, plant=None, mutate=None):
     meta['chromLen'] = int(chromLen)
 
     tap = Tap()
+    tap.capture_gets = bool(g3)
     saved, h = install(tap)
     exc = None
     table = None
@@ -269,6 +285,26 @@ def run_case(name, mode, gen, params, plant=None, mutate=None):
     ncand = [int(re.search(r'Observed Contact Number: (\d+)', m).group(1)) for m in tap.log
              if 'Observed Contact Number' in m]
     meta['ncand'] = ncand[0] if ncand else None
+
+    if g3 and exc is None and mode == 'hiccups':
+        # per executed step: Reads at the candidates still unresolved for this peak width, then the four accumulators at
+        # the candidates resolved by this step - exactly the reads of callers.py:205 and 212-213, in that order
+        for k, (spi, swi, scnt) in enumerate(steps):
+            rx, ry, rv = tap.gets[5 * k]
+            out['g3_%d_ux' % k] = rx.astype(np.int32)
+            out['g3_%d_uy' % k] = ry.astype(np.int32)
+            out['g3_%d_reads' % k] = rv
+            ex, ey, bsk = tap.gets[5 * k + 1]
+            assert ex.size == scnt and int((rv >= params['min_local_reads']).sum()) == scnt
+            out['g3_%d_ex' % k] = ex.astype(np.int32)
+            out['g3_%d_ey' % k] = ey.astype(np.int32)
+            out['g3_%d_bSK' % k] = bsk
+            out['g3_%d_bEK' % k] = tap.gets[5 * k + 2][2]
+            out['g3_%d_bSY' % k] = tap.gets[5 * k + 3][2]
+            out['g3_%d_bEY' % k] = tap.gets[5 * k + 4][2]
+            for t in (2, 3, 4):
+                assert np.array_equal(tap.gets[5 * k + t][0], ex) and np.array_equal(tap.gets[5 * k + t][1], ey)
+        meta['g3_steps'] = len(steps)
 
     if exc is not None:
         meta['exception'] = type(exc).__name__
@@ -378,6 +414,22 @@ def plant_short(raw):
     return raw
 
 
+def ones_with_a_block(raw, weight):
+    """Every stored pixel = 1 and every weight = 1: IR[d] = 1, bS = bE (sums of ones are exact) and both biases are 1,
+    so the corrected expected is *exactly* 1.0 = the boundary between the first two lambda chunks - such pixels
+    belong to no chunk and keep p = q = 1 (callers.py:38, 259-260).  A block of larger counts makes the diagonals it
+    touches differ (IR != 1 there), so that the same run also holds ordinary pixels and calls."""
+    n, num = raw.shape
+    raw = np.ones_like(raw)
+    rr = np.arange(n)[:, None]
+    raw[(rr + np.arange(num)[None, :]) >= n] = 0
+    for (r, d) in ((60, 18), (150, 25)):
+        for dr in (-1, 0, 1):
+            for dc in (-1, 0, 1):
+                raw[r + dr, d + dc - dr] = 30
+    return raw, np.ones_like(weight)
+
+
 def main():
     only = sys.argv[1:]
     cases = []
@@ -422,6 +474,18 @@ def main():
     g = dict(n=360, num=61, depth=60.0, nloops=10, seed=23)
     cases.append(('bhfdr_w20', 'bhfdr', g, P(pw=2, ww=5, maxww=20, maxapart=400000, min_marginal_peaks=3,
                                              onlyanchor=True), None, None))
+    # ---- round 2: single (4,7) pair, wide bands (several column chunks of the stencil's tiling), per-step accumulators
+    # captured from the reference (G3), E exactly on a chunk boundary
+    g = dict(n=500, num=71, depth=12.0, nloops=14, seed=31)
+    cases.append(('hiccups_p4w7', 'hiccups', g, P(pw=[4], ww=[7], maxapart=600000), None, None, True))
+    g = dict(n=300, num=46, depth=12.0, nloops=8, seed=32)
+    cases.append(('hiccups_union_g3', 'hiccups', g, P(pw=[1, 2, 4], ww=[3, 5, 7], maxapart=350000), None, None, True))
+    g = dict(n=640, num=331, depth=60.0, nloops=30, seed=33)
+    cases.append(('hiccups_wide_p2w5', 'hiccups', g, P(pw=[2], ww=[5], maxapart=3200000), None, None))
+    g = dict(n=560, num=311, depth=25.0, nloops=30, seed=34)
+    cases.append(('hiccups_wide_p4w7', 'hiccups', g, P(pw=[4], ww=[7], maxapart=3000000), None, None))
+    g = dict(n=260, num=41, depth=5.0, nloops=0, seed=35, nan_frac=0.0)
+    cases.append(('hiccups_E_on_boundary', 'hiccups', g, P(pw=[2], ww=[5], maxapart=300000), None, ones_with_a_block))
     for c in cases:
         if only and c[0] not in only:
             continue

@@ -17,6 +17,21 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+@pytest.fixture(scope='session', autouse=True)
+def _torch_before_libhpk(request):
+    """GPU sessions: PyTorch bundles its own HIP runtime; when libhpk's (system ROCm) initialises first, torch no
+    longer finds the device.  Touch the GPU through torch once before any hpk context exists."""
+    expr = request.config.getoption('-m') or ''
+    if 'gpu' in expr and 'not gpu' not in expr:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.zeros(1, device='cuda')
+        except ImportError:
+            pass
+    yield
+
+
 class Golden(object):
     """One fixture produced by oracle/gen_golden.py from the real reference."""
 

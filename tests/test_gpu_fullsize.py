@@ -1,0 +1,150 @@
+"""BASELINE.json configs[3] and configs[4] at full size on the GPU: the wide-band code paths (num = 2011: ~20 column
+chunks per row block, 2001-entry expected tables, 32-bit table offsets, the last-tile gap-row rule) that no fixture
+reaches.  The reference cannot run at these sizes in a test (hours), so the checks are size-independent properties:
+
+  * counting identities of the widening log (candidates, band pixels, executed prefix, resolve counts),
+  * gap rows against an independent reduction of the band,
+  * the production kernels' sums and resolving widths at ~25 000 sampled pixels (`hpk_probe_sums`) against the
+    explicit-window kernel `hpk_brute` (no summed-area table, no tiles) - the sample covers the first and the last
+    column chunk and both chromosome ends,
+  * p <= q <= sig for every reported pixel.
+"""
+import numpy as np
+import pytest
+
+from hicpeaks_amd import _lib, band as hband
+
+pytestmark = pytest.mark.gpu
+
+SIG, MIN_READS = 0.05, 16
+CASES = {
+    # configs[3] largest work item: hg38 chr1 at 5 kb, (p, w) = (4, 7), 10 Mb band, weights-only input
+    'chr1_5kb_p4w7': dict(n=49792, res=5000, maxapart=10000000, pw=[4], ww=[7], maxww=10, depth=25.0, nloops=800, seed=5),
+    # configs[4]: synthetic 1 kb deep Hi-C, 2 Mb band, 250 000 bins
+    'deep_1kb_p2w5': dict(n=250000, res=1000, maxapart=2000000, pw=[2], ww=[5], maxww=10, depth=8.0, nloops=2000, seed=6),
+}
+
+
+@pytest.fixture(scope='module')
+def ctx():
+    c = _lib.Context(0)
+    yield c
+    c.close()
+
+
+def _sample(raw_d, n, num, mw, D, W, rng):
+    """Candidate pixels (non-zero count, mw <= d <= D): random ones plus the corners of the band."""
+    import torch
+    dev = raw_d.device
+    picks = []
+    r = torch.from_numpy(rng.integers(0, n, 600000)).to(dev)
+    k = torch.from_numpy(rng.integers(mw, D + 1, 600000)).to(dev)
+    ok = (r + k < n) & (raw_d[r, k] != 0)
+    picks.append(torch.stack([r[ok], k[ok]], 1)[:20000])
+
+    def block(rsl, ksl, cap):
+        sub = raw_d[rsl, ksl]
+        rr, kk = torch.nonzero(sub, as_tuple=True)
+        rr = rr + (rsl.start or 0)
+        kk = kk + (ksl.start or 0)
+        ok = rr + kk < n
+        sel = torch.stack([rr[ok], kk[ok]], 1)
+        if sel.shape[0] > cap:
+            sel = sel[torch.from_numpy(rng.choice(sel.shape[0], cap, replace=False)).to(dev)]
+        return sel
+    picks.append(block(slice(0, W + 2), slice(mw, D + 1), 3000))                      # first rows: window clipped above
+    picks.append(block(slice(n - D - 5, n), slice(mw, D + 1), 200000))                 # last columns: filtered below
+    picks.append(block(slice(0, n), slice(mw, mw + 4), 2000))                          # first column chunk, d = mw ..
+    picks.append(block(slice(0, n), slice(D - 3, D + 1), 2000))                        # last column chunk, d = .. D
+    picks.append(block(slice(0, 300), slice(mw, D + 1), 1500))
+    p = torch.cat(picks).cpu().numpy()
+    rows, ks = p[:, 0], p[:, 1]
+    cols = rows + ks
+    keep = np.ones(rows.size, bool)
+    far = rows >= n - D - 5
+    keep[far] = (cols[far] >= n - W - 2) | (rng.random(int(far.sum())) < 0.002)     # right end: window clipped at the side
+    rows, cols = rows[keep], cols[keep]
+    _, first = np.unique(rows.astype(np.int64) * n + cols, return_index=True)
+    return rows[first].astype(np.int32), cols[first].astype(np.int32)
+
+
+@pytest.mark.parametrize('name', sorted(CASES))
+def test_full_size_wide_band(name, ctx):
+    import torch
+    from hicpeaks_amd import bandgen
+    cfg = CASES[name]
+    n, res, W = cfg['n'], cfg['res'], cfg['maxww']
+    mw, D = min(cfg['ww']), cfg['maxapart'] // res
+    num = D + W + 1
+    ld = (num + 63) // 64 * 64
+    dev = torch.device('cuda', 0)
+    raw_d, w_d, ir_d, b_d = bandgen.device_band(n, num, ld, mw, depth=cfg['depth'], nloops=cfg['nloops'], seed=cfg['seed'],
+                                                device=dev)
+    torch.cuda.synchronize()
+    prm = _lib.make_params(_lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], W, SIG, cfg['maxapart'], res, MIN_READS, 0)
+    bd = ctx._band(n, num, ld, raw_d.data_ptr(), None, w_d.data_ptr(), ir_d.data_ptr(), b_d.data_ptr(), b_d.data_ptr(), True)
+    R = ctx.score(bd, prm, n)
+
+    # ---- counting identities
+    kk = torch.arange(ld, device=dev)
+    rr = torch.arange(n, device=dev)
+    inband = (kk[None, :] >= mw) & (kk[None, :] <= D) & ((rr[:, None] + kk[None, :]) < n)
+    assert R.ncand == int(((raw_d != 0) & inband).sum().item())
+    assert R.band_px == hband.band_pixels(n, num, mw, D)
+    assert R.tiles == -(-n // 59) * -(-(59 + D - mw) // 107) and -(-(59 + D - mw) // 107) >= 19      # ~20 column chunks
+    ex = [e for _, _, _, e in R.steps]
+    assert ex == sorted(ex, reverse=True) and ex[0]
+    assert all(wi <= R.frozen_w for _, wi, _, e in R.steps if e)
+    assert sum(c for _, _, c, e in R.steps if e) <= R.ncand
+    assert [wi for _, wi, _, _ in R.steps] == list(range(max(cfg['ww']), W + 1))
+
+    # ---- gap rows: rows of the balanced upper band (diagonals mw .. num-1) that sum to 0 (callers.py:238)
+    wc = torch.where(rr[:, None] + kk[None, :] < n, w_d[(rr[:, None] + kk[None, :]).clamp(max=n - 1)], torch.zeros((), dtype=w_d.dtype, device=dev))
+    live = torch.zeros(n, dtype=torch.bool, device=dev)
+    for r0 in range(0, n, 16384):                        # in slabs: the f64 product of the whole band would be 4 GB
+        sl = slice(r0, min(n, r0 + 16384))
+        b = (raw_d[sl].to(torch.float64) * w_d[sl, None]) * wc[sl]
+        b = torch.nan_to_num(b, nan=0.0)
+        b[:, :mw] = 0
+        b[:, num:] = 0
+        live[sl] = (b != 0).any(dim=1)
+    np.testing.assert_array_equal(R.gap, ~live.cpu().numpy())
+    del wc, inband
+
+    # ---- sampled pixels: production records vs explicit windows
+    rng = np.random.default_rng(cfg['seed'])
+    rows, cols = _sample(raw_d, n, num, mw, D, W, rng)
+    assert rows.size > 15000
+    assert (rows < W).sum() > 200 and (cols >= n - W).sum() > 20                       # both chromosome ends
+    d = cols - rows
+    assert (d < mw + 4).sum() > 500 and (d > D - 4).sum() > 50                          # first and last column chunk
+    pr = ctx.probe_sums(bd, prm, rows, cols, 1)[:, 0, :]
+    width = pr[:, 4].astype(np.int64)
+    assert np.all(width >= 0)                                                           # every sampled pixel is a candidate
+    steps = [(pi, wi) for pi, wi, _, _ in R.steps]
+    reads_at = {}
+    for si, (pi, wi) in enumerate(steps):
+        bf = ctx.bruteforce_band(bd, prm, si, rows, cols)
+        reads_at[wi] = bf[:, 4]
+        sel = width == wi
+        if sel.any():
+            np.testing.assert_allclose(pr[sel, :4], bf[sel, :4], rtol=1e-11, atol=0)
+            assert np.array_equal(pr[sel, :4] == 0, bf[sel, :4] == 0)
+            assert np.all(bf[sel, 4] >= MIN_READS)
+            if si > 0:                                                                  # first sufficient width
+                assert np.all(reads_at[steps[si - 1][1]][sel] < MIN_READS)
+    never = width == 0
+    assert np.all(reads_at[steps[-1][1]][never] < MIN_READS)
+    assert len(set(width.tolist())) >= 3                                                # the sample exercises the widening
+    # a zero-count pixel is not a candidate
+    zr = torch.nonzero(raw_d[1000:1064, mw:D + 1] == 0)[:50].cpu().numpy()
+    pz = ctx.probe_sums(bd, prm, zr[:, 0] + 1000, zr[:, 0] + 1000 + zr[:, 1] + mw, 1)
+    assert np.all(pz[:, 0, 4] == -1)
+
+    # ---- reported pixels
+    for s in R.sets:
+        assert s['x'].size > 0
+        assert np.all(s['p'] <= s['q'] + 1e-18) and np.all(s['q'] <= SIG)
+        assert np.all((s['y'] - s['x'] >= max(cfg['ww'])) & (s['y'] - s['x'] <= D))
+        o = raw_d[torch.from_numpy(s['x']).to(dev), torch.from_numpy(s['y'] - s['x']).to(dev)].cpu().numpy()
+        np.testing.assert_array_equal(s['O'], o)

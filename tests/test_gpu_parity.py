@@ -150,6 +150,34 @@ def test_dense_sums_match_oracle(name, ctx):
                 assert np.array_equal(sums[res_, col] == 0, want[res_] == 0)
 
 
+@pytest.mark.parametrize('name', ['hiccups_p4w7', 'hiccups_union_g3'])
+@pytest.mark.parametrize('mode', ['weight', 'balanced'])
+def test_sums_match_reference_accumulators(name, mode, ctx):
+    """G3 without the oracle in between: the four sums the reference itself read out of its accumulators at the step
+    that resolved each candidate (callers.py:212-213, recorded by oracle/gen_golden.py) against the kernel's sums at
+    the same candidates, and the resolving width."""
+    g = load_golden(name)
+    detail = dict(dense=True)
+    _call(g, ctx, mode, detail)
+    R = detail['result']
+    slot_of = {pi: s for s, pi in enumerate(R.slot_pi)}
+    assert g.meta['g3_steps'] == sum(1 for st in R.steps if st[3])
+    ncheck = 0
+    for k in range(g.meta['g3_steps']):
+        pi, wi, cnt = (int(v) for v in g['steps'][k])
+        ex, ey = g['g3_%d_ex' % k].astype(np.int64), g['g3_%d_ey' % k].astype(np.int64)
+        assert ex.size == cnt
+        slot = slot_of[pi]
+        np.testing.assert_array_equal(R.dense_w[slot][ex, ey - ex], wi)
+        got = R.dense_sums[slot][ex, ey - ex]
+        for col, key in enumerate(('bSK', 'bEK', 'bSY', 'bEY')):
+            want = g['g3_%d_%s' % (k, key)]
+            np.testing.assert_allclose(got[:, col], want, rtol=1e-11, atol=0)
+            assert np.array_equal(got[:, col] == 0, want == 0)
+        ncheck += ex.size
+    assert ncheck > 3000
+
+
 def test_poisson_sf_matches_scipy(ctx):
     from scipy.special import pdtr
     rng = np.random.default_rng(0)

@@ -106,3 +106,42 @@ def test_pw_ww_pairs_known_answer():
                                                              (2, 7), (4, 7)]
     assert len(orc.pw_ww_pairs([1, 2, 4], [3, 5, 7], 10)) == 18
     assert orc.pw_ww_pairs([2], [12], 10) == []
+
+
+@pytest.mark.parametrize('name', ['hiccups_p4w7', 'hiccups_union_g3'])
+def test_per_step_accumulators_match_reference(name):
+    """G3: what the reference read out of its CSR accumulators at every executed step (Reads at the still unresolved
+    candidates, callers.py:205; bS / bE of both filters at the candidates the step resolves, callers.py:212-213),
+    captured by oracle/gen_golden.py, against the oracle's dense-band accumulators at the same step."""
+    g = load_golden(name)
+    p = g.params
+    num = g.meta['num']
+    raw = g['raw'][:, :num]
+    n = raw.shape[0]
+    IR, cband, biases = orc.prep_from_band(raw, g['weight'], g.mw)
+    seen = []
+
+    def trace(k, pi, wi, bS, bE, Reads):
+        assert (pi, wi) == tuple(int(v) for v in g['steps'][k][:2])
+        ux, uy = g['g3_%d_ux' % k].astype(np.int64), g['g3_%d_uy' % k].astype(np.int64)
+        np.testing.assert_array_equal(Reads[ux, uy - ux], g['g3_%d_reads' % k])
+        ex, ey = g['g3_%d_ex' % k].astype(np.int64), g['g3_%d_ey' % k].astype(np.int64)
+        for fl, a, b in (('K', 'bSK', 'bEK'), ('Y', 'bSY', 'bEY')):
+            np.testing.assert_allclose(bS[fl][ex, ey - ex], g['g3_%d_%s' % (k, a)], rtol=1e-13, atol=0)
+            np.testing.assert_allclose(bE[fl][ex, ey - ex], g['g3_%d_%s' % (k, b)], rtol=1e-13, atol=0)
+        seen.append(k)
+
+    orc.hiccups_local_sums(raw, cband, IR, n, num, p['pw'], p['ww'], p['maxww'], p['maxapart'], p['res'],
+                           p['min_local_reads'], trace=trace)
+    assert seen == list(range(g.meta['g3_steps'])) and len(seen) >= 4
+
+
+def test_expected_exactly_on_a_chunk_boundary():
+    """Fixture hiccups_E_on_boundary: the reference leaves pixels whose corrected expected is exactly 1.0 (the boundary
+    of the first two lambda chunks) in no chunk, p = q = 1 (callers.py:38, 259-260)."""
+    g = load_golden('hiccups_E_on_boundary')
+    for t in range(g.meta['nsets']):
+        E, ch = g['s%d_E' % t], g['s%d_chunk' % t]
+        on = E == 1.0
+        assert on.sum() >= 20 and np.all(ch[on] == 0) and np.all(g['s%d_p' % t][on] == 1) and np.all(g['s%d_q' % t][on] == 1)
+        assert np.all(ch[~on] > 0)
