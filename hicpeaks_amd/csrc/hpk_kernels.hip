@@ -622,34 +622,108 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
 }
 
 // ------------------------------------------------------------------ stencil for "simple Reads" plans
-// Second-generation stencil kernel (same tile geometry, SAT planes and record output as hpk_stencil above, which
-// stays for plans whose Reads matrix is not monotone in the width).  What the phase clocks of the first kernel showed
-// (profiles/r02_phase_clock.txt) and what is different here:
-//   * the band rows of the next tile were fetched by five *serialised* scalar weight loads and ten branch-wrapped
-//     loads, a quarter of the kernel: here every prefetch load is a bounds-checked buffer load (out-of-range cells
-//     return 0: no branches), the row weights arrive in one vector load and are handed out with v_readlane;
+// Second-generation stencil kernel: same tile geometry, SAT planes and record output as hpk_stencil above (which stays
+// for plans whose Reads matrix is not monotone in the width, and for maxww < 4).  What the phase clocks and the ISA of
+// the first kernel showed (profiles/r02_phase_clock.txt), and what is different here:
+//   * the next tile's band rows were fetched by ten branch-wrapped loads and five *serialised* scalar weight loads - a
+//     quarter of the kernel's time: here every prefetch load is a bounds-checked buffer load (cells outside the
+//     matrix or the stored diagonals read 0, no branches), the row weights arrive in one vector load and are handed
+//     out with v_readlane;
+//   * the SAT rows of the waves above were summed by a serial loop of up to fifteen dependent LDS reads after the
+//     wave's own scans: here every wave first builds the SAT *of its own rows* in registers, publishes only its last
+//     row, four waves turn those into exclusive prefixes (plain column sums, no scans), and the wave adds its base
+//     while it stores the SAT;
 //   * the candidate lists were built after the SAT from four LDS reads per pixel, one dependent round trip per half
-//     row: here they come out of the registers of phase 1 (ballot + mbcnt), into ONE tile-wide list whose batches are
-//     dealt round-robin to the sixteen waves (no idle waves on tiles whose candidates sit in a few rows);
-//   * the column totals of the waves above were summed by a serial loop of up to fifteen dependent LDS reads: here
-//     the sixteen waves form all prefixes in parallel (eight columns per wave, four shuffle steps);
-//   * a batch of 64 candidates went through ~12 dependent LDS round trips: here the Reads boxes of all widths are
-//     read together, the box terms two at a time, and the resolve histogram is kept per *width* with one ballot per
-//     width (converted to steps once per workgroup at the end);
+//     row: here they come out of the registers of phase 1 (ballot + mbcnt) in the same pass, into ONE tile-wide list
+//     (a row's slice is reserved with an LDS atomic whose return is only consumed after the row's scan), whose
+//     batches are dealt round-robin to the sixteen waves;
+//   * the SAT ran left to right.  In the tiles next to the main diagonal the contact counts fall by two orders of
+//     magnitude from left to right, so every table entry of the far pixels carried the near pixels' mass and a box
+//     sum of the far pixels was a small difference of large numbers.  Here the row direction of the table is
+//     reversed (entry (Y, X) = sum over rows <= Y and columns >= X): the large values no longer sit under the small
+//     boxes, and the exact fallback below is left for genuine outliers;
+//   * a batch of 64 candidates went through ~12 dependent LDS round trips with per-batch ballot loops for the resolve
+//     histogram: here the Reads boxes are read together, the histogram is kept per *width* with one ballot per width
+//     (converted to steps once per workgroup), the plan sits in LDS;
 //   * the scoring work list was appended with a returning global atomic that the tile's first wave waited for before
 //     the next tile could pass its first barrier: here the append of tile i is finished while tile i + 1 ends.
-#define HPK_SLIST 8000                      // tile-wide candidate list: TR * TC <= 64 * 125 entries
+// The code is written branch-free where the compiler would otherwise wrap every cell in its own exec-mask branch
+// (selects on the inputs instead of ifs around the arithmetic).
+#define HPK_TLIST 7680                      // tile-wide candidate list: TR * TC <= 64 * 119 entries (maxww >= 4)
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 constexpr unsigned OOB_OFF = 0x7ffffff0u;   // beyond every buffer's num_records (all < 2^31): the load returns 0
 
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
-__device__ __forceinline__ float ldbuf_f32(rsrc_t r, unsigned off) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+__device__ __forceinline__ float ldbuf_f32(rsrc_t r, unsigned off, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, (int)soff, 0));
 }
-__device__ __forceinline__ double ldbuf_f64(rsrc_t r, unsigned off) {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0));
+__device__ __forceinline__ double ldbuf_f64(rsrc_t r, unsigned off, unsigned soff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, (int)soff, 0));
+}
+// SAT row of a wave's j-th row: rows 0..2 in the upper part (3 per wave: SAT rows 0..47), rows 3..4 in the lower part
+// (2 per wave: SAT rows 48..79)
+__device__ __forceinline__ constexpr int sat_row(int wave, int j) { return j < 3 ? 3 * wave + j : 48 + 2 * wave + (j - 3); }
+
+// box sums on the column-reversed table P(Y, X) = sum over rows <= Y, columns >= X (hpk_stencil_s).
+// Lower-left box of capped raw counts at radius rho: rows (Y, Y + rho], columns [X - rho, X - 1]; sr = P(Y, X).
+__device__ __forceinline__ unsigned reads_box_m(const unsigned* __restrict__ Pr, int base, int rho, unsigned sr) {
+    const int b = base + rho * LC;
+    return (Pr[b - rho] - Pr[b] - Pr[base - rho] + sr) & PK_MASK;
+}
+// Four off-cross quadrants (donut support) and the lower-left quadrant at Chebyshev radius rho (per lane) around cell
+// `base` = Y * LC + X.  pixc: the pixel's own balanced value; sc = P(Y, X).
+__device__ __forceinline__ void box_ky_m(const double* __restrict__ P, int base, int rho, double pixc, double sc, double& kc, double& yc) {
+    const int t = base - (rho + 1) * LC, b = base + rho * LC, m0 = base - LC;
+    const double tl = P[t - rho], tm = P[t], tm1 = P[t + 1], tr = P[t + rho + 1];
+    const double bl = P[b - rho], bm = P[b], bm1 = P[b + 1], br = P[b + rho + 1];
+    const double ml1 = P[base - rho], ml0 = P[m0 - rho], mr1 = P[base + rho + 1], mr0 = P[m0 + rho + 1];
+    const double bot = (bl - bm) + (bm1 - br);          // rows <= Y + rho, columns [X - rho, X - 1] and [X + 1, X + rho]
+    const double top = (tl - tm) + (tm1 - tr);          // rows <= Y - rho - 1, same columns
+    const double mid = (ml1 - mr1) - (ml0 - mr0);       // row Y, columns [X - rho, X + rho]
+    kc = ((bot - top) - mid) + pixc;
+    yc = (bl - bm) - (ml1 - sc);
+}
+__device__ __noinline__ unsigned long long box_ky_valid_m(const unsigned* __restrict__ Pv, int base, int rho, unsigned pixv, unsigned sv) {
+    const int t = base - (rho + 1) * LC, b = base + rho * LC, m0 = base - LC;
+    const unsigned tl = Pv[t - rho], tm = Pv[t], tm1 = Pv[t + 1], tr = Pv[t + rho + 1];
+    const unsigned bl = Pv[b - rho], bm = Pv[b], bm1 = Pv[b + 1], br = Pv[b + rho + 1];
+    const unsigned ml1 = Pv[base - rho], ml0 = Pv[m0 - rho], mr1 = Pv[base + rho + 1], mr0 = Pv[m0 + rho + 1];
+    const unsigned kv = (bl - bm + bm1 - br) - (tl - tm + tm1 - tr) - (ml1 - mr1 - ml0 + mr0) + pixv;
+    const unsigned yv = bl - bm - ml1 + sv;
+    return (unsigned long long)(kv >> PK_SHIFT) | (unsigned long long)(yv >> PK_SHIFT) << 32;
+}
+
+// Explicit window sums of one pixel at one step (rare path of the stencil): taken when the summed-area table cannot
+// deliver ~1e-11 - the box sum is a difference of f64 prefix sums, so its absolute error is that of the largest
+// corner; a window of small values in a tile that also holds values hundreds of thousands of times larger (a badly
+// balanced bin, a count outlier) would come out with the large values' rounding noise.  The reference adds the
+// window cells themselves (callers.py:175-198) and has no such failure mode.  The whole wave works on one pixel: the
+// (2w + 1)^2 window cells are dealt to the 64 lanes (independent loads, one memory latency), then a wave reduction.
+// (r, c, m, Wm) are wave-uniform.  Returns (bS_K, bS_Y) in every lane.
+__device__ __noinline__ double2 explicit_sums_wave(const float* __restrict__ raw, const double* __restrict__ bal,
+                                                   const double* __restrict__ weight, const int32_t* __restrict__ m, int Wm,
+                                                   int r, int c, int n, int num, int64_t ld, int mw, int lane) {
+    while (Wm > 1 && m[Wm] == 0) --Wm;                  // the step's widest ring
+    const int side = 2 * Wm + 1, cells = side * side;
+    double sk = 0.0, sy = 0.0;
+    for (int idx = lane; idx < cells; idx += 64) {
+        const int di = idx / side - Wm, dj = idx - (di + Wm) * side - Wm;
+        const int adi = di < 0 ? -di : di, adj = dj < 0 ? -dj : dj;
+        const int rr = r + di, cc = c + dj, kk = cc - rr;
+        const bool in = di != 0 && dj != 0 && rr >= 0 && rr < n && cc >= 0 && cc < n && kk >= mw && kk < num;
+        if (!in) continue;
+        const int mm = m[adi > adj ? adi : adj];
+        double b;
+        if (bal) { b = bal[(int64_t)rr * ld + kk]; b = (b == b) ? b : 0.0; }
+        else b = balanced_of(raw[(int64_t)rr * ld + kk], weight[rr], weight[cc]);
+        const double v = (double)mm * b;
+        sk += v;
+        if (di > 0 && dj < 0) sy += v;
+    }
+    for (int off = 32; off > 0; off >>= 1) { sk += __shfl_xor(sk, off); sy += __shfl_xor(sy, off); }
+    return make_double2(sk, sy);
 }
 
 template <bool BALF64>
@@ -660,120 +734,118 @@ struct TileRegsS {
     double wrow;                        // weight mode: lane j (j < 5) holds the weight of the wave's row j
 };
 
+// Tile geometry of hpk_stencil_s.  SAT row Y <-> matrix row r0 - W - 1 + Y (row 0 is the table's origin row);
+// SAT column X <-> matrix column c0 - W + X (columns run the other way: X = 127 is the origin side).  Output pixel
+// (y, x) of the tile sits at (Y, X) = (y + W + 1, x + W).  Lane l holds the cells X = 127 - 2l (e = 0) and 126 - 2l
+// (e = 1) of each of its wave's rows, so that the wave scan runs from high to low columns.
 template <bool BALF64>
-__device__ __forceinline__ void tile_load_s(const HpkStencilArgs& a, int tid, int wave, int lane, TileRegsS<BALF64>& t) {
-    const int rb = tid / a.J, cj = tid - rb * a.J;
+__device__ __forceinline__ void tile_load_s(const HpkStencilArgs& a, int rb, int cj, int wave, int lane, TileRegsS<BALF64>& t) {
     const int r0 = rb * a.TR;
-    const int c0 = r0 + a.mw + cj * a.TC;
     const int rt0 = r0 - a.W - 1;                          // matrix row of SAT row 0 (negative in the first row block)
-    const int rb0 = rt0 > 0 ? rt0 : 0;                     // the buffer of this tile starts at this matrix row
+    const int rb0 = rt0 > 0 ? rt0 : 0;                     // the tile's buffer starts at this matrix row
     int rows = a.n - rb0;
-    rows = rows > 96 ? 96 : rows;                          // rows at or beyond n fall outside the buffer: they read 0
-    const int rr0 = rt0 + wave * 5;
-    const int cc0 = c0 - a.W - 1 + 2 * lane;
-    const int kb = cc0 - rr0;                              // diagonal of cell (row 0 of the wave, e = 0)
+    rows = rows > 96 ? 96 : rows;
     const unsigned ldu = (unsigned)a.ld;
-    // byte offset of cell (j = 0, e = 0) in the tile's buffer; negative rows wrap to offsets >= 2^31: out of range
-    const unsigned voff0 = ((unsigned)(rr0 - rb0) * ldu + (unsigned)kb) * 4u;
-    const unsigned rstep = (ldu - 1u) * 4u;                // one row down, same column: one diagonal less
+    const int koff = a.mw + cj * a.TC + 1;                 // diagonal of SAT cell (0, 0): (c0 - W) - (r0 - W - 1)
+    const int k4l = (koff + 127 - 2 * lane) * 4;           // byte offset within a band row of the lane's cell e = 0 at SAT row 0
     const rsrc_t rraw = make_rsrc(a.raw + (int64_t)rb0 * a.ld, (unsigned)rows * ldu * 4u);
-    bool cok[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) cok[e] = (unsigned)(cc0 + e) < (unsigned)a.n;
+    rsrc_t rbal = rraw;
+    if (BALF64) rbal = make_rsrc(a.bal + (int64_t)rb0 * a.ld, (unsigned)rows * ldu * 8u);
     if (!BALF64) {
         const rsrc_t rw = make_rsrc(a.weight, (unsigned)a.n * 8u);
+        const int cc0 = rt0 + koff + 127 - 2 * lane;       // matrix column of cell e = 0; columns < 0 or >= n read 0
 #pragma unroll
-        for (int e = 0; e < 2; ++e) t.wc[e] = ldbuf_f64(rw, (unsigned)(cc0 + e) * 8u);    // columns < 0 or >= n read 0
-        t.wrow = ldbuf_f64(rw, (unsigned)(rr0 + (lane & 7)) * 8u);
+        for (int e = 0; e < 2; ++e) t.wc[e] = ldbuf_f64(rw, (unsigned)(cc0 - e) * 8u, 0u);
+        const int jl = lane & 7;
+        const int Yl = jl < 3 ? 3 * wave + jl : 48 + 2 * wave + (jl - 3);
+        t.wrow = ldbuf_f64(rw, (unsigned)(rt0 + Yl) * 8u, 0u);
+    }
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < 5; ++j) {
+        const int Y = sat_row(wave, j);
+        const int rr = rt0 + Y;
+        // a cell holds data iff 0 <= k < lim: inside the stored diagonals and left of the matrix end (column r + k < n)
+        int lim = a.n - rr;
+        lim = lim < a.num ? lim : a.num;
+        const bool rowok = rr >= 0 && lim > 0;
+        const unsigned lim4 = (unsigned)__builtin_amdgcn_readfirstlane(rowok ? lim * 4 : 0);
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(rowok ? (int)((unsigned)(rr - rb0) * ldu * 4u) : 0);
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const bool ok = cok[e] && (unsigned)(kb + e - j) < (unsigned)a.num;
-                t.raw[j][e] = ldbuf_f32(rraw, ok ? voff0 + (unsigned)e * 4u + (unsigned)j * rstep : OOB_OFF);
-            }
-        }
-    } else {
-        const rsrc_t rbal = make_rsrc(a.bal + (int64_t)rb0 * a.ld, (unsigned)rows * ldu * 8u);
-#pragma unroll
-        for (int j = 0; j < 5; ++j) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int k = kb + e - j;
-                const bool ok = cok[e] && (unsigned)k < (unsigned)a.num;
-                const unsigned off = voff0 + (unsigned)e * 4u + (unsigned)j * rstep;
-                t.raw[j][e] = ldbuf_f32(rraw, ok ? off : OOB_OFF);
-                t.bal[j][e] = ldbuf_f64(rbal, (ok && k >= a.mw) ? off * 2u : OOB_OFF);
+        for (int e = 0; e < 2; ++e) {
+            const unsigned k4 = (unsigned)(k4l - 4 * e - 4 * Y);
+            t.raw[j][e] = ldbuf_f32(rraw, k4 < lim4 ? k4 : OOB_OFF, soff);
+            if (BALF64) {
+                const unsigned mw4 = (unsigned)a.mw * 4u;
+                const unsigned span = lim4 > mw4 ? lim4 - mw4 : 0u;
+                t.bal[j][e] = ldbuf_f64(rbal, (k4 - mw4) < span ? k4 * 2u : OOB_OFF, soff * 2u);
             }
         }
     }
 }
 
-// Explicit window sums of one pixel at one step (rare path of both stencil kernels): taken when the summed-area table
-// cannot deliver ~1e-11 - the box sum is a difference of f64 prefix sums, so its absolute error is that of the
-// largest corner; a window of small values in a tile that also holds values thousands of times larger (a badly
-// balanced bin, a count outlier) would come out with the large values' rounding noise.  The reference adds the
-// window cells themselves (callers.py:175-198) and has no such failure mode.
-__device__ __noinline__ double2 explicit_sums(const float* __restrict__ raw, const double* __restrict__ bal,
-                                              const double* __restrict__ weight, const int32_t* __restrict__ m, int W, int r, int c,
-                                              int n, int num, int64_t ld, int mw) {
-    double sk = 0.0, sy = 0.0;
-    for (int di = -W; di <= W; ++di) {
-        const int rr = r + di;
-        if (di == 0 || rr < 0 || rr >= n) continue;
-        const double wr = weight ? weight[rr] : 0.0;
-        for (int dj = -W; dj <= W; ++dj) {
-            if (dj == 0) continue;
-            const int adi = di < 0 ? -di : di, adj = dj < 0 ? -dj : dj;
-            const int mm = m[adi > adj ? adi : adj];
-            const int cc = c + dj, kk = cc - rr;
-            if (mm == 0 || cc < 0 || cc >= n || kk < mw || kk >= num) continue;
-            double b;
-            if (bal) { b = bal[(int64_t)rr * ld + kk]; b = (b == b) ? b : 0.0; }
-            else b = balanced_of(raw[(int64_t)rr * ld + kk], wr, weight[cc]);
-            const double v = (double)mm * b;
-            sk += v;
-            if (di > 0 && dj < 0) sy += v;
-        }
+// Persistent tile walk without divisions: local index k of the XCD's run -> (row block, column chunk), advanced by
+// the workgroups-per-XCD stride (see tile_of).
+struct TileWalk {
+    int k, rbk, ck, rm;                 // local index, row block, column chunk before rotation, row block mod J
+    int dk, dr, dc, drm;                // per step: index stride, its quotient and remainder by J, quotient mod J
+    __device__ __forceinline__ void init(const HpkStencilArgs& a) {
+        const int xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+        dk = (int)(gridDim.x >> 3);
+        dr = dk / a.J; dc = dk - dr * a.J; drm = dr % a.J;
+        k = j;
+        const int t = xcd * a.chunk + k;
+        rbk = t / a.J; ck = t - rbk * a.J; rm = rbk % a.J;
     }
-    return make_double2(sk, sy);
-}
+    __device__ __forceinline__ bool valid(const HpkStencilArgs& a) const {
+        return k < a.chunk && (int)(blockIdx.x & 7) * a.chunk + k < a.ntiles;
+    }
+    __device__ __forceinline__ int cj(const HpkStencilArgs& a) const {
+        if (a.order == 0) return ck;
+        const int c = ck + rm;
+        return c >= a.J ? c - a.J : c;
+    }
+    __device__ __forceinline__ void step(const HpkStencilArgs& a) {
+        k += dk; rbk += dr; ck += dc; rm += drm;
+        if (ck >= a.J) { ck -= a.J; rbk += 1; rm += 1; }
+        if (rm >= a.J) rm -= a.J;
+        if (rm >= a.J) rm -= a.J;
+    }
+};
 
 template <bool BALF64>
 __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     constexpr int NW = 16, RPW = 5;
-    static_assert(LR == NW * RPW && LC == 128, "tile geometry of the simple-plan kernel");
+    static_assert(LR == 80 && LC == 128, "tile geometry of the simple-plan kernel");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* __restrict__ Sc = reinterpret_cast<double*>(smem);
     unsigned* __restrict__ Sp = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 8);
-    unsigned* __restrict__ lst = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 12);
-    unsigned* __restrict__ wcnt = lst + HPK_SLIST;          // [16] candidates of each wave's rows in the current tile
+    unsigned* __restrict__ lst = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 12);      // [HPK_TLIST] tile-wide candidate list
+    unsigned* __restrict__ tcount = lst + HPK_TLIST;                  // [2] entries in the list, tiles alternate
     // the widening plan as the batches read it: per step 8 words {w0 (HpkDevPlan::packed[0]), four words of box terms},
-    // then step_of[slot][width] as bytes and the slots' first widths
-    unsigned* __restrict__ pl = wcnt + 64;                    // [HPK_MAX_STEPS][8]
+    // then step_of[slot][width] as bytes
+    unsigned* __restrict__ pl = tcount + 32;                          // [HPK_MAX_STEPS][8]
     unsigned char* __restrict__ stepof = reinterpret_cast<unsigned char*>(pl + HPK_MAX_STEPS * 8);   // [HPK_KSLOTS][32]
 
     const int lane_k = threadIdx.x & 63;
     const int wave_k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = lane_k, wave = wave_k;
     const int W = a.W, n = a.n, mw = a.mw, TR = a.TR, TC = a.TC;
     const int Dm = a.D < a.num - 1 ? a.D : a.num - 1;      // last diagonal that holds band pixels
 
-    // ---- plan in registers: lane s holds step s
     const HpkDevPlan* __restrict__ plan = a.plan;
     const int nsteps = plan->nsteps, nslots = plan->nslots;
     int maxnkt = 0;
     {
         int pk0 = 0;
-        if (lane < nsteps) pk0 = (int)plan->packed[lane][0];
-        if (wave == 0) {
-            if (lane < nsteps) {
-                const uint32_t* pk = plan->packed[lane];
-                pl[lane * 8 + 0] = pk[0]; pl[lane * 8 + 1] = pk[3]; pl[lane * 8 + 2] = pk[4]; pl[lane * 8 + 3] = pk[5];
-                pl[lane * 8 + 4] = pk[6];
+        if (lane_k < nsteps) pk0 = (int)plan->packed[lane_k][0];
+        if (wave_k == 0) {
+            if (lane_k < nsteps) {
+                const uint32_t* pk = plan->packed[lane_k];
+                pl[lane_k * 8 + 0] = pk[0]; pl[lane_k * 8 + 1] = pk[3]; pl[lane_k * 8 + 2] = pk[4]; pl[lane_k * 8 + 3] = pk[5];
+                pl[lane_k * 8 + 4] = pk[6];
             }
-            stepof[lane] = plan->step_of[lane >> 5][lane & 31];
-            stepof[64 + lane] = plan->step_of[2 + (lane >> 5)][lane & 31];
+            stepof[lane_k] = plan->step_of[lane_k >> 5][lane_k & 31];
+            stepof[64 + lane_k] = plan->step_of[2 + (lane_k >> 5)][lane_k & 31];
+            if (lane_k < 2) tcount[lane_k] = 0u;
         }
         for (int s = 0; s < nsteps; ++s) {
             const int k = (__builtin_amdgcn_readlane(pk0, s) >> 20) & 15;
@@ -794,158 +866,189 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
 
     HPK_CLK_DECL
     TileRegsS<BALF64> nxt;
-    int tid = tile_of(a, 0);
-    if (tid >= 0) tile_load_s<BALF64>(a, tid, wave, lane, nxt);
+    int par = 0;                        // which of the two list counters the current tile uses
+    TileWalk tw;
+    tw.init(a);
+    bool have = tw.valid(a);
+    int rb = tw.rbk, cj = tw.cj(a);
+    if (have) tile_load_s<BALF64>(a, rb, cj, wave_k, lane_k, nxt);
+    __syncthreads();                    // plan and counters in LDS
 #pragma unroll 1
-    for (int it = 0; tid >= 0; ++it) {
+    for (int it = 0; have; ++it) {
     // Everything below that depends only on (wave, lane) is the same for every tile, and the compiler would hoist it
-    // out of the tile loop - ten list-entry templates, row flags, compare constants: 100+ SGPRs and a dozen VGPRs
-    // that then spill to scratch, whose reloads (vmcnt(0)) also wait for the prefetch.  Opaque copies keep it in here.
+    // out of the tile loop - list-entry templates, row flags, compare constants: 100+ SGPRs and a dozen VGPRs that
+    // then spill to scratch, whose reloads (vmcnt(0)) also wait for the prefetch.  Opaque copies keep it in here.
     int wave = wave_k, lane = lane_k;
     asm volatile("" : "+s"(wave));
     asm volatile("" : "+v"(lane));
-    const int rb = tid / a.J, cj = tid - rb * a.J;
+    const int tid = rb * a.J + cj;
     const int r0 = rb * TR;
     const int c0 = r0 + mw + cj * TC;
     const bool empty_tile = c0 >= n || (mw + cj * TC - (TR - 1)) > a.D;       // no band pixel inside the matrix
-    const int tid_next = tile_of(a, it + 1);
+    tw.step(a);
+    const bool have_next = tw.valid(a);
+    const int rb_next = tw.rbk, cj_next = tw.cj(a);
     if (empty_tile) {
-        if (tid_next >= 0) tile_load_s<BALF64>(a, tid_next, wave, lane, nxt);
-        tid = tid_next;
+        if (have_next) tile_load_s<BALF64>(a, rb_next, cj_next, wave, lane, nxt);
+        have = have_next; rb = rb_next; cj = cj_next;
         continue;
     }
-    // ---- phase 1: balanced values, packed cells, column totals of this wave's five rows; candidate masks
-    const int xx0 = 2 * lane;
-    const int kb = (c0 - W - 1 + xx0) - (r0 - W - 1 + wave * RPW);      // diagonal of cell (j = 0, e = 0)
-    const int xo = xx0 - (W + 1);                                       // output column of cell e = 0
-    double balv[RPW][2];
-    unsigned pkv[RPW][2];
-    double tc[2] = {0.0, 0.0};
-    unsigned tp[2] = {0u, 0u};
-    int cnt = 0;                                                        // candidates in this wave's rows (uniform)
+    unsigned* __restrict__ tcnt = tcount + par;
+    // ---- phase 1: balanced values and packed cells of the wave's five rows, the candidates among them, and the SAT of
+    // the wave's own rows (row prefix by DPP scan, column prefix by running sums within each of the two row groups)
+    const int xx0 = 126 - 2 * lane;                                     // SAT column of the lane's cell e = 1 (e = 0: xx0 + 1)
+    const int kl = mw + cj * TC + 1 + xx0 + 1;                          // diagonal of the lane's cell e = 0 at SAT row 0
+    const int xo = xx0 + 1 - W;                                         // output column of cell e = 0 (e = 1: xo - 1)
+    double satc[RPW][2];
+    unsigned satp[RPW][2];
+    double ac[2] = {0.0, 0.0};
+    unsigned ar[2] = {0u, 0u};
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
+        const int Y = sat_row(wave, j);
         double wr = 0.0;
         if (!BALF64) wr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(nxt.wrow), j),
                                            __builtin_amdgcn_readlane(__double2loint(nxt.wrow), j));
-        const int y = wave * RPW + j - (W + 1);
+        const int y = Y - (W + 1);
         const bool rowout = (unsigned)y < (unsigned)TR && r0 + y < n;
+        if (j == 3) { ac[0] = 0.0; ac[1] = 0.0; ar[0] = 0u; ar[1] = 0u; }     // the lower row group starts its own sums
+        double bv[2];
+        unsigned pk[2];
+        // candidates of the row: the list slice is reserved now, the entries are written after the row's scan
+        unsigned long long M[2] = {0ull, 0ull};
+        unsigned entv[2] = {0u, 0u};
+        unsigned slot = 0u;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const float rv = nxt.raw[j][e];
-            const int k = kb + e - j;
-            double bv = 0.0;
-            if (BALF64) { bv = nxt.bal[j][e]; bv = (bv == bv) ? bv : 0.0; }
-            else if (k >= mw) bv = balanced_of(rv, wr, nxt.wc[e]);
-            balv[j][e] = bv;
-            pkv[j][e] = pack_cell((unsigned)rv, bv != 0.0);
-            tc[e] += bv;
-            tp[e] += pkv[j][e];
-            const bool cd = rowout && (pkv[j][e] & PK_MASK) != 0u && (unsigned)(xo + e) < (unsigned)TC && (unsigned)(k - mw) <= (unsigned)(Dm - mw);
-            cnt += __popcll(__ballot(cd));
+            float rv = nxt.raw[j][e];
+            const int km = kl - e - Y - mw;                               // diagonal - min(ww)
+            const unsigned ru = (unsigned)rv;
+            const unsigned rc = ru < HPK_PK_CAP ? ru : HPK_PK_CAP;
+            if (BALF64) {
+                bv[e] = fmax(nxt.bal[j][e], 0.0);                        // NaN -> 0 (counts x weights: never negative)
+            } else {
+                rv = km >= 0 ? rv : 0.f;                                // balanced values exist from diagonal min(ww) on
+                asm volatile("" : "+v"(rv));                            // (select on the f32, not on the converted f64)
+                bv[e] = fmax(((double)rv * wr) * nxt.wc[e], 0.0);       // (raw * w_r) * w_c, NaN -> 0
+            }
+            pk[e] = rc | (bv[e] != 0.0 ? 1u << PK_SHIFT : 0u);
+            if (rowout) {                                               // uniform
+                const bool cd = (ru != 0u) & ((unsigned)(xo - e) < (unsigned)TC) & ((unsigned)km <= (unsigned)(Dm - mw));
+                M[e] = __ballot(cd);
+                const unsigned yy = ((unsigned)(y >> 4) << 7) | ((unsigned)(y & 15) << (7 + HPK_YI_BITS));
+                entv[e] = (unsigned)(xo - e) | yy | (rc << 13);
+            }
+        }
+        if (rowout) {
+            // hipcc's atomic optimiser would wait for the returned value on the spot; issued by hand, the LDS round
+            // trip runs beside the row's scan (all lanes add the same count into the same word: lane 0 only)
+            const unsigned nrow = (unsigned)(__popcll(M[0]) + __popcll(M[1]));
+            const unsigned addr = (unsigned)(size_t)tcnt;
+            if (lane == 0) asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(slot) : "v"(addr), "v"(nrow) : "memory");
+        }
+        // row prefix of the two cells (cell e = 0 first), exclusive over the lanes
+        const double l1c = bv[0] + bv[1];
+        const unsigned l1r = pk[0] + pk[1];
+        double pc = l1c;
+        unsigned pr = l1r;
+        wave_exclusive_scan(pc, pr);
+        ac[0] += pc + bv[0]; ar[0] += pr + pk[0];
+        ac[1] += pc + l1c;   ar[1] += pr + l1r;
+        satc[j][0] = ac[0]; satc[j][1] = ac[1];
+        satp[j][0] = ar[0]; satp[j][1] = ar[1];
+        // the last row of a group = the group's column-wise total, already row-prefixed: what the groups below add
+        if (j == 2 || j == 4) {
+            const int o = (sat_row(wave, j) - (j == 2 ? 1 : 0)) * LC + xx0;     // parked in a row this wave owns
+            *reinterpret_cast<double2*>(&Sc[o]) = make_double2(ac[1], ac[0]);
+            *reinterpret_cast<uint2*>(&Sp[o]) = make_uint2(ar[1], ar[0]);
+        }
+        if (rowout) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(slot) :: "memory");
+        if (rowout && (M[0] | M[1]) != 0ull) {
+            // entries in the order of the scan (descending column): cell e = 0 of a lane, then its cell e = 1
+            const unsigned at = (unsigned)__builtin_amdgcn_readfirstlane((int)slot) +
+                                __builtin_amdgcn_mbcnt_hi((unsigned)(M[0] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M[0], 0u)) +
+                                __builtin_amdgcn_mbcnt_hi((unsigned)(M[1] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M[1], 0u));
+            const bool c0b = (M[0] >> lane) & 1ull, c1b = (M[1] >> lane) & 1ull;
+            if (c0b) lst[at] = entv[0];
+            if (c1b) lst[at + (c0b ? 1u : 0u)] = entv[1];
         }
     }
     HPK_CLK(ck0)
-    if (tid_next >= 0) tile_load_s<BALF64>(a, tid_next, wave, lane, nxt);
-    // column totals of this wave's rows -> LDS row 5 wave + 1 (inside the SAT rows this wave owns: nothing else lives there now)
-    *reinterpret_cast<double2*>(&Sc[(wave * RPW + 1) * LC + xx0]) = make_double2(tc[0], tc[1]);
-    *reinterpret_cast<uint2*>(&Sp[(wave * RPW + 1) * LC + xx0]) = make_uint2(tp[0], tp[1]);
-    if (lane == 0) wcnt[wave] = (unsigned)cnt;
+    // The next tile's rows start moving now.  Waves 0-7 run the group prefixes after the barrier and are the first to
+    // reach it (the SIMDs favour their older waves): they issue their loads before it, the others behind it, while
+    // they would otherwise wait for the prefixes.
+    if (have_next && wave < 8) tile_load_s<BALF64>(a, rb_next, cj_next, wave, lane, nxt);
     __syncthreads();
     HPK_CLK(ck1)
-    // ---- prefixes over the waves, all columns in parallel: this wave takes columns 8 wave .. 8 wave + 7, lane (g, c)
-    // the totals of waves 2g and 2g + 1; inclusive scan over g by shuffles, results to row 5 w of every wave w
-    {
-        const int c = lane & 7, g = lane >> 3, col = 8 * wave + c;
-        const double a0 = Sc[(10 * g + 1) * LC + col], a1 = Sc[(10 * g + 6) * LC + col];
-        const unsigned u0 = Sp[(10 * g + 1) * LC + col], u1 = Sp[(10 * g + 6) * LC + col];
-        double s = a0 + a1;
-        unsigned us = u0 + u1;
+    if (have_next && wave >= 8) tile_load_s<BALF64>(a, rb_next, cj_next, wave, lane, nxt);
+    // ---- exclusive prefixes over the 32 row groups (upper groups of waves 0..15, then lower groups), per column: plain
+    // sums.  Waves 0-3: the f64 plane, 32 columns each; waves 4-7: the packed plane.  Lanes 0-31 walk the 16 upper
+    // groups of their column, lanes 32-63 the 16 lower groups, which then add the upper total.  Group g of the upper
+    // part parked its total in SAT row 3g + 1 and gets its base in row 3g; lower part: total in row 48 + 2g + 1, base in
+    // row 48 + 2g.
+    if (wave < 8) {
+        const int col = (wave & 3) * 32 + (lane & 31);
+        const bool low = lane >= 32;
+        // (two passes over the column: holding the sixteen values would cost 32 VGPRs this kernel does not have)
+        if (wave < 4) {
+            double tot = 0.0;
 #pragma unroll
-        for (int st = 1; st <= 4; st <<= 1) {
-            const double t = __shfl_up(s, 8 * st);
-            const unsigned ut = __shfl_up(us, 8 * st);
-            if (g >= st) { s += t; us += ut; }
-        }
-        double ex = __shfl_up(s, 8);
-        unsigned uex = __shfl_up(us, 8);
-        if (g == 0) { ex = 0.0; uex = 0u; }
-        Sc[(10 * g) * LC + col] = ex;          Sp[(10 * g) * LC + col] = uex;
-        Sc[(10 * g + 5) * LC + col] = ex + a0;  Sp[(10 * g + 5) * LC + col] = uex + u0;
-    }
-    // ---- this wave's slice of the tile-wide candidate list: base = candidates of the waves before it
-    int lbase, total;
-    {
-        unsigned v = (lane < NW) ? wcnt[lane] : 0u;
-        v += dpp_u32<DPP_ROW_SHR1, 0xf>(v);
-        v += dpp_u32<DPP_ROW_SHR2, 0xf>(v);
-        v += dpp_u32<DPP_ROW_SHR4, 0xf>(v);
-        v += dpp_u32<DPP_ROW_SHR8, 0xf>(v);
-        total = __builtin_amdgcn_readlane((int)v, NW - 1);
-        lbase = wave > 0 ? __builtin_amdgcn_readlane((int)v, wave > 0 ? wave - 1 : 0) : 0;
-    }
-    if (cnt > 0) {
-        int pos = lbase;
+            for (int g = 0; g < 16; ++g) tot += Sc[(low ? 48 + 2 * g + 1 : 3 * g + 1) * LC + col];
+            double run = __shfl(tot, lane & 31);                 // the lower half starts from the upper half's total
+            run = low ? run : 0.0;
 #pragma unroll
-        for (int j = 0; j < RPW; ++j) {
-            const int y = wave * RPW + j - (W + 1);
-            const bool rowout = (unsigned)y < (unsigned)TR && r0 + y < n;
-            if (!rowout) continue;
-            bool cd[2];
-            unsigned long long M[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int k = kb + e - j;
-                cd[e] = (pkv[j][e] & PK_MASK) != 0u && (unsigned)(xo + e) < (unsigned)TC && (unsigned)(k - mw) <= (unsigned)(Dm - mw);
-                M[e] = __ballot(cd[e]);
+            for (int g = 0; g < 16; ++g) {
+                const double v = Sc[(low ? 48 + 2 * g + 1 : 3 * g + 1) * LC + col];
+                Sc[(low ? 48 + 2 * g : 3 * g) * LC + col] = run;
+                run += v;
             }
-            if ((M[0] | M[1]) == 0ull) continue;
-            // entries in column order: even columns (e = 0) and odd columns (e = 1) of the row interleave
-            const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(M[0] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M[0], 0u)) +
-                              (int)__builtin_amdgcn_mbcnt_hi((unsigned)(M[1] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M[1], 0u));
-            const unsigned yy = ((unsigned)(y >> 4) << 7) | ((unsigned)(y & 15) << (7 + HPK_YI_BITS));
-            if (cd[0]) lst[pos + below] = (unsigned)xo | yy | ((pkv[j][0] & PK_MASK) << 13);
-            if (cd[1]) lst[pos + below + (cd[0] ? 1 : 0)] = (unsigned)(xo + 1) | yy | ((pkv[j][1] & PK_MASK) << 13);
-            pos += __popcll(M[0]) + __popcll(M[1]);
+        } else {
+            unsigned tot = 0u;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) tot += Sp[(low ? 48 + 2 * g + 1 : 3 * g + 1) * LC + col];
+            unsigned run = __shfl(tot, lane & 31);
+            run = low ? run : 0u;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const unsigned v = Sp[(low ? 48 + 2 * g + 1 : 3 * g + 1) * LC + col];
+                Sp[(low ? 48 + 2 * g : 3 * g) * LC + col] = run;
+                run += v;
+            }
         }
     }
     __syncthreads();
     HPK_CLK(ck2)
-    // ---- phase 2: SAT of the rows above (row 5 wave), prefixed along the row, then the wave's own rows
-    double ac[2];
-    unsigned ar[2];
+    // ---- phase 2: add the groups' bases and store the SAT
     {
-        const double2 t = *reinterpret_cast<const double2*>(&Sc[(wave * RPW) * LC + xx0]);
-        const uint2 u = *reinterpret_cast<const uint2*>(&Sp[(wave * RPW) * LC + xx0]);
-        double pc = t.x + t.y; unsigned pr = u.x + u.y;
-        const double l1c = pc; const unsigned l1r = pr;
-        wave_exclusive_scan(pc, pr);
-        ac[0] = pc + t.x; ar[0] = pr + u.x;
-        ac[1] = pc + l1c; ar[1] = pr + l1r;
-    }
+        const int oa = sat_row(wave, 0) * LC + xx0, ob = sat_row(wave, 3) * LC + xx0;
+        const double2 ba = *reinterpret_cast<const double2*>(&Sc[oa]);
+        const uint2 ua = *reinterpret_cast<const uint2*>(&Sp[oa]);
+        const double2 bb = *reinterpret_cast<const double2*>(&Sc[ob]);
+        const uint2 ub = *reinterpret_cast<const uint2*>(&Sp[ob]);
 #pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-        const unsigned r0u = pkv[j][0], r1u = pkv[j][1];
-        const double c0v = balv[j][0], c1v = balv[j][1];
-        const double l1c = c0v + c1v; const unsigned l1r = r0u + r1u;
-        double pc = l1c; unsigned pr = l1r;
-        wave_exclusive_scan(pc, pr);
-        ac[0] += pc + c0v; ar[0] += pr + r0u;
-        ac[1] += pc + l1c; ar[1] += pr + l1r;
-        const int o = (wave * RPW + j) * LC + xx0;
-        *reinterpret_cast<double2*>(&Sc[o]) = make_double2(ac[0], ac[1]);
-        *reinterpret_cast<uint2*>(&Sp[o]) = make_uint2(ar[0], ar[1]);
+        for (int j = 0; j < RPW; ++j) {
+            const int o = sat_row(wave, j) * LC + xx0;
+            const double2 bs = j < 3 ? ba : bb;
+            const uint2 us = j < 3 ? ua : ub;
+            *reinterpret_cast<double2*>(&Sc[o]) = make_double2(satc[j][1] + bs.x, satc[j][0] + bs.y);
+            *reinterpret_cast<uint2*>(&Sp[o]) = make_uint2(satp[j][1] + us.x, satp[j][0] + us.y);
+        }
     }
     __syncthreads();
     HPK_CLK(ck3)
-    // gap rows (callers.py:238), as in hpk_stencil
-    if ((int)threadIdx.x < TR && r0 + (int)threadIdx.x < n) {
+    const int total = (int)*tcnt;
+    // gap rows (callers.py:238): rows of the tile's columns (the last tile of a row block: up to the end of its halo)
+    // without a non-zero balanced value - exact on the valid-count field
+    const int tx = wave * 64 + lane;             // (not threadIdx.x: its address arithmetic would be hoisted and spilled)
+    if (tx < TR && r0 + tx < n) {
         const bool last = (cj == a.J - 1) || (c0 + TC >= n) || (mw + (cj + 1) * TC - (TR - 1)) > a.D;
-        const int Y = (int)threadIdx.x + W + 1;
-        const int xe = last ? LC - 1 : W + TC, xs = W;
-        const unsigned rs = Sp[Y * LC + xe] - Sp[(Y - 1) * LC + xe] - Sp[Y * LC + xs] + Sp[(Y - 1) * LC + xs];
-        if ((rs >> PK_SHIFT) != 0u) a.gap[r0 + (int)threadIdx.x] = 1;
+        const int Y = tx + W + 1;
+        unsigned rs = Sp[Y * LC + W] - Sp[(Y - 1) * LC + W];
+        const int xe = last ? W : W + TC;        // last: nothing is taken off (the two reads below cancel)
+        rs -= last ? 0u : Sp[Y * LC + xe] - Sp[(Y - 1) * LC + xe];
+        if ((rs >> PK_SHIFT) != 0u) a.gap[r0 + tx] = 1;
     }
+    if (tx == 0) tcount[par ^ 1] = 0u;             // the next tile's counter (its atomics start after the barrier below)
     // ---- phase 3: batches of 64 candidates, dealt round-robin to the waves
     const int64_t tbase = (int64_t)tid * a.tilecap;
     unsigned* __restrict__ ent_t = a.rec_ent + tbase;
@@ -960,37 +1063,43 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         const unsigned id = lst[cand ? i : 0];
         const int x = (int)(id & 127u);
         const int y = (int)((id >> (7 + HPK_YI_BITS)) & 15u) + 16 * (int)((id >> 7) & ((1u << HPK_YI_BITS) - 1u));
-        const int base = (y + W + 1) * LC + W + 1 + x;
+        const int base = (y + W + 1) * LC + W + x;
         if (cand) ent_t[i] = id;
-        // one round of reads: S(Y, X-1) of both planes, the pixel's own value, the three Reads boxes that decide most
-        // candidates (p0: subtracted from all, narrowest, widest), the far corner of the widest window
-        const unsigned sr = Sp[base - 1];
-        const double sc = Sc[base - 1];
-        const double pixc = (Sc[base] - Sc[base - LC]) - (sc - Sc[base - LC - 1]);
-        const double amax = Sc[base + W * LC + W];
-        const unsigned b0 = (p0_p > 0) ? reads_box(Sp, base, p0_p, sr) : 0u;
-        const unsigned bf = reads_box(Sp, base, wmin_p, sr);
-        const unsigned bl = reads_box(Sp, base, W, sr);
+        // one round of reads: P(Y, X) of both planes, the pixel's own value, the three Reads boxes that decide most
+        // candidates (p0: subtracted from all, narrowest, widest), the largest corner of the widest window
+        const unsigned sr = Sp[base];
+        const double sc = Sc[base];
+        const double pixc = (sc - Sc[base + 1]) - (Sc[base - LC] - Sc[base - LC + 1]);
+        const double amax = Sc[base + W * LC - W];
+        const unsigned b0 = (p0_p > 0) ? reads_box_m(Sp, base, p0_p, sr) : 0u;
+        const unsigned bf = reads_box_m(Sp, base, wmin_p, sr);
+        const unsigned bl = reads_box_m(Sp, base, W, sr);
         int wstar = 255;
-        if (cand && bf - b0 >= (unsigned)minr_p) wstar = wmin_p;
-        else if (cand && bl - b0 >= (unsigned)minr_p) wstar = W;
+        wstar = (cand & (bl - b0 >= (unsigned)minr_p)) ? W : wstar;
+        wstar = (cand & (bf - b0 >= (unsigned)minr_p)) ? wmin_p : wstar;
         // lanes that pass the widest but not the narrowest box: all widths in between, four at a time (Reads is monotone)
         if (W - wmin_p > 1 && __ballot(wstar == W) != 0ull) {
 #pragma unroll 1
             for (int wa = wmin_p + 1; wa < W; wa += 4) {
                 unsigned rd[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) rd[t] = reads_box(Sp, base, (wa + t < W) ? wa + t : W - 1, sr);
+                for (int t = 0; t < 4; ++t) rd[t] = reads_box_m(Sp, base, (wa + t < W) ? wa + t : W - 1, sr);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    if (wa + t < W && wstar == W && rd[t] - b0 >= (unsigned)minr_p) wstar = wa + t;
+                    wstar = ((wa + t < W) & (wstar == W) & (rd[t] - b0 >= (unsigned)minr_p)) ? wa + t : wstar;
             }
         }
-        // resolve histogram by width: one ballot per width
+        // resolve histogram by width: one ballot per width present
+        {
+            const unsigned long long mf = __ballot(wstar == wmin_p);
+            if (lane == wmin_p) myhist += (unsigned)__popcll(mf);
+            if (__ballot((wstar != wmin_p) & (wstar != 255)) != 0ull) {
 #pragma unroll 1
-        for (int w = wmin_p; w <= W; ++w) {
-            const unsigned c = (unsigned)__popcll(__ballot(wstar == w));
-            if (lane == w) myhist += c;
+                for (int w = wmin_p + 1; w <= W; ++w) {
+                    const unsigned c = (unsigned)__popcll(__ballot(wstar == w));
+                    if (lane == w) myhist += c;
+                }
+            }
         }
         // ---- sums at the resolving step, once per slot
 #pragma unroll 1
@@ -998,7 +1107,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
             const int wf = (q == 0) ? wf_q[0] : (q == 1) ? wf_q[1] : (q == 2) ? wf_q[2] : wf_q[3];
             const int wq = wstar > wf ? wstar : wf;
             int sq = (int)stepof[q * 32 + (wq & 31)];
-            if (wstar == 255) sq = 0xff;
+            sq = wstar == 255 ? 0xff : sq;
             const bool act = sq != 0xff;
             double SK = 0.0, SY = 0.0;
             if (__ballot(act) != 0ull) {
@@ -1017,35 +1126,45 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
                     const int rho = on ? (int)(t & 0xffu) : 1;      // idle lanes read a harmless box
                     const double cf = on ? (double)(int)(signed char)(t >> 8) : 0.0;
                     double kc, yc;
-                    box_ky(Sc, base, rho, pixc, sc, kc, yc);
+                    box_ky_m(Sc, base, rho, pixc, sc, kc, yc);
                     SK += cf * kc; SY += cf * yc;
                 }
                 // lower-left support off the band: exact 0 (see hpk_stencil)
                 const int d = c0 + x - (r0 + y);
-                if (d - (int)((w0 >> 24) & 31u) - 1 < mw) SY = 0.0;
+                SY = (d - (int)((w0 >> 24) & 31u) - 1 < mw) ? 0.0 : SY;
                 // Sums that are small against the largest corner of the window's table entries carry that corner's
-                // rounding noise: below 2^-13 of it they are redone exactly - 0 when no contributing cell is non-zero
-                // (valid-count plane), otherwise by adding the window cells themselves.
-                const double thr = amax * 0x1p-13;
-                const bool risky = act && (SK < thr || (SY < thr && SY != 0.0));
+                // rounding noise (relative error of the sum ~ 1e-15 x corner / sum): below 2^-16 of it they are redone
+                // exactly - 0 when no contributing cell is non-zero (valid-count plane), otherwise by adding the window
+                // cells themselves.
+                const double thr = amax * 0x1p-16;
+                const bool risky = act & ((SK < thr) | ((SY < thr) & (SY != 0.0)));
                 if (__ballot(risky) != 0ull) {
+#ifdef HPK_PHASE_CLOCK
+                    ck6 += (unsigned long long)__popcll(__ballot(risky && SK > 0.0)) << 40;
+#endif
                     if (risky) {
-                        const unsigned pv = Sp[base] - Sp[base - LC] - sr + Sp[base - LC - 1];
+                        const unsigned pv = sr - Sp[base + 1] - Sp[base - LC] + Sp[base - LC + 1];
                         unsigned VK = 0u, VY = 0u;
 #pragma unroll 1
                         for (int j = 0; j < nkt; ++j) {
                             const unsigned kw = (j < 2) ? k0 : (j < 4) ? k1 : (j < 6) ? k2 : k3;
                             const unsigned t = (kw >> (16 * (j & 1))) & 0xffffu;
-                            const unsigned long long kyv = box_ky_valid(Sp, base, (int)(t & 0xffu), pv, sr);
+                            const unsigned long long kyv = box_ky_valid_m(Sp, base, (int)(t & 0xffu), pv, sr);
                             VK += (unsigned)(int)(signed char)(t >> 8) * (unsigned)kyv;
                             VY += (unsigned)(int)(signed char)(t >> 8) * (unsigned)(kyv >> 32);
                         }
-                        if (VK != 0u) {
-                            const bool keepy = SY == 0.0;           // exact by construction (support off the band)
-                            const double2 ex = explicit_sums(a.raw, a.bal, a.weight, plan->steps[sq].m, W, r0 + y, c0 + x, n, a.num, a.ld, mw);
-                            SK = ex.x;
-                            if (!keepy) SY = (VY == 0u) ? 0.0 : ex.y;
-                        } else { SK = 0.0; SY = 0.0; }
+                        if (VK == 0u) { SK = 0.0; SY = 0.0; }
+                        else if (VY == 0u) SY = 0.0;
+                    }
+                    // what is left has non-zero cells: one pixel at a time, the whole wave on it
+                    unsigned long long todo = __ballot(risky && SK != 0.0);
+                    while (todo != 0ull) {
+                        const int src = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1ull;
+                        const int er = __builtin_amdgcn_readlane(r0 + y, src), ec = __builtin_amdgcn_readlane(c0 + x, src);
+                        const int es = __builtin_amdgcn_readlane(sq, src);
+                        const double2 ex = explicit_sums_wave(a.raw, a.bal, a.weight, plan->steps[es].m, W, er, ec, n, a.num, a.ld, mw, lane);
+                        if (lane == src) { SK = ex.x; SY = (SY == 0.0) ? 0.0 : ex.y; }   // SY == 0: exact by construction or no non-zero cell
                     }
                 }
             }
@@ -1075,8 +1194,10 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         }
         if (lane == 0) { a.tile_cnt[tid] = (unsigned)total; mycand += (unsigned)total; }
     }
-    tid = tid_next;
+    have = have_next; rb = rb_next; cj = cj_next;
+    par ^= 1;
     }   // tile loop
+    const int lane = lane_k, wave = wave_k;
     if (wave == 0 && pend_tid >= 0) {
         const unsigned nu = (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT;
         const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)pend_off);
@@ -1835,7 +1956,7 @@ static void launch_stencil_t(const HpkStencilArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(a.grid), dim3(NW * 64), hpk_stencil_lds_bytes(), st, a, a.raw, a.bal, a.weight, a.rec_S, a.rec_W);
 }
 
-int hpk_stencil_s_lds_bytes() { return LR * LC * 12 + HPK_SLIST * 4 + 256 + HPK_MAX_STEPS * 32 + HPK_KSLOTS * 32; }
+int hpk_stencil_s_lds_bytes() { return LR * LC * 12 + HPK_TLIST * 4 + 128 + HPK_MAX_STEPS * 32 + HPK_KSLOTS * 32; }
 
 template <bool BALF64>
 static void launch_stencil_s_t(const HpkStencilArgs& a, hipStream_t st) {
@@ -1852,8 +1973,8 @@ static void launch_stencil_s_t(const HpkStencilArgs& a, hipStream_t st) {
 // Simple-Reads plans within the buffer-addressing limits of hpk_stencil_s (32-bit byte offsets inside one tile's rows,
 // weights addressed from element 0) go to the second-generation kernel; everything else to hpk_stencil.
 bool hpk_stencil_s_applies(const HpkStencilArgs& a, bool simple) {
-    static const bool off = std::getenv("HPK_OLD_STENCIL") != nullptr || std::getenv("HPK_NEW_STENCIL") == nullptr;
-    return simple && !off && HPK_NWAVES == 16 && a.ld <= (int64_t)(1 << 21) && a.n < (1 << 27) && a.TR * a.TC <= HPK_SLIST;
+    static const bool off = std::getenv("HPK_OLD_STENCIL") != nullptr;
+    return simple && !off && HPK_NWAVES == 16 && a.ld <= (int64_t)(1 << 21) && a.n < (1 << 27) && a.W >= 4 && a.TR * a.TC <= HPK_TLIST;
 }
 
 void hpk_launch_stencil(const HpkStencilArgs& a, bool balf64, bool simple, hipStream_t st) {

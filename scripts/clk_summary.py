@@ -5,7 +5,10 @@ totals + two barriers, (2) scans + SAT stores, (3) barrier, (4) gap rows + candi
 (6) end-of-tile barrier, and (7) the number of batches.  s_memtime ticks at 100 MHz on gfx950."""
 import sys
 import numpy as np
-a = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 16, 8).astype(np.float64)
+raw = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 16, 8)
+risky = (raw[:, :, 6] >> np.uint64(40)).astype(np.float64)      # hpk_stencil_s: candidates redone exactly, in the high bits
+raw[:, :, 6] &= np.uint64((1 << 40) - 1)
+a = raw.astype(np.float64)
 names = ['wait+phase1', 'prefetch+coltot', 'scan+write', 'barrier(SAT)', 'gap+lists', 'batches', 'barrier(end)']
 tot = a[:, :, :7].sum(axis=2)
 print('workgroups %d; ticks per wave: mean %.0f  min %.0f  max %.0f' % (a.shape[0], tot.mean(), tot.min(), tot.max()))
@@ -19,3 +22,4 @@ print('batches per wave: mean %.1f; per-WG sum min %d max %d mean %.0f' % (nb.me
 wg = a[:, :, 5].mean(axis=1)
 print('batch-phase ticks per WG, deciles:', np.percentile(wg, [0, 10, 25, 50, 75, 90, 100]).round(0).tolist())
 print('ticks per batch (sum batches-phase / sum batches): %.1f' % (a[:, :, 5].sum() / max(nb.sum(), 1)))
+print('candidates redone exactly (hpk_stencil_s): %d, per-WG max %d' % (risky.sum(), risky.sum(axis=1).max()))
