@@ -910,7 +910,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         if (!BALF64) wr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(nxt.wrow), j),
                                            __builtin_amdgcn_readlane(__double2loint(nxt.wrow), j));
         const int y = Y - (W + 1);
-        const bool rowout = (unsigned)y < (unsigned)TR && r0 + y < n;
+        const bool rowout = (unsigned)y < (unsigned)TR;         // (rows at or beyond n read 0: no candidates there)
         if (j == 3) { ac[0] = 0.0; ac[1] = 0.0; ar[0] = 0u; ar[1] = 0u; }     // the lower row group starts its own sums
         double bv[2];
         unsigned pk[2];
