@@ -65,8 +65,8 @@ def make_band_host(cfg, seed, n=None):
     return raw, weight, IR, biases, num
 
 
-def cpu_baseline(cfg, rows):
-    """Oracle on a row sample of the same workload; returns px/s on one core."""
+def cpu_baseline(cfg, rows, allcores_rows=0):
+    """Oracle on a row sample of the same workload: px/s on one core, and (allcores_rows > 0) on all host cores."""
     from oracle import hiccups_oracle as orc
     from hicpeaks_amd import band
     raw, weight, IR, biases, num = make_band_host(cfg, seed=12345, n=rows)
@@ -79,9 +79,45 @@ def cpu_baseline(cfg, rows):
                 onlyanchor=False)
     t2 = time.perf_counter()
     px = band.band_pixels(rows, num, mw, cfg['maxapart'] // cfg['res']) * len(cfg['pw'])
-    return dict(value=px / (t2 - t1), unit='band px/s', cores=1, kind='port',
-                sample='%d-row slice of the workload (%d band px), numpy oracle hiccups() %.1f s (+%.1f s prep)' % (
-                    rows, px, t2 - t1, t1 - t0))
+    out = dict(value=px / (t2 - t1), unit='band px/s', cores=1, kind='port',
+               sample='%d-row slice of the workload (%d band px), numpy oracle hiccups() %.1f s (+%.1f s prep)' % (
+                   rows, px, t2 - t1, t1 - t0))
+    if allcores_rows > 0:
+        out['all_cores'] = cpu_baseline_all_cores(cfg, allcores_rows)
+    return out
+
+
+def _cpu_worker(job):
+    """One host core: the oracle on its own synthetic chromosome slice (like one worker of the reference's Pool.map over
+    chromosomes, scripts/pyHICCUPS:192-198).  -> (band px, seconds)"""
+    cfg, rows, seed = job
+    os.environ['OMP_NUM_THREADS'] = '1'
+    from oracle import hiccups_oracle as orc
+    from hicpeaks_amd import band
+    raw, weight, IR, biases, num = make_band_host(cfg, seed=seed, n=rows)
+    mw = min(cfg['ww'])
+    t0 = time.perf_counter()
+    IRo, cband, b = orc.prep_from_band(raw, weight, mw)
+    orc.hiccups(raw, cband, b, b, IRo, rows, num, pw=cfg['pw'], ww=cfg['ww'], maxww=cfg['maxww'], sig=SIG,
+                maxapart=cfg['maxapart'], res=cfg['res'], min_local_reads=MIN_READS, min_marginal_peaks=2,
+                onlyanchor=False)
+    return band.band_pixels(rows, num, mw, cfg['maxapart'] // cfg['res']) * len(cfg['pw']), time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(cfg, rows):
+    """Every host core at once, one process per core, each on its own `rows`-row slice: aggregate px/s with the core count
+    stated."""
+    import multiprocessing as mp
+    nproc = min(os.cpu_count() or 1, 64)
+    t0 = time.perf_counter()
+    with mp.get_context('spawn').Pool(nproc) as pool:
+        res = pool.map(_cpu_worker, [(cfg, rows, 777 + i) for i in range(nproc)])
+    wall = time.perf_counter() - t0
+    px = sum(r[0] for r in res)
+    busy = max(r[1] for r in res)
+    return dict(value=px / busy, unit='band px/s', cores=nproc, kind='port',
+                sample='%d processes x %d-row slices (%d band px in all), slowest worker %.1f s, wall incl. start-up %.1f s' % (
+                    nproc, rows, px, busy, wall))
 
 
 def run_genome(args, cfg, ctx, rank, world, local, dist):
@@ -158,7 +194,7 @@ def run_genome(args, cfg, ctx, rank, world, local, dist):
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': cfg['workload'], 'name': args.config, 'band_px_per_step': px_genome,
-                       'chromosomes': len(sizes), 'chromosomes_rank0': len(mine), 'pipeline_depth': depth,
+                       'chromosomes': len(sizes), 'chromosomes_rank0': len(mine), 'pipeline_depth': depth, 'ranks_seen': args.ranks_seen,
                        'candidates_rank0': int(sum(t[2] for t in last)),
                        'significant_px_rank0': int(sum(t[3] for t in last)),
                        'parallelism': 'chromosomes dealt largest-first to the GPUs, no collective',
@@ -172,11 +208,40 @@ def run_genome(args, cfg, ctx, rank, world, local, dist):
         dist.destroy_process_group()
 
 
+def launch_plan(gpus, env, ngpus_visible):
+    """What `--gpus N` means for this process (no side effects; unit-tested on CPU):
+       ('run',)            go ahead as the rank the environment describes (or as the only one),
+       ('spawn', port)     N > 1 and not under torchrun: re-launch as N ranks,
+       ('error', message)  the request cannot be honoured - never run fewer GPUs than asked for."""
+    world = int(env.get('WORLD_SIZE', '0') or 0)
+    if ngpus_visible <= 0:
+        return ('error', 'needs an MI355X: there is no CPU path')
+    if world > 0:                                   # under torchrun (the driver's launch line for N > 1)
+        if world != gpus:
+            return ('error', '--gpus %d but WORLD_SIZE=%d' % (gpus, world))
+        if ngpus_visible < (1 if env.get('HPK_BENCH_ONE_GPU') else min(world, 8)):
+            return ('error', '%d rank(s) but only %d GPU(s) visible' % (world, ngpus_visible))
+        return ('run',)
+    if gpus <= 1:
+        return ('run',)
+    if ngpus_visible < gpus:
+        return ('error', '--gpus %d but only %d GPU(s) visible' % (gpus, ngpus_visible))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    return ('spawn', port)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=0,
+                    help='chromosomes per step: a step scores a batch of this many chromosome-sized bands one after the other '
+                         '(default: 100 for the single-chromosome configurations, so that 20 steps keep the GPU busy for ~0.5 s '
+                         'and the clocks settle; 1 for the whole-genome configurations, whose step is the 23-chromosome genome)')
     ap.add_argument('--config', default='chr1_10kb', choices=sorted(CONFIGS))
     ap.add_argument('--cpu-rows', type=int, default=1 << 30,
                     help='rows of the CPU-baseline sample (default: the whole workload, ~8 s on one core; 0 = skip)')
@@ -188,22 +253,36 @@ def main():
     ap.add_argument('--host-inputs', action='store_true',
                     help='hand the band over as host (numpy) arrays every step: the PCIe-inclusive rate of DESIGN.md, never `value`')
     ap.add_argument('--stencil-only', action='store_true', help='time the stencil kernel alone (HPK_FLAG_NO_SCORE)')
+    ap.add_argument('--cpu-allcores-rows', type=int, default=3000,
+                    help='rows per process of the all-cores CPU baseline leg (0 = skip)')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
     import torch
+    plan = launch_plan(args.gpus, os.environ, torch.cuda.device_count() if torch.cuda.is_available() else 0)
+    if plan[0] == 'error':
+        raise SystemExit('bench.py: ' + plan[1])
+    if plan[0] == 'spawn':          # `python bench.py --gpus N` by hand: become N ranks, one per GPU
+        import subprocess
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(plan[1]), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: there is no CPU path')
     torch.cuda.set_device(local)
     dist = None
+    ranks_seen = 1
     if world > 1 or os.environ.get('HPK_BENCH_FORCE_DIST'):     # the env knob exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         dist.init_process_group('nccl', rank=rank, world_size=world)
+        ones = torch.ones(1, dtype=torch.int32, device=torch.device('cuda', local))
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        assert ranks_seen == world, 'all-reduce saw %d ranks of %d' % (ranks_seen, world)
+    args.ranks_seen = ranks_seen
 
     from hicpeaks_amd import _lib, band, bandgen
     ctx = _lib.Context(local)
@@ -276,10 +355,11 @@ def main():
             stencil_ms.append(done[-1].timing['stencil'])
         return done
 
+    batch = args.batch if args.batch > 0 else (100 if n * num <= 60_000_000 else 4)
     stencil_ms = []
     R = None
     run(depth)              # set-up, not a step: every lane allocates its workspaces (GBs on the large configurations) once
-    for R in run(args.warmup):
+    for R in run(args.warmup * batch):
         pass
 
     def barrier():
@@ -290,10 +370,10 @@ def main():
     barrier()
     del stencil_ms[:]
     t0 = time.perf_counter()
-    results = run(args.steps)
+    results = run(args.steps * batch)
     barrier()
     elapsed = time.perf_counter() - t0
-    assert len(stencil_ms) == args.steps
+    assert len(stencil_ms) == args.steps * batch
     stencil_ms = list(stencil_ms)
     R = results[-1]
     # outside the timed region: latency of one synchronous call (submit + collect), then a few calls with the per-phase
@@ -317,18 +397,27 @@ def main():
         st = float(np.mean(stencil_ms))
         achieved = BYTES_PER_PX * px_per_step / (st * 1e-3) / 1e9
         out = {
-            'metric': 'band pixels scored/sec (donut+LL)', 'value': world * px_per_step * args.steps / elapsed,
+            'metric': 'band pixels scored/sec (donut+LL)', 'value': world * px_per_step * batch * args.steps / elapsed,
             'unit': 'band px/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': cfg['workload'], 'name': args.config, 'band_px_per_step': px_per_step,
+            'config': {'workload': cfg['workload'], 'name': args.config, 'band_px_per_step': px_per_step * batch,
+                       'chromosomes_per_step': batch, 'band_px_per_chromosome': px_per_step,
+                       'ms_per_chromosome': ms_step / batch, 'ranks_seen': args.ranks_seen,
                        'candidates': R.ncand, 'significant_px': int(sum(s['x'].size for s in R.sets)),
                        'px_with_p_le_sig': R.nsurv_sig, 'records_copied_back': R.nsurv_cut,
                        'parallelism': 'one chromosome per GPU, no collective', 'pipeline_depth': depth,
                        'sync_call_ms': float(np.median(lat)),
                        'stencil_only': bool(args.stencil_only), 'host_inputs': bool(args.host_inputs), 'balanced_f64': bool(args.balanced_f64)},
-            'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                         'kernel_ms': st, 'algorithmic_bytes_per_launch': BYTES_PER_PX * px_per_step},
+            # frac: SURVEY.md §8-D3 convention, 20 B per band pixel per pair (4 B read + 2 x 8 B local expected written).  The
+            # kernel writes compact records for the candidates only, so two more figures keep the books honest:
+            # compact_4Bpx (the §8-D3 figure for a compacting mode: the 4 B/px that must be read) and hbm_frac_measured
+            # (counter traffic per launch / kernel time / peak - what the memory system actually carries).
+            'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil_s' if R.stencil_kernel == 2 else 'hpk_stencil', 'achieved': achieved,
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'kernel_ms': st, 'algorithmic_bytes_per_launch': BYTES_PER_PX * px_per_step,
+                         'compact_4Bpx': {'achieved': 4.0 * px_per_step / (st * 1e-3) / 1e9,
+                                          'frac': 4.0 * px_per_step / (st * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         'hbm_frac_measured': None},
             'phases_ms': {k: float(v) for k, v in R.timing.items()},
         }
         try:        # HBM traffic per launch of the dominant kernel, measured off-line with rocprofv3 --pmc (profiles/)
@@ -336,10 +425,11 @@ def main():
             if tr:
                 out['roofline']['traffic'] = tr['traffic_bytes']
                 out['roofline']['traffic_source'] = tr['source']
+                out['roofline']['hbm_frac_measured'] = tr['traffic_bytes'] / (st * 1e-3) / 1e9 / HBM_PEAK_GBS
         except Exception:
             pass
         if world == 1 and args.cpu_rows > 0:
-            out['cpu_baseline'] = cpu_baseline(cfg, min(args.cpu_rows, n))
+            out['cpu_baseline'] = cpu_baseline(cfg, min(args.cpu_rows, n), args.cpu_allcores_rows)
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

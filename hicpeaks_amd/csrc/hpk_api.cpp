@@ -426,7 +426,7 @@ struct hpk_job {
     size_t off_rowlive = 0, off_inl = 0, head_bytes = 0, off_cnt = 0, off_cu = 0, dense_elems = 0;
     int64_t cap = 0, band_px = 0, ldo = 0;
     int nsets = 0, TR = 0, TC = 0, rounds = 2;
-    bool sums = false, dense = false, do_score = true, phases = false;
+    bool sums = false, dense = false, do_score = true, phases = false, simple = false;
     double t_begin = 0.0;
     ResultBox* box = nullptr;
     ~hpk_job() { delete box; }
@@ -645,7 +645,8 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     }
 #endif
     (void)hipEventRecord(L.ev[1], c->stream);
-    hpk_launch_stencil(sa, in.bal != nullptr, plan.simple_reads != 0 && !std::getenv("HPK_GENERIC_SEARCH"), c->stream);
+    j->simple = plan.simple_reads != 0 && !std::getenv("HPK_GENERIC_SEARCH");
+    hpk_launch_stencil(sa, in.bal != nullptr, j->simple, c->stream);
     HIPCHK(c, hipGetLastError());
     (void)hipEventRecord(L.ev[2], c->stream);
     hpk_launch_freeze(sa.plan, d_hist, sa.hist_part, sa.grid, d_frozen, d_exec, d_err, c->stream);
@@ -690,6 +691,7 @@ int collect_impl(hpk_ctx* c, hpk_job* j, hpk_result** out) {
     for (int r = 0; r < n; ++r) box->gap[r] = hsmall[off_rowlive + r] ? 0 : 1;
     R.band_px = j->band_px;
     R.stencil_tiles = sa.ntiles;
+    R.stencil_kernel = hpk_stencil_s_applies(sa, j->simple) ? 2 : 1;
 
     // ---- results to host
     const unsigned long long* h_hist = reinterpret_cast<const unsigned long long*>(hsmall + OFF_HIST);

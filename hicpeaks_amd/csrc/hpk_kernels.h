@@ -126,6 +126,7 @@ struct HpkBruteArgs {
 
 int  hpk_stencil_lds_bytes();
 void hpk_launch_stencil(const HpkStencilArgs& a, bool balf64, bool simple, hipStream_t st);
+bool hpk_stencil_s_applies(const HpkStencilArgs& a, bool simple);   // the second-generation kernel takes this launch
 void hpk_launch_dense(const HpkDenseArgs& a, hipStream_t st);
 void hpk_launch_probe(const HpkDenseArgs& a, const int32_t* rows, const int32_t* cols, int64_t count, double* out, hipStream_t st);
 void hpk_launch_freeze(const HpkDevPlan* plan, unsigned long long* hist, const unsigned* hist_part, int nparts,

@@ -149,7 +149,8 @@ typedef struct {
 
     /* timing, milliseconds (HIP events on the ctx stream; wall for host parts) */
     float ms_h2d, ms_stencil, ms_freeze, ms_score, ms_tighten, ms_gap, ms_d2h, ms_host_bh, ms_total;
-    float reserved_f[3];
+    int32_t stencil_kernel;    /* stencil kernel that ran: 1 = first generation, any plan; 2 = second generation, simple-Reads plans */
+    float reserved_f[2];
     int64_t nsurv_sig;         /* pixels with p <= sig (before the BH cut is tightened on the device) */
     int64_t nsurv_cut;         /* of those, how many were copied back for the final Benjamini-Hochberg step */
     int64_t stencil_tiles;

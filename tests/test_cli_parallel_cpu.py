@@ -106,3 +106,21 @@ def test_run_sharded_batch_fn_single_rank():
     out = parallel.run_sharded(sizes, None, 0, 1, batch_fn=batch)
     assert seen == [parallel.lpt_partition(sizes, 1)[0]]
     assert out == {c: {'chrom': c} for c in sizes}
+
+
+def test_bench_gpus_flag_is_honoured_or_refused():
+    """bench.py --gpus N: never a silent single-GPU run.  launch_plan() is the whole decision."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench', os.path.join(REPO, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    lp = bench.launch_plan
+    assert lp(1, {}, 1) == ('run',)
+    assert lp(1, {}, 0)[0] == 'error'                                   # no GPU: there is no CPU path
+    kind, port = lp(8, {}, 8)                                           # by hand on an 8-GPU node: become 8 ranks
+    assert kind == 'spawn' and 1024 < port < 65536
+    assert lp(2, {}, 1)[0] == 'error' and 'only 1 GPU' in lp(2, {}, 1)[1]   # 1-GPU box: refuse, do not print n_gpus: 1
+    assert lp(8, {'WORLD_SIZE': '8', 'RANK': '3'}, 8) == ('run',)      # the driver's torchrun line
+    assert lp(8, {'WORLD_SIZE': '4'}, 8)[0] == 'error'                  # flag and launcher disagree
+    assert lp(4, {'WORLD_SIZE': '4'}, 2)[0] == 'error'                  # more ranks than GPUs
+    assert lp(1, {'WORLD_SIZE': '1'}, 1) == ('run',)
