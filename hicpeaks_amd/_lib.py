@@ -32,7 +32,7 @@ ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_EMPTY_STEP, ERR_PLAN, ERR_NOMEM, ERR_BU
 ABI_SYMBOLS = ['hpk_create', 'hpk_destroy', 'hpk_last_error', 'hpk_abi_version', 'hpk_score_band',
                'hpk_pipeline_depth', 'hpk_submit_band', 'hpk_collect',
                'hpk_result_free', 'hpk_plan_rings', 'hpk_chunk_bounds', 'hpk_set_chunk_bounds',
-               'hpk_device_info', 'hpk_poisson_sf', 'hpk_bruteforce_sums', 'hpk_probe_sums']
+               'hpk_device_info', 'hpk_poisson_sf', 'hpk_bruteforce_sums', 'hpk_probe_sums', 'hpk_band_from_coo']
 
 
 class HpkError(RuntimeError):
@@ -145,6 +145,9 @@ def load():
     lib.hpk_probe_sums.argtypes = [C.c_void_p, C.POINTER(Band), C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_int64,
                                    C.c_void_p]
     lib.hpk_probe_sums.restype = C.c_int
+    lib.hpk_band_from_coo.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                                      C.c_int64, C.c_void_p]
+    lib.hpk_band_from_coo.restype = C.c_int64
     _lib = lib
     return lib
 

@@ -9,16 +9,22 @@ import numpy as np
 
 
 def band_from_coo(i, j, v, n, num, dtype=np.float32):
-    """Upper-triangle pixels (i <= j) -> dense band raw[r, k] = count of (r, r + k); pixels beyond the band are dropped.
-    Replaces `Diags = [H.diagonal(i) for i in range(num)]` (pyHICCUPS:147)."""
-    i = np.asarray(i, dtype=np.int64)
-    j = np.asarray(j, dtype=np.int64)
-    lo, hi = np.minimum(i, j), np.maximum(i, j)
-    k = hi - lo
-    keep = k < num
-    raw = np.zeros((n, num), dtype=dtype)
-    np.add.at(raw, (lo[keep], k[keep]), np.asarray(v)[keep])
-    return raw
+    """Pixels (i, j, count) of one chromosome, each listed once in either orientation (cooler's pixel table lists the
+    upper triangle) -> dense band raw[r, k] = count of (r, r + k); pixels beyond the band are dropped, repeats add up.
+    Replaces `Diags = [H.diagonal(i) for i in range(num)]` (pyHICCUPS:147): one O(nnz) pass in the C library
+    (`hpk_band_from_coo`, host-only) instead of O(num * nnz)."""
+    from . import _lib
+    i = np.ascontiguousarray(i, dtype=np.int64)
+    j = np.ascontiguousarray(j, dtype=np.int64)
+    v = np.asarray(v)
+    f64 = v.dtype.kind == 'f'
+    v = np.ascontiguousarray(v, dtype=np.float64 if f64 else np.int32)
+    raw = np.zeros((n, num), dtype=np.float32)
+    rc = _lib.load().hpk_band_from_coo(i.ctypes.data, j.ctypes.data, v.ctypes.data, 1 if f64 else 0, i.size, n, num, num,
+                                       raw.ctypes.data)
+    if rc < 0:
+        raise _lib.HpkError(int(rc), 'hpk_band_from_coo: bad arguments')
+    return raw if dtype == np.float32 else raw.astype(dtype)
 
 
 def expected_and_biases(raw, weight, mw):

@@ -923,6 +923,23 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     return hpk_collect(c, job, out);
 }
 
+int64_t hpk_band_from_coo(const int64_t* bin1, const int64_t* bin2, const void* count, int32_t count_f64, int64_t nnz,
+                          int32_t n, int32_t num, int64_t ld, float* raw) {
+    if (!bin1 || !bin2 || !count || !raw || nnz < 0 || n <= 0 || num <= 0 || ld < num) return HPK_ERR_INVALID;
+    const int32_t* ci = static_cast<const int32_t*>(count);
+    const double* cd = static_cast<const double*>(count);
+    int64_t stored = 0;
+    for (int64_t t = 0; t < nnz; ++t) {
+        const int64_t a = bin1[t] < bin2[t] ? bin1[t] : bin2[t], b = bin1[t] < bin2[t] ? bin2[t] : bin1[t];
+        if (a < 0 || b >= n) continue;
+        const int64_t k = b - a;
+        if (k >= num) continue;                             // beyond the band
+        raw[a * ld + k] += count_f64 ? (float)cd[t] : (float)ci[t];
+        ++stored;
+    }
+    return stored;
+}
+
 int hpk_probe_sums(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, const int32_t* rows, const int32_t* cols,
                    int64_t count, double* out) {
     if (!c) return HPK_ERR_INVALID;

@@ -150,6 +150,37 @@ __device__ __noinline__ void edge_expected(const int32_t* __restrict__ m, int wi
     EY = ey;
 }
 
+// Explicit window sums of one pixel at one step (rare path of the stencil): taken when the summed-area table cannot
+// deliver ~1e-11 - the box sum is a difference of f64 prefix sums, so its absolute error is that of the largest
+// corner; a window of small values in a tile that also holds values hundreds of thousands of times larger (a badly
+// balanced bin, a count outlier) would come out with the large values' rounding noise.  The reference adds the
+// window cells themselves (callers.py:175-198) and has no such failure mode.  The whole wave works on one pixel: the
+// (2w + 1)^2 window cells are dealt to the 64 lanes (independent loads, one memory latency), then a wave reduction.
+// (r, c, m, Wm) are wave-uniform.  Returns (bS_K, bS_Y) in every lane.
+__device__ __noinline__ double2 explicit_sums_wave(const float* __restrict__ raw, const double* __restrict__ bal,
+                                                   const double* __restrict__ weight, const int32_t* __restrict__ m, int Wm,
+                                                   int r, int c, int n, int num, int64_t ld, int mw, int lane) {
+    while (Wm > 1 && m[Wm] == 0) --Wm;                  // the step's widest ring
+    const int side = 2 * Wm + 1, cells = side * side;
+    double sk = 0.0, sy = 0.0;
+    for (int idx = lane; idx < cells; idx += 64) {
+        const int di = idx / side - Wm, dj = idx - (di + Wm) * side - Wm;
+        const int adi = di < 0 ? -di : di, adj = dj < 0 ? -dj : dj;
+        const int rr = r + di, cc = c + dj, kk = cc - rr;
+        const bool in = di != 0 && dj != 0 && rr >= 0 && rr < n && cc >= 0 && cc < n && kk >= mw && kk < num;
+        if (!in) continue;
+        const int mm = m[adi > adj ? adi : adj];
+        double b;
+        if (bal) { b = bal[(int64_t)rr * ld + kk]; b = (b == b) ? b : 0.0; }
+        else b = balanced_of(raw[(int64_t)rr * ld + kk], weight[rr], weight[cc]);
+        const double v = (double)mm * b;
+        sk += v;
+        if (di > 0 && dj < 0) sy += v;
+    }
+    for (int off = 32; off > 0; off >>= 1) { sk += __shfl_xor(sk, off); sy += __shfl_xor(sy, off); }
+    return make_double2(sk, sy);
+}
+
 // ------------------------------------------------------------------ stencil
 // Band rows of one tile as they sit in registers between the load and the SAT construction: this wave's RPW rows x
 // 128 columns, two cells per lane.
@@ -553,7 +584,11 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
                 // A box whose balanced values are all 0 must come out as exact 0 (as the reference's CSR adds do);
                 // the f64 SAT leaves rounding residue of at most ~1e-13 of the tile total there.  Sums below 1e-9
                 // of the tile total are re-examined on the exact valid-count field of the packed plane.
-                const bool tiny = act && (SK <= tiny_thr || (SY <= tiny_thr && SY != 0.0));
+                // ... and sums below 2^-16 of the window's largest table entry carry that entry's rounding noise (relative
+                // error ~ 1e-15 x entry / sum): those with non-zero cells are redone by adding the window cells themselves,
+                // the whole wave on one pixel at a time (explicit_sums_wave).
+                const double thr = fmax(tiny_thr, S.c[base + W * LC + W] * 0x1p-16);
+                const bool tiny = act && (SK <= thr || (SY <= thr && SY != 0.0));
                 if (__ballot(tiny) != 0ull) {
                     if (tiny) {
                         const unsigned sv = sr;
@@ -567,8 +602,17 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
                             VK += (unsigned)(int)(signed char)(t >> 8) * (unsigned)kyv;
                             VY += (unsigned)(int)(signed char)(t >> 8) * (unsigned)(kyv >> 32);
                         }
-                        if (VK == 0u) SK = 0.0;
-                        if (VY == 0u) SY = 0.0;
+                        if (VK == 0u) { SK = 0.0; SY = 0.0; }
+                        else if (VY == 0u) SY = 0.0;
+                    }
+                    unsigned long long todo = __ballot(tiny && SK != 0.0);
+                    while (todo != 0ull) {
+                        const int src = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1ull;
+                        const int er = __builtin_amdgcn_readlane(r, src), ec = __builtin_amdgcn_readlane(c0 + x, src);
+                        const int es = __builtin_amdgcn_readlane(sq, src);
+                        const double2 ex = explicit_sums_wave(g_raw, g_bal, g_w, plan->steps[es].m, W, er, ec, n, num, a.ld, mw, lane);
+                        if (lane == src) { SK = ex.x; SY = (SY == 0.0) ? 0.0 : ex.y; }
                     }
                 }
             }
@@ -693,37 +737,6 @@ __device__ __noinline__ unsigned long long box_ky_valid_m(const unsigned* __rest
     const unsigned kv = (bl - bm + bm1 - br) - (tl - tm + tm1 - tr) - (ml1 - mr1 - ml0 + mr0) + pixv;
     const unsigned yv = bl - bm - ml1 + sv;
     return (unsigned long long)(kv >> PK_SHIFT) | (unsigned long long)(yv >> PK_SHIFT) << 32;
-}
-
-// Explicit window sums of one pixel at one step (rare path of the stencil): taken when the summed-area table cannot
-// deliver ~1e-11 - the box sum is a difference of f64 prefix sums, so its absolute error is that of the largest
-// corner; a window of small values in a tile that also holds values hundreds of thousands of times larger (a badly
-// balanced bin, a count outlier) would come out with the large values' rounding noise.  The reference adds the
-// window cells themselves (callers.py:175-198) and has no such failure mode.  The whole wave works on one pixel: the
-// (2w + 1)^2 window cells are dealt to the 64 lanes (independent loads, one memory latency), then a wave reduction.
-// (r, c, m, Wm) are wave-uniform.  Returns (bS_K, bS_Y) in every lane.
-__device__ __noinline__ double2 explicit_sums_wave(const float* __restrict__ raw, const double* __restrict__ bal,
-                                                   const double* __restrict__ weight, const int32_t* __restrict__ m, int Wm,
-                                                   int r, int c, int n, int num, int64_t ld, int mw, int lane) {
-    while (Wm > 1 && m[Wm] == 0) --Wm;                  // the step's widest ring
-    const int side = 2 * Wm + 1, cells = side * side;
-    double sk = 0.0, sy = 0.0;
-    for (int idx = lane; idx < cells; idx += 64) {
-        const int di = idx / side - Wm, dj = idx - (di + Wm) * side - Wm;
-        const int adi = di < 0 ? -di : di, adj = dj < 0 ? -dj : dj;
-        const int rr = r + di, cc = c + dj, kk = cc - rr;
-        const bool in = di != 0 && dj != 0 && rr >= 0 && rr < n && cc >= 0 && cc < n && kk >= mw && kk < num;
-        if (!in) continue;
-        const int mm = m[adi > adj ? adi : adj];
-        double b;
-        if (bal) { b = bal[(int64_t)rr * ld + kk]; b = (b == b) ? b : 0.0; }
-        else b = balanced_of(raw[(int64_t)rr * ld + kk], weight[rr], weight[cc]);
-        const double v = (double)mm * b;
-        sk += v;
-        if (di > 0 && dj < 0) sy += v;
-    }
-    for (int off = 32; off > 0; off >>= 1) { sk += __shfl_xor(sk, off); sy += __shfl_xor(sy, off); }
-    return make_double2(sk, sy);
 }
 
 template <bool BALF64>

@@ -208,6 +208,15 @@ int  hpk_bruteforce_sums(hpk_ctx* ctx, const hpk_band* band, const hpk_params* p
 int  hpk_probe_sums(hpk_ctx* ctx, const hpk_band* band, const hpk_params* params, const int32_t* rows,
                     const int32_t* cols, int64_t count, double* out);
 
+/* Host-only band builder (no device needed): counterpart of `Diags = [H.diagonal(i) for i in range(num)]`
+ * (scripts/pyHICCUPS:147), which scans all stored pixels once per diagonal - O(num * nnz).  Here one O(nnz) pass
+ * scatter-adds the pixels (bin1[t], bin2[t], count[t]) of one chromosome (bins relative to its first bin; every pixel
+ * listed once, in either orientation - cooler's pixel table lists the upper triangle) into the dense
+ * upper band raw[n][ld], raw[r][k] = count of (r, r + k), k < num.  `raw` must be zero-filled by the caller.
+ * count_f64 != 0: counts are double, otherwise int32.  Returns the number of pixels stored, or a negative status. */
+int64_t hpk_band_from_coo(const int64_t* bin1, const int64_t* bin2, const void* count, int32_t count_f64, int64_t nnz,
+                          int32_t n, int32_t num, int64_t ld, float* raw);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,11 @@ def one_case(seed, ctx):
     D = int(rng.integers(max(ww) + 2, 160))
     if os.environ.get('HPK_FUZZ_BIG'):          # many tiles: several row blocks per XCD chunk, 3-5 column chunks
         n, D = int(rng.integers(2000, 5000)), int(rng.integers(200, 520))
+    if os.environ.get('HPK_FUZZ_WIDE'):         # bands as wide as the 5 kb / 1 kb configurations: 12-20 column chunks
+        D = int(rng.integers(1200, 2001))       # (the oracle needs a minute or two per case at this width)
+        n = D + maxww + 1 + int(rng.integers(60, 500))
+        if len(ww) > 1:
+            pw, ww = pw[:1], ww[:1]
     maxapart = D * res
     num = D + maxww + 1
     depth = float(rng.choice([2.0, 8.0, 25.0, 60.0, 400.0, 5000.0]))
@@ -107,7 +112,8 @@ def main():
         tally[status] = tally.get(status, 0) + 1
         if status.startswith('MISMATCH') or status == 'CRASH' or os.environ.get('HPK_FUZZ_VERBOSE'):
             print(status, desc, note, flush=True)
-    print('fuzz: %d cases in %.0f s: %s' % (ncases, time.time() - t0, tally))
+    mode = 'wide' if os.environ.get('HPK_FUZZ_WIDE') else 'big' if os.environ.get('HPK_FUZZ_BIG') else 'small'
+    print('fuzz[%s]: seeds %d..%d, %d cases in %.0f s: %s' % (mode, first, first + ncases - 1, ncases, time.time() - t0, tally))
     return 1 if any(k.startswith('MISMATCH') or k == 'CRASH' for k in tally) else 0
 
 

@@ -47,3 +47,68 @@ def test_bench_configurations_match_the_survey_table():
     assert g10 == 148070091 and g10 * 3 == 444210273
     assert g5 == 1162778169
     assert bench.BYTES_PER_PX == 20.0 and bench.HBM_PEAK_GBS == 8000.0
+
+
+class _FakeSelector(object):
+    def __init__(self, fn):
+        self.fetch = fn
+
+
+class _FakeCooler(object):
+    """Duck-typed stand-in for cooler.Cooler (the package is not installed here): two chromosomes in one genome-wide bin
+    table, upper-triangle pixel table, a weight column with NaN bins - what scripts/pyHICCUPS:142-163 reads."""
+    def __init__(self, uri):
+        import pandas as pd
+        self.uri = uri
+        self.binsize = 10000
+        self.chromnames = ['chr1', 'chr2']
+        self._n = {'chr1': 180, 'chr2': 130}
+        self._lo = {'chr1': 0, 'chr2': 180}
+        self._bands, self._w = {}, {}
+        frames = []
+        for s, c in enumerate(self.chromnames):
+            raw, w, _ = synthetic.synth_band(self._n[c], 41, depth=8.0, seed=40 + s)
+            self._bands[c], self._w[c] = raw, w
+            i, j, v = synthetic.band_to_coo(raw)
+            frames.append(pd.DataFrame({'bin1_id': i + self._lo[c], 'bin2_id': j + self._lo[c], 'count': v.astype(np.int32)}))
+        self._px = pd.concat(frames, ignore_index=True)
+        self._bins = pd.DataFrame({'chrom': np.repeat(self.chromnames, [180, 130]),
+                                   'weight': np.r_[self._w['chr1'], self._w['chr2']],
+                                   'KR': np.r_[self._w['chr1'], self._w['chr2']] * 2.0})
+
+    def extent(self, chrom):
+        return self._lo[chrom], self._lo[chrom] + self._n[chrom]
+
+    def matrix(self, balance=False, as_pixels=False, join=False, sparse=False):
+        assert balance is False and as_pixels and not join
+        def fetch(chrom):
+            lo, hi = self.extent(chrom)
+            p = self._px
+            return p[(p.bin1_id >= lo) & (p.bin1_id < hi) & (p.bin2_id >= lo) & (p.bin2_id < hi)]
+        return _FakeSelector(fetch)
+
+    def bins(self):
+        return _FakeSelector(lambda chrom: self._bins[self._bins.chrom == chrom])
+
+
+def test_cooler_source_against_a_fake_cooler(monkeypatch):
+    """io.CoolerSource (counterpart of the cooler reads in scripts/pyHICCUPS:142-143, 163): bins relative to the
+    chromosome's extent, band by one O(nnz) scatter, weights from the chosen column."""
+    import sys, types
+    from hicpeaks_amd import io
+    mod = types.ModuleType('cooler')
+    mod.Cooler = _FakeCooler
+    monkeypatch.setitem(sys.modules, 'cooler', mod)
+    src = io.open_source('fake.cool::resolutions/10000')
+    assert isinstance(src, io.CoolerSource) and src.binsize == 10000 and src.chromnames == ['chr1', 'chr2']
+    assert src.nbins('chr2') == 130
+    for c in src.chromnames:
+        raw, w = src.fetch(c, 31)
+        assert raw.dtype == np.float32 and raw.shape == (src.nbins(c), 31)
+        np.testing.assert_array_equal(raw, src.clr._bands[c][:, :31])         # diagonals beyond num are dropped
+        np.testing.assert_array_equal(w, src.clr._w[c])
+        raw50, _ = src.fetch(c, 50)                                           # wider than what is stored: zeros
+        assert not raw50[:, 41:].any()
+        np.testing.assert_array_equal(raw50[:, :41], src.clr._bands[c])
+    _, wkr = src.fetch('chr1', 31, weight_name='KR')
+    np.testing.assert_array_equal(wkr, src.clr._w['chr1'] * 2.0)

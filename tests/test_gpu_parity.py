@@ -227,6 +227,51 @@ def test_sat_kernel_equals_bruteforce(pw, ww, ctx):
             assert np.array_equal(sums[sel] == 0, bf[:, :4] == 0)
 
 
+@pytest.mark.parametrize('mode', ['weight', 'balanced'])
+def test_dynamic_range_outliers(mode, ctx):
+    """Adversarial for the f64 summed-area table: one pixel of 10^6 counts and one bin whose weight is 10^7
+    times the others', in tiles whose far-band pixels hold 1-2 counts.  A box sum is a difference of prefix sums, so
+    small windows next to such values would carry their rounding noise; the kernel has to notice (sum below 2^-16 of
+    the window's largest table entry) and add those windows cell by cell.  Every candidate's sums against the
+    explicit-window kernel at rtol 1e-11, exact zeros exact."""
+    from hicpeaks_amd import synthetic
+    n, maxww, D = 900, 10, 230
+    num = D + maxww + 1
+    raw, weight, _ = synthetic.synth_band(n, num, depth=6.0, nloops=10, seed=21, nan_frac=0.01)
+    raw[300, 60] = 1000000
+    raw[120, 7] = 3000000
+    ok = np.where(~np.isnan(weight))[0]
+    weight[ok[np.argmin(np.abs(ok - 450))]] *= 1e7
+    weight[ok[np.argmin(np.abs(ok - 700))]] *= 1e-6
+    pw, ww = [2], [5]
+    mw = min(ww)
+    IR, cband, biases = orc.prep_from_band(raw, weight, mw)
+    prm = _lib.make_params(_lib.MODE_HICCUPS, pw, ww, maxww, 0.05, D * 10000, 10000, 16, _lib.FLAG_DENSE_SUMS | _lib.FLAG_NO_SCORE)
+    rawf = raw.astype(np.float32)
+    kw = dict(balanced=cband) if mode == 'balanced' else dict(weight=weight)
+    R = ctx.score_host(rawf, IR, biases, biases, prm, **kw)
+    rr, kk = np.nonzero(raw[:, mw:D + 1])
+    kk = kk + mw
+    keep = rr + kk < n
+    rows, cols = rr[keep].astype(np.int32), (rr + kk)[keep].astype(np.int32)
+    w = R.dense_w[0][rows, cols - rows]
+    sums = R.dense_sums[0][rows, cols - rows]
+    steps = [(a, b) for a, b, c, e in R.steps]
+    checked = 0
+    for si, (spi, swi) in enumerate(steps):
+        sel = w == swi
+        if not sel.any():
+            continue
+        bf = ctx.bruteforce_sums(rawf, IR, biases, biases, prm, si, rows[sel], cols[sel], **kw)
+        np.testing.assert_allclose(sums[sel], bf[:, :4], rtol=1e-11, atol=0)
+        assert np.array_equal(sums[sel] == 0, bf[:, :4] == 0)
+        checked += int(sel.sum())
+    assert checked > 20000
+    # the outliers really are in play: windows that hold them, and windows 10^6 times smaller in the same tiles
+    bs = sums[w > 0, 0]
+    assert bs.max() / bs[bs > 0].min() > 1e9
+
+
 def test_full_size_chr1_properties(ctx):
     """BASELINE configs[1] at full size (n = 24896, 5 Mb band at 10 kb): size-independent checks - counting
     identities of the widening log, gap rows, and an explicit-window recomputation of sampled pixels."""
