@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""gpurun_out/<tag>/ (scripts/gpu_profile_round.sh) -> the summaries kept under profiles/: <tag>_bench.json,
+<tag>_bench_other_configs.jsonl, <tag>_kernel_stats.csv, <tag>_pmc_summary.txt and traffic.json (HBM bytes per stencil
+launch = 2 x FETCH_SIZE + WRITE_SIZE, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md / the calibration in
+profiles/r01_pmc_summary.txt).  usage: collect_profiles.py <tag> [--no-copy]"""
+import csv, glob, json, os, shutil, sys, collections
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+copy = '--no-copy' not in sys.argv
+out = os.path.join(REPO, 'gpurun_out', tag)
+prof = os.path.join(REPO, 'profiles')
+
+
+def pmc_means(d, pat):
+    acc = collections.defaultdict(list)
+    for f in sorted(glob.glob(os.path.join(d, '**', '*_counter_collection.csv'), recursive=True)):
+        for row in csv.DictReader(open(f)):
+            if pat in row['Kernel_Name']:
+                acc[row['Counter_Name']].append(float(row['Counter_Value']))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+lines = ['# rocprofv3 --pmc passes of scripts/gpu_profile_round.sh %s, mean per dispatch' % tag]
+traffic = {'_comment': 'HBM traffic per stencil launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; KiB; FETCH_SIZE '
+                       'doubled per the gfx950 note in MI355X_MICROARCH.md, calibrated in profiles/r01_pmc_summary.txt); bench.py copies '
+                       'the entry of the configuration it runs into roofline.traffic'}
+for cfg in ('chr1_10kb', 'chr1_10kb_union', 'chr1_5kb', 'deep_1kb'):
+    vals = {}
+    for cnt in ('FETCH_SIZE', 'WRITE_SIZE'):
+        for kern in ('hpk_stencil', 'hpk_score'):
+            m = pmc_means(os.path.join(out, 'pmc_%s_%s' % (cfg, cnt)), kern)
+            if cnt in m:
+                vals[(kern, cnt)] = m[cnt]
+                lines.append('%-16s %-12s %-11s n=%d mean=%.5g KiB' % (cfg, kern, cnt, m[cnt][1], m[cnt][0]))
+    if ('hpk_stencil', 'FETCH_SIZE') in vals and ('hpk_stencil', 'WRITE_SIZE') in vals:
+        tb = int((2 * vals[('hpk_stencil', 'FETCH_SIZE')][0] + vals[('hpk_stencil', 'WRITE_SIZE')][0]) * 1024)
+        traffic[cfg] = {'traffic_bytes': tb, 'source': 'profiles/%s_pmc_summary.txt' % tag,
+                        'note': 'hpk_stencil*, per launch: 2 x FETCH_SIZE + WRITE_SIZE'}
+        lines.append('%-16s stencil HBM traffic per launch: %.1f MB' % (cfg, tb / 1e6))
+for kern in ('hpk_stencil', 'hpk_score'):
+    lines.append('## %s (chr1_10kb), SQ / TCC counters' % kern)
+    for d in sorted(glob.glob(os.path.join(out, 'pmc_sq_*/'))):
+        for k, (v, n) in sorted(pmc_means(d, kern).items()):
+            lines.append('%-28s n=%d mean=%.4g' % (k, n, v))
+open(os.path.join(out, 'pmc_summary.txt'), 'w').write('\n'.join(lines) + '\n')
+ks = glob.glob(os.path.join(out, 'trace', '**', '*kernel_stats.csv'), recursive=True)
+if ks:
+    shutil.copy(ks[0], os.path.join(out, 'kernel_stats.csv'))
+print('\n'.join(lines[:40]))
+if copy:
+    shutil.copy(os.path.join(out, 'bench.json'), os.path.join(prof, '%s_bench.json' % tag))
+    with open(os.path.join(prof, '%s_bench_other_configs.jsonl' % tag), 'w') as f:
+        for p in sorted(glob.glob(os.path.join(out, 'bench_*.json'))):
+            t = open(p).read().strip()
+            if t:
+                f.write(t + '\n')
+    if os.path.exists(os.path.join(out, 'kernel_stats.csv')):
+        shutil.copy(os.path.join(out, 'kernel_stats.csv'), os.path.join(prof, '%s_kernel_stats.csv' % tag))
+    shutil.copy(os.path.join(out, 'pmc_summary.txt'), os.path.join(prof, '%s_pmc_summary.txt' % tag))
+    if len(traffic) > 1:
+        json.dump(traffic, open(os.path.join(prof, 'traffic.json'), 'w'), indent=1)
+    print('copied to profiles/')
