@@ -644,13 +644,18 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
         sa.clk = c->tmpD.as<unsigned long long>();
     }
 #endif
+    sa.ticket = std::getenv("HPK_FREEZE_KERNEL") ? nullptr : reinterpret_cast<unsigned*>(small + OFF_NUNITS + 4);
+    sa.frozen = d_frozen; sa.executed = d_exec; sa.err = d_err;
+    { const char* e = std::getenv("HPK_RISK_LOG2"); sa.risk = std::ldexp(1.0, e ? -std::atoi(e) : -12); }
     (void)hipEventRecord(L.ev[1], c->stream);
     j->simple = plan.simple_reads != 0 && !std::getenv("HPK_GENERIC_SEARCH");
     hpk_launch_stencil(sa, in.bal != nullptr, j->simple, c->stream);
     HIPCHK(c, hipGetLastError());
     (void)hipEventRecord(L.ev[2], c->stream);
-    hpk_launch_freeze(sa.plan, d_hist, sa.hist_part, sa.grid, d_frozen, d_exec, d_err, c->stream);
-    HIPCHK(c, hipGetLastError());
+    if (!sa.ticket) {       // HPK_FREEZE_KERNEL: the decision as a kernel of its own instead of the last stencil workgroup
+        hpk_launch_freeze(sa.plan, d_hist, sa.hist_part, sa.grid, d_frozen, d_exec, d_err, c->stream);
+        HIPCHK(c, hipGetLastError());
+    }
     if (j->phases) (void)hipEventRecord(L.ev[3], c->stream);
     return launch_scoring(c, j, 0);
 }

@@ -41,6 +41,11 @@ struct HpkStencilArgs {
     uint8_t* gap;                       // [n] preset to 0; set for rows with a non-zero balanced value (gap = !flag)
     unsigned long long* hist;           // [HPK_MAX_STEPS + 1] totals, written by hpk_freeze
     unsigned* hist_part;                // [grid][HPK_MAX_STEPS + 1] per-workgroup resolve counts, [..][HPK_MAX_STEPS] = candidates
+    unsigned* ticket;                   // zeroed; the workgroup that draws grid - 1 runs the freeze (nullptr: hpk_freeze follows)
+    int32_t* frozen;                    // outputs of the freeze: frozen_w, executed[nsteps], first empty step + 1 or 0
+    int32_t* executed;
+    int32_t* err;
+    double risk;                        // box sums below risk x (largest table entry of the window) are redone exactly
     int32_t n, num;
     int64_t ld, ldo;
     int32_t W, mw, D;

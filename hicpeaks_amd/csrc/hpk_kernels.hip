@@ -181,6 +181,7 @@ __device__ __noinline__ double2 explicit_sums_wave(const float* __restrict__ raw
     return make_double2(sk, sy);
 }
 
+__device__ __forceinline__ void freeze_by_last_workgroup(const HpkStencilArgs& a, void* lds);
 // ------------------------------------------------------------------ stencil
 // Band rows of one tile as they sit in registers between the load and the SAT construction: this wave's RPW rows x
 // 128 columns, two cells per lane.
@@ -584,10 +585,10 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
                 // A box whose balanced values are all 0 must come out as exact 0 (as the reference's CSR adds do);
                 // the f64 SAT leaves rounding residue of at most ~1e-13 of the tile total there.  Sums below 1e-9
                 // of the tile total are re-examined on the exact valid-count field of the packed plane.
-                // ... and sums below 2^-16 of the window's largest table entry carry that entry's rounding noise (relative
+                // ... and sums below a.risk (2^-12) of the window's largest table entry carry that entry's rounding noise (relative
                 // error ~ 1e-15 x entry / sum): those with non-zero cells are redone by adding the window cells themselves,
                 // the whole wave on one pixel at a time (explicit_sums_wave).
-                const double thr = fmax(tiny_thr, S.c[base + W * LC + W] * 0x1p-16);
+                const double thr = fmax(tiny_thr, S.c[base + W * LC + W] * a.risk);
                 const bool tiny = act && (SK <= thr || (SY <= thr && SY != 0.0));
                 if (__ballot(tiny) != 0ull) {
                     if (tiny) {
@@ -663,6 +664,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
         for (int w2 = 0; w2 < NW; ++w2) tot += red[w2 * (HPK_MAX_STEPS + 1) + threadIdx.x];
         a.hist_part[(int64_t)blockIdx.x * (HPK_MAX_STEPS + 1) + threadIdx.x] = tot;
     }
+    freeze_by_last_workgroup(a, smem + 8192);
 }
 
 // ------------------------------------------------------------------ stencil for "simple Reads" plans
@@ -1146,10 +1148,11 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
                 const int d = c0 + x - (r0 + y);
                 SY = (d - (int)((w0 >> 24) & 31u) - 1 < mw) ? 0.0 : SY;
                 // Sums that are small against the largest corner of the window's table entries carry that corner's
-                // rounding noise (relative error of the sum ~ 1e-15 x corner / sum): below 2^-16 of it they are redone
+                // rounding noise (relative error of the sum ~ 1e-15 x corner / sum): below a.risk of it they are redone
                 // exactly - 0 when no contributing cell is non-zero (valid-count plane), otherwise by adding the window
-                // cells themselves.
-                const double thr = amax * 0x1p-16;
+                // cells themselves (a.risk = 2^-12: worst-case relative error of what stays on the table ~ 5e-14 x 2^12 = 2e-10,
+                // typically two orders below).
+                const double thr = amax * a.risk;
                 const bool risky = act & ((SK < thr) | ((SY < thr) & (SY != 0.0)));
                 if (__ballot(risky) != 0ull) {
 #ifdef HPK_PHASE_CLOCK
@@ -1246,6 +1249,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         } else if (threadIdx.x == HPK_MAX_STEPS) out = red[NW * 64];
         a.hist_part[(int64_t)blockIdx.x * (HPK_MAX_STEPS + 1) + threadIdx.x] = out;
     }
+    freeze_by_last_workgroup(a, smem + 8192);
 }
 
 // ------------------------------------------------------------------ 1-D expected IR[d] and biases (scripts/pyHICCUPS:149-166)
@@ -1306,15 +1310,15 @@ __global__ void __launch_bounds__(256) hpk_ir_final(const double* __restrict__ p
     IR[k] = (k >= mw && n - k > 0) ? s / (double)denom : 0.0;       // 0/0 -> NaN like numpy's mean of an empty slice
 }
 // ------------------------------------------------------------------ local-expected tables (callers.py:66-72 + 175-198)
-// ------------------------------------------------------------------ freeze (one workgroup)
-// Column sums of the per-workgroup resolve histograms (wave w sums columns w, w + 16, ...; lanes stride over the
-// partials), then one thread replays the reference's frozen_w / break logic on the totals.
-__global__ void __launch_bounds__(1024) hpk_freeze(const HpkDevPlan* __restrict__ plan, const unsigned* __restrict__ hist_part,
-                                                   int nparts, unsigned long long* __restrict__ hist_out,
-                                                   int32_t* frozen, int32_t* executed, int32_t* err) {
-    __shared__ unsigned long long hist[HPK_MAX_STEPS + 1];
-    __shared__ int swi[HPK_MAX_STEPS], sslot[HPK_MAX_STEPS];        // the serial part below reads LDS only
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// ------------------------------------------------------------------ freeze
+// Column sums of the per-workgroup resolve histograms, then one thread replays the reference's frozen_w / break logic
+// on the totals (callers.py:208-229, 505-511).  1024 threads; `lds` = scratch of >= 1.1 KiB.
+__device__ __forceinline__ void freeze_body(const HpkDevPlan* __restrict__ plan, const unsigned* __restrict__ hist_part, int nparts,
+                                            unsigned long long* __restrict__ hist_out, int32_t* frozen, int32_t* executed,
+                                            int32_t* err, void* lds) {
+    unsigned long long* hist = reinterpret_cast<unsigned long long*>(lds);                 // [HPK_MAX_STEPS + 1]
+    int* swi = reinterpret_cast<int*>(hist + HPK_MAX_STEPS + 1);                           // the serial part below reads LDS only
+    int* sslot = swi + HPK_MAX_STEPS;
     if ((int)threadIdx.x < plan->nsteps) { swi[threadIdx.x] = plan->steps[threadIdx.x].wi; sslot[threadIdx.x] = plan->steps[threadIdx.x].slot; }
     // thread t sums column t % 65 over the partials t / 65, t / 65 + 15, ... (independent loads), LDS atomics finish
     if (threadIdx.x <= HPK_MAX_STEPS) hist[threadIdx.x] = 0ull;
@@ -1329,7 +1333,6 @@ __global__ void __launch_bounds__(1024) hpk_freeze(const HpkDevPlan* __restrict_
     }
     __syncthreads();
     if (threadIdx.x <= HPK_MAX_STEPS) hist_out[threadIdx.x] = hist[threadIdx.x];
-    (void)lane; (void)wave;
     if (threadIdx.x != 0) return;
     const long long total = (long long)hist[HPK_HIST_NCAND];
     long long unres[HPK_KSLOTS];
@@ -1353,6 +1356,37 @@ __global__ void __launch_bounds__(1024) hpk_freeze(const HpkDevPlan* __restrict_
     }
     *frozen = fw;
     *err = e;
+}
+__global__ void __launch_bounds__(1024) hpk_freeze(const HpkDevPlan* __restrict__ plan, const unsigned* __restrict__ hist_part,
+                                                   int nparts, unsigned long long* __restrict__ hist_out,
+                                                   int32_t* frozen, int32_t* executed, int32_t* err) {
+    __shared__ unsigned long long lds[HPK_MAX_STEPS + 1 + HPK_MAX_STEPS];
+    freeze_body(plan, hist_part, nparts, hist_out, frozen, executed, err, lds);
+}
+// The freeze decision needs the histograms of every stencil workgroup.  Instead of a kernel of its own (~10 us of an
+// otherwise idle GPU between the stencil and the scoring kernel) the stencil workgroup that finishes last takes it:
+// every workgroup publishes its partial counts (all storing waves drain, one agent-scope release), draws a ticket, and
+// the holder of the last ticket acquires and runs freeze_body.  Placement-independent (cdna_hip_programming.md G16).
+// Call with all 1024 threads after the workgroup's hist_part stores; `lds` is scratch (>= 1.2 KiB, the SAT is dead).
+__device__ __forceinline__ void freeze_by_last_workgroup(const HpkStencilArgs& a, void* lds) {
+    if (a.ticket == nullptr) return;                    // HPK_FREEZE_KERNEL: the stand-alone kernel follows
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned* flag = reinterpret_cast<unsigned*>(lds);
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag[0] = (t == gridDim.x - 1u) ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool last = flag[0] != 0u;
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    freeze_body(a.plan, a.hist_part, (int)gridDim.x, a.hist, a.frozen, a.executed, a.err,
+                reinterpret_cast<unsigned char*>(lds) + 64);
 }
 
 // ------------------------------------------------------------------ gap rows
