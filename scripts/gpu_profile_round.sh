@@ -28,4 +28,7 @@ for cnt in "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ
 done
 cd $R
 python scripts/collect_profiles.py $TAG --no-copy
-ls $OUT | head -60
+# the raw traces are tens of MB (gpurun copies back at most 64 MiB): keep the summaries and the tails of the logs
+for f in $OUT/*.log; do tail -5 $f > $f.tail; rm $f; done
+rm -rf $OUT/trace $OUT/pmc_*/
+ls -la $OUT | head -60
