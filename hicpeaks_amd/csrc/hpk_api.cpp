@@ -646,6 +646,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
 #endif
     sa.ticket = std::getenv("HPK_FREEZE_KERNEL") ? nullptr : reinterpret_cast<unsigned*>(small + OFF_NUNITS + 4);
     sa.frozen = d_frozen; sa.executed = d_exec; sa.err = d_err;
+    sa.single = plan.single_p >= 0 ? 1 : 0;
     { const char* e = std::getenv("HPK_RISK_LOG2"); sa.risk = std::ldexp(1.0, e ? -std::atoi(e) : -12); }
     (void)hipEventRecord(L.ev[1], c->stream);
     j->simple = plan.simple_reads != 0 && !std::getenv("HPK_GENERIC_SEARCH");

@@ -53,6 +53,7 @@ struct HpkStencilArgs {
     int32_t J;                          // column chunks per row block
     int32_t ntiles, chunk;              // chunk = ceil(ntiles / 8): tiles handed to one XCD
     int32_t grid;                       // persistent workgroups (multiple of 8, one per CU)
+    int32_t single;                     // the plan is a textbook single-pair plan (HpkDevPlan::single_p >= 0)
     int32_t order;                      // tile order within an XCD's run: 0 row-major, 1 column chunks rotated per row block
     unsigned long long* clk;            // -DHPK_PHASE_CLOCK builds: [grid][waves][8] cycle sums per phase, or nullptr
     int32_t dbg_stop;                   // profiling ablation (HPK_DBG_STOP): 1 stop after the loads, 2 after the SAT,

@@ -827,7 +827,7 @@ struct TileWalk {
     }
 };
 
-template <bool BALF64>
+template <bool BALF64, bool SINGLE>
 __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     constexpr int NW = 16, RPW = 5;
     static_assert(LR == 80 && LC == 128, "tile geometry of the simple-plan kernel");
@@ -873,6 +873,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     const int nslots_p = __builtin_amdgcn_readfirstlane(nslots);
     const int minr_p = __builtin_amdgcn_readfirstlane(plan->min_reads), p0_p = __builtin_amdgcn_readfirstlane(plan->reads_p0);
     const int wmin_p = __builtin_amdgcn_readfirstlane(plan->wmin);
+    const int sp_p = __builtin_amdgcn_readfirstlane(plan->single_p);     // SINGLE: the peak width
     unsigned myhist = 0u;                 // lane w: candidates whose first sufficient width is w
     unsigned mycand = 0u;
     // scoring work list: the append of a tile is completed one tile later (the atomic's return is not waited for)
@@ -1118,35 +1119,51 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         }
         // ---- sums at the resolving step, once per slot
 #pragma unroll 1
-        for (int q = 0; q < nslots_p; ++q) {
-            const int wf = (q == 0) ? wf_q[0] : (q == 1) ? wf_q[1] : (q == 2) ? wf_q[2] : wf_q[3];
-            const int wq = wstar > wf ? wstar : wf;
-            int sq = (int)stepof[q * 32 + (wq & 31)];
-            sq = wstar == 255 ? 0xff : sq;
+        for (int q = 0; q < (SINGLE ? 1 : nslots_p); ++q) {
+            int sq;
+            if (SINGLE) sq = wstar == 255 ? 0xff : wstar - wmin_p;      // textbook plan: one step per width, in order
+            else {
+                const int wf = (q == 0) ? wf_q[0] : (q == 1) ? wf_q[1] : (q == 2) ? wf_q[2] : wf_q[3];
+                const int wq = wstar > wf ? wstar : wf;
+                sq = (int)stepof[q * 32 + (wq & 31)];
+                sq = wstar == 255 ? 0xff : sq;
+            }
             const bool act = sq != 0xff;
             double SK = 0.0, SY = 0.0;
             if (__ballot(act) != 0ull) {
-                const int src = act ? sq : 0;
-                const uint4 pw4 = *reinterpret_cast<const uint4*>(&pl[src * 8]);
-                const unsigned w0 = pw4.x, k0 = pw4.y, k1 = pw4.z, k2 = pw4.w;
-                unsigned k3 = 0u;
-                if (maxnkt > 6) k3 = pl[src * 8 + 4];
-                const int nkt = act ? (int)((w0 >> 20) & 15u) : 0;
+                unsigned w0 = 0u, k0 = 0u, k1 = 0u, k2 = 0u, k3 = 0u;
+                int nkt = 0, rho_min;
+                if (SINGLE) {
+                    // Box(w*) - Box(p): the outer radius per lane, the inner one the same for all
+                    double kcw, ycw, kcp = 0.0, ycp = 0.0;
+                    box_ky_m(Sc, base, act ? wstar : 1, pixc, sc, kcw, ycw);
+                    if (sp_p > 0) box_ky_m(Sc, base, sp_p, pixc, sc, kcp, ycp);
+                    SK = act ? kcw - kcp : 0.0;
+                    SY = act ? ycw - ycp : 0.0;
+                    rho_min = sp_p + 1;
+                } else {
+                    const int src = act ? sq : 0;
+                    const uint4 pw4 = *reinterpret_cast<const uint4*>(&pl[src * 8]);
+                    w0 = pw4.x; k0 = pw4.y; k1 = pw4.z; k2 = pw4.w;
+                    if (maxnkt > 6) k3 = pl[src * 8 + 4];
+                    nkt = act ? (int)((w0 >> 20) & 15u) : 0;
 #pragma unroll 1
-                for (int j = 0; j < maxnkt; ++j) {
-                    const bool on = j < nkt;
-                    if (__ballot(on) == 0ull) break;
-                    const unsigned kw = (j < 2) ? k0 : (j < 4) ? k1 : (j < 6) ? k2 : k3;
-                    const unsigned t = (kw >> (16 * (j & 1))) & 0xffffu;
-                    const int rho = on ? (int)(t & 0xffu) : 1;      // idle lanes read a harmless box
-                    const double cf = on ? (double)(int)(signed char)(t >> 8) : 0.0;
-                    double kc, yc;
-                    box_ky_m(Sc, base, rho, pixc, sc, kc, yc);
-                    SK += cf * kc; SY += cf * yc;
+                    for (int j = 0; j < maxnkt; ++j) {
+                        const bool on = j < nkt;
+                        if (__ballot(on) == 0ull) break;
+                        const unsigned kw = (j < 2) ? k0 : (j < 4) ? k1 : (j < 6) ? k2 : k3;
+                        const unsigned t = (kw >> (16 * (j & 1))) & 0xffffu;
+                        const int rho = on ? (int)(t & 0xffu) : 1;      // idle lanes read a harmless box
+                        const double cf = on ? (double)(int)(signed char)(t >> 8) : 0.0;
+                        double kc, yc;
+                        box_ky_m(Sc, base, rho, pixc, sc, kc, yc);
+                        SK += cf * kc; SY += cf * yc;
+                    }
+                    rho_min = (int)((w0 >> 24) & 31u);
                 }
                 // lower-left support off the band: exact 0 (see hpk_stencil)
                 const int d = c0 + x - (r0 + y);
-                SY = (d - (int)((w0 >> 24) & 31u) - 1 < mw) ? 0.0 : SY;
+                SY = (d - rho_min - 1 < mw) ? 0.0 : SY;
                 // Sums that are small against the largest corner of the window's table entries carry that corner's
                 // rounding noise (relative error of the sum ~ 1e-15 x corner / sum): below a.risk of it they are redone
                 // exactly - 0 when no contributing cell is non-zero (valid-count plane), otherwise by adding the window
@@ -1161,13 +1178,20 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
                     if (risky) {
                         const unsigned pv = sr - Sp[base + 1] - Sp[base - LC] + Sp[base - LC + 1];
                         unsigned VK = 0u, VY = 0u;
+                        if (SINGLE) {
+                            const unsigned long long vw = box_ky_valid_m(Sp, base, wstar, pv, sr);
+                            const unsigned long long vp = sp_p > 0 ? box_ky_valid_m(Sp, base, sp_p, pv, sr) : 0ull;
+                            VK = (unsigned)vw - (unsigned)vp;
+                            VY = (unsigned)(vw >> 32) - (unsigned)(vp >> 32);
+                        } else {
 #pragma unroll 1
-                        for (int j = 0; j < nkt; ++j) {
-                            const unsigned kw = (j < 2) ? k0 : (j < 4) ? k1 : (j < 6) ? k2 : k3;
-                            const unsigned t = (kw >> (16 * (j & 1))) & 0xffffu;
-                            const unsigned long long kyv = box_ky_valid_m(Sp, base, (int)(t & 0xffu), pv, sr);
-                            VK += (unsigned)(int)(signed char)(t >> 8) * (unsigned)kyv;
-                            VY += (unsigned)(int)(signed char)(t >> 8) * (unsigned)(kyv >> 32);
+                            for (int j = 0; j < nkt; ++j) {
+                                const unsigned kw = (j < 2) ? k0 : (j < 4) ? k1 : (j < 6) ? k2 : k3;
+                                const unsigned t = (kw >> (16 * (j & 1))) & 0xffffu;
+                                const unsigned long long kyv = box_ky_valid_m(Sp, base, (int)(t & 0xffu), pv, sr);
+                                VK += (unsigned)(int)(signed char)(t >> 8) * (unsigned)kyv;
+                                VY += (unsigned)(int)(signed char)(t >> 8) * (unsigned)(kyv >> 32);
+                            }
                         }
                         if (VK == 0u) { SK = 0.0; SY = 0.0; }
                         else if (VY == 0u) SY = 0.0;
@@ -2005,9 +2029,9 @@ static void launch_stencil_t(const HpkStencilArgs& a, hipStream_t st) {
 
 int hpk_stencil_s_lds_bytes() { return LR * LC * 12 + HPK_TLIST * 4 + 128 + HPK_MAX_STEPS * 32 + HPK_KSLOTS * 32; }
 
-template <bool BALF64>
+template <bool BALF64, bool SINGLE>
 static void launch_stencil_s_t(const HpkStencilArgs& a, hipStream_t st) {
-    auto kern = hpk_stencil_s<BALF64>;
+    auto kern = hpk_stencil_s<BALF64, SINGLE>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2026,7 +2050,10 @@ bool hpk_stencil_s_applies(const HpkStencilArgs& a, bool simple) {
 
 void hpk_launch_stencil(const HpkStencilArgs& a, bool balf64, bool simple, hipStream_t st) {
     if (hpk_stencil_s_applies(a, simple)) {
-        if (balf64) launch_stencil_s_t<true>(a, st); else launch_stencil_s_t<false>(a, st);
+        static const bool nosingle = std::getenv("HPK_NO_SINGLE") != nullptr;
+        const bool single = a.single && !nosingle;
+        if (balf64) { if (single) launch_stencil_s_t<true, true>(a, st); else launch_stencil_s_t<true, false>(a, st); }
+        else        { if (single) launch_stencil_s_t<false, true>(a, st); else launch_stencil_s_t<false, false>(a, st); }
         return;
     }
     constexpr int NW = HPK_NWAVES;

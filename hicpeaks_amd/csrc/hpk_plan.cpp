@@ -172,6 +172,20 @@ int hpk_build_plan(const hpk_params* prm, HpkDevPlan* plan, char* msg) {
     plan->simple_reads = simple ? 1 : 0;
     plan->reads_p0 = simple ? p0 : 0;
 
+    // textbook single-pair plans
+    plan->single_p = -1;
+    if (simple && plan->nslots == 1 && plan->nsteps == W - plan->wmin + 1) {
+        const int p = plan->slot_pi[0];
+        bool ok = true;
+        for (int s = 0; s < plan->nsteps && ok; ++s) {
+            const HpkDevStep& st = plan->steps[s];
+            ok = st.wi == plan->wmin + s && st.wi > p;
+            if (p > 0) ok = ok && st.nkt == 2 && st.kt_rho[0] == p && st.kt_coef[0] == -1 && st.kt_rho[1] == st.wi && st.kt_coef[1] == 1;
+            else ok = ok && st.nkt == 1 && st.kt_rho[0] == st.wi && st.kt_coef[0] == 1;
+        }
+        if (ok) plan->single_p = p;
+    }
+
     // cell counts per diagonal offset for the local-expected tables
     for (int s = 0; s < plan->nsteps; ++s) {
         const HpkDevStep& st = plan->steps[s];

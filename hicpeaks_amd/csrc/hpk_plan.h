@@ -55,6 +55,10 @@ struct HpkDevPlan {
     // Local-expected stencils for the device-side table build: the window of step s holds ecoef[s][fl][t] cells
     // (with multiplicity) at diagonal offset delta = t - 2W, so bE[s][fl](d) = sum_t ecoef * IR[d + t - 2W].
     int16_t ecoef[HPK_MAX_STEPS][2][4 * HPK_MAX_W + 1];
+    // "Textbook" plans - one peak width, every step (p, w) the plain donut Box(w) - Box(p) with steps at consecutive
+    // widths from wmin on (every single-pair run of hiccups() and every bhfdr() run): the peak width p, else -1.  The
+    // stencil then needs no per-candidate plan look-up: step = w* - wmin, sums = box(w*) - box(p).
+    int32_t single_p;
 };
 #define HPK_PK_RT 4
 #define HPK_PK_KT 8
