@@ -534,7 +534,8 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     j->dense = j->sums || (prm->flags & HPK_FLAG_DENSE_E) != 0;
     j->do_score = (prm->flags & HPK_FLAG_NO_SCORE) == 0;
     j->phases = (prm->flags & HPK_FLAG_PHASE_TIMING) != 0;
-    j->rounds = std::getenv("HPK_ROUNDS") ? std::atoi(std::getenv("HPK_ROUNDS")) : 2;
+    j->rounds = std::getenv("HPK_ROUNDS") ? std::atoi(std::getenv("HPK_ROUNDS")) : -1;     // < 0: one histogram pass (hpk_thr_hist)
+    if (j->rounds > 4) j->rounds = 4;
     const bool sums = j->sums, dense = j->dense;
 
     j->box = new ResultBox();

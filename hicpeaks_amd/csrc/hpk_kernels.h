@@ -68,7 +68,7 @@ struct HpkSurv {
     double E, p, bal;
 };
 #define HPK_NFAM (2 * HPK_MAX_PAIRS * (HPK_NB + 1))     // (set, chunk) families
-#define HPK_TIGHTEN_MAX 4                                // rounds of BH-cut tightening (one counter array each)
+#define HPK_TIGHTEN_MAX 16                               // counter arrays per family: exact rounds, or the bins of the one-pass histogram
 #define HPK_NREG 64                     // independent survivor regions (one reservation counter each, 256 B apart)
 #define HPK_REG_STRIDE 32               // counters are u64[HPK_NREG * HPK_REG_STRIDE]
 
@@ -146,6 +146,7 @@ void hpk_launch_gap(const float* raw, const double* bal, const double* weight, i
 void hpk_launch_score(const HpkScoreArgs& a, bool bhfdr, int cus, hipStream_t st);
 // Benjamini-Hochberg cut tightening on the survivor list: thr[f] <- sig * #{p <= thr[f]} / m[f], `rounds` times,
 // then compaction of the records with p <= thr[f] into `out` (count in *nout).
+int  hpk_thr_hist_bins(int nsets);       // bins per family of the one-pass tightening (rounds < 0)
 void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned* chunk_used,
                         const unsigned int* fam_m, const unsigned int* fam_f, unsigned int* fam_cnt, double sig, int rounds,
                         int nsets, HpkSurv* out_head, unsigned long long inl, HpkSurv* out_rest, unsigned long long* nout,

@@ -1825,6 +1825,67 @@ __device__ __forceinline__ void thr_table(double* lthr, const unsigned int* __re
         lthr[i] = t;
     }
 }
+// One-pass variant of the tightening rounds: instead of counting F(T_k) exactly, one launch per round, ONE launch
+// histograms the p-values of every family below T_0 = sig F(sig) / m on a log2 scale (bin k: T_0 2^-(k+1) < p <= T_0 2^-k,
+// the last bin open towards 0), and the compaction derives its bound from the histogram: T <- sig C(T) / m with C(T) the
+// count up to the first bin edge at or above T - an over-count, so the bound stays above the true Benjamini-Hochberg cut
+// (every p-value it drops has a step-up term above sig) while coming within a factor 2 of the exact fixed point.
+__device__ __forceinline__ double thr_t0(unsigned m, unsigned f, double sig) {
+    return m ? fmin(sig, sig * ((double)f / (double)m) * (1.0 + 1e-9)) : 0.0;
+}
+__global__ void __launch_bounds__(256) hpk_thr_hist(const HpkSurv* __restrict__ surv, const unsigned long long* __restrict__ nsurv,
+                                                    int64_t cap, const unsigned* __restrict__ chunk_used,
+                                                    const unsigned int* __restrict__ fam_m, const unsigned int* __restrict__ fam_f,
+                                                    unsigned int* __restrict__ hist, int nbins, double sig, int nfam) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    double* lt0 = reinterpret_cast<double*>(hsm);                        // [nfam]
+    unsigned* lh = reinterpret_cast<unsigned*>(hsm + (size_t)nfam * 8);   // [nfam][nbins]
+    const int reg = blockIdx.y;
+    int64_t n = (int64_t)nsurv[reg * HPK_REG_STRIDE]; if (n > cap) n = cap;
+    if ((int64_t)blockIdx.x * blockDim.x >= n) return;
+    for (int i = threadIdx.x; i < nfam; i += blockDim.x) lt0[i] = thr_t0(fam_m[i], fam_f[i], sig);
+    for (int i = threadIdx.x; i < nfam * nbins; i += blockDim.x) lh[i] = 0u;
+    __syncthreads();
+    const int64_t rb = (int64_t)reg * cap;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if ((unsigned)(i & (HPK_SCH - 1)) >= chunk_used[(rb + i) >> HPK_SCH_LOG2]) continue;
+        const HpkSurv& rec = surv[rb + i];
+        const int f = (int)rec.set * (HPK_NB + 1) + (int)rec.chunk;
+        const double p = rec.p, t0 = lt0[f];
+        if (p <= t0) {
+            int k = nbins - 1;
+            if (p > 0.0) {                 // exponent of t0 / p: the quotient never rounds below a power of two it reaches
+                k = (int)((__double_as_longlong(t0 / p) >> 52) & 0x7ff) - 1023;
+                k = k < 0 ? 0 : (k > nbins - 1 ? nbins - 1 : k);
+            }
+            atomicAdd(&lh[f * nbins + k], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nfam * nbins; i += blockDim.x) if (lh[i]) atomicAdd(&hist[i], lh[i]);
+}
+// bound per family from the histogram (see hpk_thr_hist)
+__device__ __forceinline__ void thr_table_hist(double* lthr, const unsigned int* __restrict__ fam_m, const unsigned int* __restrict__ fam_f,
+                                               const unsigned int* __restrict__ hist, int nbins, double sig, int nfam) {
+    for (int i = threadIdx.x; i < nfam; i += blockDim.x) {
+        const unsigned m = fam_m[i];
+        const double t0 = thr_t0(m, fam_f[i], sig);
+        double t = t0;
+        if (m && t0 > 0.0) {
+            for (int it = 0; it < 2 * nbins; ++it) {
+                // largest k whose edge t0 2^-k is still >= t (with a margin for the rounding of the quotient)
+                int k = (int)((__double_as_longlong(t0 / (t * (1.0 + 1e-12))) >> 52) & 0x7ff) - 1023;
+                k = k < 0 ? 0 : (k > nbins - 1 ? nbins - 1 : k);
+                unsigned long long c = 0ull;
+                for (int kk = k; kk < nbins; ++kk) c += hist[(size_t)i * nbins + kk];
+                const double tn = fmin(t, sig * ((double)c / (double)m) * (1.0 + 1e-9));
+                if (!(tn < t)) break;
+                t = tn;
+            }
+        }
+        lthr[i] = t;
+    }
+}
 __global__ void __launch_bounds__(256) hpk_thr_count(const HpkSurv* __restrict__ surv, const unsigned long long* __restrict__ nsurv,
                                                      int64_t cap, const unsigned* __restrict__ chunk_used,
                                                      const unsigned int* __restrict__ fam_m, const unsigned int* __restrict__ fam_f,
@@ -1865,7 +1926,8 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkSurv* __restrict
     const int reg = blockIdx.y;
     int64_t n = (int64_t)nsurv[reg * HPK_REG_STRIDE]; if (n > cap) n = cap;
     if ((int64_t)blockIdx.x * blockDim.x >= n) return;
-    thr_table(lthr, fam_m, fam_f, cnt, rounds, sig, nfam);
+    if (rounds < 0) thr_table_hist(lthr, fam_m, fam_f, cnt, -rounds, sig, nfam);
+    else thr_table(lthr, fam_m, fam_f, cnt, rounds, sig, nfam);
     __syncthreads();
     const int64_t rb = (int64_t)reg * cap;
     for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
@@ -2100,6 +2162,8 @@ void hpk_launch_score(const HpkScoreArgs& a, bool bhfdr, int cus, hipStream_t st
     else hipLaunchKernelGGL(hpk_score<false>, dim3(score_grid<false>(cus)), dim3(256), 0, st, a);
 }
 
+int hpk_thr_hist_bins(int nsets) { return nsets * (HPK_NB + 1) <= 1032 ? 16 : 8; }   // LDS of hpk_thr_hist <= 83 KB
+
 void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned* chunk_used,
                         const unsigned int* fam_m, const unsigned int* fam_f, unsigned int* fam_cnt, double sig, int rounds,
                         int nsets, HpkSurv* out_head, unsigned long long inl, HpkSurv* out_rest, unsigned long long* nout,
@@ -2107,6 +2171,19 @@ void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, in
     if (rounds > HPK_TIGHTEN_MAX) rounds = HPK_TIGHTEN_MAX;
     const int nfam = nsets * (HPK_NB + 1);          // families in use: (set, chunk)
     static const int gx = std::getenv("HPK_THR_GX") ? std::atoi(std::getenv("HPK_THR_GX")) : 8;
+    if (rounds < 0) {           // one histogram pass instead of the counting rounds (fam_cnt = [nfam][nbins], zeroed)
+        const int nbins = hpk_thr_hist_bins(nsets);
+        const size_t lds = (size_t)nfam * 8 + (size_t)nfam * nbins * 4;
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hpk_thr_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(hpk_thr_hist, dim3(gx, HPK_NREG), dim3(256), lds, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt, nbins, sig, nfam);
+        hipLaunchKernelGGL(hpk_thr_compact, dim3(gx, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt,
+                           -nbins, sig, nfam, out_head, inl, out_rest, nout, bal, weight, ld);
+        return;
+    }
     for (int r = 0; r < rounds; ++r)
         hipLaunchKernelGGL(hpk_thr_count, dim3(gx, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt, r, sig, nfam);
     hipLaunchKernelGGL(hpk_thr_compact, dim3(gx, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt,
