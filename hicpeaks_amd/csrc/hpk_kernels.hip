@@ -931,8 +931,9 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         double bv[2];
         unsigned pk[2];
         // candidates of the row: the list slice is reserved now, the entries are written after the row's scan
-        unsigned long long M[2] = {0ull, 0ull};
-        unsigned entv[2] = {0u, 0u};
+        unsigned long long M[2];
+        bool cdv[2];
+        unsigned entv[2];
         unsigned slot = 0u;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -948,17 +949,15 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
                 bv[e] = fmax(((double)rv * wr) * nxt.wc[e], 0.0);       // (raw * w_r) * w_c, NaN -> 0
             }
             pk[e] = rc | (bv[e] != 0.0 ? 1u << PK_SHIFT : 0u);
-            if (rowout) {                                               // uniform
-                const bool cd = (ru != 0u) & ((unsigned)(xo - e) < (unsigned)TC) & ((unsigned)km <= (unsigned)(Dm - mw));
-                M[e] = __ballot(cd);
-                const unsigned yy = ((unsigned)(y >> 4) << 7) | ((unsigned)(y & 15) << (7 + HPK_YI_BITS));
-                entv[e] = (unsigned)(xo - e) | yy | (rc << 13);
-            }
+            // (no branch on the row: the predicate flows straight into the ballot; rows outside the output tile give 0)
+            cdv[e] = rowout & (ru != 0u) & ((unsigned)(xo - e) < (unsigned)TC) & ((unsigned)km <= (unsigned)(Dm - mw));
+            M[e] = __ballot(cdv[e]);
+            entv[e] = (unsigned)(xo - e) | (rc << 13);
         }
-        if (rowout) {
+        const unsigned nrow = (unsigned)(__popcll(M[0]) + __popcll(M[1]));
+        if (nrow != 0u) {
             // hipcc's atomic optimiser would wait for the returned value on the spot; issued by hand, the LDS round
             // trip runs beside the row's scan (all lanes add the same count into the same word: lane 0 only)
-            const unsigned nrow = (unsigned)(__popcll(M[0]) + __popcll(M[1]));
             const unsigned addr = (unsigned)(size_t)tcnt;
             if (lane == 0) asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(slot) : "v"(addr), "v"(nrow) : "memory");
         }
@@ -978,15 +977,15 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
             *reinterpret_cast<double2*>(&Sc[o]) = make_double2(ac[1], ac[0]);
             *reinterpret_cast<uint2*>(&Sp[o]) = make_uint2(ar[1], ar[0]);
         }
-        if (rowout) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(slot) :: "memory");
-        if (rowout && (M[0] | M[1]) != 0ull) {
+        if (nrow != 0u) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(slot) :: "memory");
             // entries in the order of the scan (descending column): cell e = 0 of a lane, then its cell e = 1
+            const unsigned yy = ((unsigned)(y >> 4) << 7) | ((unsigned)(y & 15) << (7 + HPK_YI_BITS));
             const unsigned at = (unsigned)__builtin_amdgcn_readfirstlane((int)slot) +
                                 __builtin_amdgcn_mbcnt_hi((unsigned)(M[0] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M[0], 0u)) +
                                 __builtin_amdgcn_mbcnt_hi((unsigned)(M[1] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M[1], 0u));
-            const bool c0b = (M[0] >> lane) & 1ull, c1b = (M[1] >> lane) & 1ull;
-            if (c0b) lst[at] = entv[0];
-            if (c1b) lst[at + (c0b ? 1u : 0u)] = entv[1];
+            if (cdv[0]) lst[at] = entv[0] | yy;
+            if (cdv[1]) lst[at + (cdv[0] ? 1u : 0u)] = entv[1] | yy;
         }
     }
     HPK_CLK(ck0)
