@@ -712,6 +712,8 @@ __device__ __forceinline__ double ldbuf_f64(rsrc_t r, unsigned off, unsigned sof
 // (2 per wave: SAT rows 48..79)
 __device__ __forceinline__ constexpr int sat_row(int wave, int j) { return j < 3 ? 3 * wave + j : 48 + 2 * wave + (j - 3); }
 
+// the lane mask of a predicate as the compiler holds it (HIP's __ballot goes through an int: v_cndmask + v_cmp per call)
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // box sums on the column-reversed table P(Y, X) = sum over rows <= Y, columns >= X (hpk_stencil_s).
 // Lower-left box of capped raw counts at radius rho: rows (Y, Y + rho], columns [X - rho, X - 1]; sr = P(Y, X).
 __device__ __forceinline__ unsigned reads_box_m(const unsigned* __restrict__ Pr, int base, int rho, unsigned sr) {
@@ -725,6 +727,34 @@ __device__ __forceinline__ void box_ky_m(const double* __restrict__ P, int base,
     const double tl = P[t - rho], tm = P[t], tm1 = P[t + 1], tr = P[t + rho + 1];
     const double bl = P[b - rho], bm = P[b], bm1 = P[b + 1], br = P[b + rho + 1];
     const double ml1 = P[base - rho], ml0 = P[m0 - rho], mr1 = P[base + rho + 1], mr0 = P[m0 + rho + 1];
+    const double bot = (bl - bm) + (bm1 - br);          // rows <= Y + rho, columns [X - rho, X - 1] and [X + 1, X + rho]
+    const double top = (tl - tm) + (tm1 - tr);          // rows <= Y - rho - 1, same columns
+    const double mid = (ml1 - mr1) - (ml0 - mr0);       // row Y, columns [X - rho, X + rho]
+    kc = ((bot - top) - mid) + pixc;
+    yc = (bl - bm) - (ml1 - sc);
+}
+// The same two on LDS byte addresses (phase 3 of hpk_stencil_s): per read one add of an offset to the cell's own address
+// instead of index arithmetic plus a scale, neighbours through the instruction's immediate.  pb = address of P(Y, X) in
+// the packed plane, cb = in the f64 plane (both include the workgroup's LDS base).
+typedef __attribute__((address_space(3))) const unsigned lds_cu32_t;
+typedef __attribute__((address_space(3))) const double lds_cf64_t;
+typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
+__device__ __forceinline__ unsigned lds_u32(unsigned addr) { return *(lds_cu32_t*)addr; }
+// (volatile: two ds_read_b64 take 2 LDS cycles each, the ds_read2_b64 the compiler would pair them into takes 8)
+__device__ __forceinline__ double lds_f64(unsigned addr) { return *(volatile lds_cf64_t*)addr; }
+__device__ __forceinline__ unsigned reads_box_b(unsigned pb, int rho, unsigned sr) {
+    const unsigned dn = (unsigned)rho * (unsigned)(LC * 4), lf = (unsigned)rho * 4u;       // (rho is uniform: scalar offsets)
+    return (lds_u32(pb + (dn - lf)) - lds_u32(pb + dn) - lds_u32(pb - lf) + sr) & PK_MASK;
+}
+__device__ __forceinline__ void box_ky_b(unsigned cb, int rho, double pixc, double sc, double& kc, double& yc) {
+    unsigned r8 = (unsigned)rho << 3, rL = (unsigned)rho << 10;      // LC * 8 = 1024
+    static_assert(LC * 8 == 1024, "row pitch of the f64 plane");
+    asm volatile("" : "+v"(r8), "+v"(rL));                           // (sums of the two, not multiplies of rho)
+    const unsigned up = cb - 1024u;                                  // row Y - 1
+    const unsigned u = rL + r8, d = rL - r8, at = up - rL, ab = cb + rL, al = up - r8, ar = up + r8;
+    const double tl = lds_f64(up - u), tm = lds_f64(at), tm1 = lds_f64(at + 8), tr = lds_f64(up - d + 8);
+    const double bl = lds_f64(cb + d), bm = lds_f64(ab), bm1 = lds_f64(ab + 8), br = lds_f64(cb + u + 8);
+    const double ml0 = lds_f64(al), ml1 = lds_f64(al + 1024), mr0 = lds_f64(ar + 8), mr1 = lds_f64(ar + 8 + 1024);
     const double bot = (bl - bm) + (bm1 - br);          // rows <= Y + rho, columns [X - rho, X - 1] and [X + 1, X + rho]
     const double top = (tl - tm) + (tm1 - tr);          // rows <= Y - rho - 1, same columns
     const double mid = (ml1 - mr1) - (ml0 - mr0);       // row Y, columns [X - rho, X + rho]
@@ -836,6 +866,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     unsigned* __restrict__ Sp = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 8);
     unsigned* __restrict__ lst = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 12);      // [HPK_TLIST] tile-wide candidate list
     unsigned* __restrict__ tcount = lst + HPK_TLIST;                  // [2] entries in the list, tiles alternate
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_u8_t*)smem;        // LDS address of the tables (phase 3 reads by address)
     // the widening plan as the batches read it: per step 8 words {w0 (HpkDevPlan::packed[0]), four words of box terms},
     // then step_of[slot][width] as bytes
     unsigned* __restrict__ pl = tcount + 32;                          // [HPK_MAX_STEPS][8]
@@ -951,7 +982,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
             pk[e] = rc | (bv[e] != 0.0 ? 1u << PK_SHIFT : 0u);
             // (no branch on the row: the predicate flows straight into the ballot; rows outside the output tile give 0)
             cdv[e] = rowout & (ru != 0u) & ((unsigned)(xo - e) < (unsigned)TC) & ((unsigned)km <= (unsigned)(Dm - mw));
-            M[e] = __ballot(cdv[e]);
+            M[e] = ballot64(cdv[e]);
             entv[e] = (unsigned)(xo - e) | (rc << 13);
         }
         const unsigned nrow = (unsigned)(__popcll(M[0]) + __popcll(M[1]));
@@ -1082,23 +1113,28 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         if (cand) ent_t[i] = id;
         // one round of reads: P(Y, X) of both planes, the pixel's own value, the three Reads boxes that decide most
         // candidates (p0: subtracted from all, narrowest, widest), the largest corner of the widest window
-        const unsigned sr = Sp[base];
-        const double sc = Sc[base];
-        const double pixc = (sc - Sc[base + 1]) - (Sc[base - LC] - Sc[base - LC + 1]);
-        const double amax = Sc[base + W * LC - W];
-        const unsigned b0 = (p0_p > 0) ? reads_box_m(Sp, base, p0_p, sr) : 0u;
-        const unsigned bf = reads_box_m(Sp, base, wmin_p, sr);
-        const unsigned bl = reads_box_m(Sp, base, W, sr);
+        const unsigned cb = lds0 + (unsigned)base * 8u, pb = lds0 + (unsigned)(LR * LC * 8) + (unsigned)base * 4u;
+        const unsigned sr = lds_u32(pb);
+        const double sc = lds_f64(cb);
+        const double pixc = (sc - lds_f64(cb + 8)) - (lds_f64(cb - LC * 8) - lds_f64(cb - LC * 8 + 8));
+        const double amax = lds_f64(cb + (unsigned)(W * (LC - 1) * 8));
+        const unsigned b0 = (p0_p > 0) ? reads_box_b(pb, p0_p, sr) : 0u;
+        const unsigned bf = reads_box_b(pb, wmin_p, sr);
+        const unsigned bl = reads_box_b(pb, W, sr);
         int wstar = 255;
         wstar = (cand & (bl - b0 >= (unsigned)minr_p)) ? W : wstar;
         wstar = (cand & (bf - b0 >= (unsigned)minr_p)) ? wmin_p : wstar;
         // lanes that pass the widest but not the narrowest box: all widths in between, four at a time (Reads is monotone)
-        if (W - wmin_p > 1 && __ballot(wstar == W) != 0ull) {
+        if (W - wmin_p > 1 && ballot64(wstar == W) != 0ull) {
 #pragma unroll 1
             for (int wa = wmin_p + 1; wa < W; wa += 4) {
+                // widths wa .. wa + 3 from three addresses (those at or beyond W read rows the list follows: not used)
+                const unsigned dn = (unsigned)wa * (unsigned)(LC * 4), lf = (unsigned)wa * 4u;
+                const unsigned a1 = pb + dn, a2 = pb + (dn - lf), a3 = pb - (lf + 12u);
                 unsigned rd[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) rd[t] = reads_box_m(Sp, base, (wa + t < W) ? wa + t : W - 1, sr);
+                for (int t = 0; t < 4; ++t)
+                    rd[t] = (lds_u32(a2 + t * (LC * 4 - 4)) - lds_u32(a1 + t * (LC * 4)) - lds_u32(a3 + (3 - t) * 4) + sr) & PK_MASK;
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     wstar = ((wa + t < W) & (wstar == W) & (rd[t] - b0 >= (unsigned)minr_p)) ? wa + t : wstar;
@@ -1106,12 +1142,12 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         }
         // resolve histogram by width: one ballot per width present
         {
-            const unsigned long long mf = __ballot(wstar == wmin_p);
+            const unsigned long long mf = ballot64(wstar == wmin_p);
             if (lane == wmin_p) myhist += (unsigned)__popcll(mf);
-            if (__ballot((wstar != wmin_p) & (wstar != 255)) != 0ull) {
+            if (ballot64((wstar != wmin_p) & (wstar != 255)) != 0ull) {
 #pragma unroll 1
                 for (int w = wmin_p + 1; w <= W; ++w) {
-                    const unsigned c = (unsigned)__popcll(__ballot(wstar == w));
+                    const unsigned c = (unsigned)__popcll(ballot64(wstar == w));
                     if (lane == w) myhist += c;
                 }
             }
@@ -1129,14 +1165,14 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
             }
             const bool act = sq != 0xff;
             double SK = 0.0, SY = 0.0;
-            if (__ballot(act) != 0ull) {
+            if (ballot64(act) != 0ull) {
                 unsigned w0 = 0u, k0 = 0u, k1 = 0u, k2 = 0u, k3 = 0u;
                 int nkt = 0, rho_min;
                 if (SINGLE) {
                     // Box(w*) - Box(p): the outer radius per lane, the inner one the same for all
                     double kcw, ycw, kcp = 0.0, ycp = 0.0;
-                    box_ky_m(Sc, base, act ? wstar : 1, pixc, sc, kcw, ycw);
-                    if (sp_p > 0) box_ky_m(Sc, base, sp_p, pixc, sc, kcp, ycp);
+                    box_ky_b(cb, act ? wstar : 1, pixc, sc, kcw, ycw);
+                    if (sp_p > 0) box_ky_b(cb, sp_p, pixc, sc, kcp, ycp);
                     SK = act ? kcw - kcp : 0.0;
                     SY = act ? ycw - ycp : 0.0;
                     rho_min = sp_p + 1;
@@ -1149,13 +1185,13 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
 #pragma unroll 1
                     for (int j = 0; j < maxnkt; ++j) {
                         const bool on = j < nkt;
-                        if (__ballot(on) == 0ull) break;
+                        if (ballot64(on) == 0ull) break;
                         const unsigned kw = (j < 2) ? k0 : (j < 4) ? k1 : (j < 6) ? k2 : k3;
                         const unsigned t = (kw >> (16 * (j & 1))) & 0xffffu;
                         const int rho = on ? (int)(t & 0xffu) : 1;      // idle lanes read a harmless box
                         const double cf = on ? (double)(int)(signed char)(t >> 8) : 0.0;
                         double kc, yc;
-                        box_ky_m(Sc, base, rho, pixc, sc, kc, yc);
+                        box_ky_b(cb, rho, pixc, sc, kc, yc);
                         SK += cf * kc; SY += cf * yc;
                     }
                     rho_min = (int)((w0 >> 24) & 31u);
@@ -1170,9 +1206,9 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
                 // typically two orders below).
                 const double thr = amax * a.risk;
                 const bool risky = act & ((SK < thr) | ((SY < thr) & (SY != 0.0)));
-                if (__ballot(risky) != 0ull) {
+                if (ballot64(risky) != 0ull) {
 #ifdef HPK_PHASE_CLOCK
-                    ck6 += (unsigned long long)__popcll(__ballot(risky && SK > 0.0)) << 40;
+                    ck6 += (unsigned long long)__popcll(ballot64(risky && SK > 0.0)) << 40;
 #endif
                     if (risky) {
                         const unsigned pv = sr - Sp[base + 1] - Sp[base - LC] + Sp[base - LC + 1];
@@ -1196,7 +1232,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
                         else if (VY == 0u) SY = 0.0;
                     }
                     // what is left has non-zero cells: one pixel at a time, the whole wave on it
-                    unsigned long long todo = __ballot(risky && SK != 0.0);
+                    unsigned long long todo = ballot64(risky && SK != 0.0);
                     while (todo != 0ull) {
                         const int src = __ffsll((long long)todo) - 1;
                         todo &= todo - 1ull;
