@@ -761,6 +761,23 @@ __device__ __forceinline__ void box_ky_b(unsigned cb, int rho, double pixc, doub
     kc = ((bot - top) - mid) + pixc;
     yc = (bl - bm) - (ml1 - sc);
 }
+// Single-pair plans take Box(w*) - Box(p): the pixel's own value and P(Y, X) cancel between the two, so neither is read.
+// kc, yc: the sums without those terms; big: the largest table entry the sums touch (what their rounding noise scales with).
+__device__ __forceinline__ void box_ky_d(unsigned cb, int rho, double& kc, double& yc, double& big) {
+    unsigned r8 = (unsigned)rho << 3, rL = (unsigned)rho << 10;
+    asm volatile("" : "+v"(r8), "+v"(rL));
+    const unsigned up = cb - 1024u;
+    const unsigned u = rL + r8, d = rL - r8, at = up - rL, ab = cb + rL, al = up - r8, ar = up + r8;
+    const double tl = lds_f64(up - u), tm = lds_f64(at), tm1 = lds_f64(at + 8), tr = lds_f64(up - d + 8);
+    const double bl = lds_f64(cb + d), bm = lds_f64(ab), bm1 = lds_f64(ab + 8), br = lds_f64(cb + u + 8);
+    const double ml0 = lds_f64(al), ml1 = lds_f64(al + 1024), mr0 = lds_f64(ar + 8), mr1 = lds_f64(ar + 8 + 1024);
+    const double bot = (bl - bm) + (bm1 - br);
+    const double top = (tl - tm) + (tm1 - tr);
+    const double mid = (ml1 - mr1) - (ml0 - mr0);
+    kc = (bot - top) - mid;
+    yc = (bl - bm) - ml1;
+    big = bl;
+}
 __device__ __noinline__ unsigned long long box_ky_valid_m(const unsigned* __restrict__ Pv, int base, int rho, unsigned pixv, unsigned sv) {
     const int t = base - (rho + 1) * LC, b = base + rho * LC, m0 = base - LC;
     const unsigned tl = Pv[t - rho], tm = Pv[t], tm1 = Pv[t + 1], tr = Pv[t + rho + 1];
@@ -1115,9 +1132,13 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         // candidates (p0: subtracted from all, narrowest, widest), the largest corner of the widest window
         const unsigned cb = lds0 + (unsigned)base * 8u, pb = lds0 + (unsigned)(LR * LC * 8) + (unsigned)base * 4u;
         const unsigned sr = lds_u32(pb);
-        const double sc = lds_f64(cb);
-        const double pixc = (sc - lds_f64(cb + 8)) - (lds_f64(cb - LC * 8) - lds_f64(cb - LC * 8 + 8));
-        const double amax = lds_f64(cb + (unsigned)(W * (LC - 1) * 8));
+        const bool diffp = SINGLE && sp_p > 0;                      // Box(w*) - Box(p): see box_ky_d
+        double sc = 0.0, pixc = 0.0, amax = 0.0;
+        if (!diffp) {
+            sc = lds_f64(cb);
+            pixc = (sc - lds_f64(cb + 8)) - (lds_f64(cb - LC * 8) - lds_f64(cb - LC * 8 + 8));
+            amax = lds_f64(cb + (unsigned)(W * (LC - 1) * 8));
+        }
         const unsigned b0 = (p0_p > 0) ? reads_box_b(pb, p0_p, sr) : 0u;
         const unsigned bf = reads_box_b(pb, wmin_p, sr);
         const unsigned bl = reads_box_b(pb, W, sr);
@@ -1171,8 +1192,11 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
                 if (SINGLE) {
                     // Box(w*) - Box(p): the outer radius per lane, the inner one the same for all
                     double kcw, ycw, kcp = 0.0, ycp = 0.0;
-                    box_ky_b(cb, act ? wstar : 1, pixc, sc, kcw, ycw);
-                    if (sp_p > 0) box_ky_b(cb, sp_p, pixc, sc, kcp, ycp);
+                    if (diffp) {
+                        double bigp;
+                        box_ky_d(cb, act ? wstar : 1, kcw, ycw, amax);
+                        box_ky_d(cb, sp_p, kcp, ycp, bigp);
+                    } else box_ky_b(cb, act ? wstar : 1, pixc, sc, kcw, ycw);
                     SK = act ? kcw - kcp : 0.0;
                     SY = act ? ycw - ycp : 0.0;
                     rho_min = sp_p + 1;
