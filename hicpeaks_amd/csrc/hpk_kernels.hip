@@ -761,9 +761,11 @@ __device__ __forceinline__ void box_ky_b(unsigned cb, int rho, double pixc, doub
     kc = ((bot - top) - mid) + pixc;
     yc = (bl - bm) - (ml1 - sc);
 }
-// Single-pair plans take Box(w*) - Box(p): the pixel's own value and P(Y, X) cancel between the two, so neither is read.
-// kc, yc: the sums without those terms; big: the largest table entry the sums touch (what their rounding noise scales with).
-__device__ __forceinline__ void box_ky_d(unsigned cb, int rho, double& kc, double& yc, double& big) {
+// The box coefficients of a step add up to 0 whenever its innermost box has a radius (Box(w*) - Box(p) for a single
+// pair): the pixel's own value then cancels in the donut sum and is neither read nor added.  kc: the donut sum without
+// it; yc as in box_ky_b - with P(Y, X), so that a lower-left box over empty rows stays an exact 0 (its four corners are
+// pairwise the same numbers); big: the largest table entry the sums touch (what their rounding noise scales with).
+__device__ __forceinline__ void box_ky_d(unsigned cb, int rho, double sc, double& kc, double& yc, double& big) {
     unsigned r8 = (unsigned)rho << 3, rL = (unsigned)rho << 10;
     asm volatile("" : "+v"(r8), "+v"(rL));
     const unsigned up = cb - 1024u;
@@ -775,7 +777,7 @@ __device__ __forceinline__ void box_ky_d(unsigned cb, int rho, double& kc, doubl
     const double top = (tl - tm) + (tm1 - tr);
     const double mid = (ml1 - mr1) - (ml0 - mr0);
     kc = (bot - top) - mid;
-    yc = (bl - bm) - ml1;
+    yc = (bl - bm) - (ml1 - sc);
     big = bl;
 }
 __device__ __noinline__ unsigned long long box_ky_valid_m(const unsigned* __restrict__ Pv, int base, int rho, unsigned pixv, unsigned sv) {
@@ -1133,9 +1135,9 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         const unsigned cb = lds0 + (unsigned)base * 8u, pb = lds0 + (unsigned)(LR * LC * 8) + (unsigned)base * 4u;
         const unsigned sr = lds_u32(pb);
         const bool diffp = SINGLE && sp_p > 0;                      // Box(w*) - Box(p): see box_ky_d
-        double sc = 0.0, pixc = 0.0, amax = 0.0;
-        if (!diffp) {
-            sc = lds_f64(cb);
+        const double sc = lds_f64(cb);
+        double pixc = 0.0, amax = 0.0;
+        if (SINGLE && !diffp) {
             pixc = (sc - lds_f64(cb + 8)) - (lds_f64(cb - LC * 8) - lds_f64(cb - LC * 8 + 8));
             amax = lds_f64(cb + (unsigned)(W * (LC - 1) * 8));
         }
@@ -1194,13 +1196,15 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
                     double kcw, ycw, kcp = 0.0, ycp = 0.0;
                     if (diffp) {
                         double bigp;
-                        box_ky_d(cb, act ? wstar : 1, kcw, ycw, amax);
-                        box_ky_d(cb, sp_p, kcp, ycp, bigp);
+                        box_ky_d(cb, act ? wstar : 1, sc, kcw, ycw, amax);
+                        box_ky_d(cb, sp_p, sc, kcp, ycp, bigp);
                     } else box_ky_b(cb, act ? wstar : 1, pixc, sc, kcw, ycw);
                     SK = act ? kcw - kcp : 0.0;
                     SY = act ? ycw - ycp : 0.0;
                     rho_min = sp_p + 1;
                 } else {
+                    double cfs = 0.0;
+                    amax = 0.0;
                     const int src = act ? sq : 0;
                     const uint4 pw4 = *reinterpret_cast<const uint4*>(&pl[src * 8]);
                     w0 = pw4.x; k0 = pw4.y; k1 = pw4.z; k2 = pw4.w;
@@ -1214,10 +1218,15 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
                         const unsigned t = (kw >> (16 * (j & 1))) & 0xffffu;
                         const int rho = on ? (int)(t & 0xffu) : 1;      // idle lanes read a harmless box
                         const double cf = on ? (double)(int)(signed char)(t >> 8) : 0.0;
-                        double kc, yc;
-                        box_ky_b(cb, rho, pixc, sc, kc, yc);
+                        double kc, yc, big;
+                        box_ky_d(cb, rho, sc, kc, yc, big);
                         SK += cf * kc; SY += cf * yc;
+                        cfs += cf;
+                        amax = on ? fmax(amax, big) : amax;
                     }
+                    // (box_ky_d) a step whose coefficients do not cancel still needs the pixel's own value
+                    if (ballot64(cfs != 0.0) != 0ull)
+                        SK += cfs * ((sc - lds_f64(cb + 8)) - (lds_f64(cb - LC * 8) - lds_f64(cb - LC * 8 + 8)));
                     rho_min = (int)((w0 >> 24) & 31u);
                 }
                 // lower-left support off the band: exact 0 (see hpk_stencil)
@@ -1256,7 +1265,10 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
                         else if (VY == 0u) SY = 0.0;
                     }
                     // what is left has non-zero cells: one pixel at a time, the whole wave on it
-                    unsigned long long todo = ballot64(risky && SK != 0.0);
+                    unsigned long long todo = ballot64(risky && SK != 0.0 && ((SK < thr) | ((SY < thr) & (SY != 0.0))));
+#ifdef HPK_PHASE_CLOCK
+                    ck7 += (unsigned long long)__popcll(todo) << 40;
+#endif
                     while (todo != 0ull) {
                         const int src = __ffsll((long long)todo) - 1;
                         todo &= todo - 1ull;

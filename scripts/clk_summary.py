@@ -8,6 +8,8 @@ import numpy as np
 raw = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 16, 8)
 risky = (raw[:, :, 6] >> np.uint64(40)).astype(np.float64)      # hpk_stencil_s: candidates redone exactly, in the high bits
 raw[:, :, 6] &= np.uint64((1 << 40) - 1)
+explicit = (raw[:, :, 7] >> np.uint64(40)).astype(np.float64)   # ... of those, added cell by cell by the whole wave
+raw[:, :, 7] &= np.uint64((1 << 40) - 1)
 a = raw.astype(np.float64)
 names = ['wait+phase1', 'prefetch+coltot', 'scan+write', 'barrier(SAT)', 'gap+lists', 'batches', 'barrier(end)']
 tot = a[:, :, :7].sum(axis=2)
@@ -22,4 +24,5 @@ print('batches per wave: mean %.1f; per-WG sum min %d max %d mean %.0f' % (nb.me
 wg = a[:, :, 5].mean(axis=1)
 print('batch-phase ticks per WG, deciles:', np.percentile(wg, [0, 10, 25, 50, 75, 90, 100]).round(0).tolist())
 print('ticks per batch (sum batches-phase / sum batches): %.1f' % (a[:, :, 5].sum() / max(nb.sum(), 1)))
-print('candidates redone exactly (hpk_stencil_s): %d, per-WG max %d' % (risky.sum(), risky.sum(axis=1).max()))
+print('sums below the risk threshold (hpk_stencil_s): %d, per-WG max %d; added cell by cell: %d, per-WG max %d' % (
+    risky.sum(), risky.sum(axis=1).max(), explicit.sum(), explicit.sum(axis=1).max()))
