@@ -16,8 +16,7 @@
 #define HPK_NWAVES 16                   // waves per stencil workgroup (16 or 8)
 #endif
 #define HPK_ROWS_PER_WAVE (64 / HPK_NWAVES)                  // output-tile rows a wave walks in phase 3 (tile rows <= 64)
-#define HPK_YI_BITS (HPK_NWAVES == 16 ? 2 : 3)              // record entry: x (7 bits) | row slot | wave | capped count << 13
-#define HPK_WV_BITS (HPK_NWAVES == 16 ? 4 : 3)
+// record entry of a candidate: x (7 bits) | y << 7 (6 bits: row of the output tile) | capped raw count << 13
 #define HPK_LISTCAP (HPK_ROWS_PER_WAVE * 128)               // candidate ids per wave and tile
 
 struct HpkStencilArgs {

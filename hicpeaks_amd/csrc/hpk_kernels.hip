@@ -448,7 +448,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
             const unsigned long long M = __ballot(cnd);
             if (M == 0ull) continue;
             const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(M >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M, 0u));
-            if (cnd) lst[cnt + below] = (unsigned)x | ((unsigned)yi << 7) | ((unsigned)wave << (7 + HPK_YI_BITS)) | ((pix & PK_MASK) << 13);
+            if (cnd) lst[cnt + below] = (unsigned)x | ((unsigned)(wave + NW * yi) << 7) | ((pix & PK_MASK) << 13);
             cnt += __popcll(M);
         }
     }
@@ -470,8 +470,8 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
     for (int kb = 0; kb < nbatch; ++kb) {
         const bool cand = kb * 64 + lane < cnt;
         const unsigned id = cand ? lst[kb * 64 + lane] : 0u;
-        const int yi = (int)((id >> 7) & ((1u << HPK_YI_BITS) - 1u)), x = (int)(id & 127u);
-        const int y = wave + NW * yi;
+        const int x = (int)(id & 127u);
+        const int y = (int)((id >> 7) & 63u);
         if (cand && a.dbg_stop != 7) a.rec_ent[rec0 + kb * 64 + lane] = id;
         const int r = r0 + y;
         const int d = c0 + x - r;
@@ -740,6 +740,7 @@ typedef __attribute__((address_space(3))) const unsigned lds_cu32_t;
 typedef __attribute__((address_space(3))) const double lds_cf64_t;
 typedef __attribute__((address_space(3))) unsigned char lds_u8_t;
 __device__ __forceinline__ unsigned lds_u32(unsigned addr) { return *(lds_cu32_t*)addr; }
+__device__ __forceinline__ void lds_st_u32(unsigned addr, unsigned v) { *(__attribute__((address_space(3))) unsigned*)addr = v; }
 // (volatile: two ds_read_b64 take 2 LDS cycles each, the ds_read2_b64 the compiler would pair them into takes 8)
 __device__ __forceinline__ double lds_f64(unsigned addr) { return *(volatile lds_cf64_t*)addr; }
 __device__ __forceinline__ unsigned reads_box_b(unsigned pb, int rho, unsigned sr) {
@@ -965,6 +966,10 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     const int xx0 = 126 - 2 * lane;                                     // SAT column of the lane's cell e = 1 (e = 0: xx0 + 1)
     const int kl = mw + cj * TC + 1 + xx0 + 1;                          // diagonal of the lane's cell e = 0 at SAT row 0
     const int xo = xx0 + 1 - W;                                         // output column of cell e = 0 (e = 1: xo - 1)
+    unsigned offx[2];
+    offx[0] = (unsigned)xo < (unsigned)TC ? 0u : 0x80000000u;
+    offx[1] = (unsigned)(xo - 1) < (unsigned)TC ? 0u : 0x80000000u;
+    asm volatile("" : "+v"(offx[0]), "+v"(offx[1]));
     double satc[RPW][2];
     unsigned satp[RPW][2];
     double ac[2] = {0.0, 0.0};
@@ -976,8 +981,9 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         if (!BALF64) wr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(nxt.wrow), j),
                                            __builtin_amdgcn_readlane(__double2loint(nxt.wrow), j));
         const int y = Y - (W + 1);
-        const bool rowout = (unsigned)y < (unsigned)TR;         // (rows at or beyond n read 0: no candidates there)
-        if (j == 3) { ac[0] = 0.0; ac[1] = 0.0; ar[0] = 0u; ar[1] = 0u; }     // the lower row group starts its own sums
+        // rows outside the output tile have no candidates: their diagonal bound is 0 (rows at or beyond n read 0)
+        unsigned kbound = (unsigned)y < (unsigned)TR ? (unsigned)(Dm - mw) + 1u : 0u;
+        asm volatile("" : "+s"(kbound));                        // (one scalar select, not a lane mask ANDed per cell)
         double bv[2];
         unsigned pk[2];
         // candidates of the row: the list slice is reserved now, the entries are written after the row's scan
@@ -1000,16 +1006,20 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
             }
             pk[e] = rc | (bv[e] != 0.0 ? 1u << PK_SHIFT : 0u);
             // (no branch on the row: the predicate flows straight into the ballot; rows outside the output tile give 0)
-            cdv[e] = rowout & (ru != 0u) & ((unsigned)(xo - e) < (unsigned)TC) & ((unsigned)km <= (unsigned)(Dm - mw));
+            // one compare decides: a zero count or a column outside the output tile sets the top bit of the diagonal
+            const unsigned kt = (unsigned)km | offx[e] | ((ru - 1u) & 0x80000000u);
+            cdv[e] = kt < kbound;
             M[e] = ballot64(cdv[e]);
             entv[e] = (unsigned)(xo - e) | (rc << 13);
         }
         const unsigned nrow = (unsigned)(__popcll(M[0]) + __popcll(M[1]));
-        if (nrow != 0u) {
+        {
             // hipcc's atomic optimiser would wait for the returned value on the spot; issued by hand, the LDS round
-            // trip runs beside the row's scan (all lanes add the same count into the same word: lane 0 only)
+            // trip runs beside the row's scan.  All lanes would add the same count into the same word: lane 0 only, by
+            // narrowing exec around the instruction (every lane is active here) instead of a branch on a lane mask.
             const unsigned addr = (unsigned)(size_t)tcnt;
-            if (lane == 0) asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(slot) : "v"(addr), "v"(nrow) : "memory");
+            asm volatile("s_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %1, %2\n\ts_mov_b64 exec, -1"
+                         : "=&v"(slot) : "v"(addr), "v"(nrow) : "memory");
         }
         // row prefix of the two cells (cell e = 0 first), exclusive over the lanes
         const double l1c = bv[0] + bv[1];
@@ -1017,8 +1027,13 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         double pc = l1c;
         unsigned pr = l1r;
         wave_exclusive_scan(pc, pr);
-        ac[0] += pc + bv[0]; ar[0] += pr + pk[0];
-        ac[1] += pc + l1c;   ar[1] += pr + l1r;
+        if (j == 0 || j == 3) {                                 // a row group starts its own sums
+            ac[0] = pc + bv[0]; ar[0] = pr + pk[0];
+            ac[1] = pc + l1c;   ar[1] = pr + l1r;
+        } else {
+            ac[0] += pc + bv[0]; ar[0] += pr + pk[0];
+            ac[1] += pc + l1c;   ar[1] += pr + l1r;
+        }
         satc[j][0] = ac[0]; satc[j][1] = ac[1];
         satp[j][0] = ar[0]; satp[j][1] = ar[1];
         // the last row of a group = the group's column-wise total, already row-prefixed: what the groups below add
@@ -1030,12 +1045,13 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         if (nrow != 0u) {
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(slot) :: "memory");
             // entries in the order of the scan (descending column): cell e = 0 of a lane, then its cell e = 1
-            const unsigned yy = ((unsigned)(y >> 4) << 7) | ((unsigned)(y & 15) << (7 + HPK_YI_BITS));
+            const unsigned yy = (unsigned)y << 7;
             const unsigned at = (unsigned)__builtin_amdgcn_readfirstlane((int)slot) +
                                 __builtin_amdgcn_mbcnt_hi((unsigned)(M[0] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M[0], 0u)) +
                                 __builtin_amdgcn_mbcnt_hi((unsigned)(M[1] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M[1], 0u));
-            if (cdv[0]) lst[at] = entv[0] | yy;
-            if (cdv[1]) lst[at + (cdv[0] ? 1u : 0u)] = entv[1] | yy;
+            const unsigned la = lds0 + (unsigned)(LR * LC * 12) + at * 4u;       // &lst[at]
+            if (cdv[0]) lds_st_u32(la, entv[0] | yy);
+            if (cdv[1]) lds_st_u32(la + (cdv[0] ? 4u : 0u), entv[1] | yy);
         }
     }
     HPK_CLK(ck0)
@@ -1127,7 +1143,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         const bool cand = i < total;
         const unsigned id = lst[cand ? i : 0];
         const int x = (int)(id & 127u);
-        const int y = (int)((id >> (7 + HPK_YI_BITS)) & 15u) + 16 * (int)((id >> 7) & ((1u << HPK_YI_BITS) - 1u));
+        const int y = (int)((id >> 7) & 63u);
         const int base = (y + W + 1) * LC + W + x;
         if (cand) ent_t[i] = id;
         // one round of reads: P(Y, X) of both planes, the pixel's own value, the three Reads boxes that decide most
@@ -1750,7 +1766,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                 s2_b = (recS_t + sl0)[ri_b];
             }
             if (!cand) ent = 0u;
-            const int r = r0 + (int)((ent >> (7 + HPK_YI_BITS)) & ((1u << HPK_WV_BITS) - 1u)) + HPK_NWAVES * (int)((ent >> 7) & ((1u << HPK_YI_BITS) - 1u));
+            const int r = r0 + (int)((ent >> 7) & 63u);
             const int c = c0 + (int)(ent & 127u);
             const int d = c - r;
             float rawpix = (float)(ent >> 13);          // the SAT holds counts capped at HPK_PK_CAP: those are re-read
@@ -2043,7 +2059,7 @@ __global__ void __launch_bounds__(256) hpk_dense(HpkDenseArgs a) {
     for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
         const int64_t ri = (int64_t)tile * a.tilecap + i;
         const unsigned ent = a.rec_ent[ri];
-        const int r = r0 + (int)((ent >> (7 + HPK_YI_BITS)) & ((1u << HPK_WV_BITS) - 1u)) + HPK_NWAVES * (int)((ent >> 7) & ((1u << HPK_YI_BITS) - 1u));
+        const int r = r0 + (int)((ent >> 7) & 63u);
         const int c = c0 + (int)(ent & 127u);
         const int d = c - r;
         const int64_t o = (int64_t)r * a.ldo + d;
@@ -2086,7 +2102,7 @@ __global__ void __launch_bounds__(64) hpk_probe(HpkDenseArgs a, const int32_t* _
         const int rb = r / a.TR, r0 = rb * a.TR, cj = (c - r0 - a.mw) / a.TC;
         const int tile = rb * a.J + cj;
         const int x = c - (r0 + a.mw + cj * a.TC), y = r - r0;
-        const unsigned key = (unsigned)x | ((unsigned)(y >> 4) << 7) | ((unsigned)(y & 15) << (7 + HPK_YI_BITS));
+        const unsigned key = (unsigned)x | ((unsigned)y << 7);
         const int cnt = (int)a.tile_cnt[tile];
         for (int i0 = 0; i0 < cnt; i0 += 64) {
             const int i = i0 + lane;
