@@ -86,6 +86,26 @@ __device__ __forceinline__ void wave_exclusive_scan(double& c, unsigned& r) {
     r = dpp_u32<DPP_WAVE_SHR1, 0xf>(r);
 }
 
+// The same with the two row-broadcast steps writing into registers of their own (z[0..1]: rows 1 and 3 of the wave,
+// z[2..3]: rows 2 and 3): the rows a step leaves alone must read 0, and a fresh destination would be zeroed before
+// every step - these keep the zeros they start with (the caller clears them once per tile).
+__device__ __forceinline__ void wave_exclusive_scan_z(double& c, unsigned& r, int (&z)[4]) {
+    scan_step<DPP_ROW_SHR1, 0xf>(c, r);
+    scan_step<DPP_ROW_SHR2, 0xf>(c, r);
+    scan_step<DPP_ROW_SHR4, 0xf>(c, r);
+    scan_step<DPP_ROW_SHR8, 0xf>(c, r);
+    z[0] = __builtin_amdgcn_update_dpp(z[0], __double2loint(c), DPP_ROW_BCAST15, 0xa, 0xf, false);
+    z[1] = __builtin_amdgcn_update_dpp(z[1], __double2hiint(c), DPP_ROW_BCAST15, 0xa, 0xf, false);
+    c += __hiloint2double(z[1], z[0]);
+    r += dpp_u32<DPP_ROW_BCAST15, 0xa>(r);
+    z[2] = __builtin_amdgcn_update_dpp(z[2], __double2loint(c), DPP_ROW_BCAST31, 0xc, 0xf, false);
+    z[3] = __builtin_amdgcn_update_dpp(z[3], __double2hiint(c), DPP_ROW_BCAST31, 0xc, 0xf, false);
+    c += __hiloint2double(z[3], z[2]);
+    r += dpp_u32<DPP_ROW_BCAST31, 0xc>(r);
+    c = dpp_f64<DPP_WAVE_SHR1, 0xf>(c);
+    r = dpp_u32<DPP_WAVE_SHR1, 0xf>(r);
+}
+
 // ------------------------------------------------------------------ box sums on the SAT
 // Four off-cross quadrants (donut support) and the lower-left quadrant at Chebyshev radius rho (per lane)
 // around SAT cell `base` = Y * LC + X.  pixc: the pixel's own balanced value; sc = S(Y, X-1).
@@ -972,6 +992,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     asm volatile("" : "+v"(offx[0]), "+v"(offx[1]));
     double satc[RPW][2];
     unsigned satp[RPW][2];
+    int zdpp[4] = {0, 0, 0, 0};
     double ac[2] = {0.0, 0.0};
     unsigned ar[2] = {0u, 0u};
 #pragma unroll
@@ -1026,7 +1047,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         const unsigned l1r = pk[0] + pk[1];
         double pc = l1c;
         unsigned pr = l1r;
-        wave_exclusive_scan(pc, pr);
+        wave_exclusive_scan_z(pc, pr, zdpp);
         if (j == 0 || j == 3) {                                 // a row group starts its own sums
             ac[0] = pc + bv[0]; ar[0] = pr + pk[0];
             ac[1] = pc + l1c;   ar[1] = pr + l1r;
