@@ -954,12 +954,22 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     HPK_CLK_DECL
     TileRegsS<BALF64> nxt;
     int par = 0;                        // which of the two list counters the current tile uses
+    // The tile walk is the same scalar arithmetic in every wave, and all sixteen would queue for the one scalar unit
+    // with it at the top of every tile: wave 0 alone walks, one tile ahead, and publishes the next tile through LDS
+    // (tseq[2], alternating: row block << 8 | column chunk, ~0 = no more tiles).
+    unsigned* __restrict__ tseq = tcount + 8;
     TileWalk tw;
     tw.init(a);
     bool have = tw.valid(a);
     int rb = tw.rbk, cj = tw.cj(a);
     if (have) tile_load_s<BALF64>(a, rb, cj, wave_k, lane_k, nxt);
-    __syncthreads();                    // plan and counters in LDS
+    if (wave_k == 0) {
+        tw.step(a);
+        if (lane_k == 0) tseq[0] = tw.valid(a) ? ((unsigned)tw.rbk << 8 | (unsigned)tw.cj(a)) : ~0u;
+    }
+    __syncthreads();                    // plan, counters and the second tile in LDS
+    unsigned tnext = lds_u32(lds0 + (unsigned)((unsigned char*)tseq - smem));
+    int tpar = 0;                       // which tseq word holds the tile after the current one
 #pragma unroll 1
     for (int it = 0; have; ++it) {
     // Everything below that depends only on (wave, lane) is the same for every tile, and the compiler would hoist it
@@ -972,12 +982,19 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     const int r0 = rb * TR;
     const int c0 = r0 + mw + cj * TC;
     const bool empty_tile = c0 >= n || (mw + cj * TC - (TR - 1)) > a.D;       // no band pixel inside the matrix
-    tw.step(a);
-    const bool have_next = tw.valid(a);
-    const int rb_next = tw.rbk, cj_next = tw.cj(a);
+    const int tn = __builtin_amdgcn_readfirstlane((int)tnext);
+    const bool have_next = tn != -1;
+    const int rb_next = (int)((unsigned)tn >> 8), cj_next = tn & 255;
+    if (wave == 0) {                    // the tile after the next one, for everybody's next round
+        tw.step(a);
+        if (lane == 0) tseq[tpar ^ 1] = tw.valid(a) ? ((unsigned)tw.rbk << 8 | (unsigned)tw.cj(a)) : ~0u;
+    }
+    tpar ^= 1;
     if (empty_tile) {
         if (have_next) tile_load_s<BALF64>(a, rb_next, cj_next, wave, lane, nxt);
         have = have_next; rb = rb_next; cj = cj_next;
+        __syncthreads();                // (rare: the far end of the chromosome) wave 0's word before it is read
+        tnext = lds_u32(lds0 + (unsigned)((unsigned char*)tseq - smem) + (unsigned)tpar * 4u);
         continue;
     }
     unsigned* __restrict__ tcnt = tcount + par;
@@ -1324,6 +1341,8 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         }
     }
     HPK_CLK(ck5)
+    // (written by wave 0 at the top of this round, three barriers ago: in flight across the barrier below)
+    tnext = lds_u32(lds0 + (unsigned)((unsigned char*)tseq - smem) + (unsigned)tpar * 4u);
     __syncthreads();                 // every wave is done with this tile's SAT and list
     HPK_CLK(ck6)
     if (wave == 0) {
