@@ -706,7 +706,6 @@ int collect_impl(hpk_ctx* c, hpk_job* j, hpk_result** out) {
     const int32_t h_err = *reinterpret_cast<const int32_t*>(hsmall + OFF_ERR);
     const int32_t* h_exec = reinterpret_cast<const int32_t*>(hsmall + OFF_EXEC);
     const unsigned long long h_nsurv = *reinterpret_cast<const unsigned long long*>(hsmall + OFF_NOUT);
-    const unsigned long long* h_nvalid = reinterpret_cast<const unsigned long long*>(hsmall + OFF_NVALID);
     const unsigned long long* h_emax = reinterpret_cast<const unsigned long long*>(hsmall + OFF_EMAX);
     const unsigned int* h_chist = reinterpret_cast<const unsigned int*>(hsmall + OFF_FAM_M);
 
@@ -802,7 +801,10 @@ int collect_impl(hpk_ctx* c, hpk_job* j, hpk_result** out) {
             hpk_set& hs = R.sets[s];
             hs.pair = (plan.mode == HPK_MODE_BHFDR) ? 0 : s / 2;
             hs.fl = (plan.mode == HPK_MODE_BHFDR) ? 0 : s % 2;
-            hs.nvalid = (int64_t)h_nvalid[s];
+            // pixels with E > 0: the families of the set added up (family 0 = those without a chunk, not a family of tests)
+            hs.nvalid = 0;
+            for (int ch = 0; ch <= HPK_NB; ++ch) hs.nvalid += (int64_t)h_chist[(size_t)s * (HPK_NB + 1) + ch];
+            box->fam[(size_t)s * (HPK_NB + 1)] = 0u;
             double emax = 0.0;
             std::memcpy(&emax, &h_emax[s], 8);
             hs.emax = emax;

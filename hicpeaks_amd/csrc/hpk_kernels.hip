@@ -1733,7 +1733,6 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     __shared__ unsigned int lf[2 * HPK_MAX_PAIRS][HPK_NB + 1];
     __shared__ double lbounds[HPK_NB];
     __shared__ unsigned long long lemax[2 * HPK_MAX_PAIRS];
-    __shared__ unsigned int lvalid[2 * HPK_MAX_PAIRS];
     __shared__ int lstepw[HPK_MAX_STEPS];
     __shared__ int lpair_slot[HPK_MAX_PAIRS], lpair_wi[HPK_MAX_PAIRS];
     __shared__ int lptoff[HPK_NB_TAB + 2];
@@ -1748,7 +1747,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     const int nsets = BH ? 1 : 2 * npairs;
     for (int i = threadIdx.x; i < nsets * (HPK_NB + 1); i += blockDim.x) { (&lm[0][0])[i] = 0u; (&lf[0][0])[i] = 0u; }
     if (threadIdx.x < HPK_NB) lbounds[threadIdx.x] = const_cast<const double*>(ka->bounds)[threadIdx.x];
-    if (threadIdx.x < 2 * HPK_MAX_PAIRS) { lemax[threadIdx.x] = 0ull; lvalid[threadIdx.x] = 0u; }
+    if (threadIdx.x < 2 * HPK_MAX_PAIRS) lemax[threadIdx.x] = 0ull;
     if (threadIdx.x < HPK_MAX_STEPS) lstepw[threadIdx.x] = (threadIdx.x < plan->nsteps) ? plan->steps[threadIdx.x].wi : 0;
     if (threadIdx.x < HPK_MAX_PAIRS) { lpair_slot[threadIdx.x] = plan->pair_slot[threadIdx.x]; lpair_wi[threadIdx.x] = plan->pair_wi[threadIdx.x]; }
     if (threadIdx.x < HPK_NB_TAB + 2) lptoff[threadIdx.x] = const_cast<const int32_t*>(ka->ptab_off)[threadIdx.x];
@@ -1820,9 +1819,13 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
             const unsigned tstride = 2u * (unsigned)(a.D + 1);          // table offsets fit 32 bits: <= 2 * 20 * 64 * 2 * (D + 1) entries
             const unsigned tbase = (top != right) ? (unsigned)(((top ? 0 : 1) * W + (top ? r : a.n - 1 - c)) * nsteps_u) * tstride : 0u;
 
+            const bool anyboth = __ballot(both) != 0ull;                // (both matrix ends in one window: short chromosomes only)
             for (int pj = 0; pj < npairs; ++pj) {
                 const int wi0 = lpair_wi[pj];
-                const int stp = stp_n;
+                // The scalar unit is this kernel's busiest one (lane masks ANDed and ORed, exec saved and restored around
+                // every divergent if): conditions are folded into the values below - a record that does not count turns
+                // into step 0, expected sum 0, E = 0 - so that each decision is one compare feeding one select.
+                int stp = cand ? stp_n : 0;             // (idle lanes hold the tile's first record)
                 const double2 s2 = s2_n;
                 if (pj + 1 < npairs) {                  // next slot's record is on its way while this one is scored
                     slot = lpair_slot[pj + 1];
@@ -1831,22 +1834,32 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                     s2_n = (recS_t + sl)[ri];
                 }
                 // resolved at an executed step (callers.py:133-134), far enough from the diagonal (callers.py:244)
-                const bool ok = cand && d >= wi0 && stp != 0 && lstepw[stp > 0 ? stp - 1 : 0] <= frozen;
-                const unsigned to = tbase + (unsigned)(ok ? stp - 1 : 0) * tstride + (cand ? (unsigned)d : 0u);
+                const int stepw = lstepw[stp > 0 ? stp - 1 : 0];
+                asm volatile("" : "+v"(stp));
+                stp = d >= wi0 ? stp : 0;
+                asm volatile("" : "+v"(stp));
+                stp = stepw <= frozen ? stp : 0;
+                asm volatile("" : "+v"(stp));
+                const unsigned srow = (unsigned)(stp > 1 ? stp - 1 : 0);
+                const unsigned to = tbase + srow * tstride + (cand ? (unsigned)d : 0u);
                 double EK = tab[to], EY = tab[to + (unsigned)(a.D + 1)];
-                if (__ballot(both && ok) != 0ull) {
-                    if (both && ok) edge_expected(plan->steps[stp - 1].m, plan->steps[stp - 1].wi, a.IR, r, c, a.n, a.num, a.mw, EK, EY);
+                if (anyboth) {
+                    const bool bo = both && stp != 0;
+                    if (__ballot(bo) != 0ull) {
+                        if (bo) edge_expected(plan->steps[stp - 1].m, plan->steps[stp - 1].wi, a.IR, r, c, a.n, a.num, a.mw, EK, EY);
+                    }
                 }
-                if (a.dbg == 2) { EK = 1.0; EY = 1.0; }
+                EK = stp != 0 ? EK : 0.0;
+                EY = stp != 0 ? EY : 0.0;
                 // callers.py:244-249: E = ((IR[d] * (bS / bE)) * B1[x]) * B2[y] where bE != 0
-                const double eK = (ok && EK != 0.0) ? ((ir * (s2.x / EK)) * b1r) * b2c : 0.0;
-                const double eY = (ok && EY != 0.0) ? ((ir * (s2.y / EY)) * b1r) * b2c : 0.0;
+                const double eK = (EK != 0.0) ? ((ir * (s2.x / EK)) * b1r) * b2c : 0.0;
+                const double eY = (EY != 0.0) ? ((ir * (s2.y / EY)) * b1r) * b2c : 0.0;
                 constexpr int nfl = BH ? 1 : 2;
 #pragma unroll
                 for (int fl = 0; fl < nfl; ++fl) {
                     const int set = BH ? 0 : pj * 2 + fl;
                     const double E = fl ? eY : eK;
-                    const bool valid = ok && (E > 0.0);                       // callers.py:250
+                    const bool valid = E > 0.0;                               // callers.py:250 (E = 0 where the record does not count)
                     int chunk = 0;
                     double p = 1.0;
                     if (BH) {
@@ -1855,44 +1868,72 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                             p = poisson_sf(O, E, const_cast<const double*>(ka->sfe));      // callers.py:536-540
                         }
                     } else {
-                        // lo = number of boundaries <= E (boundaries lbounds[i] = 2^(i/3), i = 0..); membership is strict
-                        // on both sides (callers.py:38), so E sitting on a boundary belongs to no chunk.  E in
-                        // [2^k, 2^(k+1)) has the three boundaries lbounds[3k .. 3k+2] at or below it to compare with.
-                        // Written with selects: this kernel is issue-bound and divergent ifs cost scalar work.
-                        const int e3 = 3 * (((int)(__double_as_longlong(E) >> 52) & 0x7ff) - 1023);
-                        const bool ge1 = valid && E >= 1.0;
-                        const bool big = e3 + 2 >= HPK_NB;
-                        const int i0b = (ge1 && !big) ? e3 : 0;                // clamped: every lane reads inside the table
+                        // Chunk of E: boundaries lbounds[i] = 2^(i/3); membership is strict on both sides (callers.py:38), so
+                        // E sitting on a boundary belongs to no chunk.  E in [2^k, 2^(k+1)) has lbounds[3k .. 3k+2] at or
+                        // below it; E < 1 is chunk 1.  The common case - below 2^15 (the Poisson table's range) and not on
+                        // a boundary - is straight-line code; one ballot sends the rest of a batch through the general rules.
+                        const int ex = (int)((unsigned long long)__double_as_longlong(E) >> 52) - 1023;     // E = 0: -1023
+                        int i0b = 3 * ex;
+                        i0b = i0b < 0 ? 0 : i0b;
+                        i0b = i0b > HPK_NB - 3 ? HPK_NB - 3 : i0b;              // clamped: every lane reads inside the table
                         const double bq = lbounds[i0b], bA = lbounds[i0b + 1], bB = lbounds[i0b + 2];
-                        const int lo = ge1 ? (big ? HPK_NB : e3 + 1 + (E >= bA ? 1 : 0) + (E >= bB ? 1 : 0)) : 0;
-                        const bool onb = ge1 && !big && (E == bq || E == bA || E == bB);
-                        const bool inch = valid && lo < HPK_NB && !onb;
-                        chunk = inch ? lo + 1 : 0;
-                        const bool tabd = inch && chunk <= HPK_NB_TAB;
-                        const int ct = tabd ? chunk : 1;
-                        const int base = lptoff[ct], len = lptoff[ct + 1] - base;
+                        int ch = 3 * ex + 2 + (E >= bA ? 1 : 0) + (E >= bB ? 1 : 0);
+                        ch = ex >= 0 ? ch : 1;
+                        asm volatile("" : "+v"(ch));
+                        ch = valid ? ch : 0;
+                        unsigned odd = ex >= 15 ? 1u : 0u;                     // lambda beyond the table
+                        asm volatile("" : "+v"(odd));
+                        odd = E == bq ? 1u : odd;
+                        asm volatile("" : "+v"(odd));
+                        odd = E == bA ? 1u : odd;
+                        asm volatile("" : "+v"(odd));
+                        odd = E == bB ? 1u : odd;
+                        asm volatile("" : "+v"(odd));
                         const int kO = (int)O;
-                        if (tabd) p = (a.dbg == 1) ? 0.5 : ((kO < len) ? a.ptab[(unsigned)(base + kO)] : 0.0);
-                        const bool rare = inch && !tabd;                      // lambda > 2^15: beyond the table
-                        if (__ballot(rare) != 0ull) {
-                            if (rare) p = poisson_sf(O, lbounds[chunk - 1], const_cast<const double*>(ka->sfe));   // callers.py:268-270
+                        if (__ballot(odd != 0u) == 0ull) {
+                            chunk = ch;
+                            const int ct = ch > 1 ? ch : 1;
+                            const int base = lptoff[ct], len = lptoff[ct + 1] - base;
+                            p = a.ptab[(unsigned)(base + (kO < len ? kO : 0))];
+                            p = kO < len ? p : 0.0;
+                        } else {
+                            const int e3 = 3 * ex;
+                            const bool ge1 = valid && E >= 1.0;
+                            const bool big = e3 + 2 >= HPK_NB;
+                            const int lo = ge1 ? (big ? HPK_NB : e3 + 1 + (E >= bA ? 1 : 0) + (E >= bB ? 1 : 0)) : 0;
+                            const bool onb = ge1 && !big && (E == bq || E == bA || E == bB);
+                            const bool inch = valid && lo < HPK_NB && !onb;
+                            chunk = inch ? lo + 1 : 0;
+                            const bool tabd = inch && chunk <= HPK_NB_TAB;
+                            const int ct = tabd ? chunk : 1;
+                            const int base = lptoff[ct], len = lptoff[ct + 1] - base;
+                            if (tabd) p = (kO < len) ? a.ptab[(unsigned)(base + kO)] : 0.0;
+                            const bool rare = inch && !tabd;                      // lambda > 2^15: beyond the table
+                            if (__ballot(rare) != 0ull) {
+                                if (rare) p = poisson_sf(O, lbounds[chunk - 1], const_cast<const double*>(ka->sfe));   // callers.py:268-270
+                            }
                         }
                     }
-                    const bool surv = valid && chunk != 0 && p <= a.sig && a.dbg != 3;      // only these can reach q <= sig
-                    // per-wave aggregation before touching the LDS counters
-                    const unsigned long long vm = (a.dbg == 4) ? 0ull : __ballot(valid);
+                    // only p <= sig can reach q <= sig; a pixel without a chunk keeps p = 1 (callers.py:259-260)
+                    double psel = valid ? p : 2.0;
+                    asm volatile("" : "+v"(psel));
+                    psel = chunk != 0 ? psel : 2.0;
+                    const bool surv = psel <= a.sig;
+                    const unsigned long long vm = __ballot(valid);
                     const unsigned long long sm = __ballot(surv);
                     if (vm != 0ull) {
-                        if (lane == 0) atomicAdd(&lvalid[set], (unsigned)__popcll(vm));
-                        // Emax of the set: E > 0, so its bit pattern orders like its value.  The block's running maximum
-                        // settles after a few batches; only lanes that beat it touch the LDS atomic.
+                        // Emax of the set: E > 0, so its bit pattern orders like its value (E = 0: never above).  The
+                        // block's running maximum settles after a few batches; only lanes that beat it touch the LDS atomic.
                         const unsigned long long ebits = (unsigned long long)__double_as_longlong(E);
-                        const bool beats = valid && ebits > lemax[set];
+                        const bool beats = ebits > lemax[set];
                         if (__ballot(beats) != 0ull) { if (beats) atomicMax(&lemax[set], ebits); }
-                        if (valid && chunk) atomicAdd(&lm[set][chunk], 1u);
-                        if (surv) atomicAdd(&lf[set][chunk], 1u);
+                        // tests per family; family 0 of a set collects its valid pixels without a chunk (the host adds the
+                        // families up to the set's number of valid pixels)
+                        if (valid) atomicAdd(&lm[set][chunk], 1u);
                     }
                     if (sm != 0ull) {
+                        if (surv) atomicAdd(&lf[set][chunk], 1u);
+                        // per-wave reservation of survivor slots
                         const unsigned scnt = (unsigned)__popcll(sm);
                         if (wused + scnt > HPK_SCH) {            // wave-uniform: retire the chunk, take a new one
                             if (have_chunk && lane == 0 && (int64_t)wbase < a.cap) const_cast<unsigned*>(ka->chunk_used)[(rbase + (int64_t)wbase) / HPK_SCH] = wused;
@@ -1927,7 +1968,6 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
         if (f) atomicAdd(&const_cast<unsigned int*>(ka->fam_f)[i], f);
     }
     if (threadIdx.x < nsets) {
-        if (lvalid[threadIdx.x]) atomicAdd(&const_cast<unsigned long long*>(ka->nvalid)[threadIdx.x], (unsigned long long)lvalid[threadIdx.x]);
         if (lemax[threadIdx.x]) atomicMax(&const_cast<unsigned long long*>(ka->emax_bits)[threadIdx.x], lemax[threadIdx.x]);
     }
 }
