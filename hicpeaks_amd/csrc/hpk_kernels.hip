@@ -1855,23 +1855,26 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                 const double eK = (EK != 0.0) ? ((ir * (s2.x / EK)) * b1r) * b2c : 0.0;
                 const double eY = (EY != 0.0) ? ((ir * (s2.y / EY)) * b1r) * b2c : 0.0;
                 constexpr int nfl = BH ? 1 : 2;
+                int chunk2[2] = {0, 0};
+                double p2[2] = {1.0, 1.0};
+                const int kO = (int)O;
+                if (BH) {
+                    if (eK > 0.0) {
+                        chunk2[0] = 1;
+                        p2[0] = poisson_sf(O, eK, const_cast<const double*>(ka->sfe));      // callers.py:536-540
+                    }
+                } else {
+                    // Chunk of E: boundaries lbounds[i] = 2^(i/3); membership is strict on both sides (callers.py:38), so E
+                    // sitting on a boundary belongs to no chunk.  E in [2^k, 2^(k+1)) has lbounds[3k .. 3k+2] at or below
+                    // it; E < 1 is chunk 1.  The common case - below 2^15 (the Poisson table's range) and not on a boundary -
+                    // is straight-line code for both expected values, whose two table reads then travel together; one
+                    // ballot sends the rest of a batch through the general rules.
+                    unsigned odd = 0u;
+                    int len2[2];
+                    unsigned at2[2];
 #pragma unroll
-                for (int fl = 0; fl < nfl; ++fl) {
-                    const int set = BH ? 0 : pj * 2 + fl;
-                    const double E = fl ? eY : eK;
-                    const bool valid = E > 0.0;                               // callers.py:250 (E = 0 where the record does not count)
-                    int chunk = 0;
-                    double p = 1.0;
-                    if (BH) {
-                        if (valid) {
-                            chunk = 1;
-                            p = poisson_sf(O, E, const_cast<const double*>(ka->sfe));      // callers.py:536-540
-                        }
-                    } else {
-                        // Chunk of E: boundaries lbounds[i] = 2^(i/3); membership is strict on both sides (callers.py:38), so
-                        // E sitting on a boundary belongs to no chunk.  E in [2^k, 2^(k+1)) has lbounds[3k .. 3k+2] at or
-                        // below it; E < 1 is chunk 1.  The common case - below 2^15 (the Poisson table's range) and not on
-                        // a boundary - is straight-line code; one ballot sends the rest of a batch through the general rules.
+                    for (int fl = 0; fl < 2; ++fl) {
+                        const double E = fl ? eY : eK;
                         const int ex = (int)((unsigned long long)__double_as_longlong(E) >> 52) - 1023;     // E = 0: -1023
                         int i0b = 3 * ex;
                         i0b = i0b < 0 ? 0 : i0b;
@@ -1880,8 +1883,9 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                         int ch = 3 * ex + 2 + (E >= bA ? 1 : 0) + (E >= bB ? 1 : 0);
                         ch = ex >= 0 ? ch : 1;
                         asm volatile("" : "+v"(ch));
-                        ch = valid ? ch : 0;
-                        unsigned odd = ex >= 15 ? 1u : 0u;                     // lambda beyond the table
+                        ch = E > 0.0 ? ch : 0;
+                        asm volatile("" : "+v"(odd));
+                        odd = ex >= 15 ? 1u : odd;                             // lambda beyond the table
                         asm volatile("" : "+v"(odd));
                         odd = E == bq ? 1u : odd;
                         asm volatile("" : "+v"(odd));
@@ -1889,31 +1893,51 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                         asm volatile("" : "+v"(odd));
                         odd = E == bB ? 1u : odd;
                         asm volatile("" : "+v"(odd));
-                        const int kO = (int)O;
-                        if (__ballot(odd != 0u) == 0ull) {
-                            chunk = ch;
-                            const int ct = ch > 1 ? ch : 1;
-                            const int base = lptoff[ct], len = lptoff[ct + 1] - base;
-                            p = a.ptab[(unsigned)(base + (kO < len ? kO : 0))];
-                            p = kO < len ? p : 0.0;
-                        } else {
-                            const int e3 = 3 * ex;
+                        chunk2[fl] = ch;
+                        const int ct = ch > 1 ? ch : 1;
+                        const int base = lptoff[ct];
+                        len2[fl] = lptoff[ct + 1] - base;
+                        at2[fl] = (unsigned)(base + (kO < len2[fl] ? kO : 0));
+                    }
+                    if (__ballot(odd != 0u) == 0ull) {
+                        p2[0] = a.ptab[at2[0]];
+                        p2[1] = a.ptab[at2[1]];
+                        p2[0] = kO < len2[0] ? p2[0] : 0.0;
+                        p2[1] = kO < len2[1] ? p2[1] : 0.0;
+                    } else {
+#pragma unroll 1
+                        for (int fl = 0; fl < 2; ++fl) {
+                            const double E = fl ? eY : eK;
+                            const bool valid = E > 0.0;
+                            const int e3 = 3 * ((int)((unsigned long long)__double_as_longlong(E) >> 52) - 1023);
                             const bool ge1 = valid && E >= 1.0;
                             const bool big = e3 + 2 >= HPK_NB;
+                            const int i0b = (ge1 && !big) ? e3 : 0;
+                            const double bq = lbounds[i0b], bA = lbounds[i0b + 1], bB = lbounds[i0b + 2];
                             const int lo = ge1 ? (big ? HPK_NB : e3 + 1 + (E >= bA ? 1 : 0) + (E >= bB ? 1 : 0)) : 0;
                             const bool onb = ge1 && !big && (E == bq || E == bA || E == bB);
                             const bool inch = valid && lo < HPK_NB && !onb;
-                            chunk = inch ? lo + 1 : 0;
+                            const int chunk = inch ? lo + 1 : 0;
                             const bool tabd = inch && chunk <= HPK_NB_TAB;
                             const int ct = tabd ? chunk : 1;
                             const int base = lptoff[ct], len = lptoff[ct + 1] - base;
+                            double p = 1.0;
                             if (tabd) p = (kO < len) ? a.ptab[(unsigned)(base + kO)] : 0.0;
                             const bool rare = inch && !tabd;                      // lambda > 2^15: beyond the table
                             if (__ballot(rare) != 0ull) {
                                 if (rare) p = poisson_sf(O, lbounds[chunk - 1], const_cast<const double*>(ka->sfe));   // callers.py:268-270
                             }
+                            if (fl == 0) { chunk2[0] = chunk; p2[0] = p; } else { chunk2[1] = chunk; p2[1] = p; }
                         }
                     }
+                }
+#pragma unroll
+                for (int fl = 0; fl < nfl; ++fl) {
+                    const int set = BH ? 0 : pj * 2 + fl;
+                    const double E = fl ? eY : eK;
+                    const bool valid = E > 0.0;                               // callers.py:250 (E = 0 where the record does not count)
+                    const int chunk = chunk2[fl];
+                    const double p = p2[fl];
                     // only p <= sig can reach q <= sig; a pixel without a chunk keeps p = 1 (callers.py:259-260)
                     double psel = valid ? p : 2.0;
                     asm volatile("" : "+v"(psel));
