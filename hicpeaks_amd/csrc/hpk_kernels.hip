@@ -728,9 +728,8 @@ __device__ __forceinline__ float ldbuf_f32(rsrc_t r, unsigned off, unsigned soff
 __device__ __forceinline__ double ldbuf_f64(rsrc_t r, unsigned off, unsigned soff) {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, (int)soff, 0));
 }
-// SAT row of a wave's j-th row: rows 0..2 in the upper part (3 per wave: SAT rows 0..47), rows 3..4 in the lower part
-// (2 per wave: SAT rows 48..79)
-__device__ __forceinline__ constexpr int sat_row(int wave, int j) { return j < 3 ? 3 * wave + j : 48 + 2 * wave + (j - 3); }
+// SAT row of a wave's j-th row: five consecutive rows per wave (one row group per wave: sixteen group totals to prefix)
+__device__ __forceinline__ constexpr int sat_row(int wave, int j) { return 5 * wave + j; }
 
 // the lane mask of a predicate as the compiler holds it (HIP's __ballot goes through an int: v_cndmask + v_cmp per call)
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -841,8 +840,7 @@ __device__ __forceinline__ void tile_load_s(const HpkStencilArgs& a, int rb, int
         const int cc0 = rt0 + koff + 127 - 2 * lane;       // matrix column of cell e = 0; columns < 0 or >= n read 0
 #pragma unroll
         for (int e = 0; e < 2; ++e) t.wc[e] = ldbuf_f64(rw, (unsigned)(cc0 - e) * 8u, 0u);
-        const int jl = lane & 7;
-        const int Yl = jl < 3 ? 3 * wave + jl : 48 + 2 * wave + (jl - 3);
+        const int Yl = sat_row(wave, lane & 7);            // (lanes 5-7: rows of the next wave, never used)
         t.wrow = ldbuf_f64(rw, (unsigned)(rt0 + Yl) * 8u, 0u);
     }
 #pragma unroll
@@ -1065,7 +1063,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         double pc = l1c;
         unsigned pr = l1r;
         wave_exclusive_scan_z(pc, pr, zdpp);
-        if (j == 0 || j == 3) {                                 // a row group starts its own sums
+        if (j == 0) {                                           // the wave's rows start their own sums
             ac[0] = pc + bv[0]; ar[0] = pr + pk[0];
             ac[1] = pc + l1c;   ar[1] = pr + l1r;
         } else {
@@ -1074,9 +1072,9 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         }
         satc[j][0] = ac[0]; satc[j][1] = ac[1];
         satp[j][0] = ar[0]; satp[j][1] = ar[1];
-        // the last row of a group = the group's column-wise total, already row-prefixed: what the groups below add
-        if (j == 2 || j == 4) {
-            const int o = (sat_row(wave, j) - (j == 2 ? 1 : 0)) * LC + xx0;     // parked in a row this wave owns
+        // the wave's last row = the column-wise total of its rows, already row-prefixed: what the waves below add
+        if (j == RPW - 1) {
+            const int o = sat_row(wave, 1) * LC + xx0;             // parked in a row this wave owns
             *reinterpret_cast<double2*>(&Sc[o]) = make_double2(ac[1], ac[0]);
             *reinterpret_cast<uint2*>(&Sp[o]) = make_uint2(ar[1], ar[0]);
         }
@@ -1100,38 +1098,39 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     __syncthreads();
     HPK_CLK(ck1)
     if (have_next && wave >= 8) tile_load_s<BALF64>(a, rb_next, cj_next, wave, lane, nxt);
-    // ---- exclusive prefixes over the 32 row groups (upper groups of waves 0..15, then lower groups), per column: plain
-    // sums.  Waves 0-3: the f64 plane, 32 columns each; waves 4-7: the packed plane.  Lanes 0-31 walk the 16 upper
-    // groups of their column, lanes 32-63 the 16 lower groups, which then add the upper total.  Group g of the upper
-    // part parked its total in SAT row 3g + 1 and gets its base in row 3g; lower part: total in row 48 + 2g + 1, base in
-    // row 48 + 2g.
+    // ---- exclusive prefixes over the 16 waves' row groups, per column: plain sums in wave order.  Waves 0-3: the f64
+    // plane, 32 columns each; waves 4-7: the packed plane.  Lanes 0-31 walk groups 0-7 of their column, lanes 32-63 groups
+    // 8-15, which start from the first half's total.  Group g parked its total in SAT row 5g + 1 and gets its base in row 5g.
     if (wave < 8) {
         const int col = (wave & 3) * 32 + (lane & 31);
-        const bool low = lane >= 32;
-        // (two passes over the column: holding the sixteen values would cost 32 VGPRs this kernel does not have)
+        const int g0 = lane >= 32 ? 8 : 0;
         if (wave < 4) {
-            double tot = 0.0;
+            double v[8];
 #pragma unroll
-            for (int g = 0; g < 16; ++g) tot += Sc[(low ? 48 + 2 * g + 1 : 3 * g + 1) * LC + col];
-            double run = __shfl(tot, lane & 31);                 // the lower half starts from the upper half's total
-            run = low ? run : 0.0;
+            for (int g = 0; g < 8; ++g) v[g] = Sc[(5 * (g0 + g) + 1) * LC + col];
+            double tot = v[0];
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const double v = Sc[(low ? 48 + 2 * g + 1 : 3 * g + 1) * LC + col];
-                Sc[(low ? 48 + 2 * g : 3 * g) * LC + col] = run;
-                run += v;
+            for (int g = 1; g < 8; ++g) tot += v[g];
+            double run = __shfl(tot, lane & 31);                 // the second half starts from the first half's total
+            run = g0 ? run : 0.0;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                Sc[(5 * (g0 + g)) * LC + col] = run;
+                run += v[g];
             }
         } else {
-            unsigned tot = 0u;
+            unsigned v[8];
 #pragma unroll
-            for (int g = 0; g < 16; ++g) tot += Sp[(low ? 48 + 2 * g + 1 : 3 * g + 1) * LC + col];
+            for (int g = 0; g < 8; ++g) v[g] = Sp[(5 * (g0 + g) + 1) * LC + col];
+            unsigned tot = v[0];
+#pragma unroll
+            for (int g = 1; g < 8; ++g) tot += v[g];
             unsigned run = __shfl(tot, lane & 31);
-            run = low ? run : 0u;
+            run = g0 ? run : 0u;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const unsigned v = Sp[(low ? 48 + 2 * g + 1 : 3 * g + 1) * LC + col];
-                Sp[(low ? 48 + 2 * g : 3 * g) * LC + col] = run;
-                run += v;
+            for (int g = 0; g < 8; ++g) {
+                Sp[(5 * (g0 + g)) * LC + col] = run;
+                run += v[g];
             }
         }
     }
@@ -1139,16 +1138,12 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     HPK_CLK(ck2)
     // ---- phase 2: add the groups' bases and store the SAT
     {
-        const int oa = sat_row(wave, 0) * LC + xx0, ob = sat_row(wave, 3) * LC + xx0;
-        const double2 ba = *reinterpret_cast<const double2*>(&Sc[oa]);
-        const uint2 ua = *reinterpret_cast<const uint2*>(&Sp[oa]);
-        const double2 bb = *reinterpret_cast<const double2*>(&Sc[ob]);
-        const uint2 ub = *reinterpret_cast<const uint2*>(&Sp[ob]);
+        const int oa = sat_row(wave, 0) * LC + xx0;
+        const double2 bs = *reinterpret_cast<const double2*>(&Sc[oa]);
+        const uint2 us = *reinterpret_cast<const uint2*>(&Sp[oa]);
 #pragma unroll
         for (int j = 0; j < RPW; ++j) {
             const int o = sat_row(wave, j) * LC + xx0;
-            const double2 bs = j < 3 ? ba : bb;
-            const uint2 us = j < 3 ? ua : ub;
             *reinterpret_cast<double2*>(&Sc[o]) = make_double2(satc[j][1] + bs.x, satc[j][0] + bs.y);
             *reinterpret_cast<uint2*>(&Sp[o]) = make_uint2(satp[j][1] + us.x, satp[j][0] + us.y);
         }
