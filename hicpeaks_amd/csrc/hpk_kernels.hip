@@ -843,19 +843,25 @@ __device__ __forceinline__ void tile_load_s(const HpkStencilArgs& a, int rb, int
         const int Yl = sat_row(wave, lane & 7);            // (lanes 5-7: rows of the next wave, never used)
         t.wrow = ldbuf_f64(rw, (unsigned)(rt0 + Yl) * 8u, 0u);
     }
+    // The wave's rows are consecutive: row offset and row length step by constants.  A row above the matrix or below its
+    // end gets length 0 - every lane then reads out of bounds (0), whatever the row offset says.
+    const int Y0 = sat_row(wave, 0), rr0 = rt0 + Y0;
+    const unsigned ld4 = ldu * 4u;
+    unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(rr0 - rb0) * ld4));
+    int limn = __builtin_amdgcn_readfirstlane(a.n - rr0);            // columns left of the matrix end in row rr0
+    const unsigned k4w = (unsigned)(k4l - 4 * Y0);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-        const int Y = sat_row(wave, j);
-        const int rr = rt0 + Y;
         // a cell holds data iff 0 <= k < lim: inside the stored diagonals and left of the matrix end (column r + k < n)
-        int lim = a.n - rr;
+        int lim = limn - j;
         lim = lim < a.num ? lim : a.num;
-        const bool rowok = rr >= 0 && lim > 0;
-        const unsigned lim4 = (unsigned)__builtin_amdgcn_readfirstlane(rowok ? lim * 4 : 0);
-        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(rowok ? (int)((unsigned)(rr - rb0) * ldu * 4u) : 0);
+        lim = lim > 0 ? lim : 0;
+        lim = rr0 + j >= 0 ? lim : 0;
+        asm volatile("" : "+s"(lim));                       // (a scalar select per row, not a lane mask ANDed per cell)
+        const unsigned lim4 = (unsigned)lim * 4u;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const unsigned k4 = (unsigned)(k4l - 4 * e - 4 * Y);
+            const unsigned k4 = k4w - (unsigned)(4 * e + 4 * j);
             t.raw[j][e] = ldbuf_f32(rraw, k4 < lim4 ? k4 : OOB_OFF, soff);
             if (BALF64) {
                 const unsigned mw4 = (unsigned)a.mw * 4u;
@@ -863,6 +869,7 @@ __device__ __forceinline__ void tile_load_s(const HpkStencilArgs& a, int rb, int
                 t.bal[j][e] = ldbuf_f64(rbal, (k4 - mw4) < span ? k4 * 2u : OOB_OFF, soff * 2u);
             }
         }
+        soff += ld4;
     }
 }
 
