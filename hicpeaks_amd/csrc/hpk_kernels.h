@@ -26,7 +26,7 @@ struct HpkStencilArgs {
     const HpkDevPlan* plan;
     // Output: compact candidate records, one region of `tilecap` records per tile.  Waves reserve their share of a
     // region with one atomicAdd on tile_cnt[tile] (distinct addresses per tile: no serialisation).
-    //   rec_ent[tile * tilecap + i]                    x | row slot << 7 | stencil wave << 9 | min(raw, HPK_PK_CAP) << 13
+    //   rec_ent[tile * tilecap + i]                    x | row of the output tile << 7 | min(raw, HPK_PK_CAP) << 13
     //   rec_S[slot * rec_stride + tile * tilecap + i]  (bS_K, bS_Y) at the resolving step
     //   rec_W[slot * rec_stride + tile * tilecap + i]  resolving step + 1, 0 = unresolved
     unsigned* rec_ent;

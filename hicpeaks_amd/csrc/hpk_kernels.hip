@@ -1004,7 +1004,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     }
     unsigned* __restrict__ tcnt = tcount + par;
     // ---- phase 1: balanced values and packed cells of the wave's five rows, the candidates among them, and the SAT of
-    // the wave's own rows (row prefix by DPP scan, column prefix by running sums within each of the two row groups)
+    // the wave's own rows (row prefix by DPP scan, column prefix by running sums down the wave's rows)
     const int xx0 = 126 - 2 * lane;                                     // SAT column of the lane's cell e = 1 (e = 0: xx0 + 1)
     const int kl = mw + cj * TC + 1 + xx0 + 1;                          // diagonal of the lane's cell e = 0 at SAT row 0
     const int xo = xx0 + 1 - W;                                         // output column of cell e = 0 (e = 1: xo - 1)

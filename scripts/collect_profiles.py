@@ -21,6 +21,7 @@ def pmc_means(d, pat):
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
 
+have_raw = bool(glob.glob(os.path.join(out, '**', '*_counter_collection.csv'), recursive=True))
 lines = ['# rocprofv3 --pmc passes of scripts/gpu_profile_round.sh %s, mean per dispatch' % tag]
 traffic = {'_comment': 'HBM traffic per stencil launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; KiB; FETCH_SIZE '
                        'doubled per the gfx950 note in MI355X_MICROARCH.md, calibrated in profiles/r01_pmc_summary.txt); bench.py copies '
@@ -43,11 +44,15 @@ for kern in ('hpk_stencil', 'hpk_score'):
     for d in sorted(glob.glob(os.path.join(out, 'pmc_sq_*/'))):
         for k, (v, n) in sorted(pmc_means(d, kern).items()):
             lines.append('%-28s n=%d mean=%.4g' % (k, n, v))
-open(os.path.join(out, 'pmc_summary.txt'), 'w').write('\n'.join(lines) + '\n')
+# (the GPU box deletes the raw counter files after this step: a later run here, without them, only copies)
+if have_raw:
+    open(os.path.join(out, 'pmc_summary.txt'), 'w').write('\n'.join(lines) + '\n')
+    if len(traffic) > 1:
+        json.dump(traffic, open(os.path.join(out, 'traffic.json'), 'w'), indent=1)
 ks = glob.glob(os.path.join(out, 'trace', '**', '*kernel_stats.csv'), recursive=True)
 if ks:
     shutil.copy(ks[0], os.path.join(out, 'kernel_stats.csv'))
-print('\n'.join(lines[:40]))
+print('\n'.join(lines[:80]))
 if copy:
     shutil.copy(os.path.join(out, 'bench.json'), os.path.join(prof, '%s_bench.json' % tag))
     with open(os.path.join(prof, '%s_bench_other_configs.jsonl' % tag), 'w') as f:
@@ -58,6 +63,6 @@ if copy:
     if os.path.exists(os.path.join(out, 'kernel_stats.csv')):
         shutil.copy(os.path.join(out, 'kernel_stats.csv'), os.path.join(prof, '%s_kernel_stats.csv' % tag))
     shutil.copy(os.path.join(out, 'pmc_summary.txt'), os.path.join(prof, '%s_pmc_summary.txt' % tag))
-    if len(traffic) > 1:
-        json.dump(traffic, open(os.path.join(prof, 'traffic.json'), 'w'), indent=1)
+    if os.path.exists(os.path.join(out, 'traffic.json')):
+        shutil.copy(os.path.join(out, 'traffic.json'), os.path.join(prof, 'traffic.json'))
     print('copied to profiles/')
