@@ -475,11 +475,16 @@ int launch_scoring(hpk_ctx* c, hpk_job* j, int attempt) {
         sc.nvalid = reinterpret_cast<unsigned long long*>(small + OFF_NVALID);
         sc.nsurv = d_nsurv;
         { const char* e = std::getenv("HPK_DBG_SCORE"); sc.dbg = e ? std::atoi(e) : 0; }
+        // default: the scoring kernel keeps the p-value histogram the cut is derived from (no separate pass over the
+        // survivors); HPK_ROUNDS = -1: hpk_thr_hist, >= 0: exact counting rounds
+        int rounds = j->rounds;
+        sc.hist = d_cnt; sc.hbins = 0; sc.nsets_half = plan.npairs;
+        if (rounds <= -2) { sc.hbins = hpk_score_hist_bins(j->nsets); rounds = -100 - sc.hbins; }
         sc.cap = cap; sc.surv = L.surv.as<HpkSurv>(); sc.chunk_used = d_chunkused;
         hpk_launch_score(sc, plan.mode == HPK_MODE_BHFDR, c->cus, c->stream);
         HIPCHK(c, hipGetLastError());
         if (j->phases) (void)hipEventRecord(L.ev[4], c->stream);
-        hpk_launch_tighten(sc.surv, d_nsurv, cap, sc.chunk_used, d_fam_m, d_fam_f, d_cnt, j->prm.sig, j->rounds, j->nsets,
+        hpk_launch_tighten(sc.surv, d_nsurv, cap, sc.chunk_used, d_fam_m, d_fam_f, d_cnt, j->prm.sig, rounds, j->nsets,
                            reinterpret_cast<HpkSurv*>(small + j->off_inl), HEAD_INLINE, L.surv2.as<HpkSurv>(), d_nout,
                            j->in.bal, j->in.weight, j->ld, c->cus, c->stream);
         HIPCHK(c, hipGetLastError());
@@ -534,7 +539,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     j->dense = j->sums || (prm->flags & HPK_FLAG_DENSE_E) != 0;
     j->do_score = (prm->flags & HPK_FLAG_NO_SCORE) == 0;
     j->phases = (prm->flags & HPK_FLAG_PHASE_TIMING) != 0;
-    j->rounds = std::getenv("HPK_ROUNDS") ? std::atoi(std::getenv("HPK_ROUNDS")) : -1;     // < 0: one histogram pass (hpk_thr_hist)
+    j->rounds = std::getenv("HPK_ROUNDS") ? std::atoi(std::getenv("HPK_ROUNDS")) : -2;     // -2: histogram kept by hpk_score, -1: hpk_thr_hist
     if (j->rounds > 4) j->rounds = 4;
     const bool sums = j->sums, dense = j->dense;
 

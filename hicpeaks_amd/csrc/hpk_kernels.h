@@ -67,6 +67,7 @@ struct HpkSurv {
     double E, p, bal;
 };
 #define HPK_NFAM (2 * HPK_MAX_PAIRS * (HPK_NB + 1))     // (set, chunk) families
+#define HPK_HSHIFT 1                                     // hpk_score's p-value histogram: bins a factor 4 wide (8 bins reach sig 2^-14; fewer, fuller bins to flush)
 #define HPK_TIGHTEN_MAX 16                               // counter arrays per family: exact rounds, or the bins of the one-pass histogram
 #define HPK_NREG 64                     // independent survivor regions (one reservation counter each, 256 B apart)
 #define HPK_REG_STRIDE 32               // counters are u64[HPK_NREG * HPK_REG_STRIDE]
@@ -108,6 +109,9 @@ struct HpkScoreArgs {
     int64_t cap;                        // survivor capacity per region (multiple of 256)
     HpkSurv* surv;
     unsigned* chunk_used;               // [HPK_NREG * cap / HPK_SCH] filled slots per chunk
+    unsigned int* hist;                 // [nsets * (HPK_NB + 1)][hbins] p-values <= sig by family and log2 bin (zeroed), or unused
+    int32_t hbins;                      // bins per family of `hist`, 0 = no histogram (hpk_thr_hist / counting rounds do the cut)
+    int32_t nsets_half;                 // (pw, ww) pairs of the call: the launcher sizes the histogram's LDS with it
     int32_t dbg;                        // profiling ablation (HPK_DBG_SCORE): 1 no Poisson table read, 2 no expected table,
                                         // 3 no survivor stores, 4 no counters
 };
@@ -146,6 +150,7 @@ void hpk_launch_score(const HpkScoreArgs& a, bool bhfdr, int cus, hipStream_t st
 // Benjamini-Hochberg cut tightening on the survivor list: thr[f] <- sig * #{p <= thr[f]} / m[f], `rounds` times,
 // then compaction of the records with p <= thr[f] into `out` (count in *nout).
 int  hpk_thr_hist_bins(int nsets);       // bins per family of the one-pass tightening (rounds < 0)
+int  hpk_score_hist_bins(int nsets);     // bins per family of the histogram hpk_score keeps (rounds <= -100)
 void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned* chunk_used,
                         const unsigned int* fam_m, const unsigned int* fam_f, unsigned int* fam_cnt, double sig, int rounds,
                         int nsets, HpkSurv* out_head, unsigned long long inl, HpkSurv* out_rest, unsigned long long* nout,

@@ -1738,6 +1738,10 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     __shared__ int lstepw[HPK_MAX_STEPS];
     __shared__ int lpair_slot[HPK_MAX_PAIRS], lpair_wi[HPK_MAX_PAIRS];
     __shared__ int lptoff[HPK_NB_TAB + 2];
+    // p-values at or below sig by family and log bin (bin k: sig 4^-(k+1) < p <= sig 4^-k, the last one open towards 0):
+    // what the Benjamini-Hochberg cut is derived from (hpk_thr_compact).  Families of the table's chunks are counted here,
+    // [nsets][HPK_NB_TAB + 1][a.hbins], the few beyond it straight in global memory.
+    extern __shared__ unsigned int lhist[];
     const HpkDevPlan* __restrict__ plan = a.plan;
     // Arguments that only rare paths need (re-read of a capped count, Poisson beyond the table, chunk bookkeeping) are
     // fetched from the kernel-argument segment where they are used instead of being held in SGPRs for the whole
@@ -1748,6 +1752,10 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     const int W = plan->W;
     const int nsets = BH ? 1 : 2 * npairs;
     for (int i = threadIdx.x; i < nsets * (HPK_NB + 1); i += blockDim.x) { (&lm[0][0])[i] = 0u; (&lf[0][0])[i] = 0u; }
+    const int hbins = a.hbins;
+    for (int i = threadIdx.x; i < nsets * (HPK_NB_TAB + 1) * hbins; i += blockDim.x) lhist[i] = 0u;
+    const int sig_e = (int)((unsigned long long)__double_as_longlong(a.sig) >> 52);                  // sig > 0, normal
+    const unsigned long long sig_m = (unsigned long long)__double_as_longlong(a.sig) & 0xfffffffffffffull;
     if (threadIdx.x < HPK_NB) lbounds[threadIdx.x] = const_cast<const double*>(ka->bounds)[threadIdx.x];
     if (threadIdx.x < 2 * HPK_MAX_PAIRS) lemax[threadIdx.x] = 0ull;
     if (threadIdx.x < HPK_MAX_STEPS) lstepw[threadIdx.x] = (threadIdx.x < plan->nsteps) ? plan->steps[threadIdx.x].wi : 0;
@@ -1958,7 +1966,19 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                         if (valid) atomicAdd(&lm[set][chunk], 1u);
                     }
                     if (sm != 0ull) {
-                        if (surv) atomicAdd(&lf[set][chunk], 1u);
+                        if (surv) {
+                            atomicAdd(&lf[set][chunk], 1u);
+                            if (hbins) {
+                                // floor(log2(sig / p)) from the two exponents and a mantissa compare (p = 0, subnormal: last bin)
+                                const unsigned long long pb = (unsigned long long)__double_as_longlong(p);
+                                int k = sig_e - (int)(pb >> 52) - ((pb & 0xfffffffffffffull) > sig_m ? 1 : 0);
+                                k >>= HPK_HSHIFT;                                 // bins a factor 2^(2^HPK_HSHIFT) wide
+                                k = (pb >> 52) == 0ull ? hbins - 1 : k;
+                                k = k < 0 ? 0 : (k > hbins - 1 ? hbins - 1 : k);
+                                if (chunk <= HPK_NB_TAB) atomicAdd(&lhist[(set * (HPK_NB_TAB + 1) + chunk) * hbins + k], 1u);
+                                else atomicAdd(&const_cast<unsigned int*>(ka->hist)[(set * (HPK_NB + 1) + chunk) * hbins + k], 1u);
+                            }
+                        }
                         // per-wave reservation of survivor slots
                         const unsigned scnt = (unsigned)__popcll(sm);
                         if (wused + scnt > HPK_SCH) {            // wave-uniform: retire the chunk, take a new one
@@ -1995,6 +2015,13 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     }
     if (threadIdx.x < nsets) {
         if (lemax[threadIdx.x]) atomicMax(&const_cast<unsigned long long*>(ka->emax_bits)[threadIdx.x], lemax[threadIdx.x]);
+    }
+    for (int i = threadIdx.x; i < nsets * (HPK_NB_TAB + 1) * hbins; i += blockDim.x) {
+        const unsigned v = lhist[i];
+        if (v) {
+            const int k = i % hbins, fc = i / hbins, ch = fc % (HPK_NB_TAB + 1), st = fc / (HPK_NB_TAB + 1);
+            atomicAdd(&const_cast<unsigned int*>(ka->hist)[(st * (HPK_NB + 1) + ch) * hbins + k], v);
+        }
     }
 }
 
@@ -2057,17 +2084,19 @@ __global__ void __launch_bounds__(256) hpk_thr_hist(const HpkSurv* __restrict__ 
     __syncthreads();
     for (int i = threadIdx.x; i < nfam * nbins; i += blockDim.x) if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
-// bound per family from the histogram (see hpk_thr_hist)
+// bound per family from the histogram (see hpk_thr_hist; absolute: the bins of hpk_score, edges sig 2^-k instead of T_0 2^-k)
 __device__ __forceinline__ void thr_table_hist(double* lthr, const unsigned int* __restrict__ fam_m, const unsigned int* __restrict__ fam_f,
-                                               const unsigned int* __restrict__ hist, int nbins, double sig, int nfam) {
+                                               const unsigned int* __restrict__ hist, int nbins, double sig, int nfam, bool absolute) {
     for (int i = threadIdx.x; i < nfam; i += blockDim.x) {
         const unsigned m = fam_m[i];
         const double t0 = thr_t0(m, fam_f[i], sig);
+        const double ref = absolute ? sig : t0;
         double t = t0;
         if (m && t0 > 0.0) {
             for (int it = 0; it < 2 * nbins; ++it) {
-                // largest k whose edge t0 2^-k is still >= t (with a margin for the rounding of the quotient)
-                int k = (int)((__double_as_longlong(t0 / (t * (1.0 + 1e-12))) >> 52) & 0x7ff) - 1023;
+                // largest k whose edge ref 2^-k is still >= t (with a margin for the rounding of the quotient)
+                int k = (int)((__double_as_longlong(ref / (t * (1.0 + 1e-12))) >> 52) & 0x7ff) - 1023;
+                if (absolute) k >>= HPK_HSHIFT;
                 k = k < 0 ? 0 : (k > nbins - 1 ? nbins - 1 : k);
                 unsigned long long c = 0ull;
                 for (int kk = k; kk < nbins; ++kk) c += hist[(size_t)i * nbins + kk];
@@ -2119,7 +2148,8 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkSurv* __restrict
     const int reg = blockIdx.y;
     int64_t n = (int64_t)nsurv[reg * HPK_REG_STRIDE]; if (n > cap) n = cap;
     if ((int64_t)blockIdx.x * blockDim.x >= n) return;
-    if (rounds < 0) thr_table_hist(lthr, fam_m, fam_f, cnt, -rounds, sig, nfam);
+    if (rounds <= -100) thr_table_hist(lthr, fam_m, fam_f, cnt, -rounds - 100, sig, nfam, true);
+    else if (rounds < 0) thr_table_hist(lthr, fam_m, fam_f, cnt, -rounds, sig, nfam, false);
     else thr_table(lthr, fam_m, fam_f, cnt, rounds, sig, nfam);
     __syncthreads();
     const int64_t rb = (int64_t)reg * cap;
@@ -2339,20 +2369,25 @@ void hpk_launch_gap(const float* raw, const double* bal, const double* weight, i
 // Persistent grid: exactly the workgroups that are resident at once (occupancy x CUs), so that no second round of
 // workgroups pays the prologue again (measured: 0.105 -> 0.095 ms against twice as many).
 template <bool BH>
-static int score_grid(int cus) {
+static int score_grid(int cus, size_t lds) {
     static int per_cu = 0;
-    if (per_cu == 0) {
+    static size_t per_cu_lds = ~(size_t)0;
+    if (per_cu == 0 || per_cu_lds != lds) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hpk_score<BH>, 256, 0) != hipSuccess || nb <= 0) nb = 4;
-        per_cu = nb;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hpk_score<BH>, 256, lds) != hipSuccess || nb <= 0) nb = 4;
+        per_cu = nb; per_cu_lds = lds;
     }
     static const int gm = std::getenv("HPK_SCORE_GM") ? std::atoi(std::getenv("HPK_SCORE_GM")) : 0;
     return cus * (gm > 0 ? gm : per_cu);
 }
+// bins per family of the p-value histogram hpk_score keeps (0 = none: HpkScoreArgs::hbins)
+int hpk_score_hist_bins(int nsets) { return nsets <= 6 ? 8 : 4; }
 void hpk_launch_score(const HpkScoreArgs& a, bool bhfdr, int cus, hipStream_t st) {
     if (a.ntiles <= 0 || a.n <= 0) return;
-    if (bhfdr) hipLaunchKernelGGL(hpk_score<true>, dim3(score_grid<true>(cus)), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(hpk_score<false>, dim3(score_grid<false>(cus)), dim3(256), 0, st, a);
+    const int nsets = bhfdr ? 1 : 2 * a.nsets_half;
+    const size_t lds = (size_t)nsets * (HPK_NB_TAB + 1) * (size_t)a.hbins * 4;
+    if (bhfdr) hipLaunchKernelGGL(hpk_score<true>, dim3(score_grid<true>(cus, lds)), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(hpk_score<false>, dim3(score_grid<false>(cus, lds)), dim3(256), lds, st, a);
 }
 
 int hpk_thr_hist_bins(int nsets) { return nsets * (HPK_NB + 1) <= 1032 ? 16 : 8; }   // LDS of hpk_thr_hist <= 83 KB
@@ -2364,6 +2399,11 @@ void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, in
     if (rounds > HPK_TIGHTEN_MAX) rounds = HPK_TIGHTEN_MAX;
     const int nfam = nsets * (HPK_NB + 1);          // families in use: (set, chunk)
     static const int gx = std::getenv("HPK_THR_GX") ? std::atoi(std::getenv("HPK_THR_GX")) : 8;
+    if (rounds <= -100) {       // the histogram came with the scoring kernel: only the compaction is left
+        hipLaunchKernelGGL(hpk_thr_compact, dim3(gx, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt,
+                           rounds, sig, nfam, out_head, inl, out_rest, nout, bal, weight, ld);
+        return;
+    }
     if (rounds < 0) {           // one histogram pass instead of the counting rounds (fam_cnt = [nfam][nbins], zeroed)
         const int nbins = hpk_thr_hist_bins(nsets);
         const size_t lds = (size_t)nfam * 8 + (size_t)nfam * nbins * 4;
