@@ -505,7 +505,13 @@ int launch_scoring(hpk_ctx* c, hpk_job* j, int attempt) {
     if (std::getenv("HPK_HEAD_COPY")) {
         HIPCHK(c, hipMemcpyAsync(L.h_head, small, j->head_bytes, hipMemcpyDeviceToHost, c->stream));
     } else {        // pinned memory is device-visible: a small kernel writes it (head_bytes is a multiple of 16)
-        hpk_launch_publish(small, L.h_head, j->head_bytes, c->stream);
+        if (j->do_score && !std::getenv("HPK_PUBLISH_ALL")) {
+            // the stretches a chromosome fills: counters up to the families in use, their F(sig) counts, the row flags,
+            // and as many inline survivors as the cut left
+            const size_t nfam_b = sizeof(unsigned) * (size_t)j->nsets * (HPK_NB + 1);
+            const size_t seg[3][2] = {{0, OFF_FAM_M + nfam_b}, {OFF_FAM_F, OFF_FAM_F + nfam_b}, {j->off_rowlive, j->off_rowlive + (size_t)j->n}};
+            hpk_launch_publish_head(small, L.h_head, seg, j->off_inl, d_nout, (unsigned)HEAD_INLINE, (unsigned)sizeof(HpkSurv), c->stream);
+        } else hpk_launch_publish(small, L.h_head, j->head_bytes, c->stream);
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(L.ev_done, c->stream));
@@ -726,7 +732,8 @@ int collect_impl(hpk_ctx* c, hpk_job* j, hpk_result** out) {
     for (int q = 0; q < plan.nslots; ++q) R.slot_pi[q] = plan.slot_pi[q];
     R.ncand = (int64_t)h_hist[HPK_HIST_NCAND];
     R.nsurv_sig = 0;
-    for (int i = 0; i < HPK_NFAM; ++i) R.nsurv_sig += reinterpret_cast<const unsigned int*>(hsmall + OFF_FAM_F)[i];
+    for (int i = 0; i < nsets * (HPK_NB + 1); ++i)      // (only the families of the sets in use are copied back)
+        R.nsurv_sig += reinterpret_cast<const unsigned int*>(hsmall + OFF_FAM_F)[i];
     R.nsurv_cut = (int64_t)h_nsurv;
     R.gap = box->gap.data();
     if (h_err != 0 && sa.dbg_stop == 0) {

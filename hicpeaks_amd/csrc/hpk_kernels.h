@@ -156,6 +156,8 @@ void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, in
                         int nsets, HpkSurv* out_head, unsigned long long inl, HpkSurv* out_rest, unsigned long long* nout,
                         const double* bal, const double* weight, int64_t ld, int cus, hipStream_t st);
 void hpk_launch_publish(const void* src, void* dst_host_mapped, size_t bytes, hipStream_t st);
+void hpk_launch_publish_head(const void* src, void* dst_host_mapped, const size_t seg[3][2], size_t inl_begin,
+                             const unsigned long long* nout, unsigned inl, unsigned recbytes, hipStream_t st);
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,
                      hipStream_t st);
 void hpk_launch_poisson_sf(const double* k, const double* lam, const double* sfe, double* out, int64_t count,

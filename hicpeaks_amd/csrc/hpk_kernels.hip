@@ -2441,15 +2441,41 @@ void hpk_launch_etab(const HpkDevPlan* plan, int nsteps, int D, int W, const dou
                        reinterpret_cast<uint4*>(zero), (unsigned long long)(zero_bytes / 16), ntab);
 }
 
-// result head -> pinned host memory by a kernel (the copy engine costs ~15 us of start-up latency per chromosome)
-__global__ void __launch_bounds__(256) hpk_publish(const uint4* __restrict__ src, uint4* __restrict__ dst, unsigned n16) {
-    const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n16) dst[i] = src[i];
+// result head -> pinned host memory by a kernel (the copy engine costs ~15 us of start-up latency per chromosome).  The
+// head is 200 KB of which a chromosome fills a third - family counters of the sets in use, one flag per row, the
+// survivors that made the cut - and the PCIe write is what the launch takes: only the filled stretches travel (up to
+// four [begin, end) in 16-byte units; the last one ends after min(*nout, inl) records of recbytes).
+struct HpkPubSegs { unsigned b[4], e[4]; };
+__global__ void __launch_bounds__(256) hpk_publish(const uint4* __restrict__ src, uint4* __restrict__ dst, HpkPubSegs sg,
+                                                   const unsigned long long* __restrict__ nout, unsigned inl, unsigned recbytes) {
+    if (nout) {
+        const unsigned long long no = *nout;
+        sg.e[3] = sg.b[3] + (unsigned)(((no < inl ? no : (unsigned long long)inl) * recbytes + 15ull) / 16ull);
+    }
+    unsigned i = blockIdx.x * 256u + threadIdx.x;       // thread index -> unit: the stretches back to back
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const unsigned len = sg.e[k] - sg.b[k];
+        if (i < len) { dst[sg.b[k] + i] = src[sg.b[k] + i]; return; }
+        i -= len;
+    }
 }
 void hpk_launch_publish(const void* src, void* dst_host_mapped, size_t bytes, hipStream_t st) {
-    const unsigned n16 = (unsigned)((bytes + 15) / 16);
-    hipLaunchKernelGGL(hpk_publish, dim3((n16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4*>(src),
-                       reinterpret_cast<uint4*>(dst_host_mapped), n16);
+    HpkPubSegs sg = {{0u, 0u, 0u, 0u}, {(unsigned)((bytes + 15) / 16), 0u, 0u, 0u}};
+    hipLaunchKernelGGL(hpk_publish, dim3((sg.e[0] + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4*>(src),
+                       reinterpret_cast<uint4*>(dst_host_mapped), sg, nullptr, 0u, 16u);
+}
+// seg: three fixed stretches in bytes (begin, end), then the survivors' area from inl_begin on
+void hpk_launch_publish_head(const void* src, void* dst_host_mapped, const size_t seg[3][2], size_t inl_begin,
+                             const unsigned long long* nout, unsigned inl, unsigned recbytes, hipStream_t st) {
+    HpkPubSegs sg;
+    unsigned most = 0;
+    for (int k = 0; k < 3; ++k) { sg.b[k] = (unsigned)(seg[k][0] / 16); sg.e[k] = (unsigned)((seg[k][1] + 15) / 16); most += sg.e[k] - sg.b[k]; }
+    sg.b[3] = (unsigned)(inl_begin / 16);
+    sg.e[3] = sg.b[3] + (unsigned)(((size_t)inl * recbytes + 15) / 16);
+    most += sg.e[3] - sg.b[3];
+    hipLaunchKernelGGL(hpk_publish, dim3((most + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4*>(src),
+                       reinterpret_cast<uint4*>(dst_host_mapped), sg, nout, inl, recbytes);
 }
 
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,
