@@ -24,6 +24,7 @@ FLAG_DENSE_E = 1
 FLAG_DENSE_SUMS = 2
 FLAG_NO_SCORE = 4
 FLAG_PHASE_TIMING = 8
+FLAG_NO_STENCIL_TIMING = 16
 
 HPK_OK = 0
 ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_EMPTY_STEP, ERR_PLAN, ERR_NOMEM, ERR_BUSY = -1, -2, -3, -4, -5, -6, -7

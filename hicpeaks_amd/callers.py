@@ -142,9 +142,9 @@ def hiccups_band_submit(raw, IR, B1, B2, chrom='', balanced=None, weight=None, p
                         min_marginal_peaks=3, onlyanchor=True, min_local_reads=25, device=0, detail=None, ctx=None):
     """Arguments of `hiccups_band`; returns a PendingCall."""
     ctx = ctx or _lib.default_context(device)
-    flags = 0
+    flags = _lib.FLAG_NO_STENCIL_TIMING
     if detail is not None and detail.get('dense'):
-        flags = _lib.FLAG_DENSE_SUMS
+        flags |= _lib.FLAG_DENSE_SUMS
     prm = _lib.make_params(_lib.MODE_HICCUPS, pw, ww, maxww, sig, maxapart, res, min_local_reads, flags)
     n = raw.shape[0]
     logger.info('Chrom:{0}, Two local neighborhoods, two expected matrices ...'.format(chrom))
@@ -195,9 +195,9 @@ def bhfdr_band_submit(raw, IR, B1, B2, chrom='', balanced=None, weight=None, pw=
                       maxapart=2000000, res=10000, min_marginal_peaks=3, onlyanchor=False, device=0, detail=None, ctx=None):
     """Arguments of `bhfdr_band`; returns a PendingCall."""
     ctx = ctx or _lib.default_context(device)
-    flags = 0
+    flags = _lib.FLAG_NO_STENCIL_TIMING
     if detail is not None and detail.get('dense'):
-        flags = _lib.FLAG_DENSE_SUMS
+        flags |= _lib.FLAG_DENSE_SUMS
     prm = _lib.make_params(_lib.MODE_BHFDR, [pw], [ww], maxww, sig, maxapart, res, 16, flags)
     n = raw.shape[0]
     logger.info('Chrom:{0}, Calculate the expected matrix ...'.format(chrom))

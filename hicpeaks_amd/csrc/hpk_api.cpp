@@ -426,7 +426,7 @@ struct hpk_job {
     size_t off_rowlive = 0, off_inl = 0, head_bytes = 0, off_cnt = 0, off_cu = 0, dense_elems = 0;
     int64_t cap = 0, band_px = 0, ldo = 0;
     int nsets = 0, TR = 0, TC = 0, rounds = 2;
-    bool sums = false, dense = false, do_score = true, phases = false, simple = false;
+    bool sums = false, dense = false, do_score = true, phases = false, simple = false, time_stencil = true;
     double t_begin = 0.0;
     ResultBox* box = nullptr;
     ~hpk_job() { delete box; }
@@ -660,11 +660,12 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     sa.frozen = d_frozen; sa.executed = d_exec; sa.err = d_err;
     sa.single = plan.single_p >= 0 ? 1 : 0;
     { const char* e = std::getenv("HPK_RISK_LOG2"); sa.risk = std::ldexp(1.0, e ? -std::atoi(e) : -12); }
-    (void)hipEventRecord(L.ev[1], c->stream);
+    j->time_stencil = j->phases || !(prm->flags & HPK_FLAG_NO_STENCIL_TIMING);
+    if (j->time_stencil) (void)hipEventRecord(L.ev[1], c->stream);
     j->simple = plan.simple_reads != 0 && !std::getenv("HPK_GENERIC_SEARCH");
     hpk_launch_stencil(sa, in.bal != nullptr, j->simple, c->stream);
     HIPCHK(c, hipGetLastError());
-    (void)hipEventRecord(L.ev[2], c->stream);
+    if (j->time_stencil) (void)hipEventRecord(L.ev[2], c->stream);
     if (!sa.ticket) {       // HPK_FREEZE_KERNEL: the decision as a kernel of its own instead of the last stencil workgroup
         hpk_launch_freeze(sa.plan, d_hist, sa.hist_part, sa.grid, d_frozen, d_exec, d_err, c->stream);
         HIPCHK(c, hipGetLastError());
@@ -870,7 +871,7 @@ int collect_impl(hpk_ctx* c, hpk_job* j, hpk_result** out) {
     if (std::getenv("HPK_HOST_PROF")) std::fprintf(stderr, "[hpk host] total host_bh=%.3f d2h=%.3f\n", t_end - t_d2h1, t_d2h1 - t_d2h0);
 
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, L.ev[1], L.ev[2]) == hipSuccess) R.ms_stencil = ms;
+    if (j->time_stencil && hipEventElapsedTime(&ms, L.ev[1], L.ev[2]) == hipSuccess) R.ms_stencil = ms;
     if (j->phases) {
         if (hipEventElapsedTime(&ms, L.ev[0], L.ev[1]) == hipSuccess) R.ms_h2d = ms;
         if (hipEventElapsedTime(&ms, L.ev[2], L.ev[3]) == hipSuccess) R.ms_freeze = ms;

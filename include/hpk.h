@@ -58,8 +58,10 @@ enum {
     HPK_FLAG_DENSE_E = 1,      /* copy the dense per-slot local expected (E_K, E_Y) and resolving width back */
     HPK_FLAG_DENSE_SUMS = 2,   /* debug: also the four raw sums (bS_K, bE_K, bS_Y, bE_Y) at every candidate */
     HPK_FLAG_NO_SCORE = 4,     /* stop after the stencil (bench: time the donut kernel alone) */
-    HPK_FLAG_PHASE_TIMING = 8  /* also time upload / freeze / scoring / tightening (five more events on the compute
-                                  stream, ~6 us of idle each); ms_stencil, ms_d2h, ms_host_bh, ms_total are always filled */
+    HPK_FLAG_PHASE_TIMING = 8, /* also time upload / freeze / scoring / tightening (five more events on the compute
+                                  stream, ~3 us of idle each); ms_d2h, ms_host_bh, ms_total are always filled */
+    HPK_FLAG_NO_STENCIL_TIMING = 16  /* leave out the two events around the stencil launch (~6 us of idle per call):
+                                  ms_stencil = 0.  Production callers set it; bench.py brackets every fourth launch */
 };
 
 /* hiccups(): pw/ww lists, maxww, sig, maxapart, res, min_local_reads (callers.py:44-46);
