@@ -372,10 +372,7 @@ int stage_inputs(hpk_ctx* c, Lane& L, const hpk_band* band, int mw, Staged* s) {
         s->b1 = L.b1.as<double>();
         s->b2 = s->b1;
     }
-    if (!band->on_device || derive) {      // the kernels wait for the uploads / the derivation, not the other way round
-        HIPCHK(c, hipEventRecord(L.ev_up, L.up));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, L.ev_up, 0));
-    }
+    // (submit_impl adds the expected tables to the side stream, then lets the compute stream wait for all of it)
     return HPK_OK;
 }
 
@@ -559,7 +556,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     const Staged& in = j->in;
     if (!plan_hit) {
         HIPCHK(c, L.plan.reserve(sizeof(HpkDevPlan)));
-        HIPCHK(c, hipMemcpyAsync(L.plan.p, &L.plan_host, sizeof(HpkDevPlan), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(L.plan.p, &L.plan_host, sizeof(HpkDevPlan), hipMemcpyHostToDevice, L.up));
         L.plan_key = key;
         L.plan_valid = true;
     }
@@ -598,10 +595,21 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     const size_t zero_bytes = (off_cu + sizeof(unsigned) * (size_t)(cap / HPK_SCH * HPK_NREG + 1) + 4095) / 4096 * 4096;
     j->off_rowlive = off_rowlive; j->off_inl = off_inl; j->head_bytes = head_bytes; j->off_cnt = off_cnt; j->off_cu = off_cu;
     HIPCHK(c, L.small.reserve(zero_bytes));
-    // expected tables of this chromosome; the same launch zero-fills the block (extra workgroups)
+    // expected tables of this chromosome; the same launch zero-fills the block (extra workgroups).  On the lane's side
+    // stream, like the uploads and the derivation of IR / biases: for the chromosome submitted one ahead this runs beside
+    // the scoring and cut kernels of the chromosome before; the compute stream waits for the lot.
+    static const bool etab_main = std::getenv("HPK_ETAB_MAIN") != nullptr;        // A/B: everything on the compute stream
+    if (etab_main) {
+        HIPCHK(c, hipEventRecord(L.ev_up, L.up));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, L.ev_up, 0));
+    }
     hpk_launch_etab(L.plan.as<HpkDevPlan>(), plan.nsteps, D, W, in.IR, n, num, L.etab.as<double>(), L.eedge.as<double>(),
-                    L.small.p, zero_bytes, c->stream);
+                    L.small.p, zero_bytes, etab_main ? c->stream : L.up);
     HIPCHK(c, hipGetLastError());
+    if (!etab_main) {
+        HIPCHK(c, hipEventRecord(L.ev_up, L.up));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, L.ev_up, 0));
+    }
     if (L.h_head_cap < head_bytes) {
         if (L.h_head) (void)hipHostFree(L.h_head);
         L.h_head = nullptr; L.h_head_cap = 0;
