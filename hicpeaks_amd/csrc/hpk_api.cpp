@@ -47,9 +47,13 @@ double now_ms() {
 // One lane = everything a chromosome in flight owns: upload stream, events, device workspaces, the pinned landing
 // area of its result head and the cached device copy of its widening plan.  Two lanes let the host half of
 // chromosome i (Benjamini-Hochberg, result assembly, the caller's Python) and the upload of chromosome i + 1 overlap
-// the kernels.  All kernels of all lanes run in submission order on the context's one compute stream: the stencil
-// fills the whole chip (one 160 KiB-LDS workgroup per CU), so running two chromosomes' kernels side by side would
-// only time-slice them - and would blur the per-kernel timings.
+// the kernels.  The stencil, the scoring and the cut of all lanes run in submission order on the context's one compute
+// stream: the stencil fills the whole chip (one 160 KiB-LDS workgroup per CU), so running two chromosomes' big kernels
+// side by side would only time-slice them.  What a chromosome needs *before* its stencil - uploads, IR / biases, the
+// expected tables and the zero-fill of its counters - runs on the lane's side stream, beside the scoring / cut kernels
+// of the chromosome before.  (The cut and the copy of the result head were tried on the side stream too: they then
+// wait behind the next chromosome's stencil, the host collects a result later and submits the chromosome after next
+// later - 0.203 -> 0.228 ms per chromosome.)
 #define HPK_LANES 2
 struct Lane {
     hipStream_t up = nullptr;           // uploads of host inputs run beside the kernels of the chromosome before
