@@ -478,6 +478,37 @@ def test_survivor_overflow_rerun(ctx, monkeypatch):
         _same_result(j.result(), want)
 
 
+@pytest.mark.parametrize('mode', ['hiccups', 'bhfdr'])
+def test_bh_cut_variants_agree(ctx, monkeypatch, mode):
+    """Three ways to the Benjamini-Hochberg cut - the histogram the scoring kernel keeps (default), the histogram pass
+    of its own (HPK_ROUNDS=-1), exact counting rounds (HPK_ROUNDS=2) - must leave the same significant pixels with the
+    same p and q; none may cut below the true bound (every significant pixel is among the records copied back).  Also:
+    a call without the stencil's timing events (HPK_FLAG_NO_STENCIL_TIMING) returns the same result and no kernel time."""
+    from hicpeaks_amd import synthetic
+    n, res, maxapart, maxww = 4000, 10000, 2000000, 10
+    num = maxapart // res + maxww + 1
+    raw, weight, _ = synthetic.synth_band(n, num, depth=60.0, nloops=60, seed=11)
+    raw = raw.astype(np.float32)
+    if mode == 'hiccups':
+        mk = lambda fl: _lib.make_params(_lib.MODE_HICCUPS, [1, 2, 4], [3, 5, 7], maxww, 0.1, maxapart, res, 16, fl)
+    else:
+        mk = lambda fl: _lib.make_params(_lib.MODE_BHFDR, [2], [5], maxww, 0.05, maxapart, res, 16, fl)
+    want = ctx.score_host(raw, None, None, None, mk(0), weight=weight)
+    assert sum(s['x'].size for s in want.sets) > 50 and want.nsurv_sig > 1000
+    assert want.nsurv_cut >= sum(s['x'].size for s in want.sets)
+    assert want.nsurv_cut < want.nsurv_sig                         # the cut did remove most of the p <= sig records
+    assert want.timing['stencil'] > 0
+    for rounds in ('-1', '2'):
+        monkeypatch.setenv('HPK_ROUNDS', rounds)
+        got = ctx.score_host(raw, None, None, None, mk(0), weight=weight)
+        _same_result(got, want)
+        assert got.nsurv_sig == want.nsurv_sig and got.nsurv_cut >= sum(s['x'].size for s in got.sets)
+    monkeypatch.delenv('HPK_ROUNDS')
+    quiet = ctx.score_host(raw, None, None, None, mk(_lib.FLAG_NO_STENCIL_TIMING), weight=weight)
+    _same_result(quiet, want)
+    assert quiet.timing['stencil'] == 0 and quiet.nsurv_cut == want.nsurv_cut
+
+
 def test_random_parameter_sets_against_oracle(ctx):
     """A slice of scripts/gpu_fuzz.py (random chromosomes, maxww 3..20, one to three pairs in any order, thresholds,
     hiccups and bhfdr): final tables and resolving widths equal the oracle's, and both sides raise together.  The full
