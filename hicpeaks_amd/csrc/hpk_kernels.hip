@@ -951,6 +951,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     const int wmin_p = __builtin_amdgcn_readfirstlane(plan->wmin);
     const int sp_p = __builtin_amdgcn_readfirstlane(plan->single_p);     // SINGLE: the peak width
     unsigned myhist = 0u;                 // lane w: candidates whose first sufficient width is w
+    unsigned long long hpack0 = 0ull, hpack1 = 0ull;      // this lane's candidates by width min(ww) + k: 16 bits each, k = 0..3 | 4..7
     unsigned mycand = 0u;
     // scoring work list: the append of a tile is completed one tile later (the atomic's return is not waited for)
     int pend_tid = -1;
@@ -1219,13 +1220,17 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
                     wstar = ((wa + t < W) & (wstar == W) & (rd[t] - b0 >= (unsigned)minr_p)) ? wa + t : wstar;
             }
         }
-        // resolve histogram by width: one ballot per width present
+        // resolve histogram by width.  The first eight widths are counted per lane, 16 bits each in two registers
+        // (a lane sees at most one candidate per batch: no field overflows before 65 535 batches of this wave), and added
+        // up over the wave once, after the last tile; wider ones (maxww >= min(ww) + 8) by one ballot per width.
         {
-            const unsigned long long mf = ballot64(wstar == wmin_p);
-            if (lane == wmin_p) myhist += (unsigned)__popcll(mf);
-            if (ballot64((wstar != wmin_p) & (wstar != 255)) != 0ull) {
+            const unsigned off = (unsigned)(wstar - wmin_p);              // 255 - min(ww) >= 8 for "no sufficient width"
+            const unsigned long long inc = 1ull << ((off & 3u) * 16u);
+            hpack0 += off < 4u ? inc : 0ull;
+            hpack1 += (off - 4u) < 4u ? inc : 0ull;
+            if (W - wmin_p >= 8 && ballot64((off >= 8u) & (wstar != 255)) != 0ull) {
 #pragma unroll 1
-                for (int w = wmin_p + 1; w <= W; ++w) {
+                for (int w = wmin_p + 8; w <= W; ++w) {
                     const unsigned c = (unsigned)__popcll(ballot64(wstar == w));
                     if (lane == w) myhist += c;
                 }
@@ -1381,6 +1386,13 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     // ---- resolve histogram of the workgroup: widths summed over the waves in LDS, then per step s of slot q and width
     // w: the candidates whose first sufficient width is w (w above the slot's first width) or at most w (at it)
     unsigned* red = reinterpret_cast<unsigned*>(smem);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {         // the per-lane width counts, summed over the wave, into lane min(ww) + k
+        unsigned v = (unsigned)((k < 4 ? hpack0 : hpack1) >> (16 * (k & 3))) & 0xffffu;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) v += (unsigned)__shfl_xor((int)v, m);
+        if (lane == wmin_p + k) myhist += v;
+    }
     __syncthreads();
     red[wave * 64 + lane] = myhist;
     if (lane == 0) red[NW * 64 + wave] = mycand;
