@@ -1210,7 +1210,8 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
             for (int wa = wmin_p + 1; wa < W; wa += 4) {
                 // widths wa .. wa + 3 from three addresses (those at or beyond W read rows the list follows: not used)
                 const unsigned dn = (unsigned)wa * (unsigned)(LC * 4), lf = (unsigned)wa * 4u;
-                const unsigned a1 = pb + dn, a2 = pb + (dn - lf), a3 = pb - (lf + 12u);
+                unsigned a1 = pb + dn, a2 = pb + (dn - lf), a3 = pb - (lf + 12u);
+                asm volatile("" : "+v"(a1), "+v"(a2), "+v"(a3));     // (whole addresses: the steps below fit the reads' immediates)
                 unsigned rd[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
