@@ -950,6 +950,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     const int minr_p = __builtin_amdgcn_readfirstlane(plan->min_reads), p0_p = __builtin_amdgcn_readfirstlane(plan->reads_p0);
     const int wmin_p = __builtin_amdgcn_readfirstlane(plan->wmin);
     const int sp_p = __builtin_amdgcn_readfirstlane(plan->single_p);     // SINGLE: the peak width
+    const int fr_p = SINGLE ? 0 : __builtin_amdgcn_readfirstlane(plan->first_rho);   // general plans: the box every step starts with
     unsigned myhist = 0u;                 // lane w: candidates whose first sufficient width is w
     unsigned long long hpack0 = 0ull, hpack1 = 0ull;      // this lane's candidates by width min(ww) + k: 16 bits each, k = 0..3 | 4..7
     unsigned mycand = 0u;
@@ -1237,6 +1238,9 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
                 }
             }
         }
+        // general plans: the innermost box is the same in every step of every slot - formed once per candidate
+        double kc0 = 0.0, yc0 = 0.0, big0 = 0.0;
+        if (!SINGLE && fr_p > 0) box_ky_d(cb, fr_p, sc, kc0, yc0, big0);
         // ---- sums at the resolving step, once per slot
 #pragma unroll 1
         for (int q = 0; q < (SINGLE ? 1 : nslots_p); ++q) {
@@ -1272,8 +1276,16 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
                     w0 = pw4.x; k0 = pw4.y; k1 = pw4.z; k2 = pw4.w;
                     if (maxnkt > 6) k3 = pl[src * 8 + 4];
                     nkt = act ? (int)((w0 >> 20) & 15u) : 0;
+                    int j0 = 0;
+                    if (fr_p > 0) {                         // term 0 of every step: the shared box
+                        const double cf = nkt > 0 ? (double)(int)(signed char)((k0 >> 8) & 0xffu) : 0.0;
+                        SK = cf * kc0; SY = cf * yc0;
+                        cfs = cf;
+                        amax = nkt > 0 ? big0 : 0.0;
+                        j0 = 1;
+                    }
 #pragma unroll 1
-                    for (int j = 0; j < maxnkt; ++j) {
+                    for (int j = j0; j < maxnkt; ++j) {
                         const bool on = j < nkt;
                         if (ballot64(on) == 0ull) break;
                         const unsigned kw = (j < 2) ? k0 : (j < 4) ? k1 : (j < 6) ? k2 : k3;

@@ -186,6 +186,14 @@ int hpk_build_plan(const hpk_params* prm, HpkDevPlan* plan, char* msg) {
         if (ok) plan->single_p = p;
     }
 
+    plan->first_rho = 0;
+    if (plan->nsteps > 0 && plan->steps[0].nkt > 0) {
+        int fr = plan->steps[0].kt_rho[0];
+        for (int s = 0; s < plan->nsteps; ++s)
+            if (plan->steps[s].nkt < 1 || plan->steps[s].kt_rho[0] != fr) fr = 0;
+        plan->first_rho = fr;
+    }
+
     // cell counts per diagonal offset for the local-expected tables
     for (int s = 0; s < plan->nsteps; ++s) {
         const HpkDevStep& st = plan->steps[s];

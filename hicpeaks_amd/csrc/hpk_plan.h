@@ -59,6 +59,10 @@ struct HpkDevPlan {
     // widths from wmin on (every single-pair run of hiccups() and every bhfdr() run): the peak width p, else -1.  The
     // stencil then needs no per-candidate plan look-up: step = w* - wmin, sums = box(w*) - box(p).
     int32_t single_p;
+    // Every step's first (innermost) donut box has this radius and a non-zero coefficient, else 0.  True of every plan
+    // with min(pw) >= 1: the innermost ring is min(pw) + 1 wide whatever the step.  The stencil then forms that box once
+    // per candidate and reuses it in every slot.
+    int32_t first_rho;
 };
 #define HPK_PK_RT 4
 #define HPK_PK_KT 8
