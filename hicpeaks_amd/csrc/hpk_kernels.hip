@@ -1100,13 +1100,12 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         }
     }
     HPK_CLK(ck0)
-    // The next tile's rows start moving now.  Waves 0-7 run the group prefixes after the barrier and are the first to
-    // reach it (the SIMDs favour their older waves): they issue their loads before it, the others behind it, while
-    // they would otherwise wait for the prefixes.
-    if (have_next && wave < 8) tile_load_s<BALF64>(a, rb_next, cj_next, wave, lane, nxt);
+    // The next tile's rows start moving now, from every wave.  (With 32 row groups the prefix stage behind the barrier
+    // was long and the waves not in it issued their loads there; with 16 it is short, and on the wide-band
+    // configurations - few candidates, the tile is all table building - the earlier request is worth 2 %.)
+    if (have_next) tile_load_s<BALF64>(a, rb_next, cj_next, wave, lane, nxt);
     __syncthreads();
     HPK_CLK(ck1)
-    if (have_next && wave >= 8) tile_load_s<BALF64>(a, rb_next, cj_next, wave, lane, nxt);
     // ---- exclusive prefixes over the 16 waves' row groups, per column: plain sums in wave order.  Waves 0-3: the f64
     // plane, 32 columns each; waves 4-7: the packed plane.  Lanes 0-31 walk groups 0-7 of their column, lanes 32-63 groups
     // 8-15, which start from the first half's total.  Group g parked its total in SAT row 5g + 1 and gets its base in row 5g.
