@@ -1103,9 +1103,12 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     // The next tile's rows start moving now, from every wave.  (With 32 row groups the prefix stage behind the barrier
     // was long and the waves not in it issued their loads there; with 16 it is short, and on the wide-band
     // configurations - few candidates, the tile is all table building - the earlier request is worth 2 %.)
-    if (have_next) tile_load_s<BALF64>(a, rb_next, cj_next, wave, lane, nxt);
+    if (have_next && (!BALF64 || wave < 8)) tile_load_s<BALF64>(a, rb_next, cj_next, wave, lane, nxt);
     __syncthreads();
     HPK_CLK(ck1)
+    // (f64 input: the waves that sit out the prefix stage request their rows there - thirty registers fewer to hold
+    // across the barrier)
+    if (BALF64 && have_next && wave >= 8) tile_load_s<BALF64>(a, rb_next, cj_next, wave, lane, nxt);
     // ---- exclusive prefixes over the 16 waves' row groups, per column: plain sums in wave order.  Waves 0-3: the f64
     // plane, 32 columns each; waves 4-7: the packed plane.  Lanes 0-31 walk groups 0-7 of their column, lanes 32-63 groups
     // 8-15, which start from the first half's total.  Group g parked its total in SAT row 5g + 1 and gets its base in row 5g.
@@ -1224,7 +1227,8 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         // resolve histogram by width.  The first eight widths are counted per lane, 16 bits each in two registers
         // (a lane sees at most one candidate per batch: no field overflows before 65 535 batches of this wave), and added
         // up over the wave once, after the last tile; wider ones (maxww >= min(ww) + 8) by one ballot per width.
-        {
+        // (The f64-input variants are out of registers - their prefetch holds 30 instead of 16 - and keep the ballots.)
+        if (!BALF64) {
             const unsigned off = (unsigned)(wstar - wmin_p);              // 255 - min(ww) >= 8 for "no sufficient width"
             const unsigned long long inc = 1ull << ((off & 3u) * 16u);
             hpack0 += off < 4u ? inc : 0ull;
@@ -1232,6 +1236,16 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
             if (W - wmin_p >= 8 && ballot64((off >= 8u) & (wstar != 255)) != 0ull) {
 #pragma unroll 1
                 for (int w = wmin_p + 8; w <= W; ++w) {
+                    const unsigned c = (unsigned)__popcll(ballot64(wstar == w));
+                    if (lane == w) myhist += c;
+                }
+            }
+        } else {
+            const unsigned long long mf = ballot64(wstar == wmin_p);
+            if (lane == wmin_p) myhist += (unsigned)__popcll(mf);
+            if (ballot64((wstar != wmin_p) & (wstar != 255)) != 0ull) {
+#pragma unroll 1
+                for (int w = wmin_p + 1; w <= W; ++w) {
                     const unsigned c = (unsigned)__popcll(ballot64(wstar == w));
                     if (lane == w) myhist += c;
                 }
@@ -1399,7 +1413,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     // w: the candidates whose first sufficient width is w (w above the slot's first width) or at most w (at it)
     unsigned* red = reinterpret_cast<unsigned*>(smem);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {         // the per-lane width counts, summed over the wave, into lane min(ww) + k
+    for (int k = 0; k < (BALF64 ? 0 : 8); ++k) {         // the per-lane width counts, summed over the wave, into lane min(ww) + k
         unsigned v = (unsigned)((k < 4 ? hpack0 : hpack1) >> (16 * (k & 3))) & 0xffffu;
 #pragma unroll
         for (int m = 32; m > 0; m >>= 1) v += (unsigned)__shfl_xor((int)v, m);
