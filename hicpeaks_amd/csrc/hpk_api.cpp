@@ -475,7 +475,6 @@ int launch_scoring(hpk_ctx* c, hpk_job* j, int attempt) {
         sc.emax_bits = reinterpret_cast<unsigned long long*>(small + OFF_EMAX);
         sc.nvalid = reinterpret_cast<unsigned long long*>(small + OFF_NVALID);
         sc.nsurv = d_nsurv;
-        { const char* e = std::getenv("HPK_DBG_SCORE"); sc.dbg = e ? std::atoi(e) : 0; }
         // default: the scoring kernel keeps the p-value histogram the cut is derived from (no separate pass over the
         // survivors); HPK_ROUNDS = -1: hpk_thr_hist, >= 0: exact counting rounds
         int rounds = j->rounds;

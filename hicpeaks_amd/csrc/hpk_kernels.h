@@ -112,8 +112,7 @@ struct HpkScoreArgs {
     unsigned int* hist;                 // [nsets * (HPK_NB + 1)][hbins] p-values <= sig by family and log2 bin (zeroed), or unused
     int32_t hbins;                      // bins per family of `hist`, 0 = no histogram (hpk_thr_hist / counting rounds do the cut)
     int32_t nsets_half;                 // (pw, ww) pairs of the call: the launcher sizes the histogram's LDS with it
-    int32_t dbg;                        // profiling ablation (HPK_DBG_SCORE): 1 no Poisson table read, 2 no expected table,
-                                        // 3 no survivor stores, 4 no counters
+    int32_t dbg;                        // unused (the ablation switches of round 1 cost scalar work in the hot loop)
 };
 
 struct HpkDenseArgs {
