@@ -61,6 +61,21 @@ def test_plan_single_pair_is_textbook_donut():
     assert mk[-1][:21].tolist() == [1 if 2 < rho <= 20 else 0 for rho in range(21)]
 
 
+@pytest.mark.parametrize('pw,ww,maxww', [([1, 2, 4], [3, 5, 7], 10), ([2], [5], 10), ([4], [7], 10), ([1, 2], [3, 5], 8),
+                                         ([2, 4], [5, 7], 20), ([1], [3], 6)])
+def test_innermost_box_is_shared_by_all_steps(pw, ww, maxww):
+    """What hpk_stencil_s's shared inner box rests on (HpkDevPlan::first_rho): written as box terms c_rho = m_rho - m_(rho+1),
+    every step's first term sits at radius min(pw) - no ring at or inside it ever counts, the ring just outside always does."""
+    p = _lib.make_params(_lib.MODE_HICCUPS, pw, ww, maxww, 0.05, 5000000, 10000)
+    steps, mk, mr = _lib.plan_rings(p)
+    assert steps
+    for (pi, wi), m in zip(steps, mk):
+        m = m.tolist() + [0]
+        terms = [(rho, m[rho] - m[rho + 1]) for rho in range(1, maxww + 1) if m[rho] - m[rho + 1] != 0]
+        assert terms[0][0] == min(pw) and terms[0][1] < 0, (pi, wi, terms)
+        assert sum(c for _, c in terms) == 0                    # the pixel's own value cancels (box_ky_d)
+
+
 def test_plan_rejects_bad_arguments():
     with pytest.raises(_lib.HpkError):
         _lib.plan_rings(_lib.make_params(_lib.MODE_HICCUPS, [2], [5], 21, 0.05, 2000000, 10000))
