@@ -1767,7 +1767,7 @@ __global__ void __launch_bounds__(64) hpk_etab_edge(const HpkDevPlan* __restrict
 // Persistent blocks: block b walks rows b, b + gridDim.x, ...; the per-family counters live in LDS for the block's
 // whole life and are flushed once.  Chunk boundaries sit in LDS; the chunk of E is 3 * exponent(E) plus two
 // comparisons against the reference's own boundary values.
-template <bool BH>            // BH: bhfdr (one set, per-pixel lambda = E); otherwise hiccups (lambda chunks)
+template <bool BH, bool ONE>  // BH: bhfdr (one set, per-pixel lambda = E); otherwise hiccups (lambda chunks); ONE: a single (pw, ww) pair
 __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     __shared__ unsigned int lm[2 * HPK_MAX_PAIRS][HPK_NB + 1];
     __shared__ unsigned int lf[2 * HPK_MAX_PAIRS][HPK_NB + 1];
@@ -1786,7 +1786,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     // kernel: with ~45 scalars live the compiler spilled ~80 of them to VGPR lanes, and the spill traffic
     // (v_readlane / v_writelane / s_nop) was 15 % of the instruction stream of this issue-bound kernel.
     const volatile HpkScoreArgs* ka = (const volatile HpkScoreArgs*)(const void*)__builtin_amdgcn_kernarg_segment_ptr();
-    const int npairs = plan->npairs;
+    const int npairs = ONE ? 1 : plan->npairs;
     const int W = plan->W;
     const int nsets = BH ? 1 : 2 * npairs;
     for (int i = threadIdx.x; i < nsets * (HPK_NB + 1); i += blockDim.x) { (&lm[0][0])[i] = 0u; (&lf[0][0])[i] = 0u; }
@@ -1816,55 +1816,107 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     const unsigned nunits = *a.nunits;                      // work list appended by hpk_stencil: non-empty units only
     const unsigned gw = (unsigned)((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
     const unsigned nwv = (unsigned)(((int64_t)gridDim.x * blockDim.x) >> 6);
-    uint2 un_next = (gw < nunits) ? a.units[gw] : make_uint2(0u, 0u);
-    for (unsigned u = gw; u < nunits; u += nwv) {
-        const uint2 un = un_next;
-        if (u + nwv < nunits) un_next = a.units[u + nwv];       // the next unit's entry is on its way
+    // One batch ahead.  While a batch is scored the records of the next one - of the same work unit or of the wave's
+    // next unit - are on their way, and as soon as this batch's Poisson-table reads are issued the next batch's second
+    // round of loads (IR, biases, the local-expected table entries of its first pair: all addressed from its record) is
+    // requested behind them.  A batch then waits for one memory round trip, the table's, where it used to wait for
+    // three in a row (records at the start of a unit, second round, table).
+    struct Geo { int r0, c0, cnt, i0, iend; int64_t tbase0; };
+    const int slot0 = lpair_slot[0], wi00 = lpair_wi[0];
+    const int64_t sl0 = slot0 * a.rec_stride;
+    const unsigned tstride = 2u * (unsigned)(a.D + 1);          // table offsets fit 32 bits: <= 2 * 20 * 64 * 2 * (D + 1) entries
+    unsigned ri_b = 0u, ent_b = 0u;
+    int stp_b = 0;
+    double2 s2_b = make_double2(0.0, 0.0);
+    double ir_b = 0.0, b1_b = 0.0, b2_b = 0.0, EK_b = 0.0, EY_b = 0.0;
+    auto decode = [&](const uint2 un, Geo& g) {
         const int tile = (int)un.x, ub = (int)(un.y & 255u);
-        const int cnt = (int)(un.y >> 8);
+        g.cnt = (int)(un.y >> 8);
         const int rb = tile / a.J, cj = tile - rb * a.J;
-        const int r0 = rb * a.TR, c0 = r0 + a.mw + cj * a.TC;
-        const int iend = (ub * HPK_UNIT + HPK_UNIT < cnt) ? ub * HPK_UNIT + HPK_UNIT : cnt;
-        // Dependent rounds of loads per batch: (1) entry + first slot's step and sums - requested one batch ahead (idle
-        // lanes read the tile's first record: always allocated, never used), (2) IR, biases and the local-expected
-        // table entries, all addressed from the entry, (3) the Poisson table.
-        // wave-uniform bases of the tile's record region (scalar arithmetic), 32-bit lane offsets
-        const int slot0 = lpair_slot[0];
-        const int64_t tbase0 = (int64_t)tile * a.tilecap;
-        const unsigned* __restrict__ ent_t = a.rec_ent + tbase0;
-        const uint8_t* __restrict__ recW_t = a.rec_W + tbase0;
-        const double2* __restrict__ recS_t = a.rec_S + tbase0;
-        const int64_t sl0 = slot0 * a.rec_stride;
-        unsigned ri_b = (ub * HPK_UNIT + lane < cnt) ? (unsigned)(ub * HPK_UNIT + lane) : 0u;
-        unsigned ent_b = ent_t[ri_b];
-        int stp_b = (int)(recW_t + sl0)[ri_b];
-        double2 s2_b = (recS_t + sl0)[ri_b];
-        for (int i0 = ub * HPK_UNIT; i0 < iend; i0 += 64) {
-            const bool cand = i0 + lane < cnt;
+        g.r0 = rb * a.TR;
+        g.c0 = g.r0 + a.mw + cj * a.TC;
+        g.i0 = ub * HPK_UNIT;
+        g.iend = (g.i0 + HPK_UNIT < g.cnt) ? g.i0 + HPK_UNIT : g.cnt;
+        g.tbase0 = (int64_t)tile * a.tilecap;
+    };
+    // first round: entry, first slot's step and sums (idle lanes read the tile's first record: always allocated, never used)
+    auto issue_records = [&](const Geo& g) {
+        ri_b = (g.i0 + lane < g.cnt) ? (unsigned)(g.i0 + lane) : 0u;
+        ent_b = (a.rec_ent + g.tbase0)[ri_b];
+        stp_b = (int)(a.rec_W + g.tbase0 + sl0)[ri_b];
+        s2_b = (a.rec_S + g.tbase0 + sl0)[ri_b];
+    };
+    // second round of the batch whose records are in (ent_b, stp_b); stp_b becomes the step that counts (0: none)
+    auto issue_round2 = [&](const Geo& g) {
+        const bool cn = g.i0 + lane < g.cnt;
+        const unsigned e = cn ? ent_b : 0u;
+        const int r = g.r0 + (int)((e >> 7) & 63u), c = g.c0 + (int)(e & 127u), d = c - r;
+        ir_b = a.IR[cn ? (unsigned)d : 0u];
+        b2_b = a.b2[cn ? (unsigned)c : 0u];
+        b1_b = a.b1[cn ? (unsigned)r : 0u];
+        const bool top = cn && r < W, right = cn && c >= a.n - W;
+        const double* __restrict__ tab = (top != right) ? a.eedge : a.etab;
+        const unsigned tbase = (top != right) ? (unsigned)(((top ? 0 : 1) * W + (top ? r : a.n - 1 - c)) * nsteps_u) * tstride : 0u;
+        int stp = cn ? stp_b : 0;
+        const int stepw = lstepw[stp > 0 ? stp - 1 : 0];
+        asm volatile("" : "+v"(stp));
+        stp = d >= wi00 ? stp : 0;
+        asm volatile("" : "+v"(stp));
+        stp = stepw <= frozen ? stp : 0;
+        asm volatile("" : "+v"(stp));
+        const unsigned srow = (unsigned)(stp > 1 ? stp - 1 : 0);
+        const unsigned to = tbase + srow * tstride + (cn ? (unsigned)d : 0u);
+        EK_b = tab[to];
+        EY_b = tab[to + (unsigned)(a.D + 1)];
+        stp_b = stp;
+    };
+    if (gw < nunits) {
+        Geo gn;
+        decode(a.units[gw], gn);
+        unsigned u = gw;
+        uint2 un_next = (u + nwv < nunits) ? a.units[u + nwv] : make_uint2(0u, 0u);
+        issue_records(gn);
+        // (several pairs: the batch-ahead second round costs 25 registers and a wave per SIMD - those keep it in the batch)
+        constexpr bool AHEAD2 = ONE;
+        if (AHEAD2) issue_round2(gn);
+        bool more = true;
+        while (more) {
+            if (!AHEAD2) issue_round2(gn);
+            const Geo g = gn;
+            const int i0 = g.i0;
+            const bool cand = i0 + lane < g.cnt;
             const unsigned ri = ri_b;
             unsigned ent = ent_b;
-            int slot = slot0;
-            int stp_n = stp_b;
-            double2 s2_n = s2_b;
-            if (i0 + 64 < iend) {
-                ri_b = (i0 + 64 + lane < cnt) ? (unsigned)(i0 + 64 + lane) : 0u;
-                ent_b = ent_t[ri_b];
-                stp_b = (int)(recW_t + sl0)[ri_b];
-                s2_b = (recS_t + sl0)[ri_b];
+            const int stp0 = stp_b;
+            const double2 s20 = s2_b;
+            const double ir = ir_b, b1r = b1_b, b2c = b2_b, EK0 = EK_b, EY0 = EY_b;
+            // the batch after this one: the same unit's next 64 records or the first of the wave's next unit
+            gn.i0 += 64;
+            if (gn.i0 >= gn.iend) {
+                u += nwv;
+                more = u < nunits;
+                if (more) {
+                    decode(un_next, gn);
+                    if (u + nwv < nunits) un_next = a.units[u + nwv];
+                }
             }
+            if (more) issue_records(gn);
+            const uint8_t* __restrict__ recW_t = a.rec_W + g.tbase0;
+            const double2* __restrict__ recS_t = a.rec_S + g.tbase0;
+            int slot = slot0;
+            int stp_n = 0;
+            double2 s2_n = make_double2(0.0, 0.0);
             if (!cand) ent = 0u;
-            const int r = r0 + (int)((ent >> 7) & 63u);
-            const int c = c0 + (int)(ent & 127u);
+            const int r = g.r0 + (int)((ent >> 7) & 63u);
+            const int c = g.c0 + (int)(ent & 127u);
             const int d = c - r;
             float rawpix = (float)(ent >> 13);          // the SAT holds counts capped at HPK_PK_CAP: those are re-read
             if (cand && (ent >> 13) >= HPK_PK_CAP) rawpix = ka->raw[(int64_t)r * ka->ld + d];
             const double O = (double)rawpix;
-            const double ir = a.IR[cand ? (unsigned)d : 0u], b2c = a.b2[cand ? (unsigned)c : 0u], b1r = a.b1[cand ? (unsigned)r : 0u];
             // which local-expected table serves this pixel (interior / clipped by one matrix end / both: explicit)
             const bool top = cand && r < W, right = cand && c >= a.n - W;
             const bool both = top && right;
             const double* __restrict__ tab = (top != right) ? a.eedge : a.etab;
-            const unsigned tstride = 2u * (unsigned)(a.D + 1);          // table offsets fit 32 bits: <= 2 * 20 * 64 * 2 * (D + 1) entries
             const unsigned tbase = (top != right) ? (unsigned)(((top ? 0 : 1) * W + (top ? r : a.n - 1 - c)) * nsteps_u) * tstride : 0u;
 
             const bool anyboth = __ballot(both) != 0ull;                // (both matrix ends in one window: short chromosomes only)
@@ -1873,24 +1925,28 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                 // The scalar unit is this kernel's busiest one (lane masks ANDed and ORed, exec saved and restored around
                 // every divergent if): conditions are folded into the values below - a record that does not count turns
                 // into step 0, expected sum 0, E = 0 - so that each decision is one compare feeding one select.
-                int stp = cand ? stp_n : 0;             // (idle lanes hold the tile's first record)
-                const double2 s2 = s2_n;
+                int stp = (pj == 0) ? stp0 : (cand ? stp_n : 0);       // (idle lanes hold the tile's first record)
+                const double2 s2 = (pj == 0) ? s20 : s2_n;
+                double EK = EK0, EY = EY0;
                 if (pj + 1 < npairs) {                  // next slot's record is on its way while this one is scored
                     slot = lpair_slot[pj + 1];
                     const int64_t sl = slot * a.rec_stride;
                     stp_n = (int)(recW_t + sl)[ri];
                     s2_n = (recS_t + sl)[ri];
                 }
-                // resolved at an executed step (callers.py:133-134), far enough from the diagonal (callers.py:244)
-                const int stepw = lstepw[stp > 0 ? stp - 1 : 0];
-                asm volatile("" : "+v"(stp));
-                stp = d >= wi0 ? stp : 0;
-                asm volatile("" : "+v"(stp));
-                stp = stepw <= frozen ? stp : 0;
-                asm volatile("" : "+v"(stp));
-                const unsigned srow = (unsigned)(stp > 1 ? stp - 1 : 0);
-                const unsigned to = tbase + srow * tstride + (cand ? (unsigned)d : 0u);
-                double EK = tab[to], EY = tab[to + (unsigned)(a.D + 1)];
+                if (pj != 0) {
+                    // resolved at an executed step (callers.py:133-134), far enough from the diagonal (callers.py:244)
+                    const int stepw = lstepw[stp > 0 ? stp - 1 : 0];
+                    asm volatile("" : "+v"(stp));
+                    stp = d >= wi0 ? stp : 0;
+                    asm volatile("" : "+v"(stp));
+                    stp = stepw <= frozen ? stp : 0;
+                    asm volatile("" : "+v"(stp));
+                    const unsigned srow = (unsigned)(stp > 1 ? stp - 1 : 0);
+                    const unsigned to = tbase + srow * tstride + (cand ? (unsigned)d : 0u);
+                    EK = tab[to];
+                    EY = tab[to + (unsigned)(a.D + 1)];
+                }
                 if (anyboth) {
                     const bool bo = both && stp != 0;
                     if (__ballot(bo) != 0ull) {
@@ -1907,6 +1963,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                 double p2[2] = {1.0, 1.0};
                 const int kO = (int)O;
                 if (BH) {
+                    if (AHEAD2 && more) issue_round2(gn);       // (bhfdr: one pair; the series below is all arithmetic)
                     if (eK > 0.0) {
                         chunk2[0] = 1;
                         p2[0] = poisson_sf(O, eK, const_cast<const double*>(ka->sfe));      // callers.py:536-540
@@ -1950,6 +2007,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                     if (__ballot(odd != 0u) == 0ull) {
                         p2[0] = a.ptab[at2[0]];
                         p2[1] = a.ptab[at2[1]];
+                        if (AHEAD2 && pj == 0 && more) issue_round2(gn);      // behind this batch's table reads, ahead of their use
                         p2[0] = kO < len2[0] ? p2[0] : 0.0;
                         p2[1] = kO < len2[1] ? p2[1] : 0.0;
                     } else {
@@ -1977,6 +2035,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                             }
                             if (fl == 0) { chunk2[0] = chunk; p2[0] = p; } else { chunk2[1] = chunk; p2[1] = p; }
                         }
+                        if (AHEAD2 && pj == 0 && more) issue_round2(gn);
                     }
                 }
 #pragma unroll
@@ -2406,13 +2465,13 @@ void hpk_launch_gap(const float* raw, const double* bal, const double* weight, i
 
 // Persistent grid: exactly the workgroups that are resident at once (occupancy x CUs), so that no second round of
 // workgroups pays the prologue again (measured: 0.105 -> 0.095 ms against twice as many).
-template <bool BH>
+template <bool BH, bool ONE>
 static int score_grid(int cus, size_t lds) {
     static int per_cu = 0;
     static size_t per_cu_lds = ~(size_t)0;
     if (per_cu == 0 || per_cu_lds != lds) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hpk_score<BH>, 256, lds) != hipSuccess || nb <= 0) nb = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hpk_score<BH, ONE>, 256, lds) != hipSuccess || nb <= 0) nb = 4;
         per_cu = nb; per_cu_lds = lds;
     }
     static const int gm = std::getenv("HPK_SCORE_GM") ? std::atoi(std::getenv("HPK_SCORE_GM")) : 0;
@@ -2424,8 +2483,9 @@ void hpk_launch_score(const HpkScoreArgs& a, bool bhfdr, int cus, hipStream_t st
     if (a.ntiles <= 0 || a.n <= 0) return;
     const int nsets = bhfdr ? 1 : 2 * a.nsets_half;
     const size_t lds = (size_t)nsets * (HPK_NB_TAB + 1) * (size_t)a.hbins * 4;
-    if (bhfdr) hipLaunchKernelGGL(hpk_score<true>, dim3(score_grid<true>(cus, lds)), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(hpk_score<false>, dim3(score_grid<false>(cus, lds)), dim3(256), lds, st, a);
+    if (bhfdr) hipLaunchKernelGGL((hpk_score<true, true>), dim3(score_grid<true, true>(cus, lds)), dim3(256), lds, st, a);
+    else if (a.nsets_half == 1) hipLaunchKernelGGL((hpk_score<false, true>), dim3(score_grid<false, true>(cus, lds)), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((hpk_score<false, false>), dim3(score_grid<false, false>(cus, lds)), dim3(256), lds, st, a);
 }
 
 int hpk_thr_hist_bins(int nsets) { return nsets * (HPK_NB + 1) <= 1032 ? 16 : 8; }   // LDS of hpk_thr_hist <= 83 KB
