@@ -16,12 +16,24 @@ def _lines(path):
 
 
 def _numeric_equal(got, want):
+    """The text itself: coordinates and counts identical, and every '%.3g' field the same string as the reference's -
+    except where a value sits on a rounding boundary of its third digit (the device's sums agree with the reference's
+    to ~1e-12, which can still tip such a value): those may differ by one unit of that digit, and there must be
+    next to none of them."""
     assert len(got) == len(want), (len(got), len(want))
+    fields = tipped = 0
     for g, w in zip(got, want):
         gf, wf = g.split('\t'), w.split('\t')
         assert gf[:7] == wf[:7] and gf[8:10] == wf[8:10]
         for a, b in zip(gf[7:8] + gf[10:], wf[7:8] + wf[10:]):
-            assert abs(float(a) - float(b)) <= 1e-6 + 2e-3 * abs(float(b)), (g, w)      # .3g text
+            fields += 1
+            if a == b:
+                continue
+            tipped += 1
+            fb = float(b)
+            ulp3 = 10.0 ** (np.floor(np.log10(abs(fb))) - 2) if fb != 0.0 else 0.0
+            assert abs(float(a) - fb) <= 1.01 * ulp3, (g, w)
+    assert tipped <= max(1, fields // 500), (tipped, fields)
 
 
 @pytest.mark.parametrize('name', ['hiccups_union_shallow', 'hiccups_p2w5'])
