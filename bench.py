@@ -260,6 +260,7 @@ def main():
                          'the weights: 12 B/px read instead of 4')
     ap.add_argument('--host-inputs', action='store_true',
                     help='hand the band over as host (numpy) arrays every step: the PCIe-inclusive rate of DESIGN.md, never `value`')
+    ap.add_argument('--seeds', type=int, default=3, help='bands (seeds) the passes rotate through, SURVEY 8-D2 (configurations generated on the host)')
     ap.add_argument('--stencil-only', action='store_true', help='time the stencil kernel alone (HPK_FLAG_NO_SCORE)')
     ap.add_argument('--cpu-allcores-rows', type=int, default=3000,
                     help='rows per process of the all-cores CPU baseline leg (0 = skip)')
@@ -302,16 +303,26 @@ def main():
     num = D + cfg['maxww'] + 1
     ld = (num + 63) // 64 * 64
     dev = torch.device('cuda', local)
-    if n * num <= 20_000_000:         # small enough for the host generator shared with the tests
-        raw, weight, IR, biases, num = make_band_host(cfg, seed=rank)
-        raw_d = torch.zeros((n, ld), dtype=torch.float32, device=dev)
-        raw_d[:, :num] = torch.from_numpy(raw.astype(np.float32)).to(dev)
-        w_d = torch.from_numpy(weight).to(dev)
-        ir_d = torch.from_numpy(IR).to(dev)
-        b_d = torch.from_numpy(biases).to(dev)
-    else:                             # same recipe, generated in HBM
-        raw_d, w_d, ir_d, b_d = bandgen.device_band(n, num, ld, mw, depth=cfg['depth'], nloops=cfg['nloops'], seed=rank,
-                                                    device=dev)
+    # the figure is taken over seeds 0..2 - consecutive passes rotate through the bands of --seeds seeds
+    # (one band for the configurations generated in HBM, whose single band is 0.4-2 GB)
+    small = n * num <= 20_000_000       # small enough for the host generator shared with the tests
+    nseeds = max(1, args.seeds) if small else 1
+    bands = []
+    for sd in range(nseeds):
+        if small:
+            raw, weight, IR, biases, num = make_band_host(cfg, seed=nseeds * rank + sd)
+            raw_d = torch.zeros((n, ld), dtype=torch.float32, device=dev)
+            raw_d[:, :num] = torch.from_numpy(raw.astype(np.float32)).to(dev)
+            w_d = torch.from_numpy(weight).to(dev)
+            ir_d = torch.from_numpy(IR).to(dev)
+            b_d = torch.from_numpy(biases).to(dev)
+        else:                           # same recipe, generated in HBM
+            raw_d, w_d, ir_d, b_d = bandgen.device_band(n, num, ld, mw, depth=cfg['depth'], nloops=cfg['nloops'], seed=rank,
+                                                        device=dev)
+        bands.append((raw_d, w_d, ir_d, b_d))
+    raw_d, w_d, ir_d, b_d = bands[0]
+    if args.host_inputs or args.balanced_f64:
+        nseeds = 1
     torch.cuda.synchronize()
     flags = _lib.FLAG_NO_SCORE if args.stencil_only else 0
     prm = _lib.make_params(_lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], cfg['maxww'], SIG, cfg['maxapart'], cfg['res'],
@@ -356,8 +367,9 @@ def main():
                                      balanced_ptr=bal_d.data_ptr())
         if args.host_inputs:
             return ctx.submit_host(raw_h, ir_h, b_h, b_h, p, weight=w_h)
-        return ctx.submit_device(n, num, ld, raw_d.data_ptr(), ir_d.data_ptr(), b_d.data_ptr(), b_d.data_ptr(), p,
-                                 weight_ptr=w_d.data_ptr())
+        r_, w_, i_, b_ = bands[nsub[0] % nseeds]
+        return ctx.submit_device(n, num, ld, r_.data_ptr(), i_.data_ptr(), b_.data_ptr(), b_.data_ptr(), p,
+                                 weight_ptr=w_.data_ptr())
 
     def run(k):
         pending, done = collections.deque(), []
@@ -421,7 +433,7 @@ def main():
             'unit': 'band px/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': cfg['workload'], 'name': args.config, 'band_px_per_step': px_per_step * batch,
-                       'chromosomes_per_step': batch, 'band_px_per_chromosome': px_per_step,
+                       'chromosomes_per_step': batch, 'band_px_per_chromosome': px_per_step, 'seeds': nseeds,
                        'ms_per_chromosome': ms_step / batch, 'ranks_seen': args.ranks_seen,
                        'candidates': R.ncand, 'significant_px': int(sum(s['x'].size for s in R.sets)),
                        'px_with_p_le_sig': R.nsurv_sig, 'records_copied_back': R.nsurv_cut,
