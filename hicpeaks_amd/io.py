@@ -5,6 +5,9 @@ Counterpart of the data access in scripts/pyHICCUPS:142-166: instead of two spar
 `num` calls of `H.diagonal(i)`, a source hands over the dense upper band of raw counts and the balancing weights;
 the balanced values are formed on the GPU.
 """
+import struct
+import zipfile
+
 import numpy as np
 
 from . import band as _band
@@ -26,15 +29,46 @@ class NpzSource(BandSource):
     """Archive written by `save_band_archive`: res, chroms, and per chromosome `raw_<c>` [n, num_max] + `weight_<c>`."""
 
     def __init__(self, path):
+        self.path = str(path)
         self.z = np.load(path, allow_pickle=False)
         self.binsize = int(self.z['res'])
         self.chromnames = [str(c) for c in self.z['chroms']]
+        self._zip = zipfile.ZipFile(self.path)
+
+    def _member(self, name):
+        """A member of the archive as an array.  Members stored without compression are mapped straight from the file
+        (page cache -> upload, no copy and no CRC pass: numpy's own reader moves ~0.2-0.7 GB/s, which was 5 of the 7 s
+        of a whole-genome run at 5 kb); compressed ones go through numpy."""
+        try:
+            info = self._zip.getinfo(name + '.npy')
+            if info.compress_type != zipfile.ZIP_STORED:
+                return self.z[name]
+            with open(self.path, 'rb') as f:
+                f.seek(info.header_offset)
+                hdr = f.read(30)
+                if hdr[:4] != b'PK\x03\x04':
+                    return self.z[name]
+                nlen, elen = struct.unpack('<HH', hdr[26:30])
+                f.seek(info.header_offset + 30 + nlen + elen)
+                version = np.lib.format.read_magic(f)
+                if version == (1, 0):
+                    shape, fortran, dtype = np.lib.format.read_array_header_1_0(f)
+                elif version == (2, 0):
+                    shape, fortran, dtype = np.lib.format.read_array_header_2_0(f)
+                else:
+                    return self.z[name]
+                off = f.tell()
+            if dtype.hasobject or fortran or int(np.prod(shape)) == 0:
+                return self.z[name]
+            return np.memmap(self.path, dtype=dtype, mode='r', offset=off, shape=tuple(shape), order='C')
+        except (KeyError, ValueError, OSError):
+            return self.z[name]
 
     def nbins(self, chrom):
-        return int(self.z['raw_' + chrom].shape[0])
+        return int(self._member('raw_' + chrom).shape[0])
 
     def fetch(self, chrom, num, weight_name='weight'):
-        raw = self.z['raw_' + chrom]
+        raw = self._member('raw_' + chrom)
         n = raw.shape[0]
         w = np.asarray(self.z[weight_name + '_' + chrom], dtype=np.float64)
         if raw.shape[1] == num and raw.dtype == np.float32 and raw.flags.c_contiguous:

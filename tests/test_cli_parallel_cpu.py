@@ -46,6 +46,26 @@ def test_band_archive_roundtrip(tmp_path):
     assert r.shape == (120, 40) and not r[:, 31:].any()
 
 
+@pytest.mark.parametrize('compressed', [True, False])
+def test_band_archive_members_mapped_or_read(tmp_path, compressed):
+    """Uncompressed archives are mapped member by member (no copy, no CRC pass), compressed ones read by numpy: same
+    arrays either way, and a band stored as f32 [n, num] reaches the library without a second copy."""
+    raw, w, _ = synthetic.synth_band(90, 27, depth=5.0, seed=3)
+    raw = raw.astype(np.float32)
+    path = str(tmp_path / 'a.npz')
+    io.save_band_archive(path, 5000, {'chr2': (raw, w), 'chr3': (raw[:50], w[:50])}, compressed=compressed)
+    src = io.open_source(path)
+    assert src.binsize == 5000 and src.chromnames == ['chr2', 'chr3'] and src.nbins('chr3') == 50
+    for c, rr, wwant in (('chr2', raw, w), ('chr3', raw[:50], w[:50])):
+        r, ww = src.fetch(c, 27)
+        assert r.dtype == np.float32 and r.flags.c_contiguous
+        np.testing.assert_array_equal(np.asarray(r), rr)
+        np.testing.assert_array_equal(ww, wwant)
+        assert isinstance(r, np.memmap) == (not compressed)
+    r, _ = src.fetch('chr2', 20)
+    np.testing.assert_array_equal(r, raw[:, :20])
+
+
 def test_lpt_partition_balances_hg38():
     sizes = synthetic.hg38_bins(10000)
     parts = parallel.lpt_partition(sizes, 8)
