@@ -1809,7 +1809,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     unsigned long long wbase = 0ull;
     unsigned wused = HPK_SCH;               // "no chunk yet"
     bool have_chunk = false;
-    const int region = (int)((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) % HPK_NREG);
+    const int region = __builtin_amdgcn_readfirstlane((int)((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) % HPK_NREG));
     const int64_t rbase = (int64_t)region * a.cap;      // this wave's survivor region
     // Work unit = 4 consecutive 64-record batches of one tile's record region; units are dealt round-robin to all
     // waves of the grid (tiles differ a lot in candidate count), reads are coalesced.
@@ -1821,9 +1821,10 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     // round of loads (IR, biases, the local-expected table entries of its first pair: all addressed from its record) is
     // requested behind them.  A batch then waits for one memory round trip, the table's, where it used to wait for
     // three in a row (records at the start of a unit, second round, table).
-    struct Geo { int r0, c0, cnt, i0, iend; int64_t tbase0; };
-    const int slot0 = lpair_slot[0], wi00 = lpair_wi[0];
-    const int64_t sl0 = slot0 * a.rec_stride;
+    // Several (pw, ww) pairs: a work item is one pair of one batch (pair after pair, then the unit's next batch), each
+    // reading its own slot's record - the pairs share nothing but the entry, and one stream of single-pair items keeps
+    // every item on the one-ahead schedule (a pair loop inside the batch exposed two round trips per pair).
+    struct Geo { int r0, c0, cnt, i0, iend, pj, wi0; int64_t tbase0, sl; };
     const unsigned tstride = 2u * (unsigned)(a.D + 1);          // table offsets fit 32 bits: <= 2 * 20 * 64 * 2 * (D + 1) entries
     unsigned ri_b = 0u, ent_b = 0u;
     int stp_b = 0;
@@ -1839,12 +1840,17 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
         g.iend = (g.i0 + HPK_UNIT < g.cnt) ? g.i0 + HPK_UNIT : g.cnt;
         g.tbase0 = (int64_t)tile * a.tilecap;
     };
+    auto set_pair = [&](Geo& g, const int pj) {
+        g.pj = pj;
+        g.wi0 = __builtin_amdgcn_readfirstlane(lpair_wi[pj]);
+        g.sl = (int64_t)__builtin_amdgcn_readfirstlane(lpair_slot[pj]) * a.rec_stride;
+    };
     // first round: entry, first slot's step and sums (idle lanes read the tile's first record: always allocated, never used)
     auto issue_records = [&](const Geo& g) {
         ri_b = (g.i0 + lane < g.cnt) ? (unsigned)(g.i0 + lane) : 0u;
         ent_b = (a.rec_ent + g.tbase0)[ri_b];
-        stp_b = (int)(a.rec_W + g.tbase0 + sl0)[ri_b];
-        s2_b = (a.rec_S + g.tbase0 + sl0)[ri_b];
+        stp_b = (int)(a.rec_W + g.tbase0 + g.sl)[ri_b];
+        s2_b = (a.rec_S + g.tbase0 + g.sl)[ri_b];
     };
     // second round of the batch whose records are in (ent_b, stp_b); stp_b becomes the step that counts (0: none)
     auto issue_round2 = [&](const Geo& g) {
@@ -1860,7 +1866,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
         int stp = cn ? stp_b : 0;
         const int stepw = lstepw[stp > 0 ? stp - 1 : 0];
         asm volatile("" : "+v"(stp));
-        stp = d >= wi00 ? stp : 0;
+        stp = d >= g.wi0 ? stp : 0;
         asm volatile("" : "+v"(stp));
         stp = stepw <= frozen ? stp : 0;
         asm volatile("" : "+v"(stp));
@@ -1873,39 +1879,38 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     if (gw < nunits) {
         Geo gn;
         decode(a.units[gw], gn);
+        set_pair(gn, 0);
         unsigned u = gw;
         uint2 un_next = (u + nwv < nunits) ? a.units[u + nwv] : make_uint2(0u, 0u);
         issue_records(gn);
-        // (several pairs: the batch-ahead second round costs 25 registers and a wave per SIMD - those keep it in the batch)
-        constexpr bool AHEAD2 = ONE;
-        if (AHEAD2) issue_round2(gn);
+        issue_round2(gn);
         bool more = true;
         while (more) {
-            if (!AHEAD2) issue_round2(gn);
             const Geo g = gn;
             const int i0 = g.i0;
             const bool cand = i0 + lane < g.cnt;
-            const unsigned ri = ri_b;
             unsigned ent = ent_b;
             const int stp0 = stp_b;
             const double2 s20 = s2_b;
             const double ir = ir_b, b1r = b1_b, b2c = b2_b, EK0 = EK_b, EY0 = EY_b;
             // the batch after this one: the same unit's next 64 records or the first of the wave's next unit
-            gn.i0 += 64;
-            if (gn.i0 >= gn.iend) {
-                u += nwv;
-                more = u < nunits;
-                if (more) {
-                    decode(un_next, gn);
-                    if (u + nwv < nunits) un_next = a.units[u + nwv];
+            bool next_batch = true;
+            if (!ONE) {
+                next_batch = gn.pj + 1 >= npairs;
+                set_pair(gn, next_batch ? 0 : gn.pj + 1);
+            }
+            if (next_batch) {
+                gn.i0 += 64;
+                if (gn.i0 >= gn.iend) {
+                    u += nwv;
+                    more = u < nunits;
+                    if (more) {
+                        decode(un_next, gn);
+                        if (u + nwv < nunits) un_next = a.units[u + nwv];
+                    }
                 }
             }
             if (more) issue_records(gn);
-            const uint8_t* __restrict__ recW_t = a.rec_W + g.tbase0;
-            const double2* __restrict__ recS_t = a.rec_S + g.tbase0;
-            int slot = slot0;
-            int stp_n = 0;
-            double2 s2_n = make_double2(0.0, 0.0);
             if (!cand) ent = 0u;
             const int r = g.r0 + (int)((ent >> 7) & 63u);
             const int c = g.c0 + (int)(ent & 127u);
@@ -1916,37 +1921,16 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
             // which local-expected table serves this pixel (interior / clipped by one matrix end / both: explicit)
             const bool top = cand && r < W, right = cand && c >= a.n - W;
             const bool both = top && right;
-            const double* __restrict__ tab = (top != right) ? a.eedge : a.etab;
-            const unsigned tbase = (top != right) ? (unsigned)(((top ? 0 : 1) * W + (top ? r : a.n - 1 - c)) * nsteps_u) * tstride : 0u;
 
             const bool anyboth = __ballot(both) != 0ull;                // (both matrix ends in one window: short chromosomes only)
-            for (int pj = 0; pj < npairs; ++pj) {
-                const int wi0 = lpair_wi[pj];
+            {
                 // The scalar unit is this kernel's busiest one (lane masks ANDed and ORed, exec saved and restored around
-                // every divergent if): conditions are folded into the values below - a record that does not count turns
-                // into step 0, expected sum 0, E = 0 - so that each decision is one compare feeding one select.
-                int stp = (pj == 0) ? stp0 : (cand ? stp_n : 0);       // (idle lanes hold the tile's first record)
-                const double2 s2 = (pj == 0) ? s20 : s2_n;
+                // every divergent if): conditions are folded into the values - a record that does not count turns into
+                // step 0, expected sum 0, E = 0 (issue_round2) - so that each decision is one compare feeding one select.
+                const int pj = ONE ? 0 : g.pj;
+                const int stp = stp0;                   // resolved at an executed step, far enough from the diagonal, or 0
+                const double2 s2 = s20;
                 double EK = EK0, EY = EY0;
-                if (pj + 1 < npairs) {                  // next slot's record is on its way while this one is scored
-                    slot = lpair_slot[pj + 1];
-                    const int64_t sl = slot * a.rec_stride;
-                    stp_n = (int)(recW_t + sl)[ri];
-                    s2_n = (recS_t + sl)[ri];
-                }
-                if (pj != 0) {
-                    // resolved at an executed step (callers.py:133-134), far enough from the diagonal (callers.py:244)
-                    const int stepw = lstepw[stp > 0 ? stp - 1 : 0];
-                    asm volatile("" : "+v"(stp));
-                    stp = d >= wi0 ? stp : 0;
-                    asm volatile("" : "+v"(stp));
-                    stp = stepw <= frozen ? stp : 0;
-                    asm volatile("" : "+v"(stp));
-                    const unsigned srow = (unsigned)(stp > 1 ? stp - 1 : 0);
-                    const unsigned to = tbase + srow * tstride + (cand ? (unsigned)d : 0u);
-                    EK = tab[to];
-                    EY = tab[to + (unsigned)(a.D + 1)];
-                }
                 if (anyboth) {
                     const bool bo = both && stp != 0;
                     if (__ballot(bo) != 0ull) {
@@ -1963,7 +1947,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                 double p2[2] = {1.0, 1.0};
                 const int kO = (int)O;
                 if (BH) {
-                    if (AHEAD2 && more) issue_round2(gn);       // (bhfdr: one pair; the series below is all arithmetic)
+                    if (more) issue_round2(gn);                 // (bhfdr: one pair; the series below is all arithmetic)
                     if (eK > 0.0) {
                         chunk2[0] = 1;
                         p2[0] = poisson_sf(O, eK, const_cast<const double*>(ka->sfe));      // callers.py:536-540
@@ -2007,7 +1991,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                     if (__ballot(odd != 0u) == 0ull) {
                         p2[0] = a.ptab[at2[0]];
                         p2[1] = a.ptab[at2[1]];
-                        if (AHEAD2 && pj == 0 && more) issue_round2(gn);      // behind this batch's table reads, ahead of their use
+                        if (more) issue_round2(gn);      // behind this batch's table reads, ahead of their use
                         p2[0] = kO < len2[0] ? p2[0] : 0.0;
                         p2[1] = kO < len2[1] ? p2[1] : 0.0;
                     } else {
@@ -2035,7 +2019,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                             }
                             if (fl == 0) { chunk2[0] = chunk; p2[0] = p; } else { chunk2[1] = chunk; p2[1] = p; }
                         }
-                        if (AHEAD2 && pj == 0 && more) issue_round2(gn);
+                        if (more) issue_round2(gn);
                     }
                 }
 #pragma unroll
@@ -2083,7 +2067,8 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                             have_chunk = true;
                             unsigned long long nb = 0ull;
                             if (lane == 0) nb = atomicAdd(&a.nsurv[region * HPK_REG_STRIDE], (unsigned long long)HPK_SCH);
-                            wbase = __shfl(nb, 0);
+                            wbase = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)nb) |
+                                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(nb >> 32)) << 32;
                             wused = 0u;
                         }
                         const unsigned long long basei = wbase + wused;
