@@ -96,6 +96,11 @@ struct hpk_ctx {
     DevBuf d_bounds, d_off, d_sfe, d_ptab;
     Lane lane[HPK_LANES];
     DevBuf tmpA, tmpB, tmpC, tmpD;
+    // The width the widening froze at (freeze_body) in the last chromosome collected with these parameters: the next
+    // stencil writes records up to it only (HpkStencilArgs::wguess); a chromosome that freezes later is redone in full.
+    hpk_params hint_key;
+    int hint_w = -1;
+    long long spec_reruns = 0;
 };
 
 namespace {
@@ -426,6 +431,8 @@ struct hpk_job {
     HpkStencilArgs sa;
     size_t off_rowlive = 0, off_inl = 0, head_bytes = 0, off_cnt = 0, off_cu = 0, dense_elems = 0;
     int64_t cap = 0, band_px = 0, ldo = 0;
+    size_t zero_bytes = 0;
+    hpk_params key;
     int nsets = 0, TR = 0, TC = 0, rounds = 2;
     bool sums = false, dense = false, do_score = true, phases = false, simple = false, time_stencil = true;
     double t_begin = 0.0;
@@ -518,6 +525,25 @@ int launch_scoring(hpk_ctx* c, hpk_job* j, int attempt) {
     return HPK_OK;
 }
 
+// stencil (+ the freeze decision) of a staged chromosome whose counter block is zero
+int launch_stencil_stage(hpk_ctx* c, hpk_job* j) {
+    Lane& L = c->lane[j->lane];
+    const HpkStencilArgs& sa = j->sa;
+    unsigned char* small = L.small.as<unsigned char>();
+    if (j->time_stencil) (void)hipEventRecord(L.ev[1], c->stream);
+    hpk_launch_stencil(sa, j->in.bal != nullptr, j->simple, c->stream);
+    HIPCHK(c, hipGetLastError());
+    if (j->time_stencil) (void)hipEventRecord(L.ev[2], c->stream);
+    if (!sa.ticket) {       // HPK_FREEZE_KERNEL: the decision as a kernel of its own instead of the last stencil workgroup
+        hpk_launch_freeze(sa.plan, reinterpret_cast<unsigned long long*>(small + OFF_HIST), sa.hist_part, sa.grid,
+                          reinterpret_cast<int32_t*>(small + OFF_FROZEN), reinterpret_cast<int32_t*>(small + OFF_EXEC),
+                          reinterpret_cast<int32_t*>(small + OFF_ERR), c->stream);
+        HIPCHK(c, hipGetLastError());
+    }
+    if (j->phases) (void)hipEventRecord(L.ev[3], c->stream);
+    return HPK_OK;
+}
+
 int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* prm) {
     Lane& L = c->lane[j->lane];
     hpk_params key = *prm;
@@ -597,6 +623,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     const size_t off_cu = up256(off_cnt + sizeof(unsigned) * HPK_NFAM * HPK_TIGHTEN_MAX);
     const size_t zero_bytes = (off_cu + sizeof(unsigned) * (size_t)(cap / HPK_SCH * HPK_NREG + 1) + 4095) / 4096 * 4096;
     j->off_rowlive = off_rowlive; j->off_inl = off_inl; j->head_bytes = head_bytes; j->off_cnt = off_cnt; j->off_cu = off_cu;
+    j->zero_bytes = zero_bytes; j->key = key;
     HIPCHK(c, L.small.reserve(zero_bytes));
     // expected tables of this chromosome; the same launch zero-fills the block (extra workgroups).  On the lane's side
     // stream, like the uploads and the derivation of IR / biases: for the chromosome submitted one ahead this runs beside
@@ -672,16 +699,19 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     sa.single = plan.single_p >= 0 ? 1 : 0;
     { const char* e = std::getenv("HPK_RISK_LOG2"); sa.risk = std::ldexp(1.0, e ? -std::atoi(e) : -12); }
     j->time_stencil = j->phases || !(prm->flags & HPK_FLAG_NO_STENCIL_TIMING);
-    if (j->time_stencil) (void)hipEventRecord(L.ev[1], c->stream);
     j->simple = plan.simple_reads != 0 && !std::getenv("HPK_GENERIC_SEARCH");
-    hpk_launch_stencil(sa, in.bal != nullptr, j->simple, c->stream);
-    HIPCHK(c, hipGetLastError());
-    if (j->time_stencil) (void)hipEventRecord(L.ev[2], c->stream);
-    if (!sa.ticket) {       // HPK_FREEZE_KERNEL: the decision as a kernel of its own instead of the last stencil workgroup
-        hpk_launch_freeze(sa.plan, d_hist, sa.hist_part, sa.grid, d_frozen, d_exec, d_err, c->stream);
-        HIPCHK(c, hipGetLastError());
+    // Which candidates get a record.  Dense outputs and probes want every candidate; the scoring kernel needs those
+    // resolved up to the width the widening freezes at, which the chromosome collected last with the same parameters
+    // tells within a step or so (HPK_SPEC=0: no guess, every resolved candidate; HPK_SPEC_MARGIN: widths added to it).
+    sa.wguess = 255;
+    if (j->do_score && !dense) {
+        static const bool spec = !(std::getenv("HPK_SPEC") && std::atoi(std::getenv("HPK_SPEC")) == 0);
+        static const int margin = std::getenv("HPK_SPEC_MARGIN") ? std::atoi(std::getenv("HPK_SPEC_MARGIN")) : 0;
+        sa.wguess = W;
+        if (spec && c->hint_w >= 0 && std::memcmp(&key, &c->hint_key, sizeof(key)) == 0) sa.wguess = std::min(W, c->hint_w + margin);
     }
-    if (j->phases) (void)hipEventRecord(L.ev[3], c->stream);
+    rc = launch_stencil_stage(c, j);
+    if (rc != HPK_OK) return rc;
     return launch_scoring(c, j, 0);
 }
 
@@ -701,6 +731,20 @@ int collect_impl(hpk_ctx* c, hpk_job* j, hpk_result** out) {
     const unsigned char* hsmall = static_cast<const unsigned char*>(L.h_head);
     for (int attempt = 0;; ++attempt) {
         HIPCHK(c, hipEventSynchronize(L.ev_done));       // this chromosome only; the next one keeps running
+        {   // the widening froze later than the bound the stencil wrote records up to: once more, with every resolved candidate
+            const int32_t fz = *reinterpret_cast<const int32_t*>(hsmall + OFF_FROZEN);
+            const int32_t er = *reinterpret_cast<const int32_t*>(hsmall + OFF_ERR);
+            if (do_score && er == 0 && j->sa.wguess < plan.W && fz > j->sa.wguess) {
+                j->sa.wguess = plan.W;
+                c->spec_reruns += 1;
+                HIPCHK(c, hipMemsetAsync(L.small.p, 0, j->zero_bytes, c->stream));
+                int rc = launch_stencil_stage(c, j);
+                if (rc == HPK_OK) rc = launch_scoring(c, j, 0);
+                if (rc != HPK_OK) return rc;
+                attempt = -1;
+                continue;
+            }
+        }
         unsigned long long ns = 0;              // fullest region
         for (int rg = 0; rg < HPK_NREG; ++rg)
             ns = std::max(ns, reinterpret_cast<const unsigned long long*>(hsmall + OFF_NSURV)[rg * HPK_REG_STRIDE]);
@@ -727,6 +771,7 @@ int collect_impl(hpk_ctx* c, hpk_job* j, hpk_result** out) {
     const unsigned long long* h_hist = reinterpret_cast<const unsigned long long*>(hsmall + OFF_HIST);
     const int32_t h_frozen = *reinterpret_cast<const int32_t*>(hsmall + OFF_FROZEN);
     const int32_t h_err = *reinterpret_cast<const int32_t*>(hsmall + OFF_ERR);
+    if (do_score && h_err == 0) { c->hint_w = h_frozen; c->hint_key = j->key; }      // the next stencil's record bound
     const int32_t* h_exec = reinterpret_cast<const int32_t*>(hsmall + OFF_EXEC);
     const unsigned long long h_nsurv = *reinterpret_cast<const unsigned long long*>(hsmall + OFF_NOUT);
     const unsigned long long* h_emax = reinterpret_cast<const unsigned long long*>(hsmall + OFF_EMAX);

@@ -54,6 +54,7 @@ struct HpkStencilArgs {
     int32_t grid;                       // persistent workgroups (multiple of 8, one per CU)
     int32_t single;                     // the plan is a textbook single-pair plan (HpkDevPlan::single_p >= 0)
     int32_t order;                      // tile order within an XCD's run: 0 row-major, 1 column chunks rotated per row block
+    int32_t wguess;                     // hpk_stencil_s: records only for candidates whose first sufficient width is <= wguess (255: all)
     unsigned long long* clk;            // -DHPK_PHASE_CLOCK builds: [grid][waves][8] cycle sums per phase, or nullptr
     int32_t dbg_stop;                   // profiling ablation (HPK_DBG_STOP): 1 stop after the loads, 2 after the SAT,
                                         // 4 no candidates (loads + SAT + zero stores), 5 search without box sums

@@ -936,7 +936,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
             }
             stepof[lane_k] = plan->step_of[lane_k >> 5][lane_k & 31];
             stepof[64 + lane_k] = plan->step_of[2 + (lane_k >> 5)][lane_k & 31];
-            if (lane_k < 2) tcount[lane_k] = 0u;
+            if (lane_k < 2) { tcount[lane_k] = 0u; tcount[4 + lane_k] = 0u; }     // list entries | records written, tiles alternate
         }
         for (int s = 0; s < nsteps; ++s) {
             const int k = (__builtin_amdgcn_readlane(pk0, s) >> 20) & 15;
@@ -950,6 +950,11 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     const int minr_p = __builtin_amdgcn_readfirstlane(plan->min_reads), p0_p = __builtin_amdgcn_readfirstlane(plan->reads_p0);
     const int wmin_p = __builtin_amdgcn_readfirstlane(plan->wmin);
     const int sp_p = __builtin_amdgcn_readfirstlane(plan->single_p);     // SINGLE: the peak width
+    // Records are written for candidates whose first sufficient width is at most a.wguess, packed (a tile's record i is
+    // no longer its list entry i): the widening stops at a width that only the whole chromosome's histogram decides
+    // (frozen_w, freeze_body), wider candidates and unresolved ones are dropped by the scoring kernel anyway, and the
+    // caller knows a bound from the chromosome before (hpk_api.cpp; 255 = every candidate, as the dense outputs want).
+    const int wg_p = __builtin_amdgcn_readfirstlane(a.wguess);
     const int fr_p = SINGLE ? 0 : __builtin_amdgcn_readfirstlane(plan->first_rho);   // general plans: the box every step starts with
     unsigned myhist = 0u;                 // lane w: candidates whose first sufficient width is w
     unsigned long long hpack0 = 0ull, hpack1 = 0ull;      // this lane's candidates by width min(ww) + k: 16 bits each, k = 0..3 | 4..7
@@ -1173,7 +1178,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         rs -= last ? 0u : Sp[Y * LC + xe] - Sp[(Y - 1) * LC + xe];
         if ((rs >> PK_SHIFT) != 0u) a.gap[r0 + tx] = 1;
     }
-    if (tx == 0) tcount[par ^ 1] = 0u;             // the next tile's counter (its atomics start after the barrier below)
+    if (tx == 0) { tcount[par ^ 1] = 0u; tcount[4 + (par ^ 1)] = 0u; }    // the next tile's counters (its atomics start after the barrier below)
     // ---- phase 3: batches of 64 candidates, dealt round-robin to the waves
     const int64_t tbase = (int64_t)tid * a.tilecap;
     unsigned* __restrict__ ent_t = a.rec_ent + tbase;
@@ -1189,7 +1194,6 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         const int x = (int)(id & 127u);
         const int y = (int)((id >> 7) & 63u);
         const int base = (y + W + 1) * LC + W + x;
-        if (cand) ent_t[i] = id;
         // one round of reads: P(Y, X) of both planes, the pixel's own value, the three Reads boxes that decide most
         // candidates (p0: subtracted from all, narrowest, widest), the largest corner of the widest window
         const unsigned cb = lds0 + (unsigned)base * 8u, pb = lds0 + (unsigned)(LR * LC * 8) + (unsigned)base * 4u;
@@ -1251,10 +1255,25 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
                 }
             }
         }
+        // The candidates that get a record: a batch without any is done here; the others take their (packed) places in the
+        // tile's record region from the tile's counter - one LDS atomic per batch, lane 0 (see phase 1), whose return is
+        // waited for after the box sums.
+        const bool live = cand & (wstar <= wg_p);
+        const unsigned long long lm = ballot64(live);
+        if (lm == 0ull) continue;
+        unsigned rslot = 0u;
+        {
+            const unsigned addr = (unsigned)(size_t)(tcount + 4 + par);
+            const unsigned nl = (unsigned)__popcll(lm);
+            asm volatile("s_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %1, %2\n\ts_mov_b64 exec, -1"
+                         : "=&v"(rslot) : "v"(addr), "v"(nl) : "memory");
+        }
+        wstar = live ? wstar : 255;                 // (candidates beyond the bound count as unresolved from here on)
         // general plans: the innermost box is the same in every step of every slot - formed once per candidate
         double kc0 = 0.0, yc0 = 0.0, big0 = 0.0;
         if (!SINGLE && fr_p > 0) box_ky_d(cb, fr_p, sc, kc0, yc0, big0);
         // ---- sums at the resolving step, once per slot
+        unsigned ri = 0u;
 #pragma unroll 1
         for (int q = 0; q < (SINGLE ? 1 : nslots_p); ++q) {
             int sq;
@@ -1263,7 +1282,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
                 const int wf = (q == 0) ? wf_q[0] : (q == 1) ? wf_q[1] : (q == 2) ? wf_q[2] : wf_q[3];
                 const int wq = wstar > wf ? wstar : wf;
                 sq = (int)stepof[q * 32 + (wq & 31)];
-                sq = wstar == 255 ? 0xff : sq;
+                sq = (wstar == 255) | (wq > wg_p) ? 0xff : sq;      // (a slot whose own first width lies beyond the bound)
             }
             const bool act = sq != 0xff;
             double SK = 0.0, SY = 0.0;
@@ -1366,8 +1385,14 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
                     }
                 }
             }
-            if (cand) {
-                const int64_t o = q * a.rec_stride + tbase + i;
+            if (q == 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rslot) :: "memory");
+                ri = (unsigned)__builtin_amdgcn_readfirstlane((int)rslot) +
+                     __builtin_amdgcn_mbcnt_hi((unsigned)(lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm, 0u));
+                if (live) ent_t[ri] = id;
+            }
+            if (live) {
+                const int64_t o = q * a.rec_stride + tbase + ri;
                 a.rec_S[o] = make_double2(act ? SK : 0.0, act ? SY : 0.0);
                 a.rec_W[o] = act ? (uint8_t)(sq + 1) : (uint8_t)0;
             }
@@ -1387,12 +1412,13 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
             if ((unsigned)lane < nu) a.units[off + lane] = make_uint2((unsigned)pend_tid, (unsigned)lane | (pend_c << 8));
         }
         pend_tid = -1;
-        if (total > 0) {
+        const unsigned nrec = (unsigned)__builtin_amdgcn_readfirstlane((int)tcount[4 + par]);    // records of this tile
+        if (nrec > 0u) {
             pend_tid = tid;
-            pend_c = (unsigned)total;
+            pend_c = nrec;
             if (lane == 0) pend_off = atomicAdd(a.nunits, (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT);
         }
-        if (lane == 0) { a.tile_cnt[tid] = (unsigned)total; mycand += (unsigned)total; }
+        if (lane == 0) { a.tile_cnt[tid] = nrec; mycand += (unsigned)total; }
     }
     have = have_next; rb = rb_next; cj = cj_next;
     par ^= 1;
@@ -1911,6 +1937,11 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                 }
             }
             if (more) issue_records(gn);
+            // nothing in this item counts (every record resolved beyond the width the widening froze at): next
+            if (__ballot(stp0 != 0) == 0ull) {
+                if (more) issue_round2(gn);
+                continue;
+            }
             if (!cand) ent = 0u;
             const int r = g.r0 + (int)((ent >> 7) & 63u);
             const int c = g.c0 + (int)(ent & 127u);
