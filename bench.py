@@ -437,6 +437,9 @@ def main():
                        'ms_per_chromosome': ms_step / batch, 'ranks_seen': args.ranks_seen,
                        'candidates': R.ncand, 'significant_px': int(sum(s['x'].size for s in R.sets)),
                        'px_with_p_le_sig': R.nsurv_sig, 'records_copied_back': R.nsurv_cut,
+                       # candidates resolved beyond the width the widening freezes at are dropped by the scoring kernel; the
+                       # stencil leaves their records out, bounded by the previous pass's frozen width (HPK_SPEC=0: no bound)
+                       'record_bound_w': R.record_bound, 'frozen_w': R.frozen_w, 'redone_in_full': bool(R.redone),
                        'parallelism': 'one chromosome per GPU, no collective', 'pipeline_depth': depth,
                        'sync_call_ms': float(np.median(lat)),
                        'stencil_only': bool(args.stencil_only), 'host_inputs': bool(args.host_inputs), 'balanced_f64': bool(args.balanced_f64)},

@@ -83,7 +83,7 @@ class Result(C.Structure):
                 ('dense_w', C.POINTER(C.c_uint8)), ('dense_sums', C.POINTER(C.c_double)),
                 ('ms_h2d', C.c_float), ('ms_stencil', C.c_float), ('ms_freeze', C.c_float), ('ms_score', C.c_float),
                 ('ms_tighten', C.c_float), ('ms_gap', C.c_float), ('ms_d2h', C.c_float), ('ms_host_bh', C.c_float), ('ms_total', C.c_float),
-                ('stencil_kernel', C.c_int32), ('reserved_f', C.c_float * 2), ('nsurv_sig', C.c_int64), ('nsurv_cut', C.c_int64),
+                ('stencil_kernel', C.c_int32), ('record_bound', C.c_int32), ('redone', C.c_int32), ('nsurv_sig', C.c_int64), ('nsurv_cut', C.c_int64),
                 ('stencil_tiles', C.c_int64), ('band_px', C.c_int64)]
 
 
@@ -218,6 +218,8 @@ class BandResult(object):
         self.band_px = int(r.band_px)
         self.tiles = int(r.stencil_tiles)
         self.stencil_kernel = int(r.stencil_kernel)
+        self.record_bound = int(r.record_bound)      # records for candidates resolved up to this width (255: all)
+        self.redone = bool(r.redone)                 # the bound from the previous chromosome was too narrow: computed twice
         ns = int(r.nsig)
         x, y = _arr(r.x, ns, np.int64), _arr(r.y, ns, np.int64)
         O, bal, E = _arr(r.O, ns, np.float64), _arr(r.bal, ns, np.float64), _arr(r.E, ns, np.float64)

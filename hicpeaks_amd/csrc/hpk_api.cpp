@@ -434,7 +434,7 @@ struct hpk_job {
     size_t zero_bytes = 0;
     hpk_params key;
     int nsets = 0, TR = 0, TC = 0, rounds = 2;
-    bool sums = false, dense = false, do_score = true, phases = false, simple = false, time_stencil = true;
+    bool sums = false, dense = false, do_score = true, phases = false, simple = false, time_stencil = true, redone = false;
     double t_begin = 0.0;
     ResultBox* box = nullptr;
     ~hpk_job() { delete box; }
@@ -709,6 +709,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
         static const int margin = std::getenv("HPK_SPEC_MARGIN") ? std::atoi(std::getenv("HPK_SPEC_MARGIN")) : 0;
         sa.wguess = W;
         if (spec && c->hint_w >= 0 && std::memcmp(&key, &c->hint_key, sizeof(key)) == 0) sa.wguess = std::min(W, c->hint_w + margin);
+        if (const char* e = std::getenv("HPK_SPEC_FORCE")) sa.wguess = std::min(W, std::max(0, std::atoi(e)));     // tests: a bound that is too narrow
     }
     rc = launch_stencil_stage(c, j);
     if (rc != HPK_OK) return rc;
@@ -736,6 +737,7 @@ int collect_impl(hpk_ctx* c, hpk_job* j, hpk_result** out) {
             const int32_t er = *reinterpret_cast<const int32_t*>(hsmall + OFF_ERR);
             if (do_score && er == 0 && j->sa.wguess < plan.W && fz > j->sa.wguess) {
                 j->sa.wguess = plan.W;
+                j->redone = true;
                 c->spec_reruns += 1;
                 HIPCHK(c, hipMemsetAsync(L.small.p, 0, j->zero_bytes, c->stream));
                 int rc = launch_stencil_stage(c, j);
@@ -772,6 +774,8 @@ int collect_impl(hpk_ctx* c, hpk_job* j, hpk_result** out) {
     const int32_t h_frozen = *reinterpret_cast<const int32_t*>(hsmall + OFF_FROZEN);
     const int32_t h_err = *reinterpret_cast<const int32_t*>(hsmall + OFF_ERR);
     if (do_score && h_err == 0) { c->hint_w = h_frozen; c->hint_key = j->key; }      // the next stencil's record bound
+    R.record_bound = sa.wguess;
+    R.redone = j->redone ? 1 : 0;
     const int32_t* h_exec = reinterpret_cast<const int32_t*>(hsmall + OFF_EXEC);
     const unsigned long long h_nsurv = *reinterpret_cast<const unsigned long long*>(hsmall + OFF_NOUT);
     const unsigned long long* h_emax = reinterpret_cast<const unsigned long long*>(hsmall + OFF_EMAX);

@@ -152,7 +152,10 @@ typedef struct {
     /* timing, milliseconds (HIP events on the ctx stream; wall for host parts) */
     float ms_h2d, ms_stencil, ms_freeze, ms_score, ms_tighten, ms_gap, ms_d2h, ms_host_bh, ms_total;
     int32_t stencil_kernel;    /* stencil kernel that ran: 1 = first generation, any plan; 2 = second generation, simple-Reads plans */
-    float reserved_f[2];
+    int32_t record_bound;      /* the stencil wrote records for candidates resolved up to this width (255: all of them;
+                                  HPK_FLAG_DENSE_*, HPK_FLAG_NO_SCORE); see hpk_submit_band */
+    int32_t redone;            /* 1: the widening froze beyond the bound taken from the previous chromosome and the
+                                  chromosome was computed once more with every resolved candidate */
     int64_t nsurv_sig;         /* pixels with p <= sig (before the BH cut is tightened on the device) */
     int64_t nsurv_cut;         /* of those, how many were copied back for the final Benjamini-Hochberg step */
     int64_t stencil_tiles;
@@ -178,7 +181,11 @@ void hpk_result_free(hpk_result* res);
  * on the host and hands out the result.  With one chromosome submitted ahead, the host half of chromosome i and the
  * upload of chromosome i + 1 overlap the kernels.  hpk_score_band == submit + collect.
  * Host input arrays (band->on_device == 0) must stay valid until the job is collected.  hpk_collect always
- * consumes the job, also on error.  HPK_ERR_BUSY: no free lane. */
+ * consumes the job, also on error.  HPK_ERR_BUSY: no free lane.
+ * A context remembers the width at which the widening froze (callers.py:223-229) in the chromosome it collected last
+ * for the same parameters, and the next submission's stencil writes candidate records up to that width only - wider
+ * ones are dropped by the scoring rules anyway (callers.py:133-134).  A chromosome that freezes later is noticed at
+ * collection and computed once more in full (hpk_result::redone); results never depend on the bound. */
 typedef struct hpk_job hpk_job;
 int  hpk_pipeline_depth(void);
 int  hpk_submit_band(hpk_ctx* ctx, const hpk_band* band, const hpk_params* params, hpk_job** job);

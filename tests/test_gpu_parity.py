@@ -524,3 +524,50 @@ def test_random_parameter_sets_against_oracle(ctx):
         assert not status.startswith('MISMATCH'), (status, desc, note)
         tally[status] = tally.get(status, 0) + 1
     assert tally.get('ok', 0) >= 30, tally
+
+
+def test_record_bound_from_the_previous_chromosome(monkeypatch):
+    """The stencil writes records up to a width bound taken from the chromosome collected last with the same
+    parameters (the width its widening froze at); whatever the bound, the result is the one a fresh context gives:
+    (i) no previous chromosome - every resolved candidate; (ii) the same chromosome again - records up to its own
+    frozen width; (iii) a sparser chromosome, which freezes later - detected at collection, computed once more in
+    full; (iv) a bound forced below every width (HPK_SPEC_FORCE) - likewise; (v) other parameters - no bound taken over."""
+    from hicpeaks_amd import synthetic
+    n, res, maxapart, maxww = 3000, 10000, 2000000, 10
+    num = maxapart // res + maxww + 1
+    prm = _lib.make_params(_lib.MODE_HICCUPS, [2], [5], maxww, 0.1, maxapart, res, 16, 0)
+    bands = {}
+    for name, depth in (('deep', 400.0), ('shallow', 25.0)):
+        raw, weight, _ = synthetic.synth_band(n, num, depth=depth, nloops=40, seed=21)
+        bands[name] = (raw.astype(np.float32), weight)
+    want = {}
+    for name, (raw, weight) in bands.items():
+        c0 = _lib.Context(0)
+        want[name] = c0.score_host(raw, None, None, None, prm, weight=weight)
+        assert want[name].record_bound == maxww and not want[name].redone
+        c0.close()
+    assert want['deep'].frozen_w < want['shallow'].frozen_w <= maxww, (want['deep'].frozen_w, want['shallow'].frozen_w)
+    c = _lib.Context(0)
+    try:
+        a1 = c.score_host(*bands['deep'][:1], None, None, None, prm, weight=bands['deep'][1])
+        assert a1.record_bound == maxww and not a1.redone
+        a2 = c.score_host(*bands['deep'][:1], None, None, None, prm, weight=bands['deep'][1])
+        assert a2.record_bound == want['deep'].frozen_w and not a2.redone
+        b = c.score_host(*bands['shallow'][:1], None, None, None, prm, weight=bands['shallow'][1])
+        assert b.redone and b.record_bound == maxww
+        for got, name in ((a1, 'deep'), (a2, 'deep'), (b, 'shallow')):
+            _same_result(got, want[name])
+        # two in flight: the second is submitted before the first is collected and takes the bound of the one before
+        jobs = [c.submit_host(bands[k][0], None, None, None, prm, weight=bands[k][1]) for k in ('deep', 'shallow')]
+        for j, k in zip(jobs, ('deep', 'shallow')):
+            _same_result(j.result(), want[k])
+        monkeypatch.setenv('HPK_SPEC_FORCE', '5')
+        f = c.score_host(*bands['shallow'][:1], None, None, None, prm, weight=bands['shallow'][1])
+        assert f.redone
+        _same_result(f, want['shallow'])
+        monkeypatch.delenv('HPK_SPEC_FORCE')
+        prm2 = _lib.make_params(_lib.MODE_HICCUPS, [2], [5], maxww, 0.05, maxapart, res, 16, 0)
+        o = c.score_host(*bands['deep'][:1], None, None, None, prm2, weight=bands['deep'][1])
+        assert o.record_bound == maxww and not o.redone
+    finally:
+        c.close()
