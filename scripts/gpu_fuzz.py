@@ -95,6 +95,27 @@ def one_case(seed, ctx):
             w = np.where(w > R.frozen_w, 0, w)
             if not np.array_equal(w, loc['wres'][pi]):
                 return 'MISMATCH-widths', desc, 'slot %d: %d differ' % (slot, int((w != loc['wres'][pi]).sum()))
+    # The production path once more: no dense outputs, so the stencil writes records up to a width bound only - first
+    # the width this very case froze at (taken over from the call above), then a bound forced to the narrowest width
+    # (HPK_SPEC_FORCE: the widening freezes later, the library notices and computes the case again in full).
+    for force in (None, str(mw)):
+        if force is not None:
+            os.environ['HPK_SPEC_FORCE'] = force
+        try:
+            d2 = dict()
+            if mode == 'hiccups':
+                again = callers.hiccups_band(rawf, gIR, gb, gb, chrom='T', pw=pw, ww=ww, maxww=maxww, sig=sig,
+                                             maxapart=maxapart, res=res, min_local_reads=min_reads, min_marginal_peaks=2,
+                                             onlyanchor=False, ctx=ctx, detail=d2, **(dict(balanced=cband) if inp == 'balanced' else dict(weight=weight)))
+            else:
+                again = callers.bhfdr_band(rawf, gIR, gb, gb, chrom='T', pw=pw[0], ww=ww[0], sig=sig,
+                                           maxww=maxww, maxapart=maxapart, res=res, min_marginal_peaks=2, onlyanchor=False,
+                                           ctx=ctx, detail=d2, **(dict(balanced=cband) if inp == 'balanced' else dict(weight=weight)))
+        finally:
+            os.environ.pop('HPK_SPEC_FORCE', None)
+        k2, v2 = table_arrays(again)
+        if not (np.array_equal(k2, k) and np.array_equal(v2, v)):
+            return 'MISMATCH-record-bound', desc, 'bound %s' % (force or 'own')
     return 'ok', desc, '%d pixels' % len(k)
 
 
