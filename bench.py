@@ -152,7 +152,7 @@ def run_genome(args, cfg, ctx, rank, world, local, dist):
     depth = max(1, min(args.pipeline_depth, ctx.pipeline_depth))
 
     def light(R):         # what the report needs; holding every BandResult makes Python's cyclic GC slower pass after pass
-        return (R.timing['stencil'], R.band_px, R.ncand, int(sum(s['x'].size for s in R.sets)))
+        return (R.timing['stencil'], R.band_px, R.ncand, int(sum(s['x'].size for s in R.sets)), int(R.redone), R.frozen_w)
 
     def one_pass():
         pending, done = collections.deque(), []
@@ -204,6 +204,9 @@ def run_genome(args, cfg, ctx, rank, world, local, dist):
                        'chromosomes': len(sizes), 'chromosomes_rank0': len(mine), 'pipeline_depth': depth, 'ranks_seen': args.ranks_seen,
                        'candidates_rank0': int(sum(t[2] for t in last)),
                        'significant_px_rank0': int(sum(t[3] for t in last)),
+                       # record bound = the previous chromosome's frozen width: chromosomes of the last pass
+                       # that froze later than their predecessor and were computed once more, and the widths they froze at
+                       'redone_in_full_rank0': int(sum(t[4] for t in last)), 'frozen_w_rank0': sorted(set(t[5] for t in last)),
                        'parallelism': 'chromosomes dealt largest-first to the GPUs, no collective',
                        'whole_genome_wall_ms': elapsed / args.steps * 1e3, 'host_inputs': bool(args.host_inputs)},
             'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -378,17 +381,20 @@ def main():
             if len(pending) >= depth:
                 done.append(pending.popleft().result())
                 del done[:-1]           # the report needs the kernel times (below) and one result, not K of them
+                nredone[0] += int(done[-1].redone)
                 if done[-1].timing['stencil'] > 0:
                     stencil_ms.append(done[-1].timing['stencil'])
         while pending:
             done.append(pending.popleft().result())
             del done[:-1]
+            nredone[0] += int(done[-1].redone)
             if done[-1].timing['stencil'] > 0:
                 stencil_ms.append(done[-1].timing['stencil'])
         return done
 
     batch = args.batch if args.batch > 0 else (100 if n * num <= 60_000_000 else 4)
     stencil_ms = []
+    nredone = [0]
     R = None
     run(depth)              # set-up, not a step: every lane allocates its workspaces (GBs on the large configurations) once
     for R in run(args.warmup * batch):
@@ -401,10 +407,12 @@ def main():
 
     barrier()
     del stencil_ms[:]
+    nredone[0] = 0
     t0 = time.perf_counter()
     results = run(args.steps * batch)
     barrier()
     elapsed = time.perf_counter() - t0
+    nredone_timed = nredone[0]
     assert len(stencil_ms) >= args.steps * batch // TIMED_EVERY
     stencil_ms = list(stencil_ms)
     R = results[-1]
@@ -439,7 +447,7 @@ def main():
                        'px_with_p_le_sig': R.nsurv_sig, 'records_copied_back': R.nsurv_cut,
                        # candidates resolved beyond the width the widening freezes at are dropped by the scoring kernel; the
                        # stencil leaves their records out, bounded by the previous pass's frozen width (HPK_SPEC=0: no bound)
-                       'record_bound_w': R.record_bound, 'frozen_w': R.frozen_w, 'redone_in_full': bool(R.redone),
+                       'record_bound_w': R.record_bound, 'frozen_w': R.frozen_w, 'passes_redone_in_full': nredone_timed,
                        'parallelism': 'one chromosome per GPU, no collective', 'pipeline_depth': depth,
                        'sync_call_ms': float(np.median(lat)),
                        'stencil_only': bool(args.stencil_only), 'host_inputs': bool(args.host_inputs), 'balanced_f64': bool(args.balanced_f64)},
