@@ -59,6 +59,12 @@ if copy:
         for p in sorted(glob.glob(os.path.join(out, 'bench_*.json'))):
             t = open(p).read().strip()
             if t:
+                try:            # which run of the round script the line is (file name minus "bench_")
+                    dd = json.loads(t)
+                    dd['config']['run'] = os.path.basename(p)[len('bench_'):-len('.json')]
+                    t = json.dumps(dd)
+                except Exception:
+                    pass
                 f.write(t + '\n')
     if os.path.exists(os.path.join(out, 'kernel_stats.csv')):
         shutil.copy(os.path.join(out, 'kernel_stats.csv'), os.path.join(prof, '%s_kernel_stats.csv' % tag))

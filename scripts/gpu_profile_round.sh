@@ -12,6 +12,7 @@ for c in chr1_10kb_union chr1_5kb deep_1kb wg_10kb_union wg_5kb; do
   timeout 900 python bench.py --config $c --steps 5 --warmup 1 --cpu-rows 0 2>/dev/null | tail -1 > $OUT/bench_$c.json
 done
 timeout 600 python bench.py --balanced-f64 --steps 5 --warmup 1 --cpu-rows 0 2>/dev/null | tail -1 > $OUT/bench_chr1_10kb_balanced_f64.json
+HPK_SPEC=0 timeout 600 python bench.py --cpu-rows 0 2>/dev/null | tail -1 > $OUT/bench_chr1_10kb_no_record_bound.json
 timeout 600 python bench.py --host-inputs --steps 3 --warmup 1 --batch 20 --cpu-rows 0 2>/dev/null | tail -1 > $OUT/bench_chr1_10kb_host_inputs.json
 cd /tmp && export TMPDIR=/tmp
 PB="--steps 2 --warmup 1 --batch 10 --cpu-rows 0"
