@@ -94,7 +94,8 @@ def build(force=False, quiet=True):
         newest = max(os.path.getmtime(s) for s in srcs)
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
-    out = subprocess.run(['make', '-C', CSRC], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    # force: -B, make's own time stamps must not answer "does it build" either
+    out = subprocess.run(['make'] + (['-B'] if force else []) + ['-C', CSRC], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if out.returncode != 0:
         raise RuntimeError('building libhpk.so failed:\n' + out.stdout)
     if not quiet:
