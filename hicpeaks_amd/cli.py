@@ -58,7 +58,7 @@ def _hiccups_parser():
     g2.add_argument('--clr-weight-name', default='weight', help='Name of the weight column.')
     g2.add_argument('--use-raw', action='store_true', help='Sort peak pixels by raw signals during local clustering.')
     g2.add_argument('--min-marginal-peaks', type=int, default=2, help='Minimum marginal number of peaks of an anchor.')
-    g2.add_argument('--min-local-reads', type=int, default=16, help='Minimum sum of contacts in the vicinity of a loop (at most 1023).')
+    g2.add_argument('--min-local-reads', type=int, default=16, help='Minimum sum of contacts in the vicinity of a loop (at most 2097151 // (2 maxww + 1)**2: 4755 at --maxww 10).')
     g2.add_argument('--only-anchors', action='store_true', help='Either of the peak loci must be an anchor.')
     g2.add_argument('--maxapart', type=int, default=10000000, help='Maximum genomic distance between two loci.')
     g2.add_argument('--nproc', type=int, default=1, help='Number of worker processes (one per GPU; clamped to the GPUs present).')

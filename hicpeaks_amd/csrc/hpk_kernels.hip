@@ -42,7 +42,7 @@ constexpr int LR = HPK_LR;
 //   bits 21..31  number of cells with a non-zero balanced value (a box holds < 2^11 of them).
 // Sums wrap mod 2^32, box differences are exact in both fields.  Sizes: 80 KiB + 40 KiB; the rest of the LDS holds
 // the per-wave candidate lists.
-constexpr unsigned PK_SHIFT = 21u, PK_MASK = (1u << PK_SHIFT) - 1u;
+constexpr unsigned PK_SHIFT = HPK_PK_BITS, PK_MASK = (1u << PK_SHIFT) - 1u;
 static_assert((2 * HPK_MAX_W + 1) * (2 * HPK_MAX_W + 1) * HPK_PK_CAP < (1u << PK_SHIFT), "capped raw box sum must fit its field");
 static_assert((2 * HPK_MAX_W + 1) * (2 * HPK_MAX_W + 1) < (1u << (32 - PK_SHIFT)), "valid count of a box must fit its field");
 struct Sat {
@@ -50,8 +50,8 @@ struct Sat {
     unsigned* p;        // capped raw | valid << 21
     unsigned* l;        // candidate lists: HPK_LISTCAP entries per wave
 };
-__device__ __forceinline__ unsigned pack_cell(unsigned ru, bool valid) {
-    return (ru < HPK_PK_CAP ? ru : HPK_PK_CAP) | (valid ? 1u << PK_SHIFT : 0u);
+__device__ __forceinline__ unsigned pack_cell(unsigned ru, bool valid, unsigned cap) {
+    return (ru < cap ? ru : cap) | (valid ? 1u << PK_SHIFT : 0u);
 }
 
 // ------------------------------------------------------------------ wave64 DPP scan (gfx9 DPP controls)
@@ -303,6 +303,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
     // stores.  (Keeping it in LDS instead was measured 5 % slower.)
     const HpkDevPlan* __restrict__ plan = a.plan;
     const int nsteps = plan->nsteps, nslots = plan->nslots, min_reads = plan->min_reads;
+    const unsigned pkcap_p = (unsigned)__builtin_amdgcn_readfirstlane(plan->pk_cap);
     int pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, pk6 = 0;
     if (lane < nsteps) {
         const uint32_t* pk = plan->packed[lane];
@@ -368,7 +369,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
             if (BALF64) { bv = nxt.bal[j][e]; bv = (bv == bv) ? bv : 0.0; }
             else if (k >= mw) bv = balanced_of(rv, nxt.wrow[BALF64 ? 0 : j], nxt.wc[e]);
             balv[j][e] = bv;
-            pkv[j][e] = pack_cell((unsigned)rv, bv != 0.0);
+            pkv[j][e] = pack_cell((unsigned)rv, bv != 0.0, pkcap_p);
             tc[e] += bv;
             tp[e] += pkv[j][e];
         }
@@ -955,6 +956,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     // (frozen_w, freeze_body), wider candidates and unresolved ones are dropped by the scoring kernel anyway, and the
     // caller knows a bound from the chromosome before (hpk_api.cpp; 255 = every candidate, as the dense outputs want).
     const int wg_p = __builtin_amdgcn_readfirstlane(a.wguess);
+    const unsigned pkcap_p = (unsigned)__builtin_amdgcn_readfirstlane(plan->pk_cap);
     const int fr_p = SINGLE ? 0 : __builtin_amdgcn_readfirstlane(plan->first_rho);   // general plans: the box every step starts with
     unsigned myhist = 0u;                 // lane w: candidates whose first sufficient width is w
     unsigned long long hpack0 = 0ull, hpack1 = 0ull;      // this lane's candidates by width min(ww) + k: 16 bits each, k = 0..3 | 4..7
@@ -1046,7 +1048,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
             float rv = nxt.raw[j][e];
             const int km = kl - e - Y - mw;                               // diagonal - min(ww)
             const unsigned ru = (unsigned)rv;
-            const unsigned rc = ru < HPK_PK_CAP ? ru : HPK_PK_CAP;
+            const unsigned rc = ru < pkcap_p ? ru : pkcap_p;
             if (BALF64) {
                 bv[e] = fmax(nxt.bal[j][e], 0.0);                        // NaN -> 0 (counts x weights: never negative)
             } else {
@@ -1830,6 +1832,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     const int lane = threadIdx.x & 63;
     const int nsteps_u = plan->nsteps;
     const int frozen = *const_cast<const int32_t*>(ka->frozen);
+    const unsigned pkcap = (unsigned)plan->pk_cap;
     // Survivor slots are reserved from the global counter HPK_SCH records at a time per wave (same-address atomics
     // run at ~90 per microsecond device-wide); how many slots of a chunk were filled goes to chunk_used[].
     unsigned long long wbase = 0ull;
@@ -1947,7 +1950,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
             const int c = g.c0 + (int)(ent & 127u);
             const int d = c - r;
             float rawpix = (float)(ent >> 13);          // the SAT holds counts capped at HPK_PK_CAP: those are re-read
-            if (cand && (ent >> 13) >= HPK_PK_CAP) rawpix = ka->raw[(int64_t)r * ka->ld + d];
+            if (cand && (ent >> 13) >= pkcap) rawpix = ka->raw[(int64_t)r * ka->ld + d];
             const double O = (double)rawpix;
             // which local-expected table serves this pixel (interior / clipped by one matrix end / both: explicit)
             const bool top = cand && r < W, right = cand && c >= a.n - W;

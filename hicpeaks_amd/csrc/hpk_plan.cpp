@@ -52,10 +52,15 @@ int hpk_build_plan(const hpk_params* prm, HpkDevPlan* plan, char* msg) {
     plan->maxw = maxw;
     plan->D = (int32_t)(prm->maxapart / prm->res);
     plan->min_reads = (prm->mode == HPK_MODE_BHFDR) ? 16 : prm->min_local_reads;   // callers.py:490
-    if (plan->min_reads > (int32_t)HPK_PK_CAP) {
-        std::snprintf(msg, 256, "min_local_reads = %d: the stencil compares Reads on counts capped at %u, larger thresholds are not supported",
-                      plan->min_reads, HPK_PK_CAP);
-        return HPK_ERR_INVALID;
+    plan->pk_cap = std::max<int32_t>((int32_t)HPK_PK_CAP, plan->min_reads);
+    {   // a box of (2 maxww + 1)^2 capped counts must fit the packed plane's field
+        const int64_t cells = (int64_t)(2 * W + 1) * (2 * W + 1);
+        const int64_t most = ((int64_t)1 << HPK_PK_BITS) - 1;
+        if (plan->min_reads < 0 || cells * plan->pk_cap > most) {
+            std::snprintf(msg, 256, "min_local_reads = %d with maxww = %d: the stencil sums capped counts in %d bits, at most %lld is supported at this maxww",
+                          plan->min_reads, W, HPK_PK_BITS, (long long)(most / cells));
+            return HPK_ERR_INVALID;
+        }
     }
     plan->npairs = prm->npairs;
 

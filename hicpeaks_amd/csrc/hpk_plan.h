@@ -8,7 +8,8 @@
 #define HPK_KSLOTS 4            // distinct peak widths the stencil kernel keeps in registers
 #define HPK_NB     128          // lambda-chunk boundaries 2^((i-1)/3), i = 1..HPK_NB
 #define HPK_NB_TAB 46           // chunks served from the device-built Poisson table (rv <= 2^15)
-#define HPK_PK_CAP 1023u        // raw counts enter the stencil's packed SAT plane capped here: min_local_reads may not exceed it
+#define HPK_PK_CAP 1023u        // raw counts enter the stencil's packed SAT plane capped at max(this, min_local_reads): HpkDevPlan::pk_cap
+#define HPK_PK_BITS 21          // width of the capped-count field of the packed plane: a box of (2 maxww + 1)^2 capped cells must fit
 
 struct HpkDevStep {
     int32_t slot;               // output slot = index of pi among the distinct peak widths
@@ -63,6 +64,9 @@ struct HpkDevPlan {
     // with min(pw) >= 1: the innermost ring is min(pw) + 1 wide whatever the step.  The stencil then forms that box once
     // per candidate and reuses it in every slot.
     int32_t first_rho;
+    // Counts enter the packed plane (and the record entries) capped here: max(HPK_PK_CAP, min_reads).  Only
+    // Reads >= min_reads is ever asked of them, and a cell capped at or above the threshold decides that like the true count.
+    int32_t pk_cap;
 };
 #define HPK_PK_RT 4
 #define HPK_PK_KT 8

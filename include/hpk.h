@@ -72,7 +72,9 @@ typedef struct {
     int32_t pw[HPK_MAX_PAIRS];
     int32_t ww[HPK_MAX_PAIRS];
     int32_t maxww;
-    int32_t min_local_reads;   /* <= 1023: the stencil compares Reads on counts capped there (exact for any such threshold);
+    int32_t min_local_reads;   /* the stencil compares Reads on counts capped at max(1023, this) (exact for the threshold) and
+                                  sums a box of them in 21 bits: at most (2^21 - 1) / (2 maxww + 1)^2, i.e. 4755 at maxww = 10,
+                                  1247 at maxww = 20;
                                   larger values return HPK_ERR_INVALID.  The reference's defaults are 25 / 16 */
     int64_t maxapart;
     int64_t res;

@@ -389,16 +389,18 @@ def test_submit_collect_matches_synchronous_call(ctx):
     _same_result(a.result(), sync[0])
 
 
-@pytest.mark.parametrize('depth,min_reads', [(30000.0, 16), (3000.0, 900), (3000.0, 1023)])
+@pytest.mark.parametrize('depth,min_reads', [(30000.0, 16), (3000.0, 900), (3000.0, 1023), (3000.0, 1024), (30000.0, 4000),
+                                             (30000.0, 4755)])
 def test_deep_counts_beyond_the_sat_cap(depth, min_reads, ctx):
-    """Counts far above HPK_PK_CAP = 1023 (the stencil's packed SAT plane holds capped counts): the widening decisions,
-    the sums, O and the final table still equal the oracle's, also with a threshold close to the cap; a threshold above
-    the cap is refused."""
+    """Counts far above HPK_PK_CAP = 1023 (the stencil's packed SAT plane holds counts capped at max(1023,
+    min_local_reads)): the widening decisions, the sums, O and the final table still equal the oracle's, also with a
+    threshold close to, at and above 1023, up to the largest one whose box of capped counts fits the plane's 21 bits at
+    maxww = 10 (4755); the next one is refused."""
     from hicpeaks_amd import synthetic
     n, res, maxapart, maxww = 700, 10000, 900000, 10
     num = maxapart // res + maxww + 1
     raw, weight, _ = synthetic.synth_band(n, num, depth=depth, nloops=12, seed=7)
-    assert (raw > 1023).sum() > 500
+    assert (raw > max(1023, min_reads)).sum() > 500
     pw, ww, sig = [2], [5], 0.05
     IR, cband, biases = orc.prep_from_band(raw, weight, min(ww))
     loc = orc.hiccups_local_sums(raw, cband, IR, n, num, pw, ww, maxww, maxapart, res, min_reads)
@@ -421,7 +423,7 @@ def test_deep_counts_beyond_the_sat_cap(depth, min_reads, ctx):
         np.testing.assert_allclose(v, vw, rtol=1e-9, atol=1e-9)
     with pytest.raises(_lib.HpkError):
         callers.hiccups_band(raw.astype(np.float32), IR, biases, biases, chrom='T', weight=weight, pw=pw, ww=ww,
-                             maxww=maxww, sig=sig, maxapart=maxapart, res=res, min_local_reads=1024, ctx=ctx)
+                             maxww=maxww, sig=sig, maxapart=maxapart, res=res, min_local_reads=4756, ctx=ctx)
 
 
 @pytest.mark.parametrize('maxww,pw,ww', [(3, [1], [3]), (5, [2], [4]), (6, [1, 2], [3, 5]), (7, [2], [5])])
