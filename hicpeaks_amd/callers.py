@@ -153,6 +153,9 @@ def hiccups_band_submit(raw, IR, B1, B2, chrom='', balanced=None, weight=None, p
 
     def finish(R):
         logger.info('Chrom:{0}, Observed Contact Number: {1}'.format(chrom, R.ncand))
+        if R.redone:
+            logger.info('Chrom:{0}, widening froze at {1}, beyond the width bound taken from the previous chromosome: '
+                        'computed once more in full'.format(chrom, R.frozen_w))
         npairs = prm.npairs
         final, table = _finish_hiccups(R, n, chrom, pw[:npairs], ww[:npairs], sig, sumq, double_fold,
                                        single_fold, res, use_raw, min_marginal_peaks, onlyanchor)
@@ -205,6 +208,9 @@ def bhfdr_band_submit(raw, IR, B1, B2, chrom='', balanced=None, weight=None, pw=
 
     def finish(R):
         logger.info('Chrom:{0}, Observed Contact Number: {1}'.format(chrom, R.ncand))
+        if R.redone:
+            logger.info('Chrom:{0}, widening froze at {1}, beyond the width bound taken from the previous chromosome: '
+                        'computed once more in full'.format(chrom, R.frozen_w))
         s = R.sets[0]
         logger.info('Chrom:{0}, Number of Poisson Models: {1}'.format(chrom, s['nvalid']))
         if s['nvalid'] == 0:
