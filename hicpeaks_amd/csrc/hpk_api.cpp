@@ -471,6 +471,10 @@ int launch_scoring(hpk_ctx* c, hpk_job* j, int attempt) {
         sc.raw = j->in.raw; sc.bal = j->in.bal; sc.weight = j->in.weight; sc.plan = sa.plan;
         sc.etab = L.etab.as<double>(); sc.eedge = L.eedge.as<double>(); sc.IR = j->in.IR; sc.b1 = j->in.b1; sc.b2 = j->in.b2;
         sc.frozen = reinterpret_cast<int32_t*>(small + OFF_FROZEN);
+        sc.hist_acc = sa.hist_acc;
+        sc.hist_out = reinterpret_cast<unsigned long long*>(small + OFF_HIST);
+        sc.executed = reinterpret_cast<int32_t*>(small + OFF_EXEC);
+        sc.err = reinterpret_cast<int32_t*>(small + OFF_ERR);
         sc.bounds = c->d_bounds.as<double>(); sc.ptab = c->d_ptab.as<double>();
         sc.ptab_off = c->d_off.as<int32_t>(); sc.sfe = c->d_sfe.as<double>(); sc.sig = j->prm.sig;
         sc.n = j->n; sc.num = j->num; sc.ld = j->ld; sc.ldo = j->ldo; sc.mw = plan.mw; sc.D = plan.D;
@@ -534,7 +538,14 @@ int launch_stencil_stage(hpk_ctx* c, hpk_job* j) {
     hpk_launch_stencil(sa, j->in.bal != nullptr, j->simple, c->stream);
     HIPCHK(c, hipGetLastError());
     if (j->time_stencil) (void)hipEventRecord(L.ev[2], c->stream);
-    if (!sa.ticket) {       // HPK_FREEZE_KERNEL: the decision as a kernel of its own instead of the last stencil workgroup
+    if (sa.hist_acc) {      // totals: the scoring kernel decides in its prologue; without scoring, a one-workgroup kernel
+        if (!j->do_score) {
+            hpk_launch_freeze_tot(sa.plan, sa.hist_acc, reinterpret_cast<unsigned long long*>(small + OFF_HIST),
+                                  reinterpret_cast<int32_t*>(small + OFF_FROZEN), reinterpret_cast<int32_t*>(small + OFF_EXEC),
+                                  reinterpret_cast<int32_t*>(small + OFF_ERR), c->stream);
+            HIPCHK(c, hipGetLastError());
+        }
+    } else if (!sa.ticket) {       // HPK_FREEZE_KERNEL: the decision as a kernel of its own instead of the last stencil workgroup
         hpk_launch_freeze(sa.plan, reinterpret_cast<unsigned long long*>(small + OFF_HIST), sa.hist_part, sa.grid,
                           reinterpret_cast<int32_t*>(small + OFF_FROZEN), reinterpret_cast<int32_t*>(small + OFF_EXEC),
                           reinterpret_cast<int32_t*>(small + OFF_ERR), c->stream);
@@ -695,6 +706,15 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
     }
 #endif
     sa.ticket = std::getenv("HPK_FREEZE_KERNEL") ? nullptr : reinterpret_cast<unsigned*>(small + OFF_NUNITS + 4);
+    // default: the workgroups add their resolve counts into totals (the zeroed partial-count area, one word per 128 bytes)
+    // and the freeze decision is replayed where it is needed; HPK_FREEZE_TICKET=1: by the stencil's last workgroup as before
+    sa.hist_acc = nullptr;
+    const char* ft = std::getenv("HPK_FREEZE_TICKET");
+    if (!(ft && std::atoi(ft) != 0) && !std::getenv("HPK_FREEZE_KERNEL") &&
+        sizeof(unsigned) * (size_t)grid_ * (HPK_MAX_STEPS + 1) >= 8 * (size_t)(HPK_MAX_STEPS + 1) * HPK_ACC_STRIDE) {
+        sa.hist_acc = reinterpret_cast<unsigned long long*>(small + off_hp);
+        sa.ticket = nullptr;
+    }
     sa.frozen = d_frozen; sa.executed = d_exec; sa.err = d_err;
     sa.single = plan.single_p >= 0 ? 1 : 0;
     { const char* e = std::getenv("HPK_RISK_LOG2"); sa.risk = std::ldexp(1.0, e ? -std::atoi(e) : -12); }

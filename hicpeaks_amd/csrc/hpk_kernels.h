@@ -12,6 +12,7 @@
 #define HPK_SCH 64                      // survivor slots a scoring wave reserves at a time (one batch always fits)
 #define HPK_SCH_LOG2 6
 #define HPK_HIST_NCAND HPK_MAX_STEPS    // hist[HPK_MAX_STEPS] counts the candidates
+#define HPK_ACC_STRIDE 16                // u64 words between the chromosome's resolve totals (HpkStencilArgs::hist_acc): one per 128 bytes
 #ifndef HPK_NWAVES
 #define HPK_NWAVES 16                   // waves per stencil workgroup (16 or 8)
 #endif
@@ -40,6 +41,7 @@ struct HpkStencilArgs {
     uint8_t* gap;                       // [n] preset to 0; set for rows with a non-zero balanced value (gap = !flag)
     unsigned long long* hist;           // [HPK_MAX_STEPS + 1] totals, written by hpk_freeze
     unsigned* hist_part;                // [grid][HPK_MAX_STEPS + 1] per-workgroup resolve counts, [..][HPK_MAX_STEPS] = candidates
+    unsigned long long* hist_acc;       // or (scoring follows): [(HPK_MAX_STEPS + 1) * HPK_ACC_STRIDE] zeroed totals the workgroups add to
     unsigned* ticket;                   // zeroed; the workgroup that draws grid - 1 runs the freeze (nullptr: hpk_freeze follows)
     int32_t* frozen;                    // outputs of the freeze: frozen_w, executed[nsteps], first empty step + 1 or 0
     int32_t* executed;
@@ -92,7 +94,11 @@ struct HpkScoreArgs {
     const double* IR;
     const double* b1;
     const double* b2;
-    const int32_t* frozen;              // device scalar written by the freeze kernel
+    int32_t* frozen;                    // device scalar: written by the freeze kernel, or by this kernel's first workgroup (hist_acc)
+    const unsigned long long* hist_acc; // the stencil's resolve totals: every workgroup replays the freeze decision on them (nullptr: read `frozen`)
+    unsigned long long* hist_out;       // with hist_acc: totals, executed flags and error for the host, written by the first workgroup
+    int32_t* executed;
+    int32_t* err;
     const double* bounds;               // [HPK_NB] chunk upper bounds
     const double* ptab;                 // Poisson survival table
     const int32_t* ptab_off;            // [HPK_NB_TAB + 2]
@@ -138,6 +144,8 @@ void hpk_launch_stencil(const HpkStencilArgs& a, bool balf64, bool simple, hipSt
 bool hpk_stencil_s_applies(const HpkStencilArgs& a, bool simple);   // the second-generation kernel takes this launch
 void hpk_launch_dense(const HpkDenseArgs& a, hipStream_t st);
 void hpk_launch_probe(const HpkDenseArgs& a, const int32_t* rows, const int32_t* cols, int64_t count, double* out, hipStream_t st);
+void hpk_launch_freeze_tot(const HpkDevPlan* plan, const unsigned long long* hist_acc, unsigned long long* hist,
+                           int32_t* frozen, int32_t* executed, int32_t* err, hipStream_t st);
 void hpk_launch_freeze(const HpkDevPlan* plan, unsigned long long* hist, const unsigned* hist_part, int nparts,
                        int32_t* frozen, int32_t* executed, int32_t* err, hipStream_t st);
 void hpk_launch_prep(const float* raw, const double* weight, int n, int num, int64_t ld, int mw, double* psum, unsigned* pnan,

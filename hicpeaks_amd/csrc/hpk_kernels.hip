@@ -683,7 +683,8 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
     if (threadIdx.x <= HPK_MAX_STEPS) {
         unsigned tot = 0u;
         for (int w2 = 0; w2 < NW; ++w2) tot += red[w2 * (HPK_MAX_STEPS + 1) + threadIdx.x];
-        a.hist_part[(int64_t)blockIdx.x * (HPK_MAX_STEPS + 1) + threadIdx.x] = tot;
+        if (a.hist_acc) { if (tot) atomicAdd(&a.hist_acc[threadIdx.x * HPK_ACC_STRIDE], (unsigned long long)tot); }
+        else a.hist_part[(int64_t)blockIdx.x * (HPK_MAX_STEPS + 1) + threadIdx.x] = tot;
     }
     freeze_by_last_workgroup(a, smem + 8192);
 }
@@ -1466,7 +1467,10 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
             if (st.wi > wf) out = hw[st.wi];
             else for (int w = 0; w <= wf && w < 64; ++w) out += hw[w];
         } else if (threadIdx.x == HPK_MAX_STEPS) out = red[NW * 64];
-        a.hist_part[(int64_t)blockIdx.x * (HPK_MAX_STEPS + 1) + threadIdx.x] = out;
+        // (scoring follows: the counts go straight into the chromosome's totals - one word per cache line, 256 adds each -
+        // and every scoring workgroup replays the freeze decision on them; no ticket, no fences, no tail in this kernel)
+        if (a.hist_acc) { if (out) atomicAdd(&a.hist_acc[threadIdx.x * HPK_ACC_STRIDE], (unsigned long long)out); }
+        else a.hist_part[(int64_t)blockIdx.x * (HPK_MAX_STEPS + 1) + threadIdx.x] = out;
     }
     freeze_by_last_workgroup(a, smem + 8192);
 }
@@ -1530,6 +1534,8 @@ __global__ void __launch_bounds__(256) hpk_ir_final(const double* __restrict__ p
 }
 // ------------------------------------------------------------------ local-expected tables (callers.py:66-72 + 175-198)
 // ------------------------------------------------------------------ freeze
+__device__ __forceinline__ void freeze_replay(const HpkDevPlan* __restrict__ plan, const unsigned long long* hist, const int* swi,
+                                              const int* sslot, int32_t* executed, int& fw_out, int& err_out);
 // Column sums of the per-workgroup resolve histograms, then one thread replays the reference's frozen_w / break logic
 // on the totals (callers.py:208-229, 505-511).  1024 threads; `lds` = scratch of >= 1.1 KiB.
 __device__ __forceinline__ void freeze_body(const HpkDevPlan* __restrict__ plan, const unsigned* __restrict__ hist_part, int nparts,
@@ -1553,6 +1559,15 @@ __device__ __forceinline__ void freeze_body(const HpkDevPlan* __restrict__ plan,
     __syncthreads();
     if (threadIdx.x <= HPK_MAX_STEPS) hist_out[threadIdx.x] = hist[threadIdx.x];
     if (threadIdx.x != 0) return;
+    int fw, e;
+    freeze_replay(plan, hist, swi, sslot, executed, fw, e);
+    *frozen = fw;
+    *err = e;
+}
+// The reference's frozen_w / break logic on the chromosome's totals (callers.py:208-229, 505-511), one thread.
+// hist[s] = candidates resolved at step s, hist[HPK_HIST_NCAND] = all candidates; executed may be nullptr.
+__device__ __forceinline__ void freeze_replay(const HpkDevPlan* __restrict__ plan, const unsigned long long* hist, const int* swi,
+                                              const int* sslot, int32_t* executed, int& fw_out, int& err_out) {
     const long long total = (long long)hist[HPK_HIST_NCAND];
     long long unres[HPK_KSLOTS];
     for (int q = 0; q < HPK_KSLOTS; ++q) unres[q] = total;
@@ -1562,8 +1577,8 @@ __device__ __forceinline__ void freeze_body(const HpkDevPlan* __restrict__ plan,
     const bool bh = plan->mode == HPK_MODE_BHFDR;
     for (int s = 0; s < nsteps; ++s) {
         struct { int wi, slot; } st = {swi[s], sslot[s]};
-        if (st.wi > fw) { executed[s] = 0; continue; }                 // callers.py:133-134 / break at 505-511
-        executed[s] = 1;
+        if (st.wi > fw) { if (executed) executed[s] = 0; continue; }   // callers.py:133-134 / break at 505-511
+        if (executed) executed[s] = 1;
         const long long before = unres[st.slot];
         if (before == 0 && e == 0) e = s + 1;                           // the reference raises here
         const long long now = (long long)hist[s];
@@ -1573,14 +1588,29 @@ __device__ __forceinline__ void freeze_body(const HpkDevPlan* __restrict__ plan,
         const bool widest = bh || (st.wi >= maxw);
         if (widest && (vr < 0.3 || lr < 0.03)) fw = st.wi;              // callers.py:223-229
     }
-    *frozen = fw;
-    *err = e;
+    fw_out = fw;
+    err_out = e;
 }
 __global__ void __launch_bounds__(1024) hpk_freeze(const HpkDevPlan* __restrict__ plan, const unsigned* __restrict__ hist_part,
                                                    int nparts, unsigned long long* __restrict__ hist_out,
                                                    int32_t* frozen, int32_t* executed, int32_t* err) {
     __shared__ unsigned long long lds[HPK_MAX_STEPS + 1 + HPK_MAX_STEPS];
     freeze_body(plan, hist_part, nparts, hist_out, frozen, executed, err, lds);
+}
+// The same on totals the stencil workgroups added up themselves (HpkStencilArgs::hist_acc), for launches that no scoring follows.
+__global__ void __launch_bounds__(128) hpk_freeze_tot(const HpkDevPlan* __restrict__ plan, const unsigned long long* __restrict__ acc,
+                                                      unsigned long long* __restrict__ hist_out, int32_t* frozen, int32_t* executed,
+                                                      int32_t* err) {
+    __shared__ unsigned long long hist[HPK_MAX_STEPS + 1];
+    __shared__ int swi[HPK_MAX_STEPS], sslot[HPK_MAX_STEPS];
+    if ((int)threadIdx.x < plan->nsteps) { swi[threadIdx.x] = plan->steps[threadIdx.x].wi; sslot[threadIdx.x] = plan->steps[threadIdx.x].slot; }
+    if (threadIdx.x <= HPK_MAX_STEPS) { hist[threadIdx.x] = acc[threadIdx.x * HPK_ACC_STRIDE]; hist_out[threadIdx.x] = hist[threadIdx.x]; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    int fw, e;
+    freeze_replay(plan, hist, swi, sslot, executed, fw, e);
+    *frozen = fw;
+    *err = e;
 }
 // The freeze decision needs the histograms of every stencil workgroup.  Instead of a kernel of its own (~10 us of an
 // otherwise idle GPU between the stencil and the scoring kernel) the stencil workgroup that finishes last takes it:
@@ -1827,11 +1857,32 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     if (threadIdx.x < HPK_MAX_STEPS) lstepw[threadIdx.x] = (threadIdx.x < plan->nsteps) ? plan->steps[threadIdx.x].wi : 0;
     if (threadIdx.x < HPK_MAX_PAIRS) { lpair_slot[threadIdx.x] = plan->pair_slot[threadIdx.x]; lpair_wi[threadIdx.x] = plan->pair_wi[threadIdx.x]; }
     if (threadIdx.x < HPK_NB_TAB + 2) lptoff[threadIdx.x] = const_cast<const int32_t*>(ka->ptab_off)[threadIdx.x];
+    // The width the widening froze at.  The stencil's workgroups added their resolve counts into the chromosome's totals;
+    // every workgroup here replays the reference's decision on them (a handful of steps, one thread), the first one
+    // also leaves totals, executed flags and the "empty step" verdict for the host.  (It used to be the tail of the
+    // stencil kernel: drain, release, ticket, acquire, replay by the last workgroup - 5 us of every launch.)
+    __shared__ unsigned long long lhtot[HPK_MAX_STEPS + 1];
+    __shared__ int lslot[HPK_MAX_STEPS];
+    __shared__ int lfrozen;
+    if (ka->hist_acc) {
+        if (threadIdx.x <= HPK_MAX_STEPS) lhtot[threadIdx.x] = const_cast<const unsigned long long*>(ka->hist_acc)[threadIdx.x * HPK_ACC_STRIDE];
+        if (threadIdx.x < HPK_MAX_STEPS) lslot[threadIdx.x] = (threadIdx.x < plan->nsteps) ? plan->steps[threadIdx.x].slot : 0;
+    }
     __syncthreads();
+    if (ka->hist_acc) {
+        if (threadIdx.x == 0) {
+            int fw, e;
+            freeze_replay(plan, lhtot, lstepw, lslot, blockIdx.x == 0 ? const_cast<int32_t*>(ka->executed) : nullptr, fw, e);
+            lfrozen = fw;
+            if (blockIdx.x == 0) { *const_cast<int32_t*>(ka->frozen) = fw; *const_cast<int32_t*>(ka->err) = e; }
+        }
+        if (blockIdx.x == 0 && threadIdx.x <= HPK_MAX_STEPS) const_cast<unsigned long long*>(ka->hist_out)[threadIdx.x] = lhtot[threadIdx.x];
+        __syncthreads();
+    }
 
     const int lane = threadIdx.x & 63;
     const int nsteps_u = plan->nsteps;
-    const int frozen = *const_cast<const int32_t*>(ka->frozen);
+    const int frozen = ka->hist_acc ? lfrozen : *const_cast<const int32_t*>(ka->frozen);
     const unsigned pkcap = (unsigned)plan->pk_cap;
     // Survivor slots are reserved from the global counter HPK_SCH records at a time per wave (same-address atomics
     // run at ~90 per microsecond device-wide); how many slots of a chunk were filled goes to chunk_used[].
@@ -2472,6 +2523,10 @@ void hpk_launch_probe(const HpkDenseArgs& a, const int32_t* rows, const int32_t*
     hipLaunchKernelGGL(hpk_probe, dim3((unsigned)count), dim3(64), 0, st, a, rows, cols, count, out);
 }
 
+void hpk_launch_freeze_tot(const HpkDevPlan* plan, const unsigned long long* hist_acc, unsigned long long* hist,
+                           int32_t* frozen, int32_t* executed, int32_t* err, hipStream_t st) {
+    hipLaunchKernelGGL(hpk_freeze_tot, dim3(1), dim3(128), 0, st, plan, hist_acc, hist, frozen, executed, err);
+}
 void hpk_launch_freeze(const HpkDevPlan* plan, unsigned long long* hist, const unsigned* hist_part, int nparts,
                        int32_t* frozen, int32_t* executed, int32_t* err, hipStream_t st) {
     hipLaunchKernelGGL(hpk_freeze, dim3(1), dim3(1024), 0, st, plan, hist_part, nparts, hist, frozen, executed, err);
