@@ -41,6 +41,9 @@ def synth_band(n, num, depth=60.0, alpha=1.0, nloops=20, seed=0,
                     kk = cc - rr
                     if 0 <= rr < n and 0 <= cc < n and 0 <= kk < num:
                         lam2d[rr, kk] *= enrich
+    # (planted loops may pile up on one cell of a tiny chromosome: 8^k times the rate overflowed the integer type and left
+    # negative "counts"; counts stay below 2^24, where f32 holds them exactly)
+    np.minimum(lam2d, 4.0e6, out=lam2d)
     raw = rng.poisson(lam2d).astype(dtype)
     # zero the part of the band that falls outside the matrix
     rr = np.arange(n)[:, None]

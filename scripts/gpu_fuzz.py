@@ -39,6 +39,8 @@ def one_case(seed, ctx):
     min_reads = int(rng.choice([1, 8, 16, 25, 200, 1000]))
     sig = float(rng.choice([0.01, 0.05, 0.1, 0.3]))
     raw, weight, _ = synthetic.synth_band(n, num, depth=depth, nloops=int(rng.integers(0, 25)), seed=seed)
+    if raw.min() < 0 or raw.max() >= (1 << 24):      # outside the domain (counts, exact in f32): a generator artefact, not a case
+        return 'invalid-input', dict(seed=seed), 'counts outside [0, 2^24)'
     mode = 'bhfdr' if rng.random() < 0.2 else 'hiccups'
     inp = str(rng.choice(['weight', 'balanced', 'derive']))       # weights + IR | f64 balanced band + IR | weights only
     desc = dict(seed=seed, mode=mode, inp=inp, n=n, D=D, maxww=maxww, pw=pw, ww=ww, depth=depth, min_reads=min_reads, sig=sig)
