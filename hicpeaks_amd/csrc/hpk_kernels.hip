@@ -1808,9 +1808,12 @@ __global__ void __launch_bounds__(64) hpk_etab_edge(const HpkDevPlan* __restrict
     if (d > D) return;
     double EK = 0.0, EY = 0.0;
     for (int tp = 0; tp <= 4 * wi; ++tp) {
+        // (a diagonal without a single unmasked pixel has IR = NaN - far corners of short chromosomes: it may only reach
+        // the sums of windows that really hold one of its cells, as in the reference's cell-by-cell adds; 0 x NaN is NaN)
         const double v = lir[(int)threadIdx.x + tp];
-        EK += tapK[tp] * v;
-        EY += tapY[tp] * v;
+        const double ck = tapK[tp], cy = tapY[tp];
+        EK += ck != 0.0 ? ck * v : 0.0;
+        EY += cy != 0.0 ? cy * v : 0.0;
     }
     if (interior) {
         etab[(int64_t)(s * 2) * (D + 1) + d] = EK;

@@ -521,7 +521,10 @@ def test_random_parameter_sets_against_oracle(ctx):
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     tally = {}
-    for seed in range(300, 360):
+    # + the seeds the full runs ever flagged: 1410599 - a diagonal without an unmasked pixel (IR = NaN) next to windows
+    # clipped by the matrix end, whose tap-form expected sums multiplied it by a zero coefficient (NaN where the reference
+    # has a number: one test fewer in the family, q off by 1e-3); 1300317 - a band the old generator overflowed
+    for seed in list(range(300, 360)) + [1410599, 1300317]:
         status, desc, note = fz.one_case(seed, ctx)
         assert not status.startswith('MISMATCH'), (status, desc, note)
         tally[status] = tally.get(status, 0) + 1
