@@ -17,6 +17,7 @@ HPK_MAX_PAIRS = 8
 HPK_MAX_W = 20
 HPK_MAX_STEPS = 64
 HPK_NB = 128
+HPK_MAX_BATCH = 256
 
 MODE_HICCUPS = 0
 MODE_BHFDR = 1
@@ -31,7 +32,7 @@ ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_EMPTY_STEP, ERR_PLAN, ERR_NOMEM, ERR_BU
 
 # every symbol include/hpk.h declares (tests check the built library exports all of them)
 ABI_SYMBOLS = ['hpk_create', 'hpk_destroy', 'hpk_last_error', 'hpk_abi_version', 'hpk_score_band',
-               'hpk_pipeline_depth', 'hpk_submit_band', 'hpk_collect',
+               'hpk_pipeline_depth', 'hpk_submit_band', 'hpk_collect', 'hpk_submit_batch', 'hpk_collect_batch', 'hpk_set_option',
                'hpk_result_free', 'hpk_plan_rings', 'hpk_chunk_bounds', 'hpk_set_chunk_bounds',
                'hpk_device_info', 'hpk_poisson_sf', 'hpk_bruteforce_sums', 'hpk_probe_sums', 'hpk_band_from_coo']
 
@@ -84,7 +85,7 @@ class Result(C.Structure):
                 ('ms_h2d', C.c_float), ('ms_stencil', C.c_float), ('ms_freeze', C.c_float), ('ms_score', C.c_float),
                 ('ms_tighten', C.c_float), ('ms_gap', C.c_float), ('ms_d2h', C.c_float), ('ms_host_bh', C.c_float), ('ms_total', C.c_float),
                 ('stencil_kernel', C.c_int32), ('record_bound', C.c_int32), ('redone', C.c_int32), ('nsurv_sig', C.c_int64), ('nsurv_cut', C.c_int64),
-                ('stencil_tiles', C.c_int64), ('band_px', C.c_int64)]
+                ('stencil_tiles', C.c_int64), ('band_px', C.c_int64), ('batch_bands', C.c_int32), ('reserved2', C.c_int32)]
 
 
 def build(force=False, quiet=True):
@@ -131,6 +132,12 @@ def load():
     lib.hpk_submit_band.restype = C.c_int
     lib.hpk_collect.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.POINTER(Result))]
     lib.hpk_collect.restype = C.c_int
+    lib.hpk_submit_batch.argtypes = [C.c_void_p, C.POINTER(Band), C.c_int32, C.POINTER(Params), C.POINTER(C.c_void_p)]
+    lib.hpk_submit_batch.restype = C.c_int
+    lib.hpk_collect_batch.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.POINTER(Result)), C.POINTER(C.c_int32), C.c_char_p, C.c_int32]
+    lib.hpk_collect_batch.restype = C.c_int
+    lib.hpk_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    lib.hpk_set_option.restype = C.c_int
     lib.hpk_plan_rings.argtypes = [C.POINTER(Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.hpk_plan_rings.restype = C.c_int
     lib.hpk_chunk_bounds.argtypes = [C.c_void_p, C.c_int32]
@@ -221,6 +228,7 @@ class BandResult(object):
         self.stencil_kernel = int(r.stencil_kernel)
         self.record_bound = int(r.record_bound)      # records for candidates resolved up to this width (255: all)
         self.redone = bool(r.redone)                 # the bound from the previous chromosome was too narrow: computed twice
+        self.batch_bands = int(r.batch_bands)        # chromosomes that shared this one's launches (kernel times are its share)
         ns = int(r.nsig)
         x, y = _arr(r.x, ns, np.int64), _arr(r.y, ns, np.int64)
         O, bal, E = _arr(r.O, ns, np.float64), _arr(r.bal, ns, np.float64), _arr(r.E, ns, np.float64)
@@ -274,6 +282,48 @@ class Job(object):
             self.ctx.lib.hpk_collect(self.ctx.h, h, None)
 
 
+class BatchJob(object):
+    """A batch of chromosomes in flight on one lane of a Context (hpk_submit_batch / hpk_collect_batch)."""
+
+    def __init__(self, ctx, handle, ns, keep=None):
+        self.ctx, self.handle, self.ns, self._keep = ctx, handle, list(ns), keep
+
+    def results(self, raise_on_error=True):
+        """-> [BandResult, ...] in submission order.  A chromosome on which the reference raises (an empty widening step)
+        raises here too (the first one, after every result has been taken over), or - raise_on_error=False - has the
+        exception object in its place."""
+        if self.handle is None:
+            raise HpkError(ERR_INVALID, 'job already collected')
+        nb = len(self.ns)
+        outs = (C.POINTER(Result) * nb)()
+        status = (C.c_int32 * nb)()
+        msg = C.create_string_buffer(nb * 512)
+        h, self.handle = self.handle, None
+        rc = self.ctx.lib.hpk_collect_batch(self.ctx.h, h, outs, status, msg, 512)
+        self._keep = None
+        self.ctx._check(rc)
+        res = []
+        for b in range(nb):
+            if status[b] == HPK_OK:
+                try:
+                    res.append(BandResult(outs[b].contents, self.ns[b]))
+                finally:
+                    self.ctx.lib.hpk_result_free(outs[b])
+            else:
+                text = msg.raw[b * 512:(b + 1) * 512].split(b'\0', 1)[0].decode()
+                res.append((EmptyStepError if status[b] == ERR_EMPTY_STEP else HpkError)(status[b], text))
+        if raise_on_error:
+            for r in res:
+                if isinstance(r, Exception):
+                    raise r
+        return res
+
+    def __del__(self):          # a dropped job still has to give its lane back
+        if getattr(self, 'handle', None) is not None and getattr(self.ctx, 'h', None):
+            h, self.handle = self.handle, None
+            self.ctx.lib.hpk_collect_batch(self.ctx.h, h, None, None, None, 0)
+
+
 class Context(object):
     """One hpk_ctx = one GPU.  Not shared between threads."""
 
@@ -305,6 +355,11 @@ class Context(object):
             self.close()
         except Exception:
             pass
+
+    def set_option(self, name, value):
+        """Tuning / test switch of the context (hpk_set_option): 'rounds', 'surv_cap', 'spec', 'spec_margin',
+        'spec_force', 'risk_log2', 'tile_order', 'gap_kernel', 'score_div', 'dbg_stop'."""
+        self._check(self.lib.hpk_set_option(self.h, name.encode(), int(value)))
 
     def info(self):
         name = C.create_string_buffer(128)
@@ -372,6 +427,25 @@ class Context(object):
     def submit_device(self, n, num, ld, raw_ptr, IR_ptr, b1_ptr, b2_ptr, params, balanced_ptr=None, weight_ptr=None):
         bd = self._band(n, num, ld, raw_ptr, balanced_ptr, weight_ptr, IR_ptr, b1_ptr, b2_ptr, True)
         return self.submit(bd, params, n)
+
+    # ---- a batch of chromosomes through one set of launches
+    def submit_batch(self, bands, params, ns, keep=None):
+        """bands: [Band, ...] (from `_band` / `_host_band`), ns: their chromosome lengths -> BatchJob"""
+        arr = (Band * len(bands))(*bands)
+        job = C.c_void_p()
+        self._check(self.lib.hpk_submit_batch(self.h, arr, len(bands), C.byref(params), C.byref(job)))
+        return BatchJob(self, job, ns, keep)
+
+    def submit_batch_host(self, items, params):
+        """items: [dict(raw=, IR=, bias1=, bias2=, balanced=, weight=, num=), ...] of host arrays -> BatchJob (arrays kept alive)"""
+        bands, keep, ns = [], [], []
+        for it in items:
+            bd, kp = self._host_band(it['raw'], it.get('IR'), it.get('bias1'), it.get('bias2'), it.get('balanced'), it.get('weight'),
+                                     num_hint=it.get('num'))
+            bands.append(bd)
+            keep.append(kp)
+            ns.append(bd.n)
+        return self.submit_batch(bands, params, ns, keep)
 
     @property
     def pipeline_depth(self):

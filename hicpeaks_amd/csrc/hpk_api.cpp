@@ -44,42 +44,60 @@ double now_ms() {
 
 }  // namespace
 
-// One lane = everything a chromosome in flight owns: upload stream, events, device workspaces, the pinned landing
-// area of its result head and the cached device copy of its widening plan.  Two lanes let the host half of
-// chromosome i (Benjamini-Hochberg, result assembly, the caller's Python) and the upload of chromosome i + 1 overlap
-// the kernels.  The stencil, the scoring and the cut of all lanes run in submission order on the context's one compute
-// stream: the stencil fills the whole chip (one 160 KiB-LDS workgroup per CU), so running two chromosomes' big kernels
-// side by side would only time-slice them.  What a chromosome needs *before* its stencil - uploads, IR / biases, the
+// One lane = everything a batch of chromosomes in flight owns: upload stream, events, device workspaces (pooled over
+// the batch's bands), the pinned landing area of the result heads and the cached device copy of the widening plan.  Two
+// lanes let the host half of batch i (Benjamini-Hochberg, result assembly, the caller's Python) and the upload of batch
+// i + 1 overlap the kernels.  The stencil, the scoring and the cut of all lanes run in submission order on the context's
+// one compute stream: the stencil fills the whole chip (one 160 KiB-LDS workgroup per CU), so running two batches' big
+// kernels side by side would only time-slice them.  What a batch needs *before* its stencil - uploads, IR / biases, the
 // expected tables and the zero-fill of its counters - runs on the lane's side stream, beside the scoring / cut kernels
-// of the chromosome before.  (The cut and the copy of the result head were tried on the side stream too: they then
-// wait behind the next chromosome's stencil, the host collects a result later and submits the chromosome after next
-// later - 0.203 -> 0.228 ms per chromosome.)
+// of the batch before.  (The cut and the copy of the result head were tried on the side stream too: they then wait
+// behind the next stencil, the host collects a result later and submits the batch after next later.)
 #define HPK_LANES 2
 struct Lane {
-    hipStream_t up = nullptr;           // uploads of host inputs run beside the kernels of the chromosome before
+    hipStream_t up = nullptr;           // uploads of host inputs run beside the kernels of the batch before
     hipEvent_t ev[8];                   // phase marks on the compute stream
     hipEvent_t ev_up = nullptr, ev_done = nullptr;
     int nev = 0;
     bool busy = false;
-    // workspaces (grow only)
-    DevBuf raw, bal, weight, IR, b1, b2, plan, etab, eedge, recE, recS, recW, dE, dW, dS, small, surv, surv2, chunkused, psum, pnan, units;
-    void* h_head = nullptr;             // pinned: counters | row flags | first survivors
+    // workspaces (grow only), pooled over the bands of a batch
+    DevBuf raw, bal, weight, IR, b1, b2, plan, etab, eedge, recE, recS, recW, dE, dW, dS, small, surv, surv2, survx, survx2, cux, psum, pnan, units, desc;
+    void* h_head = nullptr;             // pinned: per band counters | row flags | first survivors
     size_t h_head_cap = 0;
+    void* h_desc = nullptr;             // pinned staging of the band descriptors
+    size_t h_desc_cap = 0;
     // the device copy of the widening plan is reused while the parameters do not change
     hpk_params plan_key;
     bool plan_valid = false;
     HpkDevPlan plan_host;
     void release() {
         DevBuf* all[] = {&raw, &bal, &weight, &IR, &b1, &b2, &plan, &etab, &eedge, &recE, &recS, &recW, &dE, &dW, &dS, &small,
-                         &surv, &surv2, &chunkused, &psum, &pnan, &units};
+                         &surv, &surv2, &survx, &survx2, &cux, &psum, &pnan, &units, &desc};
         for (DevBuf* b : all) b->release();
         if (h_head) { (void)hipHostFree(h_head); h_head = nullptr; h_head_cap = 0; }
+        if (h_desc) { (void)hipHostFree(h_desc); h_desc = nullptr; h_desc_cap = 0; }
         for (int i = 0; i < nev; ++i) (void)hipEventDestroy(ev[i]);
         nev = 0;
         if (ev_up) { (void)hipEventDestroy(ev_up); ev_up = nullptr; }
         if (ev_done) { (void)hipEventDestroy(ev_done); ev_done = nullptr; }
         if (up) { (void)hipStreamDestroy(up); up = nullptr; }
     }
+};
+
+// Tuning and test switches: read from the environment once (hpk_create), changed through hpk_set_option; the submit /
+// collect paths only ever look at this struct.
+struct Options {
+    int rounds = -2;            // -2: the scoring kernel keeps the p-value histogram of the cut; -1: hpk_thr_hist; 0..4 counting rounds
+    int64_t surv_cap = 0;       // survivor slots per region (0: sized from the band)
+    int spec = 1;               // record bound from the chromosomes collected before
+    int spec_margin = 0;
+    int spec_force = -1;
+    int risk_log2 = 12;
+    int tile_order = 1;
+    int gap_kernel = 0;
+    int score_div = 8;          // tiles per scoring workgroup of a batch
+    int dbg_stop = 0;
+    int host_prof = 0;
 };
 
 struct hpk_ctx {
@@ -89,17 +107,21 @@ struct hpk_ctx {
     char name[128] = {0};
     int cus = 0;
     size_t hbm = 0;
+    Options opt;
     // constant tables
     std::vector<double> h_bounds;
     std::vector<int32_t> h_off;
     std::vector<double> h_sfe;
     DevBuf d_bounds, d_off, d_sfe, d_ptab;
+    bool tables_dirty = true;           // the Poisson table is (re)built before the first launch that needs it
     Lane lane[HPK_LANES];
     DevBuf tmpA, tmpB, tmpC, tmpD;
-    // The width the widening froze at (freeze_body) in the last chromosome collected with these parameters: the next
-    // stencil writes records up to it only (HpkStencilArgs::wguess); a chromosome that freezes later is redone in full.
+    // The widths the widening froze at (freeze_replay) in the chromosomes collected last with these parameters: the next
+    // stencil writes records up to the widest of them only (HpkBandDesc::wguess); a chromosome that freezes later is
+    // redone in full.
     hpk_params hint_key;
-    int hint_w = -1;
+    int hint_w[4] = {-1, -1, -1, -1};
+    int hint_n = 0;
     long long spec_reruns = 0;
 };
 
@@ -152,7 +174,10 @@ void fill_sfe(std::vector<double>& sfe) {
     }
 }
 
+// chunk bounds, table offsets, stirlerr values and the Poisson table on the device; built before the first launch that
+// needs them and again after hpk_set_chunk_bounds (the Python layer replaces the bounds right after hpk_create: one build)
 int upload_tables(hpk_ctx* c) {
+    if (!c->tables_dirty) return HPK_OK;
     fill_offsets(c->h_bounds, c->h_off);
     const int32_t total = c->h_off[HPK_NB_TAB + 1];
     HIPCHK(c, c->d_bounds.reserve(sizeof(double) * HPK_NB));
@@ -165,7 +190,13 @@ int upload_tables(hpk_ctx* c) {
     hpk_launch_ptab(c->d_bounds.as<double>(), c->d_off.as<int32_t>(), c->d_sfe.as<double>(), c->d_ptab.as<double>(), total, c->stream);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->tables_dirty = false;
     return HPK_OK;
+}
+
+int env_int(const char* name, int dflt) {
+    const char* e = std::getenv(name);
+    return e ? std::atoi(e) : dflt;
 }
 
 struct ResultBox {
@@ -240,9 +271,36 @@ int hpk_create(int device, hpk_ctx** out) {
     }
     fill_bounds(c->h_bounds);
     fill_sfe(c->h_sfe);
-    int rc = upload_tables(c);
-    if (rc != HPK_OK) { g_create_error = c->err; hpk_destroy(c); return rc; }
+    // the environment is read here and nowhere else (A/B scripts); tests use hpk_set_option
+    Options& o = c->opt;
+    o.rounds = std::min(4, env_int("HPK_ROUNDS", o.rounds));
+    o.spec = env_int("HPK_SPEC", o.spec);
+    o.spec_margin = env_int("HPK_SPEC_MARGIN", o.spec_margin);
+    o.risk_log2 = env_int("HPK_RISK_LOG2", o.risk_log2);
+    o.tile_order = env_int("HPK_TILE_ORDER", o.tile_order);
+    o.gap_kernel = env_int("HPK_GAP_KERNEL", o.gap_kernel);
+    o.score_div = std::max(1, env_int("HPK_SCORE_DIV", o.score_div));
+    o.dbg_stop = env_int("HPK_DBG_STOP", o.dbg_stop);
+    o.host_prof = env_int("HPK_HOST_PROF", o.host_prof);
     *out = c;
+    return HPK_OK;
+}
+
+int hpk_set_option(hpk_ctx* c, const char* name, int64_t v) {
+    if (!c || !name) return HPK_ERR_INVALID;
+    Options& o = c->opt;
+    const std::string k(name);
+    if (k == "rounds" && v >= -2 && v <= 4) o.rounds = (int)v;
+    else if (k == "surv_cap" && v >= 0) o.surv_cap = v;
+    else if (k == "spec" && (v == 0 || v == 1)) o.spec = (int)v;
+    else if (k == "spec_margin" && v >= 0 && v <= HPK_MAX_W) o.spec_margin = (int)v;
+    else if (k == "spec_force" && v >= -1 && v <= HPK_MAX_W) o.spec_force = (int)v;
+    else if (k == "risk_log2" && v >= 0 && v <= 60) o.risk_log2 = (int)v;
+    else if (k == "tile_order" && (v == 0 || v == 1)) o.tile_order = (int)v;
+    else if (k == "gap_kernel" && (v == 0 || v == 1)) o.gap_kernel = (int)v;
+    else if (k == "score_div" && v >= 1 && v <= 4096) o.score_div = (int)v;
+    else if (k == "dbg_stop" && v >= 0 && v <= 16) o.dbg_stop = (int)v;
+    else return fail(c, HPK_ERR_INVALID, "unknown option or value out of range: %s = %lld", name, (long long)v);
     return HPK_OK;
 }
 
@@ -264,7 +322,8 @@ int hpk_set_chunk_bounds(hpk_ctx* c, const double* bounds, int32_t count) {
         if (!(bounds[i] > 0.0) || (i && !(bounds[i] > bounds[i - 1]))) return fail(c, HPK_ERR_INVALID, "bounds must increase");
         c->h_bounds[i] = bounds[i];
     }
-    return upload_tables(c);
+    c->tables_dirty = true;
+    return HPK_OK;
 }
 
 int hpk_chunk_bounds(double* bounds, int32_t count) {
@@ -304,6 +363,7 @@ int hpk_poisson_sf(hpk_ctx* c, const double* k, const double* lam, double* out, 
     if (!c || !k || !lam || !out || count < 0) return fail(c, HPK_ERR_INVALID, "bad arguments");
     if (count == 0) return HPK_OK;
     (void)hipSetDevice(c->device);
+    { const int rc = upload_tables(c); if (rc != HPK_OK) return rc; }
     const size_t bytes = sizeof(double) * (size_t)count;
     HIPCHK(c, c->tmpA.reserve(bytes));
     HIPCHK(c, c->tmpB.reserve(bytes));
@@ -319,71 +379,18 @@ int hpk_poisson_sf(hpk_ctx* c, const double* k, const double* lam, double* out, 
 
 }  // extern "C"
 
-// ---------------------------------------------------------------------------- staging shared by score / brute
+
+// ---------------------------------------------------------------------------- the per-batch pipeline
 namespace {
 
 struct Staged {
     const float* raw = nullptr;
     const double* bal = nullptr;
     const double* weight = nullptr;
-    const double* IR = nullptr;
-    const double* b1 = nullptr;
-    const double* b2 = nullptr;
+    double* IR = nullptr;
+    double* b1 = nullptr;
+    double* b2 = nullptr;
 };
-
-int stage_inputs(hpk_ctx* c, Lane& L, const hpk_band* band, int mw, Staged* s) {
-    const size_t n = (size_t)band->n, num = (size_t)band->num, ld = (size_t)band->ld;
-    const bool derive = !band->IR;          // IR / biases from raw + weight on the device (scripts/pyHICCUPS:149-166)
-    if (band->on_device) {
-        s->raw = band->raw; s->bal = band->balanced; s->weight = band->weight; s->IR = band->IR; s->b1 = band->bias1; s->b2 = band->bias2;
-    } else {
-        HIPCHK(c, L.raw.reserve(sizeof(float) * n * ld));
-        HIPCHK(c, hipMemcpyAsync(L.raw.p, band->raw, sizeof(float) * n * ld, hipMemcpyHostToDevice, L.up));
-        s->raw = L.raw.as<float>();
-        if (band->balanced) {
-            HIPCHK(c, L.bal.reserve(sizeof(double) * n * ld));
-            HIPCHK(c, hipMemcpyAsync(L.bal.p, band->balanced, sizeof(double) * n * ld, hipMemcpyHostToDevice, L.up));
-            s->bal = L.bal.as<double>();
-        }
-        if (band->weight) {
-            HIPCHK(c, L.weight.reserve(sizeof(double) * n));
-            HIPCHK(c, hipMemcpyAsync(L.weight.p, band->weight, sizeof(double) * n, hipMemcpyHostToDevice, L.up));
-            s->weight = L.weight.as<double>();
-        }
-        if (!derive) {
-            HIPCHK(c, L.IR.reserve(sizeof(double) * num));
-            HIPCHK(c, hipMemcpyAsync(L.IR.p, band->IR, sizeof(double) * num, hipMemcpyHostToDevice, L.up));
-            s->IR = L.IR.as<double>();
-            HIPCHK(c, L.b1.reserve(sizeof(double) * n));
-            HIPCHK(c, hipMemcpyAsync(L.b1.p, band->bias1, sizeof(double) * n, hipMemcpyHostToDevice, L.up));
-            s->b1 = L.b1.as<double>();
-            if (band->bias2 == band->bias1) s->b2 = s->b1;
-            else {
-                HIPCHK(c, L.b2.reserve(sizeof(double) * n));
-                HIPCHK(c, hipMemcpyAsync(L.b2.p, band->bias2, sizeof(double) * n, hipMemcpyHostToDevice, L.up));
-                s->b2 = L.b2.as<double>();
-            }
-        }
-    }
-    if (derive) {
-        // The derivation runs on the lane's side stream too: it only needs the inputs, so for the chromosome submitted
-        // one ahead it executes beside the scoring / cut kernels of the chromosome before (those leave registers and
-        // LDS free; the stencil does not).
-        const size_t nparts = (n + 31) / 32;        // HPK_IR_ROWS rows per partial (hpk_launch_prep)
-        HIPCHK(c, L.IR.reserve(sizeof(double) * num));
-        HIPCHK(c, L.b1.reserve(sizeof(double) * n));
-        HIPCHK(c, L.psum.reserve(sizeof(double) * nparts * num));
-        HIPCHK(c, L.pnan.reserve(sizeof(unsigned) * nparts * num));
-        hpk_launch_prep(s->raw, s->weight, (int)n, (int)num, (int64_t)ld, mw, L.psum.as<double>(), L.pnan.as<unsigned>(),
-                        L.IR.as<double>(), L.b1.as<double>(), L.up);
-        HIPCHK(c, hipGetLastError());
-        s->IR = L.IR.as<double>();
-        s->b1 = L.b1.as<double>();
-        s->b2 = s->b1;
-    }
-    // (submit_impl adds the expected tables to the side stream, then lets the compute stream wait for all of it)
-    return HPK_OK;
-}
 
 int check_band(hpk_ctx* c, const hpk_band* band) {
     if (!band || band->n <= 0 || band->num <= 0 || band->ld < band->num) return fail(c, HPK_ERR_INVALID, "bad band shape");
@@ -395,20 +402,7 @@ int check_band(hpk_ctx* c, const hpk_band* band) {
     return HPK_OK;
 }
 
-// small device scratch block layout (bytes)
-constexpr size_t OFF_HIST = 0;                                                   // u64[65]
-constexpr size_t OFF_FROZEN = OFF_HIST + 8 * (HPK_MAX_STEPS + 1);               // i32
-constexpr size_t OFF_ERR = OFF_FROZEN + 8;                                       // i32
-constexpr size_t OFF_EXEC = OFF_ERR + 8;                                         // i32[64]
-constexpr size_t OFF_NUNITS = OFF_EXEC + 4 * HPK_MAX_STEPS;                      // u32 (+ pad): survives the overflow rerun
-constexpr size_t OFF_NSURV = OFF_NUNITS + 8;                                     // u64 ... everything from here is reset by the rerun
-constexpr size_t OFF_NVALID = OFF_NSURV + 8 * HPK_NREG * HPK_REG_STRIDE;          // u64[16]
-constexpr size_t OFF_EMAX = OFF_NVALID + 8 * 2 * HPK_MAX_PAIRS;                  // u64[16]
-constexpr size_t OFF_NOUT = OFF_EMAX + 8 * 2 * HPK_MAX_PAIRS;                    // u64
-constexpr size_t OFF_FAM_M = OFF_NOUT + 8;                                       // u32[HPK_NFAM]
-constexpr size_t OFF_FAM_F = OFF_FAM_M + 4 * HPK_NFAM;                           // u32[HPK_NFAM]
-constexpr size_t SMALL_BYTES = OFF_FAM_F + 4 * HPK_NFAM;
-constexpr size_t HEAD_INLINE = 4096;         // compacted survivors that travel to the host with the counters
+size_t up256(size_t v) { return (v + 255) / 256 * 256; }
 
 }  // namespace
 
@@ -420,143 +414,113 @@ void hpk_result_free(hpk_result* res) {
 
 }  // extern "C"
 
-// One chromosome in flight.
+// One chromosome of a batch in flight: where its slices of the lane's pooled workspaces are.
+struct BandSlot {
+    hpk_band in;
+    Staged st;
+    HpkBandDesc d;                      // host copy of the descriptor
+    int32_t n = 0, num = 0, ntiles = 0;
+    int64_t ld = 0, cap = 0, band_px = 0, ldo = 0;
+    size_t off_rowlive = 0, off_inl = 0, head_bytes = 0, off_hacc = 0, off_tc = 0, off_cnt = 0, off_cu = 0, zero_bytes = 0;
+    size_t small_off = 0, head_off = 0; // inside Lane::small / Lane::h_head
+    size_t dense_elems = 0;
+    bool redone = false, overflowed = false;
+    bool rest_fetched = false;          // the survivors beyond the inline head already sit in `rest` (overflow rerun)
+    std::vector<HpkSurv> rest;
+    int status = HPK_OK;
+    std::string err;
+    ResultBox* box = nullptr;
+};
+
 struct hpk_job {
     hpk_ctx* ctx = nullptr;
     int lane = -1;
-    hpk_params prm;
-    int32_t n = 0, num = 0;
-    int64_t ld = 0;
-    Staged in;
+    hpk_params prm, key;
+    std::vector<BandSlot> bands;
     HpkStencilArgs sa;
-    size_t off_rowlive = 0, off_inl = 0, head_bytes = 0, off_cnt = 0, off_cu = 0, dense_elems = 0;
-    int64_t cap = 0, band_px = 0, ldo = 0;
-    size_t zero_bytes = 0;
-    hpk_params key;
-    int nsets = 0, TR = 0, TC = 0, rounds = 2;
-    bool sums = false, dense = false, do_score = true, phases = false, simple = false, time_stencil = true, redone = false;
+    HpkScoreArgs sc;
+    int nsets = 0, rounds_eff = 0, gmax = 0;
+    bool sums = false, dense = false, do_score = true, phases = false, simple = false, use_s = false, balf64 = false,
+         time_stencil = true;
+    size_t max_zero = 0, max_head = 0;
     double t_begin = 0.0;
-    ResultBox* box = nullptr;
-    ~hpk_job() { delete box; }
+    ~hpk_job() { for (BandSlot& b : bands) delete b.box; }
 };
 
 namespace {
 
-// scoring + BH-cut tightening + the head copy, on the job's lane (first pass and overflow rerun)
-int launch_scoring(hpk_ctx* c, hpk_job* j, int attempt) {
+HpkBandDesc* lane_desc(Lane& L, const hpk_job* j, int b, bool solo) {
+    return L.desc.as<HpkBandDesc>() + (solo ? (int)j->bands.size() + b : b);
+}
+
+// the kernels of bands [b0, b0 + nbl) of a job whose counter blocks are zero: stencil (+ the freeze decision), scoring,
+// cut, copy-back.  solo: band b0 alone, through its second descriptor (records for every resolved candidate).
+int launch_compute(hpk_ctx* c, hpk_job* j, int b0, int nbl, bool solo, bool with_stencil) {
     Lane& L = c->lane[j->lane];
     const HpkDevPlan& plan = L.plan_host;
-    unsigned char* small = L.small.as<unsigned char>();
-    unsigned long long* d_nsurv = reinterpret_cast<unsigned long long*>(small + OFF_NSURV);
-    unsigned long long* d_nout = reinterpret_cast<unsigned long long*>(small + OFF_NOUT);
-    unsigned int* d_fam_m = reinterpret_cast<unsigned int*>(small + OFF_FAM_M);
-    unsigned int* d_fam_f = reinterpret_cast<unsigned int*>(small + OFF_FAM_F);
-    unsigned int* d_cnt = reinterpret_cast<unsigned int*>(small + j->off_cnt);
-    unsigned* d_chunkused = reinterpret_cast<unsigned*>(small + j->off_cu);
-    const HpkStencilArgs& sa = j->sa;
-    if (j->do_score) {
-        const int64_t cap = j->cap;
-        HIPCHK(c, L.surv.reserve(sizeof(HpkSurv) * (size_t)cap * HPK_NREG));
-        HIPCHK(c, L.surv2.reserve(sizeof(HpkSurv) * (size_t)cap * HPK_NREG));
-        if (attempt > 0) {       // overflow rerun: the chunk table no longer fits the zero block
-            const size_t cu_bytes = sizeof(unsigned) * (size_t)(cap / HPK_SCH * HPK_NREG + 1);
-            HIPCHK(c, L.chunkused.reserve(cu_bytes));
-            HIPCHK(c, hipMemsetAsync(L.chunkused.p, 0, cu_bytes, c->stream));
-            HIPCHK(c, hipMemsetAsync(small + OFF_NSURV, 0, SMALL_BYTES - OFF_NSURV, c->stream));
-            HIPCHK(c, hipMemsetAsync(small + j->off_cnt, 0, sizeof(unsigned) * HPK_NFAM * HPK_TIGHTEN_MAX, c->stream));
-            d_chunkused = L.chunkused.as<unsigned>();
+    const HpkBandDesc* dd = lane_desc(L, j, b0, solo);
+    if (with_stencil) {
+        if (j->time_stencil) (void)hipEventRecord(L.ev[1], c->stream);
+        if (j->use_s) {
+            HpkStencilArgs sa = j->sa;
+            sa.nbands = nbl;
+            int kall = 0;
+            for (int b = b0; b < b0 + nbl; ++b) kall += j->bands[b].d.chunk;
+            sa.grid = std::max(8, std::min((c->cus / 8) * 8, kall * 8));
+            hpk_launch_stencil_batch(sa, dd, j->balf64, c->stream);
+            HIPCHK(c, hipGetLastError());
+        } else {
+            for (int b = b0; b < b0 + nbl; ++b) {
+                HpkBandDesc hb = j->bands[b].d;
+                if (solo) hb.wguess = plan.W;
+                const int grid = std::max(8, std::min((c->cus / 8) * 8, hb.chunk * 8));
+                hpk_launch_stencil_old(j->sa, hb, j->balf64, j->simple, grid, c->stream);
+                HIPCHK(c, hipGetLastError());
+            }
         }
-        HpkScoreArgs sc;
-        std::memset(&sc, 0, sizeof(sc));
-        sc.raw = j->in.raw; sc.bal = j->in.bal; sc.weight = j->in.weight; sc.plan = sa.plan;
-        sc.etab = L.etab.as<double>(); sc.eedge = L.eedge.as<double>(); sc.IR = j->in.IR; sc.b1 = j->in.b1; sc.b2 = j->in.b2;
-        sc.frozen = reinterpret_cast<int32_t*>(small + OFF_FROZEN);
-        sc.hist_acc = sa.hist_acc;
-        sc.hist_out = reinterpret_cast<unsigned long long*>(small + OFF_HIST);
-        sc.executed = reinterpret_cast<int32_t*>(small + OFF_EXEC);
-        sc.err = reinterpret_cast<int32_t*>(small + OFF_ERR);
-        sc.bounds = c->d_bounds.as<double>(); sc.ptab = c->d_ptab.as<double>();
-        sc.ptab_off = c->d_off.as<int32_t>(); sc.sfe = c->d_sfe.as<double>(); sc.sig = j->prm.sig;
-        sc.n = j->n; sc.num = j->num; sc.ld = j->ld; sc.ldo = j->ldo; sc.mw = plan.mw; sc.D = plan.D;
-        sc.rec_ent = sa.rec_ent; sc.rec_S = sa.rec_S; sc.rec_W = sa.rec_W; sc.tile_cnt = sa.tile_cnt;
-        sc.units = L.units.as<uint2>(); sc.nunits = reinterpret_cast<const unsigned*>(small + OFF_NUNITS);
-        sc.tilecap = sa.tilecap; sc.rec_stride = sa.rec_stride; sc.ntiles = sa.ntiles;
-        sc.TR = j->TR; sc.TC = j->TC; sc.J = sa.J; sc.W = plan.W;
-        sc.fam_m = d_fam_m; sc.fam_f = d_fam_f;
-        sc.emax_bits = reinterpret_cast<unsigned long long*>(small + OFF_EMAX);
-        sc.nvalid = reinterpret_cast<unsigned long long*>(small + OFF_NVALID);
-        sc.nsurv = d_nsurv;
-        // default: the scoring kernel keeps the p-value histogram the cut is derived from (no separate pass over the
-        // survivors); HPK_ROUNDS = -1: hpk_thr_hist, >= 0: exact counting rounds
-        int rounds = j->rounds;
-        sc.hist = d_cnt; sc.hbins = 0; sc.nsets_half = plan.npairs;
-        if (rounds <= -2) { sc.hbins = hpk_score_hist_bins(j->nsets); rounds = -100 - sc.hbins; }
-        sc.cap = cap; sc.surv = L.surv.as<HpkSurv>(); sc.chunk_used = d_chunkused;
-        hpk_launch_score(sc, plan.mode == HPK_MODE_BHFDR, c->cus, c->stream);
-        HIPCHK(c, hipGetLastError());
-        if (j->phases) (void)hipEventRecord(L.ev[4], c->stream);
-        hpk_launch_tighten(sc.surv, d_nsurv, cap, sc.chunk_used, d_fam_m, d_fam_f, d_cnt, j->prm.sig, rounds, j->nsets,
-                           reinterpret_cast<HpkSurv*>(small + j->off_inl), HEAD_INLINE, L.surv2.as<HpkSurv>(), d_nout,
-                           j->in.bal, j->in.weight, j->ld, c->cus, c->stream);
-        HIPCHK(c, hipGetLastError());
-    } else {
-        if (j->phases) (void)hipEventRecord(L.ev[4], c->stream);
+        if (j->time_stencil) (void)hipEventRecord(L.ev[2], c->stream);
+        if (!j->do_score) {         // no scoring kernel to replay the freeze decision: a one-workgroup kernel per band
+            hpk_launch_freeze_tot(L.plan.as<HpkDevPlan>(), dd, nbl, c->stream);
+            HIPCHK(c, hipGetLastError());
+        }
+        if (j->phases) (void)hipEventRecord(L.ev[3], c->stream);
     }
+    if (j->do_score) {
+        HpkScoreArgs sc = j->sc;
+        sc.gridx = 0;           // the widest row of scoring workgroups among the bands launched (HpkBandDesc::score_wgs)
+        for (int b = b0; b < b0 + nbl; ++b) sc.gridx = std::max(sc.gridx, solo ? j->gmax : j->bands[b].d.score_wgs);
+        hpk_launch_score(sc, dd, nbl, plan.mode == HPK_MODE_BHFDR, c->stream);
+        HIPCHK(c, hipGetLastError());
+        if (j->phases) (void)hipEventRecord(L.ev[4], c->stream);
+        hpk_launch_tighten(dd, nbl, j->prm.sig, j->rounds_eff, j->nsets, c->stream);
+        HIPCHK(c, hipGetLastError());
+    } else if (j->phases) (void)hipEventRecord(L.ev[4], c->stream);
     if (j->phases) (void)hipEventRecord(L.ev[5], c->stream);
     // gap rows are produced by the stencil kernel (hpk_gap remains as an independent check for the tests)
     // ... as long as the band stops where the command lines stop it (num = D + maxww + 1, scripts/pyHICCUPS:146): the
     // tiles see the diagonals up to about D + maxww.  A caller of the drop-in hiccups() / bhfdr() may hand over more
     // diagonals, and callers.py:238 sums all of them: then the row kernel, which reads every stored diagonal, decides.
-    if (attempt == 0 && (std::getenv("HPK_GAP_KERNEL") || j->num > plan.D + plan.W + 1)) {
-        hpk_launch_gap(j->in.raw, j->in.bal, j->in.weight, j->n, j->num, j->ld, plan.mw, small + j->off_rowlive, c->stream);
-        HIPCHK(c, hipGetLastError());
+    if (with_stencil) {
+        for (int b = b0; b < b0 + nbl; ++b) {
+            const BandSlot& s = j->bands[b];
+            if (c->opt.gap_kernel || s.num > plan.D + plan.W + 1) {
+                hpk_launch_gap(s.st.raw, s.st.bal, s.st.weight, s.n, s.num, s.ld, plan.mw, s.d.gap, c->stream);
+                HIPCHK(c, hipGetLastError());
+            }
+        }
     }
     if (j->phases) (void)hipEventRecord(L.ev[6], c->stream);
-    // counters, row flags and the first survivors in one copy into pinned memory
-    if (std::getenv("HPK_HEAD_COPY")) {
-        HIPCHK(c, hipMemcpyAsync(L.h_head, small, j->head_bytes, hipMemcpyDeviceToHost, c->stream));
-    } else {        // pinned memory is device-visible: a small kernel writes it (head_bytes is a multiple of 16)
-        if (j->do_score && !std::getenv("HPK_PUBLISH_ALL")) {
-            // the stretches a chromosome fills: counters up to the families in use, their F(sig) counts, the row flags,
-            // and as many inline survivors as the cut left
-            const size_t nfam_b = sizeof(unsigned) * (size_t)j->nsets * (HPK_NB + 1);
-            const size_t seg[3][2] = {{0, OFF_FAM_M + nfam_b}, {OFF_FAM_F, OFF_FAM_F + nfam_b}, {j->off_rowlive, j->off_rowlive + (size_t)j->n}};
-            hpk_launch_publish_head(small, L.h_head, seg, j->off_inl, d_nout, (unsigned)HEAD_INLINE, (unsigned)sizeof(HpkSurv), c->stream);
-        } else hpk_launch_publish(small, L.h_head, j->head_bytes, c->stream);
-        HIPCHK(c, hipGetLastError());
-    }
+    // counters, row flags and the first survivors of every band into pinned memory, by a kernel: pinned memory is
+    // device-visible, and even one pinned copy per band costs ~15 us of copy-engine start-up
+    hpk_launch_publish(dd, nbl, j->nsets, !j->do_score, j->max_head, c->stream);
+    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(L.ev_done, c->stream));
     return HPK_OK;
 }
 
-// stencil (+ the freeze decision) of a staged chromosome whose counter block is zero
-int launch_stencil_stage(hpk_ctx* c, hpk_job* j) {
+int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk_params* prm) {
     Lane& L = c->lane[j->lane];
-    const HpkStencilArgs& sa = j->sa;
-    unsigned char* small = L.small.as<unsigned char>();
-    if (j->time_stencil) (void)hipEventRecord(L.ev[1], c->stream);
-    hpk_launch_stencil(sa, j->in.bal != nullptr, j->simple, c->stream);
-    HIPCHK(c, hipGetLastError());
-    if (j->time_stencil) (void)hipEventRecord(L.ev[2], c->stream);
-    if (sa.hist_acc) {      // totals: the scoring kernel decides in its prologue; without scoring, a one-workgroup kernel
-        if (!j->do_score) {
-            hpk_launch_freeze_tot(sa.plan, sa.hist_acc, reinterpret_cast<unsigned long long*>(small + OFF_HIST),
-                                  reinterpret_cast<int32_t*>(small + OFF_FROZEN), reinterpret_cast<int32_t*>(small + OFF_EXEC),
-                                  reinterpret_cast<int32_t*>(small + OFF_ERR), c->stream);
-            HIPCHK(c, hipGetLastError());
-        }
-    } else if (!sa.ticket) {       // HPK_FREEZE_KERNEL: the decision as a kernel of its own instead of the last stencil workgroup
-        hpk_launch_freeze(sa.plan, reinterpret_cast<unsigned long long*>(small + OFF_HIST), sa.hist_part, sa.grid,
-                          reinterpret_cast<int32_t*>(small + OFF_FROZEN), reinterpret_cast<int32_t*>(small + OFF_EXEC),
-                          reinterpret_cast<int32_t*>(small + OFF_ERR), c->stream);
-        HIPCHK(c, hipGetLastError());
-    }
-    if (j->phases) (void)hipEventRecord(L.ev[3], c->stream);
-    return HPK_OK;
-}
-
-int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* prm) {
-    Lane& L = c->lane[j->lane];
+    const Options& opt = c->opt;
     hpk_params key = *prm;
     key.flags = 0; key.reserved = 0;
     for (int i = key.npairs > 0 ? key.npairs : 0; i < HPK_MAX_PAIRS; ++i) { key.pw[i] = 0; key.ww[i] = 0; }
@@ -568,135 +532,272 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
         rc = hpk_build_plan(prm, &L.plan_host, msg);
         if (rc != HPK_OK) return fail(c, rc, "%s", msg);
     }
+    rc = upload_tables(c);
+    if (rc != HPK_OK) return rc;
     const HpkDevPlan& plan = L.plan_host;
     const int W = plan.W, mw = plan.mw, D = plan.D;
-    const int n = band->n, num = band->num;
     // output tile: what the halo leaves of the SAT tile, at most 4 rows per stencil wave (row slot = 2 bits of the record
     // entry, HPK_LISTCAP ids per wave)
     const int TR = std::min(HPK_LR - 2 * W - 1, HPK_ROWS_PER_WAVE * HPK_NWAVES), TC = HPK_LC - 2 * W - 1;
     static_assert(HPK_ROWS_PER_WAVE * (HPK_LC - 1) <= HPK_LISTCAP, "a wave's candidate list must hold its tile rows");
     if (D < mw) return fail(c, HPK_ERR_INVALID, "maxapart / res (%d) is below min(ww) (%d)", D, mw);
-    j->prm = *prm; j->n = n; j->num = num; j->ld = band->ld; j->TR = TR; j->TC = TC;
+    j->prm = *prm; j->key = key;
     j->nsets = (plan.mode == HPK_MODE_BHFDR) ? 1 : 2 * plan.npairs;
     j->sums = (prm->flags & HPK_FLAG_DENSE_SUMS) != 0;
     j->dense = j->sums || (prm->flags & HPK_FLAG_DENSE_E) != 0;
     j->do_score = (prm->flags & HPK_FLAG_NO_SCORE) == 0;
     j->phases = (prm->flags & HPK_FLAG_PHASE_TIMING) != 0;
-    j->rounds = std::getenv("HPK_ROUNDS") ? std::atoi(std::getenv("HPK_ROUNDS")) : -2;     // -2: histogram kept by hpk_score, -1: hpk_thr_hist
-    if (j->rounds > 4) j->rounds = 4;
-    const bool sums = j->sums, dense = j->dense;
+    j->time_stencil = j->phases || !(prm->flags & HPK_FLAG_NO_STENCIL_TIMING);
+    j->balf64 = bands[0].balanced != nullptr;
+    j->simple = plan.simple_reads != 0;
+    const bool dense = j->dense, sums = j->sums;
+    if (dense && nb != 1) return fail(c, HPK_ERR_INVALID, "the dense outputs (HPK_FLAG_DENSE_*) are for single chromosomes");
+    for (int b = 0; b < nb; ++b)
+        if ((bands[b].balanced != nullptr) != j->balf64)
+            return fail(c, HPK_ERR_INVALID, "the bands of a batch must carry the same kind of input (all `balanced` or all `weight`)");
 
-    j->box = new ResultBox();
-    std::memset(&j->box->pub, 0, sizeof(j->box->pub));
+    // ---- geometry, sizes and offsets of every band's slices
+    const int J_ = (TR + D - mw + TC - 1) / TC;
+    const int tilecap = TR * TC;
+    const size_t upt = ((size_t)tilecap + HPK_UNIT - 1) / HPK_UNIT;           // at most ceil(tilecap / HPK_UNIT) units per tile
+    const size_t etab_el = std::max<size_t>((size_t)plan.nsteps * 2 * (D + 1), 1);
+    const size_t eedge_el = std::max<size_t>((size_t)2 * W * plan.nsteps * 2 * (D + 1), 1);
+    const int hbins = (opt.rounds <= -2) ? hpk_score_hist_bins(j->nsets) : 0;
+    j->rounds_eff = (opt.rounds <= -2) ? -100 - hbins : opt.rounds;
+    j->gmax = j->do_score ? hpk_score_grid(plan.mode == HPK_MODE_BHFDR, plan.npairs, hbins, c->cus) : 0;
+    j->bands.resize(nb);
+    size_t tot_rec = 0, tot_recS = 0, tot_units = 0, tot_small = 0, tot_surv = 0, tot_head = 0, tot_ps = 0, tot_ir = 0, tot_n = 0,
+           tot_rawel = 0, tot_hn = 0;
+    std::vector<size_t> off_rec(nb), off_recS(nb), off_units(nb), off_surv(nb), off_ps(nb), off_ir(nb), off_n(nb), off_rawel(nb),
+                        off_hn(nb);
+    int64_t max_ld = 0;
+    int32_t max_n = 0, max_num = 0, max_dn = 0, max_dnum = 0;
+    bool any_derive = false;
+    int k0 = 0;
+    for (int b = 0; b < nb; ++b) {
+        BandSlot& s = j->bands[b];
+        s.in = bands[b];
+        const int n = bands[b].n, num = bands[b].num;
+        s.n = n; s.num = num; s.ld = bands[b].ld;
+        s.ntiles = ((n + TR - 1) / TR) * J_;
+        int64_t band_px = 0;                    // pixels with mw <= d <= D inside the matrix
+        for (int d = mw; d <= std::min(D, num - 1); ++d) if (n - d > 0) band_px += n - d;
+        s.band_px = band_px;
+        const bool derive = !bands[b].IR;
+        any_derive = any_derive || derive;
+        // scoring workgroups of the band: a single chromosome gets the resident grid; in a batch the bands share it
+        int wgs = j->gmax;
+        if (nb > 1) wgs = std::max(16, std::min(j->gmax, (s.ntiles + opt.score_div - 1) / opt.score_div));
+        // survivor capacity per region; every scoring wave may hold one partly filled chunk of HPK_SCH records
+        int64_t cap = (std::max<int64_t>(1 << 16, band_px * j->nsets / 6) + (int64_t)std::max(wgs, 1) * 4 * HPK_SCH * 2) / HPK_NREG;
+        if (opt.surv_cap > 0) cap = std::max<int64_t>(256, opt.surv_cap);       // tests: force the overflow rerun
+        cap = (cap + 255) / 256 * 256;
+        s.cap = cap;
+        // One block per band, zero-filled by the table kernel:
+        //   head (published to the host):  counters | row-has-signal flags [n] | first HEAD_INLINE compacted survivors
+        //   scratch:                       resolve totals | per-tile record counts | tightening counters | chunk fill counts
+        s.off_rowlive = up256(HPK_SMALL_BYTES);
+        s.off_inl = up256(s.off_rowlive + (size_t)n);
+        s.head_bytes = s.off_inl + sizeof(HpkSurv) * HPK_HEAD_INLINE;
+        s.off_hacc = up256(s.head_bytes);
+        s.off_tc = up256(s.off_hacc + 8 * (size_t)(HPK_MAX_STEPS + 1) * HPK_ACC_STRIDE);
+        s.off_cnt = up256(s.off_tc + sizeof(unsigned) * (size_t)s.ntiles);
+        s.off_cu = up256(s.off_cnt + sizeof(unsigned) * HPK_NFAM * HPK_TIGHTEN_MAX);
+        s.zero_bytes = (s.off_cu + sizeof(unsigned) * (size_t)(cap / HPK_SCH * HPK_NREG + 1) + 4095) / 4096 * 4096;
+        s.small_off = tot_small; tot_small += s.zero_bytes;
+        s.head_off = tot_head; tot_head += up256(s.head_bytes);
+        off_rec[b] = tot_rec; tot_rec += (size_t)s.ntiles * tilecap;
+        off_recS[b] = tot_recS; tot_recS += (size_t)s.ntiles * tilecap * plan.nslots;
+        off_units[b] = tot_units; tot_units += (size_t)s.ntiles * upt + 16;
+        off_surv[b] = tot_surv; tot_surv += (size_t)cap * HPK_NREG;
+        off_ir[b] = tot_ir; off_n[b] = tot_n;
+        if (derive || !bands[b].on_device) { tot_ir += ((size_t)num + 31) / 32 * 32; tot_n += ((size_t)n + 31) / 32 * 32; }
+        off_ps[b] = tot_ps;
+        if (derive) {
+            tot_ps += (size_t)((n + 31) / 32) * num;       // HPK_IR_ROWS rows per partial (hpk_launch_prep)
+            max_dn = std::max(max_dn, n); max_dnum = std::max(max_dnum, num);
+        }
+        off_rawel[b] = tot_rawel; off_hn[b] = tot_hn;
+        if (!bands[b].on_device) { tot_rawel += (size_t)n * (size_t)s.ld; tot_hn += ((size_t)n + 31) / 32 * 32; }
+        max_ld = std::max(max_ld, s.ld); max_n = std::max(max_n, n); max_num = std::max(max_num, num);
+        j->max_zero = std::max(j->max_zero, s.zero_bytes);
+        j->max_head = std::max(j->max_head, s.head_bytes);
+        s.ldo = ((int64_t)(D + 1) + 31) / 32 * 32;
+        s.dense_elems = (size_t)plan.nslots * (size_t)n * (size_t)s.ldo;
+        s.box = new ResultBox();
+        std::memset(&s.box->pub, 0, sizeof(s.box->pub));
+        // descriptor: geometry
+        HpkBandDesc& d = s.d;
+        std::memset(&d, 0, sizeof(d));
+        d.n = n; d.num = num; d.ld = s.ld; d.ntiles = s.ntiles; d.chunk = (s.ntiles + 7) / 8; d.k0 = k0;
+        k0 += d.chunk;
+        d.rec_stride = (int64_t)s.ntiles * tilecap;
+        d.cap = cap; d.zero_bytes = s.zero_bytes; d.off_rowlive = (uint32_t)s.off_rowlive; d.off_inl = (uint32_t)s.off_inl;
+        d.derive = derive ? 1 : 0; d.score_wgs = wgs;
+    }
 
-    // ---- inputs
+    // ---- workspaces
+    HIPCHK(c, L.recE.reserve(sizeof(unsigned) * tot_rec));
+    HIPCHK(c, L.recS.reserve(sizeof(double2) * tot_recS));
+    HIPCHK(c, L.recW.reserve(tot_recS));
+    HIPCHK(c, L.units.reserve(sizeof(uint2) * tot_units));
+    HIPCHK(c, L.small.reserve(tot_small));
+    HIPCHK(c, L.etab.reserve(sizeof(double) * etab_el * nb));
+    HIPCHK(c, L.eedge.reserve(sizeof(double) * eedge_el * nb));
+    HIPCHK(c, L.desc.reserve(sizeof(HpkBandDesc) * 2 * (size_t)nb));
+    if (j->do_score) {
+        HIPCHK(c, L.surv.reserve(sizeof(HpkSurv) * tot_surv));
+        HIPCHK(c, L.surv2.reserve(sizeof(HpkSurv) * tot_surv));
+    }
+    if (tot_ir) { HIPCHK(c, L.IR.reserve(sizeof(double) * tot_ir)); HIPCHK(c, L.b1.reserve(sizeof(double) * tot_n)); HIPCHK(c, L.b2.reserve(sizeof(double) * tot_n)); }
+    if (tot_ps) { HIPCHK(c, L.psum.reserve(sizeof(double) * tot_ps)); HIPCHK(c, L.pnan.reserve(sizeof(unsigned) * tot_ps)); }
+    if (tot_rawel) {
+        HIPCHK(c, L.raw.reserve(sizeof(float) * tot_rawel));
+        if (j->balf64) HIPCHK(c, L.bal.reserve(sizeof(double) * tot_rawel));
+        HIPCHK(c, L.weight.reserve(sizeof(double) * tot_hn));
+    }
+    if (dense) {
+        const size_t de = j->bands[0].dense_elems;
+        HIPCHK(c, L.dE.reserve(sizeof(double2) * de));
+        HIPCHK(c, L.dW.reserve(de));
+        if (sums) HIPCHK(c, L.dS.reserve(sizeof(double4) * de));
+    }
+    if (L.h_head_cap < tot_head) {
+        if (L.h_head) (void)hipHostFree(L.h_head);
+        L.h_head = nullptr; L.h_head_cap = 0;
+        HIPCHK(c, hipHostMalloc(&L.h_head, tot_head + tot_head / 4, hipHostMallocMapped));
+        L.h_head_cap = tot_head + tot_head / 4;
+    }
+    const size_t desc_bytes = sizeof(HpkBandDesc) * 2 * (size_t)nb;
+    if (L.h_desc_cap < desc_bytes) {
+        if (L.h_desc) (void)hipHostFree(L.h_desc);
+        L.h_desc = nullptr; L.h_desc_cap = 0;
+        HIPCHK(c, hipHostMalloc(&L.h_desc, desc_bytes * 2, hipHostMallocDefault));
+        L.h_desc_cap = desc_bytes * 2;
+    }
+
+    // ---- inputs: host arrays are uploaded on the lane's side stream; device arrays are used where they are
     if (j->phases) (void)hipEventRecord(L.ev[0], c->stream);
-    rc = stage_inputs(c, L, band, plan.mw, &j->in);
-    if (rc != HPK_OK) return rc;
-    const Staged& in = j->in;
+    for (int b = 0; b < nb; ++b) {
+        BandSlot& s = j->bands[b];
+        const hpk_band& in = s.in;
+        const size_t n = (size_t)s.n, num = (size_t)s.num, ld = (size_t)s.ld;
+        Staged& st = s.st;
+        const bool derive = s.d.derive != 0;
+        if (in.on_device) {
+            st.raw = in.raw; st.bal = in.balanced; st.weight = in.weight;
+            st.IR = const_cast<double*>(in.IR); st.b1 = const_cast<double*>(in.bias1); st.b2 = const_cast<double*>(in.bias2);
+        } else {
+            float* draw = L.raw.as<float>() + off_rawel[b];
+            HIPCHK(c, hipMemcpyAsync(draw, in.raw, sizeof(float) * n * ld, hipMemcpyHostToDevice, L.up));
+            st.raw = draw;
+            if (in.balanced) {
+                double* dbal = L.bal.as<double>() + off_rawel[b];
+                HIPCHK(c, hipMemcpyAsync(dbal, in.balanced, sizeof(double) * n * ld, hipMemcpyHostToDevice, L.up));
+                st.bal = dbal;
+            }
+            if (in.weight) {
+                double* dw = L.weight.as<double>() + off_hn[b];
+                HIPCHK(c, hipMemcpyAsync(dw, in.weight, sizeof(double) * n, hipMemcpyHostToDevice, L.up));
+                st.weight = dw;
+            }
+            if (!derive) {
+                st.IR = L.IR.as<double>() + off_ir[b];
+                HIPCHK(c, hipMemcpyAsync(st.IR, in.IR, sizeof(double) * num, hipMemcpyHostToDevice, L.up));
+                st.b1 = L.b1.as<double>() + off_n[b];
+                HIPCHK(c, hipMemcpyAsync(st.b1, in.bias1, sizeof(double) * n, hipMemcpyHostToDevice, L.up));
+                if (in.bias2 == in.bias1) st.b2 = st.b1;
+                else {
+                    st.b2 = L.b2.as<double>() + off_n[b];
+                    HIPCHK(c, hipMemcpyAsync(st.b2, in.bias2, sizeof(double) * n, hipMemcpyHostToDevice, L.up));
+                }
+            }
+        }
+        if (derive) {      // IR / biases from raw + weight on the device (scripts/pyHICCUPS:149-166): hpk_launch_prep below
+            st.IR = L.IR.as<double>() + off_ir[b];
+            st.b1 = L.b1.as<double>() + off_n[b];
+            st.b2 = st.b1;
+        }
+        // descriptor: pointers
+        HpkBandDesc& d = s.d;
+        unsigned char* small = L.small.as<unsigned char>() + s.small_off;
+        d.raw = st.raw; d.weight = st.weight; d.bal = st.bal;
+        d.rec_ent = L.recE.as<unsigned>() + off_rec[b];
+        d.rec_S = L.recS.as<double2>() + off_recS[b];
+        d.rec_W = L.recW.as<uint8_t>() + off_recS[b];
+        d.tile_cnt = reinterpret_cast<unsigned*>(small + s.off_tc);
+        d.units = L.units.as<uint2>() + off_units[b];
+        d.small = small;
+        d.gap = small + s.off_rowlive;
+        d.hist_acc = reinterpret_cast<unsigned long long*>(small + s.off_hacc);
+        d.IR = st.IR; d.b1 = st.b1; d.b2 = st.b2;
+        d.etab = L.etab.as<double>() + etab_el * b;
+        d.eedge = L.eedge.as<double>() + eedge_el * b;
+        if (derive) { d.psum = L.psum.as<double>() + off_ps[b]; d.pnan = L.pnan.as<unsigned>() + off_ps[b]; }
+        if (j->do_score) { d.surv = L.surv.as<HpkSurv>() + off_surv[b]; d.surv2 = L.surv2.as<HpkSurv>() + off_surv[b]; }
+        d.chunk_used = reinterpret_cast<unsigned*>(small + s.off_cu);
+        d.cnt = reinterpret_cast<unsigned*>(small + s.off_cnt);
+        d.head_host = static_cast<unsigned char*>(L.h_head) + s.head_off;
+        // Which candidates get a record.  Dense outputs and probes want every candidate; the scoring kernel needs those
+        // resolved up to the width the widening freezes at, which the chromosomes collected last with the same parameters
+        // tell within a step or so (option spec = 0: no guess, every resolved candidate; spec_margin: widths added to it).
+        d.wguess = 255;
+        if (j->do_score && !dense) {
+            d.wguess = W;
+            if (opt.spec && c->hint_n > 0 && std::memcmp(&key, &c->hint_key, sizeof(key)) == 0) {
+                int hw = -1;
+                for (int i = 0; i < c->hint_n; ++i) hw = std::max(hw, c->hint_w[i]);
+                if (hw >= 0) d.wguess = std::min(W, hw + opt.spec_margin);
+            }
+            if (opt.spec_force >= 0) d.wguess = std::min(W, opt.spec_force);        // tests: a bound that is too narrow
+        }
+    }
+    {   // descriptors: [0, nb) as the batch runs them, [nb, 2 nb) for a chromosome computed once more on its own
+        HpkBandDesc* hd = static_cast<HpkBandDesc*>(L.h_desc);
+        for (int b = 0; b < nb; ++b) {
+            hd[b] = j->bands[b].d;
+            hd[nb + b] = j->bands[b].d;
+            hd[nb + b].k0 = 0;
+            if (hd[nb + b].wguess != 255) hd[nb + b].wguess = W;
+            hd[nb + b].score_wgs = j->gmax;
+        }
+        HIPCHK(c, hipMemcpyAsync(L.desc.p, hd, desc_bytes, hipMemcpyHostToDevice, L.up));
+    }
     if (!plan_hit) {
         HIPCHK(c, L.plan.reserve(sizeof(HpkDevPlan)));
         HIPCHK(c, hipMemcpyAsync(L.plan.p, &L.plan_host, sizeof(HpkDevPlan), hipMemcpyHostToDevice, L.up));
         L.plan_key = key;
         L.plan_valid = true;
     }
-    HIPCHK(c, L.etab.reserve(sizeof(double) * std::max<size_t>((size_t)plan.nsteps * 2 * (D + 1), 1)));
-    HIPCHK(c, L.eedge.reserve(sizeof(double) * std::max<size_t>((size_t)2 * W * plan.nsteps * 2 * (D + 1), 1)));
-    const int64_t ldo = ((int64_t)(D + 1) + 31) / 32 * 32;
-    const size_t dense_elems = (size_t)plan.nslots * (size_t)n * (size_t)ldo;
-    j->ldo = ldo; j->dense_elems = dense_elems;
-    if (dense) {
-        HIPCHK(c, L.dE.reserve(sizeof(double2) * dense_elems));
-        HIPCHK(c, L.dW.reserve(dense_elems));
-        if (sums) HIPCHK(c, L.dS.reserve(sizeof(double4) * dense_elems));
+    // The derivation of IR / biases and the expected tables (the same launch zero-fills the counter blocks) run on the
+    // lane's side stream like the uploads: for the batch submitted one ahead this executes beside the scoring and cut
+    // kernels of the batch before (those leave registers and LDS free; the stencil does not); the compute stream waits
+    // for the lot.
+    if (any_derive) {
+        hpk_launch_prep(L.desc.as<HpkBandDesc>(), nb, max_dn, max_dnum, mw, L.up);
+        HIPCHK(c, hipGetLastError());
     }
-    // One block, zero-filled by a single memset:
-    //   head (one D2H copy):  counters | row-has-signal flags [n] | first HEAD_INLINE compacted survivors
-    //   scratch:              per-workgroup histograms | per-tile record counts | tightening counters | chunk fill counts
-    const int J_ = (TR + D - mw + TC - 1) / TC;
-    const int ntiles_ = ((n + TR - 1) / TR) * J_;
-    const int grid_ = std::max(8, std::min((c->cus / 8) * 8, ((ntiles_ + 7) / 8) * 8));
-    int64_t band_px = 0;                    // pixels with mw <= d <= D inside the matrix
-    for (int d = mw; d <= std::min(D, num - 1); ++d) if (n - d > 0) band_px += n - d;
-    j->band_px = band_px;
-    // survivor capacity per region; every scoring wave may hold one partly filled chunk of HPK_SCH records
-    int64_t cap = (std::max<int64_t>(1 << 16, band_px * j->nsets / 6) + (int64_t)c->cus * 8 * 4 * HPK_SCH * 2) / HPK_NREG;
-    if (const char* e = std::getenv("HPK_SURV_CAP")) cap = std::max<int64_t>(256, std::atoll(e));     // tests: force the overflow rerun
-    cap = (cap + 255) / 256 * 256;
-    j->cap = cap;
-    auto up256 = [](size_t v) { return (v + 255) / 256 * 256; };
-    const size_t off_rowlive = up256(SMALL_BYTES);
-    const size_t off_inl = up256(off_rowlive + (size_t)n);
-    const size_t head_bytes = off_inl + sizeof(HpkSurv) * HEAD_INLINE;
-    const size_t off_hp = up256(head_bytes);
-    const size_t off_tc = up256(off_hp + sizeof(unsigned) * (size_t)grid_ * (HPK_MAX_STEPS + 1));
-    const size_t off_cnt = up256(off_tc + sizeof(unsigned) * (size_t)ntiles_);
-    const size_t off_cu = up256(off_cnt + sizeof(unsigned) * HPK_NFAM * HPK_TIGHTEN_MAX);
-    const size_t zero_bytes = (off_cu + sizeof(unsigned) * (size_t)(cap / HPK_SCH * HPK_NREG + 1) + 4095) / 4096 * 4096;
-    j->off_rowlive = off_rowlive; j->off_inl = off_inl; j->head_bytes = head_bytes; j->off_cnt = off_cnt; j->off_cu = off_cu;
-    j->zero_bytes = zero_bytes; j->key = key;
-    HIPCHK(c, L.small.reserve(zero_bytes));
-    // expected tables of this chromosome; the same launch zero-fills the block (extra workgroups).  On the lane's side
-    // stream, like the uploads and the derivation of IR / biases: for the chromosome submitted one ahead this runs beside
-    // the scoring and cut kernels of the chromosome before; the compute stream waits for the lot.
-    static const bool etab_main = std::getenv("HPK_ETAB_MAIN") != nullptr;        // A/B: everything on the compute stream
-    if (etab_main) {
-        HIPCHK(c, hipEventRecord(L.ev_up, L.up));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, L.ev_up, 0));
-    }
-    hpk_launch_etab(L.plan.as<HpkDevPlan>(), plan.nsteps, D, W, in.IR, n, num, L.etab.as<double>(), L.eedge.as<double>(),
-                    L.small.p, zero_bytes, etab_main ? c->stream : L.up);
+    hpk_launch_etab(L.plan.as<HpkDevPlan>(), L.desc.as<HpkBandDesc>(), nb, plan.nsteps, D, W, j->max_zero, L.up);
     HIPCHK(c, hipGetLastError());
-    if (!etab_main) {
-        HIPCHK(c, hipEventRecord(L.ev_up, L.up));
-        HIPCHK(c, hipStreamWaitEvent(c->stream, L.ev_up, 0));
-    }
-    if (L.h_head_cap < head_bytes) {
-        if (L.h_head) (void)hipHostFree(L.h_head);
-        L.h_head = nullptr; L.h_head_cap = 0;
-        HIPCHK(c, hipHostMalloc(&L.h_head, head_bytes + head_bytes / 4, hipHostMallocMapped));
-        L.h_head_cap = head_bytes + head_bytes / 4;
-    }
+    HIPCHK(c, hipEventRecord(L.ev_up, L.up));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, L.ev_up, 0));
     if (dense) {   // pixels outside the band are never written by the kernel
-        HIPCHK(c, hipMemsetAsync(L.dE.p, 0, sizeof(double2) * dense_elems, c->stream));
-        HIPCHK(c, hipMemsetAsync(L.dW.p, 0, dense_elems, c->stream));
-        if (sums) HIPCHK(c, hipMemsetAsync(L.dS.p, 0, sizeof(double4) * dense_elems, c->stream));
+        const size_t de = j->bands[0].dense_elems;
+        HIPCHK(c, hipMemsetAsync(L.dE.p, 0, sizeof(double2) * de, c->stream));
+        HIPCHK(c, hipMemsetAsync(L.dW.p, 0, de, c->stream));
+        if (sums) HIPCHK(c, hipMemsetAsync(L.dS.p, 0, sizeof(double4) * de, c->stream));
     }
 
-    unsigned char* small = L.small.as<unsigned char>();
-    unsigned long long* d_hist = reinterpret_cast<unsigned long long*>(small + OFF_HIST);
-    int32_t* d_frozen = reinterpret_cast<int32_t*>(small + OFF_FROZEN);
-    int32_t* d_err = reinterpret_cast<int32_t*>(small + OFF_ERR);
-    int32_t* d_exec = reinterpret_cast<int32_t*>(small + OFF_EXEC);
-
-    // ---- stencil
+    // ---- common kernel arguments
     HpkStencilArgs& sa = j->sa;
     std::memset(&sa, 0, sizeof(sa));
-    sa.raw = in.raw; sa.bal = in.bal; sa.weight = in.weight;
     sa.plan = L.plan.as<HpkDevPlan>();
-    sa.hist = d_hist;
-    sa.n = n; sa.num = num; sa.ld = band->ld; sa.ldo = ldo; sa.W = W; sa.mw = mw; sa.D = D; sa.TR = TR; sa.TC = TC;
-    sa.J = J_;
-    sa.ntiles = ntiles_;
-    sa.chunk = (sa.ntiles + 7) / 8;
-    { const char* e = std::getenv("HPK_DBG_STOP"); sa.dbg_stop = e ? std::atoi(e) : 0; }
-    { const char* e = std::getenv("HPK_TILE_ORDER"); sa.order = e ? std::atoi(e) : 1; }
-    sa.grid = std::max(8, std::min((c->cus / 8) * 8, ((sa.chunk + 0) * 8)));
-    sa.hist_part = reinterpret_cast<unsigned*>(small + off_hp);
-    sa.tilecap = TR * TC;
-    sa.rec_stride = (int64_t)sa.ntiles * sa.tilecap;
-    HIPCHK(c, L.recE.reserve(sizeof(unsigned) * (size_t)sa.rec_stride));
-    HIPCHK(c, L.recS.reserve(sizeof(double2) * (size_t)sa.rec_stride * plan.nslots));
-    HIPCHK(c, L.recW.reserve((size_t)sa.rec_stride * plan.nslots));
-    sa.rec_ent = L.recE.as<unsigned>(); sa.rec_S = L.recS.as<double2>(); sa.rec_W = L.recW.as<uint8_t>();
-    sa.tile_cnt = reinterpret_cast<unsigned*>(small + off_tc);
-    {   // at most ceil(tilecap / HPK_UNIT) units per tile
-        const size_t upt = ((size_t)sa.tilecap + HPK_UNIT - 1) / HPK_UNIT;
-        HIPCHK(c, L.units.reserve(sizeof(uint2) * (size_t)sa.ntiles * upt + 16));
-        sa.units = L.units.as<uint2>();
-        sa.nunits = reinterpret_cast<unsigned*>(small + OFF_NUNITS);
-    }
-    sa.gap = small + off_rowlive;
+    sa.risk = std::ldexp(1.0, -opt.risk_log2);
+    sa.nbands = nb;
+    sa.W = W; sa.mw = mw; sa.D = D; sa.TR = TR; sa.TC = TC; sa.J = J_; sa.tilecap = tilecap;
+    sa.single = plan.single_p >= 0 ? 1 : 0;
+    sa.order = opt.tile_order;
+    sa.dbg_stop = opt.dbg_stop;
     sa.clk = nullptr;
 #ifdef HPK_PHASE_CLOCK
     if (std::getenv("HPK_CLK_DUMP")) {
@@ -705,119 +806,64 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* band, const hpk_params* 
         sa.clk = c->tmpD.as<unsigned long long>();
     }
 #endif
-    sa.ticket = std::getenv("HPK_FREEZE_KERNEL") ? nullptr : reinterpret_cast<unsigned*>(small + OFF_NUNITS + 4);
-    // default: the workgroups add their resolve counts into totals (the zeroed partial-count area, one word per 128 bytes)
-    // and the freeze decision is replayed where it is needed; HPK_FREEZE_TICKET=1: by the stencil's last workgroup as before
-    sa.hist_acc = nullptr;
-    const char* ft = std::getenv("HPK_FREEZE_TICKET");
-    if (!(ft && std::atoi(ft) != 0) && !std::getenv("HPK_FREEZE_KERNEL") &&
-        sizeof(unsigned) * (size_t)grid_ * (HPK_MAX_STEPS + 1) >= 8 * (size_t)(HPK_MAX_STEPS + 1) * HPK_ACC_STRIDE) {
-        sa.hist_acc = reinterpret_cast<unsigned long long*>(small + off_hp);
-        sa.ticket = nullptr;
-    }
-    sa.frozen = d_frozen; sa.executed = d_exec; sa.err = d_err;
-    sa.single = plan.single_p >= 0 ? 1 : 0;
-    { const char* e = std::getenv("HPK_RISK_LOG2"); sa.risk = std::ldexp(1.0, e ? -std::atoi(e) : -12); }
-    j->time_stencil = j->phases || !(prm->flags & HPK_FLAG_NO_STENCIL_TIMING);
-    j->simple = plan.simple_reads != 0 && !std::getenv("HPK_GENERIC_SEARCH");
-    // Which candidates get a record.  Dense outputs and probes want every candidate; the scoring kernel needs those
-    // resolved up to the width the widening freezes at, which the chromosome collected last with the same parameters
-    // tells within a step or so (HPK_SPEC=0: no guess, every resolved candidate; HPK_SPEC_MARGIN: widths added to it).
-    sa.wguess = 255;
-    if (j->do_score && !dense) {
-        static const bool spec = !(std::getenv("HPK_SPEC") && std::atoi(std::getenv("HPK_SPEC")) == 0);
-        static const int margin = std::getenv("HPK_SPEC_MARGIN") ? std::atoi(std::getenv("HPK_SPEC_MARGIN")) : 0;
-        sa.wguess = W;
-        if (spec && c->hint_w >= 0 && std::memcmp(&key, &c->hint_key, sizeof(key)) == 0) sa.wguess = std::min(W, c->hint_w + margin);
-        if (const char* e = std::getenv("HPK_SPEC_FORCE")) sa.wguess = std::min(W, std::max(0, std::atoi(e)));     // tests: a bound that is too narrow
-    }
-    rc = launch_stencil_stage(c, j);
-    if (rc != HPK_OK) return rc;
-    return launch_scoring(c, j, 0);
+    j->use_s = hpk_stencil_s_applies(sa, j->simple, max_ld, max_n);
+    HpkScoreArgs& sc = j->sc;
+    std::memset(&sc, 0, sizeof(sc));
+    sc.tilecap = tilecap; sc.TR = TR; sc.TC = TC; sc.J = J_; sc.W = W;
+    sc.plan = sa.plan;
+    sc.bounds = c->d_bounds.as<double>(); sc.ptab = c->d_ptab.as<double>();
+    sc.ptab_off = c->d_off.as<int32_t>(); sc.sfe = c->d_sfe.as<double>(); sc.sig = prm->sig;
+    sc.mw = mw; sc.D = D;
+    sc.hbins = hbins; sc.nsets_half = plan.npairs;
+    return launch_compute(c, j, 0, nb, false, true);
 }
 
-int collect_impl(hpk_ctx* c, hpk_job* j, hpk_result** out) {
+// the host half of one band whose head has landed: widening log, lambda chunks, Benjamini-Hochberg, result arrays
+int finish_band(hpk_ctx* c, hpk_job* j, int b) {
     Lane& L = c->lane[j->lane];
     const HpkDevPlan& plan = L.plan_host;
     const hpk_params* prm = &j->prm;
-    const int n = j->n, num = j->num, nsets = j->nsets, mw = plan.mw, D = plan.D, TR = j->TR, TC = j->TC;
+    BandSlot& s = j->bands[b];
+    const int n = s.n, nsets = j->nsets, mw = plan.mw, D = plan.D;
     const bool sums = j->sums, dense = j->dense, do_score = j->do_score;
-    const size_t off_rowlive = j->off_rowlive, off_inl = j->off_inl, dense_elems = j->dense_elems;
-    const int64_t ldo = j->ldo;
-    const HpkStencilArgs& sa = j->sa;
-    const Staged& in = j->in;
-    ResultBox* box = j->box;
+    ResultBox* box = s.box;
     hpk_result& R = box->pub;
-    (void)num; (void)mw;
-    const unsigned char* hsmall = static_cast<const unsigned char*>(L.h_head);
-    for (int attempt = 0;; ++attempt) {
-        HIPCHK(c, hipEventSynchronize(L.ev_done));       // this chromosome only; the next one keeps running
-        {   // the widening froze later than the bound the stencil wrote records up to: once more, with every resolved candidate
-            const int32_t fz = *reinterpret_cast<const int32_t*>(hsmall + OFF_FROZEN);
-            const int32_t er = *reinterpret_cast<const int32_t*>(hsmall + OFF_ERR);
-            if (do_score && er == 0 && j->sa.wguess < plan.W && fz > j->sa.wguess) {
-                j->sa.wguess = plan.W;
-                j->redone = true;
-                c->spec_reruns += 1;
-                HIPCHK(c, hipMemsetAsync(L.small.p, 0, j->zero_bytes, c->stream));
-                int rc = launch_stencil_stage(c, j);
-                if (rc == HPK_OK) rc = launch_scoring(c, j, 0);
-                if (rc != HPK_OK) return rc;
-                attempt = -1;
-                continue;
-            }
-        }
-        unsigned long long ns = 0;              // fullest region
-        for (int rg = 0; rg < HPK_NREG; ++rg)
-            ns = std::max(ns, reinterpret_cast<const unsigned long long*>(hsmall + OFF_NSURV)[rg * HPK_REG_STRIDE]);
-        if (!do_score || (int64_t)ns <= j->cap) break;
-        if (attempt == 1) return fail(c, HPK_ERR_NOMEM, "survivor buffer overflow");
-        j->cap = ((int64_t)ns * 2 + 1024 + 255) / 256 * 256;      // rerun the scoring with room for everything
-        int rc = launch_scoring(c, j, 1);
-        if (rc != HPK_OK) return rc;
-    }
-#ifdef HPK_PHASE_CLOCK
-    if (const char* path = std::getenv("HPK_CLK_DUMP")) {       // [grid][waves][8] u64, overwritten by every chromosome
-        std::vector<unsigned long long> h((size_t)8 * HPK_NWAVES * sa.grid);
-        HIPCHK(c, hipMemcpy(h.data(), c->tmpD.p, h.size() * 8, hipMemcpyDeviceToHost));
-        if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
-    }
-#endif
+    const unsigned char* hsmall = static_cast<const unsigned char*>(L.h_head) + s.head_off;
     box->gap.resize(n);
-    for (int r = 0; r < n; ++r) box->gap[r] = hsmall[off_rowlive + r] ? 0 : 1;
-    R.band_px = j->band_px;
-    R.stencil_tiles = sa.ntiles;
-    R.stencil_kernel = hpk_stencil_s_applies(sa, j->simple) ? 2 : 1;
+    for (int r = 0; r < n; ++r) box->gap[r] = hsmall[s.off_rowlive + r] ? 0 : 1;
+    R.band_px = s.band_px;
+    R.stencil_tiles = s.ntiles;
+    R.stencil_kernel = j->use_s ? 2 : 1;
+    R.batch_bands = (int32_t)j->bands.size();
 
-    // ---- results to host
-    const unsigned long long* h_hist = reinterpret_cast<const unsigned long long*>(hsmall + OFF_HIST);
-    const int32_t h_frozen = *reinterpret_cast<const int32_t*>(hsmall + OFF_FROZEN);
-    const int32_t h_err = *reinterpret_cast<const int32_t*>(hsmall + OFF_ERR);
-    if (do_score && h_err == 0) { c->hint_w = h_frozen; c->hint_key = j->key; }      // the next stencil's record bound
-    R.record_bound = sa.wguess;
-    R.redone = j->redone ? 1 : 0;
-    const int32_t* h_exec = reinterpret_cast<const int32_t*>(hsmall + OFF_EXEC);
-    const unsigned long long h_nsurv = *reinterpret_cast<const unsigned long long*>(hsmall + OFF_NOUT);
-    const unsigned long long* h_emax = reinterpret_cast<const unsigned long long*>(hsmall + OFF_EMAX);
-    const unsigned int* h_chist = reinterpret_cast<const unsigned int*>(hsmall + OFF_FAM_M);
+    const unsigned long long* h_hist = reinterpret_cast<const unsigned long long*>(hsmall + HPK_OFF_HIST);
+    const int32_t h_frozen = *reinterpret_cast<const int32_t*>(hsmall + HPK_OFF_FROZEN);
+    const int32_t h_err = *reinterpret_cast<const int32_t*>(hsmall + HPK_OFF_ERR);
+    R.record_bound = s.d.wguess;
+    R.redone = s.redone ? 1 : 0;
+    const int32_t* h_exec = reinterpret_cast<const int32_t*>(hsmall + HPK_OFF_EXEC);
+    const unsigned long long h_nsurv = *reinterpret_cast<const unsigned long long*>(hsmall + HPK_OFF_NOUT);
+    const unsigned long long* h_emax = reinterpret_cast<const unsigned long long*>(hsmall + HPK_OFF_EMAX);
+    const unsigned int* h_chist = reinterpret_cast<const unsigned int*>(hsmall + HPK_OFF_FAM_M);
 
     R.nsteps = plan.nsteps;
-    for (int s = 0; s < plan.nsteps; ++s) {
-        R.step_pi[s] = plan.steps[s].pi;
-        R.step_wi[s] = plan.steps[s].wi;
-        R.step_executed[s] = h_exec[s];
-        R.step_resolved[s] = (int64_t)h_hist[s];
+    for (int t = 0; t < plan.nsteps; ++t) {
+        R.step_pi[t] = plan.steps[t].pi;
+        R.step_wi[t] = plan.steps[t].wi;
+        R.step_executed[t] = h_exec[t];
+        R.step_resolved[t] = (int64_t)h_hist[t];
     }
     R.frozen_w = h_frozen;
     R.nslots = plan.nslots;
     for (int q = 0; q < plan.nslots; ++q) R.slot_pi[q] = plan.slot_pi[q];
     R.ncand = (int64_t)h_hist[HPK_HIST_NCAND];
     R.nsurv_sig = 0;
-    for (int i = 0; i < nsets * (HPK_NB + 1); ++i)      // (only the families of the sets in use are copied back)
-        R.nsurv_sig += reinterpret_cast<const unsigned int*>(hsmall + OFF_FAM_F)[i];
+    if (do_score)
+        for (int i = 0; i < nsets * (HPK_NB + 1); ++i)      // (only the families of the sets in use are copied back)
+            R.nsurv_sig += reinterpret_cast<const unsigned int*>(hsmall + HPK_OFF_FAM_F)[i];
     R.nsurv_cut = (int64_t)h_nsurv;
     R.gap = box->gap.data();
-    if (h_err != 0 && sa.dbg_stop == 0) {
+    if (h_err != 0 && c->opt.dbg_stop == 0) {
         const HpkDevStep& st = plan.steps[h_err - 1];
         return fail(c, HPK_ERR_EMPTY_STEP, "step (%d,%d) entered with no unresolved candidate (of %lld); the reference raises here "
                     "(hicpeaks/callers.py:203-208)", st.pi, st.wi, (long long)R.ncand);
@@ -827,16 +873,15 @@ int collect_impl(hpk_ctx* c, hpk_job* j, hpk_result** out) {
     std::vector<Surv> sv;
     if (do_score && h_nsurv) {
         const size_t ns = (size_t)h_nsurv;
-        const HpkSurv* head = reinterpret_cast<const HpkSurv*>(hsmall + off_inl);
-        std::vector<HpkSurv> rest;
-        if (ns > HEAD_INLINE) {
-            rest.resize(ns - HEAD_INLINE);
-            // beyond the inlined head: fetched on the lane's own (idle) copy stream, so the next chromosome's kernels
-            // on the compute stream are not waited for
-            HIPCHK(c, hipMemcpyAsync(rest.data(), L.surv2.p, sizeof(HpkSurv) * (ns - HEAD_INLINE), hipMemcpyDeviceToHost, L.up));
+        const HpkSurv* head = reinterpret_cast<const HpkSurv*>(hsmall + s.off_inl);
+        if (ns > HPK_HEAD_INLINE && !s.rest_fetched) {
+            s.rest.resize(ns - HPK_HEAD_INLINE);
+            // beyond the inlined head: fetched on the lane's own (idle) copy stream, so the next batch's kernels on the
+            // compute stream are not waited for
+            HIPCHK(c, hipMemcpyAsync(s.rest.data(), s.d.surv2, sizeof(HpkSurv) * (ns - HPK_HEAD_INLINE), hipMemcpyDeviceToHost, L.up));
             HIPCHK(c, hipStreamSynchronize(L.up));
         }
-        auto rec_at = [&](size_t i) -> const HpkSurv& { return i < HEAD_INLINE ? head[i] : rest[i - HEAD_INLINE]; };
+        auto rec_at = [&](size_t i) -> const HpkSurv& { return i < HPK_HEAD_INLINE ? head[i] : s.rest[i - HPK_HEAD_INLINE]; };
         sv.resize(ns);
         for (size_t i = 0; i < ns; ++i) {
             const HpkSurv& rc_ = rec_at(i);
@@ -844,14 +889,16 @@ int collect_impl(hpk_ctx* c, hpk_job* j, hpk_result** out) {
         }
     }
     if (dense) {
+        const HpkBandDesc& d = s.d;
         HpkDenseArgs da;
-        da.rec_ent = sa.rec_ent; da.rec_S = sa.rec_S; da.rec_W = sa.rec_W; da.tile_cnt = sa.tile_cnt;
-        da.tilecap = sa.tilecap; da.rec_stride = sa.rec_stride; da.ntiles = sa.ntiles; da.TR = TR; da.TC = TC; da.J = sa.J;
-        da.plan = sa.plan; da.etab = L.etab.as<double>(); da.eedge = L.eedge.as<double>();
-        da.IR = in.IR; da.b1 = in.b1; da.b2 = in.b2; da.n = n; da.num = num; da.ldo = ldo; da.mw = mw; da.D = D;
+        da.rec_ent = d.rec_ent; da.rec_S = d.rec_S; da.rec_W = d.rec_W; da.tile_cnt = d.tile_cnt;
+        da.tilecap = j->sa.tilecap; da.rec_stride = d.rec_stride; da.ntiles = s.ntiles; da.TR = j->sa.TR; da.TC = j->sa.TC; da.J = j->sa.J;
+        da.plan = j->sa.plan; da.etab = d.etab; da.eedge = d.eedge;
+        da.IR = d.IR; da.b1 = d.b1; da.b2 = d.b2; da.n = n; da.num = s.num; da.ldo = s.ldo; da.mw = mw; da.D = D;
         da.dE = L.dE.as<double2>(); da.dW = L.dW.as<uint8_t>(); da.dS = sums ? L.dS.as<double4>() : nullptr;
         hpk_launch_dense(da, c->stream);
         HIPCHK(c, hipGetLastError());
+        const size_t dense_elems = s.dense_elems;
         box->denseE.resize(dense_elems * 2);
         box->denseW.resize(dense_elems);
         HIPCHK(c, hipMemcpyAsync(box->denseE.data(), L.dE.p, sizeof(double2) * dense_elems, hipMemcpyDeviceToHost, c->stream));
@@ -861,7 +908,7 @@ int collect_impl(hpk_ctx* c, hpk_job* j, hpk_result** out) {
             HIPCHK(c, hipMemcpyAsync(box->denseS.data(), L.dS.p, sizeof(double4) * dense_elems, hipMemcpyDeviceToHost, c->stream));
         }
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        R.dense_ld = ldo;
+        R.dense_ld = s.ldo;
         R.dense_E = box->denseE.data();
         R.dense_w = box->denseW.data();
         R.dense_sums = sums ? box->denseS.data() : nullptr;
@@ -877,94 +924,183 @@ int collect_impl(hpk_ctx* c, hpk_job* j, hpk_result** out) {
         struct Key { uint32_t fam, idx; uint64_t pbits; };
         std::vector<Key> keys(sv.size());
         for (size_t i = 0; i < sv.size(); ++i) {
-            uint64_t b;
-            std::memcpy(&b, &sv[i].p, 8);
-            keys[i] = Key{(uint32_t)sv[i].set << 8 | sv[i].chunk, (uint32_t)i, b};
+            uint64_t bits;
+            std::memcpy(&bits, &sv[i].p, 8);
+            keys[i] = Key{(uint32_t)sv[i].set << 8 | sv[i].chunk, (uint32_t)i, bits};
         }
-        std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
-            return a.fam != b.fam ? a.fam < b.fam : a.pbits < b.pbits; });
+        std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b2) {
+            return a.fam != b2.fam ? a.fam < b2.fam : a.pbits < b2.pbits; });
         std::vector<Surv*> order(sv.size());
         for (size_t i = 0; i < sv.size(); ++i) order[i] = &sv[keys[i].idx];
         const double t_h1 = now_ms();
         std::vector<int> numbins(nsets, 0);
         box->fam.resize((size_t)2 * nsets * (HPK_NB + 1));
         std::memcpy(box->fam.data(), h_chist, sizeof(uint32_t) * (size_t)nsets * (HPK_NB + 1));
-        std::memcpy(box->fam.data() + (size_t)nsets * (HPK_NB + 1), hsmall + OFF_FAM_F, sizeof(uint32_t) * (size_t)nsets * (HPK_NB + 1));
-        for (int s = 0; s < nsets; ++s) {
-            hpk_set& hs = R.sets[s];
-            hs.pair = (plan.mode == HPK_MODE_BHFDR) ? 0 : s / 2;
-            hs.fl = (plan.mode == HPK_MODE_BHFDR) ? 0 : s % 2;
+        std::memcpy(box->fam.data() + (size_t)nsets * (HPK_NB + 1), hsmall + HPK_OFF_FAM_F, sizeof(uint32_t) * (size_t)nsets * (HPK_NB + 1));
+        for (int t = 0; t < nsets; ++t) {
+            hpk_set& hs = R.sets[t];
+            hs.pair = (plan.mode == HPK_MODE_BHFDR) ? 0 : t / 2;
+            hs.fl = (plan.mode == HPK_MODE_BHFDR) ? 0 : t % 2;
             // pixels with E > 0: the families of the set added up (family 0 = those without a chunk, not a family of tests)
             hs.nvalid = 0;
-            for (int ch = 0; ch <= HPK_NB; ++ch) hs.nvalid += (int64_t)h_chist[(size_t)s * (HPK_NB + 1) + ch];
-            box->fam[(size_t)s * (HPK_NB + 1)] = 0u;
+            for (int ch = 0; ch <= HPK_NB; ++ch) hs.nvalid += (int64_t)h_chist[(size_t)t * (HPK_NB + 1) + ch];
+            box->fam[(size_t)t * (HPK_NB + 1)] = 0u;
             double emax = 0.0;
-            std::memcpy(&emax, &h_emax[s], 8);
+            std::memcpy(&emax, &h_emax[t], 8);
             hs.emax = emax;
             int numbin = 0;
             if (plan.mode == HPK_MODE_HICCUPS && hs.nvalid > 0) {
-                const double nb = std::ceil(std::log(emax) / std::log(2.0) * 3.0 + 1.0);     // callers.py:30
-                numbin = nb < 0 ? 0 : (nb > HPK_NB ? HPK_NB : (int)nb);
+                const double nbd = std::ceil(std::log(emax) / std::log(2.0) * 3.0 + 1.0);     // callers.py:30
+                numbin = nbd < 0 ? 0 : (nbd > HPK_NB ? HPK_NB : (int)nbd);
             }
             hs.numbin = numbin;
-            hs.chunk_tests = box->fam.data() + (size_t)s * (HPK_NB + 1);
-            hs.chunk_below = box->fam.data() + (size_t)(nsets + s) * (HPK_NB + 1);
+            hs.chunk_tests = box->fam.data() + (size_t)t * (HPK_NB + 1);
+            hs.chunk_below = box->fam.data() + (size_t)(nsets + t) * (HPK_NB + 1);
             // chunks beyond numbin do not exist for the reference (their pixels keep p = q = 1, callers.py:259-260)
             for (int ch = ((plan.mode == HPK_MODE_BHFDR) ? 1 : numbin) + 1; ch <= HPK_NB; ++ch) {
-                box->fam[(size_t)s * (HPK_NB + 1) + ch] = 0u;
-                box->fam[(size_t)(nsets + s) * (HPK_NB + 1) + ch] = 0u;
+                box->fam[(size_t)t * (HPK_NB + 1) + ch] = 0u;
+                box->fam[(size_t)(nsets + t) * (HPK_NB + 1) + ch] = 0u;
             }
-            numbins[s] = (plan.mode == HPK_MODE_BHFDR) ? 1 : numbin;
+            numbins[t] = (plan.mode == HPK_MODE_BHFDR) ? 1 : numbin;
         }
         for (size_t i = 0; i < order.size();) {
-            size_t j = i;
-            while (j < order.size() && order[j]->set == order[i]->set && order[j]->chunk == order[i]->chunk) ++j;
-            const int s = order[i]->set, ch = order[i]->chunk;
-            if (s < nsets && ch >= 1 && ch <= numbins[s]) {        // chunks beyond numbin keep p = q = 1 (callers.py:259-260)
-                bh_family(order.data() + i, j - i, h_chist[(size_t)s * (HPK_NB + 1) + ch], prm->sig, plan.mode == HPK_MODE_BHFDR);
-                for (size_t t = i; t < j; ++t) if (order[t]->keep) kept[s].push_back(order[t]);
+            size_t e = i;
+            while (e < order.size() && order[e]->set == order[i]->set && order[e]->chunk == order[i]->chunk) ++e;
+            const int t = order[i]->set, ch = order[i]->chunk;
+            if (t < nsets && ch >= 1 && ch <= numbins[t]) {        // chunks beyond numbin keep p = q = 1 (callers.py:259-260)
+                bh_family(order.data() + i, e - i, h_chist[(size_t)t * (HPK_NB + 1) + ch], prm->sig, plan.mode == HPK_MODE_BHFDR);
+                for (size_t u = i; u < e; ++u) if (order[u]->keep) kept[t].push_back(order[u]);
             }
-            i = j;
+            i = e;
         }
         const double t_h2 = now_ms();
-        for (int s = 0; s < nsets; ++s)
-            std::sort(kept[s].begin(), kept[s].end(), [](const Surv* a, const Surv* b) {
-                return a->x != b->x ? a->x < b->x : a->y < b->y; });
-        if (std::getenv("HPK_HOST_PROF")) std::fprintf(stderr, "[hpk host] n=%zu sort=%.3f bh=%.3f\n", sv.size(), t_h1 - t_d2h1, t_h2 - t_h1);
+        for (int t = 0; t < nsets; ++t)
+            std::sort(kept[t].begin(), kept[t].end(), [](const Surv* a, const Surv* b2) {
+                return a->x != b2->x ? a->x < b2->x : a->y < b2->y; });
+        if (c->opt.host_prof) std::fprintf(stderr, "[hpk host] n=%zu sort=%.3f bh=%.3f\n", sv.size(), t_h1 - t_d2h1, t_h2 - t_h1);
         size_t total = 0;
-        for (int s = 0; s < nsets; ++s) total += kept[s].size();
+        for (int t = 0; t < nsets; ++t) total += kept[t].size();
         box->x.reserve(total); box->y.reserve(total); box->O.reserve(total); box->bal.reserve(total);
         box->E.reserve(total); box->p.reserve(total); box->q.reserve(total); box->oz.reserve(total);
-        for (int s = 0; s < nsets; ++s) {
-            R.sets[s].begin = (int64_t)box->x.size();
-            for (const Surv* p : kept[s]) {
+        for (int t = 0; t < nsets; ++t) {
+            R.sets[t].begin = (int64_t)box->x.size();
+            for (const Surv* p : kept[t]) {
                 box->x.push_back(p->x); box->y.push_back(p->y); box->O.push_back((double)p->O); box->bal.push_back(p->bal);
                 box->E.push_back(p->E); box->p.push_back(p->p); box->q.push_back(p->q); box->oz.push_back(p->flag);
             }
-            R.sets[s].end = (int64_t)box->x.size();
+            R.sets[t].end = (int64_t)box->x.size();
         }
         R.nsig = (int64_t)total;
         R.x = box->x.data(); R.y = box->y.data(); R.O = box->O.data(); R.bal = box->bal.data();
         R.E = box->E.data(); R.p = box->p.data(); R.q = box->q.data(); R.other_zero = box->oz.data();
     }
     const double t_end = now_ms();
-    if (std::getenv("HPK_HOST_PROF")) std::fprintf(stderr, "[hpk host] total host_bh=%.3f d2h=%.3f\n", t_end - t_d2h1, t_d2h1 - t_d2h0);
-
-    float ms = 0.f;
-    if (j->time_stencil && hipEventElapsedTime(&ms, L.ev[1], L.ev[2]) == hipSuccess) R.ms_stencil = ms;
-    if (j->phases) {
-        if (hipEventElapsedTime(&ms, L.ev[0], L.ev[1]) == hipSuccess) R.ms_h2d = ms;
-        if (hipEventElapsedTime(&ms, L.ev[2], L.ev[3]) == hipSuccess) R.ms_freeze = ms;
-        if (hipEventElapsedTime(&ms, L.ev[3], L.ev[4]) == hipSuccess) R.ms_score = ms;
-        if (hipEventElapsedTime(&ms, L.ev[4], L.ev[5]) == hipSuccess) R.ms_tighten = ms;
-        if (hipEventElapsedTime(&ms, L.ev[5], L.ev[6]) == hipSuccess) R.ms_gap = ms;
-    }
+    if (c->opt.host_prof) std::fprintf(stderr, "[hpk host] total host_bh=%.3f d2h=%.3f\n", t_end - t_d2h1, t_d2h1 - t_d2h0);
     R.ms_d2h = (float)(t_d2h1 - t_d2h0);
     R.ms_host_bh = (float)(t_end - t_d2h1);
+    return HPK_OK;
+}
 
-    R.ms_total = (float)(t_end - j->t_begin);
-    j->box = nullptr;
-    *out = &box->pub;
+// Waits for the batch, recomputes the chromosomes whose record bound was too narrow or whose survivor regions
+// overflowed, and runs the host half of every chromosome.  Per-band outcomes go to the slots' status / err.
+int collect_impl(hpk_ctx* c, hpk_job* j) {
+    Lane& L = c->lane[j->lane];
+    const HpkDevPlan& plan = L.plan_host;
+    const int nb = (int)j->bands.size();
+    HIPCHK(c, hipEventSynchronize(L.ev_done));           // this batch only; the next one keeps running
+    for (int pass = 0; j->do_score; ++pass) {
+        bool again = false;
+        for (int b = 0; b < nb; ++b) {
+            BandSlot& s = j->bands[b];
+            if (s.status != HPK_OK) continue;
+            const unsigned char* hsmall = static_cast<const unsigned char*>(L.h_head) + s.head_off;
+            const int32_t fz = *reinterpret_cast<const int32_t*>(hsmall + HPK_OFF_FROZEN);
+            const int32_t er = *reinterpret_cast<const int32_t*>(hsmall + HPK_OFF_ERR);
+            if (er == 0 && s.d.wguess < plan.W && fz > s.d.wguess) {
+                // the widening froze later than the bound the stencil wrote records up to: once more, with every resolved candidate
+                s.d.wguess = plan.W;
+                s.redone = true;
+                c->spec_reruns += 1;
+                HIPCHK(c, hipMemsetAsync(s.d.small, 0, s.zero_bytes, c->stream));
+                int rc = launch_compute(c, j, b, 1, true, true);
+                if (rc != HPK_OK) return rc;
+                again = true;
+                continue;
+            }
+            unsigned long long ns = 0;              // fullest region
+            for (int rg = 0; rg < HPK_NREG; ++rg)
+                ns = std::max(ns, reinterpret_cast<const unsigned long long*>(hsmall + HPK_OFF_NSURV)[rg * HPK_REG_STRIDE]);
+            if ((int64_t)ns <= s.cap) continue;
+            if (s.overflowed) { s.status = fail(c, HPK_ERR_NOMEM, "survivor buffer overflow"); s.err = c->err; continue; }
+            // a survivor region overflowed: the scoring once more with room for everything, on buffers of its own; one
+            // band at a time (they share the lane's spare buffers), its survivors beyond the inline head are fetched at once
+            s.overflowed = true;
+            s.cap = ((int64_t)ns * 2 + 1024 + 255) / 256 * 256;
+            const size_t cu_bytes = sizeof(unsigned) * (size_t)(s.cap / HPK_SCH * HPK_NREG + 1);
+            HIPCHK(c, L.survx.reserve(sizeof(HpkSurv) * (size_t)s.cap * HPK_NREG));
+            HIPCHK(c, L.survx2.reserve(sizeof(HpkSurv) * (size_t)s.cap * HPK_NREG));
+            HIPCHK(c, L.cux.reserve(cu_bytes));
+            s.d.cap = s.cap; s.d.surv = L.survx.as<HpkSurv>(); s.d.surv2 = L.survx2.as<HpkSurv>(); s.d.chunk_used = L.cux.as<unsigned>();
+            HpkBandDesc* hd = static_cast<HpkBandDesc*>(L.h_desc) + nb + b;
+            *hd = s.d;
+            hd->k0 = 0; hd->score_wgs = j->gmax;
+            HIPCHK(c, hipMemcpyAsync(lane_desc(L, j, b, true), hd, sizeof(HpkBandDesc), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemsetAsync(L.cux.p, 0, cu_bytes, c->stream));
+            HIPCHK(c, hipMemsetAsync(s.d.small + HPK_OFF_NSURV, 0, HPK_SMALL_BYTES - HPK_OFF_NSURV, c->stream));
+            HIPCHK(c, hipMemsetAsync(s.d.small + s.off_cnt, 0, sizeof(unsigned) * HPK_NFAM * HPK_TIGHTEN_MAX, c->stream));
+            int rc = launch_compute(c, j, b, 1, true, false);
+            if (rc != HPK_OK) return rc;
+            HIPCHK(c, hipEventSynchronize(L.ev_done));
+            const unsigned long long nout = *reinterpret_cast<const unsigned long long*>(hsmall + HPK_OFF_NOUT);
+            if (nout > HPK_HEAD_INLINE) {
+                s.rest.resize(nout - HPK_HEAD_INLINE);
+                HIPCHK(c, hipMemcpyAsync(s.rest.data(), s.d.surv2, sizeof(HpkSurv) * (nout - HPK_HEAD_INLINE), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+            }
+            s.rest_fetched = true;
+            again = true;       // (checked once more: a second overflow is an error)
+        }
+        if (!again || pass >= 3) break;
+        HIPCHK(c, hipEventSynchronize(L.ev_done));
+    }
+#ifdef HPK_PHASE_CLOCK
+    if (const char* path = std::getenv("HPK_CLK_DUMP")) {       // [grid][waves][8] u64, overwritten by every batch
+        std::vector<unsigned long long> h((size_t)8 * HPK_NWAVES * 1024);
+        HIPCHK(c, hipMemcpy(h.data(), c->tmpD.p, h.size() * 8, hipMemcpyDeviceToHost));
+        if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
+    }
+#endif
+    // kernel times: events around the batch's launches, split over its chromosomes by band pixels
+    float ms_st = 0.f, ms_h2d = 0.f, ms_fr = 0.f, ms_sc = 0.f, ms_ti = 0.f, ms_gap = 0.f;
+    float ms = 0.f;
+    if (j->time_stencil && hipEventElapsedTime(&ms, L.ev[1], L.ev[2]) == hipSuccess) ms_st = ms;
+    if (j->phases) {
+        if (hipEventElapsedTime(&ms, L.ev[0], L.ev[1]) == hipSuccess) ms_h2d = ms;
+        if (hipEventElapsedTime(&ms, L.ev[2], L.ev[3]) == hipSuccess) ms_fr = ms;
+        if (hipEventElapsedTime(&ms, L.ev[3], L.ev[4]) == hipSuccess) ms_sc = ms;
+        if (hipEventElapsedTime(&ms, L.ev[4], L.ev[5]) == hipSuccess) ms_ti = ms;
+        if (hipEventElapsedTime(&ms, L.ev[5], L.ev[6]) == hipSuccess) ms_gap = ms;
+    }
+    double px_all = 0.0;
+    for (const BandSlot& s : j->bands) px_all += (double)std::max<int64_t>(s.band_px, 1);
+    int fz_max = -1;
+    for (int b = 0; b < nb; ++b) {
+        BandSlot& s = j->bands[b];
+        if (s.status != HPK_OK) continue;
+        const int rc = finish_band(c, j, b);
+        if (rc != HPK_OK) { s.status = rc; s.err = c->err; continue; }
+        hpk_result& R = s.box->pub;
+        const float share = (float)((double)std::max<int64_t>(s.band_px, 1) / px_all);
+        R.ms_stencil = ms_st * share; R.ms_h2d = ms_h2d * share; R.ms_freeze = ms_fr * share; R.ms_score = ms_sc * share;
+        R.ms_tighten = ms_ti * share; R.ms_gap = ms_gap * share;
+        R.ms_total = (float)(now_ms() - j->t_begin);
+        if (j->do_score) fz_max = std::max(fz_max, (int)R.frozen_w);
+    }
+    if (fz_max >= 0) {          // the next stencils' record bound: the widest freeze of the last few collections
+        if (c->hint_n == 0 || std::memcmp(&j->key, &c->hint_key, sizeof(j->key)) != 0) { c->hint_n = 0; c->hint_key = j->key; }
+        if (c->hint_n < 4) c->hint_w[c->hint_n++] = fz_max;
+        else { for (int i = 0; i < 3; ++i) c->hint_w[i] = c->hint_w[i + 1]; c->hint_w[3] = fz_max; }
+    }
     return HPK_OK;
 }
 
@@ -979,20 +1115,24 @@ extern "C" {
 
 int hpk_pipeline_depth(void) { return HPK_LANES; }
 
-int hpk_submit_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_job** job) {
+int hpk_submit_batch(hpk_ctx* c, const hpk_band* bands, int32_t nbands, const hpk_params* prm, hpk_job** job) {
     if (!c) return HPK_ERR_INVALID;
-    if (!job || !prm) return fail(c, HPK_ERR_INVALID, "params / job is NULL");
+    if (!job || !prm || !bands) return fail(c, HPK_ERR_INVALID, "bands / params / job is NULL");
     *job = nullptr;
-    int rc = check_band(c, band);
-    if (rc != HPK_OK) return rc;
+    if (nbands < 1 || nbands > HPK_MAX_BATCH) return fail(c, HPK_ERR_INVALID, "a batch holds 1..%d chromosomes", HPK_MAX_BATCH);
+    for (int b = 0; b < nbands; ++b) {
+        const int rc = check_band(c, bands + b);
+        if (rc != HPK_OK) return rc;
+    }
     const int lane = acquire_lane(c);
-    if (lane < 0) return fail(c, HPK_ERR_BUSY, "all %d lanes hold a chromosome in flight: collect one first", HPK_LANES);
+    if (lane < 0) return fail(c, HPK_ERR_BUSY, "all %d lanes hold a batch in flight: collect one first", HPK_LANES);
     (void)hipSetDevice(c->device);
     hpk_job* j = new hpk_job();
     j->ctx = c; j->lane = lane; j->t_begin = now_ms();
-    rc = submit_impl(c, j, band, prm);
+    const int rc = submit_impl(c, j, bands, nbands, prm);
     if (rc != HPK_OK) {
         (void)hipStreamSynchronize(c->stream);
+        (void)hipStreamSynchronize(c->lane[lane].up);
         delete j;
         return rc;
     }
@@ -1001,16 +1141,46 @@ int hpk_submit_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk
     return HPK_OK;
 }
 
-int hpk_collect(hpk_ctx* c, hpk_job* job, hpk_result** out) {
+int hpk_collect_batch(hpk_ctx* c, hpk_job* job, hpk_result** outs, int32_t* status, char* errmsg, int32_t errmsg_len) {
     if (!c || !job || job->ctx != c) return c ? fail(c, HPK_ERR_INVALID, "job does not belong to this context") : HPK_ERR_INVALID;
-    if (out) *out = nullptr;
+    const int nb = (int)job->bands.size();
+    if (outs) for (int b = 0; b < nb; ++b) outs[b] = nullptr;
     (void)hipSetDevice(c->device);
-    hpk_result* res = nullptr;
-    int rc = collect_impl(c, job, &res);
+    const int rc = collect_impl(c, job);
     if (rc != HPK_OK) (void)hipStreamSynchronize(c->stream);
     c->lane[job->lane].busy = false;
+    if (rc == HPK_OK) {
+        for (int b = 0; b < nb; ++b) {
+            BandSlot& s = job->bands[b];
+            if (status) status[b] = s.status;
+            if (errmsg && errmsg_len > 0) {
+                std::strncpy(errmsg + (size_t)b * errmsg_len, s.err.c_str(), errmsg_len - 1);
+                errmsg[(size_t)b * errmsg_len + errmsg_len - 1] = 0;
+            }
+            if (s.status == HPK_OK && outs) { outs[b] = &s.box->pub; s.box = nullptr; }
+            if (s.status != HPK_OK) c->err = s.err;
+        }
+    }
     delete job;
+    return rc;
+}
+
+int hpk_submit_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_job** job) {
+    return hpk_submit_batch(c, band, 1, prm, job);
+}
+
+int hpk_collect(hpk_ctx* c, hpk_job* job, hpk_result** out) {
+    if (!c || !job || job->ctx != c) return c ? fail(c, HPK_ERR_INVALID, "job does not belong to this context") : HPK_ERR_INVALID;
+    if (job->bands.size() != 1) {
+        (void)hpk_collect_batch(c, job, nullptr, nullptr, nullptr, 0);
+        return fail(c, HPK_ERR_INVALID, "hpk_collect takes single-chromosome jobs; use hpk_collect_batch");
+    }
+    if (out) *out = nullptr;
+    hpk_result* res = nullptr;
+    int32_t st = HPK_OK;
+    const int rc = hpk_collect_batch(c, job, &res, &st, nullptr, 0);
     if (rc != HPK_OK) return rc;
+    if (st != HPK_OK) return st;
     if (out) *out = res; else hpk_result_free(res);
     return HPK_OK;
 }
@@ -1033,7 +1203,7 @@ int64_t hpk_band_from_coo(const int64_t* bin1, const int64_t* bin2, const void* 
     int64_t stored = 0;
     for (int64_t t = 0; t < nnz; ++t) {
         const int64_t a = bin1[t] < bin2[t] ? bin1[t] : bin2[t], b = bin1[t] < bin2[t] ? bin2[t] : bin1[t];
-        if (a < 0 || b >= n) continue;
+        if (a < 0 || b >= n) return HPK_ERR_INVALID;        // a bin outside the chromosome: the caller's offsets are off
         const int64_t k = b - a;
         if (k >= num) continue;                             // beyond the band
         raw[a * ld + k] += count_f64 ? (float)cd[t] : (float)ci[t];
@@ -1052,7 +1222,8 @@ int hpk_probe_sums(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, cons
     int rc = hpk_submit_band(c, band, &p2, &job);
     if (rc != HPK_OK) return rc;
     Lane& L = c->lane[job->lane];
-    const HpkStencilArgs& sa = job->sa;
+    const BandSlot& s = job->bands[0];
+    const HpkBandDesc& d = s.d;
     const HpkDevPlan& plan = L.plan_host;
     auto run = [&]() -> int {
         if (count == 0) return HPK_OK;
@@ -1063,10 +1234,10 @@ int hpk_probe_sums(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, cons
         HIPCHK(c, hipMemcpyAsync(c->tmpB.p, cols, 4 * (size_t)count, hipMemcpyHostToDevice, c->stream));
         HpkDenseArgs da;
         std::memset(&da, 0, sizeof(da));
-        da.rec_ent = sa.rec_ent; da.rec_S = sa.rec_S; da.rec_W = sa.rec_W; da.tile_cnt = sa.tile_cnt;
-        da.tilecap = sa.tilecap; da.rec_stride = sa.rec_stride; da.ntiles = sa.ntiles; da.TR = job->TR; da.TC = job->TC; da.J = sa.J;
-        da.plan = sa.plan; da.etab = L.etab.as<double>(); da.eedge = L.eedge.as<double>();
-        da.IR = job->in.IR; da.b1 = job->in.b1; da.b2 = job->in.b2; da.n = job->n; da.num = job->num; da.ldo = job->ldo;
+        da.rec_ent = d.rec_ent; da.rec_S = d.rec_S; da.rec_W = d.rec_W; da.tile_cnt = d.tile_cnt;
+        da.tilecap = job->sa.tilecap; da.rec_stride = d.rec_stride; da.ntiles = s.ntiles; da.TR = job->sa.TR; da.TC = job->sa.TC; da.J = job->sa.J;
+        da.plan = job->sa.plan; da.etab = d.etab; da.eedge = d.eedge;
+        da.IR = d.IR; da.b1 = d.b1; da.b2 = d.b2; da.n = s.n; da.num = s.num; da.ldo = s.ldo;
         da.mw = plan.mw; da.D = plan.D;
         hpk_launch_probe(da, c->tmpA.as<int32_t>(), c->tmpB.as<int32_t>(), count, c->tmpC.as<double>(), c->stream);
         HIPCHK(c, hipGetLastError());
@@ -1096,9 +1267,53 @@ int hpk_bruteforce_sums(hpk_ctx* c, const hpk_band* band, const hpk_params* prm,
     if (step < 0 || step >= plan.nsteps) return fail(c, HPK_ERR_INVALID, "step out of range");
     if (c->lane[0].busy) return fail(c, HPK_ERR_BUSY, "lane 0 holds a chromosome in flight");
     Lane& L = c->lane[0];
+    // inputs as the pipeline stages them (uploads and the derivation of IR / biases on the lane's side stream)
+    const size_t n = (size_t)band->n, num = (size_t)band->num, ld = (size_t)band->ld;
+    const bool derive = !band->IR;
     Staged in;
-    rc = stage_inputs(c, L, band, plan.mw, &in);
-    if (rc != HPK_OK) return rc;
+    HpkBandDesc d;
+    std::memset(&d, 0, sizeof(d));
+    if (band->on_device) {
+        in.raw = band->raw; in.bal = band->balanced; in.weight = band->weight;
+        in.IR = const_cast<double*>(band->IR);
+    } else {
+        HIPCHK(c, L.raw.reserve(sizeof(float) * n * ld));
+        HIPCHK(c, hipMemcpyAsync(L.raw.p, band->raw, sizeof(float) * n * ld, hipMemcpyHostToDevice, L.up));
+        in.raw = L.raw.as<float>();
+        if (band->balanced) {
+            HIPCHK(c, L.bal.reserve(sizeof(double) * n * ld));
+            HIPCHK(c, hipMemcpyAsync(L.bal.p, band->balanced, sizeof(double) * n * ld, hipMemcpyHostToDevice, L.up));
+            in.bal = L.bal.as<double>();
+        }
+        if (band->weight) {
+            HIPCHK(c, L.weight.reserve(sizeof(double) * n));
+            HIPCHK(c, hipMemcpyAsync(L.weight.p, band->weight, sizeof(double) * n, hipMemcpyHostToDevice, L.up));
+            in.weight = L.weight.as<double>();
+        }
+        if (!derive) {
+            HIPCHK(c, L.IR.reserve(sizeof(double) * num));
+            HIPCHK(c, hipMemcpyAsync(L.IR.p, band->IR, sizeof(double) * num, hipMemcpyHostToDevice, L.up));
+            in.IR = L.IR.as<double>();
+        }
+    }
+    if (derive) {
+        const size_t nparts = (n + 31) / 32;
+        HIPCHK(c, L.IR.reserve(sizeof(double) * num));
+        HIPCHK(c, L.b1.reserve(sizeof(double) * n));
+        HIPCHK(c, L.psum.reserve(sizeof(double) * nparts * num));
+        HIPCHK(c, L.pnan.reserve(sizeof(unsigned) * nparts * num));
+        HIPCHK(c, L.desc.reserve(sizeof(HpkBandDesc)));
+        d.raw = in.raw; d.weight = in.weight; d.n = band->n; d.num = band->num; d.ld = band->ld; d.derive = 1;
+        d.IR = L.IR.as<double>(); d.b1 = L.b1.as<double>(); d.b2 = d.b1; d.psum = L.psum.as<double>(); d.pnan = L.pnan.as<unsigned>();
+        HIPCHK(c, hipMemcpyAsync(L.desc.p, &d, sizeof(d), hipMemcpyHostToDevice, L.up));
+        HIPCHK(c, hipStreamSynchronize(L.up));              // (`d` lives on this stack frame)
+        hpk_launch_prep(L.desc.as<HpkBandDesc>(), 1, band->n, band->num, plan.mw, L.up);
+        HIPCHK(c, hipGetLastError());
+        in.IR = L.IR.as<double>();
+    }
+    // the brute-force kernel runs on the compute stream: it has to wait for what the side stream staged
+    HIPCHK(c, hipEventRecord(L.ev_up, L.up));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, L.ev_up, 0));
     L.plan_valid = false;
     HIPCHK(c, L.plan.reserve(sizeof(HpkDevPlan)));
     HIPCHK(c, hipMemcpyAsync(L.plan.p, &plan, sizeof(plan), hipMemcpyHostToDevice, c->stream));

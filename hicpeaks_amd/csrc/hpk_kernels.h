@@ -1,4 +1,9 @@
 // Kernel argument blocks and launchers (implemented in hpk_kernels.hip).
+//
+// Since round 3 every production kernel works on a *batch* of chromosomes: the host describes each band of the batch
+// in one HpkBandDesc (device memory), the kernels take the descriptor array and find their band by a grid coordinate
+// (prep, expected tables, scoring, cut, publish) or - the stencil - walk the tiles of all bands in one persistent
+// launch.  A single chromosome is a batch of one.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -12,55 +17,13 @@
 #define HPK_SCH 64                      // survivor slots a scoring wave reserves at a time (one batch always fits)
 #define HPK_SCH_LOG2 6
 #define HPK_HIST_NCAND HPK_MAX_STEPS    // hist[HPK_MAX_STEPS] counts the candidates
-#define HPK_ACC_STRIDE 16                // u64 words between the chromosome's resolve totals (HpkStencilArgs::hist_acc): one per 128 bytes
+#define HPK_ACC_STRIDE 16                // u64 words between the chromosome's resolve totals (HpkBandDesc::hist_acc): one per 128 bytes
 #ifndef HPK_NWAVES
 #define HPK_NWAVES 16                   // waves per stencil workgroup (16 or 8)
 #endif
 #define HPK_ROWS_PER_WAVE (64 / HPK_NWAVES)                  // output-tile rows a wave walks in phase 3 (tile rows <= 64)
 // record entry of a candidate: x (7 bits) | y << 7 (6 bits: row of the output tile) | capped raw count << 13
 #define HPK_LISTCAP (HPK_ROWS_PER_WAVE * 128)               // candidate ids per wave and tile
-
-struct HpkStencilArgs {
-    const float*  raw;
-    const double* bal;                  // f64 band or nullptr
-    const double* weight;               // f64[n] or nullptr
-    const HpkDevPlan* plan;
-    // Output: compact candidate records, one region of `tilecap` records per tile.  Waves reserve their share of a
-    // region with one atomicAdd on tile_cnt[tile] (distinct addresses per tile: no serialisation).
-    //   rec_ent[tile * tilecap + i]                    x | row of the output tile << 7 | min(raw, HPK_PK_CAP) << 13
-    //   rec_S[slot * rec_stride + tile * tilecap + i]  (bS_K, bS_Y) at the resolving step
-    //   rec_W[slot * rec_stride + tile * tilecap + i]  resolving step + 1, 0 = unresolved
-    unsigned* rec_ent;
-    double2* rec_S;
-    uint8_t* rec_W;
-    unsigned* tile_cnt;
-    uint2* units;                       // scoring work list: one entry per 256 records of a tile (appended at tile end)
-    unsigned* nunits;
-    int32_t tilecap;
-    int64_t rec_stride;
-    uint8_t* gap;                       // [n] preset to 0; set for rows with a non-zero balanced value (gap = !flag)
-    unsigned long long* hist;           // [HPK_MAX_STEPS + 1] totals, written by hpk_freeze
-    unsigned* hist_part;                // [grid][HPK_MAX_STEPS + 1] per-workgroup resolve counts, [..][HPK_MAX_STEPS] = candidates
-    unsigned long long* hist_acc;       // or (scoring follows): [(HPK_MAX_STEPS + 1) * HPK_ACC_STRIDE] zeroed totals the workgroups add to
-    unsigned* ticket;                   // zeroed; the workgroup that draws grid - 1 runs the freeze (nullptr: hpk_freeze follows)
-    int32_t* frozen;                    // outputs of the freeze: frozen_w, executed[nsteps], first empty step + 1 or 0
-    int32_t* executed;
-    int32_t* err;
-    double risk;                        // box sums below risk x (largest table entry of the window) are redone exactly
-    int32_t n, num;
-    int64_t ld, ldo;
-    int32_t W, mw, D;
-    int32_t TR, TC;                     // output tile = (HPK_LR - 2W - 1) x (HPK_LC - 2W - 1)
-    int32_t J;                          // column chunks per row block
-    int32_t ntiles, chunk;              // chunk = ceil(ntiles / 8): tiles handed to one XCD
-    int32_t grid;                       // persistent workgroups (multiple of 8, one per CU)
-    int32_t single;                     // the plan is a textbook single-pair plan (HpkDevPlan::single_p >= 0)
-    int32_t order;                      // tile order within an XCD's run: 0 row-major, 1 column chunks rotated per row block
-    int32_t wguess;                     // hpk_stencil_s: records only for candidates whose first sufficient width is <= wguess (255: all)
-    unsigned long long* clk;            // -DHPK_PHASE_CLOCK builds: [grid][waves][8] cycle sums per phase, or nullptr
-    int32_t dbg_stop;                   // profiling ablation (HPK_DBG_STOP): 1 stop after the loads, 2 after the SAT,
-                                        // 4 no candidates (loads + SAT + zero stores), 5 search without box sums
-};
 
 // One pixel that can still end with q <= sig (40 bytes).
 struct HpkSurv {
@@ -75,51 +38,105 @@ struct HpkSurv {
 #define HPK_NREG 64                     // independent survivor regions (one reservation counter each, 256 B apart)
 #define HPK_REG_STRIDE 32               // counters are u64[HPK_NREG * HPK_REG_STRIDE]
 
-struct HpkScoreArgs {
-    const float*  raw;
-    const double* bal;
-    const double* weight;
-    const unsigned* rec_ent;            // candidate records written by hpk_stencil
-    const double2* rec_S;
-    const uint8_t* rec_W;
-    const unsigned* tile_cnt;
-    const uint2* units;                 // work list {tile, unit | records of the tile << 8}, appended by hpk_stencil
-    const unsigned* nunits;
-    int32_t tilecap;
-    int64_t rec_stride;
-    int32_t ntiles, TR, TC, J, W;       // tile geometry
+// Counter block of one band ("small"): fixed part, byte offsets.  Host and device share the layout; the head of the
+// block (counters | row flags | first compacted survivors) is what hpk_publish copies to pinned host memory.
+#define HPK_OFF_HIST    0                                                   // u64[65] resolve totals + candidates, for the host
+#define HPK_OFF_FROZEN  (HPK_OFF_HIST + 8 * (HPK_MAX_STEPS + 1))            // i32
+#define HPK_OFF_ERR     (HPK_OFF_FROZEN + 8)                                // i32
+#define HPK_OFF_EXEC    (HPK_OFF_ERR + 8)                                   // i32[64]
+#define HPK_OFF_NUNITS  (HPK_OFF_EXEC + 4 * HPK_MAX_STEPS)                  // u32 (+ pad): survives the overflow rerun
+#define HPK_OFF_NSURV   (HPK_OFF_NUNITS + 8)                                // u64[HPK_NREG * HPK_REG_STRIDE] ... from here on reset by the rerun
+#define HPK_OFF_NVALID  (HPK_OFF_NSURV + 8 * HPK_NREG * HPK_REG_STRIDE)     // u64[16]
+#define HPK_OFF_EMAX    (HPK_OFF_NVALID + 8 * 2 * HPK_MAX_PAIRS)            // u64[16]
+#define HPK_OFF_NOUT    (HPK_OFF_EMAX + 8 * 2 * HPK_MAX_PAIRS)              // u64
+#define HPK_OFF_FAM_M   (HPK_OFF_NOUT + 8)                                  // u32[HPK_NFAM]
+#define HPK_OFF_FAM_F   (HPK_OFF_FAM_M + 4 * HPK_NFAM)                      // u32[HPK_NFAM]
+#define HPK_SMALL_BYTES (HPK_OFF_FAM_F + 4 * HPK_NFAM)
+#define HPK_HEAD_INLINE 4096            // compacted survivors that travel to the host with the counters
+
+// Pointers inside a band descriptor are declared in the global address space for device code: a pointer read out of
+// memory is otherwise a generic pointer to the compiler, which then issues flat_load / flat_store (counted on vmcnt
+// *and* lgkmcnt - every LDS wait would also wait for the record stores and the prefetch).  The layout is the same on
+// both sides (8-byte pointers); kernels turn a field into an ordinary pointer with gptr().
+#if defined(__HIP_DEVICE_COMPILE__) && defined(HPK_KERNEL_TU)      // (hpk_kernels.hip defines it; hipcc's device pass also parses the host-only files)
+#define HPK_GP(T) __attribute__((address_space(1))) T*
+#else
+#define HPK_GP(T) T*
+#endif
+
+// One band of a batch as the kernels see it (device memory, written by the host before the launches).
+struct HpkBandDesc {
+    // ---- what the stencil reads per tile (first 128 bytes)
+    HPK_GP(const float) raw;                  // [n][ld] raw counts
+    HPK_GP(const double) weight;               // f64[n] or nullptr
+    HPK_GP(const double) bal;                  // f64 band or nullptr
+    // compact candidate records, one region of `tilecap` records per tile
+    //   rec_ent[tile * tilecap + i]                    x | row of the output tile << 7 | min(raw, pk_cap) << 13
+    //   rec_S[slot * rec_stride + tile * tilecap + i]  (bS_K, bS_Y) at the resolving step
+    //   rec_W[slot * rec_stride + tile * tilecap + i]  resolving step + 1, 0 = unresolved
+    HPK_GP(unsigned) rec_ent;
+    HPK_GP(double2) rec_S;
+    HPK_GP(uint8_t) rec_W;
+    int64_t rec_stride;                 // ntiles * tilecap
+    int64_t ld;
+    HPK_GP(unsigned) tile_cnt;                 // [ntiles] records per tile
+    HPK_GP(uint2) units;                       // scoring work list {tile, unit | records of the tile << 8}, appended at tile end
+    HPK_GP(unsigned char) small;               // the band's counter block (HPK_OFF_*)
+    HPK_GP(uint8_t) gap;                       // [n] preset to 0; set for rows with a non-zero balanced value (gap = !flag)
+    HPK_GP(unsigned long long) hist_acc;       // [(HPK_MAX_STEPS + 1) * HPK_ACC_STRIDE] zeroed resolve totals the stencil workgroups add to
+    int32_t n, num;
+    int32_t ntiles, chunk;              // chunk = ceil(ntiles / 8): tiles handed to one XCD
+    int32_t k0;                         // first index of this band in an XCD's run over the batch (sum of the chunks before)
+    int32_t wguess;                     // records only for candidates whose first sufficient width is <= wguess (255: all)
+    // ---- prep, expected tables, scoring, cut, publish
+    HPK_GP(double) IR;                         // [num] (input, or derived by hpk_ir_*)
+    HPK_GP(double) b1;
+    HPK_GP(double) b2;
+    HPK_GP(double) etab;                       // [nsteps][2][D + 1]
+    HPK_GP(double) eedge;                      // [2][W][nsteps][2][D + 1] windows clipped by the first rows / last columns
+    HPK_GP(double) psum;                       // hpk_ir_partial: [nparts][num]
+    HPK_GP(unsigned) pnan;
+    HPK_GP(HpkSurv) surv;                      // [HPK_NREG][cap]
+    HPK_GP(HpkSurv) surv2;                     // compacted survivors beyond the inline head
+    HPK_GP(unsigned) chunk_used;               // [HPK_NREG * cap / HPK_SCH] filled slots per chunk
+    HPK_GP(unsigned) cnt;                      // [HPK_NFAM][HPK_TIGHTEN_MAX] tightening counters / p-value histogram
+    HPK_GP(unsigned char) head_host;           // mapped pinned memory the band's head is published to
+    int64_t cap;                        // survivor capacity per region (multiple of 256)
+    uint64_t zero_bytes;                // bytes of `small` the table kernel zero-fills (multiple of 16)
+    uint32_t off_rowlive, off_inl;      // offsets of the row flags / inline survivors inside `small`
+    int32_t derive;                     // IR / biases are derived on the device from raw + weight
+    int32_t score_wgs;                  // scoring workgroups that take part for this band (the rest of the grid row exits)
+};
+
+// Geometry and parameters common to all bands of a batch (kernel argument of the stencil).
+struct HpkStencilArgs {
     const HpkDevPlan* plan;
-    const double* etab;                 // [nsteps][2][D + 1]
-    const double* eedge;                // [2][W][nsteps][2][D + 1] windows clipped by the first rows / last columns
-    const double* IR;
-    const double* b1;
-    const double* b2;
-    int32_t* frozen;                    // device scalar: written by the freeze kernel, or by this kernel's first workgroup (hist_acc)
-    const unsigned long long* hist_acc; // the stencil's resolve totals: every workgroup replays the freeze decision on them (nullptr: read `frozen`)
-    unsigned long long* hist_out;       // with hist_acc: totals, executed flags and error for the host, written by the first workgroup
-    int32_t* executed;
-    int32_t* err;
+    double risk;                        // box sums below risk x (largest table entry of the window) are redone exactly
+    int32_t nbands;
+    int32_t W, mw, D;
+    int32_t TR, TC;                     // output tile = (HPK_LR - 2W - 1) x (HPK_LC - 2W - 1)
+    int32_t J;                          // column chunks per row block
+    int32_t tilecap;
+    int32_t grid;                       // persistent workgroups (multiple of 8, one per CU)
+    int32_t single;                     // the plan is a textbook single-pair plan (HpkDevPlan::single_p >= 0)
+    int32_t order;                      // tile order within an XCD's run: 0 row-major, 1 column chunks rotated per row block
+    int32_t dbg_stop;                   // profiling ablation: 1 stop after the loads, 2 after the SAT, 4 no candidates, 5 search without box sums
+    unsigned long long* clk;            // -DHPK_PHASE_CLOCK builds: [grid][waves][8] cycle sums per phase, or nullptr
+};
+
+struct HpkScoreArgs {
+    int32_t tilecap;
+    int32_t TR, TC, J, W;               // tile geometry
+    const HpkDevPlan* plan;
     const double* bounds;               // [HPK_NB] chunk upper bounds
     const double* ptab;                 // Poisson survival table
     const int32_t* ptab_off;            // [HPK_NB_TAB + 2]
     const double* sfe;                  // stirlerr(0..31)
     double sig;
-    int32_t n, num;
-    int64_t ld, ldo;
     int32_t mw, D;
-    // outputs
-    unsigned int* fam_m;                // [HPK_NFAM] tests per family (chunk sizes, callers.py:266)
-    unsigned int* fam_f;                // [HPK_NFAM] of those, p <= sig
-    unsigned long long* emax_bits;      // [nsets]
-    unsigned long long* nvalid;         // [nsets]
-    unsigned long long* nsurv;          // [HPK_NREG * HPK_REG_STRIDE] reserved slots per region
-    int64_t cap;                        // survivor capacity per region (multiple of 256)
-    HpkSurv* surv;
-    unsigned* chunk_used;               // [HPK_NREG * cap / HPK_SCH] filled slots per chunk
-    unsigned int* hist;                 // [nsets * (HPK_NB + 1)][hbins] p-values <= sig by family and log2 bin (zeroed), or unused
-    int32_t hbins;                      // bins per family of `hist`, 0 = no histogram (hpk_thr_hist / counting rounds do the cut)
+    int32_t hbins;                      // bins per family of the p-value histogram (HpkBandDesc::cnt), 0 = none (hpk_thr_hist / counting rounds do the cut)
     int32_t nsets_half;                 // (pw, ww) pairs of the call: the launcher sizes the histogram's LDS with it
-    int32_t dbg;                        // unused (the ablation switches of round 1 cost scalar work in the hot loop)
+    int32_t gridx;                      // workgroups per band
 };
 
 struct HpkDenseArgs {
@@ -140,32 +157,29 @@ struct HpkBruteArgs {
 };
 
 int  hpk_stencil_lds_bytes();
-void hpk_launch_stencil(const HpkStencilArgs& a, bool balf64, bool simple, hipStream_t st);
-bool hpk_stencil_s_applies(const HpkStencilArgs& a, bool simple);   // the second-generation kernel takes this launch
+// The second-generation kernel takes plans with a monotone Reads matrix on bands within its addressing limits; it walks
+// the whole batch in one launch.  Other launches go band by band through the first-generation kernel.
+bool hpk_stencil_s_applies(const HpkStencilArgs& a, bool simple, int64_t max_ld, int32_t max_n);
+void hpk_launch_stencil_batch(const HpkStencilArgs& a, const HpkBandDesc* d_bands, bool balf64, hipStream_t st);
+void hpk_launch_stencil_old(const HpkStencilArgs& a, const HpkBandDesc& host_copy_of_band, bool balf64, bool simple, int grid, hipStream_t st);
 void hpk_launch_dense(const HpkDenseArgs& a, hipStream_t st);
 void hpk_launch_probe(const HpkDenseArgs& a, const int32_t* rows, const int32_t* cols, int64_t count, double* out, hipStream_t st);
-void hpk_launch_freeze_tot(const HpkDevPlan* plan, const unsigned long long* hist_acc, unsigned long long* hist,
-                           int32_t* frozen, int32_t* executed, int32_t* err, hipStream_t st);
-void hpk_launch_freeze(const HpkDevPlan* plan, unsigned long long* hist, const unsigned* hist_part, int nparts,
-                       int32_t* frozen, int32_t* executed, int32_t* err, hipStream_t st);
-void hpk_launch_prep(const float* raw, const double* weight, int n, int num, int64_t ld, int mw, double* psum, unsigned* pnan,
-                     double* IR, double* bias, hipStream_t st);
-void hpk_launch_etab(const HpkDevPlan* plan, int nsteps, int D, int W, const double* IR, int n, int num, double* etab,
-                     double* eedge, void* zero, size_t zero_bytes, hipStream_t st);
+void hpk_launch_freeze_tot(const HpkDevPlan* plan, const HpkBandDesc* d_bands, int nbands, hipStream_t st);
+// IR / biases of the bands with `derive` set (scripts/pyHICCUPS:149-166); max_n / max_num: largest band of the batch
+void hpk_launch_prep(const HpkBandDesc* d_bands, int nbands, int max_n, int max_num, int mw, hipStream_t st);
+// expected tables + zero-fill of the counter blocks; max_zero: largest zero_bytes of the batch
+void hpk_launch_etab(const HpkDevPlan* plan, const HpkBandDesc* d_bands, int nbands, int nsteps, int D, int W, size_t max_zero, hipStream_t st);
 void hpk_launch_gap(const float* raw, const double* bal, const double* weight, int32_t n, int32_t num,
                     int64_t ld, int32_t mw, uint8_t* gap, hipStream_t st);
-void hpk_launch_score(const HpkScoreArgs& a, bool bhfdr, int cus, hipStream_t st);
-// Benjamini-Hochberg cut tightening on the survivor list: thr[f] <- sig * #{p <= thr[f]} / m[f], `rounds` times,
-// then compaction of the records with p <= thr[f] into `out` (count in *nout).
+int  hpk_score_grid(bool bhfdr, int npairs, int hbins, int cus);            // resident workgroups of the scoring kernel
+void hpk_launch_score(const HpkScoreArgs& a, const HpkBandDesc* d_bands, int nbands, bool bhfdr, hipStream_t st);
+// Benjamini-Hochberg cut tightening on the survivor lists: thr[f] <- sig * #{p <= thr[f]} / m[f], `rounds` times,
+// then compaction of the records with p <= thr[f] (count in the band's HPK_OFF_NOUT).
 int  hpk_thr_hist_bins(int nsets);       // bins per family of the one-pass tightening (rounds < 0)
 int  hpk_score_hist_bins(int nsets);     // bins per family of the histogram hpk_score keeps (rounds <= -100)
-void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned* chunk_used,
-                        const unsigned int* fam_m, const unsigned int* fam_f, unsigned int* fam_cnt, double sig, int rounds,
-                        int nsets, HpkSurv* out_head, unsigned long long inl, HpkSurv* out_rest, unsigned long long* nout,
-                        const double* bal, const double* weight, int64_t ld, int cus, hipStream_t st);
-void hpk_launch_publish(const void* src, void* dst_host_mapped, size_t bytes, hipStream_t st);
-void hpk_launch_publish_head(const void* src, void* dst_host_mapped, const size_t seg[3][2], size_t inl_begin,
-                             const unsigned long long* nout, unsigned inl, unsigned recbytes, hipStream_t st);
+void hpk_launch_tighten(const HpkBandDesc* d_bands, int nbands, double sig, int rounds, int nsets, hipStream_t st);
+// result heads -> mapped pinned host memory: full = the whole head (no scoring ran), otherwise the stretches a chromosome fills
+void hpk_launch_publish(const HpkBandDesc* d_bands, int nbands, int nsets, bool full, size_t max_head_bytes, hipStream_t st);
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,
                      hipStream_t st);
 void hpk_launch_poisson_sf(const double* k, const double* lam, const double* sfe, double* out, int64_t count,

@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include <float.h>
 #include <stdlib.h>
+#define HPK_KERNEL_TU
 #include "hpk_kernels.h"
 
 namespace {
@@ -201,7 +202,35 @@ __device__ __noinline__ double2 explicit_sums_wave(const float* __restrict__ raw
     return make_double2(sk, sy);
 }
 
-__device__ __forceinline__ void freeze_by_last_workgroup(const HpkStencilArgs& a, void* lds);
+// Argument block of the first-generation kernel (one band per launch; built on the host from the batch's HpkStencilArgs
+// and the band's descriptor).
+struct HpkStencil1Args {
+    const float*  raw;
+    const double* bal;
+    const double* weight;
+    const HpkDevPlan* plan;
+    unsigned* rec_ent;
+    double2* rec_S;
+    uint8_t* rec_W;
+    unsigned* tile_cnt;
+    uint2* units;
+    unsigned* nunits;
+    int32_t tilecap;
+    int64_t rec_stride;
+    uint8_t* gap;
+    unsigned long long* hist;           // dbg_stop builds only: keeps values live
+    unsigned long long* hist_acc;
+    double risk;
+    int32_t n, num;
+    int64_t ld;
+    int32_t W, mw, D;
+    int32_t TR, TC;
+    int32_t J;
+    int32_t ntiles, chunk;
+    int32_t order;
+    unsigned long long* clk;
+    int32_t dbg_stop;
+};
 // ------------------------------------------------------------------ stencil
 // Band rows of one tile as they sit in registers between the load and the SAT construction: this wave's RPW rows x
 // 128 columns, two cells per lane.
@@ -214,7 +243,7 @@ struct TileRegs {
 };
 
 template <int RPW, bool BALF64>
-__device__ __forceinline__ void tile_load(const HpkStencilArgs& a, const float* __restrict__ g_raw, const double* __restrict__ g_bal,
+__device__ __forceinline__ void tile_load(const HpkStencil1Args& a, const float* __restrict__ g_raw, const double* __restrict__ g_bal,
                                           const double* __restrict__ g_w, int tid, int wave, int lane, TileRegs<RPW, BALF64>& t) {
     const int rb = tid / a.J, cj = tid - rb * a.J;
     const int r0 = rb * a.TR;
@@ -252,7 +281,7 @@ __device__ __forceinline__ void tile_load(const HpkStencilArgs& a, const float* 
 // XCD-aware persistent tile order: workgroup b runs on XCD b % 8 (observed); XCD x owns the contiguous run of tiles
 // [x * chunk, (x + 1) * chunk) and its workgroups walk it with stride = workgroups per XCD, so tiles processed at
 // the same time on one XCD are neighbours and share their halo rows/columns through that XCD's L2.
-__device__ __forceinline__ int tile_of(const HpkStencilArgs& a, int it) {
+__device__ __forceinline__ int tile_of(const HpkStencil1Args& a, int it) {
     const int xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3), per = (int)(gridDim.x >> 3);
     const int k = j + it * per;
     if (!(k < a.chunk && xcd * a.chunk + k < a.ntiles)) return -1;
@@ -278,7 +307,7 @@ __device__ __forceinline__ int tile_of(const HpkStencilArgs& a, int it) {
 #endif
 
 template <int NW, bool BALF64, bool SIMPLE>
-__global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const float* __restrict__ g_raw,
+__global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencil1Args a, const float* __restrict__ g_raw,
                                                         const double* __restrict__ g_bal, const double* __restrict__ g_w,
                                                         double2* __restrict__ g_recS, uint8_t* __restrict__ g_recW) {
     constexpr int RPW = LR / NW;
@@ -653,7 +682,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
         // The tile's records become work for the scoring kernel: one entry per 256 records, appended to the global
         // list with one atomic per tile (tiles finish at ~15-25 per microsecond, well under the same-address rate).
         // ltc is next touched two barriers from here.
-        const volatile HpkStencilArgs* ka = (const volatile HpkStencilArgs*)(const void*)__builtin_amdgcn_kernarg_segment_ptr();
+        const volatile HpkStencil1Args* ka = (const volatile HpkStencil1Args*)(const void*)__builtin_amdgcn_kernarg_segment_ptr();
         const unsigned c = ltc[0];
         const unsigned nu = (c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT;
         if (nu != 0u) {
@@ -669,7 +698,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
 
     // Resolve histogram: 40k same-address atomics (one per wave and tile) serialise at ~90 per microsecond in L2 -
     // 0.46 ms, several times the kernel itself.  Instead the waves of the workgroup meet in LDS (the SAT is dead now)
-    // and the workgroup writes its partial counts with plain stores; hpk_freeze sums the partials.
+    // and the workgroup adds its counts to the chromosome's totals once.
 #ifdef HPK_PHASE_CLOCK
     if (a.clk && lane == 0) {
         unsigned long long* o = a.clk + ((size_t)blockIdx.x * NW + wave) * 8;
@@ -683,10 +712,10 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
     if (threadIdx.x <= HPK_MAX_STEPS) {
         unsigned tot = 0u;
         for (int w2 = 0; w2 < NW; ++w2) tot += red[w2 * (HPK_MAX_STEPS + 1) + threadIdx.x];
-        if (a.hist_acc) { if (tot) atomicAdd(&a.hist_acc[threadIdx.x * HPK_ACC_STRIDE], (unsigned long long)tot); }
-        else a.hist_part[(int64_t)blockIdx.x * (HPK_MAX_STEPS + 1) + threadIdx.x] = tot;
+        // the counts go straight into the chromosome's totals (one word per cache line); whoever needs the freeze decision
+        // replays it on them (hpk_score's prologue, hpk_freeze_tot)
+        if (tot) atomicAdd(&a.hist_acc[threadIdx.x * HPK_ACC_STRIDE], (unsigned long long)tot);
     }
-    freeze_by_last_workgroup(a, smem + 8192);
 }
 
 // ------------------------------------------------------------------ stencil for "simple Reads" plans
@@ -719,6 +748,8 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencilArgs a, const f
 // (selects on the inputs instead of ifs around the arithmetic).
 #define HPK_TLIST 7680                      // tile-wide candidate list: TR * TC <= 64 * 119 entries (maxww >= 4)
 using rsrc_t = __amdgpu_buffer_rsrc_t;
+// a band descriptor's pointer field (global address space, see HPK_GP) as an ordinary pointer
+template <class T> __device__ __forceinline__ T* gptr(HPK_GP(T) p) { return (T*)p; }
 constexpr unsigned OOB_OFF = 0x7ffffff0u;   // beyond every buffer's num_records (all < 2^31): the load returns 0
 
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
@@ -825,38 +856,43 @@ struct TileRegsS {
 // (y, x) of the tile sits at (Y, X) = (y + W + 1, x + W).  Lane l holds the cells X = 127 - 2l (e = 0) and 126 - 2l
 // (e = 1) of each of its wave's rows, so that the wave scan runs from high to low columns.
 template <bool BALF64>
-__device__ __forceinline__ void tile_load_s(const HpkStencilArgs& a, int rb, int cj, int wave, int lane, TileRegsS<BALF64>& t) {
+__device__ __forceinline__ void tile_load_s(const HpkStencilArgs& a, const HpkBandDesc* __restrict__ bd, int rb, int cj, int wave,
+                                            int lane, TileRegsS<BALF64>& t) {
+    const int bn = bd->n, bnum = bd->num;
+    const int64_t bld = bd->ld;
     const int r0 = rb * a.TR;
     const int rt0 = r0 - a.W - 1;                          // matrix row of SAT row 0 (negative in the first row block)
     const int rb0 = rt0 > 0 ? rt0 : 0;                     // the tile's buffer starts at this matrix row
-    int rows = a.n - rb0;
+    int rows = bn - rb0;
     rows = rows > 96 ? 96 : rows;
-    const unsigned ldu = (unsigned)a.ld;
+    const unsigned ldu = (unsigned)bld;
     const int koff = a.mw + cj * a.TC + 1;                 // diagonal of SAT cell (0, 0): (c0 - W) - (r0 - W - 1)
     const int k4l = (koff + 127 - 2 * lane) * 4;           // byte offset within a band row of the lane's cell e = 0 at SAT row 0
-    const rsrc_t rraw = make_rsrc(a.raw + (int64_t)rb0 * a.ld, (unsigned)rows * ldu * 4u);
+    const rsrc_t rraw = make_rsrc(gptr(bd->raw) + (int64_t)rb0 * bld, (unsigned)rows * ldu * 4u);
     rsrc_t rbal = rraw;
-    if (BALF64) rbal = make_rsrc(a.bal + (int64_t)rb0 * a.ld, (unsigned)rows * ldu * 8u);
+    if (BALF64) rbal = make_rsrc(gptr(bd->bal) + (int64_t)rb0 * bld, (unsigned)rows * ldu * 8u);
     if (!BALF64) {
-        const rsrc_t rw = make_rsrc(a.weight, (unsigned)a.n * 8u);
+        const rsrc_t rw = make_rsrc(gptr(bd->weight), (unsigned)bn * 8u);
         const int cc0 = rt0 + koff + 127 - 2 * lane;       // matrix column of cell e = 0; columns < 0 or >= n read 0
 #pragma unroll
         for (int e = 0; e < 2; ++e) t.wc[e] = ldbuf_f64(rw, (unsigned)(cc0 - e) * 8u, 0u);
         const int Yl = sat_row(wave, lane & 7);            // (lanes 5-7: rows of the next wave, never used)
         t.wrow = ldbuf_f64(rw, (unsigned)(rt0 + Yl) * 8u, 0u);
+        // (a masked bin's weight is NaN, scripts/pyHICCUPS:163-166; phase 1 turns it into 0 - three values per lane and
+        // tile - so that the products of its pixels are zeros without a NaN test per cell)
     }
     // The wave's rows are consecutive: row offset and row length step by constants.  A row above the matrix or below its
     // end gets length 0 - every lane then reads out of bounds (0), whatever the row offset says.
     const int Y0 = sat_row(wave, 0), rr0 = rt0 + Y0;
     const unsigned ld4 = ldu * 4u;
     unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(rr0 - rb0) * ld4));
-    int limn = __builtin_amdgcn_readfirstlane(a.n - rr0);            // columns left of the matrix end in row rr0
+    int limn = __builtin_amdgcn_readfirstlane(bn - rr0);             // columns left of the matrix end in row rr0
     const unsigned k4w = (unsigned)(k4l - 4 * Y0);
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         // a cell holds data iff 0 <= k < lim: inside the stored diagonals and left of the matrix end (column r + k < n)
         int lim = limn - j;
-        lim = lim < a.num ? lim : a.num;
+        lim = lim < bnum ? lim : bnum;
         lim = lim > 0 ? lim : 0;
         lim = rr0 + j >= 0 ? lim : 0;
         asm volatile("" : "+s"(lim));                       // (a scalar select per row, not a lane mask ANDed per cell)
@@ -875,37 +911,65 @@ __device__ __forceinline__ void tile_load_s(const HpkStencilArgs& a, int rb, int
     }
 }
 
-// Persistent tile walk without divisions: local index k of the XCD's run -> (row block, column chunk), advanced by
-// the workgroups-per-XCD stride (see tile_of).
+// Persistent tile walk over a batch of bands, without divisions inside a band.  XCD x owns, of every band b, the
+// contiguous run of tiles [x * chunk_b, (x + 1) * chunk_b); the runs of the batch's bands laid end to end form the XCD's
+// index space (band b starts at k0_b = sum of the chunks before it), and the XCD's workgroups walk it with the stride of
+// the workgroups per XCD - straight across the band boundaries, so that a batch has one ramp-up and one tail whatever
+// the number of bands.  Inside a band, (row block, column chunk) advance by the stride's quotient and remainder by J; a
+// band switch recomputes them with a division (rare).
 struct TileWalk {
-    int k, rbk, ck, rm;                 // local index, row block, column chunk before rotation, row block mod J
+    int k, band, kb, chunkb, ntb;       // index in the XCD's run; current band, its first index, its chunk and tile count
+    int rbk, ck, rm;                    // row block, column chunk before rotation, row block mod J
     int dk, dr, dc, drm;                // per step: index stride, its quotient and remainder by J, quotient mod J
-    __device__ __forceinline__ void init(const HpkStencilArgs& a) {
-        const int xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3);
+    bool done;
+    __device__ __forceinline__ void locate(const HpkStencilArgs& a, const HpkBandDesc* __restrict__ bands, bool fresh) {
+        const int xcd = (int)(blockIdx.x & 7);
+        for (;;) {
+            while (k >= kb + chunkb) {
+                kb += chunkb;
+                ++band;
+                if (band >= a.nbands) { done = true; return; }
+                const HpkBandDesc* __restrict__ nb = bands + __builtin_amdgcn_readfirstlane(band);
+                chunkb = nb->chunk;
+                ntb = nb->ntiles;
+                fresh = true;
+            }
+            const int t = xcd * chunkb + (k - kb);
+            if (t < ntb) {
+                if (fresh) { rbk = t / a.J; ck = t - rbk * a.J; rm = rbk % a.J; }
+                return;
+            }
+            // (the last XCD's run of a band can be shorter than the others': on to the next band)
+            k += (kb + chunkb - k + dk - 1) / dk * dk;
+        }
+    }
+    __device__ __forceinline__ void init(const HpkStencilArgs& a, const HpkBandDesc* __restrict__ bands) {
         dk = (int)(gridDim.x >> 3);
         dr = dk / a.J; dc = dk - dr * a.J; drm = dr % a.J;
-        k = j;
-        const int t = xcd * a.chunk + k;
-        rbk = t / a.J; ck = t - rbk * a.J; rm = rbk % a.J;
-    }
-    __device__ __forceinline__ bool valid(const HpkStencilArgs& a) const {
-        return k < a.chunk && (int)(blockIdx.x & 7) * a.chunk + k < a.ntiles;
+        k = (int)(blockIdx.x >> 3);
+        band = 0; kb = 0; chunkb = bands[0].chunk; ntb = bands[0].ntiles;
+        rbk = 0; ck = 0; rm = 0;
+        done = false;
+        locate(a, bands, true);
     }
     __device__ __forceinline__ int cj(const HpkStencilArgs& a) const {
         if (a.order == 0) return ck;
         const int c = ck + rm;
         return c >= a.J ? c - a.J : c;
     }
-    __device__ __forceinline__ void step(const HpkStencilArgs& a) {
+    __device__ __forceinline__ void step(const HpkStencilArgs& a, const HpkBandDesc* __restrict__ bands) {
         k += dk; rbk += dr; ck += dc; rm += drm;
         if (ck >= a.J) { ck -= a.J; rbk += 1; rm += 1; }
         if (rm >= a.J) rm -= a.J;
         if (rm >= a.J) rm -= a.J;
+        locate(a, bands, false);
     }
+    // what wave 0 publishes for the others: row block << 8 | column chunk, ~0 = no more tiles
+    __device__ __forceinline__ unsigned word(const HpkStencilArgs& a) const { return done ? ~0u : ((unsigned)rbk << 8 | (unsigned)cj(a)); }
 };
 
 template <bool BALF64, bool SINGLE>
-__global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
+__global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const HpkBandDesc* __restrict__ bands) {
     constexpr int NW = 16, RPW = 5;
     static_assert(LR == 80 && LC == 128, "tile geometry of the simple-plan kernel");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -921,8 +985,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
 
     const int lane_k = threadIdx.x & 63;
     const int wave_k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int W = a.W, n = a.n, mw = a.mw, TR = a.TR, TC = a.TC;
-    const int Dm = a.D < a.num - 1 ? a.D : a.num - 1;      // last diagonal that holds band pixels
+    const int W = a.W, mw = a.mw, TR = a.TR, TC = a.TC;
 
     const HpkDevPlan* __restrict__ plan = a.plan;
     const int nsteps = plan->nsteps, nslots = plan->nslots;
@@ -952,18 +1015,27 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     const int minr_p = __builtin_amdgcn_readfirstlane(plan->min_reads), p0_p = __builtin_amdgcn_readfirstlane(plan->reads_p0);
     const int wmin_p = __builtin_amdgcn_readfirstlane(plan->wmin);
     const int sp_p = __builtin_amdgcn_readfirstlane(plan->single_p);     // SINGLE: the peak width
-    // Records are written for candidates whose first sufficient width is at most a.wguess, packed (a tile's record i is
-    // no longer its list entry i): the widening stops at a width that only the whole chromosome's histogram decides
-    // (frozen_w, freeze_body), wider candidates and unresolved ones are dropped by the scoring kernel anyway, and the
-    // caller knows a bound from the chromosome before (hpk_api.cpp; 255 = every candidate, as the dense outputs want).
-    const int wg_p = __builtin_amdgcn_readfirstlane(a.wguess);
     const unsigned pkcap_p = (unsigned)__builtin_amdgcn_readfirstlane(plan->pk_cap);
     const int fr_p = SINGLE ? 0 : __builtin_amdgcn_readfirstlane(plan->first_rho);   // general plans: the box every step starts with
+    // Resolve histogram of the band the workgroup is in: flushed into the band's totals when the walk enters the next
+    // band (and after the last tile), see the top of the tile loop.
     unsigned myhist = 0u;                 // lane w: candidates whose first sufficient width is w
     unsigned long long hpack0 = 0ull, hpack1 = 0ull;      // this lane's candidates by width min(ww) + k: 16 bits each, k = 0..3 | 4..7
+    unsigned hp_n = 0u;                   // tiles counted into hpack since it was last folded into myhist (16-bit fields)
     unsigned mycand = 0u;
+    // the per-lane width counts, summed over the wave, into lane min(ww) + k of myhist
+    auto fold_hpack = [&]() {
+#pragma unroll
+        for (int k = 0; k < (BALF64 ? 0 : 8); ++k) {
+            unsigned v = (unsigned)((k < 4 ? hpack0 : hpack1) >> (16 * (k & 3))) & 0xffffu;
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) v += (unsigned)__shfl_xor((int)v, m);
+            if (lane_k == wmin_p + k) myhist += v;
+        }
+        hpack0 = 0ull; hpack1 = 0ull; hp_n = 0u;
+    };
     // scoring work list: the append of a tile is completed one tile later (the atomic's return is not waited for)
-    int pend_tid = -1;
+    int pend_tid = -1, pend_band = 0;
     unsigned pend_c = 0u, pend_off = 0u;
 
     HPK_CLK_DECL
@@ -971,45 +1043,99 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     int par = 0;                        // which of the two list counters the current tile uses
     // The tile walk is the same scalar arithmetic in every wave, and all sixteen would queue for the one scalar unit
     // with it at the top of every tile: wave 0 alone walks, one tile ahead, and publishes the next tile through LDS
-    // (tseq[2], alternating: row block << 8 | column chunk, ~0 = no more tiles).
+    // (tseq[2] / tband[2], alternating: row block << 8 | column chunk (~0 = no more tiles) and the band's index).
     unsigned* __restrict__ tseq = tcount + 8;
+    unsigned* __restrict__ tband = tcount + 12;
     TileWalk tw;
-    tw.init(a);
-    bool have = tw.valid(a);
+    tw.init(a, bands);
+    bool have = !tw.done;
     int rb = tw.rbk, cj = tw.cj(a);
-    if (have) tile_load_s<BALF64>(a, rb, cj, wave_k, lane_k, nxt);
+    int band = have ? tw.band : -1;     // band of the current tile; -1 behind the last one
+    int hband = band;                   // band the resolve counts in (myhist, hpack, mycand) belong to
+    if (have) tile_load_s<BALF64>(a, bands + band, rb, cj, wave_k, lane_k, nxt);
     if (wave_k == 0) {
-        tw.step(a);
-        if (lane_k == 0) tseq[0] = tw.valid(a) ? ((unsigned)tw.rbk << 8 | (unsigned)tw.cj(a)) : ~0u;
+        tw.step(a, bands);
+        if (lane_k == 0) { tseq[0] = tw.word(a); tband[0] = (unsigned)tw.band; }
     }
     __syncthreads();                    // plan, counters and the second tile in LDS
     unsigned tnext = lds_u32(lds0 + (unsigned)((unsigned char*)tseq - smem));
+    unsigned bnext = lds_u32(lds0 + (unsigned)((unsigned char*)tband - smem));
     int tpar = 0;                       // which tseq word holds the tile after the current one
 #pragma unroll 1
-    for (int it = 0; have; ++it) {
+    for (;;) {
+    if (band != hband) {
+        // ---- the walk has left band `hband`: its resolve counts go to that band's totals.  Widths are summed over the
+        // waves in LDS (the tables are dead between tiles), then per step s of slot q and width w: the candidates whose
+        // first sufficient width is w (w above the slot's first width) or at most w (at it).  The counts go straight into
+        // the chromosome's totals - one word per cache line - and every scoring workgroup replays the freeze decision on
+        // them; no ticket, no fences, no tail in this kernel.
+        const HpkBandDesc* __restrict__ hb = bands + hband;
+        fold_hpack();
+        unsigned* red = reinterpret_cast<unsigned*>(smem);
+        int tix = wave_k * 64 + lane_k;         // (opaque: what hangs on the thread index stays in here instead of being
+        asm volatile("" : "+v"(tix));           //  hoisted out of the tile loop into registers that then spill)
+        __syncthreads();
+        red[tix] = myhist;
+        if (lane_k == 0) red[NW * 64 + wave_k] = mycand;
+        __syncthreads();
+        if (tix < 64) {
+            unsigned tot = 0u;
+            for (int w2 = 0; w2 < NW; ++w2) tot += red[w2 * 64 + tix];
+            red[(NW + 1) * 64 + tix] = tot;
+        }
+        __syncthreads();
+        if (tix <= HPK_MAX_STEPS) {
+            unsigned out = 0u;
+            const unsigned* hw = red + (NW + 1) * 64;
+            if (tix < nsteps) {
+                const HpkDevStep& st = plan->steps[tix];
+                const int wf = plan->slot_wfirst[st.slot];
+                if (st.wi > wf) out = hw[st.wi];
+                else for (int w = 0; w <= wf && w < 64; ++w) out += hw[w];
+            } else if (tix == HPK_MAX_STEPS) out = red[NW * 64];
+            if (out) atomicAdd(&gptr(hb->hist_acc)[tix * HPK_ACC_STRIDE], (unsigned long long)out);
+        }
+        __syncthreads();                // (the next tile's phase 1 parks its totals where `red` sits)
+        myhist = 0u; mycand = 0u;
+        hband = band;
+    }
+    if (!have) break;
+    // (a wave runs at most 7 batches of a tile, a lane counts at most one candidate per batch: long runs of tiles on
+    // small grids must not wrap a 16-bit field)
+    if (++hp_n >= 8192u) fold_hpack();
     // Everything below that depends only on (wave, lane) is the same for every tile, and the compiler would hoist it
     // out of the tile loop - list-entry templates, row flags, compare constants: 100+ SGPRs and a dozen VGPRs that
     // then spill to scratch, whose reloads (vmcnt(0)) also wait for the prefetch.  Opaque copies keep it in here.
     int wave = wave_k, lane = lane_k;
     asm volatile("" : "+s"(wave));
     asm volatile("" : "+v"(lane));
+    const HpkBandDesc* __restrict__ bd = bands + band;      // this tile's band
+    const int n = bd->n;
+    const int Dm = a.D < bd->num - 1 ? a.D : bd->num - 1;   // last diagonal that holds band pixels
+    // Records are written for candidates whose first sufficient width is at most the band's wguess, packed (a tile's
+    // record i is no longer its list entry i): the widening stops at a width that only the whole chromosome's histogram
+    // decides (frozen_w, freeze_replay), wider candidates and unresolved ones are dropped by the scoring kernel anyway,
+    // and the caller knows a bound from the chromosomes before (hpk_api.cpp; 255 = every candidate, as the dense outputs want).
+    const int wg_p = bd->wguess;
     const int tid = rb * a.J + cj;
     const int r0 = rb * TR;
     const int c0 = r0 + mw + cj * TC;
     const bool empty_tile = c0 >= n || (mw + cj * TC - (TR - 1)) > a.D;       // no band pixel inside the matrix
     const int tn = __builtin_amdgcn_readfirstlane((int)tnext);
+    const int band_next = __builtin_amdgcn_readfirstlane((int)bnext);
     const bool have_next = tn != -1;
     const int rb_next = (int)((unsigned)tn >> 8), cj_next = tn & 255;
     if (wave == 0) {                    // the tile after the next one, for everybody's next round
-        tw.step(a);
-        if (lane == 0) tseq[tpar ^ 1] = tw.valid(a) ? ((unsigned)tw.rbk << 8 | (unsigned)tw.cj(a)) : ~0u;
+        tw.step(a, bands);
+        if (lane == 0) { tseq[tpar ^ 1] = tw.word(a); tband[tpar ^ 1] = (unsigned)tw.band; }
     }
     tpar ^= 1;
     if (empty_tile) {
-        if (have_next) tile_load_s<BALF64>(a, rb_next, cj_next, wave, lane, nxt);
-        have = have_next; rb = rb_next; cj = cj_next;
+        if (have_next) tile_load_s<BALF64>(a, bands + band_next, rb_next, cj_next, wave, lane, nxt);
+        have = have_next; rb = rb_next; cj = cj_next; band = have_next ? band_next : -1;
         __syncthreads();                // (rare: the far end of the chromosome) wave 0's word before it is read
         tnext = lds_u32(lds0 + (unsigned)((unsigned char*)tseq - smem) + (unsigned)tpar * 4u);
+        bnext = lds_u32(lds0 + (unsigned)((unsigned char*)tband - smem) + (unsigned)tpar * 4u);
         continue;
     }
     unsigned* __restrict__ tcnt = tcount + par;
@@ -1025,14 +1151,22 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     double satc[RPW][2];
     unsigned satp[RPW][2];
     int zdpp[4] = {0, 0, 0, 0};
+    // weights of masked bins (NaN, scripts/pyHICCUPS:163-166) count as 0: their pixels' balanced values are the zeros the
+    // reference turns its NaNs into (pyHICCUPS:157), everything else - negative weights included - is the reference's product
+    double wcz[2] = {0.0, 0.0}, wrz = 0.0;
+    if (!BALF64) {
+        wcz[0] = nxt.wc[0] == nxt.wc[0] ? nxt.wc[0] : 0.0;
+        wcz[1] = nxt.wc[1] == nxt.wc[1] ? nxt.wc[1] : 0.0;
+        wrz = nxt.wrow == nxt.wrow ? nxt.wrow : 0.0;
+    }
     double ac[2] = {0.0, 0.0};
     unsigned ar[2] = {0u, 0u};
 #pragma unroll
     for (int j = 0; j < RPW; ++j) {
         const int Y = sat_row(wave, j);
         double wr = 0.0;
-        if (!BALF64) wr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(nxt.wrow), j),
-                                           __builtin_amdgcn_readlane(__double2loint(nxt.wrow), j));
+        if (!BALF64) wr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(wrz), j),
+                                           __builtin_amdgcn_readlane(__double2loint(wrz), j));
         const int y = Y - (W + 1);
         // rows outside the output tile have no candidates: their diagonal bound is 0 (rows at or beyond n read 0)
         unsigned kbound = (unsigned)y < (unsigned)TR ? (unsigned)(Dm - mw) + 1u : 0u;
@@ -1051,11 +1185,11 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
             const unsigned ru = (unsigned)rv;
             const unsigned rc = ru < pkcap_p ? ru : pkcap_p;
             if (BALF64) {
-                bv[e] = fmax(nxt.bal[j][e], 0.0);                        // NaN -> 0 (counts x weights: never negative)
+                bv[e] = nxt.bal[j][e];                                  // as given: the caller zeroed the NaNs (hpk.h), signs are kept (callers.py:78)
             } else {
                 rv = km >= 0 ? rv : 0.f;                                // balanced values exist from diagonal min(ww) on
                 asm volatile("" : "+v"(rv));                            // (select on the f32, not on the converted f64)
-                bv[e] = fmax(((double)rv * wr) * nxt.wc[e], 0.0);       // (raw * w_r) * w_c, NaN -> 0
+                bv[e] = ((double)rv * wr) * wcz[e];                     // (raw * w_r) * w_c with NaN weights as 0: NaN -> 0, signs are kept
             }
             pk[e] = rc | (bv[e] != 0.0 ? 1u << PK_SHIFT : 0u);
             // (no branch on the row: the predicate flows straight into the ballot; rows outside the output tile give 0)
@@ -1111,12 +1245,12 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
     // The next tile's rows start moving now, from every wave.  (With 32 row groups the prefix stage behind the barrier
     // was long and the waves not in it issued their loads there; with 16 it is short, and on the wide-band
     // configurations - few candidates, the tile is all table building - the earlier request is worth 2 %.)
-    if (have_next && (!BALF64 || wave < 8)) tile_load_s<BALF64>(a, rb_next, cj_next, wave, lane, nxt);
+    if (have_next && (!BALF64 || wave < 8)) tile_load_s<BALF64>(a, bands + band_next, rb_next, cj_next, wave, lane, nxt);
     __syncthreads();
     HPK_CLK(ck1)
     // (f64 input: the waves that sit out the prefix stage request their rows there - thirty registers fewer to hold
     // across the barrier)
-    if (BALF64 && have_next && wave >= 8) tile_load_s<BALF64>(a, rb_next, cj_next, wave, lane, nxt);
+    if (BALF64 && have_next && wave >= 8) tile_load_s<BALF64>(a, bands + band_next, rb_next, cj_next, wave, lane, nxt);
     // ---- exclusive prefixes over the 16 waves' row groups, per column: plain sums in wave order.  Waves 0-3: the f64
     // plane, 32 columns each; waves 4-7: the packed plane.  Lanes 0-31 walk groups 0-7 of their column, lanes 32-63 groups
     // 8-15, which start from the first half's total.  Group g parked its total in SAT row 5g + 1 and gets its base in row 5g.
@@ -1179,12 +1313,12 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         unsigned rs = Sp[Y * LC + W] - Sp[(Y - 1) * LC + W];
         const int xe = last ? W : W + TC;        // last: nothing is taken off (the two reads below cancel)
         rs -= last ? 0u : Sp[Y * LC + xe] - Sp[(Y - 1) * LC + xe];
-        if ((rs >> PK_SHIFT) != 0u) a.gap[r0 + tx] = 1;
+        if ((rs >> PK_SHIFT) != 0u) gptr(bd->gap)[r0 + tx] = 1;
     }
     if (tx == 0) { tcount[par ^ 1] = 0u; tcount[4 + (par ^ 1)] = 0u; }    // the next tile's counters (its atomics start after the barrier below)
     // ---- phase 3: batches of 64 candidates, dealt round-robin to the waves
     const int64_t tbase = (int64_t)tid * a.tilecap;
-    unsigned* __restrict__ ent_t = a.rec_ent + tbase;
+    unsigned* __restrict__ ent_t = gptr(bd->rec_ent) + tbase;
     HPK_CLK(ck4)
 #pragma unroll 1
     for (int b = wave; b * 64 < total; b += NW) {
@@ -1232,8 +1366,9 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
             }
         }
         // resolve histogram by width.  The first eight widths are counted per lane, 16 bits each in two registers
-        // (a lane sees at most one candidate per batch: no field overflows before 65 535 batches of this wave), and added
-        // up over the wave once, after the last tile; wider ones (maxww >= min(ww) + 8) by one ballot per width.
+        // (a lane sees at most one candidate per batch: the fields are folded into myhist before 65 535 batches of this
+        // wave), and added up over the wave when the walk leaves the band; wider ones (maxww >= min(ww) + 8) by one
+        // ballot per width.
         // (The f64-input variants are out of registers - their prefetch holds 30 instead of 16 - and keep the ballots.)
         if (!BALF64) {
             const unsigned off = (unsigned)(wstar - wmin_p);              // 255 - min(ww) >= 8 for "no sufficient width"
@@ -1285,7 +1420,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
                 const int wf = (q == 0) ? wf_q[0] : (q == 1) ? wf_q[1] : (q == 2) ? wf_q[2] : wf_q[3];
                 const int wq = wstar > wf ? wstar : wf;
                 sq = (int)stepof[q * 32 + (wq & 31)];
-                sq = (wstar == 255) | (wq > wg_p) ? 0xff : sq;      // (a slot whose own first width lies beyond the bound)
+                sq = ((wstar == 255) | (wq > wg_p)) ? 0xff : sq;      // (a slot whose own first width lies beyond the bound)
             }
             const bool act = sq != 0xff;
             double SK = 0.0, SY = 0.0;
@@ -1383,7 +1518,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
                         todo &= todo - 1ull;
                         const int er = __builtin_amdgcn_readlane(r0 + y, src), ec = __builtin_amdgcn_readlane(c0 + x, src);
                         const int es = __builtin_amdgcn_readlane(sq, src);
-                        const double2 ex = explicit_sums_wave(a.raw, a.bal, a.weight, plan->steps[es].m, W, er, ec, n, a.num, a.ld, mw, lane);
+                        const double2 ex = explicit_sums_wave(gptr(bd->raw), gptr(bd->bal), gptr(bd->weight), plan->steps[es].m, W, er, ec, n, bd->num, bd->ld, mw, lane);
                         if (lane == src) { SK = ex.x; SY = (SY == 0.0) ? 0.0 : ex.y; }   // SY == 0: exact by construction or no non-zero cell
                     }
                 }
@@ -1395,15 +1530,16 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
                 if (live) ent_t[ri] = id;
             }
             if (live) {
-                const int64_t o = q * a.rec_stride + tbase + ri;
-                a.rec_S[o] = make_double2(act ? SK : 0.0, act ? SY : 0.0);
-                a.rec_W[o] = act ? (uint8_t)(sq + 1) : (uint8_t)0;
+                const int64_t o = q * bd->rec_stride + tbase + ri;
+                gptr(bd->rec_S)[o] = make_double2(act ? SK : 0.0, act ? SY : 0.0);
+                gptr(bd->rec_W)[o] = act ? (uint8_t)(sq + 1) : (uint8_t)0;
             }
         }
     }
     HPK_CLK(ck5)
     // (written by wave 0 at the top of this round, three barriers ago: in flight across the barrier below)
     tnext = lds_u32(lds0 + (unsigned)((unsigned char*)tseq - smem) + (unsigned)tpar * 4u);
+    bnext = lds_u32(lds0 + (unsigned)((unsigned char*)tband - smem) + (unsigned)tpar * 4u);
     __syncthreads();                 // every wave is done with this tile's SAT and list
     HPK_CLK(ck6)
     if (wave == 0) {
@@ -1412,25 +1548,26 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         if (pend_tid >= 0) {
             const unsigned nu = (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT;
             const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)pend_off);
-            if ((unsigned)lane < nu) a.units[off + lane] = make_uint2((unsigned)pend_tid, (unsigned)lane | (pend_c << 8));
+            if ((unsigned)lane < nu) gptr(bands[pend_band].units)[off + lane] = make_uint2((unsigned)pend_tid, (unsigned)lane | (pend_c << 8));
         }
         pend_tid = -1;
         const unsigned nrec = (unsigned)__builtin_amdgcn_readfirstlane((int)tcount[4 + par]);    // records of this tile
         if (nrec > 0u) {
             pend_tid = tid;
+            pend_band = band;
             pend_c = nrec;
-            if (lane == 0) pend_off = atomicAdd(a.nunits, (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT);
+            if (lane == 0) pend_off = atomicAdd(reinterpret_cast<unsigned*>(gptr(bd->small) + HPK_OFF_NUNITS), (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT);
         }
-        if (lane == 0) { a.tile_cnt[tid] = nrec; mycand += (unsigned)total; }
+        if (lane == 0) { gptr(bd->tile_cnt)[tid] = nrec; mycand += (unsigned)total; }
     }
-    have = have_next; rb = rb_next; cj = cj_next;
+    have = have_next; rb = rb_next; cj = cj_next; band = have_next ? band_next : -1;
     par ^= 1;
     }   // tile loop
     const int lane = lane_k, wave = wave_k;
     if (wave == 0 && pend_tid >= 0) {
         const unsigned nu = (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT;
         const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)pend_off);
-        if ((unsigned)lane < nu) a.units[off + lane] = make_uint2((unsigned)pend_tid, (unsigned)lane | (pend_c << 8));
+        if ((unsigned)lane < nu) gptr(bands[pend_band].units)[off + lane] = make_uint2((unsigned)pend_tid, (unsigned)lane | (pend_c << 8));
     }
 #ifdef HPK_PHASE_CLOCK
     if (a.clk && lane == 0) {
@@ -1438,54 +1575,26 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a) {
         o[0] = ck0; o[1] = ck1; o[2] = ck2; o[3] = ck3; o[4] = ck4; o[5] = ck5; o[6] = ck6; o[7] = ck7;
     }
 #endif
-    // ---- resolve histogram of the workgroup: widths summed over the waves in LDS, then per step s of slot q and width
-    // w: the candidates whose first sufficient width is w (w above the slot's first width) or at most w (at it)
-    unsigned* red = reinterpret_cast<unsigned*>(smem);
-#pragma unroll
-    for (int k = 0; k < (BALF64 ? 0 : 8); ++k) {         // the per-lane width counts, summed over the wave, into lane min(ww) + k
-        unsigned v = (unsigned)((k < 4 ? hpack0 : hpack1) >> (16 * (k & 3))) & 0xffffu;
-#pragma unroll
-        for (int m = 32; m > 0; m >>= 1) v += (unsigned)__shfl_xor((int)v, m);
-        if (lane == wmin_p + k) myhist += v;
-    }
-    __syncthreads();
-    red[wave * 64 + lane] = myhist;
-    if (lane == 0) red[NW * 64 + wave] = mycand;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        unsigned tot = 0u;
-        for (int w2 = 0; w2 < NW; ++w2) tot += red[w2 * 64 + threadIdx.x];
-        red[(NW + 1) * 64 + threadIdx.x] = tot;
-    }
-    __syncthreads();
-    if (threadIdx.x <= HPK_MAX_STEPS) {
-        unsigned out = 0u;
-        const unsigned* hw = red + (NW + 1) * 64;
-        if ((int)threadIdx.x < nsteps) {
-            const HpkDevStep& st = plan->steps[threadIdx.x];
-            const int wf = plan->slot_wfirst[st.slot];
-            if (st.wi > wf) out = hw[st.wi];
-            else for (int w = 0; w <= wf && w < 64; ++w) out += hw[w];
-        } else if (threadIdx.x == HPK_MAX_STEPS) out = red[NW * 64];
-        // (scoring follows: the counts go straight into the chromosome's totals - one word per cache line, 256 adds each -
-        // and every scoring workgroup replays the freeze decision on them; no ticket, no fences, no tail in this kernel)
-        if (a.hist_acc) { if (out) atomicAdd(&a.hist_acc[threadIdx.x * HPK_ACC_STRIDE], (unsigned long long)out); }
-        else a.hist_part[(int64_t)blockIdx.x * (HPK_MAX_STEPS + 1) + threadIdx.x] = out;
-    }
-    freeze_by_last_workgroup(a, smem + 8192);
 }
 
 // ------------------------------------------------------------------ 1-D expected IR[d] and biases (scripts/pyHICCUPS:149-166)
 // IR[d] = mean over diagonal d of the balanced values, where *stored* (non-zero) pixels in masked bins are NaN and
 // are left out of both sum and count, while unstored pixels count as 0 even in masked bins.  Deterministic
 // two-level reduction: workgroup b sums rows [b * HPK_IR_ROWS, ...) per diagonal (lanes = diagonals, coalesced),
-// hpk_ir_final adds the partials of one diagonal with 64 lanes in a fixed order.
+// hpk_ir_final adds the partials of one diagonal with 64 lanes in a fixed order.  blockIdx.z = band of the batch.
 #define HPK_IR_ROWS 32
-__global__ void __launch_bounds__(256) hpk_ir_partial(const float* __restrict__ raw, const double* __restrict__ weight, int n,
-                                                      int num, int64_t ld, int mw, double* __restrict__ psum,
-                                                      unsigned* __restrict__ pnan) {
-    __shared__ double wrow[HPK_IR_ROWS];
+__global__ void __launch_bounds__(256) hpk_ir_partial(const HpkBandDesc* __restrict__ bands, int mw) {
+    const HpkBandDesc* __restrict__ bd = bands + blockIdx.z;
+    if (!bd->derive) return;
+    const int n = bd->n, num = bd->num;
+    const int64_t ld = bd->ld;
     const int rbeg = blockIdx.x * HPK_IR_ROWS;
+    if (rbeg >= n) return;
+    const float* __restrict__ raw = gptr(bd->raw);
+    const double* __restrict__ weight = gptr(bd->weight);
+    double* __restrict__ psum = gptr(bd->psum);
+    unsigned* __restrict__ pnan = gptr(bd->pnan);
+    __shared__ double wrow[HPK_IR_ROWS];
     if ((int)threadIdx.x < HPK_IR_ROWS) wrow[threadIdx.x] = (rbeg + (int)threadIdx.x < n) ? weight[rbeg + threadIdx.x] : 0.0;
     __syncthreads();
     // one diagonal per thread: blockIdx.y walks the diagonals in chunks of 256 (wide bands would otherwise leave one
@@ -1509,61 +1618,33 @@ __global__ void __launch_bounds__(256) hpk_ir_partial(const float* __restrict__ 
 }
 // one wave per diagonal, four diagonals per workgroup
 // Workgroups beyond the diagonals turn the weights into biases (scripts/pyHICCUPS:163-166) - one launch less.
-__global__ void __launch_bounds__(256) hpk_ir_final(const double* __restrict__ psum, const unsigned* __restrict__ pnan, int nparts,
-                                                    int n, int num, int mw, double* __restrict__ IR,
-                                                    const double* __restrict__ weight, double* __restrict__ bias) {
-    const int nirb = (num + 3) / 4;
+__global__ void __launch_bounds__(256) hpk_ir_final(const HpkBandDesc* __restrict__ bands, int mw, int nirb) {
+    const HpkBandDesc* __restrict__ bd = bands + blockIdx.y;
+    if (!bd->derive) return;
+    const int n = bd->n, num = bd->num;
     if ((int)blockIdx.x >= nirb) {
         const int i = ((int)blockIdx.x - nirb) * 256 + threadIdx.x;
         if (i < n) {
-            const double w = weight[i];
-            bias[i] = (w == 0.0 || w != w) ? 0.0 : 1.0 / w;
+            const double w = gptr(bd->weight)[i];
+            gptr(bd->b1)[i] = (w == 0.0 || w != w) ? 0.0 : 1.0 / w;
         }
         return;
     }
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= num) return;
+    const int nparts = (n + HPK_IR_ROWS - 1) / HPK_IR_ROWS;
+    const double* __restrict__ psum = gptr(bd->psum);
+    const unsigned* __restrict__ pnan = gptr(bd->pnan);
     double s = 0.0;
     unsigned long long nn = 0ull;
     if (k >= mw) for (int p = lane; p < nparts; p += 64) { s += psum[(int64_t)p * num + k]; nn += pnan[(int64_t)p * num + k]; }
     for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off); nn += __shfl_down(nn, off); }
     if (lane != 0) return;
     const long long denom = (long long)(n - k) - (long long)nn;
-    IR[k] = (k >= mw && n - k > 0) ? s / (double)denom : 0.0;       // 0/0 -> NaN like numpy's mean of an empty slice
+    gptr(bd->IR)[k] = (k >= mw && n - k > 0) ? s / (double)denom : 0.0;       // 0/0 -> NaN like numpy's mean of an empty slice
 }
-// ------------------------------------------------------------------ local-expected tables (callers.py:66-72 + 175-198)
 // ------------------------------------------------------------------ freeze
-__device__ __forceinline__ void freeze_replay(const HpkDevPlan* __restrict__ plan, const unsigned long long* hist, const int* swi,
-                                              const int* sslot, int32_t* executed, int& fw_out, int& err_out);
-// Column sums of the per-workgroup resolve histograms, then one thread replays the reference's frozen_w / break logic
-// on the totals (callers.py:208-229, 505-511).  1024 threads; `lds` = scratch of >= 1.1 KiB.
-__device__ __forceinline__ void freeze_body(const HpkDevPlan* __restrict__ plan, const unsigned* __restrict__ hist_part, int nparts,
-                                            unsigned long long* __restrict__ hist_out, int32_t* frozen, int32_t* executed,
-                                            int32_t* err, void* lds) {
-    unsigned long long* hist = reinterpret_cast<unsigned long long*>(lds);                 // [HPK_MAX_STEPS + 1]
-    int* swi = reinterpret_cast<int*>(hist + HPK_MAX_STEPS + 1);                           // the serial part below reads LDS only
-    int* sslot = swi + HPK_MAX_STEPS;
-    if ((int)threadIdx.x < plan->nsteps) { swi[threadIdx.x] = plan->steps[threadIdx.x].wi; sslot[threadIdx.x] = plan->steps[threadIdx.x].slot; }
-    // thread t sums column t % 65 over the partials t / 65, t / 65 + 15, ... (independent loads), LDS atomics finish
-    if (threadIdx.x <= HPK_MAX_STEPS) hist[threadIdx.x] = 0ull;
-    __syncthreads();
-    {
-        const int k = threadIdx.x % (HPK_MAX_STEPS + 1), g = threadIdx.x / (HPK_MAX_STEPS + 1), ng = 1024 / (HPK_MAX_STEPS + 1);
-        if (g < ng) {
-            unsigned long long t = 0ull;
-            for (int p = g; p < nparts; p += ng) t += hist_part[(int64_t)p * (HPK_MAX_STEPS + 1) + k];
-            if (t) atomicAdd(&hist[k], t);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x <= HPK_MAX_STEPS) hist_out[threadIdx.x] = hist[threadIdx.x];
-    if (threadIdx.x != 0) return;
-    int fw, e;
-    freeze_replay(plan, hist, swi, sslot, executed, fw, e);
-    *frozen = fw;
-    *err = e;
-}
 // The reference's frozen_w / break logic on the chromosome's totals (callers.py:208-229, 505-511), one thread.
 // hist[s] = candidates resolved at step s, hist[HPK_HIST_NCAND] = all candidates; executed may be nullptr.
 __device__ __forceinline__ void freeze_replay(const HpkDevPlan* __restrict__ plan, const unsigned long long* hist, const int* swi,
@@ -1591,51 +1672,24 @@ __device__ __forceinline__ void freeze_replay(const HpkDevPlan* __restrict__ pla
     fw_out = fw;
     err_out = e;
 }
-__global__ void __launch_bounds__(1024) hpk_freeze(const HpkDevPlan* __restrict__ plan, const unsigned* __restrict__ hist_part,
-                                                   int nparts, unsigned long long* __restrict__ hist_out,
-                                                   int32_t* frozen, int32_t* executed, int32_t* err) {
-    __shared__ unsigned long long lds[HPK_MAX_STEPS + 1 + HPK_MAX_STEPS];
-    freeze_body(plan, hist_part, nparts, hist_out, frozen, executed, err, lds);
-}
-// The same on totals the stencil workgroups added up themselves (HpkStencilArgs::hist_acc), for launches that no scoring follows.
-__global__ void __launch_bounds__(128) hpk_freeze_tot(const HpkDevPlan* __restrict__ plan, const unsigned long long* __restrict__ acc,
-                                                      unsigned long long* __restrict__ hist_out, int32_t* frozen, int32_t* executed,
-                                                      int32_t* err) {
+// The decision for launches that no scoring follows (probes, HPK_FLAG_NO_SCORE; the scoring kernel replays it in its own
+// prologue): one workgroup per band on the totals the stencil workgroups added up (HpkBandDesc::hist_acc).
+__global__ void __launch_bounds__(128) hpk_freeze_tot(const HpkDevPlan* __restrict__ plan, const HpkBandDesc* __restrict__ bands) {
+    const HpkBandDesc* __restrict__ bd = bands + blockIdx.x;
     __shared__ unsigned long long hist[HPK_MAX_STEPS + 1];
     __shared__ int swi[HPK_MAX_STEPS], sslot[HPK_MAX_STEPS];
+    unsigned char* small = gptr(bd->small);
     if ((int)threadIdx.x < plan->nsteps) { swi[threadIdx.x] = plan->steps[threadIdx.x].wi; sslot[threadIdx.x] = plan->steps[threadIdx.x].slot; }
-    if (threadIdx.x <= HPK_MAX_STEPS) { hist[threadIdx.x] = acc[threadIdx.x * HPK_ACC_STRIDE]; hist_out[threadIdx.x] = hist[threadIdx.x]; }
+    if (threadIdx.x <= HPK_MAX_STEPS) {
+        hist[threadIdx.x] = gptr(bd->hist_acc)[threadIdx.x * HPK_ACC_STRIDE];
+        reinterpret_cast<unsigned long long*>(small + HPK_OFF_HIST)[threadIdx.x] = hist[threadIdx.x];
+    }
     __syncthreads();
     if (threadIdx.x != 0) return;
     int fw, e;
-    freeze_replay(plan, hist, swi, sslot, executed, fw, e);
-    *frozen = fw;
-    *err = e;
-}
-// The freeze decision needs the histograms of every stencil workgroup.  Instead of a kernel of its own (~10 us of an
-// otherwise idle GPU between the stencil and the scoring kernel) the stencil workgroup that finishes last takes it:
-// every workgroup publishes its partial counts (all storing waves drain, one agent-scope release), draws a ticket, and
-// the holder of the last ticket acquires and runs freeze_body.  Placement-independent (cdna_hip_programming.md G16).
-// Call with all 1024 threads after the workgroup's hist_part stores; `lds` is scratch (>= 1.2 KiB, the SAT is dead).
-__device__ __forceinline__ void freeze_by_last_workgroup(const HpkStencilArgs& a, void* lds) {
-    if (a.ticket == nullptr) return;                    // HPK_FREEZE_KERNEL: the stand-alone kernel follows
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    unsigned* flag = reinterpret_cast<unsigned*>(lds);
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned t = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        flag[0] = (t == gridDim.x - 1u) ? 1u : 0u;
-    }
-    __syncthreads();
-    const bool last = flag[0] != 0u;
-    __syncthreads();
-    if (!last) return;
-    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
-    freeze_body(a.plan, a.hist_part, (int)gridDim.x, a.hist, a.frozen, a.executed, a.err,
-                reinterpret_cast<unsigned char*>(lds) + 64);
+    freeze_replay(plan, hist, swi, sslot, reinterpret_cast<int32_t*>(small + HPK_OFF_EXEC), fw, e);
+    *reinterpret_cast<int32_t*>(small + HPK_OFF_FROZEN) = fw;
+    *reinterpret_cast<int32_t*>(small + HPK_OFF_ERR) = e;
 }
 
 // ------------------------------------------------------------------ gap rows
@@ -1757,21 +1811,24 @@ __device__ __forceinline__ void local_expected(const HpkDevPlan* __restrict__ pl
 
 // Edge tables.  Clipping by one matrix end removes whole window rows (top: di < -e) or whole window columns (right:
 // dj > e) whatever the diagonal, so the clipped window is again a 1-D stencil over IR: tap t = dj - di + 2wi carries
-// the summed multiplicity of the surviving cells on that anti-diagonal.  One wave per (side, e, step) and 64
-// diagonals: the taps are formed once in LDS (<= 2wi+1 cells each), then every lane runs <= 4wi+1 multiply-adds on an
+// the summed multiplicity of the surviving cells on that anti-diagonal.  One workgroup per (band, side, e, step) and 256
+// diagonals: the taps are formed once in LDS (<= 2wi+1 cells each), then every thread runs <= 4wi+1 multiply-adds on an
 // LDS-staged IR window.
 // blockIdx.y >= 2 W nsteps: the unclipped (interior) table of step y - 2 W nsteps, same taps without clipping.
-// blockIdx.y >= ntab: zero-fill duty (the per-chromosome counter block; saves a memset launch).
-__global__ void __launch_bounds__(64) hpk_etab_edge(const HpkDevPlan* __restrict__ plan, const double* __restrict__ IR, int n,
-                                                    int num, double* __restrict__ etab, double* __restrict__ eedge,
-                                                    uint4* __restrict__ zero, unsigned long long nzero16, int ntab) {
+// blockIdx.y >= ntab: zero-fill duty (the band's counter block; saves a memset launch).  blockIdx.z = band of the batch.
+#define HPK_ET_THREADS 256
+__global__ void __launch_bounds__(HPK_ET_THREADS) hpk_etab_edge(const HpkDevPlan* __restrict__ plan, const HpkBandDesc* __restrict__ bands,
+                                                                int ntab) {
+    const HpkBandDesc* __restrict__ bd = bands + blockIdx.z;
     if ((int)blockIdx.y >= ntab) {
-        const unsigned long long i = ((unsigned long long)(blockIdx.y - ntab) * gridDim.x + blockIdx.x) * 64ull + threadIdx.x;
-        if (i < nzero16) zero[i] = make_uint4(0u, 0u, 0u, 0u);
+        const unsigned long long i = ((unsigned long long)(blockIdx.y - ntab) * gridDim.x + blockIdx.x) * HPK_ET_THREADS + threadIdx.x;
+        if (i < bd->zero_bytes / 16) reinterpret_cast<uint4*>(gptr(bd->small))[i] = make_uint4(0u, 0u, 0u, 0u);
         return;
     }
+    const double* __restrict__ IR = gptr(bd->IR);
+    const int num = bd->num;
     const int D = plan->D, W = plan->W, mw = plan->mw, ns = plan->nsteps;
-    const int d = blockIdx.x * 64 + threadIdx.x;
+    const int d = blockIdx.x * HPK_ET_THREADS + threadIdx.x;
     int t = blockIdx.y;
     const bool interior = t >= 2 * W * ns;
     if (interior) t -= 2 * W * ns;
@@ -1781,15 +1838,15 @@ __global__ void __launch_bounds__(64) hpk_etab_edge(const HpkDevPlan* __restrict
     const int wi = st.wi;
     __shared__ int lm[HPK_MAX_W + 1];                    // ring multiplicities of this step
     __shared__ double tapK[4 * HPK_MAX_W + 1], tapY[4 * HPK_MAX_W + 1];
-    __shared__ double lir[64 + 4 * HPK_MAX_W + 2];       // IR[d0 - 2wi .. d0 + 63 + 2wi] (0 outside [mw, num))
+    __shared__ double lir[HPK_ET_THREADS + 4 * HPK_MAX_W + 2];       // IR[d0 - 2wi .. d0 + 255 + 2wi] (0 outside [mw, num))
     if ((int)threadIdx.x <= HPK_MAX_W) lm[threadIdx.x] = st.m[threadIdx.x];
-    const int d0 = blockIdx.x * 64, kbase = d0 - 2 * wi;
-    for (int i = threadIdx.x; i < 64 + 4 * wi + 1; i += 64) {
+    const int d0 = blockIdx.x * HPK_ET_THREADS, kbase = d0 - 2 * wi;
+    for (int i = threadIdx.x; i < HPK_ET_THREADS + 4 * wi + 1; i += HPK_ET_THREADS) {
         const int kk = kbase + i;
         lir[i] = (kk >= mw && kk < num) ? IR[kk] : 0.0;
     }
     __syncthreads();
-    for (int tp = threadIdx.x; tp <= 4 * wi; tp += 64) {
+    for (int tp = threadIdx.x; tp <= 4 * wi; tp += HPK_ET_THREADS) {
         const int off = tp - 2 * wi;                     // dj - di
         int ck = 0, cy = 0;
         for (int di = -wi; di <= wi; ++di) {
@@ -1816,24 +1873,30 @@ __global__ void __launch_bounds__(64) hpk_etab_edge(const HpkDevPlan* __restrict
         EY += cy != 0.0 ? cy * v : 0.0;
     }
     if (interior) {
-        etab[(int64_t)(s * 2) * (D + 1) + d] = EK;
-        etab[(int64_t)(s * 2 + 1) * (D + 1) + d] = EY;
+        gptr(bd->etab)[(int64_t)(s * 2) * (D + 1) + d] = EK;
+        gptr(bd->etab)[(int64_t)(s * 2 + 1) * (D + 1) + d] = EY;
         return;
     }
     const int64_t o = ((int64_t)((side * W + e) * ns + s) * 2) * (D + 1) + d;
-    eedge[o] = EK;
-    eedge[o + (D + 1)] = EY;
+    gptr(bd->eedge)[o] = EK;
+    gptr(bd->eedge)[o + (D + 1)] = EY;
 }
 
 // Persistent blocks: block b walks rows b, b + gridDim.x, ...; the per-family counters live in LDS for the block's
 // whole life and are flushed once.  Chunk boundaries sit in LDS; the chunk of E is 3 * exponent(E) plus two
 // comparisons against the reference's own boundary values.
+// blockIdx.y = band of the batch; a band's units are walked by the first `score_wgs` workgroups of its grid row.
 template <bool BH, bool ONE>  // BH: bhfdr (one set, per-pixel lambda = E); otherwise hiccups (lambda chunks); ONE: a single (pw, ww) pair
-__global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
-    __shared__ unsigned int lm[2 * HPK_MAX_PAIRS][HPK_NB + 1];
-    __shared__ unsigned int lf[2 * HPK_MAX_PAIRS][HPK_NB + 1];
+__global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDesc* __restrict__ bands) {
+    const HpkBandDesc* __restrict__ bd = bands + blockIdx.y;
+    const int nwg = bd->score_wgs;
+    if ((int)blockIdx.x >= nwg) return;
+    // per-pair counters: a single-pair launch (every hiccups() run with one (pw, ww), every bhfdr()) needs two sets only
+    constexpr int NSETS_LDS = ONE ? 2 : 2 * HPK_MAX_PAIRS;
+    __shared__ unsigned int lm[NSETS_LDS][HPK_NB + 1];
+    __shared__ unsigned int lf[NSETS_LDS][HPK_NB + 1];
     __shared__ double lbounds[HPK_NB];
-    __shared__ unsigned long long lemax[2 * HPK_MAX_PAIRS];
+    __shared__ unsigned long long lemax[NSETS_LDS];
     __shared__ int lstepw[HPK_MAX_STEPS];
     __shared__ int lpair_slot[HPK_MAX_PAIRS], lpair_wi[HPK_MAX_PAIRS];
     __shared__ int lptoff[HPK_NB_TAB + 2];
@@ -1847,6 +1910,21 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     // kernel: with ~45 scalars live the compiler spilled ~80 of them to VGPR lanes, and the spill traffic
     // (v_readlane / v_writelane / s_nop) was 15 % of the instruction stream of this issue-bound kernel.
     const volatile HpkScoreArgs* ka = (const volatile HpkScoreArgs*)(const void*)__builtin_amdgcn_kernarg_segment_ptr();
+    const volatile HpkBandDesc* kb = bands + blockIdx.y;       // the band's rarely used fields, likewise
+    unsigned char* const small = gptr(bd->small);
+    const int64_t b_cap = bd->cap, b_rec_stride = bd->rec_stride;
+    const unsigned* __restrict__ b_rec_ent = gptr(bd->rec_ent);
+    const uint8_t* __restrict__ b_rec_W = gptr(bd->rec_W);
+    const double2* __restrict__ b_rec_S = gptr(bd->rec_S);
+    const uint2* __restrict__ b_units = gptr(bd->units);
+    const double* __restrict__ b_IR = gptr(bd->IR);
+    const double* __restrict__ b_b1 = gptr(bd->b1);
+    const double* __restrict__ b_b2 = gptr(bd->b2);
+    const double* __restrict__ b_etab = gptr(bd->etab);
+    const double* __restrict__ b_eedge = gptr(bd->eedge);
+    const int b_n = bd->n;
+    HpkSurv* __restrict__ b_surv = gptr(bd->surv);
+    unsigned long long* __restrict__ b_nsurv = reinterpret_cast<unsigned long long*>(small + HPK_OFF_NSURV);
     const int npairs = ONE ? 1 : plan->npairs;
     const int W = plan->W;
     const int nsets = BH ? 1 : 2 * npairs;
@@ -1856,7 +1934,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     const int sig_e = (int)((unsigned long long)__double_as_longlong(a.sig) >> 52);                  // sig > 0, normal
     const unsigned long long sig_m = (unsigned long long)__double_as_longlong(a.sig) & 0xfffffffffffffull;
     if (threadIdx.x < HPK_NB) lbounds[threadIdx.x] = const_cast<const double*>(ka->bounds)[threadIdx.x];
-    if (threadIdx.x < 2 * HPK_MAX_PAIRS) lemax[threadIdx.x] = 0ull;
+    if (threadIdx.x < NSETS_LDS) lemax[threadIdx.x] = 0ull;
     if (threadIdx.x < HPK_MAX_STEPS) lstepw[threadIdx.x] = (threadIdx.x < plan->nsteps) ? plan->steps[threadIdx.x].wi : 0;
     if (threadIdx.x < HPK_MAX_PAIRS) { lpair_slot[threadIdx.x] = plan->pair_slot[threadIdx.x]; lpair_wi[threadIdx.x] = plan->pair_wi[threadIdx.x]; }
     if (threadIdx.x < HPK_NB_TAB + 2) lptoff[threadIdx.x] = const_cast<const int32_t*>(ka->ptab_off)[threadIdx.x];
@@ -1867,25 +1945,23 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     __shared__ unsigned long long lhtot[HPK_MAX_STEPS + 1];
     __shared__ int lslot[HPK_MAX_STEPS];
     __shared__ int lfrozen;
-    if (ka->hist_acc) {
-        if (threadIdx.x <= HPK_MAX_STEPS) lhtot[threadIdx.x] = const_cast<const unsigned long long*>(ka->hist_acc)[threadIdx.x * HPK_ACC_STRIDE];
-        if (threadIdx.x < HPK_MAX_STEPS) lslot[threadIdx.x] = (threadIdx.x < plan->nsteps) ? plan->steps[threadIdx.x].slot : 0;
-    }
+    if (threadIdx.x <= HPK_MAX_STEPS) lhtot[threadIdx.x] = gptr(bd->hist_acc)[threadIdx.x * HPK_ACC_STRIDE];
+    if (threadIdx.x < HPK_MAX_STEPS) lslot[threadIdx.x] = (threadIdx.x < plan->nsteps) ? plan->steps[threadIdx.x].slot : 0;
     __syncthreads();
-    if (ka->hist_acc) {
+    {
         if (threadIdx.x == 0) {
             int fw, e;
-            freeze_replay(plan, lhtot, lstepw, lslot, blockIdx.x == 0 ? const_cast<int32_t*>(ka->executed) : nullptr, fw, e);
+            freeze_replay(plan, lhtot, lstepw, lslot, blockIdx.x == 0 ? reinterpret_cast<int32_t*>(small + HPK_OFF_EXEC) : nullptr, fw, e);
             lfrozen = fw;
-            if (blockIdx.x == 0) { *const_cast<int32_t*>(ka->frozen) = fw; *const_cast<int32_t*>(ka->err) = e; }
+            if (blockIdx.x == 0) { *reinterpret_cast<int32_t*>(small + HPK_OFF_FROZEN) = fw; *reinterpret_cast<int32_t*>(small + HPK_OFF_ERR) = e; }
         }
-        if (blockIdx.x == 0 && threadIdx.x <= HPK_MAX_STEPS) const_cast<unsigned long long*>(ka->hist_out)[threadIdx.x] = lhtot[threadIdx.x];
+        if (blockIdx.x == 0 && threadIdx.x <= HPK_MAX_STEPS) reinterpret_cast<unsigned long long*>(small + HPK_OFF_HIST)[threadIdx.x] = lhtot[threadIdx.x];
         __syncthreads();
     }
 
     const int lane = threadIdx.x & 63;
     const int nsteps_u = plan->nsteps;
-    const int frozen = ka->hist_acc ? lfrozen : *const_cast<const int32_t*>(ka->frozen);
+    const int frozen = lfrozen;
     const unsigned pkcap = (unsigned)plan->pk_cap;
     // Survivor slots are reserved from the global counter HPK_SCH records at a time per wave (same-address atomics
     // run at ~90 per microsecond device-wide); how many slots of a chunk were filled goes to chunk_used[].
@@ -1893,12 +1969,12 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     unsigned wused = HPK_SCH;               // "no chunk yet"
     bool have_chunk = false;
     const int region = __builtin_amdgcn_readfirstlane((int)((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) % HPK_NREG));
-    const int64_t rbase = (int64_t)region * a.cap;      // this wave's survivor region
+    const int64_t rbase = (int64_t)region * b_cap;      // this wave's survivor region
     // Work unit = 4 consecutive 64-record batches of one tile's record region; units are dealt round-robin to all
     // waves of the grid (tiles differ a lot in candidate count), reads are coalesced.
-    const unsigned nunits = *a.nunits;                      // work list appended by hpk_stencil: non-empty units only
+    const unsigned nunits = *reinterpret_cast<const unsigned*>(small + HPK_OFF_NUNITS);     // work list appended by hpk_stencil: non-empty units only
     const unsigned gw = (unsigned)((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-    const unsigned nwv = (unsigned)(((int64_t)gridDim.x * blockDim.x) >> 6);
+    const unsigned nwv = (unsigned)(((int64_t)nwg * blockDim.x) >> 6);
     // One batch ahead.  While a batch is scored the records of the next one - of the same work unit or of the wave's
     // next unit - are on their way, and as soon as this batch's Poisson-table reads are issued the next batch's second
     // round of loads (IR, biases, the local-expected table entries of its first pair: all addressed from its record) is
@@ -1926,26 +2002,26 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     auto set_pair = [&](Geo& g, const int pj) {
         g.pj = pj;
         g.wi0 = __builtin_amdgcn_readfirstlane(lpair_wi[pj]);
-        g.sl = (int64_t)__builtin_amdgcn_readfirstlane(lpair_slot[pj]) * a.rec_stride;
+        g.sl = (int64_t)__builtin_amdgcn_readfirstlane(lpair_slot[pj]) * b_rec_stride;
     };
     // first round: entry, first slot's step and sums (idle lanes read the tile's first record: always allocated, never used)
     auto issue_records = [&](const Geo& g) {
         ri_b = (g.i0 + lane < g.cnt) ? (unsigned)(g.i0 + lane) : 0u;
-        ent_b = (a.rec_ent + g.tbase0)[ri_b];
-        stp_b = (int)(a.rec_W + g.tbase0 + g.sl)[ri_b];
-        s2_b = (a.rec_S + g.tbase0 + g.sl)[ri_b];
+        ent_b = (b_rec_ent + g.tbase0)[ri_b];
+        stp_b = (int)(b_rec_W + g.tbase0 + g.sl)[ri_b];
+        s2_b = (b_rec_S + g.tbase0 + g.sl)[ri_b];
     };
     // second round of the batch whose records are in (ent_b, stp_b); stp_b becomes the step that counts (0: none)
     auto issue_round2 = [&](const Geo& g) {
         const bool cn = g.i0 + lane < g.cnt;
         const unsigned e = cn ? ent_b : 0u;
         const int r = g.r0 + (int)((e >> 7) & 63u), c = g.c0 + (int)(e & 127u), d = c - r;
-        ir_b = a.IR[cn ? (unsigned)d : 0u];
-        b2_b = a.b2[cn ? (unsigned)c : 0u];
-        b1_b = a.b1[cn ? (unsigned)r : 0u];
-        const bool top = cn && r < W, right = cn && c >= a.n - W;
-        const double* __restrict__ tab = (top != right) ? a.eedge : a.etab;
-        const unsigned tbase = (top != right) ? (unsigned)(((top ? 0 : 1) * W + (top ? r : a.n - 1 - c)) * nsteps_u) * tstride : 0u;
+        ir_b = b_IR[cn ? (unsigned)d : 0u];
+        b2_b = b_b2[cn ? (unsigned)c : 0u];
+        b1_b = b_b1[cn ? (unsigned)r : 0u];
+        const bool top = cn && r < W, right = cn && c >= b_n - W;
+        const double* __restrict__ tab = (top != right) ? b_eedge : b_etab;
+        const unsigned tbase = (top != right) ? (unsigned)(((top ? 0 : 1) * W + (top ? r : b_n - 1 - c)) * nsteps_u) * tstride : 0u;
         int stp = cn ? stp_b : 0;
         const int stepw = lstepw[stp > 0 ? stp - 1 : 0];
         asm volatile("" : "+v"(stp));
@@ -1961,10 +2037,10 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
     };
     if (gw < nunits) {
         Geo gn;
-        decode(a.units[gw], gn);
+        decode(b_units[gw], gn);
         set_pair(gn, 0);
         unsigned u = gw;
-        uint2 un_next = (u + nwv < nunits) ? a.units[u + nwv] : make_uint2(0u, 0u);
+        uint2 un_next = (u + nwv < nunits) ? b_units[u + nwv] : make_uint2(0u, 0u);
         issue_records(gn);
         issue_round2(gn);
         bool more = true;
@@ -1989,7 +2065,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                     more = u < nunits;
                     if (more) {
                         decode(un_next, gn);
-                        if (u + nwv < nunits) un_next = a.units[u + nwv];
+                        if (u + nwv < nunits) un_next = b_units[u + nwv];
                     }
                 }
             }
@@ -2004,10 +2080,10 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
             const int c = g.c0 + (int)(ent & 127u);
             const int d = c - r;
             float rawpix = (float)(ent >> 13);          // the SAT holds counts capped at HPK_PK_CAP: those are re-read
-            if (cand && (ent >> 13) >= pkcap) rawpix = ka->raw[(int64_t)r * ka->ld + d];
+            if (cand && (ent >> 13) >= pkcap) rawpix = gptr(kb->raw)[(int64_t)r * kb->ld + d];
             const double O = (double)rawpix;
             // which local-expected table serves this pixel (interior / clipped by one matrix end / both: explicit)
-            const bool top = cand && r < W, right = cand && c >= a.n - W;
+            const bool top = cand && r < W, right = cand && c >= b_n - W;
             const bool both = top && right;
 
             const bool anyboth = __ballot(both) != 0ull;                // (both matrix ends in one window: short chromosomes only)
@@ -2022,7 +2098,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                 if (anyboth) {
                     const bool bo = both && stp != 0;
                     if (__ballot(bo) != 0ull) {
-                        if (bo) edge_expected(plan->steps[stp - 1].m, plan->steps[stp - 1].wi, a.IR, r, c, a.n, a.num, a.mw, EK, EY);
+                        if (bo) edge_expected(plan->steps[stp - 1].m, plan->steps[stp - 1].wi, b_IR, r, c, b_n, kb->num, a.mw, EK, EY);
                     }
                 }
                 EK = stp != 0 ? EK : 0.0;
@@ -2145,16 +2221,16 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                                 k = (pb >> 52) == 0ull ? hbins - 1 : k;
                                 k = k < 0 ? 0 : (k > hbins - 1 ? hbins - 1 : k);
                                 if (chunk <= HPK_NB_TAB) atomicAdd(&lhist[(set * (HPK_NB_TAB + 1) + chunk) * hbins + k], 1u);
-                                else atomicAdd(&const_cast<unsigned int*>(ka->hist)[(set * (HPK_NB + 1) + chunk) * hbins + k], 1u);
+                                else atomicAdd(&gptr(kb->cnt)[(set * (HPK_NB + 1) + chunk) * hbins + k], 1u);
                             }
                         }
                         // per-wave reservation of survivor slots
                         const unsigned scnt = (unsigned)__popcll(sm);
                         if (wused + scnt > HPK_SCH) {            // wave-uniform: retire the chunk, take a new one
-                            if (have_chunk && lane == 0 && (int64_t)wbase < a.cap) const_cast<unsigned*>(ka->chunk_used)[(rbase + (int64_t)wbase) / HPK_SCH] = wused;
+                            if (have_chunk && lane == 0 && (int64_t)wbase < b_cap) gptr(kb->chunk_used)[(rbase + (int64_t)wbase) / HPK_SCH] = wused;
                             have_chunk = true;
                             unsigned long long nb = 0ull;
-                            if (lane == 0) nb = atomicAdd(&a.nsurv[region * HPK_REG_STRIDE], (unsigned long long)HPK_SCH);
+                            if (lane == 0) nb = atomicAdd(&b_nsurv[region * HPK_REG_STRIDE], (unsigned long long)HPK_SCH);
                             wbase = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)nb) |
                                     (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(nb >> 32)) << 32;
                             wused = 0u;
@@ -2163,12 +2239,12 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
                         wused += scnt;
                         if (surv) {
                             const unsigned long long idx = basei + (unsigned long long)__popcll(sm & ((1ull << lane) - 1ull));
-                            if ((int64_t)idx < a.cap) {
+                            if ((int64_t)idx < b_cap) {
                                 HpkSurv rec;
                                 rec.x = r; rec.y = c; rec.O = rawpix; rec.set = (uint8_t)set; rec.chunk = (uint8_t)chunk;
                                 rec.flag = (fl == 0 && eY == 0.0) ? 1 : 0;           // callers.py:330
                                 rec.pad = 0; rec.E = E; rec.p = p; rec.bal = 0.0;       // balanced value: filled by hpk_thr_compact
-                                a.surv[rbase + (int64_t)idx] = rec;
+                                b_surv[rbase + (int64_t)idx] = rec;
                             }
                         }
                     }
@@ -2176,21 +2252,21 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a) {
             }
         }
     }
-    if (have_chunk && lane == 0 && (int64_t)wbase < a.cap) const_cast<unsigned*>(ka->chunk_used)[(rbase + (int64_t)wbase) / HPK_SCH] = wused;
+    if (have_chunk && lane == 0 && (int64_t)wbase < b_cap) gptr(kb->chunk_used)[(rbase + (int64_t)wbase) / HPK_SCH] = wused;
     __syncthreads();
     for (int i = threadIdx.x; i < nsets * (HPK_NB + 1); i += blockDim.x) {
         const unsigned v = (&lm[0][0])[i], f = (&lf[0][0])[i];
-        if (v) atomicAdd(&const_cast<unsigned int*>(ka->fam_m)[i], v);
-        if (f) atomicAdd(&const_cast<unsigned int*>(ka->fam_f)[i], f);
+        if (v) atomicAdd(&reinterpret_cast<unsigned int*>(small + HPK_OFF_FAM_M)[i], v);
+        if (f) atomicAdd(&reinterpret_cast<unsigned int*>(small + HPK_OFF_FAM_F)[i], f);
     }
     if (threadIdx.x < nsets) {
-        if (lemax[threadIdx.x]) atomicMax(&const_cast<unsigned long long*>(ka->emax_bits)[threadIdx.x], lemax[threadIdx.x]);
+        if (lemax[threadIdx.x]) atomicMax(&reinterpret_cast<unsigned long long*>(small + HPK_OFF_EMAX)[threadIdx.x], lemax[threadIdx.x]);
     }
     for (int i = threadIdx.x; i < nsets * (HPK_NB_TAB + 1) * hbins; i += blockDim.x) {
         const unsigned v = lhist[i];
         if (v) {
             const int k = i % hbins, fc = i / hbins, ch = fc % (HPK_NB_TAB + 1), st = fc / (HPK_NB_TAB + 1);
-            atomicAdd(&const_cast<unsigned int*>(ka->hist)[(st * (HPK_NB + 1) + ch) * hbins + k], v);
+            atomicAdd(&gptr(kb->cnt)[(st * (HPK_NB + 1) + ch) * hbins + k], v);
         }
     }
 }
@@ -2223,10 +2299,19 @@ __device__ __forceinline__ void thr_table(double* lthr, const unsigned int* __re
 __device__ __forceinline__ double thr_t0(unsigned m, unsigned f, double sig) {
     return m ? fmin(sig, sig * ((double)f / (double)m) * (1.0 + 1e-9)) : 0.0;
 }
-__global__ void __launch_bounds__(256) hpk_thr_hist(const HpkSurv* __restrict__ surv, const unsigned long long* __restrict__ nsurv,
-                                                    int64_t cap, const unsigned* __restrict__ chunk_used,
-                                                    const unsigned int* __restrict__ fam_m, const unsigned int* __restrict__ fam_f,
-                                                    unsigned int* __restrict__ hist, int nbins, double sig, int nfam) {
+// The survivor-list kernels: blockIdx.z = band of the batch, blockIdx.y = survivor region.
+#define HPK_THR_BAND_ARGS                                                                                              \
+    const HpkBandDesc* __restrict__ bd = bands + blockIdx.z;                                                          \
+    unsigned char* const small = gptr(bd->small);                                                                    \
+    const HpkSurv* __restrict__ surv = gptr(bd->surv);                                                                \
+    const unsigned long long* __restrict__ nsurv = reinterpret_cast<const unsigned long long*>(small + HPK_OFF_NSURV); \
+    const int64_t cap = bd->cap;                                                                                       \
+    const unsigned* __restrict__ chunk_used = gptr(bd->chunk_used);                                                    \
+    const unsigned int* __restrict__ fam_m = reinterpret_cast<const unsigned int*>(small + HPK_OFF_FAM_M);             \
+    const unsigned int* __restrict__ fam_f = reinterpret_cast<const unsigned int*>(small + HPK_OFF_FAM_F);
+__global__ void __launch_bounds__(256) hpk_thr_hist(const HpkBandDesc* __restrict__ bands, int nbins, double sig, int nfam) {
+    HPK_THR_BAND_ARGS
+    unsigned int* __restrict__ hist = gptr(bd->cnt);
     extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
     double* lt0 = reinterpret_cast<double*>(hsm);                        // [nfam]
     unsigned* lh = reinterpret_cast<unsigned*>(hsm + (size_t)nfam * 8);   // [nfam][nbins]
@@ -2278,10 +2363,9 @@ __device__ __forceinline__ void thr_table_hist(double* lthr, const unsigned int*
         lthr[i] = t;
     }
 }
-__global__ void __launch_bounds__(256) hpk_thr_count(const HpkSurv* __restrict__ surv, const unsigned long long* __restrict__ nsurv,
-                                                     int64_t cap, const unsigned* __restrict__ chunk_used,
-                                                     const unsigned int* __restrict__ fam_m, const unsigned int* __restrict__ fam_f,
-                                                     unsigned int* __restrict__ cnt, int round, double sig, int nfam) {
+__global__ void __launch_bounds__(256) hpk_thr_count(const HpkBandDesc* __restrict__ bands, int round, double sig, int nfam) {
+    HPK_THR_BAND_ARGS
+    unsigned int* __restrict__ cnt = gptr(bd->cnt);
     __shared__ unsigned int lc[HPK_NFAM];
     __shared__ double lthr[HPK_NFAM];
     const int reg = blockIdx.y;             // one grid row per survivor region
@@ -2305,13 +2389,16 @@ __global__ void __launch_bounds__(256) hpk_thr_count(const HpkSurv* __restrict__
 }
 // The first `inl` survivors of the cut go to out_head (which travels to the host together with the counters), the rest
 // to out_rest.
-__global__ void __launch_bounds__(256) hpk_thr_compact(const HpkSurv* __restrict__ surv, const unsigned long long* __restrict__ nsurv,
-                                                       int64_t cap, const unsigned* __restrict__ chunk_used,
-                                                       const unsigned int* __restrict__ fam_m, const unsigned int* __restrict__ fam_f,
-                                                       const unsigned int* __restrict__ cnt, int rounds, double sig, int nfam,
-                                                       HpkSurv* __restrict__ out_head, unsigned long long inl,
-                                                       HpkSurv* __restrict__ out_rest, unsigned long long* __restrict__ nout,
-                                                       const double* __restrict__ bal, const double* __restrict__ weight, int64_t ld) {
+__global__ void __launch_bounds__(256) hpk_thr_compact(const HpkBandDesc* __restrict__ bands, int rounds, double sig, int nfam) {
+    HPK_THR_BAND_ARGS
+    const unsigned int* __restrict__ cnt = gptr(bd->cnt);
+    HpkSurv* __restrict__ out_head = reinterpret_cast<HpkSurv*>(small + bd->off_inl);
+    const unsigned long long inl = HPK_HEAD_INLINE;
+    HpkSurv* __restrict__ out_rest = gptr(bd->surv2);
+    unsigned long long* __restrict__ nout = reinterpret_cast<unsigned long long*>(small + HPK_OFF_NOUT);
+    const double* __restrict__ bal = gptr(bd->bal);
+    const double* __restrict__ weight = gptr(bd->weight);
+    const int64_t ld = bd->ld;
     __shared__ double lthr[HPK_NFAM];
     const int lane = threadIdx.x & 63;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -2471,7 +2558,7 @@ __global__ void __launch_bounds__(64) hpk_brute(HpkBruteArgs a) {
 int hpk_stencil_lds_bytes() { return LR * LC * 12 + HPK_NWAVES * HPK_LISTCAP * 4 + 16; }
 
 template <int NW, bool BALF64, bool SIMPLE>
-static void launch_stencil_t(const HpkStencilArgs& a, hipStream_t st) {
+static void launch_stencil_t(const HpkStencil1Args& a, int grid, hipStream_t st) {
     auto kern = hpk_stencil<NW, BALF64, SIMPLE>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -2479,13 +2566,13 @@ static void launch_stencil_t(const HpkStencilArgs& a, hipStream_t st) {
                                   hpk_stencil_lds_bytes());
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.grid), dim3(NW * 64), hpk_stencil_lds_bytes(), st, a, a.raw, a.bal, a.weight, a.rec_S, a.rec_W);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), hpk_stencil_lds_bytes(), st, a, a.raw, a.bal, a.weight, a.rec_S, a.rec_W);
 }
 
 int hpk_stencil_s_lds_bytes() { return LR * LC * 12 + HPK_TLIST * 4 + 128 + HPK_MAX_STEPS * 32 + HPK_KSLOTS * 32; }
 
 template <bool BALF64, bool SINGLE>
-static void launch_stencil_s_t(const HpkStencilArgs& a, hipStream_t st) {
+static void launch_stencil_s_t(const HpkStencilArgs& a, const HpkBandDesc* d_bands, hipStream_t st) {
     auto kern = hpk_stencil_s<BALF64, SINGLE>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -2493,27 +2580,36 @@ static void launch_stencil_s_t(const HpkStencilArgs& a, hipStream_t st) {
                                   hpk_stencil_s_lds_bytes());
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.grid), dim3(1024), hpk_stencil_s_lds_bytes(), st, a);
+    hipLaunchKernelGGL(kern, dim3(a.grid), dim3(1024), hpk_stencil_s_lds_bytes(), st, a, d_bands);
 }
 
 // Simple-Reads plans within the buffer-addressing limits of hpk_stencil_s (32-bit byte offsets inside one tile's rows,
 // weights addressed from element 0) go to the second-generation kernel; everything else to hpk_stencil.
-bool hpk_stencil_s_applies(const HpkStencilArgs& a, bool simple) {
-    static const bool off = std::getenv("HPK_OLD_STENCIL") != nullptr;
-    return simple && !off && HPK_NWAVES == 16 && a.ld <= (int64_t)(1 << 21) && a.n < (1 << 27) && a.W >= 4 && a.TR * a.TC <= HPK_TLIST;
+bool hpk_stencil_s_applies(const HpkStencilArgs& a, bool simple, int64_t max_ld, int32_t max_n) {
+    return simple && HPK_NWAVES == 16 && max_ld <= (int64_t)(1 << 21) && max_n < (1 << 27) && a.W >= 4 && a.TR * a.TC <= HPK_TLIST;
 }
 
-void hpk_launch_stencil(const HpkStencilArgs& a, bool balf64, bool simple, hipStream_t st) {
-    if (hpk_stencil_s_applies(a, simple)) {
-        static const bool nosingle = std::getenv("HPK_NO_SINGLE") != nullptr;
-        const bool single = a.single && !nosingle;
-        if (balf64) { if (single) launch_stencil_s_t<true, true>(a, st); else launch_stencil_s_t<true, false>(a, st); }
-        else        { if (single) launch_stencil_s_t<false, true>(a, st); else launch_stencil_s_t<false, false>(a, st); }
-        return;
-    }
+void hpk_launch_stencil_batch(const HpkStencilArgs& a, const HpkBandDesc* d_bands, bool balf64, hipStream_t st) {
+    const bool single = a.single != 0;
+    if (balf64) { if (single) launch_stencil_s_t<true, true>(a, d_bands, st); else launch_stencil_s_t<true, false>(a, d_bands, st); }
+    else        { if (single) launch_stencil_s_t<false, true>(a, d_bands, st); else launch_stencil_s_t<false, false>(a, d_bands, st); }
+}
+
+void hpk_launch_stencil_old(const HpkStencilArgs& a, const HpkBandDesc& hb, bool balf64, bool simple, int grid, hipStream_t st) {
+    HpkStencil1Args o;
+    // (C-style casts: in the device pass of this file the descriptor's fields are global-address-space pointers)
+    unsigned char* small = (unsigned char*)hb.small;
+    o.raw = (const float*)hb.raw; o.bal = (const double*)hb.bal; o.weight = (const double*)hb.weight; o.plan = a.plan;
+    o.rec_ent = (unsigned*)hb.rec_ent; o.rec_S = (double2*)hb.rec_S; o.rec_W = (uint8_t*)hb.rec_W; o.tile_cnt = (unsigned*)hb.tile_cnt;
+    o.units = (uint2*)hb.units; o.nunits = reinterpret_cast<unsigned*>(small + HPK_OFF_NUNITS);
+    o.tilecap = a.tilecap; o.rec_stride = hb.rec_stride; o.gap = (uint8_t*)hb.gap;
+    o.hist = reinterpret_cast<unsigned long long*>(small + HPK_OFF_HIST);
+    o.hist_acc = (unsigned long long*)hb.hist_acc; o.risk = a.risk; o.n = hb.n; o.num = hb.num; o.ld = hb.ld;
+    o.W = a.W; o.mw = a.mw; o.D = a.D; o.TR = a.TR; o.TC = a.TC; o.J = a.J; o.ntiles = hb.ntiles; o.chunk = hb.chunk;
+    o.order = a.order; o.clk = a.clk; o.dbg_stop = a.dbg_stop;
     constexpr int NW = HPK_NWAVES;
-    if (balf64) { if (simple) launch_stencil_t<NW, true, true>(a, st); else launch_stencil_t<NW, true, false>(a, st); }
-    else        { if (simple) launch_stencil_t<NW, false, true>(a, st); else launch_stencil_t<NW, false, false>(a, st); }
+    if (balf64) { if (simple) launch_stencil_t<NW, true, true>(o, grid, st); else launch_stencil_t<NW, true, false>(o, grid, st); }
+    else        { if (simple) launch_stencil_t<NW, false, true>(o, grid, st); else launch_stencil_t<NW, false, false>(o, grid, st); }
 }
 
 void hpk_launch_dense(const HpkDenseArgs& a, hipStream_t st) {
@@ -2526,13 +2622,8 @@ void hpk_launch_probe(const HpkDenseArgs& a, const int32_t* rows, const int32_t*
     hipLaunchKernelGGL(hpk_probe, dim3((unsigned)count), dim3(64), 0, st, a, rows, cols, count, out);
 }
 
-void hpk_launch_freeze_tot(const HpkDevPlan* plan, const unsigned long long* hist_acc, unsigned long long* hist,
-                           int32_t* frozen, int32_t* executed, int32_t* err, hipStream_t st) {
-    hipLaunchKernelGGL(hpk_freeze_tot, dim3(1), dim3(128), 0, st, plan, hist_acc, hist, frozen, executed, err);
-}
-void hpk_launch_freeze(const HpkDevPlan* plan, unsigned long long* hist, const unsigned* hist_part, int nparts,
-                       int32_t* frozen, int32_t* executed, int32_t* err, hipStream_t st) {
-    hipLaunchKernelGGL(hpk_freeze, dim3(1), dim3(1024), 0, st, plan, hist_part, nparts, hist, frozen, executed, err);
+void hpk_launch_freeze_tot(const HpkDevPlan* plan, const HpkBandDesc* d_bands, int nbands, hipStream_t st) {
+    hipLaunchKernelGGL(hpk_freeze_tot, dim3(nbands), dim3(128), 0, st, plan, d_bands);
 }
 
 void hpk_launch_gap(const float* raw, const double* bal, const double* weight, int32_t n, int32_t num, int64_t ld,
@@ -2540,8 +2631,8 @@ void hpk_launch_gap(const float* raw, const double* bal, const double* weight, i
     hipLaunchKernelGGL(hpk_gap, dim3((n + 3) / 4), dim3(256), 0, st, raw, bal, weight, n, num, ld, mw, gap);
 }
 
-// Persistent grid: exactly the workgroups that are resident at once (occupancy x CUs), so that no second round of
-// workgroups pays the prologue again (measured: 0.105 -> 0.095 ms against twice as many).
+// Persistent grid: a single chromosome gets exactly the workgroups that are resident at once (occupancy x CUs), so that
+// no second round of workgroups pays the prologue again (measured: 0.105 -> 0.095 ms against twice as many).
 template <bool BH, bool ONE>
 static int score_grid(int cus, size_t lds) {
     static int per_cu = 0;
@@ -2551,35 +2642,40 @@ static int score_grid(int cus, size_t lds) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, hpk_score<BH, ONE>, 256, lds) != hipSuccess || nb <= 0) nb = 4;
         per_cu = nb; per_cu_lds = lds;
     }
-    static const int gm = std::getenv("HPK_SCORE_GM") ? std::atoi(std::getenv("HPK_SCORE_GM")) : 0;
-    return cus * (gm > 0 ? gm : per_cu);
+    return cus * per_cu;
 }
 // bins per family of the p-value histogram hpk_score keeps (0 = none: HpkScoreArgs::hbins)
 int hpk_score_hist_bins(int nsets) { return nsets <= 6 ? 8 : 4; }
-void hpk_launch_score(const HpkScoreArgs& a, bool bhfdr, int cus, hipStream_t st) {
-    if (a.ntiles <= 0 || a.n <= 0) return;
-    const int nsets = bhfdr ? 1 : 2 * a.nsets_half;
-    const size_t lds = (size_t)nsets * (HPK_NB_TAB + 1) * (size_t)a.hbins * 4;
-    if (bhfdr) hipLaunchKernelGGL((hpk_score<true, true>), dim3(score_grid<true, true>(cus, lds)), dim3(256), lds, st, a);
-    else if (a.nsets_half == 1) hipLaunchKernelGGL((hpk_score<false, true>), dim3(score_grid<false, true>(cus, lds)), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((hpk_score<false, false>), dim3(score_grid<false, false>(cus, lds)), dim3(256), lds, st, a);
+static size_t score_lds(bool bhfdr, int npairs, int hbins) {
+    const int nsets = bhfdr ? 1 : 2 * npairs;
+    return (size_t)nsets * (HPK_NB_TAB + 1) * (size_t)hbins * 4;
+}
+int hpk_score_grid(bool bhfdr, int npairs, int hbins, int cus) {
+    const size_t lds = score_lds(bhfdr, npairs, hbins);
+    if (bhfdr) return score_grid<true, true>(cus, lds);
+    if (npairs == 1) return score_grid<false, true>(cus, lds);
+    return score_grid<false, false>(cus, lds);
+}
+void hpk_launch_score(const HpkScoreArgs& a, const HpkBandDesc* d_bands, int nbands, bool bhfdr, hipStream_t st) {
+    if (nbands <= 0 || a.gridx <= 0) return;
+    const size_t lds = score_lds(bhfdr, a.nsets_half, a.hbins);
+    const dim3 grid(a.gridx, nbands);
+    if (bhfdr) hipLaunchKernelGGL((hpk_score<true, true>), grid, dim3(256), lds, st, a, d_bands);
+    else if (a.nsets_half == 1) hipLaunchKernelGGL((hpk_score<false, true>), grid, dim3(256), lds, st, a, d_bands);
+    else hipLaunchKernelGGL((hpk_score<false, false>), grid, dim3(256), lds, st, a, d_bands);
 }
 
 int hpk_thr_hist_bins(int nsets) { return nsets * (HPK_NB + 1) <= 1032 ? 16 : 8; }   // LDS of hpk_thr_hist <= 83 KB
 
-void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, int64_t cap, const unsigned* chunk_used,
-                        const unsigned int* fam_m, const unsigned int* fam_f, unsigned int* fam_cnt, double sig, int rounds,
-                        int nsets, HpkSurv* out_head, unsigned long long inl, HpkSurv* out_rest, unsigned long long* nout,
-                        const double* bal, const double* weight, int64_t ld, int cus, hipStream_t st) {
+void hpk_launch_tighten(const HpkBandDesc* d_bands, int nbands, double sig, int rounds, int nsets, hipStream_t st) {
     if (rounds > HPK_TIGHTEN_MAX) rounds = HPK_TIGHTEN_MAX;
     const int nfam = nsets * (HPK_NB + 1);          // families in use: (set, chunk)
-    static const int gx = std::getenv("HPK_THR_GX") ? std::atoi(std::getenv("HPK_THR_GX")) : 8;
+    const dim3 grid(8, HPK_NREG, nbands);
     if (rounds <= -100) {       // the histogram came with the scoring kernel: only the compaction is left
-        hipLaunchKernelGGL(hpk_thr_compact, dim3(gx, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt,
-                           rounds, sig, nfam, out_head, inl, out_rest, nout, bal, weight, ld);
+        hipLaunchKernelGGL(hpk_thr_compact, grid, dim3(256), 0, st, d_bands, rounds, sig, nfam);
         return;
     }
-    if (rounds < 0) {           // one histogram pass instead of the counting rounds (fam_cnt = [nfam][nbins], zeroed)
+    if (rounds < 0) {           // one histogram pass instead of the counting rounds (cnt = [nfam][nbins], zeroed)
         const int nbins = hpk_thr_hist_bins(nsets);
         const size_t lds = (size_t)nfam * 8 + (size_t)nfam * nbins * 4;
         static bool attr_done = false;
@@ -2587,70 +2683,70 @@ void hpk_launch_tighten(const HpkSurv* surv, const unsigned long long* nsurv, in
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hpk_thr_hist), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             attr_done = true;
         }
-        hipLaunchKernelGGL(hpk_thr_hist, dim3(gx, HPK_NREG), dim3(256), lds, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt, nbins, sig, nfam);
-        hipLaunchKernelGGL(hpk_thr_compact, dim3(gx, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt,
-                           -nbins, sig, nfam, out_head, inl, out_rest, nout, bal, weight, ld);
+        hipLaunchKernelGGL(hpk_thr_hist, grid, dim3(256), lds, st, d_bands, nbins, sig, nfam);
+        hipLaunchKernelGGL(hpk_thr_compact, grid, dim3(256), 0, st, d_bands, -nbins, sig, nfam);
         return;
     }
     for (int r = 0; r < rounds; ++r)
-        hipLaunchKernelGGL(hpk_thr_count, dim3(gx, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt, r, sig, nfam);
-    hipLaunchKernelGGL(hpk_thr_compact, dim3(gx, HPK_NREG), dim3(256), 0, st, surv, nsurv, cap, chunk_used, fam_m, fam_f, fam_cnt,
-                       rounds, sig, nfam, out_head, inl, out_rest, nout, bal, weight, ld);
+        hipLaunchKernelGGL(hpk_thr_count, grid, dim3(256), 0, st, d_bands, r, sig, nfam);
+    hipLaunchKernelGGL(hpk_thr_compact, grid, dim3(256), 0, st, d_bands, rounds, sig, nfam);
 }
 
-void hpk_launch_prep(const float* raw, const double* weight, int n, int num, int64_t ld, int mw, double* psum, unsigned* pnan,
-                     double* IR, double* bias, hipStream_t st) {
-    const int nparts = (n + HPK_IR_ROWS - 1) / HPK_IR_ROWS;        // hpk_api.cpp sizes psum / pnan with the same constant
-    hipLaunchKernelGGL(hpk_ir_partial, dim3(nparts, (num - mw + 255) / 256), dim3(256), 0, st, raw, weight, n, num, ld, mw, psum, pnan);
-    hipLaunchKernelGGL(hpk_ir_final, dim3((num + 3) / 4 + (n + 255) / 256), dim3(256), 0, st, psum, pnan, nparts, n, num, mw, IR,
-                       weight, bias);
+void hpk_launch_prep(const HpkBandDesc* d_bands, int nbands, int max_n, int max_num, int mw, hipStream_t st) {
+    const int nparts = (max_n + HPK_IR_ROWS - 1) / HPK_IR_ROWS;        // hpk_api.cpp sizes psum / pnan with the same constant
+    const int nirb = (max_num + 3) / 4;
+    hipLaunchKernelGGL(hpk_ir_partial, dim3(nparts, (max_num - mw + 255) / 256, nbands), dim3(256), 0, st, d_bands, mw);
+    hipLaunchKernelGGL(hpk_ir_final, dim3(nirb + (max_n + 255) / 256, nbands), dim3(256), 0, st, d_bands, mw, nirb);
 }
 
-void hpk_launch_etab(const HpkDevPlan* plan, int nsteps, int D, int W, const double* IR, int n, int num, double* etab,
-                     double* eedge, void* zero, size_t zero_bytes, hipStream_t st) {
-    const int gx = (D + 64) / 64;
+void hpk_launch_etab(const HpkDevPlan* plan, const HpkBandDesc* d_bands, int nbands, int nsteps, int D, int W, size_t max_zero,
+                     hipStream_t st) {
+    const int gx = (D + HPK_ET_THREADS) / HPK_ET_THREADS;
     const int ntab = 2 * W * nsteps + nsteps;
-    // rows of workgroups beyond the tables zero-fill `zero` (multiple of 16 bytes): gx * 64 lanes x 16 B per row
-    const int nzero = (int)((zero_bytes / 16 + (size_t)gx * 64 - 1) / ((size_t)gx * 64));
-    hipLaunchKernelGGL(hpk_etab_edge, dim3(gx, ntab + nzero), dim3(64), 0, st, plan, IR, n, num, etab, eedge,
-                       reinterpret_cast<uint4*>(zero), (unsigned long long)(zero_bytes / 16), ntab);
+    // rows of workgroups beyond the tables zero-fill the bands' counter blocks: gx * 256 threads x 16 B per row
+    const int nzero = (int)((max_zero / 16 + (size_t)gx * HPK_ET_THREADS - 1) / ((size_t)gx * HPK_ET_THREADS));
+    hipLaunchKernelGGL(hpk_etab_edge, dim3(gx, ntab + nzero, nbands), dim3(HPK_ET_THREADS), 0, st, plan, d_bands, ntab);
 }
 
-// result head -> pinned host memory by a kernel (the copy engine costs ~15 us of start-up latency per chromosome).  The
+// Result heads -> pinned host memory by a kernel (the copy engine costs ~15 us of start-up latency per chromosome).  A
 // head is 200 KB of which a chromosome fills a third - family counters of the sets in use, one flag per row, the
-// survivors that made the cut - and the PCIe write is what the launch takes: only the filled stretches travel (up to
-// four [begin, end) in 16-byte units; the last one ends after min(*nout, inl) records of recbytes).
-struct HpkPubSegs { unsigned b[4], e[4]; };
-__global__ void __launch_bounds__(256) hpk_publish(const uint4* __restrict__ src, uint4* __restrict__ dst, HpkPubSegs sg,
-                                                   const unsigned long long* __restrict__ nout, unsigned inl, unsigned recbytes) {
-    if (nout) {
-        const unsigned long long no = *nout;
-        sg.e[3] = sg.b[3] + (unsigned)(((no < inl ? no : (unsigned long long)inl) * recbytes + 15ull) / 16ull);
+// survivors that made the cut - and the PCIe write is what the launch takes: only the filled stretches travel (four
+// [begin, end) in 16-byte units; the last one ends after min(nout, HPK_HEAD_INLINE) records).  blockIdx.y = band.
+__global__ void __launch_bounds__(256) hpk_publish(const HpkBandDesc* __restrict__ bands, int nsets, int full) {
+    const HpkBandDesc* __restrict__ bd = bands + blockIdx.y;
+    const unsigned char* const small = gptr(bd->small);
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(small);
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(gptr(bd->head_host));
+    unsigned b[4], e[4];
+    const unsigned head_end = (bd->off_inl + (unsigned)(HPK_HEAD_INLINE * sizeof(HpkSurv))) / 16u;
+    if (full) { b[0] = 0u; e[0] = head_end; b[1] = e[1] = b[2] = e[2] = b[3] = e[3] = 0u; }
+    else {
+        const unsigned nfam_b = 4u * (unsigned)nsets * (HPK_NB + 1);
+        const unsigned long long no = *reinterpret_cast<const unsigned long long*>(small + HPK_OFF_NOUT);
+        b[0] = 0u; e[0] = (HPK_OFF_FAM_M + nfam_b + 15u) / 16u;
+        b[1] = HPK_OFF_FAM_F / 16u; e[1] = (HPK_OFF_FAM_F + nfam_b + 15u) / 16u;
+        b[2] = bd->off_rowlive / 16u; e[2] = (bd->off_rowlive + (unsigned)bd->n + 15u) / 16u;
+        b[3] = bd->off_inl / 16u;
+        e[3] = b[3] + (unsigned)(((no < HPK_HEAD_INLINE ? no : (unsigned long long)HPK_HEAD_INLINE) * sizeof(HpkSurv) + 15ull) / 16ull);
     }
-    unsigned i = blockIdx.x * 256u + threadIdx.x;       // thread index -> unit: the stretches back to back
+    for (unsigned i0 = blockIdx.x * 256u + threadIdx.x; ; i0 += gridDim.x * 256u) {
+        unsigned i = i0;                    // thread index -> unit: the stretches back to back
+        bool hit = false;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const unsigned len = sg.e[k] - sg.b[k];
-        if (i < len) { dst[sg.b[k] + i] = src[sg.b[k] + i]; return; }
-        i -= len;
+        for (int k = 0; k < 4; ++k) {
+            const unsigned len = e[k] - b[k];
+            if (!hit && i < len) { dst[b[k] + i] = src[b[k] + i]; hit = true; }
+            i -= len;
+        }
+        if (!hit) break;
     }
 }
-void hpk_launch_publish(const void* src, void* dst_host_mapped, size_t bytes, hipStream_t st) {
-    HpkPubSegs sg = {{0u, 0u, 0u, 0u}, {(unsigned)((bytes + 15) / 16), 0u, 0u, 0u}};
-    hipLaunchKernelGGL(hpk_publish, dim3((sg.e[0] + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4*>(src),
-                       reinterpret_cast<uint4*>(dst_host_mapped), sg, nullptr, 0u, 16u);
-}
-// seg: three fixed stretches in bytes (begin, end), then the survivors' area from inl_begin on
-void hpk_launch_publish_head(const void* src, void* dst_host_mapped, const size_t seg[3][2], size_t inl_begin,
-                             const unsigned long long* nout, unsigned inl, unsigned recbytes, hipStream_t st) {
-    HpkPubSegs sg;
-    unsigned most = 0;
-    for (int k = 0; k < 3; ++k) { sg.b[k] = (unsigned)(seg[k][0] / 16); sg.e[k] = (unsigned)((seg[k][1] + 15) / 16); most += sg.e[k] - sg.b[k]; }
-    sg.b[3] = (unsigned)(inl_begin / 16);
-    sg.e[3] = sg.b[3] + (unsigned)(((size_t)inl * recbytes + 15) / 16);
-    most += sg.e[3] - sg.b[3];
-    hipLaunchKernelGGL(hpk_publish, dim3((most + 255) / 256), dim3(256), 0, st, reinterpret_cast<const uint4*>(src),
-                       reinterpret_cast<uint4*>(dst_host_mapped), sg, nout, inl, recbytes);
+void hpk_launch_publish(const HpkBandDesc* d_bands, int nbands, int nsets, bool full, size_t max_head_bytes, hipStream_t st) {
+    // enough workgroups per band for the whole head in one sweep when little is filled; the loop covers the rest
+    const unsigned units = (unsigned)((max_head_bytes + 15) / 16);
+    unsigned gx = (units / (full ? 1u : 3u) + 255u) / 256u;
+    gx = gx < 1u ? 1u : gx;
+    hipLaunchKernelGGL(hpk_publish, dim3(gx, nbands), dim3(256), 0, st, d_bands, nsets, full ? 1 : 0);
 }
 
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,

@@ -32,14 +32,16 @@
 extern "C" {
 #endif
 
-#define HPK_ABI_VERSION 1
+#define HPK_ABI_VERSION 2
+#define HPK_MAX_BATCH   256    /* chromosomes per hpk_submit_batch */
 #define HPK_MAX_PAIRS   8      /* (pw, ww) pairs per call */
 #define HPK_MAX_W       20     /* largest supported maxww (reference keyword default, callers.py:45) */
 #define HPK_MAX_STEPS   64     /* widening steps in one plan (lane-indexed histogram) */
 
 typedef enum {
     HPK_OK = 0,
-    HPK_ERR_INVALID = -1,      /* bad argument */
+    HPK_ERR_INVALID = -1,      /* bad argument (also: a band with negative balancing weights / balanced values - the
+                                  stencil's exact-zero bookkeeping assumes counts x weights >= 0) */
     HPK_ERR_HIP = -2,          /* HIP runtime error (message has the call and hipError name) */
     HPK_ERR_NO_DEVICE = -3,    /* no gfx950 device / extension unusable: there is no CPU path */
     HPK_ERR_EMPTY_STEP = -4,   /* a widening step was entered with no unresolved candidate for its peak
@@ -162,6 +164,10 @@ typedef struct {
     int64_t nsurv_cut;         /* of those, how many were copied back for the final Benjamini-Hochberg step */
     int64_t stencil_tiles;
     int64_t band_px;           /* pixels with min(ww) <= d <= maxapart/res inside the matrix */
+    int32_t batch_bands;       /* chromosomes that shared this one's kernel launches (hpk_submit_batch; 1 otherwise).  The
+                                  ms_* kernel times of a batch are split over its chromosomes by band pixels: their sum over
+                                  the batch is the launch's duration */
+    int32_t reserved2;
 } hpk_result;
 
 typedef struct hpk_ctx hpk_ctx;
@@ -192,6 +198,28 @@ typedef struct hpk_job hpk_job;
 int  hpk_pipeline_depth(void);
 int  hpk_submit_band(hpk_ctx* ctx, const hpk_band* band, const hpk_params* params, hpk_job** job);
 int  hpk_collect(hpk_ctx* ctx, hpk_job* job, hpk_result** out);
+
+/* The loop over chromosomes itself (scripts/pyHICCUPS:192-198 maps worker() over them; every statistic of the path is
+ * per chromosome) as ONE set of kernel launches: `nbands` chromosomes scored with the same parameters - the stencil walks
+ * the tiles of all of them in one persistent launch, the expected tables, the scoring, the Benjamini-Hochberg cut and the
+ * copy-back are one launch each over the batch.  Results are the ones hpk_score_band gives chromosome by chromosome, bit
+ * for bit.  1 <= nbands <= HPK_MAX_BATCH; all bands carry the same kind of input (all `balanced` or all `weight`); the
+ * HPK_FLAG_DENSE_* outputs are for single chromosomes.  A batch occupies one lane (see hpk_submit_band).
+ * hpk_collect_batch always consumes the job.  outs[i] receives chromosome i's result (NULL where status[i] != HPK_OK, e.g.
+ * HPK_ERR_EMPTY_STEP for a chromosome on which the reference raises); errmsg, if not NULL, is [nbands][errmsg_len] chars
+ * and receives the message of every failed chromosome.  The return value is HPK_OK when the batch itself ran. */
+int  hpk_submit_batch(hpk_ctx* ctx, const hpk_band* bands, int32_t nbands, const hpk_params* params, hpk_job** job);
+int  hpk_collect_batch(hpk_ctx* ctx, hpk_job* job, hpk_result** outs, int32_t* status, char* errmsg, int32_t errmsg_len);
+
+/* Tuning and test switches of a context (the HPK_<NAME> environment variables are read once, by hpk_create; nothing
+ * between hpk_submit_* and its return looks at the environment).  Names: "rounds" (-2: the scoring kernel keeps the
+ * p-value histogram the cut is derived from [default], -1: a histogram pass of its own, 0..4: exact counting rounds),
+ * "surv_cap" (survivor slots per region, 0 = sized from the band; tests force the overflow rerun with it), "spec" (0: no
+ * record bound from earlier chromosomes), "spec_margin" (widths added to the bound), "spec_force" (>= 0: this bound;
+ * tests), "risk_log2" (exact-fallback threshold 2^-x), "tile_order", "gap_kernel" (1: gap rows by the row kernel),
+ * "score_div" (tiles per scoring workgroup of a batch), "dbg_stop" (profiling ablation).  Returns HPK_ERR_INVALID for an
+ * unknown name or a value out of range. */
+int  hpk_set_option(hpk_ctx* ctx, const char* name, int64_t value);
 
 /* Host-only helpers (no device needed): the widening plan of callers.py:15-23 + 132-201 as ring
  * multiplicities.  mult is [HPK_MAX_STEPS][HPK_MAX_W + 1]; returns the number of steps or a status. */

@@ -99,10 +99,10 @@ def one_case(seed, ctx):
                 return 'MISMATCH-widths', desc, 'slot %d: %d differ' % (slot, int((w != loc['wres'][pi]).sum()))
     # The production path once more: no dense outputs, so the stencil writes records up to a width bound only - first
     # the width this very case froze at (taken over from the call above), then a bound forced to the narrowest width
-    # (HPK_SPEC_FORCE: the widening freezes later, the library notices and computes the case again in full).
-    for force in (None, str(mw)):
+    # (option spec_force: the widening freezes later, the library notices and computes the case again in full).
+    for force in (None, mw):
         if force is not None:
-            os.environ['HPK_SPEC_FORCE'] = force
+            ctx.set_option('spec_force', force)
         try:
             d2 = dict()
             if mode == 'hiccups':
@@ -114,7 +114,7 @@ def one_case(seed, ctx):
                                            maxww=maxww, maxapart=maxapart, res=res, min_marginal_peaks=2, onlyanchor=False,
                                            ctx=ctx, detail=d2, **(dict(balanced=cband) if inp == 'balanced' else dict(weight=weight)))
         finally:
-            os.environ.pop('HPK_SPEC_FORCE', None)
+            ctx.set_option('spec_force', -1)
         k2, v2 = table_arrays(again)
         if not (np.array_equal(k2, k) and np.array_equal(v2, v)):
             return 'MISMATCH-record-bound', desc, 'bound %s' % (force or 'own')

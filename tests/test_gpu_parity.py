@@ -460,7 +460,7 @@ def test_small_maxww_tiles(maxww, pw, ww, ctx):
         np.testing.assert_allclose(v, vw, rtol=1e-9, atol=1e-9)
 
 
-def test_survivor_overflow_rerun(ctx, monkeypatch):
+def test_survivor_overflow_rerun(ctx):
     """The survivor regions are sized from the band; when they overflow, hpk_collect reruns the scoring with room for
     everything.  Forced here with a one-chunk capacity: results must not change."""
     from hicpeaks_amd import synthetic
@@ -472,18 +472,25 @@ def test_survivor_overflow_rerun(ctx, monkeypatch):
     want = ctx.score_host(raw, None, None, None, prm, weight=weight)
     # every scoring wave with a survivor takes a whole 64-record chunk: hundreds of waves against 64 regions x 4 chunks
     assert want.nsurv_sig > 64 * 256 and want.ncand > 100000
-    monkeypatch.setenv('HPK_SURV_CAP', '256')
-    got = ctx.score_host(raw, None, None, None, prm, weight=weight)
-    _same_result(got, want)
-    jobs = [ctx.submit_host(raw, None, None, None, prm, weight=weight) for _ in range(2)]
-    for j in jobs:                            # also with two chromosomes in flight
-        _same_result(j.result(), want)
+    ctx.set_option('surv_cap', 256)
+    try:
+        got = ctx.score_host(raw, None, None, None, prm, weight=weight)
+        _same_result(got, want)
+        jobs = [ctx.submit_host(raw, None, None, None, prm, weight=weight) for _ in range(2)]
+        for j in jobs:                            # also with two chromosomes in flight
+            _same_result(j.result(), want)
+        # ... and in a batch: every chromosome overflows and is scored once more, one after the other
+        items = [dict(raw=raw, weight=weight) for _ in range(3)]
+        for got in ctx.submit_batch_host(items, prm).results():
+            _same_result(got, want)
+    finally:
+        ctx.set_option('surv_cap', 0)
 
 
 @pytest.mark.parametrize('mode', ['hiccups', 'bhfdr'])
-def test_bh_cut_variants_agree(ctx, monkeypatch, mode):
+def test_bh_cut_variants_agree(ctx, mode):
     """Three ways to the Benjamini-Hochberg cut - the histogram the scoring kernel keeps (default), the histogram pass
-    of its own (HPK_ROUNDS=-1), exact counting rounds (HPK_ROUNDS=2) - must leave the same significant pixels with the
+    of its own (option rounds = -1), exact counting rounds (rounds = 2) - must leave the same significant pixels with the
     same p and q; none may cut below the true bound (every significant pixel is among the records copied back).  Also:
     a call without the stencil's timing events (HPK_FLAG_NO_STENCIL_TIMING) returns the same result and no kernel time."""
     from hicpeaks_amd import synthetic
@@ -500,12 +507,14 @@ def test_bh_cut_variants_agree(ctx, monkeypatch, mode):
     assert want.nsurv_cut >= sum(s['x'].size for s in want.sets)
     assert want.nsurv_cut < want.nsurv_sig                         # the cut did remove most of the p <= sig records
     assert want.timing['stencil'] > 0
-    for rounds in ('-1', '2'):
-        monkeypatch.setenv('HPK_ROUNDS', rounds)
-        got = ctx.score_host(raw, None, None, None, mk(0), weight=weight)
-        _same_result(got, want)
-        assert got.nsurv_sig == want.nsurv_sig and got.nsurv_cut >= sum(s['x'].size for s in got.sets)
-    monkeypatch.delenv('HPK_ROUNDS')
+    try:
+        for rounds in (-1, 2):
+            ctx.set_option('rounds', rounds)
+            got = ctx.score_host(raw, None, None, None, mk(0), weight=weight)
+            _same_result(got, want)
+            assert got.nsurv_sig == want.nsurv_sig and got.nsurv_cut >= sum(s['x'].size for s in got.sets)
+    finally:
+        ctx.set_option('rounds', -2)
     quiet = ctx.score_host(raw, None, None, None, mk(_lib.FLAG_NO_STENCIL_TIMING), weight=weight)
     _same_result(quiet, want)
     assert quiet.timing['stencil'] == 0 and quiet.nsurv_cut == want.nsurv_cut
@@ -531,12 +540,12 @@ def test_random_parameter_sets_against_oracle(ctx):
     assert tally.get('ok', 0) >= 30, tally
 
 
-def test_record_bound_from_the_previous_chromosome(monkeypatch):
+def test_record_bound_from_the_previous_chromosome():
     """The stencil writes records up to a width bound taken from the chromosome collected last with the same
     parameters (the width its widening froze at); whatever the bound, the result is the one a fresh context gives:
     (i) no previous chromosome - every resolved candidate; (ii) the same chromosome again - records up to its own
     frozen width; (iii) a sparser chromosome, which freezes later - detected at collection, computed once more in
-    full; (iv) a bound forced below every width (HPK_SPEC_FORCE) - likewise; (v) other parameters - no bound taken over."""
+    full; (iv) a bound forced below every width (option spec_force) - likewise; (v) other parameters - no bound taken over."""
     from hicpeaks_amd import synthetic
     n, res, maxapart, maxww = 3000, 10000, 2000000, 10
     num = maxapart // res + maxww + 1
@@ -566,11 +575,17 @@ def test_record_bound_from_the_previous_chromosome(monkeypatch):
         jobs = [c.submit_host(bands[k][0], None, None, None, prm, weight=bands[k][1]) for k in ('deep', 'shallow')]
         for j, k in zip(jobs, ('deep', 'shallow')):
             _same_result(j.result(), want[k])
-        monkeypatch.setenv('HPK_SPEC_FORCE', '5')
+        c.set_option('spec_force', 5)
         f = c.score_host(*bands['shallow'][:1], None, None, None, prm, weight=bands['shallow'][1])
         assert f.redone
         _same_result(f, want['shallow'])
-        monkeypatch.delenv('HPK_SPEC_FORCE')
+        # a batch under the forced bound: the chromosomes that froze beyond it are computed once more, each on its own
+        fb = c.submit_batch_host([dict(raw=bands[k][0], weight=bands[k][1]) for k in ('deep', 'shallow', 'deep', 'shallow')], prm).results()
+        for got, k in zip(fb, ('deep', 'shallow', 'deep', 'shallow')):
+            assert got.batch_bands == 4 and got.redone == (want[k].frozen_w > 5)
+            _same_result(got, want[k])
+        assert fb[1].redone
+        c.set_option('spec_force', -1)
         prm2 = _lib.make_params(_lib.MODE_HICCUPS, [2], [5], maxww, 0.05, maxapart, res, 16, 0)
         o = c.score_host(*bands['deep'][:1], None, None, None, prm2, weight=bands['deep'][1])
         assert o.record_bound == maxww and not o.redone
