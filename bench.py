@@ -3,15 +3,17 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config chr1_10kb]
 
-One "step" = one pass of the whole hot path (hpk_score_band: stencil -> freeze -> lambda-chunk Poisson
-scoring -> survivor compaction -> Benjamini-Hochberg) over one synthetic chromosome whose band is already
-resident in HBM.  N > 1: one process per GPU (torch.distributed / RCCL only for the barrier and the max over
-ranks); chromosomes are independent, every rank scores its own chromosome of the same shape, no data-path
+One "step" = the whole hot path (expected tables -> stencil -> freeze -> lambda-chunk Poisson scoring -> survivor
+compaction -> Benjamini-Hochberg) over `--batch` synthetic chromosomes whose bands are already resident in HBM,
+handed to the library `--group` chromosomes at a time (hpk_submit_batch: one launch per stage for the whole group,
+one group in flight ahead).  N > 1: one process per GPU (torch.distributed / RCCL only for the barrier and the max
+over ranks); chromosomes are independent, every rank scores its own chromosomes of the same shape, no data-path
 collective (weak scaling).  Rank 0 prints ONE JSON line.
 
 `roofline`   : the stencil kernel against HBM: algorithmic bytes = 20 B per band pixel per (p, w) pair
-               (4 B f32 count read + 2 x 8 B f64 local expected written) divided by
-               the kernel's mean duration from HIP events on the library's stream.
+               (4 B f32 count read + 2 x 8 B f64 local expected written) x the band
+               pixels one launch processes (a group of chromosomes) divided by the launch's mean duration from HIP
+               events on the library's stream.
 `cpu_baseline`: the numpy oracle (oracle/hiccups_oracle.py, a restatement of the reference's algorithm pinned
                to it by fixtures) timed on a bounded row sample of the same workload, rank 0, N = 1 only.
 """
@@ -122,8 +124,9 @@ def cpu_baseline_all_cores(cfg, rows):
 
 
 def run_genome(args, cfg, ctx, rank, world, local, dist):
-    """Whole-genome configurations: one step = every chromosome of the genome scored once (this rank's share of them,
-    one ahead); value = band pixels of the whole genome x pairs x steps / wall time."""
+    """Whole-genome configurations: one step = every chromosome of the genome scored once - this rank's share of them as
+    ONE batch (hpk_submit_batch: one launch per stage for all of them), the next pass submitted before this one is
+    collected; value = band pixels of the whole genome x pairs x steps / wall time."""
     import torch
     from hicpeaks_amd import _lib, band, bandgen, parallel, synthetic
     dev = torch.device('cuda', local)
@@ -150,38 +153,44 @@ def run_genome(args, cfg, ctx, rank, world, local, dist):
     npass = [0]
     px_genome = sum(band.band_pixels(n, num, mw, D) for n in sizes.values()) * len(cfg['pw'])
     depth = max(1, min(args.pipeline_depth, ctx.pipeline_depth))
+    group = len(bands) if args.group <= 0 else max(1, min(args.group, len(bands)))
 
     def light(R):         # what the report needs; holding every BandResult makes Python's cyclic GC slower pass after pass
         return (R.timing['stencil'], R.band_px, R.ncand, int(sum(s['x'].size for s in R.sets)), int(R.redone), R.frozen_w)
 
-    def one_pass():
-        pending, done = collections.deque(), []
+    def submit(part, p):
+        if args.host_inputs:
+            return ctx.submit_batch_host([dict(raw=r, weight=w, num=num) for (_, _, r, w) in part], p)
+        bd = [ctx._band(n, num, ld, r.data_ptr(), None, w.data_ptr(), None, None, None, True) for (_, n, r, w) in part]
+        return ctx.submit_batch(bd, p, [n for (_, n, _, _) in part])
+
+    def one_pass(pending, done):
         npass[0] += 1
-        for i, (c, n, raw_d, w_d) in enumerate(bands):
-            p = prm if (i + npass[0]) % TIMED_EVERY == 0 else prm_quiet        # over the passes every chromosome gets its turn
-            if args.host_inputs:
-                pending.append(ctx.submit_host(raw_d, None, None, None, p, weight=w_d, num=num))
-            else:
-                pending.append(ctx.submit_device(n, num, ld, raw_d.data_ptr(), None, None, None, p, weight_ptr=w_d.data_ptr()))
+        for g0 in range(0, len(bands), group):
+            p = prm if (npass[0] + g0) % TIMED_EVERY == 0 else prm_quiet
+            pending.append(submit(bands[g0:g0 + group], p))
             if len(pending) >= depth:
-                done.append(light(pending.popleft().result()))
+                done.append([light(R) for R in pending.popleft().results()])
+
+    def drain(pending, done):
         while pending:
-            done.append(light(pending.popleft().result()))
-        return done
+            done.append([light(R) for R in pending.popleft().results()])
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    one_pass()              # set-up, not a step: every lane allocates its workspaces once
-    for _ in range(args.warmup):
-        one_pass()
+    pending, done = collections.deque(), []
+    for _ in range(depth + args.warmup):        # set-up (every lane allocates its workspaces once) + warm-up passes
+        one_pass(pending, done)
+    drain(pending, done)
     barrier()
     t0 = time.perf_counter()
     results = []
-    for _ in range(args.steps):
-        results.append(one_pass())
+    for _ in range(args.steps):                 # the passes follow each other without a gap: one batch ahead
+        one_pass(pending, results)
+    drain(pending, results)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -189,29 +198,31 @@ def run_genome(args, cfg, ctx, rank, world, local, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        # dominant kernel: all stencil launches of this rank; achieved = algorithmic bytes / kernel time, per launch
-        timed = [t for rs in results for t in rs if t[0] > 0]
-        st_ms = sum(t[0] for t in timed)
-        st_px = sum(t[1] for t in timed) * len(cfg['pw'])
+        # dominant kernel: the stencil launches of this rank that were bracketed by events; achieved = algorithmic bytes
+        # of the launch's band pixels / its duration
+        timed = [rs for rs in results if rs[0][0] > 0]
+        st_ms = sum(t[0] for rs in timed for t in rs)
+        st_px = sum(t[1] for rs in timed for t in rs) * len(cfg['pw'])
         nlaunch = len(timed)
         achieved = BYTES_PER_PX * st_px / (st_ms * 1e-3) / 1e9
-        last = results[-1]
+        last = [t for rs in results[-((len(bands) + group - 1) // group):] for t in rs]
         out = {
             'metric': 'band pixels scored/sec (donut+LL)', 'value': px_genome * args.steps / elapsed, 'unit': 'band px/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': cfg['workload'], 'name': args.config, 'band_px_per_step': px_genome,
-                       'chromosomes': len(sizes), 'chromosomes_rank0': len(mine), 'pipeline_depth': depth, 'ranks_seen': args.ranks_seen,
+                       'chromosomes': len(sizes), 'chromosomes_rank0': len(mine), 'chromosomes_per_launch': group,
+                       'pipeline_depth': depth, 'ranks_seen': args.ranks_seen,
                        'candidates_rank0': int(sum(t[2] for t in last)),
                        'significant_px_rank0': int(sum(t[3] for t in last)),
-                       # record bound = the previous chromosome's frozen width: chromosomes of the last pass
-                       # that froze later than their predecessor and were computed once more, and the widths they froze at
+                       # record bound = the widest freeze of the chromosomes collected before: chromosomes of
+                       # the last pass that froze later and were computed once more, and the widths they froze at
                        'redone_in_full_rank0': int(sum(t[4] for t in last)), 'frozen_w_rank0': sorted(set(t[5] for t in last)),
                        'parallelism': 'chromosomes dealt largest-first to the GPUs, no collective',
                        'whole_genome_wall_ms': elapsed / args.steps * 1e3, 'host_inputs': bool(args.host_inputs)},
-            'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil_s', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel_ms': st_ms / nlaunch,
-                         'launches_timed': nlaunch, 'launches': sum(len(rs) for rs in results),
+                         'launches_timed': nlaunch, 'launches': len(results),
                          'algorithmic_bytes_per_launch': BYTES_PER_PX * st_px / nlaunch},
         }
         print(json.dumps(out))
@@ -250,14 +261,18 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=0,
-                    help='chromosomes per step: a step scores a batch of this many chromosome-sized bands one after the other '
-                         '(default: 100 for the single-chromosome configurations, so that 20 steps keep the GPU busy for ~0.5 s '
-                         'and the clocks settle; 1 for the whole-genome configurations, whose step is the 23-chromosome genome)')
+                    help='chromosomes per step: a step scores this many chromosome-sized bands '
+                         '(default: 800 for the 10 kb configurations, so that 20 steps keep the GPU busy for ~2 s '
+                         'and the clocks settle; the whole-genome configurations\' step is the 23-chromosome genome)')
+    ap.add_argument('--group', type=int, default=0,
+                    help='chromosomes per library call (hpk_submit_batch: one launch per stage for the whole group); 1 = chromosome '
+                         'by chromosome as in round 2; default: sized so that a group\'s workspaces stay below ~24 GB, at most 32; '
+                         'whole-genome configurations: the rank\'s whole share')
     ap.add_argument('--config', default='chr1_10kb', choices=sorted(CONFIGS))
     ap.add_argument('--cpu-rows', type=int, default=1 << 30,
                     help='rows of the CPU-baseline sample (default: the whole workload, ~8 s on one core; 0 = skip)')
     ap.add_argument('--pipeline-depth', type=int, default=2,
-                    help='chromosomes in flight per GPU (hpk_submit_band / hpk_collect); 1 = one synchronous call per step')
+                    help='groups in flight per GPU (hpk_submit_batch / hpk_collect_batch); 1 = synchronous calls')
     ap.add_argument('--balanced-f64', action='store_true',
                     help='hand over the balanced band as f64 [n][ld] (what the drop-in hiccups() receives as cDiags) instead of '
                          'the weights: 12 B/px read instead of 4')
@@ -360,44 +375,55 @@ def main():
         del kk, rr, cc
         torch.cuda.synchronize()
 
-    def submit(timed=None):
+    # chromosomes per library call: the records and survivor regions of a group live side by side in HBM
+    tiles = -(-n // 59) * -(-(59 + D - mw) // 107)
+    per_band = tiles * 6313 * (4 + 17 * len(set(cfg['pw']))) + 2 * 40 * band.band_pixels(n, num, mw, D) * 2 * len(cfg['pw']) // 6
+    group = args.group if args.group > 0 else max(1, min(32, int(24e9 // per_band)))
+    batch = args.batch if args.batch > 0 else (800 if n * num <= 60_000_000 else 16)
+    batch = max(group, batch // group * group)          # whole groups
+
+    def band_of(i):
+        if bal_d is not None:
+            return ctx._band(n, num, ld, raw_d.data_ptr(), bal_d.data_ptr(), None, ir_d.data_ptr(), b_d.data_ptr(), b_d.data_ptr(), True)
+        r_, w_, i_, b_ = bands[i % nseeds]
+        return ctx._band(n, num, ld, r_.data_ptr(), None, w_.data_ptr(), i_.data_ptr(), b_.data_ptr(), b_.data_ptr(), True)
+
+    def submit(timed=None, k=None):
+        """one group of `k` chromosomes (the passes rotate through the seeds' bands)"""
+        k = group if k is None else k
         if timed is None:
             timed = nsub[0] % TIMED_EVERY == 0
-            nsub[0] += 1
         p = prm if timed else prm_quiet
-        if bal_d is not None:
-            return ctx.submit_device(n, num, ld, raw_d.data_ptr(), ir_d.data_ptr(), b_d.data_ptr(), b_d.data_ptr(), p,
-                                     balanced_ptr=bal_d.data_ptr())
+        first = nsub[0] * group
+        nsub[0] += 1
         if args.host_inputs:
-            return ctx.submit_host(raw_h, ir_h, b_h, b_h, p, weight=w_h)
-        r_, w_, i_, b_ = bands[nsub[0] % nseeds]
-        return ctx.submit_device(n, num, ld, r_.data_ptr(), i_.data_ptr(), b_.data_ptr(), b_.data_ptr(), p,
-                                 weight_ptr=w_.data_ptr())
+            return ctx.submit_batch_host([dict(raw=raw_h, IR=ir_h, bias1=b_h, bias2=b_h, weight=w_h)] * k, p)
+        return ctx.submit_batch([band_of(first + i) for i in range(k)], p, [n] * k)
 
-    def run(k):
+    def take(job, done):
+        rs = job.results()
+        del done[:]
+        done.append(rs[-1])              # the report needs the kernel times (below) and one result, not all of them
+        nredone[0] += sum(int(r.redone) for r in rs)
+        st = sum(r.timing['stencil'] for r in rs)        # the group's launch: its chromosomes' shares add up to it
+        if st > 0:
+            stencil_ms.append(st)
+
+    def run(ngroups):
         pending, done = collections.deque(), []
-        for _ in range(k):
+        for _ in range(ngroups):
             pending.append(submit())
             if len(pending) >= depth:
-                done.append(pending.popleft().result())
-                del done[:-1]           # the report needs the kernel times (below) and one result, not K of them
-                nredone[0] += int(done[-1].redone)
-                if done[-1].timing['stencil'] > 0:
-                    stencil_ms.append(done[-1].timing['stencil'])
+                take(pending.popleft(), done)
         while pending:
-            done.append(pending.popleft().result())
-            del done[:-1]
-            nredone[0] += int(done[-1].redone)
-            if done[-1].timing['stencil'] > 0:
-                stencil_ms.append(done[-1].timing['stencil'])
+            take(pending.popleft(), done)
         return done
 
-    batch = args.batch if args.batch > 0 else (100 if n * num <= 60_000_000 else 4)
     stencil_ms = []
     nredone = [0]
     R = None
     run(depth)              # set-up, not a step: every lane allocates its workspaces (GBs on the large configurations) once
-    for R in run(args.warmup * batch):
+    for R in run(max(args.warmup, 1) * batch // group if args.warmup > 0 else 0):
         pass
 
     def barrier():
@@ -409,24 +435,26 @@ def main():
     del stencil_ms[:]
     nredone[0] = 0
     t0 = time.perf_counter()
-    results = run(args.steps * batch)
+    results = run(args.steps * batch // group)
     barrier()
     elapsed = time.perf_counter() - t0
     nredone_timed = nredone[0]
-    assert len(stencil_ms) >= args.steps * batch // TIMED_EVERY
+    assert len(stencil_ms) >= args.steps * batch // group // TIMED_EVERY
     stencil_ms = list(stencil_ms)
     R = results[-1]
-    # outside the timed region: latency of one synchronous call (submit + collect), then a few calls with the per-phase
-    # events switched on (they cost ~6 us of idle GPU each, so the timed passes run without them)
+    # outside the timed region: latency of one synchronous single-chromosome call (submit + collect), then a group with
+    # the per-phase events switched on (they cost ~6 us of idle GPU each, so the timed passes run without them)
     lat = []
     for _ in range(min(5, args.steps)):
         t1 = time.perf_counter()
-        submit(False).result()
+        submit(False, 1).results()
         lat.append((time.perf_counter() - t1) * 1e3)
     prm = _lib.make_params(_lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], cfg['maxww'], SIG, cfg['maxapart'], cfg['res'],
                            MIN_READS, flags | _lib.FLAG_PHASE_TIMING)
-    for _ in range(3):
-        R = submit(True).result()
+    for _ in range(2):
+        Rs = submit(True).results()
+    phases = {k: float(sum(r.timing[k] for r in Rs)) / len(Rs) for k in Rs[0].timing}       # per chromosome of a group
+    phases['total'] = float(Rs[-1].timing['total']) / len(Rs)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -434,14 +462,15 @@ def main():
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
-        st = float(np.mean(stencil_ms))
-        achieved = BYTES_PER_PX * px_per_step / (st * 1e-3) / 1e9
+        st = float(np.mean(stencil_ms))                     # one launch = one group of chromosomes
+        achieved = BYTES_PER_PX * px_per_step * group / (st * 1e-3) / 1e9
         out = {
             'metric': 'band pixels scored/sec (donut+LL)', 'value': world * px_per_step * batch * args.steps / elapsed,
             'unit': 'band px/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_step,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': cfg['workload'], 'name': args.config, 'band_px_per_step': px_per_step * batch,
-                       'chromosomes_per_step': batch, 'band_px_per_chromosome': px_per_step, 'seeds': nseeds,
+                       'chromosomes_per_step': batch, 'chromosomes_per_launch': group, 'band_px_per_chromosome': px_per_step,
+                       'seeds': nseeds,
                        'ms_per_chromosome': ms_step / batch, 'ranks_seen': args.ranks_seen,
                        'candidates': R.ncand, 'significant_px': int(sum(s['x'].size for s in R.sets)),
                        'px_with_p_le_sig': R.nsurv_sig, 'records_copied_back': R.nsurv_cut,
@@ -457,19 +486,21 @@ def main():
             # (counter traffic per launch / kernel time / peak - what the memory system actually carries).
             'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil_s' if R.stencil_kernel == 2 else 'hpk_stencil', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                         'kernel_ms': st, 'algorithmic_bytes_per_launch': BYTES_PER_PX * px_per_step,
-                         'launches_timed': len(stencil_ms), 'launches': args.steps * batch,
-                         'compact_4Bpx': {'achieved': 4.0 * px_per_step / (st * 1e-3) / 1e9,
-                                          'frac': 4.0 * px_per_step / (st * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                         'kernel_ms': st, 'kernel_ms_per_chromosome': st / group,
+                         'algorithmic_bytes_per_launch': BYTES_PER_PX * px_per_step * group,
+                         'launches_timed': len(stencil_ms), 'launches': args.steps * batch // group,
+                         'compact_4Bpx': {'achieved': 4.0 * px_per_step * group / (st * 1e-3) / 1e9,
+                                          'frac': 4.0 * px_per_step * group / (st * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          'hbm_frac_measured': None},
-            'phases_ms': {k: float(v) for k, v in R.timing.items()},
+            'phases_ms': phases,
         }
         try:        # HBM traffic per launch of the dominant kernel, measured off-line with rocprofv3 --pmc (profiles/)
             tr = json.load(open(os.path.join(REPO, 'profiles', 'traffic.json'))).get(args.config)
             if tr:
-                out['roofline']['traffic'] = tr['traffic_bytes']
+                # (counter traffic is recorded per chromosome; a launch carries a group of them)
+                out['roofline']['traffic'] = tr['traffic_bytes'] * group
                 out['roofline']['traffic_source'] = tr['source']
-                out['roofline']['hbm_frac_measured'] = tr['traffic_bytes'] / (st * 1e-3) / 1e9 / HBM_PEAK_GBS
+                out['roofline']['hbm_frac_measured'] = tr['traffic_bytes'] * group / (st * 1e-3) / 1e9 / HBM_PEAK_GBS
         except Exception:
             pass
         if world == 1 and args.cpu_rows > 0:

@@ -921,6 +921,7 @@ struct TileWalk {
     int k, band, kb, chunkb, ntb;       // index in the XCD's run; current band, its first index, its chunk and tile count
     int rbk, ck, rm;                    // row block, column chunk before rotation, row block mod J
     int dk, dr, dc, drm;                // per step: index stride, its quotient and remainder by J, quotient mod J
+    int nt;                             // tiles handed out so far (see bword)
     bool done;
     __device__ __forceinline__ void locate(const HpkStencilArgs& a, const HpkBandDesc* __restrict__ bands, bool fresh) {
         const int xcd = (int)(blockIdx.x & 7);
@@ -948,7 +949,7 @@ struct TileWalk {
         dr = dk / a.J; dc = dk - dr * a.J; drm = dr % a.J;
         k = (int)(blockIdx.x >> 3);
         band = 0; kb = 0; chunkb = bands[0].chunk; ntb = bands[0].ntiles;
-        rbk = 0; ck = 0; rm = 0;
+        rbk = 0; ck = 0; rm = 0; nt = 0;
         done = false;
         locate(a, bands, true);
     }
@@ -958,7 +959,7 @@ struct TileWalk {
         return c >= a.J ? c - a.J : c;
     }
     __device__ __forceinline__ void step(const HpkStencilArgs& a, const HpkBandDesc* __restrict__ bands) {
-        k += dk; rbk += dr; ck += dc; rm += drm;
+        k += dk; rbk += dr; ck += dc; rm += drm; nt += 1;
         if (ck >= a.J) { ck -= a.J; rbk += 1; rm += 1; }
         if (rm >= a.J) rm -= a.J;
         if (rm >= a.J) rm -= a.J;
@@ -966,6 +967,11 @@ struct TileWalk {
     }
     // what wave 0 publishes for the others: row block << 8 | column chunk, ~0 = no more tiles
     __device__ __forceinline__ unsigned word(const HpkStencilArgs& a) const { return done ? ~0u : ((unsigned)rbk << 8 | (unsigned)cj(a)); }
+    // ... and the band's index with a segment number on top that steps every 8192 tiles of the walk: the workgroup flushes
+    // its resolve counts whenever this word changes, i.e. at every band boundary and - long runs of tiles on small grids -
+    // before a 16-bit counter field can wrap (a wave runs at most 7 batches of a tile, a lane counts at most one
+    // candidate per batch), at no cost in the fifteen waves that do not walk
+    __device__ __forceinline__ unsigned bword() const { return (unsigned)band | ((unsigned)(nt >> 13) << 16); }
 };
 
 template <bool BALF64, bool SINGLE>
@@ -1021,7 +1027,6 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     // band (and after the last tile), see the top of the tile loop.
     unsigned myhist = 0u;                 // lane w: candidates whose first sufficient width is w
     unsigned long long hpack0 = 0ull, hpack1 = 0ull;      // this lane's candidates by width min(ww) + k: 16 bits each, k = 0..3 | 4..7
-    unsigned hp_n = 0u;                   // tiles counted into hpack since it was last folded into myhist (16-bit fields)
     unsigned mycand = 0u;
     // the per-lane width counts, summed over the wave, into lane min(ww) + k of myhist
     auto fold_hpack = [&]() {
@@ -1032,7 +1037,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             for (int m = 32; m > 0; m >>= 1) v += (unsigned)__shfl_xor((int)v, m);
             if (lane_k == wmin_p + k) myhist += v;
         }
-        hpack0 = 0ull; hpack1 = 0ull; hp_n = 0u;
+        hpack0 = 0ull; hpack1 = 0ull;
     };
     // scoring work list: the append of a tile is completed one tile later (the atomic's return is not waited for)
     int pend_tid = -1, pend_band = 0;
@@ -1050,26 +1055,21 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     tw.init(a, bands);
     bool have = !tw.done;
     int rb = tw.rbk, cj = tw.cj(a);
-    int band = have ? tw.band : -1;     // band of the current tile; -1 behind the last one
-    int hband = band;                   // band the resolve counts in (myhist, hpack, mycand) belong to
-    if (have) tile_load_s<BALF64>(a, bands + band, rb, cj, wave_k, lane_k, nxt);
+    unsigned bw = tw.bword();           // band (low 16 bits) and flush segment of the current tile
     if (wave_k == 0) {
         tw.step(a, bands);
-        if (lane_k == 0) { tseq[0] = tw.word(a); tband[0] = (unsigned)tw.band; }
+        if (lane_k == 0) { tseq[0] = tw.word(a); tband[0] = tw.bword(); }
     }
     __syncthreads();                    // plan, counters and the second tile in LDS
     unsigned tnext = lds_u32(lds0 + (unsigned)((unsigned char*)tseq - smem));
     unsigned bnext = lds_u32(lds0 + (unsigned)((unsigned char*)tband - smem));
     int tpar = 0;                       // which tseq word holds the tile after the current one
-#pragma unroll 1
-    for (;;) {
-    if (band != hband) {
-        // ---- the walk has left band `hband`: its resolve counts go to that band's totals.  Widths are summed over the
-        // waves in LDS (the tables are dead between tiles), then per step s of slot q and width w: the candidates whose
-        // first sufficient width is w (w above the slot's first width) or at most w (at it).  The counts go straight into
-        // the chromosome's totals - one word per cache line - and every scoring workgroup replays the freeze decision on
-        // them; no ticket, no fences, no tail in this kernel.
-        const HpkBandDesc* __restrict__ hb = bands + hband;
+    // ---- the resolve counts of a band (segment) go to that band's totals when the walk leaves it.  Widths are summed over
+    // the waves in LDS (the tables are dead between tiles), then per step s of slot q and width w: the candidates whose
+    // first sufficient width is w (w above the slot's first width) or at most w (at it).  The counts go straight into
+    // the chromosome's totals - one word per cache line - and every scoring workgroup replays the freeze decision on
+    // them; no ticket, no fences, no tail in this kernel.
+    auto flush_hist = [&](const HpkBandDesc* __restrict__ hb) {
         fold_hpack();
         unsigned* red = reinterpret_cast<unsigned*>(smem);
         int tix = wave_k * 64 + lane_k;         // (opaque: what hangs on the thread index stays in here instead of being
@@ -1097,19 +1097,14 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         }
         __syncthreads();                // (the next tile's phase 1 parks its totals where `red` sits)
         myhist = 0u; mycand = 0u;
-        hband = band;
-    }
-    if (!have) break;
-    // (a wave runs at most 7 batches of a tile, a lane counts at most one candidate per batch: long runs of tiles on
-    // small grids must not wrap a 16-bit field)
-    if (++hp_n >= 8192u) fold_hpack();
-    // Everything below that depends only on (wave, lane) is the same for every tile, and the compiler would hoist it
-    // out of the tile loop - list-entry templates, row flags, compare constants: 100+ SGPRs and a dozen VGPRs that
-    // then spill to scratch, whose reloads (vmcnt(0)) also wait for the prefetch.  Opaque copies keep it in here.
-    int wave = wave_k, lane = lane_k;
-    asm volatile("" : "+s"(wave));
-    asm volatile("" : "+v"(lane));
-    const HpkBandDesc* __restrict__ bd = bands + band;      // this tile's band
+    };
+    int hband = -1;                     // band whose resolve counts are pending in myhist / hpack / mycand
+#pragma unroll 1
+    while (have) {
+    // ---- one band (segment): what the tile loop needs of it - pointers, sizes, the record bound - does not change below
+    const unsigned cbw = bw;
+    const int band = (int)(cbw & 0xffffu);
+    const HpkBandDesc* __restrict__ bd = bands + band;
     const int n = bd->n;
     const int Dm = a.D < bd->num - 1 ? a.D : bd->num - 1;   // last diagonal that holds band pixels
     // Records are written for candidates whose first sufficient width is at most the band's wguess, packed (a tile's
@@ -1117,22 +1112,35 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     // decides (frozen_w, freeze_replay), wider candidates and unresolved ones are dropped by the scoring kernel anyway,
     // and the caller knows a bound from the chromosomes before (hpk_api.cpp; 255 = every candidate, as the dense outputs want).
     const int wg_p = bd->wguess;
+    // the band's first tile: nothing is prefetched across a boundary; the flush of the band before runs beside the loads
+    tile_load_s<BALF64>(a, bd, rb, cj, wave_k, lane_k, nxt);
+    if (hband >= 0) flush_hist(bands + hband);
+    hband = band;
+#pragma unroll 1
+    do {
+    // Everything below that depends only on (wave, lane) is the same for every tile, and the compiler would hoist it
+    // out of the tile loop - list-entry templates, row flags, compare constants: 100+ SGPRs and a dozen VGPRs that
+    // then spill to scratch, whose reloads (vmcnt(0)) also wait for the prefetch.  Opaque copies keep it in here.
+    int wave = wave_k, lane = lane_k;
+    asm volatile("" : "+s"(wave));
+    asm volatile("" : "+v"(lane));
     const int tid = rb * a.J + cj;
     const int r0 = rb * TR;
     const int c0 = r0 + mw + cj * TC;
     const bool empty_tile = c0 >= n || (mw + cj * TC - (TR - 1)) > a.D;       // no band pixel inside the matrix
     const int tn = __builtin_amdgcn_readfirstlane((int)tnext);
-    const int band_next = __builtin_amdgcn_readfirstlane((int)bnext);
+    const unsigned bw_next = (unsigned)__builtin_amdgcn_readfirstlane((int)bnext);
     const bool have_next = tn != -1;
+    const bool pre_next = have_next && bw_next == cbw;         // the next tile is this band's: its rows are prefetched
     const int rb_next = (int)((unsigned)tn >> 8), cj_next = tn & 255;
     if (wave == 0) {                    // the tile after the next one, for everybody's next round
         tw.step(a, bands);
-        if (lane == 0) { tseq[tpar ^ 1] = tw.word(a); tband[tpar ^ 1] = (unsigned)tw.band; }
+        if (lane == 0) { tseq[tpar ^ 1] = tw.word(a); tband[tpar ^ 1] = tw.bword(); }
     }
     tpar ^= 1;
     if (empty_tile) {
-        if (have_next) tile_load_s<BALF64>(a, bands + band_next, rb_next, cj_next, wave, lane, nxt);
-        have = have_next; rb = rb_next; cj = cj_next; band = have_next ? band_next : -1;
+        if (pre_next) tile_load_s<BALF64>(a, bd, rb_next, cj_next, wave, lane, nxt);
+        have = have_next; rb = rb_next; cj = cj_next; bw = bw_next;
         __syncthreads();                // (rare: the far end of the chromosome) wave 0's word before it is read
         tnext = lds_u32(lds0 + (unsigned)((unsigned char*)tseq - smem) + (unsigned)tpar * 4u);
         bnext = lds_u32(lds0 + (unsigned)((unsigned char*)tband - smem) + (unsigned)tpar * 4u);
@@ -1189,7 +1197,10 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             } else {
                 rv = km >= 0 ? rv : 0.f;                                // balanced values exist from diagonal min(ww) on
                 asm volatile("" : "+v"(rv));                            // (select on the f32, not on the converted f64)
-                bv[e] = ((double)rv * wr) * wcz[e];                     // (raw * w_r) * w_c with NaN weights as 0: NaN -> 0, signs are kept
+                // (raw * w_r) * w_c with NaN weights as 0: NaN -> 0, signs are kept.  Two rounded products, as numpy forms
+                // them (scripts/pyHICCUPS:150-152): not to be contracted with the prefix adds that follow
+                bv[e] = ((double)rv * wr) * wcz[e];
+                asm volatile("" : "+v"(bv[e]));
             }
             pk[e] = rc | (bv[e] != 0.0 ? 1u << PK_SHIFT : 0u);
             // (no branch on the row: the predicate flows straight into the ballot; rows outside the output tile give 0)
@@ -1245,12 +1256,12 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     // The next tile's rows start moving now, from every wave.  (With 32 row groups the prefix stage behind the barrier
     // was long and the waves not in it issued their loads there; with 16 it is short, and on the wide-band
     // configurations - few candidates, the tile is all table building - the earlier request is worth 2 %.)
-    if (have_next && (!BALF64 || wave < 8)) tile_load_s<BALF64>(a, bands + band_next, rb_next, cj_next, wave, lane, nxt);
+    if (pre_next && (!BALF64 || wave < 8)) tile_load_s<BALF64>(a, bd, rb_next, cj_next, wave, lane, nxt);
     __syncthreads();
     HPK_CLK(ck1)
     // (f64 input: the waves that sit out the prefix stage request their rows there - thirty registers fewer to hold
     // across the barrier)
-    if (BALF64 && have_next && wave >= 8) tile_load_s<BALF64>(a, bands + band_next, rb_next, cj_next, wave, lane, nxt);
+    if (BALF64 && pre_next && wave >= 8) tile_load_s<BALF64>(a, bd, rb_next, cj_next, wave, lane, nxt);
     // ---- exclusive prefixes over the 16 waves' row groups, per column: plain sums in wave order.  Waves 0-3: the f64
     // plane, 32 columns each; waves 4-7: the packed plane.  Lanes 0-31 walk groups 0-7 of their column, lanes 32-63 groups
     // 8-15, which start from the first half's total.  Group g parked its total in SAT row 5g + 1 and gets its base in row 5g.
@@ -1366,9 +1377,9 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             }
         }
         // resolve histogram by width.  The first eight widths are counted per lane, 16 bits each in two registers
-        // (a lane sees at most one candidate per batch: the fields are folded into myhist before 65 535 batches of this
-        // wave), and added up over the wave when the walk leaves the band; wider ones (maxww >= min(ww) + 8) by one
-        // ballot per width.
+        // (a lane sees at most one candidate per batch; the walk leaves a band's segment before 65 535 batches of this
+        // wave: TileWalk::bword), and added up over the wave when the walk leaves the band; wider ones (maxww >= min(ww) + 8)
+        // by one ballot per width.
         // (The f64-input variants are out of registers - their prefetch holds 30 instead of 16 - and keep the ballots.)
         if (!BALF64) {
             const unsigned off = (unsigned)(wstar - wmin_p);              // 255 - min(ww) >= 8 for "no sufficient width"
@@ -1560,9 +1571,11 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         }
         if (lane == 0) { gptr(bd->tile_cnt)[tid] = nrec; mycand += (unsigned)total; }
     }
-    have = have_next; rb = rb_next; cj = cj_next; band = have_next ? band_next : -1;
+    have = have_next; rb = rb_next; cj = cj_next; bw = bw_next;
     par ^= 1;
-    }   // tile loop
+    } while (have && bw == cbw);   // tile loop of the band
+    }   // bands
+    if (hband >= 0) flush_hist(bands + hband);
     const int lane = lane_k, wave = wave_k;
     if (wave == 0 && pend_tid >= 0) {
         const unsigned nu = (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT;

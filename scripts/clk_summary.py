@@ -6,11 +6,13 @@ totals + two barriers, (2) scans + SAT stores, (3) barrier, (4) gap rows + candi
 import sys
 import numpy as np
 raw = np.fromfile(sys.argv[1], dtype=np.uint64).reshape(-1, 16, 8)
+raw = raw[raw[:, :, :7].sum(axis=(1, 2)) > 0]            # (the dump holds 1024 workgroup slots)
+per = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0    # chromosomes per launch: figures per chromosome
 risky = (raw[:, :, 6] >> np.uint64(40)).astype(np.float64)      # hpk_stencil_s: candidates redone exactly, in the high bits
 raw[:, :, 6] &= np.uint64((1 << 40) - 1)
 explicit = (raw[:, :, 7] >> np.uint64(40)).astype(np.float64)   # ... of those, added cell by cell by the whole wave
 raw[:, :, 7] &= np.uint64((1 << 40) - 1)
-a = raw.astype(np.float64)
+a = raw.astype(np.float64) / per
 names = ['wait+phase1', 'prefetch+coltot', 'scan+write', 'barrier(SAT)', 'gap+lists', 'batches', 'barrier(end)']
 tot = a[:, :, :7].sum(axis=2)
 print('workgroups %d; ticks per wave: mean %.0f  min %.0f  max %.0f' % (a.shape[0], tot.mean(), tot.min(), tot.max()))

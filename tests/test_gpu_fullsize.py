@@ -12,7 +12,8 @@ reaches.  The reference cannot run at these sizes in a test (hours), so the chec
 import numpy as np
 import pytest
 
-from hicpeaks_amd import _lib, band as hband
+from hicpeaks_amd import _lib, band as hband, callers, synthetic
+from oracle import hiccups_oracle as orc
 
 pytestmark = pytest.mark.gpu
 
@@ -148,3 +149,96 @@ def test_full_size_wide_band(name, ctx):
         assert np.all((s['y'] - s['x'] >= max(cfg['ww'])) & (s['y'] - s['x'] <= D))
         o = raw_d[torch.from_numpy(s['x']).to(dev), torch.from_numpy(s['y'] - s['x']).to(dev)].cpu().numpy()
         np.testing.assert_array_equal(s['O'], o)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The headline configurations against the ORACLE at full size (above n = 640 the production kernels had only
+# ever met the builder's own explicit-window kernel).  The oracle - the numpy restatement of hicpeaks/callers.py:44-362
+# that the fixtures pin to the reference - takes 8-30 s per case on a host core; the GPU side runs the production path
+# (no dense outputs: packed records, record bound, scoring kernel, device-side cut), once as a single call and once as a
+# batch of three chromosomes.
+FULL = {
+    # BASELINE configs[1]: hg38 chr1 @10 kb, (p, w) = (2, 5), 5 Mb band: n = 24 896, num = 511
+    'chr1_10kb_p2w5': dict(n=24896, res=10000, maxapart=5000000, pw=[2], ww=[5], depth=60.0, nloops=400, seed=0),
+    # BASELINE configs[2]'s plan on its largest chromosome: union of (1,3) / (2,5) / (4,7): 18 widening steps, 3 slots
+    'chr1_10kb_union': dict(n=24896, res=10000, maxapart=5000000, pw=[1, 2, 4], ww=[3, 5, 7], depth=60.0, nloops=400, seed=1),
+}
+
+
+def _arrays(table):
+    keys = sorted(table)
+    return np.array(keys, dtype=np.int64).reshape(-1, 2), np.array([[float(v) for v in table[k]] for k in keys])
+
+
+def _check_against_oracle(R, final, det, want, pw, ww, sig):
+    loc = det['loc']
+    # widening log: candidates, resolve counts of the executed steps, the width the widening froze at
+    assert R.ncand == loc['vx'].size
+    got_steps = [(a, b, c) for a, b, c, ex in R.steps if ex]
+    assert got_steps == [tuple(int(v) for v in s) for s in loc['steps']]
+    assert R.frozen_w == loc['frozen_w']
+    # every (pair, filter) set: the pixels with q <= sig, coordinates exact, E / p / q within the parity tolerances
+    assert len(R.sets) == 2 * len(pw)
+    nsig = 0
+    for t, (s, o) in enumerate(zip(R.sets, det['sets'])):
+        assert (s['pair'], s['fl']) == (t // 2, o['fl']) and (pw[t // 2], ww[t // 2]) == (o['pi'], o['wi'])
+        assert s['nvalid'] == o['vx'].size
+        q, vx, vy = o['q'], o['vx'], o['vy']
+        firm = np.abs(q - sig) > 1e-8                       # (pixels sitting on the threshold may fall either way)
+        sel = q <= sig
+        wantpx = set(zip(vx[sel & firm].tolist(), vy[sel & firm].tolist()))
+        maybe = set(zip(vx[~firm].tolist(), vy[~firm].tolist()))
+        got = set(zip(s['x'].tolist(), s['y'].tolist()))
+        assert wantpx <= got and got <= (wantpx | maybe), (len(wantpx - got), len(got - wantpx))
+        order = np.lexsort((vy, vx))
+        key = vx[order] * (1 << 32) + vy[order]
+        ii = order[np.searchsorted(key, s['x'] * (1 << 32) + s['y'])]
+        np.testing.assert_array_equal(vx[ii], s['x'])
+        np.testing.assert_array_equal(vy[ii], s['y'])
+        np.testing.assert_array_equal(s['O'], o['O'][ii])
+        np.testing.assert_allclose(s['E'], o['E'][ii], rtol=1e-9, atol=0)
+        np.testing.assert_allclose(s['p'], o['p'][ii], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(s['q'], o['q'][ii], rtol=0, atol=1e-9)
+        # family sizes of the Benjamini-Hochberg step = the oracle's chunk memberships
+        tests = np.bincount(o['chunk'], minlength=s['chunk_tests'].size)
+        np.testing.assert_array_equal(s['chunk_tests'][1:], tests[1:s['chunk_tests'].size])
+        nsig += s['x'].size
+    assert nsig > 500
+    # gap rows and the final table (after gap filter, donut / lower-left combination, clustering)
+    np.testing.assert_array_equal(R.gap, np.isin(np.arange(R.gap.size), sorted(det['gaps'])))
+    k, v = _arrays(final)
+    kw, vw = _arrays(want)
+    np.testing.assert_array_equal(k, kw)
+    np.testing.assert_allclose(v, vw, rtol=1e-9, atol=1e-9)
+    assert len(want) > 20
+
+
+@pytest.mark.parametrize('name', sorted(FULL))
+def test_full_size_chr1_vs_oracle(name, ctx):
+    cfg = FULL[name]
+    n, res, maxww, sig = cfg['n'], cfg['res'], 10, 0.05
+    pw, ww = cfg['pw'], cfg['ww']
+    num = cfg['maxapart'] // res + maxww + 1
+    raw, weight, _ = synthetic.synth_band(n, num, depth=cfg['depth'], nloops=cfg['nloops'], seed=cfg['seed'])
+    IR, cband, biases = orc.prep_from_band(raw, weight, min(ww))
+    kw = dict(pw=pw, ww=ww, maxww=maxww, sig=sig, maxapart=cfg['maxapart'], res=res, min_local_reads=16,
+              min_marginal_peaks=2, onlyanchor=False)
+    det = {}
+    want = orc.hiccups(raw, cband, biases, biases, IR, n, num, detail=det, **kw)
+    rawf = raw.astype(np.float32)
+    # (i) one call, IR / biases given, weights on the chip
+    d1 = {}
+    final = callers.hiccups_band(rawf, IR, biases, biases, chrom='1', weight=weight, ctx=ctx, detail=d1, **kw)
+    assert d1['result'].stencil_kernel == 2 and d1['result'].tiles == -(-n // 59) * 6
+    _check_against_oracle(d1['result'], final, det, want, pw, ww, sig)
+    # (ii) the same chromosome between two others in one batch, IR / biases derived on the device
+    prm = _lib.make_params(_lib.MODE_HICCUPS, pw, ww, maxww, sig, cfg['maxapart'], res, 16, 0)
+    other, ow, _ = synthetic.synth_band(9000, num, depth=cfg['depth'], nloops=100, seed=77)
+    items = [dict(raw=other.astype(np.float32), weight=ow, num=num), dict(raw=rawf, weight=weight, num=num),
+             dict(raw=other.astype(np.float32), weight=ow, num=num)]
+    Rs = ctx.submit_batch_host(items, prm).results()
+    assert Rs[1].batch_bands == 3
+    fin2, _ = callers._finish_hiccups(Rs[1], n, '1', pw, ww, sig, 0.01, 1.75, 2, res, False, 2, False)
+    _check_against_oracle(Rs[1], fin2, det, want, pw, ww, sig)
+    # (the chromosome before and after it are the same band: same result)
+    assert Rs[0].ncand == Rs[2].ncand and [s['x'].size for s in Rs[0].sets] == [s['x'].size for s in Rs[2].sets]
