@@ -381,10 +381,15 @@ class Context(object):
         raw = np.ascontiguousarray(raw, dtype=np.float32)
         n, ld = raw.shape
         keep = [raw]
-        derive = IR is None         # IR / biases derived on the device from the weights
+        derive = IR is None         # IR (and, unless given, the biases) derived on the device from the weights
         if derive:
             num = num_hint if num_hint is not None else ld
             irp = b1p = b2p = None
+            if bias1 is not None:
+                b1 = np.ascontiguousarray(bias1, dtype=np.float64)
+                b2 = b1 if (bias2 is bias1 or bias2 is None) else np.ascontiguousarray(bias2, dtype=np.float64)
+                keep += [b1, b2]
+                b1p, b2p = b1.ctypes.data, b2.ctypes.data
         else:
             IR = np.ascontiguousarray(IR, dtype=np.float64)
             b1 = np.ascontiguousarray(bias1, dtype=np.float64)

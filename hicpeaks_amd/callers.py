@@ -23,7 +23,8 @@ from .clustering import local_clustering
 
 logger = logging.getLogger(__name__)
 
-__all__ = ['pw_ww_pairs', 'lambdachunk', 'hiccups', 'bhfdr', 'hiccups_band', 'bhfdr_band', 'local_clustering']
+__all__ = ['pw_ww_pairs', 'lambdachunk', 'hiccups', 'bhfdr', 'hiccups_band', 'bhfdr_band', 'hiccups_batch_submit',
+           'bhfdr_batch_submit', 'local_clustering']
 
 
 def pw_ww_pairs(pw, ww, maxww):
@@ -149,12 +150,18 @@ def hiccups_band_submit(raw, IR, B1, B2, chrom='', balanced=None, weight=None, p
     n = raw.shape[0]
     logger.info('Chrom:{0}, Two local neighborhoods, two expected matrices ...'.format(chrom))
     job = ctx.submit_host(raw, IR, B1, B2, prm, balanced=balanced, weight=weight)
-    pw, ww = list(pw), list(ww)
+    finish = _hiccups_finisher(prm, n, chrom, list(pw), list(ww), sig, sumq, double_fold, single_fold, res, use_raw,
+                               min_marginal_peaks, onlyanchor, detail)
+    return PendingCall(job, finish)
 
+
+def _hiccups_finisher(prm, n, chrom, pw, ww, sig, sumq, double_fold, single_fold, res, use_raw, min_marginal_peaks,
+                      onlyanchor, detail=None):
+    """The host half of one chromosome (callers.py:289-362) as a function of its BandResult."""
     def finish(R):
         logger.info('Chrom:{0}, Observed Contact Number: {1}'.format(chrom, R.ncand))
         if R.redone:
-            logger.info('Chrom:{0}, widening froze at {1}, beyond the width bound taken from the previous chromosome: '
+            logger.info('Chrom:{0}, widening froze at {1}, beyond the width bound taken from the previous chromosomes: '
                         'computed once more in full'.format(chrom, R.frozen_w))
         npairs = prm.npairs
         final, table = _finish_hiccups(R, n, chrom, pw[:npairs], ww[:npairs], sig, sumq, double_fold,
@@ -163,7 +170,42 @@ def hiccups_band_submit(raw, IR, B1, B2, chrom='', balanced=None, weight=None, p
             detail['result'] = R
             detail['pixel_table'] = table
         return final
-    return PendingCall(job, finish)
+    return finish
+
+
+class PendingBatch(object):
+    """A batch of chromosomes whose kernels are in flight (hpk_submit_batch); results() waits for it and runs the host half
+    of every chromosome, in submission order."""
+
+    def __init__(self, job, finishers):
+        self._job, self._finishers = job, finishers
+
+    def results(self):
+        return [f(R) for f, R in zip(self._finishers, self._job.results())]
+
+
+def hiccups_batch_submit(items, pw=[2], ww=[5], maxww=20, sig=0.1, sumq=0.01, double_fold=1.75, single_fold=2,
+                         maxapart=2000000, res=10000, use_raw=False, min_marginal_peaks=3, onlyanchor=True, min_local_reads=25,
+                         device=0, ctx=None):
+    """`hiccups_band` for several chromosomes at once - the loop of scripts/pyHICCUPS:192-198 as ONE set of kernel launches
+    (hpk_submit_batch).  items: [(chrom, raw [n, num], weight [n][, biases [n] or None]), ...]; IR and - unless given -
+    the biases are derived on the device (scripts/pyHICCUPS:149-166).  Returns a PendingBatch whose results() are the
+    chromosomes' final tables."""
+    ctx = ctx or _lib.default_context(device)
+    prm = _lib.make_params(_lib.MODE_HICCUPS, pw, ww, maxww, sig, maxapart, res, min_local_reads, _lib.FLAG_NO_STENCIL_TIMING)
+    fins = []
+    for it in items:
+        chrom, raw = it[0], it[1]
+        logger.info('Chrom:{0}, Two local neighborhoods, two expected matrices ...'.format(chrom))
+        fins.append(_hiccups_finisher(prm, raw.shape[0], chrom, list(pw), list(ww), sig, sumq, double_fold, single_fold, res,
+                                      use_raw, min_marginal_peaks, onlyanchor))
+    job = ctx.submit_batch_host([_batch_item(it) for it in items], prm)
+    return PendingBatch(job, fins)
+
+
+def _batch_item(it):
+    b = it[3] if len(it) > 3 else None
+    return dict(raw=it[1], weight=it[2], bias1=b, bias2=b)
 
 
 def hiccups_band(raw, IR, B1, B2, chrom='', balanced=None, weight=None, pw=[2], ww=[5], maxww=20, sig=0.1,
@@ -205,11 +247,29 @@ def bhfdr_band_submit(raw, IR, B1, B2, chrom='', balanced=None, weight=None, pw=
     n = raw.shape[0]
     logger.info('Chrom:{0}, Calculate the expected matrix ...'.format(chrom))
     job = ctx.submit_host(raw, IR, B1, B2, prm, balanced=balanced, weight=weight)
+    return PendingCall(job, _bhfdr_finisher(n, chrom, ww, res, min_marginal_peaks, onlyanchor, detail))
 
+
+def bhfdr_batch_submit(items, pw=2, ww=5, sig=0.05, maxww=20, maxapart=2000000, res=10000, min_marginal_peaks=3,
+                       onlyanchor=False, device=0, ctx=None):
+    """`bhfdr_band` for several chromosomes at once (see hiccups_batch_submit); items: [(chrom, raw, weight), ...]."""
+    ctx = ctx or _lib.default_context(device)
+    prm = _lib.make_params(_lib.MODE_BHFDR, [pw], [ww], maxww, sig, maxapart, res, 16, _lib.FLAG_NO_STENCIL_TIMING)
+    fins = []
+    for it in items:
+        chrom, raw = it[0], it[1]
+        logger.info('Chrom:{0}, Calculate the expected matrix ...'.format(chrom))
+        fins.append(_bhfdr_finisher(raw.shape[0], chrom, ww, res, min_marginal_peaks, onlyanchor))
+    job = ctx.submit_batch_host([_batch_item(it) for it in items], prm)
+    return PendingBatch(job, fins)
+
+
+def _bhfdr_finisher(n, chrom, ww, res, min_marginal_peaks, onlyanchor, detail=None):
+    """The host half of one chromosome (callers.py:555-590) as a function of its BandResult."""
     def finish(R):
         logger.info('Chrom:{0}, Observed Contact Number: {1}'.format(chrom, R.ncand))
         if R.redone:
-            logger.info('Chrom:{0}, widening froze at {1}, beyond the width bound taken from the previous chromosome: '
+            logger.info('Chrom:{0}, widening froze at {1}, beyond the width bound taken from the previous chromosomes: '
                         'computed once more in full'.format(chrom, R.frozen_w))
         s = R.sets[0]
         logger.info('Chrom:{0}, Number of Poisson Models: {1}'.format(chrom, s['nvalid']))
@@ -231,7 +291,7 @@ def bhfdr_band_submit(raw, IR, B1, B2, chrom='', balanced=None, weight=None, pw=
             detail['result'] = R
             detail['Donuts'] = Donuts
         return pixel_table
-    return PendingCall(job, finish)
+    return finish
 
 
 def bhfdr_band(raw, IR, B1, B2, chrom='', balanced=None, weight=None, pw=2, ww=5, sig=0.05, maxww=20,

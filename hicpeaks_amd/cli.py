@@ -28,6 +28,7 @@ def format_bhfdr(chrom, table, res, sort=False):
 
 # ----------------------------------------------------------------------------- command lines
 import argparse
+import itertools
 import logging
 import logging.handlers
 import sys
@@ -117,48 +118,60 @@ def select_chroms(chromnames, chroms):
     return out
 
 
-def _submit_chrom(args_dict, mode, key, device, src=None):
-    """Read one chromosome's band and put it on the GPU's queue (the first half of worker(), scripts/pyHICCUPS:139-175);
-    returns a PendingCall."""
-    from . import callers, io, _lib
+def _fetch(args_dict, src, key):
+    """One chromosome's band as the library wants it (the first half of worker(), scripts/pyHICCUPS:139-166, without the
+    per-diagonal extraction): (label, raw f32 [n, num], weight f64 [n], biases or None)."""
+    num = args_dict['maxapart'] // src.binsize + args_dict['maxww'] + 1
+    raw, w, b = src.fetch(key, num, args_dict['clr_weight_name'])
+    return key.lstrip('chr'), raw, w, b
+
+
+def _submit_group(args_dict, mode, items, device, res):
+    """A group of fetched chromosomes onto the GPU's queue as one batch (hpk_submit_batch); returns a PendingBatch."""
+    from . import callers, _lib
     a = args_dict
-    src = src or io.open_source(a['path'])
-    res = src.binsize
     ctx = _lib.default_context(device)
-    num = a['maxapart'] // res + a['maxww'] + 1
-    raw, w = src.fetch(key, num, a['clr_weight_name'])
     if mode == 'hiccups':
-        return callers.hiccups_band_submit(raw, None, None, None, chrom=key.lstrip('chr'), weight=w, pw=a['pw'],
-                                           ww=a['ww'], maxww=a['maxww'], sig=a['siglevel'], sumq=a['sumq'],
-                                           double_fold=a['double_fold'], single_fold=a['single_fold'],
-                                           maxapart=a['maxapart'], res=res, use_raw=a['use_raw'],
-                                           min_marginal_peaks=a['min_marginal_peaks'], onlyanchor=a['only_anchors'],
-                                           min_local_reads=a['min_local_reads'], ctx=ctx)
-    return callers.bhfdr_band_submit(raw, None, None, None, chrom=key.lstrip('chr'), weight=w, pw=a['pw'], ww=a['ww'],
-                                     sig=a['siglevel'], maxww=a['maxww'], maxapart=a['maxapart'], res=res, ctx=ctx)
+        return callers.hiccups_batch_submit(items, pw=a['pw'], ww=a['ww'], maxww=a['maxww'], sig=a['siglevel'], sumq=a['sumq'],
+                                            double_fold=a['double_fold'], single_fold=a['single_fold'], maxapart=a['maxapart'],
+                                            res=res, use_raw=a['use_raw'], min_marginal_peaks=a['min_marginal_peaks'],
+                                            onlyanchor=a['only_anchors'], min_local_reads=a['min_local_reads'], ctx=ctx)
+    return callers.bhfdr_batch_submit(items, pw=a['pw'], ww=a['ww'], sig=a['siglevel'], maxww=a['maxww'],
+                                      maxapart=a['maxapart'], res=res, ctx=ctx)
 
 
-def _score_chrom(args_dict, mode, key, device):
-    """One work item = one chromosome."""
-    return key.lstrip('chr'), _submit_chrom(args_dict, mode, key, device).result()
+GROUP_BYTES = 6 << 30        # band bytes of one batch: the device workspaces of a batch are ~8x its bands
 
 
-def _score_chroms(args_dict, mode, keys, device):
-    """The chromosomes of one GPU, one ahead: while chromosome i is on the GPU, chromosome i + 1 is read and uploaded
-    and chromosome i - 1 goes through clustering on the host (hpk_submit_band / hpk_collect)."""
+def _score_queue(args_dict, mode, queue, device):
+    """One GPU worker: takes chromosomes from the shared largest-first queue while it has room, hands them to the GPU in
+    batches (several chromosomes per set of launches, up to GROUP_BYTES of bands), one batch ahead - while batch i is on
+    the GPU, batch i + 1 is read and uploaded and batch i - 1 goes through clustering on the host.  -> {label: table}"""
     from . import io, _lib
     import collections
     src = io.open_source(args_dict['path'])
     depth = _lib.default_context(device).pipeline_depth
-    pending, out = collections.deque(), []
-    for key in keys:
-        pending.append((key, _submit_chrom(args_dict, mode, key, device, src)))
-        if len(pending) >= depth:
-            k, call = pending.popleft()
-            out.append((k.lstrip('chr'), call.result()))
+    pending, out = collections.deque(), {}
+
+    def collect():
+        labels, call = pending.popleft()
+        for label, table in zip(labels, call.results()):
+            out[label] = table
+
+    group, nbytes = [], 0
+    for key in itertools.chain(queue, [None]):
+        if key is not None:
+            item = _fetch(args_dict, src, key)
+            group.append(item)
+            nbytes += item[1].nbytes
+        # a batch is closed when it is full - or as soon as the GPU has nothing in flight (the first chromosomes start at once)
+        if group and (key is None or nbytes >= GROUP_BYTES or len(group) >= _lib.HPK_MAX_BATCH or not pending):
+            pending.append(([g[0] for g in group], _submit_group(args_dict, mode, group, device, src.binsize)))
+            group, nbytes = [], 0
+            if len(pending) >= depth:
+                collect()
     while pending:
-        k, call = pending.popleft()
-        out.append((k.lstrip('chr'), call.result()))
+        collect()
     return out
 
 
@@ -183,9 +196,39 @@ def worker_devices(nproc, device, ngpus):
     return n, list(range(n))
 
 
-def _pool_worker(job):
-    args_dict, mode, keys, device = job
-    return _score_chroms(args_dict, mode, keys, device)
+def _gpu_worker(args_dict, mode, device, sizes, value, results):
+    """One worker process = one GPU: drains the shared queue (a counter over the same largest-first list in every
+    process) and sends back its {label: table}, or the exception that stopped it."""
+    from . import parallel
+    try:
+        queue = parallel.WorkQueue(sizes, parallel.mp_counter(value))
+        results.put((device, _score_queue(args_dict, mode, queue, device), None))
+    except BaseException as e:              # the parent re-raises (HpkError / EmptyStepError pickle, see _lib)
+        results.put((device, None, e))
+
+
+def run_workers(args_dict, mode, sizes, devices):
+    """--nproc N: one process per GPU around one queue (counterpart of Pool(nproc).map(worker, Params),
+    scripts/pyHICCUPS:192-198) -> {label: table} of all chromosomes."""
+    import multiprocessing as mp
+    ctxmp = mp.get_context('spawn')
+    value = ctxmp.Value('i', 0)
+    results = ctxmp.Queue()
+    procs = [ctxmp.Process(target=_gpu_worker, args=(args_dict, mode, d, sizes, value, results)) for d in devices]
+    for p in procs:
+        p.start()
+    tables, err = {}, None
+    for _ in procs:
+        _, part, e = results.get()
+        if e is not None:
+            err = err or e
+        else:
+            tables.update(part)
+    for p in procs:
+        p.join()
+    if err is not None:
+        raise err
+    return tables
 
 
 def _run(mode, argv):
@@ -208,33 +251,30 @@ def _run(mode, argv):
     a = vars(args)
     rank, world, local = parallel.dist_env()
     logger.info('Calling Peaks ...')
-    if world > 1:                                    # torchrun: one rank per GPU, tables gathered on rank 0
+    if world > 1:                                    # torchrun: one rank per GPU, one queue, tables gathered on rank 0
         import torch.distributed as dist
-        dist.init_process_group('gloo')              # only Python objects travel
+        dist.init_process_group('gloo')              # only the queue's counter and Python objects travel
         dev = local if args.device is None else args.device
-        tables = parallel.run_sharded(sizes, None, rank, world,
-                                      batch_fn=lambda ks: [t for _, t in _score_chroms(a, mode, ks, dev)])
+        queue = parallel.WorkQueue(sizes, parallel.store_counter())
+        tables = parallel.gather_tables(_score_queue(a, mode, queue, dev), rank, world)
         dist.destroy_process_group()
         if rank != 0:
             return 0
-        results = [(k.lstrip('chr'), tables[k]) for k in keys]
     else:
         # Pool.map over GPU workers (scripts/pyHICCUPS:192-198); one worker runs in this process
         nworkers, devices = worker_devices(args.nproc, args.device, _gpu_count() if args.nproc > 1 else 0)
         if args.nproc > 1:
             logger.info('--nproc {0}: {1} worker(s) on GPU(s) {2}'.format(args.nproc, nworkers, devices))
         if nworkers > 1:
-            import multiprocessing as mp
-            parts = parallel.lpt_partition(sizes, nworkers)
-            jobs = [(a, mode, part, devices[w]) for w, part in enumerate(parts)]
-            with mp.get_context('spawn').Pool(nworkers) as pool:
-                done = dict(kv for part in pool.map(_pool_worker, jobs) for kv in part)
-            results = [(k.lstrip('chr'), done[k.lstrip('chr')]) for k in keys]
+            tables = run_workers(a, mode, sizes, devices)
         else:
-            results = _score_chroms(a, mode, keys, devices[0] if args.device is not None else 0)
+            queue = parallel.WorkQueue(sizes, parallel.local_counter())
+            tables = _score_queue(a, mode, queue, devices[0] if args.device is not None else 0)
     with open(args.output, 'w') as out:
-        for key, table in results:
-            out.write(format_hiccups(key, table, res) if mode == 'hiccups' else format_bhfdr(key, table, res))
+        for key in keys:                             # the order of the chromosomes in the file, as the reference writes them
+            label = key.lstrip('chr')
+            table = tables[label]
+            out.write(format_hiccups(label, table, res) if mode == 'hiccups' else format_bhfdr(label, table, res))
     logger.info('Done!')
     return 0
 

@@ -1,0 +1,291 @@
+"""Minimal reader of the cooler file format (.cool / .mcool, HDF5) - what scripts/pyHICCUPS:142-166 asks of the
+`cooler` package, without the package: the pixel table of one chromosome, the bin table's weight column, the bin size
+and the chromosome list.
+
+Schema read (cooler format version 3, https://cooler.readthedocs.io/en/latest/schema.html):
+
+    chroms/name [S], chroms/length [i]            one row per chromosome
+    bins/chrom [enum -> i], start, end [i]        one row per bin, genome order; bins/<weight> [f8], NaN = masked bin
+    pixels/bin1_id, bin2_id [i8], count [i4|f8]   upper triangle, sorted by (bin1_id, bin2_id)
+    indexes/chrom_offset [i8]                     first bin of every chromosome (+ total)
+    indexes/bin1_offset [i8]                      first pixel of every bin1 (+ total)
+    attrs: bin-size
+
+Backends: `h5py` when importable; otherwise the HDF5 C library itself through ctypes (libhdf5.so - on this image under
+/opt/conda/lib; HPK_LIBHDF5 names another one).  Neither h5py nor cooler is a dependency of the package.
+
+Balancing conventions (cooler.Cooler.matrix, not under /root/reference and not installed here - SURVEY 8-C2 - so taken from
+cooler's documentation, not verified against the package): balanced = count * w[bin1] * w[bin2]; the 4DN-style columns
+"KR", "VC", "VC_SQRT" are *divisive* (balanced = count / (w[bin1] * w[bin2])) unless the column's `divisive_weights`
+attribute says otherwise.
+"""
+import ctypes as C
+import ctypes.util
+import os
+
+import numpy as np
+
+DIVISIVE_NAMES = ('KR', 'VC', 'VC_SQRT')
+
+
+def parse_uri(uri):
+    """'file.mcool::/resolutions/10000' -> ('file.mcool', '/resolutions/10000'); a plain path -> (path, '/')."""
+    uri = str(uri)
+    if '::' in uri:
+        path, group = uri.split('::', 1)
+        group = '/' + group.strip('/')
+        return path, group
+    return uri, '/'
+
+
+# ----------------------------------------------------------------------------- libhdf5 through ctypes
+class _H5C(object):
+    """The dozen HDF5 C calls a cooler needs.  Data sets are read as native int64 / float64 / fixed strings (HDF5 converts
+    whatever the file holds, enums included), whole or as a [start, stop) slice of the first dimension."""
+
+    _lib = None
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is not None:
+            return cls._lib
+        names = [os.environ.get('HPK_LIBHDF5'), ctypes.util.find_library('hdf5'), 'libhdf5.so', '/opt/conda/lib/libhdf5.so',
+                 '/usr/lib/x86_64-linux-gnu/hdf5/serial/libhdf5.so']
+        last = None
+        for nm in names:
+            if not nm:
+                continue
+            try:
+                L = C.CDLL(nm)
+                break
+            except OSError as e:
+                last = e
+        else:
+            raise ImportError('neither h5py nor libhdf5 is available (%s); set HPK_LIBHDF5' % last)
+        hid, hs, he = C.c_int64, C.c_uint64, C.c_int
+        sig = dict(H5open=(he, []), H5Fopen=(hid, [C.c_char_p, C.c_uint, hid]), H5Fclose=(he, [hid]),
+                   H5Gopen2=(hid, [hid, C.c_char_p, hid]), H5Gclose=(he, [hid]),
+                   H5Dopen2=(hid, [hid, C.c_char_p, hid]), H5Dclose=(he, [hid]), H5Dget_space=(hid, [hid]),
+                   H5Dget_type=(hid, [hid]), H5Dread=(he, [hid, hid, hid, hid, hid, C.c_void_p]),
+                   H5Sget_simple_extent_ndims=(C.c_int, [hid]), H5Sget_simple_extent_dims=(C.c_int, [hid, C.POINTER(hs), C.POINTER(hs)]),
+                   H5Sselect_hyperslab=(he, [hid, C.c_int, C.POINTER(hs), C.POINTER(hs), C.POINTER(hs), C.POINTER(hs)]),
+                   H5Screate_simple=(hid, [C.c_int, C.POINTER(hs), C.POINTER(hs)]), H5Sclose=(he, [hid]),
+                   H5Tget_class=(C.c_int, [hid]), H5Tget_size=(C.c_size_t, [hid]), H5Tclose=(he, [hid]), H5Tcopy=(hid, [hid]),
+                   H5Tset_size=(he, [hid, C.c_size_t]), H5Tis_variable_str=(C.c_int, [hid]),
+                   H5Aexists_by_name=(C.c_int, [hid, C.c_char_p, C.c_char_p, hid]),
+                   H5Aopen_by_name=(hid, [hid, C.c_char_p, C.c_char_p, hid, hid]), H5Aread=(he, [hid, hid, C.c_void_p]),
+                   H5Aget_type=(hid, [hid]), H5Aclose=(he, [hid]), H5Lexists=(C.c_int, [hid, C.c_char_p, hid]),
+                   H5Eset_auto2=(he, [hid, C.c_void_p, C.c_void_p]))
+        for name, (res, args) in sig.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        if L.H5open() < 0:
+            raise ImportError('H5open failed')
+        L.H5Eset_auto2(0, None, None)               # no error stack printing: failures become Python exceptions here
+        cls.T_I64 = C.c_int64.in_dll(L, 'H5T_NATIVE_INT64_g').value
+        cls.T_F64 = C.c_int64.in_dll(L, 'H5T_NATIVE_DOUBLE_g').value
+        cls.T_C_S1 = C.c_int64.in_dll(L, 'H5T_C_S1_g').value
+        cls._lib = L
+        return L
+
+    def __init__(self, path, group):
+        L = self.lib()
+        self.f = L.H5Fopen(str(path).encode(), 0, 0)            # H5F_ACC_RDONLY, H5P_DEFAULT
+        if self.f < 0:
+            raise IOError('cannot open %s as an HDF5 file' % path)
+        self.g = L.H5Gopen2(self.f, group.encode(), 0)
+        if self.g < 0:
+            L.H5Fclose(self.f)
+            raise IOError('no group %s in %s' % (group, path))
+
+    def close(self):
+        L = self.lib()
+        if getattr(self, 'g', -1) >= 0:
+            L.H5Gclose(self.g)
+            self.g = -1
+        if getattr(self, 'f', -1) >= 0:
+            L.H5Fclose(self.f)
+            self.f = -1
+
+    def exists(self, name):
+        L = self.lib()
+        cur = ''
+        for part in name.strip('/').split('/'):             # H5Lexists wants every intermediate link to exist
+            cur = cur + '/' + part if cur else part
+            if L.H5Lexists(self.g, cur.encode(), 0) <= 0:
+                return False
+        return True
+
+    def _open(self, name):
+        d = self.lib().H5Dopen2(self.g, name.encode(), 0)
+        if d < 0:
+            raise KeyError(name)
+        return d
+
+    def shape(self, name):
+        L = self.lib()
+        d = self._open(name)
+        sp = L.H5Dget_space(d)
+        dims = (C.c_uint64 * 4)()
+        nd = L.H5Sget_simple_extent_dims(sp, dims, None)
+        L.H5Sclose(sp)
+        L.H5Dclose(d)
+        return tuple(int(dims[i]) for i in range(nd))
+
+    def read(self, name, start=None, stop=None, kind=None):
+        """kind: 'i' -> int64, 'f' -> float64, 's' -> list of str, None -> by the data set's class"""
+        L = self.lib()
+        d = self._open(name)
+        try:
+            ft = L.H5Dget_type(d)
+            cls, size = L.H5Tget_class(ft), L.H5Tget_size(ft)
+            varstr = cls == 3 and L.H5Tis_variable_str(ft) > 0
+            L.H5Tclose(ft)
+            if kind is None:
+                kind = {0: 'i', 1: 'f', 3: 's', 8: 'i'}.get(cls)        # H5T_INTEGER, FLOAT, STRING, ENUM
+            if kind is None or varstr:
+                raise TypeError('%s: unsupported HDF5 type class %d' % (name, cls))
+            sp = L.H5Dget_space(d)
+            dims = (C.c_uint64 * 4)()
+            nd = L.H5Sget_simple_extent_dims(sp, dims, None)
+            if nd != 1:
+                L.H5Sclose(sp)
+                raise TypeError('%s: one-dimensional data sets only' % name)
+            n = int(dims[0])
+            a = 0 if start is None else max(0, min(int(start), n))
+            b = n if stop is None else max(a, min(int(stop), n))
+            cnt = b - a
+            if kind == 's':
+                mt = L.H5Tcopy(self.T_C_S1)
+                L.H5Tset_size(mt, size)
+                out = np.zeros(cnt, dtype='S%d' % size)
+            else:
+                mt = self.T_I64 if kind == 'i' else self.T_F64
+                out = np.empty(cnt, dtype=np.int64 if kind == 'i' else np.float64)
+            if cnt:
+                st, ct = (C.c_uint64 * 1)(a), (C.c_uint64 * 1)(cnt)
+                L.H5Sselect_hyperslab(sp, 0, st, None, ct, None)       # H5S_SELECT_SET
+                ms = L.H5Screate_simple(1, ct, None)
+                rc = L.H5Dread(d, mt, ms, sp, 0, out.ctypes.data)
+                L.H5Sclose(ms)
+                if rc < 0:
+                    raise IOError('H5Dread failed on %s' % name)
+            L.H5Sclose(sp)
+            if kind == 's':
+                L.H5Tclose(mt)
+                return [v.decode() for v in out]
+            return out
+        finally:
+            L.H5Dclose(d)
+
+    def attr(self, obj, name, default=None):
+        """Scalar integer / float / boolean-like attribute of the group (obj = '.') or of a data set."""
+        L = self.lib()
+        if L.H5Aexists_by_name(self.g, obj.encode(), name.encode(), 0) <= 0:
+            return default
+        a = L.H5Aopen_by_name(self.g, obj.encode(), name.encode(), 0, 0)
+        if a < 0:
+            return default
+        try:
+            t = L.H5Aget_type(a)
+            cls = L.H5Tget_class(t)
+            L.H5Tclose(t)
+            if cls in (0, 8):
+                v = C.c_int64(0)
+                return int(v.value) if L.H5Aread(a, self.T_I64, C.byref(v)) >= 0 else default
+            if cls == 1:
+                v = C.c_double(0)
+                return float(v.value) if L.H5Aread(a, self.T_F64, C.byref(v)) >= 0 else default
+            return default
+        finally:
+            L.H5Aclose(a)
+
+
+class _H5Py(object):
+    def __init__(self, path, group):
+        import h5py
+        self.f = h5py.File(path, 'r')
+        self.g = self.f[group]
+
+    def close(self):
+        self.f.close()
+
+    def exists(self, name):
+        return name in self.g
+
+    def shape(self, name):
+        return tuple(self.g[name].shape)
+
+    def read(self, name, start=None, stop=None, kind=None):
+        d = self.g[name]
+        v = d[slice(start, stop)]
+        if v.dtype.kind in 'SO':
+            return [x.decode() if isinstance(x, bytes) else str(x) for x in v]
+        return v.astype(np.float64 if (kind == 'f' or (kind is None and v.dtype.kind == 'f')) else np.int64)
+
+    def attr(self, obj, name, default=None):
+        o = self.g if obj == '.' else self.g[obj]
+        if name not in o.attrs:
+            return default
+        v = o.attrs[name]
+        return v.item() if hasattr(v, 'item') else v
+
+
+def _backend(path, group):
+    try:
+        import h5py  # noqa: F401
+        return _H5Py(path, group)
+    except ImportError:
+        return _H5C(path, group)
+
+
+# ----------------------------------------------------------------------------- the cooler itself
+class CoolFile(object):
+    """One cooler (a .cool file, or one resolution of an .mcool: 'file.mcool::/resolutions/5000')."""
+
+    def __init__(self, uri):
+        self.path, self.group = parse_uri(uri)
+        self.h = _backend(self.path, self.group)
+        for need in ('chroms/name', 'bins/chrom', 'pixels/bin1_id', 'indexes/chrom_offset', 'indexes/bin1_offset'):
+            if not self.h.exists(need):
+                self.h.close()
+                raise IOError('%s%s is not a cooler: %s is missing' % (self.path, '::' + self.group if self.group != '/' else '', need))
+        self.binsize = self.h.attr('.', 'bin-size')
+        if self.binsize is None:
+            raise IOError('cooler without a fixed bin-size (variable-size bins are not supported)')
+        self.binsize = int(self.binsize)
+        self.chromnames = self.h.read('chroms/name', kind='s')
+        self.chrom_offset = self.h.read('indexes/chrom_offset', kind='i')
+        self._cid = {c: i for i, c in enumerate(self.chromnames)}
+
+    def close(self):
+        self.h.close()
+
+    def extent(self, chrom):
+        i = self._cid[chrom]
+        return int(self.chrom_offset[i]), int(self.chrom_offset[i + 1])
+
+    def weights(self, chrom, name='weight'):
+        """(weight f64 [n] of the chromosome's bins, divisive) - the column as stored, NaN = masked bin"""
+        lo, hi = self.extent(chrom)
+        col = 'bins/' + name
+        if not self.h.exists(col):
+            raise KeyError('no bin column %r (balance the cooler first, or pick --clr-weight-name)' % name)
+        w = self.h.read(col, lo, hi, kind='f')
+        div = self.h.attr(col, 'divisive_weights')
+        divisive = bool(div) if div is not None else (name in DIVISIVE_NAMES)
+        return w, divisive
+
+    def pixels(self, chrom):
+        """The intra-chromosomal pixels of `chrom`, bins relative to its first bin: (bin1 i8, bin2 i8, count) - what
+        `clr.matrix(balance=False, as_pixels=True, join=False).fetch(chrom)` holds (scripts/pyHICCUPS:142)."""
+        lo, hi = self.extent(chrom)
+        off = self.h.read('indexes/bin1_offset', lo, hi + 1, kind='i')
+        p0, p1 = int(off[0]), int(off[-1])
+        b1 = self.h.read('pixels/bin1_id', p0, p1, kind='i')
+        b2 = self.h.read('pixels/bin2_id', p0, p1, kind='i')
+        cnt = self.h.read('pixels/count', p0, p1)
+        keep = b2 < hi                                  # pixels are sorted by bin1: the trans ones have bin2 beyond the chromosome
+        if not keep.all():
+            b1, b2, cnt = b1[keep], b2[keep], cnt[keep]
+        return b1 - lo, b2 - lo, cnt

@@ -396,9 +396,10 @@ int check_band(hpk_ctx* c, const hpk_band* band) {
     if (!band || band->n <= 0 || band->num <= 0 || band->ld < band->num) return fail(c, HPK_ERR_INVALID, "bad band shape");
     if (!band->raw) return fail(c, HPK_ERR_INVALID, "raw pointer required");
     if (!band->balanced && !band->weight) return fail(c, HPK_ERR_INVALID, "either balanced or weight must be given");
-    const bool derive = !band->IR && !band->bias1 && !band->bias2;
+    const bool derive = !band->IR;
     if (derive && !band->weight) return fail(c, HPK_ERR_INVALID, "IR / biases can only be derived on the device from `weight`");
-    if (!derive && (!band->IR || !band->bias1 || !band->bias2)) return fail(c, HPK_ERR_INVALID, "IR, bias1 and bias2 go together");
+    if ((band->bias1 == nullptr) != (band->bias2 == nullptr)) return fail(c, HPK_ERR_INVALID, "bias1 and bias2 go together");
+    if (!derive && !band->bias1) return fail(c, HPK_ERR_INVALID, "IR needs bias1 and bias2 (only IR itself, or all three, may be left to the device)");
     return HPK_OK;
 }
 
@@ -633,7 +634,8 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         k0 += d.chunk;
         d.rec_stride = (int64_t)s.ntiles * tilecap;
         d.cap = cap; d.zero_bytes = s.zero_bytes; d.off_rowlive = (uint32_t)s.off_rowlive; d.off_inl = (uint32_t)s.off_inl;
-        d.derive = derive ? 1 : 0; d.score_wgs = wgs;
+        d.derive = derive ? (bands[b].bias1 ? 2 : 1) : 0;       // 1: IR and biases, 2: IR only
+        d.score_wgs = wgs;
     }
 
     // ---- workspaces
@@ -715,8 +717,18 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         }
         if (derive) {      // IR / biases from raw + weight on the device (scripts/pyHICCUPS:149-166): hpk_launch_prep below
             st.IR = L.IR.as<double>() + off_ir[b];
-            st.b1 = L.b1.as<double>() + off_n[b];
-            st.b2 = st.b1;
+            if (!in.bias1) {
+                st.b1 = L.b1.as<double>() + off_n[b];
+                st.b2 = st.b1;
+            } else if (!in.on_device) {     // IR only: the caller's biases (e.g. of a divisive weight column) are uploaded
+                st.b1 = L.b1.as<double>() + off_n[b];
+                HIPCHK(c, hipMemcpyAsync(st.b1, in.bias1, sizeof(double) * n, hipMemcpyHostToDevice, L.up));
+                if (in.bias2 == in.bias1) st.b2 = st.b1;
+                else {
+                    st.b2 = L.b2.as<double>() + off_n[b];
+                    HIPCHK(c, hipMemcpyAsync(st.b2, in.bias2, sizeof(double) * n, hipMemcpyHostToDevice, L.up));
+                }
+            }
         }
         // descriptor: pointers
         HpkBandDesc& d = s.d;
@@ -949,9 +961,9 @@ int finish_band(hpk_ctx* c, hpk_job* j, int b) {
             std::memcpy(&emax, &h_emax[t], 8);
             hs.emax = emax;
             int numbin = 0;
-            if (plan.mode == HPK_MODE_HICCUPS && hs.nvalid > 0) {
+            if (plan.mode == HPK_MODE_HICCUPS && hs.nvalid > 0 && emax > 0.0) {
                 const double nbd = std::ceil(std::log(emax) / std::log(2.0) * 3.0 + 1.0);     // callers.py:30
-                numbin = nbd < 0 ? 0 : (nbd > HPK_NB ? HPK_NB : (int)nbd);
+                numbin = !(nbd >= 0) ? 0 : (nbd > HPK_NB ? HPK_NB : (int)nbd);
             }
             hs.numbin = numbin;
             hs.chunk_tests = box->fam.data() + (size_t)t * (HPK_NB + 1);

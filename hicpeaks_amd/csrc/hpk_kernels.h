@@ -104,7 +104,7 @@ struct HpkBandDesc {
     int64_t cap;                        // survivor capacity per region (multiple of 256)
     uint64_t zero_bytes;                // bytes of `small` the table kernel zero-fills (multiple of 16)
     uint32_t off_rowlive, off_inl;      // offsets of the row flags / inline survivors inside `small`
-    int32_t derive;                     // IR / biases are derived on the device from raw + weight
+    int32_t derive;                     // 1: IR and biases are derived on the device from raw + weight, 2: IR only, 0: given
     int32_t score_wgs;                  // scoring workgroups that take part for this band (the rest of the grid row exits)
 };
 

@@ -1637,7 +1637,7 @@ __global__ void __launch_bounds__(256) hpk_ir_final(const HpkBandDesc* __restric
     const int n = bd->n, num = bd->num;
     if ((int)blockIdx.x >= nirb) {
         const int i = ((int)blockIdx.x - nirb) * 256 + threadIdx.x;
-        if (i < n) {
+        if (i < n && bd->derive == 1) {         // (derive == 2: the caller gave the biases, only IR is derived)
             const double w = gptr(bd->weight)[i];
             gptr(bd->b1)[i] = (w == 0.0 || w != w) ? 0.0 : 1.0 / w;
         }
@@ -2216,7 +2216,8 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                     if (vm != 0ull) {
                         // Emax of the set: E > 0, so its bit pattern orders like its value (E = 0: never above).  The
                         // block's running maximum settles after a few batches; only lanes that beat it touch the LDS atomic.
-                        const unsigned long long ebits = (unsigned long long)__double_as_longlong(E);
+                        // (a negative E - negative balanced values - is not valid and must not enter: its sign bit would win)
+                        const unsigned long long ebits = valid ? (unsigned long long)__double_as_longlong(E) : 0ull;
                         const bool beats = ebits > lemax[set];
                         if (__ballot(beats) != 0ull) { if (beats) atomicMax(&lemax[set], ebits); }
                         // tests per family; family 0 of a set collects its valid pixels without a chunk (the host adds the

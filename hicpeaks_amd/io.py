@@ -1,5 +1,5 @@
-"""Band sources for the command lines: a cooler file (when the `cooler` package is importable) or a band archive
-(.npz) - the latter is what tests, benchmarks and machines without cooler / h5py use.
+"""Band sources for the command lines: a cooler file (through the `cooler` package when it is importable, else through
+hicpeaks_amd/cool.py on h5py or libhdf5) or a band archive (.npz).
 
 Counterpart of the data access in scripts/pyHICCUPS:142-166: instead of two sparse matrices per chromosome and
 `num` calls of `H.diagonal(i)`, a source hands over the dense upper band of raw counts and the balancing weights;
@@ -21,7 +21,7 @@ class BandSource(object):
         raise NotImplementedError
 
     def fetch(self, chrom, num, weight_name='weight'):
-        """-> (raw f32 [n, num], weight f64 [n])"""
+        """-> (raw f32 [n, num], weight f64 [n], biases f64 [n] or None: see CoolerSource)"""
         raise NotImplementedError
 
 
@@ -72,11 +72,11 @@ class NpzSource(BandSource):
         n = raw.shape[0]
         w = np.asarray(self.z[weight_name + '_' + chrom], dtype=np.float64)
         if raw.shape[1] == num and raw.dtype == np.float32 and raw.flags.c_contiguous:
-            return raw, w                       # stored exactly as the library wants it: no second copy
+            return raw, w, None                 # stored exactly as the library wants it: no second copy
         out = np.zeros((n, num), dtype=np.float32)
         k = min(num, raw.shape[1])
         out[:, :k] = raw[:, :k]
-        return out, w
+        return out, w, None
 
 
 def save_band_archive(path, res, bands, compressed=True):
@@ -89,26 +89,55 @@ def save_band_archive(path, res, bands, compressed=True):
 
 
 class CoolerSource(BandSource):
-    """cooler URI (scripts/pyHICCUPS:178-179).  Needs the `cooler` package."""
+    """cooler URI (scripts/pyHICCUPS:178-179): through the `cooler` package when it is importable, otherwise through the
+    package's own reader of the format (hicpeaks_amd/cool.py: h5py or libhdf5).
+
+    Balancing (scripts/pyHICCUPS:143 `Lib.matrix(balance=<column>)`): balanced = count * w[bin1] * w[bin2]; for a
+    *divisive* column (cooler: 'KR', 'VC', 'VC_SQRT', or the column's divisive_weights attribute) count / (w[bin1] *
+    w[bin2]) - `fetch` then hands over 1 / column as the weights, and, as third value, the biases the reference forms
+    from the column as stored (1 / column, 0 where it is 0 / NaN: scripts/pyHICCUPS:163-166 does not know about
+    divisive columns), so that the corrected expected comes out as the reference's does."""
 
     def __init__(self, uri):
-        import cooler  # noqa: deferred, optional dependency
-        self.clr = cooler.Cooler(uri)
-        self.binsize = self.clr.binsize
-        self.chromnames = list(self.clr.chromnames)
+        self.clr = None
+        try:
+            import cooler  # noqa: optional dependency
+            self.clr = cooler.Cooler(uri)
+            self.binsize = self.clr.binsize
+            self.chromnames = list(self.clr.chromnames)
+        except ImportError:
+            from . import cool
+            self.f = cool.CoolFile(uri)
+            self.binsize = self.f.binsize
+            self.chromnames = list(self.f.chromnames)
 
     def nbins(self, chrom):
-        lo, hi = self.clr.extent(chrom)
+        lo, hi = self.clr.extent(chrom) if self.clr is not None else self.f.extent(chrom)
         return hi - lo
 
     def fetch(self, chrom, num, weight_name='weight'):
-        lo, hi = self.clr.extent(chrom)
-        px = self.clr.matrix(balance=False, as_pixels=True, join=False).fetch(chrom)
-        i = px['bin1_id'].values - lo
-        j = px['bin2_id'].values - lo
-        raw = _band.band_from_coo(i, j, px['count'].values, hi - lo, num, dtype=np.float32)
-        w = self.clr.bins().fetch(chrom)[weight_name].values.astype(np.float64)
-        return raw, w
+        """-> (raw f32 [n, num], weight f64 [n], biases f64 [n] or None)"""
+        if self.clr is not None:
+            from . import cool
+            lo, hi = self.clr.extent(chrom)
+            px = self.clr.matrix(balance=False, as_pixels=True, join=False).fetch(chrom)
+            i, j, cnt = px['bin1_id'].values - lo, px['bin2_id'].values - lo, px['count'].values
+            col = self.clr.bins().fetch(chrom)[weight_name]
+            w = col.values.astype(np.float64)
+            divisive = weight_name in cool.DIVISIVE_NAMES
+        else:
+            lo, hi = self.f.extent(chrom)
+            i, j, cnt = self.f.pixels(chrom)
+            w, divisive = self.f.weights(chrom, weight_name)
+        raw = _band.band_from_coo(i, j, cnt, hi - lo, num, dtype=np.float32)
+        if not divisive:
+            return raw, w, None
+        with np.errstate(divide='ignore', invalid='ignore'):
+            ok = ~((w == 0) | np.isnan(w))
+            biases = np.zeros_like(w)
+            biases[ok] = 1.0 / w[ok]                    # scripts/pyHICCUPS:163-166 on the column as stored
+            wm = np.where(ok, 1.0 / np.where(ok, w, 1.0), np.nan)       # count / (w1 w2) as a product; masked bins stay NaN
+        return raw, wm, biases
 
 
 def open_source(path):
@@ -116,6 +145,6 @@ def open_source(path):
         return NpzSource(path)
     try:
         return CoolerSource(path)
-    except ImportError:
-        raise SystemExit('reading %s needs the `cooler` package (not installed); band archives (.npz, see '
-                         'hicpeaks_amd.io.save_band_archive) work without it' % path)
+    except ImportError as e:
+        raise SystemExit('reading %s needs the `cooler` package, h5py or libhdf5 (%s); band archives (.npz, see '
+                         'hicpeaks_amd.io.save_band_archive) work without them' % (path, e))

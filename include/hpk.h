@@ -100,7 +100,9 @@ typedef struct {
     const double* bias2;       /* [n] B2 */
                                /* IR = bias1 = bias2 = NULL (needs `weight`): the library derives them on the device the
                                   way scripts/pyHICCUPS:149-166 does - IR[d] = mean of the balanced diagonal with stored
-                                  pixels of masked bins left out, biases = 1 / weight (0 where the weight is 0 / NaN) */
+                                  pixels of masked bins left out, biases = 1 / weight (0 where the weight is 0 / NaN).
+                                  IR = NULL with bias1 / bias2 given: only IR is derived (a divisive weight column: the
+                                  caller hands over weight = 1 / column and the biases the reference forms from the column) */
     int32_t on_device;         /* non-zero: all pointers above are device pointers on the ctx's device */
     int32_t reserved;
 } hpk_band;

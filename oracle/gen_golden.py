@@ -486,6 +486,11 @@ def main():
     cases.append(('hiccups_wide_p4w7', 'hiccups', g, P(pw=[4], ww=[7], maxapart=3000000), None, None))
     g = dict(n=260, num=41, depth=5.0, nloops=0, seed=35, nan_frac=0.0)
     cases.append(('hiccups_E_on_boundary', 'hiccups', g, P(pw=[2], ww=[5], maxapart=300000), None, ones_with_a_block))
+    # ---- round 3: a contig shorter than the band (n < num): the reference's worker() fails before hiccups() is reached,
+    # `sparse.diags(Diags, ...)` refuses offsets beyond the matrix (scripts/pyHICCUPS:148) - the golden
+    # outcome is that exception
+    g = dict(n=45, num=61, depth=60.0, nloops=1, seed=41, loop_dist=(10, 20))
+    cases.append(('hiccups_short_contig', 'hiccups', g, P(pw=[2], ww=[5], maxapart=500000), None, None))
     for c in cases:
         if only and c[0] not in only:
             continue

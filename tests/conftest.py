@@ -15,6 +15,7 @@ GOLDEN_DIR = os.path.join(REPO, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'slow: minutes of host time and ~10 GB of host memory (skipped unless HPK_SLOW=1)')
 
 
 @pytest.fixture(scope='session', autouse=True)

@@ -74,7 +74,8 @@ class _FakeCooler(object):
         self._px = pd.concat(frames, ignore_index=True)
         self._bins = pd.DataFrame({'chrom': np.repeat(self.chromnames, [180, 130]),
                                    'weight': np.r_[self._w['chr1'], self._w['chr2']],
-                                   'KR': np.r_[self._w['chr1'], self._w['chr2']] * 2.0})
+                                   'w2': np.r_[self._w['chr1'], self._w['chr2']] * 2.0,
+                                   'KR': 1.0 / np.r_[self._w['chr1'], self._w['chr2']]})
 
     def extent(self, chrom):
         return self._lo[chrom], self._lo[chrom] + self._n[chrom]
@@ -103,12 +104,22 @@ def test_cooler_source_against_a_fake_cooler(monkeypatch):
     assert isinstance(src, io.CoolerSource) and src.binsize == 10000 and src.chromnames == ['chr1', 'chr2']
     assert src.nbins('chr2') == 130
     for c in src.chromnames:
-        raw, w = src.fetch(c, 31)
-        assert raw.dtype == np.float32 and raw.shape == (src.nbins(c), 31)
+        raw, w, b = src.fetch(c, 31)
+        assert b is None and raw.dtype == np.float32 and raw.shape == (src.nbins(c), 31)
         np.testing.assert_array_equal(raw, src.clr._bands[c][:, :31])         # diagonals beyond num are dropped
         np.testing.assert_array_equal(w, src.clr._w[c])
-        raw50, _ = src.fetch(c, 50)                                           # wider than what is stored: zeros
+        raw50, _, _ = src.fetch(c, 50)                                         # wider than what is stored: zeros
         assert not raw50[:, 41:].any()
         np.testing.assert_array_equal(raw50[:, :41], src.clr._bands[c])
-    _, wkr = src.fetch('chr1', 31, weight_name='KR')
-    np.testing.assert_array_equal(wkr, src.clr._w['chr1'] * 2.0)
+    _, w2, b2 = src.fetch('chr1', 31, weight_name='w2')
+    np.testing.assert_array_equal(w2, src.clr._w['chr1'] * 2.0)
+    assert b2 is None
+    # a divisive column (cooler: balanced = count / (KR1 KR2)): 1 / column as the weights, and the biases the reference
+    # forms from the column as stored (scripts/pyHICCUPS:163-166)
+    _, wkr, bkr = src.fetch('chr1', 31, weight_name='KR')
+    kr = 1.0 / src.clr._w['chr1']
+    ok = ~np.isnan(kr)
+    np.testing.assert_array_equal(np.isnan(wkr), ~ok)
+    np.testing.assert_array_equal(wkr[ok], 1.0 / kr[ok])
+    np.testing.assert_array_equal(bkr[ok], 1.0 / kr[ok])
+    assert np.all(bkr[~ok] == 0)

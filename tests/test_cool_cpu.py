@@ -1,0 +1,107 @@
+"""The cooler-reading half of scripts/pyHICCUPS:142-166 on a real cooler-format file (HDF5, schema version 3:
+tests/golden/tiny.cool, written by scripts/make_cool.py with h5py - gzip-compressed chunked data sets, bins/chrom as an
+HDF5 enum, fixed-length ASCII names, a NaN-masked weight column and a divisive 'KR' column, trans pixels between the
+chromosomes).  The `cooler` package is not installed in this image; the file goes through the package's own reader
+(hicpeaks_amd/cool.py on libhdf5 or h5py).  What is pinned: the band, the weights and - with the reference's own rule -
+IR / cDiags / biases of every chromosome equal what worker() builds from `Lib.matrix(...).fetch(key)`."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REPO, GOLDEN_DIR
+from hicpeaks_amd import band as hband, io, synthetic
+from oracle import hiccups_oracle as orc
+
+COOL = os.path.join(GOLDEN_DIR, 'tiny.cool')
+CHROMS = [('chrA', 400), ('chrB', 57), ('chrC', 260)]          # scripts/make_cool.py
+NUM = 61
+
+
+def _reader_available():
+    try:
+        from hicpeaks_amd import cool
+        cool.CoolFile(COOL).close()
+        return True
+    except ImportError:
+        return False
+
+
+pytestmark = pytest.mark.skipif(not _reader_available(), reason='neither h5py nor libhdf5 here')
+
+
+def _expected(i, n):
+    raw, w, _ = synthetic.synth_band(n, NUM, depth=40.0, nloops=max(1, n // 40), seed=50 + i,
+                                     loop_dist=(10, min(NUM - 15, max(n - 8, 12))))
+    rr = np.arange(n)[:, None]
+    raw[(rr + np.arange(NUM)[None, :]) >= n] = 0
+    return raw, w
+
+
+def test_cooler_file_through_the_own_reader():
+    src = io.open_source(COOL)
+    assert isinstance(src, io.CoolerSource) and src.clr is None           # no cooler package: hicpeaks_amd.cool
+    assert src.binsize == 10000 and src.chromnames == [c for c, _ in CHROMS]
+    for i, (c, n) in enumerate(CHROMS):
+        assert src.nbins(c) == n
+        want_raw, want_w = _expected(i, n)
+        raw, w, b = src.fetch(c, NUM)
+        assert b is None and raw.dtype == np.float32 and raw.shape == (n, NUM)
+        np.testing.assert_array_equal(raw, want_raw)                      # trans pixels are not part of the chromosome
+        np.testing.assert_array_equal(w, want_w)                          # NaN = masked bins, bit for bit
+        assert np.isnan(w).sum() == np.isnan(want_w).sum() > 0
+        narrow, _, _ = src.fetch(c, 31)                                   # a narrower band: diagonals beyond it are dropped
+        np.testing.assert_array_equal(narrow, want_raw[:, :31])
+
+
+@pytest.mark.parametrize('ci', [0, 2])
+def test_prep_from_the_cooler_equals_the_reference_rule(ci):
+    """IR[d] with the NaN-denominator rule, cDiags (NaN -> 0) and biases (scripts/pyHICCUPS:149-166, restated by the oracle
+    and pinned to the reference by the fixtures) from what the reader hands over."""
+    c, n = CHROMS[ci]
+    src = io.open_source(COOL)
+    raw, w, _ = src.fetch(c, NUM)
+    for mw in (3, 5):
+        IR, cband, biases = orc.prep_from_band(raw.astype(np.int64), w, mw)
+        IRh, bh = hband.expected_and_biases(raw, w, mw)
+        np.testing.assert_allclose(IRh, IR, rtol=1e-13, atol=0)
+        np.testing.assert_array_equal(bh, biases)
+        np.testing.assert_array_equal(synthetic.balanced_band(raw.astype(np.int64), w, mw), cband)
+        assert (biases == 0).sum() == np.isnan(w).sum()
+
+
+def test_divisive_weight_column():
+    """'KR' holds 1 / weight with divisive_weights = True: the balanced values are the multiplicative column's (count /
+    (KR1 KR2) = count w1 w2), while the biases are what the reference forms from the column as stored (1 / KR)."""
+    src = io.open_source(COOL)
+    for c, n in CHROMS:
+        raw, w, b = src.fetch(c, NUM)
+        raw2, wkr, bkr = src.fetch(c, NUM, weight_name='KR')
+        np.testing.assert_array_equal(raw2, raw)
+        ok = ~np.isnan(w)
+        np.testing.assert_array_equal(np.isnan(wkr), ~ok)
+        np.testing.assert_allclose(wkr[ok], w[ok], rtol=4e-16, atol=0)     # 1 / (1 / w)
+        np.testing.assert_allclose(bkr[ok], w[ok], rtol=4e-16, atol=0)     # 1 / KR, as scripts/pyHICCUPS:163-166 would
+        assert np.all(bkr[~ok] == 0)
+        np.testing.assert_allclose(synthetic.balanced_band(raw.astype(np.int64), wkr, 5),
+                                   synthetic.balanced_band(raw.astype(np.int64), w, 5), rtol=1e-15, atol=0)
+
+
+def test_mcool_uri_and_errors(tmp_path):
+    from hicpeaks_amd import cool
+    assert cool.parse_uri('a.mcool::/resolutions/5000') == ('a.mcool', '/resolutions/5000')
+    assert cool.parse_uri('a.mcool::resolutions/5000') == ('a.mcool', '/resolutions/5000')
+    assert cool.parse_uri('b.cool') == ('b.cool', '/')
+    with pytest.raises(IOError):
+        cool.CoolFile(str(tmp_path / 'missing.cool'))
+    with pytest.raises(IOError):
+        cool.CoolFile(COOL + '::/resolutions/5000')                      # no such group
+    f = cool.CoolFile(COOL)
+    with pytest.raises(KeyError):
+        f.weights('chrA', 'no_such_column')
+    # pixel table of the short chromosome: bins relative to its first bin, upper triangle, sorted by (bin1, bin2)
+    b1, b2, cnt = f.pixels('chrB')
+    assert b1.min() >= 0 and b2.max() < 57 and np.all(b2 >= b1) and np.all(cnt > 0)
+    assert np.all(np.diff(b1 * 1000 + b2) > 0)
+    f.close()

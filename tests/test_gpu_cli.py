@@ -88,3 +88,46 @@ def test_pyhiccups_cli_several_chromosomes_one_ahead(tmp_path):
     for name, g in (('chr1', ga), ('chr2', gb), ('chr3', ga)):
         want = sorted(l.replace('chrT', name) for l in g.meta['lines'].splitlines())
         _numeric_equal(sorted(l for l in got if l.startswith(name + '\t')), want)
+
+
+def test_pyhiccups_cli_reads_a_cooler_file(tmp_path):
+    """`-p file.cool` (scripts/pyHICCUPS:178-179): the cooler-format fixture through the package's own reader, every
+    chromosome (one of them shorter than the band) - the text equals what the same bands give as a band archive; with the
+    divisive 'KR' column the balanced band is the same and the biases are the reference's 1 / column."""
+    import os
+    from conftest import GOLDEN_DIR
+    from hicpeaks_amd import callers, band as hband
+    cool = os.path.join(GOLDEN_DIR, 'tiny.cool')
+    try:
+        src = io.open_source(cool)
+    except SystemExit:
+        pytest.skip('neither h5py nor libhdf5 here')
+    num = 500000 // 10000 + 10 + 1
+    bands = {c: src.fetch(c, num)[:2] for c in src.chromnames}
+    arc = str(tmp_path / 'same.npz')
+    io.save_band_archive(arc, 10000, bands)
+    outs = {}
+    for tag, path in (('cool', cool), ('npz', arc)):
+        out = str(tmp_path / (tag + '.bedpe'))
+        argv = ['-O', out, '-p', path, '-C', 'A', 'B', 'C', '--pw', '2', '--ww', '5', '--maxapart', '500000', '--siglevel', '0.1',
+                '--logFile', str(tmp_path / 'log.txt')]
+        assert cli.main_hiccups(argv) == 0
+        outs[tag] = open(out).read()
+    assert outs['cool'] == outs['npz'] and len(outs['cool'].splitlines()) >= 3
+    assert [l.split('\t')[0] for l in outs['cool'].splitlines()] == sorted(l.split('\t')[0] for l in outs['cool'].splitlines())
+    # the divisive column: IR derived on the device from 1 / KR, biases given (1 / KR as stored) == everything given
+    raw, wkr, bkr = src.fetch('chrA', num, weight_name='KR')
+    assert bkr is not None
+    from hicpeaks_amd import _lib
+    ctx = _lib.default_context(0)
+    prm = _lib.make_params(_lib.MODE_HICCUPS, [2], [5], 10, 0.1, 500000, 10000, 16, 0)
+    IR, _ = hband.expected_and_biases(raw, wkr, 5)
+    want = ctx.score_host(raw, IR, bkr, bkr, prm, weight=wkr)
+    got = ctx.submit_batch_host([dict(raw=raw, weight=wkr, bias1=bkr, bias2=bkr)], prm).results()[0]
+    assert got.ncand == want.ncand and got.steps == want.steps
+    for sg, sw in zip(got.sets, want.sets):
+        assert sg['nvalid'] == sw['nvalid'] > 1000
+        np.testing.assert_allclose(sg['emax'], sw['emax'], rtol=1e-12)
+        np.testing.assert_array_equal(sg['x'], sw['x'])
+    # (with biases = 1 / KR = w the corrected expected is w^2-small: the reference's rule for a divisive column, as coded)
+    assert want.sets[0]['emax'] < 1.0

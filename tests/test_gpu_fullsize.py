@@ -203,19 +203,27 @@ def _check_against_oracle(R, final, det, want, pw, ww, sig):
         tests = np.bincount(o['chunk'], minlength=s['chunk_tests'].size)
         np.testing.assert_array_equal(s['chunk_tests'][1:], tests[1:s['chunk_tests'].size])
         nsig += s['x'].size
-    assert nsig > 500
+    assert nsig > 100
     # gap rows and the final table (after gap filter, donut / lower-left combination, clustering)
     np.testing.assert_array_equal(R.gap, np.isin(np.arange(R.gap.size), sorted(det['gaps'])))
     k, v = _arrays(final)
     kw, vw = _arrays(want)
     np.testing.assert_array_equal(k, kw)
     np.testing.assert_allclose(v, vw, rtol=1e-9, atol=1e-9)
-    assert len(want) > 20
+    assert len(want) >= 10
 
 
-@pytest.mark.parametrize('name', sorted(FULL))
+# BASELINE configs[3]'s largest chromosome, chr1 @5 kb, (4,7), 10 Mb band (n = 49 792, num = 2011): the oracle needs ~10 GB
+# of host memory and 1-4 minutes of a core - run with HPK_SLOW=1 (scripts/gpu_slow_tests.sh, profiles/r03_slow_tests.txt)
+SLOW = {'chr1_5kb_p4w7': dict(n=49792, res=5000, maxapart=10000000, pw=[4], ww=[7], depth=25.0, nloops=800, seed=0)}
+
+
+@pytest.mark.parametrize('name', sorted(FULL) + [pytest.param(k, marks=pytest.mark.slow) for k in sorted(SLOW)])
 def test_full_size_chr1_vs_oracle(name, ctx):
-    cfg = FULL[name]
+    import os
+    if name in SLOW and not os.environ.get('HPK_SLOW'):
+        pytest.skip('slow: set HPK_SLOW=1')
+    cfg = FULL.get(name) or SLOW[name]
     n, res, maxww, sig = cfg['n'], cfg['res'], 10, 0.05
     pw, ww = cfg['pw'], cfg['ww']
     num = cfg['maxapart'] // res + maxww + 1
@@ -229,7 +237,7 @@ def test_full_size_chr1_vs_oracle(name, ctx):
     # (i) one call, IR / biases given, weights on the chip
     d1 = {}
     final = callers.hiccups_band(rawf, IR, biases, biases, chrom='1', weight=weight, ctx=ctx, detail=d1, **kw)
-    assert d1['result'].stencil_kernel == 2 and d1['result'].tiles == -(-n // 59) * 6
+    assert d1['result'].stencil_kernel == 2 and d1['result'].tiles == -(-n // 59) * -(-(59 + cfg['maxapart'] // res - min(ww)) // 107)
     _check_against_oracle(d1['result'], final, det, want, pw, ww, sig)
     # (ii) the same chromosome between two others in one batch, IR / biases derived on the device
     prm = _lib.make_params(_lib.MODE_HICCUPS, pw, ww, maxww, sig, cfg['maxapart'], res, 16, 0)

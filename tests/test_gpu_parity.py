@@ -591,3 +591,82 @@ def test_record_bound_from_the_previous_chromosome():
         assert o.record_bound == maxww and not o.redone
     finally:
         c.close()
+
+
+def test_contig_shorter_than_the_band(ctx):
+    """Fixture hiccups_short_contig (n = 45 bins, 61 stored diagonals): the reference never reaches hiccups() - its
+    worker() fails in sparse.diags (scripts/pyHICCUPS:148; the fixture records the ValueError).  The band-level entry
+    points have no such step and score the contig: widening log, survivors and final table equal the oracle's on the
+    same band arrays (IR = 0 on diagonals beyond the matrix), from host IR / biases and from the device-derived ones."""
+    from hicpeaks_amd import band as hband, synthetic
+    g = load_golden('hiccups_short_contig')
+    assert g.meta['prep_exception'] == 'ValueError'
+    p = g.params
+    raw = g['raw']
+    n, num = raw.shape
+    assert n < num
+    mw = min(p['ww'])
+    IR, biases = hband.expected_and_biases(raw, g['weight'], mw)
+    cband = synthetic.balanced_band(raw, g['weight'], mw)
+    kw = dict(pw=p['pw'], ww=p['ww'], maxww=p['maxww'], sig=p['sig'], sumq=p['sumq'], double_fold=p['double_fold'],
+              single_fold=p['single_fold'], maxapart=p['maxapart'], res=p['res'], use_raw=p['use_raw'],
+              min_marginal_peaks=p['min_marginal_peaks'], onlyanchor=p['onlyanchor'], min_local_reads=p['min_local_reads'])
+    det = {}
+    want = orc.hiccups(raw, cband, biases, biases, IR, n, num, detail=det, **kw)
+    for given in (True, False):
+        d = {}
+        got = callers.hiccups_band(raw.astype(np.float32), IR if given else None, biases if given else None,
+                                   biases if given else None, chrom='T', weight=g['weight'], ctx=ctx, detail=d, **kw)
+        R = d['result']
+        assert R.ncand == det['loc']['vx'].size and R.frozen_w == det['loc']['frozen_w']
+        assert [(a, b, c) for a, b, c, ex in R.steps if ex] == [tuple(int(v) for v in s) for s in det['loc']['steps']]
+        for s, o in zip(R.sets, det['sets']):
+            _check_set(s, o['vx'], o['vy'], o['E'], o['O'], o['p'], o['q'], p['sig'])
+        k, v = _table_arrays(got)
+        kw_, vw = _table_arrays(want)
+        np.testing.assert_array_equal(k, kw_)
+        if k.size:
+            np.testing.assert_allclose(v, vw, rtol=1e-9, atol=1e-9)
+
+
+def test_negative_balanced_values_are_kept(ctx):
+    """A negative balancing weight (unphysical for ICE / KR, but `hiccups()` accepts arbitrary cDiags): the reference adds
+    the products as they are (hicpeaks/callers.py:78), and so do both stencil kernels - sums, resolving widths and the
+    final table equal the oracle's, in weight mode and with the f64 band handed over."""
+    from hicpeaks_amd import synthetic
+    n, res, maxapart, maxww = 900, 10000, 1500000, 10
+    num = maxapart // res + maxww + 1
+    raw, weight, _ = synthetic.synth_band(n, num, depth=40.0, nloops=15, seed=17)
+    ok = np.where(~np.isnan(weight))[0]
+    weight[ok[np.argmin(np.abs(ok - 300))]] *= -1.0
+    weight[ok[np.argmin(np.abs(ok - 640))]] *= -0.5
+    for pw, ww in (([2], [5]), ([1, 2, 4], [3, 5, 7])):
+        mw = min(ww)
+        IR, cband, biases = orc.prep_from_band(raw, weight, mw)
+        assert (cband < 0).sum() > 200
+        loc = orc.hiccups_local_sums(raw, cband, IR, n, num, pw, ww, maxww, maxapart, res, 16)
+        want = orc.hiccups(raw, cband, biases, biases, IR, n, num, pw=pw, ww=ww, maxww=maxww, sig=0.1, maxapart=maxapart,
+                           res=res, min_local_reads=16, min_marginal_peaks=2, onlyanchor=False)
+        for mode in ('weight', 'balanced'):
+            detail = dict(dense=True)
+            kw = dict(balanced=cband) if mode == 'balanced' else dict(weight=weight)
+            got = callers.hiccups_band(raw.astype(np.float32), IR, biases, biases, chrom='T', pw=pw, ww=ww, maxww=maxww,
+                                       sig=0.1, maxapart=maxapart, res=res, min_local_reads=16, min_marginal_peaks=2,
+                                       onlyanchor=False, ctx=ctx, detail=detail, **kw)
+            R = detail['result']
+            vx, vy = loc['vx'], loc['vy']
+            for slot, pi in enumerate(R.slot_pi):
+                w = R.dense_w[slot][vx, vy - vx].astype(np.int64)
+                w = np.where(w > R.frozen_w, 0, w)
+                np.testing.assert_array_equal(w, loc['wres'][pi])
+                sums = R.dense_sums[slot][vx, vy - vx]
+                res_ = w > 0
+                for col, (fl, arr) in enumerate([('K', 'bSV'), ('K', 'bEV'), ('Y', 'bSV'), ('Y', 'bEV')]):
+                    ref = loc[arr][pi][fl][res_]
+                    # (sums of mixed signs: the tolerance is relative to the window's magnitudes, not to a sum that cancels)
+                    np.testing.assert_allclose(sums[res_, col], ref, rtol=1e-10, atol=1e-12 * np.abs(cband).max() * 400)
+            k, v = _table_arrays(got)
+            kw_, vw = _table_arrays(want)
+            np.testing.assert_array_equal(k, kw_)
+            if k.size:
+                np.testing.assert_allclose(v, vw, rtol=1e-9, atol=1e-9)

@@ -124,7 +124,10 @@ def test_hiccups_positional_seam(name):
     np.testing.assert_array_equal(k, g['final_keys'])
     if k.size:
         np.testing.assert_allclose(v, g['final_vals'], rtol=1e-9, atol=1e-9)
-    assert cli.format_hiccups('T', final, p['res'], sort=True).split() == g.meta['lines'].split() or True
+    # the text of scripts/pyHICCUPS:200-210 through the positional seam: the reference's own lines (a '%.3g' field whose
+    # value sits on a rounding boundary of its third digit may differ by one unit of that digit)
+    from test_gpu_cli import _numeric_equal
+    _numeric_equal(sorted(cli.format_hiccups('T', final, p['res'], sort=True).splitlines()), sorted(g.meta['lines'].splitlines()))
 
 
 @pytest.mark.gpu
