@@ -85,7 +85,7 @@ class Result(C.Structure):
                 ('ms_h2d', C.c_float), ('ms_stencil', C.c_float), ('ms_freeze', C.c_float), ('ms_score', C.c_float),
                 ('ms_tighten', C.c_float), ('ms_gap', C.c_float), ('ms_d2h', C.c_float), ('ms_host_bh', C.c_float), ('ms_total', C.c_float),
                 ('stencil_kernel', C.c_int32), ('record_bound', C.c_int32), ('redone', C.c_int32), ('nsurv_sig', C.c_int64), ('nsurv_cut', C.c_int64),
-                ('stencil_tiles', C.c_int64), ('band_px', C.c_int64), ('batch_bands', C.c_int32), ('reserved2', C.c_int32)]
+                ('stencil_tiles', C.c_int64), ('band_px', C.c_int64), ('batch_bands', C.c_int32), ('halo_w', C.c_int32)]
 
 
 def build(force=False, quiet=True):
@@ -228,6 +228,7 @@ class BandResult(object):
         self.stencil_kernel = int(r.stencil_kernel)
         self.record_bound = int(r.record_bound)      # records for candidates resolved up to this width (255: all)
         self.redone = bool(r.redone)                 # the bound from the previous chromosome was too narrow: computed twice
+        self.halo_w = int(r.halo_w)                  # halo of the stencil tiles: maxww, or the record bound (spec_halo)
         self.batch_bands = int(r.batch_bands)        # chromosomes that shared this one's launches (kernel times are its share)
         ns = int(r.nsig)
         x, y = _arr(r.x, ns, np.int64), _arr(r.y, ns, np.int64)

@@ -92,6 +92,7 @@ struct Options {
     int spec = 1;               // record bound from the chromosomes collected before
     int spec_margin = 0;
     int spec_force = -1;
+    int spec_halo = 1;          // tiles laid out for the record bound's halo instead of maxww's (hpk_stencil_s launches)
     int risk_log2 = 12;
     int tile_order = 1;
     int gap_kernel = 0;
@@ -276,6 +277,7 @@ int hpk_create(int device, hpk_ctx** out) {
     o.rounds = std::min(4, env_int("HPK_ROUNDS", o.rounds));
     o.spec = env_int("HPK_SPEC", o.spec);
     o.spec_margin = env_int("HPK_SPEC_MARGIN", o.spec_margin);
+    o.spec_halo = env_int("HPK_SPEC_HALO", o.spec_halo);
     o.risk_log2 = env_int("HPK_RISK_LOG2", o.risk_log2);
     o.tile_order = env_int("HPK_TILE_ORDER", o.tile_order);
     o.gap_kernel = env_int("HPK_GAP_KERNEL", o.gap_kernel);
@@ -294,6 +296,7 @@ int hpk_set_option(hpk_ctx* c, const char* name, int64_t v) {
     else if (k == "surv_cap" && v >= 0) o.surv_cap = v;
     else if (k == "spec" && (v == 0 || v == 1)) o.spec = (int)v;
     else if (k == "spec_margin" && v >= 0 && v <= HPK_MAX_W) o.spec_margin = (int)v;
+    else if (k == "spec_halo" && (v == 0 || v == 1)) o.spec_halo = (int)v;
     else if (k == "spec_force" && v >= -1 && v <= HPK_MAX_W) o.spec_force = (int)v;
     else if (k == "risk_log2" && v >= 0 && v <= 60) o.risk_log2 = (int)v;
     else if (k == "tile_order" && (v == 0 || v == 1)) o.tile_order = (int)v;
@@ -421,6 +424,7 @@ struct BandSlot {
     Staged st;
     HpkBandDesc d;                      // host copy of the descriptor
     int32_t n = 0, num = 0, ntiles = 0;
+    int32_t ntiles_full = 0;            // tiles under the plan's own halo (the geometry of a chromosome computed once more)
     int64_t ld = 0, cap = 0, band_px = 0, ldo = 0;
     size_t off_rowlive = 0, off_inl = 0, head_bytes = 0, off_hacc = 0, off_tc = 0, off_cnt = 0, off_cu = 0, zero_bytes = 0;
     size_t small_off = 0, head_off = 0; // inside Lane::small / Lane::h_head
@@ -438,8 +442,8 @@ struct hpk_job {
     int lane = -1;
     hpk_params prm, key;
     std::vector<BandSlot> bands;
-    HpkStencilArgs sa;
-    HpkScoreArgs sc;
+    HpkStencilArgs sa, sa_full;         // tile geometry of the batch's launches | of a chromosome computed once more on its own
+    HpkScoreArgs sc, sc_full;
     int nsets = 0, rounds_eff = 0, gmax = 0;
     bool sums = false, dense = false, do_score = true, phases = false, simple = false, use_s = false, balf64 = false,
          time_stencil = true;
@@ -460,10 +464,12 @@ int launch_compute(hpk_ctx* c, hpk_job* j, int b0, int nbl, bool solo, bool with
     Lane& L = c->lane[j->lane];
     const HpkDevPlan& plan = L.plan_host;
     const HpkBandDesc* dd = lane_desc(L, j, b0, solo);
+    // a chromosome computed once more (its record bound was too narrow) runs under the plan's own halo and tile geometry
+    const bool full = solo && j->bands[b0].redone;
     if (with_stencil) {
         if (j->time_stencil) (void)hipEventRecord(L.ev[1], c->stream);
         if (j->use_s) {
-            HpkStencilArgs sa = j->sa;
+            HpkStencilArgs sa = full ? j->sa_full : j->sa;
             sa.nbands = nbl;
             int kall = 0;
             for (int b = b0; b < b0 + nbl; ++b) kall += j->bands[b].d.chunk;
@@ -487,7 +493,7 @@ int launch_compute(hpk_ctx* c, hpk_job* j, int b0, int nbl, bool solo, bool with
         if (j->phases) (void)hipEventRecord(L.ev[3], c->stream);
     }
     if (j->do_score) {
-        HpkScoreArgs sc = j->sc;
+        HpkScoreArgs sc = full ? j->sc_full : j->sc;
         sc.gridx = 0;           // the widest row of scoring workgroups among the bands launched (HpkBandDesc::score_wgs)
         for (int b = b0; b < b0 + nbl; ++b) sc.gridx = std::max(sc.gridx, solo ? j->gmax : j->bands[b].d.score_wgs);
         hpk_launch_score(sc, dd, nbl, plan.mode == HPK_MODE_BHFDR, c->stream);
@@ -537,11 +543,29 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     if (rc != HPK_OK) return rc;
     const HpkDevPlan& plan = L.plan_host;
     const int W = plan.W, mw = plan.mw, D = plan.D;
-    // output tile: what the halo leaves of the SAT tile, at most 4 rows per stencil wave (row slot = 2 bits of the record
-    // entry, HPK_LISTCAP ids per wave)
-    const int TR = std::min(HPK_LR - 2 * W - 1, HPK_ROWS_PER_WAVE * HPK_NWAVES), TC = HPK_LC - 2 * W - 1;
     static_assert(HPK_ROWS_PER_WAVE * (HPK_LC - 1) <= HPK_LISTCAP, "a wave's candidate list must hold its tile rows");
     if (D < mw) return fail(c, HPK_ERR_INVALID, "maxapart / res (%d) is below min(ww) (%d)", D, mw);
+    // Tile geometry under a halo of Wh widths.  Output tile: what the halo leaves of the SAT tile, at most 4 rows per
+    // stencil wave (row slot = 2 bits of the record entry, HPK_LISTCAP ids per wave).  The tiles of a row block reach the
+    // last stored diagonal D + maxww (gap rows, callers.py:238) through the last tile's right halo: with a halo below
+    // maxww the chunks themselves have to go further (Dg).
+    struct Geo { int W, Dg, TR, TC, J, tilecap; size_t upt; };
+    auto geo_of = [&](int Wh) {
+        Geo g;
+        g.W = Wh; g.Dg = D + (W - Wh);
+        g.TR = std::min(HPK_LR - 2 * Wh - 1, HPK_ROWS_PER_WAVE * HPK_NWAVES); g.TC = HPK_LC - 2 * Wh - 1;
+        g.J = (g.TR + g.Dg - mw + g.TC - 1) / g.TC;
+        g.tilecap = g.TR * g.TC;
+        g.upt = ((size_t)g.tilecap + HPK_UNIT - 1) / HPK_UNIT;          // at most ceil(tilecap / HPK_UNIT) units per tile
+        return g;
+    };
+    auto stencil_args_of = [&](const Geo& g) {
+        HpkStencilArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.W = g.W; a.mw = mw; a.D = D; a.Dg = g.Dg; a.TR = g.TR; a.TC = g.TC; a.J = g.J; a.tilecap = g.tilecap;
+        return a;
+    };
+    const Geo GF = geo_of(W);
     j->prm = *prm; j->key = key;
     j->nsets = (plan.mode == HPK_MODE_BHFDR) ? 1 : 2 * plan.npairs;
     j->sums = (prm->flags & HPK_FLAG_DENSE_SUMS) != 0;
@@ -557,10 +581,39 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         if ((bands[b].balanced != nullptr) != j->balf64)
             return fail(c, HPK_ERR_INVALID, "the bands of a batch must carry the same kind of input (all `balanced` or all `weight`)");
 
+    // ---- which candidates get a record, and the halo that goes with it.  Dense outputs and probes want every candidate;
+    // the scoring kernel needs those resolved up to the width the widening freezes at, which the chromosomes collected
+    // last with the same parameters tell within a step or so (option spec = 0: no guess, every resolved candidate;
+    // spec_margin: widths added to it).  Widths beyond that bound are then not looked at at all: the search stops at it,
+    // the resolve counts beyond it stay 0 - the freeze decision up to the bound does not read them - and the tiles carry
+    // the bound's halo instead of maxww's (larger output tiles, fewer of them; option spec_halo = 0: the plan's own).  A
+    // chromosome that does not freeze by the bound is computed once more under the plan's geometry (collect_impl).
+    int wg_all = 255;
+    if (j->do_score && !dense) {
+        wg_all = W;
+        if (opt.spec && c->hint_n > 0 && std::memcmp(&key, &c->hint_key, sizeof(key)) == 0) {
+            int hw = -1;
+            for (int i = 0; i < c->hint_n; ++i) hw = std::max(hw, c->hint_w[i]);
+            if (hw >= 0) wg_all = std::min(W, hw + opt.spec_margin);
+        }
+        if (opt.spec_force >= 0) wg_all = std::min(W, opt.spec_force);        // tests: a bound that is too narrow
+    }
+    int64_t max_ld = 0;
+    int32_t max_n = 0, max_num = 0, max_dn = 0, max_dnum = 0;
+    for (int b = 0; b < nb; ++b) {
+        max_ld = std::max<int64_t>(max_ld, bands[b].ld); max_n = std::max(max_n, bands[b].n); max_num = std::max(max_num, bands[b].num);
+    }
+    j->use_s = hpk_stencil_s_applies(stencil_args_of(GF), j->simple, max_ld, max_n);
+    Geo GS = GF;
+    if (j->use_s && opt.spec_halo && wg_all < W) {
+        const int Wh = std::min(W, std::max(std::max(wg_all, (int)plan.wmin), 4));
+        const Geo g = geo_of(Wh);
+        if (Wh < W && hpk_stencil_s_applies(stencil_args_of(g), j->simple, max_ld, max_n)) GS = g;
+    }
     // ---- geometry, sizes and offsets of every band's slices
-    const int J_ = (TR + D - mw + TC - 1) / TC;
-    const int tilecap = TR * TC;
-    const size_t upt = ((size_t)tilecap + HPK_UNIT - 1) / HPK_UNIT;           // at most ceil(tilecap / HPK_UNIT) units per tile
+    const int TR = GS.TR, TC = GS.TC, J_ = GS.J, tilecap = GS.tilecap;
+    (void)TC;
+    const size_t upt = std::max(GS.upt, GF.upt);
     const size_t etab_el = std::max<size_t>((size_t)plan.nsteps * 2 * (D + 1), 1);
     const size_t eedge_el = std::max<size_t>((size_t)2 * W * plan.nsteps * 2 * (D + 1), 1);
     const int hbins = (opt.rounds <= -2) ? hpk_score_hist_bins(j->nsets) : 0;
@@ -571,8 +624,6 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
            tot_rawel = 0, tot_hn = 0;
     std::vector<size_t> off_rec(nb), off_recS(nb), off_units(nb), off_surv(nb), off_ps(nb), off_ir(nb), off_n(nb), off_rawel(nb),
                         off_hn(nb);
-    int64_t max_ld = 0;
-    int32_t max_n = 0, max_num = 0, max_dn = 0, max_dnum = 0;
     bool any_derive = false;
     int k0 = 0;
     for (int b = 0; b < nb; ++b) {
@@ -581,6 +632,9 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         const int n = bands[b].n, num = bands[b].num;
         s.n = n; s.num = num; s.ld = bands[b].ld;
         s.ntiles = ((n + TR - 1) / TR) * J_;
+        s.ntiles_full = ((n + GF.TR - 1) / GF.TR) * GF.J;
+        const size_t tiles_max = (size_t)std::max(s.ntiles, s.ntiles_full);
+        const size_t rec_max = std::max((size_t)s.ntiles * tilecap, (size_t)s.ntiles_full * GF.tilecap);
         int64_t band_px = 0;                    // pixels with mw <= d <= D inside the matrix
         for (int d = mw; d <= std::min(D, num - 1); ++d) if (n - d > 0) band_px += n - d;
         s.band_px = band_px;
@@ -602,14 +656,14 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         s.head_bytes = s.off_inl + sizeof(HpkSurv) * HPK_HEAD_INLINE;
         s.off_hacc = up256(s.head_bytes);
         s.off_tc = up256(s.off_hacc + 8 * (size_t)(HPK_MAX_STEPS + 1) * HPK_ACC_STRIDE);
-        s.off_cnt = up256(s.off_tc + sizeof(unsigned) * (size_t)s.ntiles);
+        s.off_cnt = up256(s.off_tc + sizeof(unsigned) * tiles_max);
         s.off_cu = up256(s.off_cnt + sizeof(unsigned) * HPK_NFAM * HPK_TIGHTEN_MAX);
         s.zero_bytes = (s.off_cu + sizeof(unsigned) * (size_t)(cap / HPK_SCH * HPK_NREG + 1) + 4095) / 4096 * 4096;
         s.small_off = tot_small; tot_small += s.zero_bytes;
         s.head_off = tot_head; tot_head += up256(s.head_bytes);
-        off_rec[b] = tot_rec; tot_rec += (size_t)s.ntiles * tilecap;
-        off_recS[b] = tot_recS; tot_recS += (size_t)s.ntiles * tilecap * plan.nslots;
-        off_units[b] = tot_units; tot_units += (size_t)s.ntiles * upt + 16;
+        off_rec[b] = tot_rec; tot_rec += rec_max;
+        off_recS[b] = tot_recS; tot_recS += rec_max * plan.nslots;
+        off_units[b] = tot_units; tot_units += tiles_max * upt + 16;
         off_surv[b] = tot_surv; tot_surv += (size_t)cap * HPK_NREG;
         off_ir[b] = tot_ir; off_n[b] = tot_n;
         if (derive || !bands[b].on_device) { tot_ir += ((size_t)num + 31) / 32 * 32; tot_n += ((size_t)n + 31) / 32 * 32; }
@@ -620,7 +674,6 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         }
         off_rawel[b] = tot_rawel; off_hn[b] = tot_hn;
         if (!bands[b].on_device) { tot_rawel += (size_t)n * (size_t)s.ld; tot_hn += ((size_t)n + 31) / 32 * 32; }
-        max_ld = std::max(max_ld, s.ld); max_n = std::max(max_n, n); max_num = std::max(max_num, num);
         j->max_zero = std::max(j->max_zero, s.zero_bytes);
         j->max_head = std::max(j->max_head, s.head_bytes);
         s.ldo = ((int64_t)(D + 1) + 31) / 32 * 32;
@@ -750,19 +803,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         d.chunk_used = reinterpret_cast<unsigned*>(small + s.off_cu);
         d.cnt = reinterpret_cast<unsigned*>(small + s.off_cnt);
         d.head_host = static_cast<unsigned char*>(L.h_head) + s.head_off;
-        // Which candidates get a record.  Dense outputs and probes want every candidate; the scoring kernel needs those
-        // resolved up to the width the widening freezes at, which the chromosomes collected last with the same parameters
-        // tell within a step or so (option spec = 0: no guess, every resolved candidate; spec_margin: widths added to it).
-        d.wguess = 255;
-        if (j->do_score && !dense) {
-            d.wguess = W;
-            if (opt.spec && c->hint_n > 0 && std::memcmp(&key, &c->hint_key, sizeof(key)) == 0) {
-                int hw = -1;
-                for (int i = 0; i < c->hint_n; ++i) hw = std::max(hw, c->hint_w[i]);
-                if (hw >= 0) d.wguess = std::min(W, hw + opt.spec_margin);
-            }
-            if (opt.spec_force >= 0) d.wguess = std::min(W, opt.spec_force);        // tests: a bound that is too narrow
-        }
+        d.wguess = wg_all;
     }
     {   // descriptors: [0, nb) as the batch runs them, [nb, 2 nb) for a chromosome computed once more on its own
         HpkBandDesc* hd = static_cast<HpkBandDesc*>(L.h_desc);
@@ -771,6 +812,9 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
             hd[nb + b] = j->bands[b].d;
             hd[nb + b].k0 = 0;
             if (hd[nb + b].wguess != 255) hd[nb + b].wguess = W;
+            hd[nb + b].ntiles = j->bands[b].ntiles_full;
+            hd[nb + b].chunk = (j->bands[b].ntiles_full + 7) / 8;
+            hd[nb + b].rec_stride = (int64_t)j->bands[b].ntiles_full * GF.tilecap;
             hd[nb + b].score_wgs = j->gmax;
         }
         HIPCHK(c, hipMemcpyAsync(L.desc.p, hd, desc_bytes, hipMemcpyHostToDevice, L.up));
@@ -806,7 +850,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     sa.plan = L.plan.as<HpkDevPlan>();
     sa.risk = std::ldexp(1.0, -opt.risk_log2);
     sa.nbands = nb;
-    sa.W = W; sa.mw = mw; sa.D = D; sa.TR = TR; sa.TC = TC; sa.J = J_; sa.tilecap = tilecap;
+    sa.W = GS.W; sa.mw = mw; sa.D = D; sa.Dg = GS.Dg; sa.TR = GS.TR; sa.TC = GS.TC; sa.J = GS.J; sa.tilecap = GS.tilecap;
     sa.single = plan.single_p >= 0 ? 1 : 0;
     sa.order = opt.tile_order;
     sa.dbg_stop = opt.dbg_stop;
@@ -818,15 +862,19 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         sa.clk = c->tmpD.as<unsigned long long>();
     }
 #endif
-    j->use_s = hpk_stencil_s_applies(sa, j->simple, max_ld, max_n);
+    j->sa_full = sa;
+    j->sa_full.W = GF.W; j->sa_full.Dg = GF.Dg; j->sa_full.TR = GF.TR; j->sa_full.TC = GF.TC; j->sa_full.J = GF.J;
+    j->sa_full.tilecap = GF.tilecap;
     HpkScoreArgs& sc = j->sc;
     std::memset(&sc, 0, sizeof(sc));
-    sc.tilecap = tilecap; sc.TR = TR; sc.TC = TC; sc.J = J_; sc.W = W;
+    sc.tilecap = GS.tilecap; sc.TR = GS.TR; sc.TC = GS.TC; sc.J = GS.J; sc.W = GS.W;
     sc.plan = sa.plan;
     sc.bounds = c->d_bounds.as<double>(); sc.ptab = c->d_ptab.as<double>();
     sc.ptab_off = c->d_off.as<int32_t>(); sc.sfe = c->d_sfe.as<double>(); sc.sig = prm->sig;
     sc.mw = mw; sc.D = D;
     sc.hbins = hbins; sc.nsets_half = plan.npairs;
+    j->sc_full = sc;
+    j->sc_full.tilecap = GF.tilecap; j->sc_full.TR = GF.TR; j->sc_full.TC = GF.TC; j->sc_full.J = GF.J; j->sc_full.W = GF.W;
     return launch_compute(c, j, 0, nb, false, true);
 }
 
@@ -852,6 +900,7 @@ int finish_band(hpk_ctx* c, hpk_job* j, int b) {
     const int32_t h_frozen = *reinterpret_cast<const int32_t*>(hsmall + HPK_OFF_FROZEN);
     const int32_t h_err = *reinterpret_cast<const int32_t*>(hsmall + HPK_OFF_ERR);
     R.record_bound = s.d.wguess;
+    R.halo_w = s.redone ? j->sa_full.W : j->sa.W;
     R.redone = s.redone ? 1 : 0;
     const int32_t* h_exec = reinterpret_cast<const int32_t*>(hsmall + HPK_OFF_EXEC);
     const unsigned long long h_nsurv = *reinterpret_cast<const unsigned long long*>(hsmall + HPK_OFF_NOUT);
@@ -863,7 +912,9 @@ int finish_band(hpk_ctx* c, hpk_job* j, int b) {
         R.step_pi[t] = plan.steps[t].pi;
         R.step_wi[t] = plan.steps[t].wi;
         R.step_executed[t] = h_exec[t];
-        R.step_resolved[t] = (int64_t)h_hist[t];
+        // (steps the widening never runs - beyond frozen_w, callers.py:133-134 - have no count in the reference; here they
+        // are counted only when every candidate gets a record: dense outputs, probes, HPK_FLAG_NO_SCORE)
+        R.step_resolved[t] = (h_exec[t] || s.d.wguess == 255) ? (int64_t)h_hist[t] : 0;
     }
     R.frozen_w = h_frozen;
     R.nslots = plan.nslots;
@@ -1031,6 +1082,9 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
             if (er == 0 && s.d.wguess < plan.W && fz > s.d.wguess) {
                 // the widening froze later than the bound the stencil wrote records up to: once more, with every resolved candidate
                 s.d.wguess = plan.W;
+                s.d.ntiles = s.ntiles_full; s.d.chunk = (s.ntiles_full + 7) / 8;
+                s.d.rec_stride = (int64_t)s.ntiles_full * j->sa_full.tilecap;
+                s.ntiles = s.ntiles_full;
                 s.redone = true;
                 c->spec_reruns += 1;
                 HIPCHK(c, hipMemsetAsync(s.d.small, 0, s.zero_bytes, c->stream));

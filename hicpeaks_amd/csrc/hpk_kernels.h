@@ -113,8 +113,9 @@ struct HpkStencilArgs {
     const HpkDevPlan* plan;
     double risk;                        // box sums below risk x (largest table entry of the window) are redone exactly
     int32_t nbands;
-    int32_t W, mw, D;
-    int32_t TR, TC;                     // output tile = (HPK_LR - 2W - 1) x (HPK_LC - 2W - 1)
+    int32_t W, mw, D;                   // W: halo of the tiles = widest width the search looks at (<= the plan's maxww, see Dg)
+    int32_t Dg;                         // last diagonal the tiles must cover for the gap rows: D + (maxww - W)
+    int32_t TR, TC;                     // output tile = min(HPK_LR - 2W - 1, 64) x (HPK_LC - 2W - 1)
     int32_t J;                          // column chunks per row block
     int32_t tilecap;
     int32_t grid;                       // persistent workgroups (multiple of 8, one per CU)

@@ -1127,7 +1127,9 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     const int tid = rb * a.J + cj;
     const int r0 = rb * TR;
     const int c0 = r0 + mw + cj * TC;
-    const bool empty_tile = c0 >= n || (mw + cj * TC - (TR - 1)) > a.D;       // no band pixel inside the matrix
+    // (a.Dg, not a.D: with a halo below maxww the stored diagonals beyond D - read for the gap rows only, callers.py:238 -
+    // reach further than the last candidates' tile sees)
+    const bool empty_tile = c0 >= n || (mw + cj * TC - (TR - 1)) > a.Dg;      // no stored pixel inside the matrix
     const int tn = __builtin_amdgcn_readfirstlane((int)tnext);
     const unsigned bw_next = (unsigned)__builtin_amdgcn_readfirstlane((int)bnext);
     const bool have_next = tn != -1;
@@ -1319,7 +1321,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     // without a non-zero balanced value - exact on the valid-count field
     const int tx = wave * 64 + lane;             // (not threadIdx.x: its address arithmetic would be hoisted and spilled)
     if (tx < TR && r0 + tx < n) {
-        const bool last = (cj == a.J - 1) || (c0 + TC >= n) || (mw + (cj + 1) * TC - (TR - 1)) > a.D;
+        const bool last = (cj == a.J - 1) || (c0 + TC >= n) || (mw + (cj + 1) * TC - (TR - 1)) > a.Dg;
         const int Y = tx + W + 1;
         unsigned rs = Sp[Y * LC + W] - Sp[(Y - 1) * LC + W];
         const int xe = last ? W : W + TC;        // last: nothing is taken off (the two reads below cancel)

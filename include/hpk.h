@@ -127,7 +127,8 @@ typedef struct {
     int32_t step_pi[HPK_MAX_STEPS];
     int32_t step_wi[HPK_MAX_STEPS];
     int32_t step_executed[HPK_MAX_STEPS];
-    int64_t step_resolved[HPK_MAX_STEPS];
+    int64_t step_resolved[HPK_MAX_STEPS];   /* candidates resolved at the step; 0 for steps not executed (beyond frozen_w)
+                                               unless the call asked for every candidate (dense outputs, HPK_FLAG_NO_SCORE) */
     int32_t frozen_w;
     int32_t nslots;            /* distinct peak widths */
     int32_t slot_pi[HPK_MAX_PAIRS];
@@ -169,7 +170,10 @@ typedef struct {
     int32_t batch_bands;       /* chromosomes that shared this one's kernel launches (hpk_submit_batch; 1 otherwise).  The
                                   ms_* kernel times of a batch are split over its chromosomes by band pixels: their sum over
                                   the batch is the launch's duration */
-    int32_t reserved2;
+    int32_t halo_w;            /* halo of the stencil's tiles = widest width its search looked at: maxww, or - second-generation
+                                  kernel, hpk_set_option spec_halo = 1 (default) - the record bound.  Box sums are differences of
+                                  table entries summed from the tile's corner, so two runs of one chromosome under different halos
+                                  agree to ~1e-13 relative in E / p / q (coordinates, counts and the widening log exactly) */
 } hpk_result;
 
 typedef struct hpk_ctx hpk_ctx;

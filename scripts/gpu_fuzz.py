@@ -116,7 +116,8 @@ def one_case(seed, ctx):
         finally:
             ctx.set_option('spec_force', -1)
         k2, v2 = table_arrays(again)
-        if not (np.array_equal(k2, k) and np.array_equal(v2, v)):
+        # (the bounded run's tiles carry the bound's halo: sums from other tile corners, equal to rounding)
+        if not (np.array_equal(k2, k) and np.allclose(v2, v, rtol=1e-10, atol=1e-12)):
             return 'MISMATCH-record-bound', desc, 'bound %s' % (force or 'own')
     return 'ok', desc, '%d pixels' % len(k)
 
