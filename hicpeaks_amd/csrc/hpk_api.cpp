@@ -297,7 +297,7 @@ int hpk_set_option(hpk_ctx* c, const char* name, int64_t v) {
     else if (k == "spec" && (v == 0 || v == 1)) o.spec = (int)v;
     else if (k == "spec_margin" && v >= 0 && v <= HPK_MAX_W) o.spec_margin = (int)v;
     else if (k == "spec_halo" && (v == 0 || v == 1)) o.spec_halo = (int)v;
-    else if (k == "spec_force" && v >= -1 && v <= HPK_MAX_W) o.spec_force = (int)v;
+    else if (k == "spec_force" && v >= -1 && v <= 255) o.spec_force = (int)v;     // (clamped to maxww where it is used)
     else if (k == "risk_log2" && v >= 0 && v <= 60) o.risk_log2 = (int)v;
     else if (k == "tile_order" && (v == 0 || v == 1)) o.tile_order = (int)v;
     else if (k == "gap_kernel" && (v == 0 || v == 1)) o.gap_kernel = (int)v;

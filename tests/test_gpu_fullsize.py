@@ -246,6 +246,10 @@ def test_full_size_chr1_vs_oracle(name, ctx):
              dict(raw=other.astype(np.float32), weight=ow, num=num)]
     Rs = ctx.submit_batch_host(items, prm).results()
     assert Rs[1].batch_bands == 3
+    # (the batch took its record bound from call (i), and with it the halo of its tiles: this comparison runs the
+    # bound's tile geometry - 64 x (127 - 2 halo) output tiles, search stopped at the bound - against the oracle)
+    assert Rs[1].record_bound == d1['result'].frozen_w and not Rs[1].redone
+    assert d1['result'].halo_w == maxww and Rs[1].halo_w == max(Rs[1].record_bound, min(ww), 4) < maxww
     fin2, _ = callers._finish_hiccups(Rs[1], n, '1', pw, ww, sig, 0.01, 1.75, 2, res, False, 2, False)
     _check_against_oracle(Rs[1], fin2, det, want, pw, ww, sig)
     # (the chromosome before and after it are the same band: same result)
