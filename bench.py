@@ -280,6 +280,9 @@ def main():
                     help='hand the band over as host (numpy) arrays every step: the PCIe-inclusive rate of DESIGN.md, never `value`')
     ap.add_argument('--seeds', type=int, default=3, help='bands (seeds) the passes rotate through, SURVEY 8-D2 (configurations generated on the host)')
     ap.add_argument('--stencil-only', action='store_true', help='time the stencil kernel alone (HPK_FLAG_NO_SCORE)')
+    ap.add_argument('--no-probes', action='store_true',
+                    help='skip the single-chromosome latency probes and the phase-timed launches after the timed region (profiling '
+                         'runs: every stencil launch of the process then carries a whole group)')
     ap.add_argument('--cpu-allcores-rows', type=int, default=3000,
                     help='rows per process of the all-cores CPU baseline leg (0 = skip)')
     args = ap.parse_args()
@@ -445,16 +448,18 @@ def main():
     # outside the timed region: latency of one synchronous single-chromosome call (submit + collect), then a group with
     # the per-phase events switched on (they cost ~6 us of idle GPU each, so the timed passes run without them)
     lat = []
-    for _ in range(min(5, args.steps)):
+    for _ in range(0 if args.no_probes else min(5, args.steps)):
         t1 = time.perf_counter()
         submit(False, 1).results()
         lat.append((time.perf_counter() - t1) * 1e3)
     prm = _lib.make_params(_lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], cfg['maxww'], SIG, cfg['maxapart'], cfg['res'],
                            MIN_READS, flags | _lib.FLAG_PHASE_TIMING)
-    for _ in range(2):
-        Rs = submit(True).results()
-    phases = {k: float(sum(r.timing[k] for r in Rs)) / len(Rs) for k in Rs[0].timing}       # per chromosome of a group
-    phases['total'] = float(Rs[-1].timing['total']) / len(Rs)
+    phases = {}
+    if not args.no_probes:
+        for _ in range(2):
+            Rs = submit(True).results()
+        phases = {k: float(sum(r.timing[k] for r in Rs)) / len(Rs) for k in Rs[0].timing}       # per chromosome of a group
+        phases['total'] = float(Rs[-1].timing['total']) / len(Rs)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -478,7 +483,7 @@ def main():
                        # stencil leaves their records out, bounded by the previous pass's frozen width (HPK_SPEC=0: no bound)
                        'record_bound_w': R.record_bound, 'frozen_w': R.frozen_w, 'passes_redone_in_full': nredone_timed,
                        'parallelism': 'one chromosome per GPU, no collective', 'pipeline_depth': depth,
-                       'sync_call_ms': float(np.median(lat)),
+                       'sync_call_ms': float(np.median(lat)) if lat else None,
                        'stencil_only': bool(args.stencil_only), 'host_inputs': bool(args.host_inputs), 'balanced_f64': bool(args.balanced_f64)},
             # frac: SURVEY.md §8-D3 convention, 20 B per band pixel per pair (4 B read + 2 x 8 B local expected written).  The
             # kernel writes compact records for the candidates only, so two more figures keep the books honest:

@@ -198,8 +198,12 @@ void hpk_result_free(hpk_result* res);
  * consumes the job, also on error.  HPK_ERR_BUSY: no free lane.
  * A context remembers the width at which the widening froze (callers.py:223-229) in the chromosome it collected last
  * for the same parameters, and the next submission's stencil writes candidate records up to that width only - wider
- * ones are dropped by the scoring rules anyway (callers.py:133-134).  A chromosome that freezes later is noticed at
- * collection and computed once more in full (hpk_result::redone); results never depend on the bound. */
+ * ones are dropped by the scoring rules anyway (callers.py:133-134).  With option spec_halo (default 1) the launch also
+ * stops the search for the first sufficient width at the bound and lays its tiles out for the bound's halo instead of
+ * maxww's (hpk_result::halo_w: larger output tiles, fewer of them).  A chromosome that freezes later is noticed at
+ * collection and computed once more in full, under the plan's own tiles (hpk_result::redone).  The pixels reported, their
+ * counts and the widening log never depend on the bound; E / p / q are bit-identical under spec_halo = 0 and equal to
+ * rounding (~1e-13 relative: the box sums are differences of table entries summed from other tile corners) otherwise. */
 typedef struct hpk_job hpk_job;
 int  hpk_pipeline_depth(void);
 int  hpk_submit_band(hpk_ctx* ctx, const hpk_band* band, const hpk_params* params, hpk_job** job);
@@ -209,7 +213,7 @@ int  hpk_collect(hpk_ctx* ctx, hpk_job* job, hpk_result** out);
  * per chromosome) as ONE set of kernel launches: `nbands` chromosomes scored with the same parameters - the stencil walks
  * the tiles of all of them in one persistent launch, the expected tables, the scoring, the Benjamini-Hochberg cut and the
  * copy-back are one launch each over the batch.  Results are the ones hpk_score_band gives chromosome by chromosome, bit
- * for bit.  1 <= nbands <= HPK_MAX_BATCH; all bands carry the same kind of input (all `balanced` or all `weight`); the
+ * for bit (under the same record bound, see hpk_submit_band).  1 <= nbands <= HPK_MAX_BATCH; all bands carry the same kind of input (all `balanced` or all `weight`); the
  * HPK_FLAG_DENSE_* outputs are for single chromosomes.  A batch occupies one lane (see hpk_submit_band).
  * hpk_collect_batch always consumes the job.  outs[i] receives chromosome i's result (NULL where status[i] != HPK_OK, e.g.
  * HPK_ERR_EMPTY_STEP for a chromosome on which the reference raises); errmsg, if not NULL, is [nbands][errmsg_len] chars
@@ -222,7 +226,7 @@ int  hpk_collect_batch(hpk_ctx* ctx, hpk_job* job, hpk_result** outs, int32_t* s
  * p-value histogram the cut is derived from [default], -1: a histogram pass of its own, 0..4: exact counting rounds),
  * "surv_cap" (survivor slots per region, 0 = sized from the band; tests force the overflow rerun with it), "spec" (0: no
  * record bound from earlier chromosomes), "spec_margin" (widths added to the bound), "spec_force" (>= 0: this bound;
- * tests), "risk_log2" (exact-fallback threshold 2^-x), "tile_order", "gap_kernel" (1: gap rows by the row kernel),
+ * tests), "spec_halo" (0: tiles always under maxww's halo - runs of one chromosome are then bit-identical whatever the bound), "risk_log2" (exact-fallback threshold 2^-x), "tile_order", "gap_kernel" (1: gap rows by the row kernel),
  * "score_div" (tiles per scoring workgroup of a batch), "dbg_stop" (profiling ablation).  Returns HPK_ERR_INVALID for an
  * unknown name or a value out of range. */
 int  hpk_set_option(hpk_ctx* ctx, const char* name, int64_t value);

@@ -26,21 +26,30 @@ lines = ['# rocprofv3 --pmc passes of scripts/gpu_profile_round.sh %s, mean per 
 traffic = {'_comment': 'HBM traffic per stencil launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; KiB; FETCH_SIZE '
                        'doubled per the gfx950 note in MI355X_MICROARCH.md, calibrated in profiles/r01_pmc_summary.txt); bench.py copies '
                        'the entry of the configuration it runs into roofline.traffic'}
+def group_of(name):
+    try:
+        return int(open(os.path.join(out, 'pmc_group_%s.txt' % name)).read())
+    except Exception:
+        return 1
+
+
 for cfg in ('chr1_10kb', 'chr1_10kb_union', 'chr1_5kb', 'deep_1kb'):
     vals = {}
+    G = group_of(cfg)           # chromosomes per launch of the counter passes: figures below are per chromosome
     for cnt in ('FETCH_SIZE', 'WRITE_SIZE'):
         for kern in ('hpk_stencil', 'hpk_score'):
             m = pmc_means(os.path.join(out, 'pmc_%s_%s' % (cfg, cnt)), kern)
             if cnt in m:
-                vals[(kern, cnt)] = m[cnt]
-                lines.append('%-16s %-12s %-11s n=%d mean=%.5g KiB' % (cfg, kern, cnt, m[cnt][1], m[cnt][0]))
+                vals[(kern, cnt)] = (m[cnt][0] / G, m[cnt][1])
+                lines.append('%-16s %-12s %-11s launches=%d of %d chromosomes, per chromosome %.5g KiB' % (cfg, kern, cnt, m[cnt][1], G, m[cnt][0] / G))
     if ('hpk_stencil', 'FETCH_SIZE') in vals and ('hpk_stencil', 'WRITE_SIZE') in vals:
         tb = int((2 * vals[('hpk_stencil', 'FETCH_SIZE')][0] + vals[('hpk_stencil', 'WRITE_SIZE')][0]) * 1024)
         traffic[cfg] = {'traffic_bytes': tb, 'source': 'profiles/%s_pmc_summary.txt' % tag,
-                        'note': 'hpk_stencil*, per launch: 2 x FETCH_SIZE + WRITE_SIZE'}
-        lines.append('%-16s stencil HBM traffic per launch: %.1f MB' % (cfg, tb / 1e6))
+                        'note': 'hpk_stencil*, per chromosome of a launch: 2 x FETCH_SIZE + WRITE_SIZE'}
+        lines.append('%-16s stencil HBM traffic per chromosome: %.1f MB' % (cfg, tb / 1e6))
+Gs = group_of('sq')
 for kern in ('hpk_stencil', 'hpk_score'):
-    lines.append('## %s (chr1_10kb), SQ / TCC counters' % kern)
+    lines.append('## %s (chr1_10kb), SQ / TCC counters per launch of %d chromosomes' % (kern, Gs))
     for d in sorted(glob.glob(os.path.join(out, 'pmc_sq_*/'))):
         for k, (v, n) in sorted(pmc_means(d, kern).items()):
             lines.append('%-28s n=%d mean=%.4g' % (k, n, v))

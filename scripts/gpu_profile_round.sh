@@ -2,7 +2,7 @@
 # Round profile: bench JSON lines + rocprofv3 kernel trace/stats + PMC (FETCH_SIZE / WRITE_SIZE in separate passes, per
 # configuration).  Everything lands in gpurun_out/$TAG; scripts/collect_profiles.py copies the summaries to profiles/.
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
@@ -15,14 +15,21 @@ timeout 600 python bench.py --balanced-f64 --steps 5 --warmup 1 --cpu-rows 0 2>/
 HPK_SPEC=0 timeout 600 python bench.py --cpu-rows 0 2>/dev/null | tail -1 > $OUT/bench_chr1_10kb_no_record_bound.json
 timeout 600 python bench.py --host-inputs --steps 3 --warmup 1 --batch 20 --cpu-rows 0 2>/dev/null | tail -1 > $OUT/bench_chr1_10kb_host_inputs.json
 cd /tmp && export TMPDIR=/tmp
-PB="--steps 2 --warmup 1 --batch 10 --cpu-rows 0"
+# kernel trace of the default command's launch shape: every stencil / scoring launch carries a whole group of 32
+# chromosomes (--no-probes leaves the single-chromosome probes out), so the averages are those of bench.json's kernel_ms
+PB="--steps 30 --warmup 1 --batch 64 --group 32 --cpu-rows 0 --no-probes"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o k --output-format csv -- python $R/bench.py $PB > $OUT/trace.log 2>&1
+# HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes, launches of G chromosomes (collect_profiles.py divides by G)
 for c in chr1_10kb chr1_10kb_union chr1_5kb deep_1kb; do
-  PBc="--config $c --steps 1 --warmup 1 --batch 3 --cpu-rows 0"
+  G=8; [ $c = chr1_5kb ] && G=4; [ $c = deep_1kb ] && G=1
+  echo $G > $OUT/pmc_group_$c.txt
+  PBc="--config $c --steps 1 --warmup 1 --batch $G --group $G --cpu-rows 0 --no-probes"
   for cnt in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --kernel-trace --pmc $cnt -d $OUT/pmc_${c}_$cnt -o c --output-format csv -- python $R/bench.py $PBc > $OUT/pmc_${c}_$cnt.log 2>&1
   done
 done
+PB="--steps 1 --warmup 1 --batch 8 --group 8 --cpu-rows 0 --no-probes"
+echo 8 > $OUT/pmc_group_sq.txt
 for cnt in "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA"; do
   nm=$(echo $cnt | tr ' ' '_' | cut -c1-40)
   rocprofv3 --kernel-trace --pmc $cnt -d $OUT/pmc_sq_$nm -o c --output-format csv -- python $R/bench.py $PB > $OUT/pmc_sq_$nm.log 2>&1
