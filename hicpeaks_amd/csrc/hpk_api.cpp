@@ -92,6 +92,7 @@ struct Options {
     int spec = 1;               // record bound from the chromosomes collected before
     int spec_margin = 0;
     int spec_force = -1;
+    int tr_cap = 127;           // most rows of an hpk_stencil_s output tile (A/B: 64 = the first-generation kernel's limit)
     int spec_halo = 1;          // tiles laid out for the record bound's halo instead of maxww's (hpk_stencil_s launches)
     int risk_log2 = 12;
     int tile_order = 1;
@@ -278,6 +279,7 @@ int hpk_create(int device, hpk_ctx** out) {
     o.spec = env_int("HPK_SPEC", o.spec);
     o.spec_margin = env_int("HPK_SPEC_MARGIN", o.spec_margin);
     o.spec_halo = env_int("HPK_SPEC_HALO", o.spec_halo);
+    o.tr_cap = std::max(16, std::min(127, env_int("HPK_TR_CAP", o.tr_cap)));
     o.risk_log2 = env_int("HPK_RISK_LOG2", o.risk_log2);
     o.tile_order = env_int("HPK_TILE_ORDER", o.tile_order);
     o.gap_kernel = env_int("HPK_GAP_KERNEL", o.gap_kernel);
@@ -545,15 +547,20 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     const int W = plan.W, mw = plan.mw, D = plan.D;
     static_assert(HPK_ROWS_PER_WAVE * (HPK_LC - 1) <= HPK_LISTCAP, "a wave's candidate list must hold its tile rows");
     if (D < mw) return fail(c, HPK_ERR_INVALID, "maxapart / res (%d) is below min(ww) (%d)", D, mw);
-    // Tile geometry under a halo of Wh widths.  Output tile: what the halo leaves of the SAT tile, at most 4 rows per
-    // stencil wave (row slot = 2 bits of the record entry, HPK_LISTCAP ids per wave).  The tiles of a row block reach the
+    // Tile geometry under a halo of Wh widths.  Output tile: what the halo leaves of the SAT tile - for the first-generation
+    // kernel at most 4 rows per stencil wave (HPK_LISTCAP ids per wave), for hpk_stencil_s as many rows as its tile-wide
+    // candidate list holds (HPK_TLIST entries; 7 bits of the record entry).  The tiles of a row block reach the
     // last stored diagonal D + maxww (gap rows, callers.py:238) through the last tile's right halo: with a halo below
     // maxww the chunks themselves have to go further (Dg).
     struct Geo { int W, Dg, TR, TC, J, tilecap; size_t upt; };
-    auto geo_of = [&](int Wh) {
+    // (rows beyond 64 pay on single-pair plans - chr1 @10 kb: 66 rows at a halo of 6, -4.5 % - and cost 2 % on the
+    // three-slot union plan, measured with HPK_TR_CAP)
+    const int tr_cap_s = plan.single_p >= 0 ? opt.tr_cap : std::min(opt.tr_cap, 64);
+    auto geo_of = [&](int Wh, bool for_s) {
         Geo g;
         g.W = Wh; g.Dg = D + (W - Wh);
-        g.TR = std::min(HPK_LR - 2 * Wh - 1, HPK_ROWS_PER_WAVE * HPK_NWAVES); g.TC = HPK_LC - 2 * Wh - 1;
+        g.TC = HPK_LC - 2 * Wh - 1;
+        g.TR = std::min(HPK_LR - 2 * Wh - 1, for_s ? std::min(tr_cap_s, HPK_TLIST / g.TC) : HPK_ROWS_PER_WAVE * HPK_NWAVES);
         g.J = (g.TR + g.Dg - mw + g.TC - 1) / g.TC;
         g.tilecap = g.TR * g.TC;
         g.upt = ((size_t)g.tilecap + HPK_UNIT - 1) / HPK_UNIT;          // at most ceil(tilecap / HPK_UNIT) units per tile
@@ -565,7 +572,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         a.W = g.W; a.mw = mw; a.D = D; a.Dg = g.Dg; a.TR = g.TR; a.TC = g.TC; a.J = g.J; a.tilecap = g.tilecap;
         return a;
     };
-    const Geo GF = geo_of(W);
+    Geo GF = geo_of(W, false);
     j->prm = *prm; j->key = key;
     j->nsets = (plan.mode == HPK_MODE_BHFDR) ? 1 : 2 * plan.npairs;
     j->sums = (prm->flags & HPK_FLAG_DENSE_SUMS) != 0;
@@ -604,10 +611,11 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         max_ld = std::max<int64_t>(max_ld, bands[b].ld); max_n = std::max(max_n, bands[b].n); max_num = std::max(max_num, bands[b].num);
     }
     j->use_s = hpk_stencil_s_applies(stencil_args_of(GF), j->simple, max_ld, max_n);
+    if (j->use_s) GF = geo_of(W, true);
     Geo GS = GF;
     if (j->use_s && opt.spec_halo && wg_all < W) {
         const int Wh = std::min(W, std::max(std::max(wg_all, (int)plan.wmin), 4));
-        const Geo g = geo_of(Wh);
+        const Geo g = geo_of(Wh, true);
         if (Wh < W && hpk_stencil_s_applies(stencil_args_of(g), j->simple, max_ld, max_n)) GS = g;
     }
     // ---- geometry, sizes and offsets of every band's slices

@@ -22,7 +22,10 @@
 #define HPK_NWAVES 16                   // waves per stencil workgroup (16 or 8)
 #endif
 #define HPK_ROWS_PER_WAVE (64 / HPK_NWAVES)                  // output-tile rows a wave walks in phase 3 (tile rows <= 64)
-// record entry of a candidate: x (7 bits) | y << 7 (6 bits: row of the output tile) | capped raw count << 13
+// record entry of a candidate: x (7 bits) | y << 7 (7 bits: row of the output tile) | capped raw count << 14 (<= pk_cap < 2^13)
+#define HPK_ENT_Y(e) (((e) >> 7) & 127u)
+#define HPK_ENT_CNT_SHIFT 14
+#define HPK_TLIST 7680                  // entries of hpk_stencil_s's tile-wide candidate list: TR * TC must fit
 #define HPK_LISTCAP (HPK_ROWS_PER_WAVE * 128)               // candidate ids per wave and tile
 
 // One pixel that can still end with q <= sig (40 bytes).

@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencil1Args a, const 
             const unsigned long long M = __ballot(cnd);
             if (M == 0ull) continue;
             const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(M >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M, 0u));
-            if (cnd) lst[cnt + below] = (unsigned)x | ((unsigned)(wave + NW * yi) << 7) | ((pix & PK_MASK) << 13);
+            if (cnd) lst[cnt + below] = (unsigned)x | ((unsigned)(wave + NW * yi) << 7) | ((pix & PK_MASK) << HPK_ENT_CNT_SHIFT);
             cnt += __popcll(M);
         }
     }
@@ -521,7 +521,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencil1Args a, const 
         const bool cand = kb * 64 + lane < cnt;
         const unsigned id = cand ? lst[kb * 64 + lane] : 0u;
         const int x = (int)(id & 127u);
-        const int y = (int)((id >> 7) & 63u);
+        const int y = (int)HPK_ENT_Y(id);
         if (cand && a.dbg_stop != 7) a.rec_ent[rec0 + kb * 64 + lane] = id;
         const int r = r0 + y;
         const int d = c0 + x - r;
@@ -746,7 +746,7 @@ __global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencil1Args a, const 
 //     the next tile could pass its first barrier: here the append of tile i is finished while tile i + 1 ends.
 // The code is written branch-free where the compiler would otherwise wrap every cell in its own exec-mask branch
 // (selects on the inputs instead of ifs around the arithmetic).
-#define HPK_TLIST 7680                      // tile-wide candidate list: TR * TC <= 64 * 119 entries (maxww >= 4)
+// (HPK_TLIST, hpk_kernels.h: the tile-wide candidate list holds TR * TC entries - 64 x 119 at a halo of 4, 66 x 115 at 6)
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 // a band descriptor's pointer field (global address space, see HPK_GP) as an ordinary pointer
 template <class T> __device__ __forceinline__ T* gptr(HPK_GP(T) p) { return (T*)p; }
@@ -1210,7 +1210,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             const unsigned kt = (unsigned)km | offx[e] | ((ru - 1u) & 0x80000000u);
             cdv[e] = kt < kbound;
             M[e] = ballot64(cdv[e]);
-            entv[e] = (unsigned)(xo - e) | (rc << 13);
+            entv[e] = (unsigned)(xo - e) | (rc << HPK_ENT_CNT_SHIFT);
         }
         const unsigned nrow = (unsigned)(__popcll(M[0]) + __popcll(M[1]));
         {
@@ -1342,7 +1342,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         const bool cand = i < total;
         const unsigned id = lst[cand ? i : 0];
         const int x = (int)(id & 127u);
-        const int y = (int)((id >> 7) & 63u);
+        const int y = (int)HPK_ENT_Y(id);
         const int base = (y + W + 1) * LC + W + x;
         // one round of reads: P(Y, X) of both planes, the pixel's own value, the three Reads boxes that decide most
         // candidates (p0: subtracted from all, narrowest, widest), the largest corner of the widest window
@@ -2030,7 +2030,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
     auto issue_round2 = [&](const Geo& g) {
         const bool cn = g.i0 + lane < g.cnt;
         const unsigned e = cn ? ent_b : 0u;
-        const int r = g.r0 + (int)((e >> 7) & 63u), c = g.c0 + (int)(e & 127u), d = c - r;
+        const int r = g.r0 + (int)HPK_ENT_Y(e), c = g.c0 + (int)(e & 127u), d = c - r;
         ir_b = b_IR[cn ? (unsigned)d : 0u];
         b2_b = b_b2[cn ? (unsigned)c : 0u];
         b1_b = b_b1[cn ? (unsigned)r : 0u];
@@ -2091,11 +2091,11 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                 continue;
             }
             if (!cand) ent = 0u;
-            const int r = g.r0 + (int)((ent >> 7) & 63u);
+            const int r = g.r0 + (int)HPK_ENT_Y(ent);
             const int c = g.c0 + (int)(ent & 127u);
             const int d = c - r;
-            float rawpix = (float)(ent >> 13);          // the SAT holds counts capped at HPK_PK_CAP: those are re-read
-            if (cand && (ent >> 13) >= pkcap) rawpix = gptr(kb->raw)[(int64_t)r * kb->ld + d];
+            float rawpix = (float)(ent >> HPK_ENT_CNT_SHIFT);          // the SAT holds counts capped at HPK_PK_CAP: those are re-read
+            if (cand && (ent >> HPK_ENT_CNT_SHIFT) >= pkcap) rawpix = gptr(kb->raw)[(int64_t)r * kb->ld + d];
             const double O = (double)rawpix;
             // which local-expected table serves this pixel (interior / clipped by one matrix end / both: explicit)
             const bool top = cand && r < W, right = cand && c >= b_n - W;
@@ -2468,7 +2468,7 @@ __global__ void __launch_bounds__(256) hpk_dense(HpkDenseArgs a) {
     for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
         const int64_t ri = (int64_t)tile * a.tilecap + i;
         const unsigned ent = a.rec_ent[ri];
-        const int r = r0 + (int)((ent >> 7) & 63u);
+        const int r = r0 + (int)HPK_ENT_Y(ent);
         const int c = c0 + (int)(ent & 127u);
         const int d = c - r;
         const int64_t o = (int64_t)r * a.ldo + d;
@@ -2515,7 +2515,7 @@ __global__ void __launch_bounds__(64) hpk_probe(HpkDenseArgs a, const int32_t* _
         const int cnt = (int)a.tile_cnt[tile];
         for (int i0 = 0; i0 < cnt; i0 += 64) {
             const int i = i0 + lane;
-            const bool hit = i < cnt && (a.rec_ent[(int64_t)tile * a.tilecap + i] & 0x1fffu) == key;
+            const bool hit = i < cnt && (a.rec_ent[(int64_t)tile * a.tilecap + i] & ((1u << HPK_ENT_CNT_SHIFT) - 1u)) == key;
             const unsigned long long m = __ballot(hit);
             if (m) { found = (long long)tile * a.tilecap + i0 + (__ffsll((long long)m) - 1); break; }
         }
