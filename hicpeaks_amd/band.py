@@ -17,7 +17,12 @@ def band_from_coo(i, j, v, n, num, dtype=np.float32):
     i = np.ascontiguousarray(i, dtype=np.int64)
     j = np.ascontiguousarray(j, dtype=np.int64)
     v = np.asarray(v)
-    f64 = v.dtype.kind == 'f'
+    # counts travel as int32 or, when they are floats or do not fit, as f64 (exact up to 2^53); the band itself is f32,
+    # in which counts are exact below 2^24 - the limit of the whole path (include/hpk.h), checked here on the way in
+    f64 = v.dtype.kind == 'f' or (v.size > 0 and v.dtype.itemsize >= 4 and v.dtype != np.int32 and
+                                  (int(v.max()) > 0x7fffffff or int(v.min()) < -0x80000000))
+    if v.size and float(v.max()) >= float(1 << 24):
+        raise ValueError('band_from_coo: a count of %g is beyond what the f32 band holds exactly (2^24)' % float(v.max()))
     v = np.ascontiguousarray(v, dtype=np.float64 if f64 else np.int32)
     raw = np.zeros((n, num), dtype=np.float32)
     rc = _lib.load().hpk_band_from_coo(i.ctypes.data, j.ctypes.data, v.ctypes.data, 1 if f64 else 0, i.size, n, num, num,

@@ -123,3 +123,16 @@ def test_cooler_source_against_a_fake_cooler(monkeypatch):
     np.testing.assert_array_equal(wkr[ok], 1.0 / kr[ok])
     np.testing.assert_array_equal(bkr[ok], 1.0 / kr[ok])
     assert np.all(bkr[~ok] == 0)
+
+
+def test_band_from_coo_wide_integer_counts():
+    """int64 / uint32 counts do not wrap on their way into the band; counts the f32 band cannot hold exactly
+    are refused."""
+    i = np.array([0, 1, 2]); j = np.array([1, 3, 2])
+    for dt in (np.int64, np.uint32, np.int32, np.float64):
+        raw = band.band_from_coo(i, j, np.array([5, 70000, 16777215], dtype=dt), 4, 3)
+        assert raw[0, 1] == 5 and raw[1, 2] == 70000 and raw[2, 0] == 16777215
+    with pytest.raises(ValueError):
+        band.band_from_coo(i, j, np.array([1, 2, 1 << 33], dtype=np.int64), 4, 3)
+    with pytest.raises(ValueError):
+        band.band_from_coo(i, j, np.array([1, 2, 1 << 24], dtype=np.uint32), 4, 3)
