@@ -215,9 +215,12 @@ def _arr(ptr, n, dtype):
 
 
 class BandResult(object):
-    """Host copy of one hpk_result."""
+    """Host copy of one hpk_result.  The scalars are copied at once; the arrays (`sets`, `gap`, the dense outputs) are
+    copied out of the library's result when they are first read - a caller that only wants counts and timings of a
+    chromosome (bench.py does, for all but one chromosome of a batch) does not pay ~13 numpy conversions for it.  The
+    library's result is released when both have been read, or with this object."""
 
-    def __init__(self, r, n):
+    def __init__(self, r, n, owner=None):
         self.steps = [(r.step_pi[s], r.step_wi[s], int(r.step_resolved[s]), bool(r.step_executed[s]))
                       for s in range(r.nsteps)]
         self.frozen_w = r.frozen_w
@@ -230,32 +233,66 @@ class BandResult(object):
         self.redone = bool(r.redone)                 # the bound from the previous chromosome was too narrow: computed twice
         self.halo_w = int(r.halo_w)                  # halo of the stencil tiles: maxww, or the record bound (spec_halo)
         self.batch_bands = int(r.batch_bands)        # chromosomes that shared this one's launches (kernel times are its share)
-        ns = int(r.nsig)
-        x, y = _arr(r.x, ns, np.int64), _arr(r.y, ns, np.int64)
-        O, bal, E = _arr(r.O, ns, np.float64), _arr(r.bal, ns, np.float64), _arr(r.E, ns, np.float64)
-        p, q, oz = _arr(r.p, ns, np.float64), _arr(r.q, ns, np.float64), _arr(r.other_zero, ns, np.uint8)
-        self.sets = []
-        for i in range(r.nsets):
-            s = r.sets[i]
-            sl = slice(int(s.begin), int(s.end))
-            self.sets.append(dict(pair=s.pair, fl='KY'[s.fl], nvalid=int(s.nvalid), numbin=s.numbin, emax=s.emax,
-                                  x=x[sl], y=y[sl], O=O[sl], bal=bal[sl], E=E[sl], p=p[sl], q=q[sl],
-                                  other_zero=oz[sl].astype(bool),
-                                  chunk_tests=_arr(s.chunk_tests, HPK_NB + 1, np.int64),
-                                  chunk_below=_arr(s.chunk_below, HPK_NB + 1, np.int64)))
-        self.gap = _arr(r.gap, n, np.uint8).astype(bool)
+        self.nsig = int(r.nsig)                      # pixels reported over all sets
         self.nsurv_sig, self.nsurv_cut = int(r.nsurv_sig), int(r.nsurv_cut)
         self.timing = dict(h2d=r.ms_h2d, stencil=r.ms_stencil, freeze=r.ms_freeze, score=r.ms_score, tighten=r.ms_tighten,
                            gap=r.ms_gap,
                            d2h=r.ms_d2h, host_bh=r.ms_host_bh, total=r.ms_total)
-        self.dense_E = self.dense_w = self.dense_sums = None
+        self._n = n
+        self._r = r                  # the library's result: valid until _release
+        self._owner = owner          # (lib, pointer) to free it with, or None: the caller frees it and wants everything now
+        self._sets = self._gap = None
+        self._dense = None
+        if owner is None:
+            self._materialise()
+
+    def _materialise(self):
+        if self._r is None:
+            return
+        r, n = self._r, self._n
+        ns = int(r.nsig)
+        x, y = _arr(r.x, ns, np.int64), _arr(r.y, ns, np.int64)
+        O, bal, E = _arr(r.O, ns, np.float64), _arr(r.bal, ns, np.float64), _arr(r.E, ns, np.float64)
+        p, q, oz = _arr(r.p, ns, np.float64), _arr(r.q, ns, np.float64), _arr(r.other_zero, ns, np.uint8)
+        sets = []
+        for i in range(r.nsets):
+            s = r.sets[i]
+            sl = slice(int(s.begin), int(s.end))
+            sets.append(dict(pair=s.pair, fl='KY'[s.fl], nvalid=int(s.nvalid), numbin=s.numbin, emax=s.emax,
+                             x=x[sl], y=y[sl], O=O[sl], bal=bal[sl], E=E[sl], p=p[sl], q=q[sl],
+                             other_zero=oz[sl].astype(bool),
+                             chunk_tests=_arr(s.chunk_tests, HPK_NB + 1, np.int64),
+                             chunk_below=_arr(s.chunk_below, HPK_NB + 1, np.int64)))
+        self._sets = sets
+        self._gap = _arr(r.gap, n, np.uint8).astype(bool)
+        dE = dw = dS = None
         if r.dense_E:
             ld = int(r.dense_ld)
             k = r.nslots * n * ld
-            self.dense_E = np.ctypeslib.as_array(r.dense_E, shape=(k * 2,)).reshape(r.nslots, n, ld, 2).copy()
-            self.dense_w = np.ctypeslib.as_array(r.dense_w, shape=(k,)).reshape(r.nslots, n, ld).copy()
+            dE = np.ctypeslib.as_array(r.dense_E, shape=(k * 2,)).reshape(r.nslots, n, ld, 2).copy()
+            dw = np.ctypeslib.as_array(r.dense_w, shape=(k,)).reshape(r.nslots, n, ld).copy()
             if r.dense_sums:
-                self.dense_sums = np.ctypeslib.as_array(r.dense_sums, shape=(k * 4,)).reshape(r.nslots, n, ld, 4).copy()
+                dS = np.ctypeslib.as_array(r.dense_sums, shape=(k * 4,)).reshape(r.nslots, n, ld, 4).copy()
+        self._dense = (dE, dw, dS)
+        self._release()
+
+    def _release(self):
+        r, owner = self._r, self._owner
+        self._r = self._owner = None
+        if r is not None and owner is not None:
+            owner[0].hpk_result_free(owner[1])
+
+    sets = property(lambda self: (self._materialise(), self._sets)[1])
+    gap = property(lambda self: (self._materialise(), self._gap)[1])
+    dense_E = property(lambda self: (self._materialise(), self._dense[0])[1])
+    dense_w = property(lambda self: (self._materialise(), self._dense[1])[1])
+    dense_sums = property(lambda self: (self._materialise(), self._dense[2])[1])
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
 
 
 class Job(object):
@@ -272,10 +309,7 @@ class Job(object):
         rc = self.ctx.lib.hpk_collect(self.ctx.h, h, C.byref(res))
         self._keep = None
         self.ctx._check(rc)
-        try:
-            return BandResult(res.contents, self.n)
-        finally:
-            self.ctx.lib.hpk_result_free(res)
+        return BandResult(res.contents, self.n, owner=(self.ctx.lib, res))
 
     def __del__(self):          # a dropped job still has to give its lane back
         if getattr(self, 'handle', None) is not None and getattr(self.ctx, 'h', None):
@@ -306,10 +340,8 @@ class BatchJob(object):
         res = []
         for b in range(nb):
             if status[b] == HPK_OK:
-                try:
-                    res.append(BandResult(outs[b].contents, self.ns[b]))
-                finally:
-                    self.ctx.lib.hpk_result_free(outs[b])
+                # (the pointer object is the result's own: `outs` is an array, whose elements are temporaries)
+                res.append(BandResult(outs[b].contents, self.ns[b], owner=(self.ctx.lib, C.cast(outs[b], C.POINTER(Result)))))
             else:
                 text = msg.raw[b * 512:(b + 1) * 512].split(b'\0', 1)[0].decode()
                 res.append((EmptyStepError if status[b] == ERR_EMPTY_STEP else HpkError)(status[b], text))
