@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -100,6 +102,7 @@ struct Options {
     int score_div = 8;          // tiles per scoring workgroup of a batch
     int dbg_stop = 0;
     int host_prof = 0;
+    int host_threads = 8;       // threads of a batch's host half (hpk_collect_batch), at most one per four chromosomes
 };
 
 struct hpk_ctx {
@@ -279,6 +282,7 @@ int hpk_create(int device, hpk_ctx** out) {
     o.spec = env_int("HPK_SPEC", o.spec);
     o.spec_margin = env_int("HPK_SPEC_MARGIN", o.spec_margin);
     o.spec_halo = env_int("HPK_SPEC_HALO", o.spec_halo);
+    o.host_threads = std::max(1, std::min(64, env_int("HPK_HOST_THREADS", o.host_threads)));
     o.tr_cap = std::max(16, std::min(127, env_int("HPK_TR_CAP", o.tr_cap)));
     o.risk_log2 = env_int("HPK_RISK_LOG2", o.risk_log2);
     o.tile_order = env_int("HPK_TILE_ORDER", o.tile_order);
@@ -299,6 +303,7 @@ int hpk_set_option(hpk_ctx* c, const char* name, int64_t v) {
     else if (k == "spec" && (v == 0 || v == 1)) o.spec = (int)v;
     else if (k == "spec_margin" && v >= 0 && v <= HPK_MAX_W) o.spec_margin = (int)v;
     else if (k == "spec_halo" && (v == 0 || v == 1)) o.spec_halo = (int)v;
+    else if (k == "host_threads" && v >= 1 && v <= 64) o.host_threads = (int)v;
     else if (k == "spec_force" && v >= -1 && v <= 255) o.spec_force = (int)v;     // (clamped to maxww where it is used)
     else if (k == "risk_log2" && v >= 0 && v <= 60) o.risk_log2 = (int)v;
     else if (k == "tile_order" && (v == 0 || v == 1)) o.tile_order = (int)v;
@@ -431,7 +436,7 @@ struct BandSlot {
     size_t off_rowlive = 0, off_inl = 0, head_bytes = 0, off_hacc = 0, off_tc = 0, off_cnt = 0, off_cu = 0, zero_bytes = 0;
     size_t small_off = 0, head_off = 0; // inside Lane::small / Lane::h_head
     size_t dense_elems = 0;
-    bool redone = false, overflowed = false;
+    bool redone = false, overflowed = false, finished = false;
     bool rest_fetched = false;          // the survivors beyond the inline head already sit in `rest` (overflow rerun)
     std::vector<HpkSurv> rest;
     int status = HPK_OK;
@@ -887,7 +892,8 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
 }
 
 // the host half of one band whose head has landed: widening log, lambda chunks, Benjamini-Hochberg, result arrays
-int finish_band(hpk_ctx* c, hpk_job* j, int b) {
+// (`err`: where a message goes when several chromosomes are finished at once - hpk_ctx::err is the calling thread's)
+int finish_band(hpk_ctx* c, hpk_job* j, int b, std::string* err = nullptr) {
     Lane& L = c->lane[j->lane];
     const HpkDevPlan& plan = L.plan_host;
     const hpk_params* prm = &j->prm;
@@ -936,8 +942,11 @@ int finish_band(hpk_ctx* c, hpk_job* j, int b) {
     R.gap = box->gap.data();
     if (h_err != 0 && c->opt.dbg_stop == 0) {
         const HpkDevStep& st = plan.steps[h_err - 1];
-        return fail(c, HPK_ERR_EMPTY_STEP, "step (%d,%d) entered with no unresolved candidate (of %lld); the reference raises here "
-                    "(hicpeaks/callers.py:203-208)", st.pi, st.wi, (long long)R.ncand);
+        char msg[256];
+        std::snprintf(msg, sizeof(msg), "step (%d,%d) entered with no unresolved candidate (of %lld); the reference raises here "
+                      "(hicpeaks/callers.py:203-208)", st.pi, st.wi, (long long)R.ncand);
+        if (err) { *err = msg; return HPK_ERR_EMPTY_STEP; }
+        return fail(c, HPK_ERR_EMPTY_STEP, "%s", msg);
     }
 
     const double t_d2h0 = now_ms();
@@ -1158,11 +1167,51 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
     double px_all = 0.0;
     for (const BandSlot& s : j->bands) px_all += (double)std::max<int64_t>(s.band_px, 1);
     int fz_max = -1;
+    // The host half of a chromosome (sorting its survivors, Benjamini-Hochberg, result arrays: ~0.06 ms) is independent of
+    // the others': a large batch spreads it over a few threads - the kernels of the next batch take 0.1 ms per chromosome,
+    // and the host half must stay well below that.  HIP is only called from this thread: survivors beyond the inline heads
+    // are fetched first; dense outputs belong to single chromosomes and stay serial.
+    const int nthreads = (!j->dense && nb >= 8) ? std::min(c->opt.host_threads, nb / 4) : 1;
+    if (nthreads > 1) {
+        bool fetched = false;
+        for (int b = 0; b < nb; ++b) {
+            BandSlot& s = j->bands[b];
+            if (s.status != HPK_OK || !j->do_score || s.rest_fetched) continue;
+            const unsigned char* hsmall = static_cast<const unsigned char*>(L.h_head) + s.head_off;
+            const size_t ns = (size_t)*reinterpret_cast<const unsigned long long*>(hsmall + HPK_OFF_NOUT);
+            if (ns > HPK_HEAD_INLINE) {
+                s.rest.resize(ns - HPK_HEAD_INLINE);
+                HIPCHK(c, hipMemcpyAsync(s.rest.data(), s.d.surv2, sizeof(HpkSurv) * (ns - HPK_HEAD_INLINE), hipMemcpyDeviceToHost, L.up));
+                s.rest_fetched = true;
+                fetched = true;
+            }
+        }
+        if (fetched) HIPCHK(c, hipStreamSynchronize(L.up));
+        std::atomic<int> next{0};
+        auto work = [&]() {
+            for (;;) {
+                const int b = next.fetch_add(1);
+                if (b >= nb) break;
+                BandSlot& s = j->bands[b];
+                if (s.status != HPK_OK) continue;
+                std::string msg;
+                const int rc = finish_band(c, j, b, &msg);
+                if (rc != HPK_OK) { s.status = rc; s.err = msg; }
+                else s.finished = true;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nthreads; ++t) pool.emplace_back(work);
+        work();
+        for (std::thread& t : pool) t.join();
+    }
     for (int b = 0; b < nb; ++b) {
         BandSlot& s = j->bands[b];
         if (s.status != HPK_OK) continue;
-        const int rc = finish_band(c, j, b);
-        if (rc != HPK_OK) { s.status = rc; s.err = c->err; continue; }
+        if (!s.finished) {
+            const int rc = finish_band(c, j, b);
+            if (rc != HPK_OK) { s.status = rc; s.err = c->err; continue; }
+        }
         hpk_result& R = s.box->pub;
         const float share = (float)((double)std::max<int64_t>(s.band_px, 1) / px_all);
         R.ms_stencil = ms_st * share; R.ms_h2d = ms_h2d * share; R.ms_freeze = ms_fr * share; R.ms_score = ms_sc * share;
