@@ -230,7 +230,8 @@ class BandResult(object):
         self.tiles = int(r.stencil_tiles)
         self.stencil_kernel = int(r.stencil_kernel)
         self.record_bound = int(r.record_bound)      # records for candidates resolved up to this width (255: all)
-        self.redone = bool(r.redone)                 # the bound from the previous chromosome was too narrow: computed twice
+        self.rescored = bool(r.redone & 2)           # the survivor bound was too narrow: scoring and cut ran twice
+        self.redone = bool(r.redone & 1)                 # the bound from the previous chromosome was too narrow: computed twice
         self.halo_w = int(r.halo_w)                  # halo of the stencil tiles: maxww, or the record bound (spec_halo)
         self.batch_bands = int(r.batch_bands)        # chromosomes that shared this one's launches (kernel times are its share)
         self.nsig = int(r.nsig)                      # pixels reported over all sets

@@ -63,7 +63,7 @@ struct Lane {
     int nev = 0;
     bool busy = false;
     // workspaces (grow only), pooled over the bands of a batch
-    DevBuf raw, bal, weight, IR, b1, b2, plan, etab, eedge, recE, recS, recW, dE, dW, dS, small, surv, surv2, survx, survx2, cux, psum, pnan, units, desc;
+    DevBuf raw, bal, weight, IR, b1, b2, plan, etab, eedge, recE, recS, recW, dE, dW, dS, small, surv, surv2, survx, survx2, cux, psum, pnan, units, desc, kmin;
     void* h_head = nullptr;             // pinned: per band counters | row flags | first survivors
     size_t h_head_cap = 0;
     void* h_desc = nullptr;             // pinned staging of the band descriptors
@@ -74,7 +74,7 @@ struct Lane {
     HpkDevPlan plan_host;
     void release() {
         DevBuf* all[] = {&raw, &bal, &weight, &IR, &b1, &b2, &plan, &etab, &eedge, &recE, &recS, &recW, &dE, &dW, &dS, &small,
-                         &surv, &surv2, &survx, &survx2, &cux, &psum, &pnan, &units, &desc};
+                         &surv, &surv2, &survx, &survx2, &cux, &psum, &pnan, &units, &desc, &kmin};
         for (DevBuf* b : all) b->release();
         if (h_head) { (void)hipHostFree(h_head); h_head = nullptr; h_head_cap = 0; }
         if (h_desc) { (void)hipHostFree(h_desc); h_desc = nullptr; h_desc_cap = 0; }
@@ -102,6 +102,9 @@ struct Options {
     int score_div = 8;          // tiles per scoring workgroup of a batch
     int dbg_stop = 0;
     int host_prof = 0;
+    int spec_surv = 1;          // survivor records only up to the cut's histogram bin of the chromosomes before (minus spec_surv_margin bins)
+    int spec_surv_margin = 2;
+    int spec_surv_force = -1;   // tests: this bin for every family (too narrow a bound: scored once more)
     int host_threads = 8;       // threads of a batch's host half (hpk_collect_batch), at most one per four chromosomes
 };
 
@@ -128,6 +131,11 @@ struct hpk_ctx {
     int hint_w[4] = {-1, -1, -1, -1};
     int hint_n = 0;
     long long spec_reruns = 0;
+    // ... and the histogram bins their Benjamini-Hochberg cuts fell into, per family (HPK_OFF_TBIN): the smallest bin of the
+    // last collections, minus a margin, bounds the survivor records the next scoring launches write (HpkScoreArgs::kmin)
+    uint8_t hint_bin[4][HPK_NFAM];
+    int hint_bn = 0;
+    long long surv_rescored = 0;
 };
 
 namespace {
@@ -283,6 +291,8 @@ int hpk_create(int device, hpk_ctx** out) {
     o.spec_margin = env_int("HPK_SPEC_MARGIN", o.spec_margin);
     o.spec_halo = env_int("HPK_SPEC_HALO", o.spec_halo);
     o.host_threads = std::max(1, std::min(64, env_int("HPK_HOST_THREADS", o.host_threads)));
+    o.spec_surv = env_int("HPK_SPEC_SURV", o.spec_surv) ? 1 : 0;
+    o.spec_surv_margin = std::max(0, env_int("HPK_SPEC_SURV_MARGIN", o.spec_surv_margin));
     o.tr_cap = std::max(16, std::min(127, env_int("HPK_TR_CAP", o.tr_cap)));
     o.risk_log2 = env_int("HPK_RISK_LOG2", o.risk_log2);
     o.tile_order = env_int("HPK_TILE_ORDER", o.tile_order);
@@ -304,6 +314,9 @@ int hpk_set_option(hpk_ctx* c, const char* name, int64_t v) {
     else if (k == "spec_margin" && v >= 0 && v <= HPK_MAX_W) o.spec_margin = (int)v;
     else if (k == "spec_halo" && (v == 0 || v == 1)) o.spec_halo = (int)v;
     else if (k == "host_threads" && v >= 1 && v <= 64) o.host_threads = (int)v;
+    else if (k == "spec_surv" && (v == 0 || v == 1)) o.spec_surv = (int)v;
+    else if (k == "spec_surv_margin" && v >= 0 && v <= 16) o.spec_surv_margin = (int)v;
+    else if (k == "spec_surv_force" && v >= -1 && v <= 16) o.spec_surv_force = (int)v;
     else if (k == "spec_force" && v >= -1 && v <= 255) o.spec_force = (int)v;     // (clamped to maxww where it is used)
     else if (k == "risk_log2" && v >= 0 && v <= 60) o.risk_log2 = (int)v;
     else if (k == "tile_order" && (v == 0 || v == 1)) o.tile_order = (int)v;
@@ -436,7 +449,7 @@ struct BandSlot {
     size_t off_rowlive = 0, off_inl = 0, head_bytes = 0, off_hacc = 0, off_tc = 0, off_cnt = 0, off_cu = 0, zero_bytes = 0;
     size_t small_off = 0, head_off = 0; // inside Lane::small / Lane::h_head
     size_t dense_elems = 0;
-    bool redone = false, overflowed = false, finished = false;
+    bool redone = false, overflowed = false, finished = false, rescored = false;
     bool rest_fetched = false;          // the survivors beyond the inline head already sit in `rest` (overflow rerun)
     std::vector<HpkSurv> rest;
     int status = HPK_OK;
@@ -456,6 +469,7 @@ struct hpk_job {
          time_stencil = true;
     size_t max_zero = 0, max_head = 0;
     double t_begin = 0.0;
+    uint8_t kmin_host[HPK_NFAM];        // the survivor bound of the batch's scoring launches (HpkScoreArgs::kmin), if any
     ~hpk_job() { for (BandSlot& b : bands) delete b.box; }
 };
 
@@ -467,7 +481,7 @@ HpkBandDesc* lane_desc(Lane& L, const hpk_job* j, int b, bool solo) {
 
 // the kernels of bands [b0, b0 + nbl) of a job whose counter blocks are zero: stencil (+ the freeze decision), scoring,
 // cut, copy-back.  solo: band b0 alone, through its second descriptor (records for every resolved candidate).
-int launch_compute(hpk_ctx* c, hpk_job* j, int b0, int nbl, bool solo, bool with_stencil) {
+int launch_compute(hpk_ctx* c, hpk_job* j, int b0, int nbl, bool solo, bool with_stencil, bool all_survivors = false) {
     Lane& L = c->lane[j->lane];
     const HpkDevPlan& plan = L.plan_host;
     const HpkBandDesc* dd = lane_desc(L, j, b0, solo);
@@ -501,12 +515,13 @@ int launch_compute(hpk_ctx* c, hpk_job* j, int b0, int nbl, bool solo, bool with
     }
     if (j->do_score) {
         HpkScoreArgs sc = full ? j->sc_full : j->sc;
+        if (all_survivors) sc.kmin = nullptr;       // (a chromosome whose cut lay above the bound of its survivor records)
         sc.gridx = 0;           // the widest row of scoring workgroups among the bands launched (HpkBandDesc::score_wgs)
         for (int b = b0; b < b0 + nbl; ++b) sc.gridx = std::max(sc.gridx, solo ? j->gmax : j->bands[b].d.score_wgs);
         hpk_launch_score(sc, dd, nbl, plan.mode == HPK_MODE_BHFDR, c->stream);
         HIPCHK(c, hipGetLastError());
         if (j->phases) (void)hipEventRecord(L.ev[4], c->stream);
-        hpk_launch_tighten(dd, nbl, j->prm.sig, j->rounds_eff, j->nsets, c->stream);
+        hpk_launch_tighten(dd, nbl, j->prm.sig, j->rounds_eff, j->nsets, sc.kmin, c->stream);
         HIPCHK(c, hipGetLastError());
     } else if (j->phases) (void)hipEventRecord(L.ev[4], c->stream);
     if (j->phases) (void)hipEventRecord(L.ev[5], c->stream);
@@ -886,6 +901,31 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     sc.ptab_off = c->d_off.as<int32_t>(); sc.sfe = c->d_sfe.as<double>(); sc.sig = prm->sig;
     sc.mw = mw; sc.D = D;
     sc.hbins = hbins; sc.nsets_half = plan.npairs;
+    // Survivor records: p <= sig is what can reach q <= sig, but the Benjamini-Hochberg cut of a family lies orders of
+    // magnitude below sig (sig x rejections / tests), and the chromosomes collected last with these parameters say in which
+    // histogram bin.  The launch writes records from that bin (minus a margin) on; hpk_thr_compact verifies.
+    sc.kmin = nullptr;
+    if (hbins > 0 && opt.spec_surv && j->do_score && !dense) {
+        uint8_t* km = j->kmin_host;
+        bool have = false;
+        if (opt.spec_surv_force >= 0) {
+            std::memset(km, std::min(opt.spec_surv_force, hbins - 1), HPK_NFAM);
+            have = true;
+        } else if (c->hint_bn > 0 && c->hint_n > 0 && std::memcmp(&key, &c->hint_key, sizeof(key)) == 0) {
+            for (int f = 0; f < HPK_NFAM; ++f) {
+                int kb = 255;
+                for (int i = 0; i < c->hint_bn; ++i) kb = std::min<int>(kb, c->hint_bin[i][f]);
+                km[f] = (uint8_t)std::max(0, std::min(kb, hbins - 1) - opt.spec_surv_margin);
+            }
+            have = true;
+        }
+        if (have) {
+            HIPCHK(c, L.kmin.reserve(HPK_NFAM));
+            HIPCHK(c, hipMemcpyAsync(L.kmin.p, km, HPK_NFAM, hipMemcpyHostToDevice, c->stream));
+            sc.kmin = L.kmin.as<uint8_t>();
+            if (opt.host_prof) std::fprintf(stderr, "[hpk host] survivor bound: bins %d %d %d ... (hbins %d)\n", km[1], km[2], km[HPK_NB + 2], hbins);
+        }
+    }
     j->sc_full = sc;
     j->sc_full.tilecap = GF.tilecap; j->sc_full.TR = GF.TR; j->sc_full.TC = GF.TC; j->sc_full.J = GF.J; j->sc_full.W = GF.W;
     return launch_compute(c, j, 0, nb, false, true);
@@ -915,7 +955,7 @@ int finish_band(hpk_ctx* c, hpk_job* j, int b, std::string* err = nullptr) {
     const int32_t h_err = *reinterpret_cast<const int32_t*>(hsmall + HPK_OFF_ERR);
     R.record_bound = s.d.wguess;
     R.halo_w = s.redone ? j->sa_full.W : j->sa.W;
-    R.redone = s.redone ? 1 : 0;
+    R.redone = (s.redone ? 1 : 0) | (s.rescored ? 2 : 0);
     const int32_t* h_exec = reinterpret_cast<const int32_t*>(hsmall + HPK_OFF_EXEC);
     const unsigned long long h_nsurv = *reinterpret_cast<const unsigned long long*>(hsmall + HPK_OFF_NOUT);
     const unsigned long long* h_emax = reinterpret_cast<const unsigned long long*>(hsmall + HPK_OFF_EMAX);
@@ -1110,6 +1150,24 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
                 again = true;
                 continue;
             }
+            if (c->opt.host_prof) std::fprintf(stderr, "[hpk host] band %d specfail %u tbin %d %d %d\n", b, *reinterpret_cast<const unsigned*>(hsmall + HPK_OFF_SPECFAIL), hsmall[HPK_OFF_TBIN + 1], hsmall[HPK_OFF_TBIN + 2], hsmall[HPK_OFF_TBIN + HPK_NB + 2]);
+            if (*reinterpret_cast<const unsigned*>(hsmall + HPK_OFF_SPECFAIL) != 0u && !s.rescored) {
+                // the cut of some family lies above the bound the survivor records were written to: scoring and cut once
+                // more, with a record for every p <= sig
+                s.rescored = true;
+                c->surv_rescored += 1;
+                HpkBandDesc* hd = static_cast<HpkBandDesc*>(L.h_desc) + nb + b;
+                *hd = s.d;
+                hd->k0 = 0;             // (the band's own scoring grid: its survivor regions were sized for that many waves)
+                HIPCHK(c, hipMemcpyAsync(lane_desc(L, j, b, true), hd, sizeof(HpkBandDesc), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipMemsetAsync(s.d.chunk_used, 0, sizeof(unsigned) * (size_t)(s.cap / HPK_SCH * HPK_NREG + 1), c->stream));
+                HIPCHK(c, hipMemsetAsync(s.d.small + HPK_OFF_NSURV, 0, HPK_SMALL_BYTES - HPK_OFF_NSURV, c->stream));
+                HIPCHK(c, hipMemsetAsync(s.d.small + s.off_cnt, 0, sizeof(unsigned) * HPK_NFAM * HPK_TIGHTEN_MAX, c->stream));
+                int rc = launch_compute(c, j, b, 1, true, false, true);
+                if (rc != HPK_OK) return rc;
+                again = true;
+                continue;
+            }
             unsigned long long ns = 0;              // fullest region
             for (int rg = 0; rg < HPK_NREG; ++rg)
                 ns = std::max(ns, reinterpret_cast<const unsigned long long*>(hsmall + HPK_OFF_NSURV)[rg * HPK_REG_STRIDE]);
@@ -1131,7 +1189,7 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
             HIPCHK(c, hipMemsetAsync(L.cux.p, 0, cu_bytes, c->stream));
             HIPCHK(c, hipMemsetAsync(s.d.small + HPK_OFF_NSURV, 0, HPK_SMALL_BYTES - HPK_OFF_NSURV, c->stream));
             HIPCHK(c, hipMemsetAsync(s.d.small + s.off_cnt, 0, sizeof(unsigned) * HPK_NFAM * HPK_TIGHTEN_MAX, c->stream));
-            int rc = launch_compute(c, j, b, 1, true, false);
+            int rc = launch_compute(c, j, b, 1, true, false, s.rescored);
             if (rc != HPK_OK) return rc;
             HIPCHK(c, hipEventSynchronize(L.ev_done));
             const unsigned long long nout = *reinterpret_cast<const unsigned long long*>(hsmall + HPK_OFF_NOUT);
@@ -1143,8 +1201,9 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
             s.rest_fetched = true;
             again = true;       // (checked once more: a second overflow is an error)
         }
-        if (!again || pass >= 3) break;
+        if (!again) break;
         HIPCHK(c, hipEventSynchronize(L.ev_done));
+        if (pass >= 6) break;           // (each of the three reruns fires at most once per chromosome)
     }
 #ifdef HPK_PHASE_CLOCK
     if (const char* path = std::getenv("HPK_CLK_DUMP")) {       // [grid][waves][8] u64, overwritten by every batch
@@ -1220,7 +1279,23 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
         if (j->do_score) fz_max = std::max(fz_max, (int)R.frozen_w);
     }
     if (fz_max >= 0) {          // the next stencils' record bound: the widest freeze of the last few collections
-        if (c->hint_n == 0 || std::memcmp(&j->key, &c->hint_key, sizeof(j->key)) != 0) { c->hint_n = 0; c->hint_key = j->key; }
+        if (c->hint_n == 0 || std::memcmp(&j->key, &c->hint_key, sizeof(j->key)) != 0) { c->hint_n = 0; c->hint_bn = 0; c->hint_key = j->key; }
+        if (j->rounds_eff <= -100) {        // ... and the bins of the families' cuts (smallest over the batch)
+            uint8_t bins[HPK_NFAM];
+            std::memset(bins, 255, sizeof(bins));
+            bool any = false;
+            for (int b = 0; b < nb; ++b) {
+                const BandSlot& s = j->bands[b];
+                if (s.status != HPK_OK) continue;
+                const unsigned char* tb = static_cast<const unsigned char*>(L.h_head) + s.head_off + HPK_OFF_TBIN;
+                for (int f = 0; f < HPK_NFAM; ++f) bins[f] = std::min(bins[f], tb[f]);
+                any = true;
+            }
+            if (any) {
+                if (c->hint_bn == 4) { std::memmove(c->hint_bin[0], c->hint_bin[1], 3 * HPK_NFAM); c->hint_bn = 3; }
+                std::memcpy(c->hint_bin[c->hint_bn++], bins, HPK_NFAM);
+            }
+        }
         if (c->hint_n < 4) c->hint_w[c->hint_n++] = fz_max;
         else { for (int i = 0; i < 3; ++i) c->hint_w[i] = c->hint_w[i + 1]; c->hint_w[3] = fz_max; }
     }

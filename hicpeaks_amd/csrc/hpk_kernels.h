@@ -52,7 +52,9 @@ struct HpkSurv {
 #define HPK_OFF_NVALID  (HPK_OFF_NSURV + 8 * HPK_NREG * HPK_REG_STRIDE)     // u64[16]
 #define HPK_OFF_EMAX    (HPK_OFF_NVALID + 8 * 2 * HPK_MAX_PAIRS)            // u64[16]
 #define HPK_OFF_NOUT    (HPK_OFF_EMAX + 8 * 2 * HPK_MAX_PAIRS)              // u64
-#define HPK_OFF_FAM_M   (HPK_OFF_NOUT + 8)                                  // u32[HPK_NFAM]
+#define HPK_OFF_SPECFAIL (HPK_OFF_NOUT + 8)                                 // u32 (+ pad): a family's cut lies above the bound its survivors were written to
+#define HPK_OFF_TBIN    (HPK_OFF_SPECFAIL + 8)                              // u8[HPK_NFAM]: histogram bin of every family's cut (hpk_thr_compact)
+#define HPK_OFF_FAM_M   (HPK_OFF_TBIN + (HPK_NFAM + 15) / 16 * 16)          // u32[HPK_NFAM]
 #define HPK_OFF_FAM_F   (HPK_OFF_FAM_M + 4 * HPK_NFAM)                      // u32[HPK_NFAM]
 #define HPK_SMALL_BYTES (HPK_OFF_FAM_F + 4 * HPK_NFAM)
 #define HPK_HEAD_INLINE 4096            // compacted survivors that travel to the host with the counters
@@ -141,6 +143,7 @@ struct HpkScoreArgs {
     int32_t hbins;                      // bins per family of the p-value histogram (HpkBandDesc::cnt), 0 = none (hpk_thr_hist / counting rounds do the cut)
     int32_t nsets_half;                 // (pw, ww) pairs of the call: the launcher sizes the histogram's LDS with it
     int32_t gridx;                      // workgroups per band
+    const uint8_t* kmin;                // [HPK_NFAM] or nullptr: survivor records only for p-values in histogram bin >= kmin[family]
 };
 
 struct HpkDenseArgs {
@@ -181,7 +184,7 @@ void hpk_launch_score(const HpkScoreArgs& a, const HpkBandDesc* d_bands, int nba
 // then compaction of the records with p <= thr[f] (count in the band's HPK_OFF_NOUT).
 int  hpk_thr_hist_bins(int nsets);       // bins per family of the one-pass tightening (rounds < 0)
 int  hpk_score_hist_bins(int nsets);     // bins per family of the histogram hpk_score keeps (rounds <= -100)
-void hpk_launch_tighten(const HpkBandDesc* d_bands, int nbands, double sig, int rounds, int nsets, hipStream_t st);
+void hpk_launch_tighten(const HpkBandDesc* d_bands, int nbands, double sig, int rounds, int nsets, const uint8_t* kmin, hipStream_t st);
 // result heads -> mapped pinned host memory: full = the whole head (no scoring ran), otherwise the stretches a chromosome fills
 void hpk_launch_publish(const HpkBandDesc* d_bands, int nbands, int nsets, bool full, size_t max_head_bytes, hipStream_t st);
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,

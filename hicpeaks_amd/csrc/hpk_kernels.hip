@@ -1915,6 +1915,12 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
     __shared__ int lstepw[HPK_MAX_STEPS];
     __shared__ int lpair_slot[HPK_MAX_PAIRS], lpair_wi[HPK_MAX_PAIRS];
     __shared__ int lptoff[HPK_NB_TAB + 2];
+    // Survivor records are only written for p-values at or below a per-family bound, given as a histogram bin (p <= sig
+    // 4^-kmin): the cut of the chromosomes before lies orders of magnitude below sig, and 99 % of the p <= sig records
+    // used to be written only for the compaction to drop them.  The histogram and the family counts still see every
+    // p <= sig; hpk_thr_compact checks that the cut it derives lies inside the bound (HPK_OFF_SPECFAIL otherwise: the
+    // host scores the chromosome once more without a bound).
+    __shared__ unsigned char lkmin[NSETS_LDS * (HPK_NB + 1)];
     // p-values at or below sig by family and log bin (bin k: sig 4^-(k+1) < p <= sig 4^-k, the last one open towards 0):
     // what the Benjamini-Hochberg cut is derived from (hpk_thr_compact).  Families of the table's chunks are counted here,
     // [nsets][HPK_NB_TAB + 1][a.hbins], the few beyond it straight in global memory.
@@ -1944,6 +1950,10 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
     const int W = plan->W;
     const int nsets = BH ? 1 : 2 * npairs;
     for (int i = threadIdx.x; i < nsets * (HPK_NB + 1); i += blockDim.x) { (&lm[0][0])[i] = 0u; (&lf[0][0])[i] = 0u; }
+    {
+        const uint8_t* km = const_cast<const uint8_t*>(ka->kmin);
+        for (int i = threadIdx.x; i < nsets * (HPK_NB + 1); i += blockDim.x) lkmin[i] = km ? km[i] : (unsigned char)0;
+    }
     const int hbins = a.hbins;
     for (int i = threadIdx.x; i < nsets * (HPK_NB_TAB + 1) * hbins; i += blockDim.x) lhist[i] = 0u;
     const int sig_e = (int)((unsigned long long)__double_as_longlong(a.sig) >> 52);                  // sig > 0, normal
@@ -2227,6 +2237,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                         if (valid) atomicAdd(&lm[set][chunk], 1u);
                     }
                     if (sm != 0ull) {
+                        bool wr = surv;
                         if (surv) {
                             atomicAdd(&lf[set][chunk], 1u);
                             if (hbins) {
@@ -2238,10 +2249,13 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                                 k = k < 0 ? 0 : (k > hbins - 1 ? hbins - 1 : k);
                                 if (chunk <= HPK_NB_TAB) atomicAdd(&lhist[(set * (HPK_NB_TAB + 1) + chunk) * hbins + k], 1u);
                                 else atomicAdd(&gptr(kb->cnt)[(set * (HPK_NB + 1) + chunk) * hbins + k], 1u);
+                                wr = k >= (int)lkmin[set * (HPK_NB + 1) + chunk];
                             }
                         }
+                        const unsigned long long wm = __ballot(wr);
+                        if (wm == 0ull) continue;
                         // per-wave reservation of survivor slots
-                        const unsigned scnt = (unsigned)__popcll(sm);
+                        const unsigned scnt = (unsigned)__popcll(wm);
                         if (wused + scnt > HPK_SCH) {            // wave-uniform: retire the chunk, take a new one
                             if (have_chunk && lane == 0 && (int64_t)wbase < b_cap) gptr(kb->chunk_used)[(rbase + (int64_t)wbase) / HPK_SCH] = wused;
                             have_chunk = true;
@@ -2253,8 +2267,8 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                         }
                         const unsigned long long basei = wbase + wused;
                         wused += scnt;
-                        if (surv) {
-                            const unsigned long long idx = basei + (unsigned long long)__popcll(sm & ((1ull << lane) - 1ull));
+                        if (wr) {
+                            const unsigned long long idx = basei + (unsigned long long)__popcll(wm & ((1ull << lane) - 1ull));
                             if ((int64_t)idx < b_cap) {
                                 HpkSurv rec;
                                 rec.x = r; rec.y = c; rec.O = rawpix; rec.set = (uint8_t)set; rec.chunk = (uint8_t)chunk;
@@ -2405,7 +2419,8 @@ __global__ void __launch_bounds__(256) hpk_thr_count(const HpkBandDesc* __restri
 }
 // The first `inl` survivors of the cut go to out_head (which travels to the host together with the counters), the rest
 // to out_rest.
-__global__ void __launch_bounds__(256) hpk_thr_compact(const HpkBandDesc* __restrict__ bands, int rounds, double sig, int nfam) {
+__global__ void __launch_bounds__(256) hpk_thr_compact(const HpkBandDesc* __restrict__ bands, int rounds, double sig, int nfam,
+                                                       const uint8_t* __restrict__ kmin) {
     HPK_THR_BAND_ARGS
     const unsigned int* __restrict__ cnt = gptr(bd->cnt);
     HpkSurv* __restrict__ out_head = reinterpret_cast<HpkSurv*>(small + bd->off_inl);
@@ -2420,11 +2435,30 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkBandDesc* __rest
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int reg = blockIdx.y;
     int64_t n = (int64_t)nsurv[reg * HPK_REG_STRIDE]; if (n > cap) n = cap;
-    if ((int64_t)blockIdx.x * blockDim.x >= n) return;
+    // the band's first workgroup also reports, per family, the histogram bin its cut falls into (what the next chromosomes'
+    // scoring bounds its survivor records with) and whether a cut lies above the bound this chromosome's were written to
+    const bool lead = blockIdx.x == 0 && blockIdx.y == 0 && rounds <= -100;
+    if (!lead && (int64_t)blockIdx.x * blockDim.x >= n) return;
     if (rounds <= -100) thr_table_hist(lthr, fam_m, fam_f, cnt, -rounds - 100, sig, nfam, true);
     else if (rounds < 0) thr_table_hist(lthr, fam_m, fam_f, cnt, -rounds, sig, nfam, false);
     else thr_table(lthr, fam_m, fam_f, cnt, rounds, sig, nfam);
     __syncthreads();
+    if (lead) {
+        const int hb = -rounds - 100;
+        const int sig_e = (int)((unsigned long long)__double_as_longlong(sig) >> 52);
+        const unsigned long long sig_m = (unsigned long long)__double_as_longlong(sig) & 0xfffffffffffffull;
+        for (int i = threadIdx.x; i < nfam; i += blockDim.x) {
+            const unsigned long long tb = (unsigned long long)__double_as_longlong(lthr[i]);
+            int k = sig_e - (int)(tb >> 52) - ((tb & 0xfffffffffffffull) > sig_m ? 1 : 0);      // as hpk_score bins a p-value
+            k >>= HPK_HSHIFT;
+            k = (tb >> 52) == 0ull ? hb - 1 : k;
+            k = k < 0 ? 0 : (k > hb - 1 ? hb - 1 : k);
+            if (fam_f[i] == 0u) k = hb - 1;                 // no p-value at or below sig: nothing to keep
+            small[HPK_OFF_TBIN + i] = (unsigned char)k;
+            if (kmin && fam_f[i] != 0u && k < (int)kmin[i]) *reinterpret_cast<unsigned*>(small + HPK_OFF_SPECFAIL) = 1u;
+        }
+        if ((int64_t)blockIdx.x * blockDim.x >= n) return;
+    }
     const int64_t rb = (int64_t)reg * cap;
     for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
         const int64_t i = i0 + threadIdx.x;
@@ -2683,14 +2717,15 @@ void hpk_launch_score(const HpkScoreArgs& a, const HpkBandDesc* d_bands, int nba
 
 int hpk_thr_hist_bins(int nsets) { return nsets * (HPK_NB + 1) <= 1032 ? 16 : 8; }   // LDS of hpk_thr_hist <= 83 KB
 
-void hpk_launch_tighten(const HpkBandDesc* d_bands, int nbands, double sig, int rounds, int nsets, hipStream_t st) {
+void hpk_launch_tighten(const HpkBandDesc* d_bands, int nbands, double sig, int rounds, int nsets, const uint8_t* kmin, hipStream_t st) {
     if (rounds > HPK_TIGHTEN_MAX) rounds = HPK_TIGHTEN_MAX;
     const int nfam = nsets * (HPK_NB + 1);          // families in use: (set, chunk)
     const dim3 grid(8, HPK_NREG, nbands);
     if (rounds <= -100) {       // the histogram came with the scoring kernel: only the compaction is left
-        hipLaunchKernelGGL(hpk_thr_compact, grid, dim3(256), 0, st, d_bands, rounds, sig, nfam);
+        hipLaunchKernelGGL(hpk_thr_compact, grid, dim3(256), 0, st, d_bands, rounds, sig, nfam, kmin);
         return;
     }
+    const uint8_t* none = nullptr;
     if (rounds < 0) {           // one histogram pass instead of the counting rounds (cnt = [nfam][nbins], zeroed)
         const int nbins = hpk_thr_hist_bins(nsets);
         const size_t lds = (size_t)nfam * 8 + (size_t)nfam * nbins * 4;
@@ -2700,12 +2735,12 @@ void hpk_launch_tighten(const HpkBandDesc* d_bands, int nbands, double sig, int 
             attr_done = true;
         }
         hipLaunchKernelGGL(hpk_thr_hist, grid, dim3(256), lds, st, d_bands, nbins, sig, nfam);
-        hipLaunchKernelGGL(hpk_thr_compact, grid, dim3(256), 0, st, d_bands, -nbins, sig, nfam);
+        hipLaunchKernelGGL(hpk_thr_compact, grid, dim3(256), 0, st, d_bands, -nbins, sig, nfam, none);
         return;
     }
     for (int r = 0; r < rounds; ++r)
         hipLaunchKernelGGL(hpk_thr_count, grid, dim3(256), 0, st, d_bands, r, sig, nfam);
-    hipLaunchKernelGGL(hpk_thr_compact, grid, dim3(256), 0, st, d_bands, rounds, sig, nfam);
+    hipLaunchKernelGGL(hpk_thr_compact, grid, dim3(256), 0, st, d_bands, rounds, sig, nfam, none);
 }
 
 void hpk_launch_prep(const HpkBandDesc* d_bands, int nbands, int max_n, int max_num, int mw, hipStream_t st) {

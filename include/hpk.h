@@ -161,8 +161,10 @@ typedef struct {
     int32_t stencil_kernel;    /* stencil kernel that ran: 1 = first generation, any plan; 2 = second generation, simple-Reads plans */
     int32_t record_bound;      /* the stencil wrote records for candidates resolved up to this width (255: all of them;
                                   HPK_FLAG_DENSE_*, HPK_FLAG_NO_SCORE); see hpk_submit_band */
-    int32_t redone;            /* 1: the widening froze beyond the bound taken from the previous chromosome and the
-                                  chromosome was computed once more with every resolved candidate */
+    int32_t redone;            /* bit 0: the widening froze beyond the bound taken from the previous chromosome and the
+                                  chromosome was computed once more with every resolved candidate; bit 1: the
+                                  Benjamini-Hochberg cut of a family lay above the bound the survivor records were written to
+                                  (hpk_set_option spec_surv) and scoring + cut ran once more with a record for every p <= sig */
     int64_t nsurv_sig;         /* pixels with p <= sig (before the BH cut is tightened on the device) */
     int64_t nsurv_cut;         /* of those, how many were copied back for the final Benjamini-Hochberg step */
     int64_t stencil_tiles;
@@ -226,7 +228,9 @@ int  hpk_collect_batch(hpk_ctx* ctx, hpk_job* job, hpk_result** outs, int32_t* s
  * p-value histogram the cut is derived from [default], -1: a histogram pass of its own, 0..4: exact counting rounds),
  * "surv_cap" (survivor slots per region, 0 = sized from the band; tests force the overflow rerun with it), "spec" (0: no
  * record bound from earlier chromosomes), "spec_margin" (widths added to the bound), "spec_force" (>= 0: this bound;
- * tests), "spec_halo" (0: tiles always under maxww's halo - runs of one chromosome are then bit-identical whatever the bound), "risk_log2" (exact-fallback threshold 2^-x), "tile_order", "gap_kernel" (1: gap rows by the row kernel),
+ * tests), "spec_surv" (0: a survivor record for every p <= sig; 1 [default]: only up to the histogram bin the families' cuts fell
+ * into in the chromosomes before, minus "spec_surv_margin" bins - verified, hpk_result::redone bit 1), "spec_surv_force" (tests),
+ * "host_threads" (threads of a batch's host half), "spec_halo" (0: tiles always under maxww's halo - runs of one chromosome are then bit-identical whatever the bound), "risk_log2" (exact-fallback threshold 2^-x), "tile_order", "gap_kernel" (1: gap rows by the row kernel),
  * "score_div" (tiles per scoring workgroup of a batch), "dbg_stop" (profiling ablation).  Returns HPK_ERR_INVALID for an
  * unknown name or a value out of range. */
 int  hpk_set_option(hpk_ctx* ctx, const char* name, int64_t value);

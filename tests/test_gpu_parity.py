@@ -497,6 +497,52 @@ def test_survivor_overflow_rerun(ctx):
 
 
 @pytest.mark.parametrize('mode', ['hiccups', 'bhfdr'])
+def test_survivor_bound_from_the_previous_chromosomes(mode):
+    """The scoring kernel writes survivor records only for p-values in the histogram bins where the families' cuts of the
+    chromosomes before fell (option spec_surv): whatever the bound - none (a fresh context), the one taken over,
+    one forced to the last bin (too narrow: detected by the cut kernel, scored once more), switched off - the result is the
+    same, and far fewer records are copied... the cut is what it was."""
+    from hicpeaks_amd import synthetic
+    n, res, maxapart, maxww = 4000, 10000, 2000000, 10
+    num = maxapart // res + maxww + 1
+    raw, weight, _ = synthetic.synth_band(n, num, depth=60.0, nloops=60, seed=12)
+    raw = raw.astype(np.float32)
+    other, ow, _ = synthetic.synth_band(2500, num, depth=25.0, nloops=10, seed=13)     # sparser and smaller: other cuts
+    other = other.astype(np.float32)
+    if mode == 'hiccups':
+        prm = _lib.make_params(_lib.MODE_HICCUPS, [1, 2], [3, 5], maxww, 0.1, maxapart, res, 16, 0)
+    else:
+        prm = _lib.make_params(_lib.MODE_BHFDR, [2], [5], maxww, 0.05, maxapart, res, 16, 0)
+    c = _lib.Context(0)
+    c.set_option('spec_halo', 0)            # (bit-identical box sums whatever the record bound: this test is about the survivors)
+    try:
+        first = c.score_host(raw, None, None, None, prm, weight=weight)
+        assert not first.rescored and sum(s['x'].size for s in first.sets) > 20
+        second = c.score_host(raw, None, None, None, prm, weight=weight)            # bound = first's bins - margin
+        assert not second.rescored
+        _same_result(second, first)
+        assert second.nsurv_sig == first.nsurv_sig and second.nsurv_cut == first.nsurv_cut
+        # another chromosome in between, then a batch of both
+        o1 = c.score_host(other, None, None, None, prm, weight=ow)
+        rs = c.submit_batch_host([dict(raw=raw, weight=weight), dict(raw=other, weight=ow), dict(raw=raw, weight=weight)], prm).results()
+        _same_result(rs[0], first); _same_result(rs[2], first); _same_result(rs[1], o1)
+        c.set_option('spec_surv_force', 15)      # the last bin for every family: too narrow wherever a cut lies above it
+        forced = c.score_host(raw, None, None, None, prm, weight=weight)
+        assert forced.rescored
+        _same_result(forced, first)
+        fb = c.submit_batch_host([dict(raw=raw, weight=weight), dict(raw=other, weight=ow)], prm).results()
+        assert fb[0].rescored
+        _same_result(fb[0], first); _same_result(fb[1], o1)
+        c.set_option('spec_surv_force', -1)
+        c.set_option('spec_surv', 0)
+        off = c.score_host(raw, None, None, None, prm, weight=weight)
+        assert not off.rescored
+        _same_result(off, first)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize('mode', ['hiccups', 'bhfdr'])
 def test_bh_cut_variants_agree(ctx, mode):
     """Three ways to the Benjamini-Hochberg cut - the histogram the scoring kernel keeps (default), the histogram pass
     of its own (option rounds = -1), exact counting rounds (rounds = 2) - must leave the same significant pixels with the
