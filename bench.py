@@ -262,7 +262,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=0,
                     help='chromosomes per step: a step scores this many chromosome-sized bands '
-                         '(default: 960 for the 10 kb configurations, so that 20 steps keep the GPU busy for ~2 s '
+                         '(default: 1280 for the 10 kb configurations, so that 20 steps keep the GPU busy for ~2 s '
                          'and the clocks settle; the whole-genome configurations\' step is the 23-chromosome genome)')
     ap.add_argument('--group', type=int, default=0,
                     help='chromosomes per library call (hpk_submit_batch: one launch per stage for the whole group); 1 = chromosome '
@@ -382,7 +382,7 @@ def main():
     tiles = -(-n // 59) * -(-(59 + D - mw) // 107)
     per_band = tiles * 6313 * (4 + 17 * len(set(cfg['pw']))) + 2 * 40 * band.band_pixels(n, num, mw, D) * 2 * len(cfg['pw']) // 6
     group = args.group if args.group > 0 else max(1, min(32, int(24e9 // per_band)))
-    batch = args.batch if args.batch > 0 else (960 if n * num <= 60_000_000 else 16)
+    batch = args.batch if args.batch > 0 else (1280 if n * num <= 60_000_000 else 16)
     batch = max(group, batch // group * group)          # whole groups
 
     def band_of(i):
