@@ -119,7 +119,17 @@ def test_batch_raises_like_the_single_call(ctx):
     with pytest.raises((ValueError, ZeroDivisionError)):
         ctx.submit_batch_host([dict(raw=raw, weight=weight, num=num), dict(raw=empty, weight=weight, num=num)], prm).results()
     ok = ctx.submit_batch_host([dict(raw=raw, weight=weight, num=num)], prm).results()[0]
-    _same(ok, ctx.score_host(raw, None, None, None, prm, weight=weight, num=num))
+    want = ctx.score_host(raw, None, None, None, prm, weight=weight, num=num)
+    _same(ok, want)
+    # a batch large enough for its host half to run on several threads (hpk_collect_batch: from 8 chromosomes on), two
+    # of them empty: every chromosome keeps its own outcome and its own message
+    items = [dict(raw=(empty if i in (3, 10) else raw), weight=weight, num=num) for i in range(12)]
+    got = ctx.submit_batch_host(items, prm).results(raise_on_error=False)
+    for i, g in enumerate(got):
+        if i in (3, 10):
+            assert isinstance(g, _lib.EmptyStepError) and 'no unresolved candidate' in str(g)
+        else:
+            _same(g, want)
     with pytest.raises(_lib.HpkError) as ei:
         ctx.submit_batch_host([dict(raw=raw, weight=weight, num=num)] * (_lib.HPK_MAX_BATCH + 1), prm)
     assert ei.value.status == _lib.ERR_INVALID
