@@ -1765,15 +1765,17 @@ __device__ __noinline__ double poisson_sf(double k, double lam, const double* __
     k = floor(k);
     double cdf;
     if (k < lam) {                         // lower sum, terms shrink going down from k
+        // (a pmf that underflowed to 0 stays 0 all the way down: without the t > 0 test such a lane - k thousands below a
+        // large lambda - walked every term to j = 0, and the table kernel spent 2 ms in a few hundred such waves)
         double t = dpois(k, lam, sfe), sum = t, j = k;
-        while (j > 0.0) {
+        while (j > 0.0 && t > 0.0) {
             t *= j / lam; j -= 1.0; sum += t;
             if (t < sum * 1e-18) break;
         }
         cdf = sum < 1.0 ? sum : 1.0;
     } else {                               // upper tail, terms shrink going up from k + 1
         double j = k + 1.0, t = dpois(j, lam, sfe), sum = t;
-        for (int it = 0; it < 100000; ++it) {
+        for (int it = 0; it < 100000 && t > 0.0; ++it) {        // (t = 0: the tail is 0 to the last bit, no term can change it)
             j += 1.0; t *= lam / j; sum += t;
             if (t < sum * 1e-18) break;
         }
