@@ -150,8 +150,10 @@ __device__ __forceinline__ double balanced_of(float raw, double wr, double wc) {
 }
 
 // explicit local-expected sums for pixels whose window is clipped by the matrix ends (callers.py:50-96 padding)
-__device__ __noinline__ void edge_expected(const int32_t* __restrict__ m, int wi, const double* __restrict__ IR, int r,
-                                           int c, int n, int num, int mw, double& EK, double& EY) {
+// (returned by value: reference parameters of a call that is not inlined live in scratch memory, and the scoring kernel
+// then stored and re-loaded its expected sums around the - rare - call in every work item)
+__device__ __noinline__ double2 edge_expected(const int32_t* __restrict__ m, int wi, const double* __restrict__ IR, int r,
+                                              int c, int n, int num, int mw) {
     double ek = 0.0, ey = 0.0;
     for (int di = -wi; di <= wi; ++di) {
         for (int dj = -wi; dj <= wi; ++dj) {
@@ -167,8 +169,7 @@ __device__ __noinline__ void edge_expected(const int32_t* __restrict__ m, int wi
             if (di > 0 && dj < 0) ey += v;
         }
     }
-    EK = ek;
-    EY = ey;
+    return make_double2(ek, ey);
 }
 
 // Explicit window sums of one pixel at one step (rare path of the stencil): taken when the summed-area table cannot
@@ -1822,7 +1823,8 @@ __device__ __forceinline__ void local_expected(const HpkDevPlan* __restrict__ pl
         EK = eedge[o];
         EY = eedge[o + (D + 1)];
     } else {
-        edge_expected(plan->steps[step].m, plan->steps[step].wi, IR, r, c, n, num, mw, EK, EY);
+        const double2 ee = edge_expected(plan->steps[step].m, plan->steps[step].wi, IR, r, c, n, num, mw);
+        EK = ee.x; EY = ee.y;
     }
 }
 
@@ -2079,6 +2081,26 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
             const int stp0 = stp_b;
             const double2 s20 = s2_b;
             const double ir = ir_b, b1r = b1_b, b2c = b2_b, EK0 = EK_b, EY0 = EY_b;
+            // This item's pixel, and - short chromosomes only - the explicit expected sums of windows clipped by both matrix
+            // ends: a call, placed ahead of the next item's loads so that nothing is in flight (and nothing has to be
+            // parked in scratch) across it.
+            if (!cand) ent = 0u;
+            const int r = g.r0 + (int)HPK_ENT_Y(ent);
+            const int c = g.c0 + (int)(ent & 127u);
+            const int d = c - r;
+            // which local-expected table serves this pixel (interior / clipped by one matrix end / both: explicit)
+            const bool top = cand && r < W, right = cand && c >= b_n - W;
+            const bool both = top && right;
+            double EK = EK0, EY = EY0;
+            if (__ballot(both) != 0ull) {                               // (both matrix ends in one window)
+                const bool bo = both && stp0 != 0;
+                if (__ballot(bo) != 0ull) {
+                    if (bo) {
+                        const double2 ee = edge_expected(plan->steps[stp0 - 1].m, plan->steps[stp0 - 1].wi, b_IR, r, c, b_n, kb->num, a.mw);
+                        EK = ee.x; EY = ee.y;
+                    }
+                }
+            }
             // the batch after this one: the same unit's next 64 records or the first of the wave's next unit
             bool next_batch = true;
             if (!ONE) {
@@ -2102,18 +2124,9 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                 if (more) issue_round2(gn);
                 continue;
             }
-            if (!cand) ent = 0u;
-            const int r = g.r0 + (int)HPK_ENT_Y(ent);
-            const int c = g.c0 + (int)(ent & 127u);
-            const int d = c - r;
             float rawpix = (float)(ent >> HPK_ENT_CNT_SHIFT);          // the SAT holds counts capped at HPK_PK_CAP: those are re-read
             if (cand && (ent >> HPK_ENT_CNT_SHIFT) >= pkcap) rawpix = gptr(kb->raw)[(int64_t)r * kb->ld + d];
             const double O = (double)rawpix;
-            // which local-expected table serves this pixel (interior / clipped by one matrix end / both: explicit)
-            const bool top = cand && r < W, right = cand && c >= b_n - W;
-            const bool both = top && right;
-
-            const bool anyboth = __ballot(both) != 0ull;                // (both matrix ends in one window: short chromosomes only)
             {
                 // The scalar unit is this kernel's busiest one (lane masks ANDed and ORed, exec saved and restored around
                 // every divergent if): conditions are folded into the values - a record that does not count turns into
@@ -2121,13 +2134,6 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                 const int pj = ONE ? 0 : g.pj;
                 const int stp = stp0;                   // resolved at an executed step, far enough from the diagonal, or 0
                 const double2 s2 = s20;
-                double EK = EK0, EY = EY0;
-                if (anyboth) {
-                    const bool bo = both && stp != 0;
-                    if (__ballot(bo) != 0ull) {
-                        if (bo) edge_expected(plan->steps[stp - 1].m, plan->steps[stp - 1].wi, b_IR, r, c, b_n, kb->num, a.mw, EK, EY);
-                    }
-                }
                 EK = stp != 0 ? EK : 0.0;
                 EY = stp != 0 ? EY : 0.0;
                 // callers.py:244-249: E = ((IR[d] * (bS / bE)) * B1[x]) * B2[y] where bE != 0
