@@ -2471,18 +2471,21 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkBandDesc* __rest
     for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
         const int64_t i = i0 + threadIdx.x;
         bool keep = false;
-        HpkSurv rec;
+        // (the record travels as four 8-byte words - records are 40 bytes apart - and a double: a local HpkSurv would live
+        // in scratch memory)
+        uint2 q0 = make_uint2(0u, 0u), q1 = q0, q2 = q0, q3 = q0;
+        double b = 0.0;
         if (i < n) {
             if ((unsigned)(i & (HPK_SCH - 1)) < chunk_used[(rb + i) >> HPK_SCH_LOG2]) {
                 const HpkSurv& src = surv[rb + i];
                 keep = src.p <= lthr[(int)src.set * (HPK_NB + 1) + (int)src.chunk];
                 if (keep) {                               // the other 30 bytes only for the few that stay
-                    rec = src;
+                    const uint2* s2 = reinterpret_cast<const uint2*>(&src);
+                    q0 = s2[0]; q1 = s2[1]; q2 = s2[2]; q3 = s2[3];       // x, y | O, set chunk flag pad | E | p
+                    const int rx = (int)q0.x, ry = (int)q0.y;
                     // the pixel's balanced value (reported with the call, callers.py:254-256), for these few only
-                    double b;
-                    if (bal) { b = bal[(int64_t)rec.x * ld + (rec.y - rec.x)]; b = (b == b) ? b : 0.0; }
-                    else b = balanced_of(rec.O, weight[rec.x], weight[rec.y]);
-                    rec.bal = b;
+                    if (bal) { b = bal[(int64_t)rx * ld + (ry - rx)]; b = (b == b) ? b : 0.0; }
+                    else b = balanced_of(__uint_as_float(q1.x), weight[rx], weight[ry]);
                 }
             }
         }
@@ -2493,7 +2496,10 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkBandDesc* __rest
         basei = __shfl(basei, 0);
         if (keep) {
             const unsigned long long o = basei + (unsigned long long)__popcll(km & ((1ull << lane) - 1ull));
-            if (o < inl) out_head[o] = rec; else out_rest[o - inl] = rec;
+            HpkSurv* dst = (o < inl) ? out_head + o : out_rest + (o - inl);
+            uint2* d2 = reinterpret_cast<uint2*>(dst);
+            d2[0] = q0; d2[1] = q1; d2[2] = q2; d2[3] = q3;
+            dst->bal = b;
         }
     }
 }
