@@ -49,6 +49,10 @@ CONFIGS = {
                           nloops=400, workload='hg38 chr1-22,X @10kb, union (1,3)/(2,5)/(4,7), 5Mb band, 23 chromosomes'),
     'wg_5kb': dict(genome=True, n=49792, res=5000, maxapart=10000000, pw=[4], ww=[7], maxww=10, depth=25.0, nloops=800,
                    workload='hg38 chr1-22,X @5kb, (p,w)=(4,7), 10Mb band, 23 chromosomes'),
+    # the sibling path (callers.py:364-590, scripts/pyBHFDR defaults): donut only, per-pixel Poisson(lambda = E), one
+    # Benjamini-Hochberg family per chromosome; 2 Mb band
+    'chr1_10kb_bhfdr': dict(mode='bhfdr', n=24896, res=10000, maxapart=2000000, pw=[2], ww=[5], maxww=10, depth=60.0, nloops=400,
+                            workload='hg38 chr1 @10kb (n=24896), bhfdr (p,w)=(2,5), 2Mb band'),
     'tiny': dict(n=3000, res=10000, maxapart=2000000, pw=[2], ww=[5], maxww=10, depth=60.0, nloops=40,
                  workload='tiny self-test'),
 }
@@ -146,9 +150,9 @@ def run_genome(args, cfg, ctx, rank, world, local, dist):
         else:
             bands.append((c, n, raw_d, w_d))
     torch.cuda.synchronize()
-    prm = _lib.make_params(_lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], cfg['maxww'], SIG, cfg['maxapart'], cfg['res'],
+    prm = _lib.make_params(_lib.MODE_BHFDR if cfg.get('mode') == 'bhfdr' else _lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], cfg['maxww'], SIG, cfg['maxapart'], cfg['res'],
                            MIN_READS, 0)
-    prm_quiet = _lib.make_params(_lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], cfg['maxww'], SIG, cfg['maxapart'], cfg['res'],
+    prm_quiet = _lib.make_params(_lib.MODE_BHFDR if cfg.get('mode') == 'bhfdr' else _lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], cfg['maxww'], SIG, cfg['maxapart'], cfg['res'],
                                  MIN_READS, _lib.FLAG_NO_STENCIL_TIMING)      # see run_chromosome: every TIMED_EVERY-th launch is timed
     npass = [0]
     px_genome = sum(band.band_pixels(n, num, mw, D) for n in sizes.values()) * len(cfg['pw'])
@@ -346,12 +350,12 @@ def main():
         nseeds = 1
     torch.cuda.synchronize()
     flags = _lib.FLAG_NO_SCORE if args.stencil_only else 0
-    prm = _lib.make_params(_lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], cfg['maxww'], SIG, cfg['maxapart'], cfg['res'],
+    prm = _lib.make_params(_lib.MODE_BHFDR if cfg.get('mode') == 'bhfdr' else _lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], cfg['maxww'], SIG, cfg['maxapart'], cfg['res'],
                            MIN_READS, flags)
     # The stencil's duration comes from two HIP events around its launch on the library's stream; a pair of events
     # idles the GPU ~6 us, so every TIMED_EVERY-th launch of the timed region is bracketed and the others run as a
     # production call does (HPK_FLAG_NO_STENCIL_TIMING).
-    prm_quiet = _lib.make_params(_lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], cfg['maxww'], SIG, cfg['maxapart'], cfg['res'],
+    prm_quiet = _lib.make_params(_lib.MODE_BHFDR if cfg.get('mode') == 'bhfdr' else _lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], cfg['maxww'], SIG, cfg['maxapart'], cfg['res'],
                                  MIN_READS, flags | _lib.FLAG_NO_STENCIL_TIMING)
     nsub = [0]
     px_per_step = band.band_pixels(n, num, mw, D) * len(cfg['pw'])
@@ -452,7 +456,7 @@ def main():
         t1 = time.perf_counter()
         submit(False, 1).results()
         lat.append((time.perf_counter() - t1) * 1e3)
-    prm = _lib.make_params(_lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], cfg['maxww'], SIG, cfg['maxapart'], cfg['res'],
+    prm = _lib.make_params(_lib.MODE_BHFDR if cfg.get('mode') == 'bhfdr' else _lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], cfg['maxww'], SIG, cfg['maxapart'], cfg['res'],
                            MIN_READS, flags | _lib.FLAG_PHASE_TIMING)
     phases = {}
     if not args.no_probes:

@@ -316,7 +316,7 @@ int hpk_set_option(hpk_ctx* c, const char* name, int64_t v) {
     else if (k == "host_threads" && v >= 1 && v <= 64) o.host_threads = (int)v;
     else if (k == "spec_surv" && (v == 0 || v == 1)) o.spec_surv = (int)v;
     else if (k == "spec_surv_margin" && v >= 0 && v <= 16) o.spec_surv_margin = (int)v;
-    else if (k == "spec_surv_force" && v >= -1 && v <= 16) o.spec_surv_force = (int)v;
+    else if (k == "spec_surv_force" && v >= -1 && v <= 255) o.spec_surv_force = (int)v;      // (clamped to the last bin)
     else if (k == "spec_force" && v >= -1 && v <= 255) o.spec_force = (int)v;     // (clamped to maxww where it is used)
     else if (k == "risk_log2" && v >= 0 && v <= 60) o.risk_log2 = (int)v;
     else if (k == "tile_order" && (v == 0 || v == 1)) o.tile_order = (int)v;
@@ -644,7 +644,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     const size_t upt = std::max(GS.upt, GF.upt);
     const size_t etab_el = std::max<size_t>((size_t)plan.nsteps * 2 * (D + 1), 1);
     const size_t eedge_el = std::max<size_t>((size_t)2 * W * plan.nsteps * 2 * (D + 1), 1);
-    const int hbins = (opt.rounds <= -2) ? hpk_score_hist_bins(j->nsets) : 0;
+    const int hbins = (opt.rounds <= -2) ? hpk_score_hist_bins(j->nsets, plan.mode == HPK_MODE_BHFDR) : 0;
     j->rounds_eff = (opt.rounds <= -2) ? -100 - hbins : opt.rounds;
     j->gmax = j->do_score ? hpk_score_grid(plan.mode == HPK_MODE_BHFDR, plan.npairs, hbins, c->cus) : 0;
     j->bands.resize(nb);
@@ -915,7 +915,8 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
             for (int f = 0; f < HPK_NFAM; ++f) {
                 int kb = 255;
                 for (int i = 0; i < c->hint_bn; ++i) kb = std::min<int>(kb, c->hint_bin[i][f]);
-                km[f] = (uint8_t)std::max(0, std::min(kb, hbins - 1) - opt.spec_surv_margin);
+                // (margin in factor-4 bins; bhfdr's fine bins are four to the octave)
+                km[f] = (uint8_t)std::max(0, std::min(kb, hbins - 1) - opt.spec_surv_margin * (hbins > 16 ? 8 : 1));
             }
             have = true;
         }

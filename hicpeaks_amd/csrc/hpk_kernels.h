@@ -183,7 +183,7 @@ void hpk_launch_score(const HpkScoreArgs& a, const HpkBandDesc* d_bands, int nba
 // Benjamini-Hochberg cut tightening on the survivor lists: thr[f] <- sig * #{p <= thr[f]} / m[f], `rounds` times,
 // then compaction of the records with p <= thr[f] (count in the band's HPK_OFF_NOUT).
 int  hpk_thr_hist_bins(int nsets);       // bins per family of the one-pass tightening (rounds < 0)
-int  hpk_score_hist_bins(int nsets);     // bins per family of the histogram hpk_score keeps (rounds <= -100)
+int  hpk_score_hist_bins(int nsets, bool bhfdr);     // bins per family of the histogram hpk_score keeps (rounds <= -100): 8 | 4, bhfdr 64 fine ones
 void hpk_launch_tighten(const HpkBandDesc* d_bands, int nbands, double sig, int rounds, int nsets, const uint8_t* kmin, hipStream_t st);
 // result heads -> mapped pinned host memory: full = the whole head (no scoring ran), otherwise the stretches a chromosome fills
 void hpk_launch_publish(const HpkBandDesc* d_bands, int nbands, int nsets, bool full, size_t max_head_bytes, hipStream_t st);

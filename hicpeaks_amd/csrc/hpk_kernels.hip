@@ -1802,6 +1802,17 @@ __global__ void __launch_bounds__(256) hpk_poisson_sf_k(const double* __restrict
     if (i < count) out[i] = poisson_sf(k[i], lam[i], sfe);
 }
 
+// Fine p-value bins (bhfdr: one family of millions of tests per chromosome, whose cut the eight factor-4 bins of the
+// lambda-chunk families bracket only within a factor ~20: 55 000 records copied back for 3 300 pixels): four bins per
+// octave of x = sig / p, edges at 2^e x {1, 1.25, 1.5, 1.75}, the last bin open.  Any binning that is monotone in the
+// rounded quotient keeps the cut's bound an over-count (thr_table_hist) and the survivors' bound safe (hpk_thr_compact).
+#define HPK_FINE_BINS 64
+__device__ __forceinline__ int fine_bin(double x, int nbins) {
+    const unsigned long long xb = (unsigned long long)__double_as_longlong(x);
+    int k = ((int)((xb >> 52) & 0x7ff) - 1023) * 4 + (int)((xb >> 50) & 3ull);
+    k = (x == x) ? k : nbins - 1;                 // (0 / 0)
+    return k < 0 ? 0 : (k > nbins - 1 ? nbins - 1 : k);
+}
 // ------------------------------------------------------------------ scoring
 // local expected of a pixel at its resolving step: table value in the interior; within maxww of the first rows or the
 // last columns the window is clipped by the matrix end (callers.py:50-96 padding) and the value comes from the edge
@@ -2255,6 +2266,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                                 k >>= HPK_HSHIFT;                                 // bins a factor 2^(2^HPK_HSHIFT) wide
                                 k = (pb >> 52) == 0ull ? hbins - 1 : k;
                                 k = k < 0 ? 0 : (k > hbins - 1 ? hbins - 1 : k);
+                                if (BH && hbins > 16) k = fine_bin(a.sig / p, hbins);     // (bhfdr: four bins per octave)
                                 if (chunk <= HPK_NB_TAB) atomicAdd(&lhist[(set * (HPK_NB_TAB + 1) + chunk) * hbins + k], 1u);
                                 else atomicAdd(&gptr(kb->cnt)[(set * (HPK_NB + 1) + chunk) * hbins + k], 1u);
                                 wr = k >= (int)lkmin[set * (HPK_NB + 1) + chunk];
@@ -2388,9 +2400,13 @@ __device__ __forceinline__ void thr_table_hist(double* lthr, const unsigned int*
         if (m && t0 > 0.0) {
             for (int it = 0; it < 2 * nbins; ++it) {
                 // largest k whose edge ref 2^-k is still >= t (with a margin for the rounding of the quotient)
-                int k = (int)((__double_as_longlong(ref / (t * (1.0 + 1e-12))) >> 52) & 0x7ff) - 1023;
-                if (absolute) k >>= HPK_HSHIFT;
-                k = k < 0 ? 0 : (k > nbins - 1 ? nbins - 1 : k);
+                int k;
+                if (absolute && nbins > 16) k = fine_bin(ref / (t * (1.0 + 1e-12)), nbins);
+                else {
+                    k = (int)((__double_as_longlong(ref / (t * (1.0 + 1e-12))) >> 52) & 0x7ff) - 1023;
+                    if (absolute) k >>= HPK_HSHIFT;
+                    k = k < 0 ? 0 : (k > nbins - 1 ? nbins - 1 : k);
+                }
                 unsigned long long c = 0ull;
                 for (int kk = k; kk < nbins; ++kk) c += hist[(size_t)i * nbins + kk];
                 const double tn = fmin(t, sig * ((double)c / (double)m) * (1.0 + 1e-9));
@@ -2461,6 +2477,7 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkBandDesc* __rest
             k >>= HPK_HSHIFT;
             k = (tb >> 52) == 0ull ? hb - 1 : k;
             k = k < 0 ? 0 : (k > hb - 1 ? hb - 1 : k);
+            if (hb > 16) k = fine_bin(sig / lthr[i], hb);
             if (fam_f[i] == 0u) k = hb - 1;                 // no p-value at or below sig: nothing to keep
             small[HPK_OFF_TBIN + i] = (unsigned char)k;
             if (kmin && fam_f[i] != 0u && k < (int)kmin[i]) *reinterpret_cast<unsigned*>(small + HPK_OFF_SPECFAIL) = 1u;
@@ -2709,7 +2726,7 @@ static int score_grid(int cus, size_t lds) {
     return cus * per_cu;
 }
 // bins per family of the p-value histogram hpk_score keeps (0 = none: HpkScoreArgs::hbins)
-int hpk_score_hist_bins(int nsets) { return nsets <= 6 ? 8 : 4; }
+int hpk_score_hist_bins(int nsets, bool bhfdr) { return bhfdr ? HPK_FINE_BINS : (nsets <= 6 ? 8 : 4); }
 static size_t score_lds(bool bhfdr, int npairs, int hbins) {
     const int nsets = bhfdr ? 1 : 2 * npairs;
     return (size_t)nsets * (HPK_NB_TAB + 1) * (size_t)hbins * 4;

@@ -526,7 +526,7 @@ def test_survivor_bound_from_the_previous_chromosomes(mode):
         o1 = c.score_host(other, None, None, None, prm, weight=ow)
         rs = c.submit_batch_host([dict(raw=raw, weight=weight), dict(raw=other, weight=ow), dict(raw=raw, weight=weight)], prm).results()
         _same_result(rs[0], first); _same_result(rs[2], first); _same_result(rs[1], o1)
-        c.set_option('spec_surv_force', 15)      # the last bin for every family: too narrow wherever a cut lies above it
+        c.set_option('spec_surv_force', 255)     # the last bin for every family: too narrow wherever a cut lies above it
         forced = c.score_host(raw, None, None, None, prm, weight=weight)
         assert forced.rescored
         _same_result(forced, first)
