@@ -160,7 +160,7 @@ def run_genome(args, cfg, ctx, rank, world, local, dist):
     group = len(bands) if args.group <= 0 else max(1, min(args.group, len(bands)))
 
     def light(R):         # what the report needs; holding every BandResult makes Python's cyclic GC slower pass after pass
-        return (R.timing['stencil'], R.band_px, R.ncand, int(sum(s['x'].size for s in R.sets)), int(R.redone), R.frozen_w)
+        return (R.timing['stencil'], R.band_px, R.ncand, R.nsig, int(R.redone), R.frozen_w, int(R.rescored))
 
     def submit(part, p):
         if args.host_inputs:
@@ -222,6 +222,8 @@ def run_genome(args, cfg, ctx, rank, world, local, dist):
                        # record bound = the widest freeze of the chromosomes collected before: chromosomes of
                        # the last pass that froze later and were computed once more, and the widths they froze at
                        'redone_in_full_rank0': int(sum(t[4] for t in last)), 'frozen_w_rank0': sorted(set(t[5] for t in last)),
+                       # ... and chromosomes whose Benjamini-Hochberg cut lay above the bound of their survivor records
+                       'rescored_rank0': int(sum(t[6] for t in last)),
                        'parallelism': 'chromosomes dealt largest-first to the GPUs, no collective',
                        'whole_genome_wall_ms': elapsed / args.steps * 1e3, 'host_inputs': bool(args.host_inputs)},
             'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil_s', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -412,6 +414,7 @@ def main():
         del done[:]
         done.append(rs[-1])              # the report needs the kernel times (below) and one result, not all of them
         nredone[0] += sum(int(r.redone) for r in rs)
+        nrescored[0] += sum(int(r.rescored) for r in rs)
         st = sum(r.timing['stencil'] for r in rs)        # the group's launch: its chromosomes' shares add up to it
         if st > 0:
             stencil_ms.append(st)
@@ -427,7 +430,7 @@ def main():
         return done
 
     stencil_ms = []
-    nredone = [0]
+    nredone, nrescored = [0], [0]
     R = None
     run(depth)              # set-up, not a step: every lane allocates its workspaces (GBs on the large configurations) once
     for R in run(max(args.warmup, 1) * batch // group if args.warmup > 0 else 0):
@@ -440,12 +443,12 @@ def main():
 
     barrier()
     del stencil_ms[:]
-    nredone[0] = 0
+    nredone[0] = nrescored[0] = 0
     t0 = time.perf_counter()
     results = run(args.steps * batch // group)
     barrier()
     elapsed = time.perf_counter() - t0
-    nredone_timed = nredone[0]
+    nredone_timed, nrescored_timed = nredone[0], nrescored[0]
     assert len(stencil_ms) >= args.steps * batch // group // TIMED_EVERY
     stencil_ms = list(stencil_ms)
     R = results[-1]
@@ -486,6 +489,7 @@ def main():
                        # candidates resolved beyond the width the widening freezes at are dropped by the scoring kernel; the
                        # stencil leaves their records out, bounded by the previous pass's frozen width (HPK_SPEC=0: no bound)
                        'record_bound_w': R.record_bound, 'frozen_w': R.frozen_w, 'passes_redone_in_full': nredone_timed,
+                       'passes_rescored': nrescored_timed,
                        'parallelism': 'one chromosome per GPU, no collective', 'pipeline_depth': depth,
                        'sync_call_ms': float(np.median(lat)) if lat else None,
                        'stencil_only': bool(args.stencil_only), 'host_inputs': bool(args.host_inputs), 'balanced_f64': bool(args.balanced_f64)},
