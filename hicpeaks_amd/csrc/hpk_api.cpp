@@ -697,7 +697,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         if (derive || !bands[b].on_device) { tot_ir += ((size_t)num + 31) / 32 * 32; tot_n += ((size_t)n + 31) / 32 * 32; }
         off_ps[b] = tot_ps;
         if (derive) {
-            tot_ps += (size_t)((n + 31) / 32) * num;       // HPK_IR_ROWS rows per partial (hpk_launch_prep)
+            tot_ps += (size_t)((n + 31) / 32) * num;       // room for one partial per 32 rows (hpk_ir_partial takes 128 per partial)
             max_dn = std::max(max_dn, n); max_dnum = std::max(max_dnum, num);
         }
         off_rawel[b] = tot_rawel; off_hn[b] = tot_hn;

@@ -1597,42 +1597,78 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
 // IR[d] = mean over diagonal d of the balanced values, where *stored* (non-zero) pixels in masked bins are NaN and
 // are left out of both sum and count, while unstored pixels count as 0 even in masked bins.  Deterministic
 // two-level reduction: workgroup b sums rows [b * HPK_IR_ROWS, ...) per diagonal (lanes = diagonals, coalesced),
-// hpk_ir_final adds the partials of one diagonal with 64 lanes in a fixed order.  blockIdx.z = band of the batch.
-#define HPK_IR_ROWS 32
+// hpk_ir_final adds the partials of one diagonal in a fixed order (eight threads, then their eight sums).  blockIdx.z = band of the batch.
+#define HPK_IR_ROWS 128                             // rows per partial sum (hpk_api.cpp sizes psum / pnan for 32: an upper bound)
+#define HPK_IR_KPT 8                                // diagonals per thread: a workgroup covers 2048 diagonals of its rows
+// A workgroup sums 128 whole band rows (their stored diagonals in chunks of 2048: every row is read as one contiguous
+// stretch, 8 KB at num = 2011) - thread t takes the diagonals t, t + 256, ... and keeps their sums in registers; the
+// column weights of the window, weight[rbeg + k + j], sit in LDS.  (Round 2's version gave a workgroup 256 diagonals of
+// 32 rows - 1 KB per row, the rest of the row read by seven other workgroups at other times - and fetched the column
+// weight of every pixel from the cache: 1.7 TB/s, 2.9 ms of a whole genome @5 kb's 7.6; 16-byte loads - four consecutive
+// diagonals per thread - were tried on top and were no faster.)  Sums run over the rows in ascending order.
 __global__ void __launch_bounds__(256) hpk_ir_partial(const HpkBandDesc* __restrict__ bands, int mw) {
     const HpkBandDesc* __restrict__ bd = bands + blockIdx.z;
     if (!bd->derive) return;
     const int n = bd->n, num = bd->num;
     const int64_t ld = bd->ld;
     const int rbeg = blockIdx.x * HPK_IR_ROWS;
-    if (rbeg >= n) return;
+    const int k0 = mw + (int)blockIdx.y * (256 * HPK_IR_KPT);
+    if (rbeg >= n || k0 >= num) return;
+    const int kend = (k0 + 256 * HPK_IR_KPT < num) ? k0 + 256 * HPK_IR_KPT : num;
     const float* __restrict__ raw = gptr(bd->raw);
     const double* __restrict__ weight = gptr(bd->weight);
     double* __restrict__ psum = gptr(bd->psum);
     unsigned* __restrict__ pnan = gptr(bd->pnan);
     __shared__ double wrow[HPK_IR_ROWS];
+    __shared__ double wwin[256 * HPK_IR_KPT + HPK_IR_ROWS];      // weight[rbeg + k0 + i]
     if ((int)threadIdx.x < HPK_IR_ROWS) wrow[threadIdx.x] = (rbeg + (int)threadIdx.x < n) ? weight[rbeg + threadIdx.x] : 0.0;
+    for (int i = threadIdx.x; i < kend - k0 + HPK_IR_ROWS; i += 256) {
+        const int c = rbeg + k0 + i;
+        wwin[i] = c < n ? weight[c] : 0.0;
+    }
     __syncthreads();
-    // one diagonal per thread: blockIdx.y walks the diagonals in chunks of 256 (wide bands would otherwise leave one
-    // wave per SIMD looping over eight diagonals each)
-    for (int k = mw + blockIdx.y * blockDim.x + threadIdx.x; k < num; k += gridDim.y * blockDim.x) {
-        double s = 0.0;
-        unsigned nn = 0u;
-        int rows = n - k - rbeg;                    // rows of this group that still have column r + k inside the matrix
-        rows = rows > HPK_IR_ROWS ? HPK_IR_ROWS : rows;
-        const float* __restrict__ src = raw + (int64_t)rbeg * ld + k;
-        const double* __restrict__ wc = weight + rbeg + k;
-#pragma unroll 8
-        for (int j = 0; j < rows; ++j) {
-            const float cnt = src[(int64_t)j * ld];
-            const double b = ((double)cnt * wrow[j]) * wc[j];
-            if (cnt != 0.f) { if (b == b) s += b; else ++nn; }
+    double s[HPK_IR_KPT];
+    unsigned nn[HPK_IR_KPT];
+#pragma unroll
+    for (int q = 0; q < HPK_IR_KPT; ++q) { s[q] = 0.0; nn[q] = 0u; }
+    const int kt = k0 + (int)threadIdx.x;
+    const float* __restrict__ src = raw + (int64_t)rbeg * ld + kt;
+    if (rbeg + HPK_IR_ROWS + kend <= n && kend - k0 == 256 * HPK_IR_KPT) {
+        // every row of the group holds every diagonal of the chunk: no tests
+#pragma unroll 4
+        for (int j = 0; j < HPK_IR_ROWS; ++j) {
+            const double wr = wrow[j];
+#pragma unroll
+            for (int q = 0; q < HPK_IR_KPT; ++q) {
+                const float cnt = src[(int64_t)j * ld + 256 * q];
+                const double b = ((double)cnt * wr) * wwin[(int)threadIdx.x + 256 * q + j];
+                if (cnt != 0.f) { if (b == b) s[q] += b; else ++nn[q]; }
+            }
         }
-        psum[(int64_t)blockIdx.x * num + k] = s;
-        pnan[(int64_t)blockIdx.x * num + k] = nn;
+    } else {
+#pragma unroll 2
+        for (int j = 0; j < HPK_IR_ROWS; ++j) {
+            const double wr = wrow[j];
+#pragma unroll
+            for (int q = 0; q < HPK_IR_KPT; ++q) {
+                const int k = kt + 256 * q;
+                // rows of this group that still have column r + k inside the matrix: j < n - k - rbeg
+                const bool in = k < kend && rbeg + j + k < n;
+                const float cnt = in ? src[(int64_t)j * ld + 256 * q] : 0.f;
+                const double b = ((double)cnt * wr) * wwin[in ? (int)threadIdx.x + 256 * q + j : 0];
+                if (cnt != 0.f) { if (b == b) s[q] += b; else ++nn[q]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < HPK_IR_KPT; ++q) {
+        const int k = kt + 256 * q;
+        if (k < kend) {
+            psum[(int64_t)blockIdx.x * num + k] = s[q];
+            pnan[(int64_t)blockIdx.x * num + k] = nn[q];
+        }
     }
 }
-// one wave per diagonal, four diagonals per workgroup
 // Workgroups beyond the diagonals turn the weights into biases (scripts/pyHICCUPS:163-166) - one launch less.
 __global__ void __launch_bounds__(256) hpk_ir_final(const HpkBandDesc* __restrict__ bands, int mw, int nirb) {
     const HpkBandDesc* __restrict__ bd = bands + blockIdx.y;
@@ -1646,17 +1682,22 @@ __global__ void __launch_bounds__(256) hpk_ir_final(const HpkBandDesc* __restric
         }
         return;
     }
-    const int lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (k >= num) return;
+    // 32 consecutive diagonals per workgroup (the partials of one row group are read as 256 contiguous bytes), eight
+    // threads per diagonal that each walk every eighth row group; their sums are added in a fixed order
+    const int kl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + kl;
     const int nparts = (n + HPK_IR_ROWS - 1) / HPK_IR_ROWS;
     const double* __restrict__ psum = gptr(bd->psum);
     const unsigned* __restrict__ pnan = gptr(bd->pnan);
     double s = 0.0;
     unsigned long long nn = 0ull;
-    if (k >= mw) for (int p = lane; p < nparts; p += 64) { s += psum[(int64_t)p * num + k]; nn += pnan[(int64_t)p * num + k]; }
-    for (int off = 32; off > 0; off >>= 1) { s += __shfl_down(s, off); nn += __shfl_down(nn, off); }
-    if (lane != 0) return;
+    if (k >= mw && k < num) for (int p = pl; p < nparts; p += 8) { s += psum[(int64_t)p * num + k]; nn += pnan[(int64_t)p * num + k]; }
+    __shared__ double ls[8][32];
+    __shared__ unsigned long long ln[8][32];
+    ls[pl][kl] = s; ln[pl][kl] = nn;
+    __syncthreads();
+    if (pl != 0 || k >= num) return;
+    for (int q = 1; q < 8; ++q) { s += ls[q][kl]; nn += ln[q][kl]; }
     const long long denom = (long long)(n - k) - (long long)nn;
     gptr(bd->IR)[k] = (k >= mw && n - k > 0) ? s / (double)denom : 0.0;       // 0/0 -> NaN like numpy's mean of an empty slice
 }
@@ -2776,8 +2817,8 @@ void hpk_launch_tighten(const HpkBandDesc* d_bands, int nbands, double sig, int 
 
 void hpk_launch_prep(const HpkBandDesc* d_bands, int nbands, int max_n, int max_num, int mw, hipStream_t st) {
     const int nparts = (max_n + HPK_IR_ROWS - 1) / HPK_IR_ROWS;        // hpk_api.cpp sizes psum / pnan with the same constant
-    const int nirb = (max_num + 3) / 4;
-    hipLaunchKernelGGL(hpk_ir_partial, dim3(nparts, (max_num - mw + 255) / 256, nbands), dim3(256), 0, st, d_bands, mw);
+    const int nirb = (max_num + 31) / 32;
+    hipLaunchKernelGGL(hpk_ir_partial, dim3(nparts, (max_num - mw + 256 * HPK_IR_KPT - 1) / (256 * HPK_IR_KPT), nbands), dim3(256), 0, st, d_bands, mw);
     hipLaunchKernelGGL(hpk_ir_final, dim3(nirb + (max_n + 255) / 256, nbands), dim3(256), 0, st, d_bands, mw, nirb);
 }
 
