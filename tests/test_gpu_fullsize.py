@@ -254,3 +254,39 @@ def test_full_size_chr1_vs_oracle(name, ctx):
     _check_against_oracle(Rs[1], fin2, det, want, pw, ww, sig)
     # (the chromosome before and after it are the same band: same result)
     assert Rs[0].ncand == Rs[2].ncand and [s['x'].size for s in Rs[0].sets] == [s['x'].size for s in Rs[2].sets]
+
+
+def test_full_size_chr1_bhfdr_vs_oracle(ctx):
+    """The sibling path at full size: pyBHFDR's defaults ((2,5), 2 Mb band) on chr1 @10 kb against the oracle's bhfdr() -
+    one Benjamini-Hochberg family of ~2.5 million tests per chromosome, whose cut the device brackets with 64 fine p-value
+    bins - as a first call (no bounds), again (record bound, halo and survivor bound taken over) and in a batch."""
+    n, res, maxww, maxapart, sig = 24896, 10000, 10, 2000000, 0.05
+    num = maxapart // res + maxww + 1
+    raw, weight, _ = synthetic.synth_band(n, num, depth=60.0, nloops=400, seed=2)
+    IR, cband, biases = orc.prep_from_band(raw, weight, 5)
+    kw = dict(pw=2, ww=5, sig=sig, maxww=maxww, maxapart=maxapart, res=res, min_marginal_peaks=2, onlyanchor=False)
+    want = orc.bhfdr(raw, cband, biases, biases, IR, n, num, **kw)
+    assert len(want) >= 10
+    kwant, vwant = _arrays(want)
+    rawf = raw.astype(np.float32)
+    c = _lib.Context(0)
+    try:
+        for rnd in range(2):
+            d = {}
+            got = callers.bhfdr_band(rawf, IR, biases, biases, chrom='1', weight=weight, ctx=c, detail=d, **kw)
+            k, v = _arrays(got)
+            np.testing.assert_array_equal(k, kwant)
+            np.testing.assert_allclose(v, vwant, rtol=1e-9, atol=1e-9)
+            R = d['result']
+            assert R.halo_w == (maxww if rnd == 0 else max(R.record_bound, 5)) and not R.redone
+            # the cut comes within the bins' resolution of the pixels reported: a few hundred records too many, not tens of thousands
+            assert R.nsurv_cut < 2 * R.nsig + 1000, (R.nsurv_cut, R.nsig)
+        prm = _lib.make_params(_lib.MODE_BHFDR, [2], [5], maxww, sig, maxapart, res, 16, 0)
+        Rs = c.submit_batch_host([dict(raw=rawf, weight=weight, num=num)] * 3, prm).results()
+        for R in Rs:
+            fin = callers._bhfdr_finisher(n, '1', 5, res, 2, False, None)(R)
+            k, v = _arrays(fin)
+            np.testing.assert_array_equal(k, kwant)
+            np.testing.assert_allclose(v, vwant, rtol=1e-9, atol=1e-9)
+    finally:
+        c.close()
