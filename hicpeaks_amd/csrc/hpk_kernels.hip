@@ -1801,10 +1801,15 @@ __device__ __forceinline__ double dpois(double x, double lam, const double* __re
 }
 // 1 - cdf(k; lam) formed like the reference forms it (1 - pdtr): through the cdf rounded to f64, so that the
 // far tail quantises to multiples of 2^-53 and reaches exactly 0.
-__device__ __noinline__ double poisson_sf(double k, double lam, const double* __restrict__ sfe) {
+// sigcap: the scoring kernel only asks "is p <= sig, and if so what is it".  For an integer k below lambda >= 1 the
+// survival is at least P(X >= 2; lambda = 1) = 1 - 2/e = 0.264 (the minimum over lambda >= 1 sits just above lambda = 1 with
+// k = 1), so with sig <= 0.25 such a pixel cannot pass and its lower sum - half of bhfdr's per-pixel series - is not
+// formed: any value above sig will do (1.0).  The table kernel and the test helper pass sigcap = 1: every value exact.
+__device__ __noinline__ double poisson_sf(double k, double lam, const double* __restrict__ sfe, double sigcap) {
     if (!(lam > 0.0)) return 0.0;
     if (k < 0.0) return 1.0;
     k = floor(k);
+    if (sigcap <= 0.25 && k < lam && lam >= 1.0) return 1.0;
     double cdf;
     if (k < lam) {                         // lower sum, terms shrink going down from k
         // (a pmf that underflowed to 0 stays 0 all the way down: without the t > 0 test such a lane - k thousands below a
@@ -1833,14 +1838,14 @@ __global__ void __launch_bounds__(256) hpk_ptab(const double* __restrict__ bound
     int ch = 1;
     while (ch < HPK_NB_TAB && i >= off[ch + 1]) ++ch;      // off[ch] .. off[ch+1]-1 belong to chunk ch (1-based)
     const double k = (double)(i - off[ch]);
-    ptab[i] = poisson_sf(k, bounds[ch - 1], sfe);
+    ptab[i] = poisson_sf(k, bounds[ch - 1], sfe, 1.0);
 }
 
 __global__ void __launch_bounds__(256) hpk_poisson_sf_k(const double* __restrict__ k, const double* __restrict__ lam,
                                                         const double* __restrict__ sfe, double* __restrict__ out,
                                                         int64_t count) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) out[i] = poisson_sf(k[i], lam[i], sfe);
+    if (i < count) out[i] = poisson_sf(k[i], lam[i], sfe, 1.0);
 }
 
 // Fine p-value bins (bhfdr: one family of millions of tests per chromosome, whose cut the eight factor-4 bins of the
@@ -2199,7 +2204,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                     if (more) issue_round2(gn);                 // (bhfdr: one pair; the series below is all arithmetic)
                     if (eK > 0.0) {
                         chunk2[0] = 1;
-                        p2[0] = poisson_sf(O, eK, const_cast<const double*>(ka->sfe));      // callers.py:536-540
+                        p2[0] = poisson_sf(O, eK, const_cast<const double*>(ka->sfe), a.sig);      // callers.py:536-540
                     }
                 } else {
                     // Chunk of E: boundaries lbounds[i] = 2^(i/3); membership is strict on both sides (callers.py:38), so E
@@ -2264,7 +2269,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                             if (tabd) p = (kO < len) ? a.ptab[(unsigned)(base + kO)] : 0.0;
                             const bool rare = inch && !tabd;                      // lambda > 2^15: beyond the table
                             if (__ballot(rare) != 0ull) {
-                                if (rare) p = poisson_sf(O, lbounds[chunk - 1], const_cast<const double*>(ka->sfe));   // callers.py:268-270
+                                if (rare) p = poisson_sf(O, lbounds[chunk - 1], const_cast<const double*>(ka->sfe), a.sig);   // callers.py:268-270
                             }
                             if (fl == 0) { chunk2[0] = chunk; p2[0] = p; } else { chunk2[1] = chunk; p2[1] = p; }
                         }

@@ -1,6 +1,6 @@
-cd /tmp && export TMPDIR=/tmp
-for lib in libhpk.so libhpk_exp_ir.so; do
-rm -rf /tmp/wg
-HPK_LIB=$GRAFT_REPO_ROOT/hicpeaks_amd/$lib rocprofv3 --kernel-trace --stats -d /tmp/wg -o k --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --config wg_5kb --steps 4 --warmup 1 --cpu-rows 0 > /tmp/wg.log 2>&1
-f=$(find /tmp/wg -name "*kernel_stats.csv" | head -1); echo $lib; grep "hpk_ir_partial" $f | cut -c1-140
-done
+cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -3
+python bench.py --config chr1_10kb_bhfdr --steps 5 --warmup 2 --cpu-rows 0 2>&1 | tail -1 | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); c=d['config']
+print('bhfdr value %.4g ms/chrom %.4f sig %s copied %s' % (d['value'], c['ms_per_chromosome'], c['significant_px'], c['records_copied_back']), {k: round(v,4) for k,v in d['phases_ms'].items()})"
