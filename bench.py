@@ -272,7 +272,7 @@ def main():
                          'and the clocks settle; the whole-genome configurations\' step is the 23-chromosome genome)')
     ap.add_argument('--group', type=int, default=0,
                     help='chromosomes per library call (hpk_submit_batch: one launch per stage for the whole group); 1 = chromosome '
-                         'by chromosome as in round 2; default: sized so that a group\'s workspaces stay below ~24 GB, at most 32; '
+                         'by chromosome as in round 2; default: sized so that a group\'s workspaces stay below ~60 GB (two groups are in flight: 288 GB of HBM), at most 64; '
                          'whole-genome configurations: the rank\'s whole share')
     ap.add_argument('--config', default='chr1_10kb', choices=sorted(CONFIGS))
     ap.add_argument('--cpu-rows', type=int, default=1 << 30,
@@ -387,7 +387,7 @@ def main():
     # chromosomes per library call: the records and survivor regions of a group live side by side in HBM
     tiles = -(-n // 59) * -(-(59 + D - mw) // 107)
     per_band = tiles * 6313 * (4 + 17 * len(set(cfg['pw']))) + 2 * 40 * band.band_pixels(n, num, mw, D) * 2 * len(cfg['pw']) // 6
-    group = args.group if args.group > 0 else max(1, min(32, int(24e9 // per_band)))
+    group = args.group if args.group > 0 else max(1, min(64, int(60e9 // per_band)))
     batch = args.batch if args.batch > 0 else (1280 if n * num <= 60_000_000 else 16)
     batch = max(group, batch // group * group)          # whole groups
 

@@ -15,9 +15,9 @@ timeout 600 python bench.py --balanced-f64 --steps 5 --warmup 1 --cpu-rows 0 2>/
 HPK_SPEC=0 timeout 600 python bench.py --cpu-rows 0 2>/dev/null | tail -1 > $OUT/bench_chr1_10kb_no_record_bound.json
 timeout 600 python bench.py --host-inputs --steps 3 --warmup 1 --batch 20 --cpu-rows 0 2>/dev/null | tail -1 > $OUT/bench_chr1_10kb_host_inputs.json
 cd /tmp && export TMPDIR=/tmp
-# kernel trace of the default command's launch shape: every stencil / scoring launch carries a whole group of 32
+# kernel trace of the default command's launch shape: every stencil / scoring launch carries a whole group of 64
 # chromosomes (--no-probes leaves the single-chromosome probes out), so the averages are those of bench.json's kernel_ms
-PB="--steps 30 --warmup 1 --batch 64 --group 32 --cpu-rows 0 --no-probes"
+PB="--steps 20 --warmup 1 --batch 128 --group 64 --cpu-rows 0 --no-probes"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o k --output-format csv -- python $R/bench.py $PB > $OUT/trace.log 2>&1
 # HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes, launches of G chromosomes (collect_profiles.py divides by G)
 for c in chr1_10kb chr1_10kb_union chr1_5kb deep_1kb; do
