@@ -8,7 +8,7 @@ scripts/pyHICCUPS:139-166, and of the Pool.map loop at :192-198):
 and the command line itself (scripts/pyHICCUPS) on the same file.  The file is written by scripts/make_cool.py (plain
 h5py under /opt/conda: the `cooler` package is not in this image) from the synthetic genome at 5 kb, 10 Mb band
 (num = 2011 stored diagonals) - by default chr1, chr21 and chrX (90 343 of the genome's 617 665 bins: the file for all
-23 chromosomes takes ~25 min to write), extrapolated to the genome by bins.
+23 chromosomes takes ~40 s to write: --chroms 1 2 ... 22 X, profiles/r03_host_e2e_wg.txt), extrapolated to the genome by bins.
 
     python scripts/host_e2e.py [--chroms 1 21 X] [--res 5000] [--file /tmp/hpk_e2e.mcool] > profiles/r03_host_e2e.txt
 """
