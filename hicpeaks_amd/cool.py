@@ -44,6 +44,7 @@ class _H5C(object):
     whatever the file holds, enums included), whole or as a [start, stop) slice of the first dimension."""
 
     _lib = None
+    _pool, _pool_n = None, 0            # decoding threads of read_big
 
     @classmethod
     def lib(cls):
@@ -75,7 +76,19 @@ class _H5C(object):
                    H5Aexists_by_name=(C.c_int, [hid, C.c_char_p, C.c_char_p, hid]),
                    H5Aopen_by_name=(hid, [hid, C.c_char_p, C.c_char_p, hid, hid]), H5Aread=(he, [hid, hid, C.c_void_p]),
                    H5Aget_type=(hid, [hid]), H5Aclose=(he, [hid]), H5Lexists=(C.c_int, [hid, C.c_char_p, hid]),
-                   H5Eset_auto2=(he, [hid, C.c_void_p, C.c_void_p]))
+                   H5Eset_auto2=(he, [hid, C.c_void_p, C.c_void_p]),
+                   H5Dget_create_plist=(hid, [hid]), H5Pclose=(he, [hid]), H5Pget_layout=(C.c_int, [hid]),
+                   H5Pget_chunk=(C.c_int, [hid, C.c_int, C.POINTER(hs)]), H5Pget_nfilters=(C.c_int, [hid]),
+                   H5Pget_filter2=(C.c_int, [hid, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_size_t), C.POINTER(C.c_uint),
+                                             C.c_size_t, C.c_char_p, C.POINTER(C.c_uint)]),
+                   H5Tget_sign=(C.c_int, [hid]), H5Tget_order=(C.c_int, [hid]))
+        # raw chunk access (HDF5 >= 1.10.5): lets the gzip streams of a big read be inflated on several threads
+        cls.have_chunks = all(hasattr(L, f) for f in ('H5Dget_chunk_info_by_coord', 'H5Dread_chunk'))
+        if cls.have_chunks:
+            L.H5Dget_chunk_info_by_coord.restype = he
+            L.H5Dget_chunk_info_by_coord.argtypes = [hid, C.POINTER(hs), C.POINTER(C.c_uint), C.POINTER(hs), C.POINTER(hs)]
+            L.H5Dread_chunk.restype = he
+            L.H5Dread_chunk.argtypes = [hid, hid, C.POINTER(hs), C.POINTER(C.c_uint32), C.c_void_p]
         for name, (res, args) in sig.items():
             f = getattr(L, name)
             f.restype, f.argtypes = res, args
@@ -178,6 +191,80 @@ class _H5C(object):
         finally:
             L.H5Dclose(d)
 
+    PARALLEL_MIN = 1 << 20          # elements from which a read goes chunk by chunk (below: one H5Dread)
+
+    def read_big(self, name, start, stop, kind, threads=None):
+        """`read` for the long slices of the pixel table: the data set's chunks are fetched as stored (H5Dread_chunk: the
+        library itself is not thread-safe, so this part stays serial - it is a copy out of the page cache) and inflated /
+        un-shuffled on a thread pool (zlib and numpy release the GIL).  cooler writes its columns gzip-compressed with the
+        shuffle filter in chunks; the decoding is 90 % of what reading a chromosome costs.  Anything unexpected - another
+        filter, big-endian data, an old libhdf5 - falls back to `read`."""
+        import zlib
+        from concurrent.futures import ThreadPoolExecutor
+        L = self.lib()
+        if not self.have_chunks or stop - start < self.PARALLEL_MIN:
+            return self.read(name, start, stop, kind)
+        d = self._open(name)
+        try:
+            pl = L.H5Dget_create_plist(d)
+            cs = (C.c_uint64 * 4)()
+            ok = pl >= 0 and L.H5Pget_layout(pl) == 2 and L.H5Pget_chunk(pl, 4, cs) == 1        # H5D_CHUNKED, rank 1
+            filt = []
+            if ok:
+                for i in range(L.H5Pget_nfilters(pl)):
+                    flags, ne, cfg = C.c_uint(0), C.c_size_t(0), C.c_uint(0)
+                    filt.append(L.H5Pget_filter2(pl, i, C.byref(flags), C.byref(ne), None, 0, None, C.byref(cfg)))
+            if pl >= 0:
+                L.H5Pclose(pl)
+            ft = L.H5Dget_type(d)
+            tcls, size = L.H5Tget_class(ft), int(L.H5Tget_size(ft))
+            signed = L.H5Tget_sign(ft) != 0 if tcls in (0, 8) else True
+            little = L.H5Tget_order(ft) == 0
+            L.H5Tclose(ft)
+            ok = ok and filt in ([1], [2, 1]) and little and tcls in (0, 1, 8) and size in (1, 2, 4, 8)     # deflate | shuffle + deflate
+            if not ok:
+                return self.read(name, start, stop, kind)
+            if kind is None:
+                kind = 'f' if tcls == 1 else 'i'
+            dt = np.dtype(('<f%d' % size) if tcls == 1 else ('<%s%d' % ('i' if signed else 'u', size)))
+            cs = int(cs[0])
+            shuffle = filt[0] == 2
+            raws = []
+            for ci in range(start // cs, (stop - 1) // cs + 1):
+                off = (C.c_uint64 * 1)(ci * cs)
+                mask, addr, nbytes = C.c_uint(0), C.c_uint64(0), C.c_uint64(0)
+                if L.H5Dget_chunk_info_by_coord(d, off, C.byref(mask), C.byref(addr), C.byref(nbytes)) < 0 or mask.value != 0 \
+                        or nbytes.value == 0:
+                    return self.read(name, start, stop, kind)
+                buf = C.create_string_buffer(nbytes.value)
+                fm = C.c_uint32(0)
+                if L.H5Dread_chunk(d, 0, off, C.byref(fm), buf) < 0 or fm.value != 0:
+                    return self.read(name, start, stop, kind)
+                raws.append((ci, buf))
+        finally:
+            L.H5Dclose(d)
+        out = np.empty(stop - start, dtype=np.int64 if kind == 'i' else np.float64)
+
+        def decode(item):
+            ci, buf = item
+            b = zlib.decompress(buf)
+            a = np.frombuffer(b, dtype=np.uint8)
+            if shuffle and size > 1:
+                a = np.ascontiguousarray(a.reshape(size, -1).T).reshape(-1)
+            v = a.view(dt)
+            lo, hi = max(start, ci * cs), min(stop, ci * cs + cs)
+            out[lo - start:hi - start] = v[lo - ci * cs:hi - ci * cs]
+
+        nthr = threads or min(8, os.cpu_count() or 1)
+        if nthr > 1 and len(raws) > 1:
+            if _H5C._pool is None or _H5C._pool_n != nthr:
+                _H5C._pool, _H5C._pool_n = ThreadPoolExecutor(nthr), nthr
+            list(_H5C._pool.map(decode, raws))
+        else:
+            for it in raws:
+                decode(it)
+        return out
+
     def attr(self, obj, name, default=None):
         """Scalar integer / float / boolean-like attribute of the group (obj = '.') or of a data set."""
         L = self.lib()
@@ -222,6 +309,9 @@ class _H5Py(object):
         if v.dtype.kind in 'SO':
             return [x.decode() if isinstance(x, bytes) else str(x) for x in v]
         return v.astype(np.float64 if (kind == 'f' or (kind is None and v.dtype.kind == 'f')) else np.int64)
+
+    def read_big(self, name, start, stop, kind, threads=None):
+        return self.read(name, start, stop, kind)
 
     def attr(self, obj, name, default=None):
         o = self.g if obj == '.' else self.g[obj]
@@ -282,9 +372,9 @@ class CoolFile(object):
         lo, hi = self.extent(chrom)
         off = self.h.read('indexes/bin1_offset', lo, hi + 1, kind='i')
         p0, p1 = int(off[0]), int(off[-1])
-        b1 = self.h.read('pixels/bin1_id', p0, p1, kind='i')
-        b2 = self.h.read('pixels/bin2_id', p0, p1, kind='i')
-        cnt = self.h.read('pixels/count', p0, p1)
+        b1 = self.h.read_big('pixels/bin1_id', p0, p1, 'i')
+        b2 = self.h.read_big('pixels/bin2_id', p0, p1, 'i')
+        cnt = self.h.read_big('pixels/count', p0, p1, None)
         keep = b2 < hi                                  # pixels are sorted by bin1: the trans ones have bin2 beyond the chromosome
         if not keep.all():
             b1, b2, cnt = b1[keep], b2[keep], cnt[keep]

@@ -105,3 +105,30 @@ def test_mcool_uri_and_errors(tmp_path):
     assert b1.min() >= 0 and b2.max() < 57 and np.all(b2 >= b1) and np.all(cnt > 0)
     assert np.all(np.diff(b1 * 1000 + b2) > 0)
     f.close()
+
+
+def test_chunkwise_reading_equals_h5dread():
+    """The pixel table of a big chromosome is read chunk by chunk (H5Dread_chunk) and inflated / un-shuffled on a thread pool
+    (cool._H5C.read_big); on the fixture every column is a single chunk, forced through that path here - whole and
+    partial ranges, integer and float columns - and compared with the library's own H5Dread."""
+    from hicpeaks_amd import cool
+    f = cool.CoolFile(COOL)
+    h = f.h
+    if not isinstance(h, cool._H5C) or not h.have_chunks:
+        pytest.skip('h5py backend or an HDF5 library without H5Dread_chunk')
+    old = h.PARALLEL_MIN
+    h.PARALLEL_MIN = 0
+    try:
+        n = h.shape('pixels/bin1_id')[0]
+        for name, kind in (('pixels/bin1_id', 'i'), ('pixels/bin2_id', 'i'), ('pixels/count', None), ('bins/weight', 'f')):
+            m = h.shape(name)[0]
+            for a, b in ((0, m), (3, m - 5), (m // 2, m // 2 + 1)):
+                np.testing.assert_array_equal(h.read_big(name, a, b, kind, threads=2), h.read(name, a, b, kind))
+        i, j, c = f.pixels('chrA')
+        h.PARALLEL_MIN = 1 << 60
+        i2, j2, c2 = f.pixels('chrA')
+        np.testing.assert_array_equal(i, i2); np.testing.assert_array_equal(j, j2); np.testing.assert_array_equal(c, c2)
+        assert n > 0
+    finally:
+        h.PARALLEL_MIN = old
+        f.close()
