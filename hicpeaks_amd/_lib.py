@@ -34,7 +34,8 @@ ERR_INVALID, ERR_HIP, ERR_NO_DEVICE, ERR_EMPTY_STEP, ERR_PLAN, ERR_NOMEM, ERR_BU
 ABI_SYMBOLS = ['hpk_create', 'hpk_destroy', 'hpk_last_error', 'hpk_abi_version', 'hpk_score_band',
                'hpk_pipeline_depth', 'hpk_submit_band', 'hpk_collect', 'hpk_submit_batch', 'hpk_collect_batch', 'hpk_set_option',
                'hpk_result_free', 'hpk_plan_rings', 'hpk_chunk_bounds', 'hpk_set_chunk_bounds',
-               'hpk_device_info', 'hpk_poisson_sf', 'hpk_bruteforce_sums', 'hpk_probe_sums', 'hpk_band_from_coo']
+               'hpk_device_info', 'hpk_poisson_sf', 'hpk_bruteforce_sums', 'hpk_probe_sums', 'hpk_band_from_coo',
+               'hpk_devband_create', 'hpk_devband_free']
 
 
 class HpkError(RuntimeError):
@@ -157,6 +158,11 @@ def load():
     lib.hpk_band_from_coo.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                       C.c_int64, C.c_void_p]
     lib.hpk_band_from_coo.restype = C.c_int64
+    lib.hpk_devband_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(Band)]
+    lib.hpk_devband_create.restype = C.c_int64
+    lib.hpk_devband_free.argtypes = [C.c_void_p, C.c_void_p]
+    lib.hpk_devband_free.restype = None
     _lib = lib
     return lib
 
@@ -294,6 +300,24 @@ class BandResult(object):
             self._release()
         except Exception:
             pass
+
+
+class DeviceBand(object):
+    """One chromosome's band built in device memory from its pixel table (hpk_devband_create): what travels over the bus is
+    the pixels, not the dense band.  `band` goes into Context.submit / submit_batch; the memory is handed back when this
+    object goes (keep it until the job that uses it has been collected - BatchJob / Job do, through `keep`)."""
+
+    def __init__(self, ctx, handle, band, stored):
+        self.ctx, self.handle, self.band, self.stored = ctx, handle, band, int(stored)
+        self.shape = (int(band.n), int(band.num))
+        self.nbytes = 4 * int(band.n) * int(band.ld)
+
+    def close(self):
+        h, self.handle = self.handle, None
+        if h is not None and getattr(self.ctx, 'h', None):
+            self.ctx.lib.hpk_devband_free(self.ctx.h, h)
+
+    __del__ = close
 
 
 class Job(object):
@@ -444,6 +468,27 @@ class Context(object):
         bd = self._band(n, num, ld, raw.ctypes.data, balp, wp, irp, b1p, b2p, False)
         return bd, keep
 
+    def devband(self, bin1, bin2, count, n, num, weight, bias=None):
+        """Pixels (bin1, bin2, count) of one chromosome, bins relative to its first bin, each pixel once in either
+        orientation -> DeviceBand (the GPU counterpart of band.band_from_coo; weights / biases as `hpk_band` takes them)."""
+        i = np.ascontiguousarray(bin1, dtype=np.int64)
+        j = np.ascontiguousarray(bin2, dtype=np.int64)
+        v = np.asarray(count)
+        f64 = v.dtype.kind == 'f' or (v.size > 0 and v.dtype.itemsize >= 4 and v.dtype != np.int32 and
+                                      (int(v.max()) > 0x7fffffff or int(v.min()) < -0x80000000))
+        if v.size and float(v.max()) >= float(1 << 24):
+            raise ValueError('devband: a count of %g is beyond what the f32 band holds exactly (2^24)' % float(v.max()))
+        v = np.ascontiguousarray(v, dtype=np.float64 if f64 else np.int32)
+        w = np.ascontiguousarray(weight, dtype=np.float64)
+        b = None if bias is None else np.ascontiguousarray(bias, dtype=np.float64)
+        assert w.size == n and (b is None or b.size == n) and i.size == j.size == v.size
+        h, bd = C.c_void_p(), Band()
+        rc = self.lib.hpk_devband_create(self.h, i.ctypes.data, j.ctypes.data, v.ctypes.data, 1 if f64 else 0, i.size, int(n), int(num),
+                                         w.ctypes.data, None if b is None else b.ctypes.data, C.byref(h), C.byref(bd))
+        if rc < 0:
+            self._check(int(rc))
+        return DeviceBand(self, h, bd, rc)
+
     def score(self, band, params, n):
         res = C.POINTER(Result)()
         rc = self.lib.hpk_score_band(self.h, C.byref(band), C.byref(params), C.byref(res))
@@ -477,9 +522,15 @@ class Context(object):
         return BatchJob(self, job, ns, keep)
 
     def submit_batch_host(self, items, params):
-        """items: [dict(raw=, IR=, bias1=, bias2=, balanced=, weight=, num=), ...] of host arrays -> BatchJob (arrays kept alive)"""
+        """items: [dict(raw=, IR=, bias1=, bias2=, balanced=, weight=, num=), ...] of host arrays - or dict(raw=DeviceBand) -
+        -> BatchJob (arrays / device bands kept alive until the results are in)"""
         bands, keep, ns = [], [], []
         for it in items:
+            if isinstance(it.get('raw'), DeviceBand):           # built on the device from the pixel table: nothing to upload
+                bands.append(it['raw'].band)
+                keep.append(it['raw'])
+                ns.append(it['raw'].band.n)
+                continue
             bd, kp = self._host_band(it['raw'], it.get('IR'), it.get('bias1'), it.get('bias2'), it.get('balanced'), it.get('weight'),
                                      num_hint=it.get('num'))
             bands.append(bd)

@@ -124,6 +124,10 @@ struct hpk_ctx {
     bool tables_dirty = true;           // the Poisson table is (re)built before the first launch that needs it
     Lane lane[HPK_LANES];
     DevBuf tmpA, tmpB, tmpC, tmpD;
+    // hpk_devband_create: a stream of its own, staging buffers for the pixel table, and the bands handed back (kept for reuse)
+    hipStream_t aux = nullptr;
+    DevBuf cooA, cooB, cooC;
+    std::vector<std::pair<size_t, void*>> pool;
     // The widths the widening froze at (freeze_replay) in the chromosomes collected last with these parameters: the next
     // stencil writes records up to the widest of them only (HpkBandDesc::wguess); a chromosome that freezes later is
     // redone in full.
@@ -331,8 +335,11 @@ void hpk_destroy(hpk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DevBuf* all[] = {&c->d_bounds, &c->d_off, &c->d_sfe, &c->d_ptab, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD};
+    DevBuf* all[] = {&c->d_bounds, &c->d_off, &c->d_sfe, &c->d_ptab, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD, &c->cooA, &c->cooB, &c->cooC};
     for (DevBuf* b : all) b->release();
+    for (auto& e : c->pool) (void)hipFree(e.second);
+    c->pool.clear();
+    if (c->aux) { (void)hipStreamDestroy(c->aux); c->aux = nullptr; }
     for (int l = 0; l < HPK_LANES; ++l) c->lane[l].release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1409,6 +1416,88 @@ int64_t hpk_band_from_coo(const int64_t* bin1, const int64_t* bin2, const void* 
         ++stored;
     }
     return stored;
+}
+
+struct hpk_devband { float* raw = nullptr; double* weight = nullptr; double* bias = nullptr; size_t raw_bytes = 0, w_bytes = 0; };
+
+namespace {
+// Device memory of the band builder: freed blocks are kept and handed out again (hipFree synchronises the device, which
+// would stall the batch in flight; a genome's chromosomes come largest first, so a freed band fits the next ones).
+hipError_t pool_alloc(hpk_ctx* c, size_t bytes, void** p, size_t* got) {
+    size_t best = (size_t)-1;
+    for (size_t i = 0; i < c->pool.size(); ++i)
+        if (c->pool[i].first >= bytes && (best == (size_t)-1 || c->pool[i].first < c->pool[best].first)) best = i;
+    if (best != (size_t)-1 && c->pool[best].first <= 2 * bytes + (1 << 20)) {
+        *p = c->pool[best].second; *got = c->pool[best].first;
+        c->pool.erase(c->pool.begin() + best);
+        return hipSuccess;
+    }
+    *got = bytes;
+    return hipMalloc(p, bytes);
+}
+void pool_free(hpk_ctx* c, void* p, size_t bytes) {
+    if (!p) return;
+    if (c && c->pool.size() < 64) c->pool.emplace_back(bytes, p);
+    else (void)hipFree(p);
+}
+}  // namespace
+
+int64_t hpk_devband_create(hpk_ctx* c, const int64_t* bin1, const int64_t* bin2, const void* count, int32_t count_f64, int64_t nnz,
+                           int32_t n, int32_t num, const double* weight, const double* bias, hpk_devband** out, hpk_band* band) {
+    if (!c) return HPK_ERR_INVALID;
+    if (!out || !band || !weight || nnz < 0 || n <= 0 || num <= 0 || (nnz > 0 && (!bin1 || !bin2 || !count)))
+        return fail(c, HPK_ERR_INVALID, "hpk_devband_create: bad arguments");
+    *out = nullptr;
+    (void)hipSetDevice(c->device);
+    if (!c->aux && hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess)
+        return fail(c, HPK_ERR_HIP, "hpk_devband_create: stream creation failed");
+    const int64_t ld = ((int64_t)num + 63) / 64 * 64;
+    hpk_devband* b = new hpk_devband();
+    auto run = [&]() -> int64_t {
+        // (on a stream of its own: the batches in flight on the compute stream are not waited for)
+        HIPCHK(c, pool_alloc(c, sizeof(float) * (size_t)n * (size_t)ld, reinterpret_cast<void**>(&b->raw), &b->raw_bytes));
+        HIPCHK(c, pool_alloc(c, sizeof(double) * (size_t)n * (bias ? 2 : 1), reinterpret_cast<void**>(&b->weight), &b->w_bytes));
+        if (bias) b->bias = b->weight + n;
+        HIPCHK(c, hipMemsetAsync(b->raw, 0, sizeof(float) * (size_t)n * (size_t)ld, c->aux));
+        HIPCHK(c, hipMemcpyAsync(b->weight, weight, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->aux));
+        if (bias) HIPCHK(c, hipMemcpyAsync(b->bias, bias, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, c->aux));
+        unsigned long long info[2] = {0ull, 0ull};
+        if (nnz > 0) {
+            const size_t cb = ((count_f64 ? 8 : 4) * (size_t)nnz + 7) / 8 * 8;
+            HIPCHK(c, c->cooA.reserve(8 * (size_t)nnz));
+            HIPCHK(c, c->cooB.reserve(8 * (size_t)nnz));
+            HIPCHK(c, c->cooC.reserve(cb + 16));
+            unsigned long long* d_info = reinterpret_cast<unsigned long long*>(static_cast<char*>(c->cooC.p) + cb);
+            HIPCHK(c, hipMemcpyAsync(c->cooA.p, bin1, 8 * (size_t)nnz, hipMemcpyHostToDevice, c->aux));
+            HIPCHK(c, hipMemcpyAsync(c->cooB.p, bin2, 8 * (size_t)nnz, hipMemcpyHostToDevice, c->aux));
+            HIPCHK(c, hipMemcpyAsync(c->cooC.p, count, (count_f64 ? 8 : 4) * (size_t)nnz, hipMemcpyHostToDevice, c->aux));
+            HIPCHK(c, hipMemsetAsync(d_info, 0, 16, c->aux));
+            hpk_launch_coo_scatter(c->cooA.as<int64_t>(), c->cooB.as<int64_t>(), c->cooC.p, count_f64 ? 1 : 0, nnz, n, num, ld, b->raw,
+                                   d_info, c->aux);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipMemcpyAsync(info, d_info, 16, hipMemcpyDeviceToHost, c->aux));
+        }
+        HIPCHK(c, hipStreamSynchronize(c->aux));
+        if (info[1]) return fail(c, HPK_ERR_INVALID, "hpk_devband_create: a bin outside [0, %d) (are the bins relative to the chromosome's first bin?)", n);
+        return (int64_t)info[0];
+    };
+    const int64_t rc = run();
+    if (rc < 0) { hpk_devband_free(c, b); return rc; }
+    std::memset(band, 0, sizeof(*band));
+    band->n = n; band->num = num; band->ld = ld;
+    band->raw = b->raw; band->weight = b->weight;
+    band->bias1 = b->bias; band->bias2 = b->bias;
+    band->on_device = 1;
+    *out = b;
+    return rc;
+}
+
+void hpk_devband_free(hpk_ctx* c, hpk_devband* b) {
+    if (!b) return;
+    if (c) (void)hipSetDevice(c->device);
+    pool_free(c, b->raw, b->raw_bytes);
+    pool_free(c, b->weight, b->w_bytes);
+    delete b;
 }
 
 int hpk_probe_sums(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, const int32_t* rows, const int32_t* cols,

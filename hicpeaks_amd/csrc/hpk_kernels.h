@@ -192,3 +192,6 @@ void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe
 void hpk_launch_poisson_sf(const double* k, const double* lam, const double* sfe, double* out, int64_t count,
                            hipStream_t st);
 void hpk_launch_brute(const HpkBruteArgs& a, hipStream_t st);
+// pixels of one chromosome -> zero-filled band (info[0] += stored pixels, info[1] = 1 on a bin outside [0, n))
+void hpk_launch_coo_scatter(const int64_t* bin1, const int64_t* bin2, const void* count, int count_f64, int64_t nnz, int n, int num,
+                            int64_t ld, float* raw, unsigned long long* info, hipStream_t st);

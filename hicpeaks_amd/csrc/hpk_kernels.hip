@@ -1593,6 +1593,28 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
 #endif
 }
 
+// ------------------------------------------------------------------ band from the pixel table (hpk_devband_create)
+// One pixel (bin1, bin2, count) per thread, scatter-added into the zero-filled band raw[n][ld]: counts are integers
+// below 2^24, so the f32 sums are exact whatever order the adds come in.  A bin outside [0, n) sets the error flag.
+__global__ void __launch_bounds__(256) hpk_coo_scatter(const int64_t* __restrict__ bin1, const int64_t* __restrict__ bin2,
+                                                       const void* __restrict__ count, int count_f64, int64_t nnz, int n, int num,
+                                                       int64_t ld, float* __restrict__ raw, unsigned long long* __restrict__ info) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long stored = 0ull;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nnz; t += stride) {
+        const int64_t i = bin1[t], j = bin2[t];
+        const int64_t a = i < j ? i : j, b = i < j ? j : i;
+        if (a < 0 || b >= n) { info[1] = 1ull; continue; }
+        const int64_t k = b - a;
+        if (k >= num) continue;                             // beyond the band
+        const float v = count_f64 ? (float)static_cast<const double*>(count)[t] : (float)static_cast<const int32_t*>(count)[t];
+        atomicAdd(&raw[a * ld + k], v);
+        ++stored;
+    }
+    for (int off = 32; off > 0; off >>= 1) stored += __shfl_down(stored, off);
+    if ((threadIdx.x & 63) == 0 && stored) atomicAdd(&info[0], stored);
+}
+
 // ------------------------------------------------------------------ 1-D expected IR[d] and biases (scripts/pyHICCUPS:149-166)
 // IR[d] = mean over diagonal d of the balanced values, where *stored* (non-zero) pixels in masked bins are NaN and
 // are left out of both sum and count, while unstored pixels count as 0 even in masked bins.  Deterministic
@@ -2885,6 +2907,14 @@ void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe
 void hpk_launch_poisson_sf(const double* k, const double* lam, const double* sfe, double* out, int64_t count,
                            hipStream_t st) {
     hipLaunchKernelGGL(hpk_poisson_sf_k, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, k, lam, sfe, out, count);
+}
+
+void hpk_launch_coo_scatter(const int64_t* bin1, const int64_t* bin2, const void* count, int count_f64, int64_t nnz, int n, int num,
+                            int64_t ld, float* raw, unsigned long long* info, hipStream_t st) {
+    if (nnz <= 0) return;
+    const int64_t blocks = (nnz + 255) / 256;
+    hipLaunchKernelGGL(hpk_coo_scatter, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, st, bin1, bin2, count, count_f64, nnz,
+                       n, num, ld, raw, info);
 }
 
 void hpk_launch_brute(const HpkBruteArgs& a, hipStream_t st) {

@@ -115,6 +115,25 @@ class CoolerSource(BandSource):
         lo, hi = self.clr.extent(chrom) if self.clr is not None else self.f.extent(chrom)
         return hi - lo
 
+    def fetch_pixels(self, chrom, weight_name='weight'):
+        """-> (bin1, bin2, count, n, weight f64 [n], biases f64 [n] or None): the pixel table itself, for the device-side band
+        builder (hpk_devband_create); same balancing conventions as `fetch`."""
+        if self.clr is not None:
+            from . import cool
+            lo, hi = self.clr.extent(chrom)
+            px = self.clr.matrix(balance=False, as_pixels=True, join=False).fetch(chrom)
+            i, j, cnt = px['bin1_id'].values - lo, px['bin2_id'].values - lo, px['count'].values
+            w = self.clr.bins().fetch(chrom)[weight_name].values.astype(np.float64)
+            divisive = weight_name in cool.DIVISIVE_NAMES
+        else:
+            lo, hi = self.f.extent(chrom)
+            i, j, cnt = self.f.pixels(chrom)
+            w, divisive = self.f.weights(chrom, weight_name)
+        if not divisive:
+            return i, j, cnt, hi - lo, w, None
+        wm, biases = _divisive(w)
+        return i, j, cnt, hi - lo, wm, biases
+
     def fetch(self, chrom, num, weight_name='weight'):
         """-> (raw f32 [n, num], weight f64 [n], biases f64 [n] or None)"""
         if self.clr is not None:
@@ -132,12 +151,18 @@ class CoolerSource(BandSource):
         raw = _band.band_from_coo(i, j, cnt, hi - lo, num, dtype=np.float32)
         if not divisive:
             return raw, w, None
-        with np.errstate(divide='ignore', invalid='ignore'):
-            ok = ~((w == 0) | np.isnan(w))
-            biases = np.zeros_like(w)
-            biases[ok] = 1.0 / w[ok]                    # scripts/pyHICCUPS:163-166 on the column as stored
-            wm = np.where(ok, 1.0 / np.where(ok, w, 1.0), np.nan)       # count / (w1 w2) as a product; masked bins stay NaN
+        wm, biases = _divisive(w)
         return raw, wm, biases
+
+
+def _divisive(w):
+    """a divisive weight column -> (the multiplicative weights 1 / column, the biases the reference forms from the column)"""
+    with np.errstate(divide='ignore', invalid='ignore'):
+        ok = ~((w == 0) | np.isnan(w))
+        biases = np.zeros_like(w)
+        biases[ok] = 1.0 / w[ok]                    # scripts/pyHICCUPS:163-166 on the column as stored
+        wm = np.where(ok, 1.0 / np.where(ok, w, 1.0), np.nan)       # count / (w1 w2) as a product; masked bins stay NaN
+    return wm, biases
 
 
 def open_source(path):

@@ -50,7 +50,10 @@ def stages(uri, chroms, a, ctx):
         i, j, cnt = src.f.pixels(key)
         w, _ = src.f.weights(key, 'weight')
         t1 = time.perf_counter()
-        raw = band.band_from_coo(i, j, cnt, hi - lo, num, dtype=np.float32)
+        if a.host_bands:        # dense band on the host (hpk_band_from_coo), uploaded with the call
+            raw = band.band_from_coo(i, j, cnt, hi - lo, num, dtype=np.float32)
+        else:                   # the pixel table goes to the GPU, the band is built there (hpk_devband_create)
+            raw, w = ctx.devband(i, j, cnt, hi - lo, num, w), None
         t2 = time.perf_counter()
         call = callers.hiccups_batch_submit([(c, raw, w, None)], pw=[a.pw], ww=[a.ww], maxww=a.maxww, sig=0.1, sumq=0.01,
                                             double_fold=1.75, single_fold=2, maxapart=a.maxapart, res=res, use_raw=False,
@@ -71,13 +74,14 @@ def main():
     ap.add_argument('--ww', type=int, default=7)
     ap.add_argument('--file', default='/tmp/hpk_e2e.mcool')
     ap.add_argument('--depth', type=float, default=25.0)
+    ap.add_argument('--host-bands', action='store_true', help='build the dense bands on the host (band_from_coo) instead of on the GPU')
     a = ap.parse_args()
     from hicpeaks_amd import _lib, synthetic
     num = a.maxapart // a.res + a.maxww + 1
     group = '/resolutions/%d' % a.res
     uri = '%s::%s' % (a.file, group)
-    print('# scripts/host_e2e.py: chromosomes %s @%d bp, band %d diagonals, (p, w) = (%d, %d)' % (
-        ' '.join(a.chroms), a.res, num, a.pw, a.ww))
+    print('# scripts/host_e2e.py: chromosomes %s @%d bp, band %d diagonals, (p, w) = (%d, %d); bands built on the %s' % (
+        ' '.join(a.chroms), a.res, num, a.pw, a.ww, 'host (band_s = hpk_band_from_coo)' if a.host_bands else 'GPU (band_s = hpk_devband_create: upload of the pixels + scatter)'))
     if not os.path.exists(a.file):
         t0 = time.perf_counter()
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
@@ -113,7 +117,8 @@ def main():
         cmd = [sys.executable, os.path.join(REPO, 'scripts', 'pyHICCUPS'), '-p', uri, '-O', outp, '--pw', str(a.pw), '--ww', str(a.ww),
                '--maxww', str(a.maxww), '--maxapart', str(a.maxapart), '-C'] + a.chroms + ['--logFile', '/tmp/hpk_e2e.log']
         t0 = time.perf_counter()
-        rc = subprocess.call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        rc = subprocess.call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                             env=dict(os.environ, **({'HPK_HOST_BANDS': '1'} if a.host_bands else {})))
         dt = time.perf_counter() - t0
         nl = sum(1 for _ in open(outp)) if rc == 0 and os.path.exists(outp) else -1
         print('## scripts/pyHICCUPS on the file, %s page cache: %.2f s wall, rc %d, %d BEDPE lines (x %.2f by bins: %.0f s for the genome on one GPU, '

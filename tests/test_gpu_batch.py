@@ -160,3 +160,43 @@ def test_fixture_in_the_middle_of_a_batch(name, ctx):
     got = ctx.submit_batch_host(items, prm).results(raise_on_error=False)
     assert not isinstance(got[1], Exception)
     _same(got[1], want)
+
+
+def test_device_band_builder_equals_host_band(ctx):
+    """hpk_devband_create (the pixel table goes to the GPU, the band is scattered together there) against the host
+    builder (band_from_coo + upload of the dense band): the same results bit for bit - pixels in either orientation,
+    repeated pixels adding up, pixels beyond the band, NaN weights, given biases (a divisive weight column); a bin outside
+    the chromosome is refused."""
+    from hicpeaks_amd import band as hband
+    res, maxapart, maxww = 10000, 600000, 10
+    num = maxapart // res + maxww + 1
+    prm = _lib.make_params(_lib.MODE_HICCUPS, [2], [5], maxww, 0.1, maxapart, res, 16, 0)
+    (raw, weight), (raw2, weight2) = _chroms([1500, 90], num, 60.0, 31)
+    weight = weight.copy(); weight[100:110] = np.nan
+    items_h, items_d = [], []
+    rng = np.random.default_rng(5)
+    for rw, w, bias in ((raw, weight, None), (raw2, weight2, None), (raw, weight, np.where(np.isnan(weight), 0.0, 1.0 / np.where(np.isnan(weight), 1.0, weight)))):
+        n = rw.shape[0]
+        r, k = np.nonzero(rw)
+        keep = r + k < n
+        r, k = r[keep], k[keep]
+        i, j, v = r.copy(), r + k, rw[r, k].astype(np.int32)
+        flip = rng.random(i.size) < 0.3                          # either orientation
+        i[flip], j[flip] = j[flip].copy(), i[flip].copy()
+        # a repeated pixel (its count split in two) and a pixel beyond the band
+        big = np.nonzero(v >= 2)[0][:50]
+        v2 = v.copy(); v2[big] -= 1
+        i2 = np.concatenate([i, i[big], [0]]); j2 = np.concatenate([j, j[big], [min(n - 1, num + 5)]]); v3 = np.concatenate([v2, np.ones(big.size, np.int32), [7]])
+        host = hband.band_from_coo(i2, j2, v3, n, num)
+        np.testing.assert_array_equal(host, np.where(np.arange(n)[:, None] + np.arange(num)[None, :] < n, rw, 0).astype(np.float32))
+        db = ctx.devband(i2, j2, v3, n, num, w, bias)
+        assert db.stored == int((np.abs(j2 - i2) < num).sum()) and db.shape == (n, num)
+        items_d.append(dict(raw=db))
+        items_h.append(dict(raw=host, weight=w, bias1=bias, bias2=bias, num=num))
+    got = ctx.submit_batch_host(items_d, prm).results()
+    want = ctx.submit_batch_host(items_h, prm).results()
+    for g, w in zip(got, want):
+        _same(g, w)
+    with pytest.raises(_lib.HpkError) as ei:
+        ctx.devband(np.array([0, 5]), np.array([3, 1500]), np.array([1, 1], dtype=np.int32), 1500, num, weight)
+    assert ei.value.status == _lib.ERR_INVALID
