@@ -127,7 +127,10 @@ def _fetch(args_dict, src, key, ctx=None):
     num = args_dict['maxapart'] // src.binsize + args_dict['maxww'] + 1
     if ctx is not None and hasattr(src, 'fetch_pixels') and not os.environ.get('HPK_HOST_BANDS'):
         i, j, cnt, n, w, b = src.fetch_pixels(key, args_dict['clr_weight_name'])
-        return key.lstrip('chr'), ctx.devband(i, j, cnt, n, num, w, b), None, None
+        if 20 * i.size <= 4 * n * num:          # (a band denser than one stored pixel in five cells is smaller than its pixel table)
+            return key.lstrip('chr'), ctx.devband(i, j, cnt, n, num, w, b), None, None
+        from . import band as _band
+        return key.lstrip('chr'), _band.band_from_coo(i, j, cnt, n, num, dtype='float32'), w, b
     raw, w, b = src.fetch(key, num, args_dict['clr_weight_name'])
     return key.lstrip('chr'), raw, w, b
 
