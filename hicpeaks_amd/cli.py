@@ -130,7 +130,7 @@ def _fetch(args_dict, src, key, ctx=None):
         if 20 * i.size <= 4 * n * num:          # (a band denser than one stored pixel in five cells is smaller than its pixel table)
             return key.lstrip('chr'), ctx.devband(i, j, cnt, n, num, w, b), None, None
         from . import band as _band
-        return key.lstrip('chr'), _band.band_from_coo(i, j, cnt, n, num, dtype='float32'), w, b
+        return key.lstrip('chr'), _band.band_from_coo(i, j, cnt, n, num), w, b
     raw, w, b = src.fetch(key, num, args_dict['clr_weight_name'])
     return key.lstrip('chr'), raw, w, b
 
