@@ -122,7 +122,7 @@ def main():
         dt = time.perf_counter() - t0
         nl = sum(1 for _ in open(outp)) if rc == 0 and os.path.exists(outp) else -1
         print('## scripts/pyHICCUPS on the file, %s page cache: %.2f s wall, rc %d, %d BEDPE lines (x %.2f by bins: %.0f s for the genome on one GPU, '
-              'reading and band building on one host core)' % (label, dt, rc, nl, scale, dt * scale))
+              'reading on up to 16 decoding threads)' % (label, dt, rc, nl, scale, dt * scale))
 
 
 def _have(mod):
