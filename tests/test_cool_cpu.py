@@ -132,3 +132,36 @@ def test_chunkwise_reading_equals_h5dread():
     finally:
         h.PARALLEL_MIN = old
         f.close()
+
+
+def test_chunkwise_reading_across_chunk_borders(tmp_path):
+    """A pixel table of several chunks (chr21 @5 kb of the synthetic genome, written by scripts/make_cool.py under the image's
+    conda python, which has h5py): ranges that start and end inside chunks, decoded on four threads, against H5Dread."""
+    import subprocess
+    from hicpeaks_amd import cool
+    conda = '/opt/conda/bin/python3.9'
+    if not os.path.exists(conda):
+        pytest.skip('no interpreter with h5py to write the file')
+    path = str(tmp_path / 'c21.mcool')
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rc = subprocess.call([conda, os.path.join(repo, 'scripts', 'make_cool.py'), path, '--genome', 'hg38', '--res', '5000', '--num', '2011',
+                          '--group', '/resolutions/5000', '--depth', '25', '--chroms', '21'], env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'),
+                         stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    if rc != 0:
+        pytest.skip('make_cool.py could not write the file here')
+    f = cool.CoolFile(path + '::/resolutions/5000')
+    h = f.h
+    if not isinstance(h, cool._H5C) or not h.have_chunks:
+        pytest.skip('h5py backend or an HDF5 library without H5Dread_chunk')
+    try:
+        n = h.shape('pixels/bin2_id')[0]
+        assert n > 3 * (1 << 18)                        # more than three chunks of 2^18 pixels
+        old, h.PARALLEL_MIN = h.PARALLEL_MIN, 0
+        for a, b in ((0, n), (5, 300000), ((1 << 18) - 3, (1 << 18) + (1 << 19) + 7), (n - 10, n)):
+            for name, kind in (('pixels/bin1_id', 'i'), ('pixels/bin2_id', 'i'), ('pixels/count', None)):
+                np.testing.assert_array_equal(h.read_big(name, a, b, kind, threads=4), h.read(name, a, b, kind))
+        h.PARALLEL_MIN = old
+        i, j, c = f.pixels('chr21')
+        assert i.size == n and (j >= i).all() and c.min() >= 1
+    finally:
+        f.close()
