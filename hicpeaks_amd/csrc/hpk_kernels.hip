@@ -1278,7 +1278,12 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             double tot = v[0];
 #pragma unroll
             for (int g = 1; g < 8; ++g) tot += v[g];
-            double run = __shfl(tot, lane & 31);                 // the second half starts from the first half's total
+            // the second half starts from the first half's total.  (ds_bpermute on the loop's own lane number: __shfl()
+            // takes its own, which is hoisted out of every loop and - in the f64 variant - spilled: the reload's vmcnt(0)
+            // then waits here for the whole prefetch of the next tile)
+            const int src4 = (lane & 31) << 2;
+            double run = __hiloint2double(__builtin_amdgcn_ds_bpermute(src4, __double2hiint(tot)),
+                                          __builtin_amdgcn_ds_bpermute(src4, __double2loint(tot)));
             run = g0 ? run : 0.0;
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
@@ -1292,7 +1297,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             unsigned tot = v[0];
 #pragma unroll
             for (int g = 1; g < 8; ++g) tot += v[g];
-            unsigned run = __shfl(tot, lane & 31);
+            unsigned run = (unsigned)__builtin_amdgcn_ds_bpermute((lane & 31) << 2, (int)tot);
             run = g0 ? run : 0u;
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
