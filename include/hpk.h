@@ -40,8 +40,10 @@ extern "C" {
 
 typedef enum {
     HPK_OK = 0,
-    HPK_ERR_INVALID = -1,      /* bad argument (also: a band with negative balancing weights / balanced values - the
-                                  stencil's exact-zero bookkeeping assumes counts x weights >= 0) */
+    HPK_ERR_INVALID = -1,      /* bad argument: null pointers, shapes / sizes / option values out of range, inputs that
+                                  do not go together.  (Negative balancing weights / balanced values are NOT an error:
+                                  they are kept with their sign, as callers.py:78 keeps them -
+                                  tests/test_gpu_parity.py::test_negative_balanced_values_are_kept.) */
     HPK_ERR_HIP = -2,          /* HIP runtime error (message has the call and hipError name) */
     HPK_ERR_NO_DEVICE = -3,    /* no gfx950 device / extension unusable: there is no CPU path */
     HPK_ERR_EMPTY_STEP = -4,   /* a widening step was entered with no unresolved candidate for its peak

@@ -58,6 +58,8 @@ def golden_names(mode=None):
     out = []
     for p in sorted(glob.glob(os.path.join(GOLDEN_DIR, '*.npz'))):
         name = os.path.basename(p)[:-4]
+        if name.startswith('ref_'):          # reference-pinned outputs above fixture size: tests/refbig.py
+            continue
         if mode is None or name.startswith(mode):
             out.append(name)
     return out

@@ -588,7 +588,12 @@ def test_random_parameter_sets_against_oracle(ctx):
     # + the seeds the full runs ever flagged: 1410599 - a diagonal without an unmasked pixel (IR = NaN) next to windows
     # clipped by the matrix end, whose tap-form expected sums multiplied it by a zero coefficient (NaN where the reference
     # has a number: one test fewer in the family, q off by 1e-3); 1300317 - a band the old generator overflowed
-    for seed in list(range(300, 360)) + [1410599, 1300317]:
+    # + the seeds behind the 'CRASH': 7 tally of profiles/r03_fuzz.txt (slice 100000..102499): a pair wider than HPK_MAX_W
+    # (ww = 21 or 22 with maxww = 19 or 20: it contributes no step, callers.py:15-23) made the harness force the record bound
+    # to min(ww) > 20, which hpk_set_option("spec_force") then refused - an exception out of the test hook, not a result of
+    # the library; the option takes any width up to 255 since (clamped to maxww where used), and one_case() may not raise
+    crash7 = [100955, 101171, 101482, 101572, 101689, 101801, 101993, 102243, 102246, 102399, 102415, 102446]
+    for seed in list(range(300, 360)) + [1410599, 1300317] + crash7:
         status, desc, note = fz.one_case(seed, ctx)
         assert not status.startswith('MISMATCH'), (status, desc, note)
         tally[status] = tally.get(status, 0) + 1
