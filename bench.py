@@ -127,13 +127,15 @@ def cpu_baseline_all_cores(cfg, rows):
                     nproc, rows, px, busy, wall))
 
 
-def run_genome(args, cfg, ctx, rank, world, local, dist):
+def run_genome(args, cfg, ctx, rank, world, local, dist, emit=True, steps=None, warmup=None):
     """Whole-genome configurations: one step = every chromosome of the genome scored once - this rank's share of them as
     ONE batch (hpk_submit_batch: one launch per stage for all of them), the next pass submitted before this one is
     collected; value = band pixels of the whole genome x pairs x steps / wall time."""
     import torch
     from hicpeaks_amd import _lib, band, bandgen, parallel, synthetic
     dev = torch.device('cuda', local)
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     res, mw, D = cfg['res'], min(cfg['ww']), cfg['maxapart'] // cfg['res']
     num = D + cfg['maxww'] + 1
     ld = (num + 63) // 64 * 64
@@ -186,33 +188,34 @@ def run_genome(args, cfg, ctx, rank, world, local, dist):
         torch.cuda.synchronize()
 
     pending, done = collections.deque(), []
-    for _ in range(depth + args.warmup):        # set-up (every lane allocates its workspaces once) + warm-up passes
+    for _ in range(depth + warmup):             # set-up (every lane allocates its workspaces once) + warm-up passes
         one_pass(pending, done)
     drain(pending, done)
     barrier()
     t0 = time.perf_counter()
     results = []
-    for _ in range(args.steps):                 # the passes follow each other without a gap: one batch ahead
+    for _ in range(steps):                      # the passes follow each other without a gap: one batch ahead
         one_pass(pending, results)
     drain(pending, results)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=args.coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    out = None
     if rank == 0:
         # dominant kernel: the stencil launches of this rank that were bracketed by events; achieved = algorithmic bytes
         # of the launch's band pixels / its duration
         timed = [rs for rs in results if rs[0][0] > 0]
         st_ms = sum(t[0] for rs in timed for t in rs)
         st_px = sum(t[1] for rs in timed for t in rs) * len(cfg['pw'])
-        nlaunch = len(timed)
-        achieved = BYTES_PER_PX * st_px / (st_ms * 1e-3) / 1e9
+        nlaunch = max(1, len(timed))
+        achieved = BYTES_PER_PX * st_px / (st_ms * 1e-3) / 1e9 if timed else 0.0
         last = [t for rs in results[-((len(bands) + group - 1) // group):] for t in rs]
         out = {
-            'metric': 'band pixels scored/sec (donut+LL)', 'value': px_genome * args.steps / elapsed, 'unit': 'band px/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'metric': 'band pixels scored/sec (donut+LL)', 'value': px_genome * steps / elapsed, 'unit': 'band px/s',
+            'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3,
             'higher_is_better': True, 'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': cfg['workload'], 'name': args.config, 'band_px_per_step': px_genome,
                        'chromosomes': len(sizes), 'chromosomes_rank0': len(mine), 'chromosomes_per_launch': group,
@@ -225,15 +228,18 @@ def run_genome(args, cfg, ctx, rank, world, local, dist):
                        # ... and chromosomes whose Benjamini-Hochberg cut lay above the bound of their survivor records
                        'rescored_rank0': int(sum(t[6] for t in last)),
                        'parallelism': 'chromosomes dealt largest-first to the GPUs, no collective',
-                       'whole_genome_wall_ms': elapsed / args.steps * 1e3, 'host_inputs': bool(args.host_inputs)},
+                       'whole_genome_wall_ms': elapsed / steps * 1e3, 'host_inputs': bool(args.host_inputs)},
             'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil_s', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel_ms': st_ms / nlaunch,
                          'launches_timed': nlaunch, 'launches': len(results),
                          'algorithmic_bytes_per_launch': BYTES_PER_PX * st_px / nlaunch},
         }
-        print(json.dumps(out))
-    if dist is not None:
+        if emit:
+            print(json.dumps(out))
+    del bands
+    if emit and dist is not None:
         dist.destroy_process_group()
+    return out
 
 
 def launch_plan(gpus, env, ngpus_visible):
@@ -284,7 +290,13 @@ def main():
                          'the weights: 12 B/px read instead of 4')
     ap.add_argument('--host-inputs', action='store_true',
                     help='hand the band over as host (numpy) arrays every step: the PCIe-inclusive rate of DESIGN.md, never `value`')
-    ap.add_argument('--seeds', type=int, default=3, help='bands (seeds) the passes rotate through, SURVEY 8-D2 (configurations generated on the host)')
+    ap.add_argument('--distinct', type=int, default=64,
+                    help='distinct bands resident in HBM that a step\'s chromosomes rotate through (seeds 0..N-1; configurations up to 20 M cells per band)')
+    ap.add_argument('--depths', default='',
+                    help='comma-separated sequencing depths the distinct bands cycle through (default: the configuration\'s depth x 5/12, 2/3, 1, 3/2)')
+    ap.add_argument('--no-extra', action='store_true',
+                    help='skip the extra measurements of the default run (the same workload without any bound from earlier chromosomes, '
+                         'the whole-genome configurations)')
     ap.add_argument('--stencil-only', action='store_true', help='time the stencil kernel alone (HPK_FLAG_NO_SCORE)')
     ap.add_argument('--no-probes', action='store_true',
                     help='skip the single-chromosome latency probes and the phase-timed launches after the timed region (profiling '
@@ -306,19 +318,27 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # HPK_BENCH_ONE_GPU (tests on a one-GPU box): the ranks share the GPUs there are; RCCL refuses two ranks on one device, so
+    # the barrier / max / rank count then travel over gloo (CPU tensors) - the process plumbing and the arithmetic over
+    # ranks are the ones of a real N-GPU run, the collective's transport is not
+    shared = bool(os.environ.get('HPK_BENCH_ONE_GPU')) and world > torch.cuda.device_count()
+    if shared:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dist = None
     ranks_seen = 1
+    args.coll_device = torch.device('cpu') if shared else torch.device('cuda', local)
     if world > 1 or os.environ.get('HPK_BENCH_FORCE_DIST'):     # the env knob exercises the RCCL path on a 1-GPU box
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
-        ones = torch.ones(1, dtype=torch.int32, device=torch.device('cuda', local))
+        dist.init_process_group('gloo' if shared else 'nccl', rank=rank, world_size=world)
+        ones = torch.ones(1, dtype=torch.int32, device=args.coll_device)
         dist.all_reduce(ones)
         ranks_seen = int(ones.item())
         assert ranks_seen == world, 'all-reduce saw %d ranks of %d' % (ranks_seen, world)
     args.ranks_seen = ranks_seen
+    args.backend = None if dist is None else ('gloo' if shared else 'nccl')
 
     from hicpeaks_amd import _lib, band, bandgen
     ctx = _lib.Context(local)
@@ -330,23 +350,24 @@ def main():
     num = D + cfg['maxww'] + 1
     ld = (num + 63) // 64 * 64
     dev = torch.device('cuda', local)
-    # the figure is taken over seeds 0..2 - consecutive passes rotate through the bands of --seeds seeds
-    # (one band for the configurations generated in HBM, whose single band is 0.4-2 GB)
-    small = n * num <= 20_000_000       # small enough for the host generator shared with the tests
-    nseeds = max(1, args.seeds) if small else 1
-    bands = []
-    for sd in range(nseeds):
-        if small:
-            raw, weight, IR, biases, num = make_band_host(cfg, seed=nseeds * rank + sd)
-            raw_d = torch.zeros((n, ld), dtype=torch.float32, device=dev)
-            raw_d[:, :num] = torch.from_numpy(raw.astype(np.float32)).to(dev)
-            w_d = torch.from_numpy(weight).to(dev)
-            ir_d = torch.from_numpy(IR).to(dev)
-            b_d = torch.from_numpy(biases).to(dev)
-        else:                           # same recipe, generated in HBM
-            raw_d, w_d, ir_d, b_d = bandgen.device_band(n, num, ld, mw, depth=cfg['depth'], nloops=cfg['nloops'], seed=rank,
-                                                        device=dev)
+    # The step's chromosomes are DISTINCT bands resident in HBM (--distinct, default 64: 64 x 51 MB = 3.3 GB at 10 kb, past the
+    # 256 MiB Infinity Cache) whose depths cycle through --depths (default: the configuration's depth x 5/12, 2/3, 1, 3/2 -
+    # 25 / 40 / 60 / 90 at 10 kb), so that the widening freezes at different widths from chromosome to chromosome: the record
+    # bound, the halo and the survivors' bound are inherited from *other* chromosomes, and the chromosomes
+    # that have to be computed or scored once more because of it are inside `value`.  SURVEY 8-D2's recipe and seeds, generated in HBM
+    # (bandgen.device_band; the large configurations - 0.4-2 GB per band - keep one band).
+    small = n * num <= 20_000_000
+    ndist = max(1, args.distinct) if small else 1
+    depths = [float(v) for v in args.depths.split(',')] if args.depths else \
+        ([round(cfg['depth'] * f, 1) for f in (5 / 12., 2 / 3., 1.0, 1.5)] if small and ndist >= 4 else [cfg['depth']])
+    bands, band_depth = [], []
+    for sd in range(ndist):
+        dp = depths[sd % len(depths)]
+        raw_d, w_d, ir_d, b_d = bandgen.device_band(n, num, ld, mw, depth=dp, nloops=cfg['nloops'], seed=ndist * rank + sd, device=dev)
         bands.append((raw_d, w_d, ir_d, b_d))
+        band_depth.append(dp)
+    nseeds = ndist
+    order = np.random.default_rng(2024).permutation(ndist)       # which band the i-th chromosome of the run is: depths interleaved
     raw_d, w_d, ir_d, b_d = bands[0]
     if args.host_inputs or args.balanced_f64:
         nseeds = 1
@@ -394,7 +415,7 @@ def main():
     def band_of(i):
         if bal_d is not None:
             return ctx._band(n, num, ld, raw_d.data_ptr(), bal_d.data_ptr(), None, ir_d.data_ptr(), b_d.data_ptr(), b_d.data_ptr(), True)
-        r_, w_, i_, b_ = bands[i % nseeds]
+        r_, w_, i_, b_ = bands[int(order[i % nseeds])]
         return ctx._band(n, num, ld, r_.data_ptr(), None, w_.data_ptr(), i_.data_ptr(), b_.data_ptr(), b_.data_ptr(), True)
 
     def submit(timed=None, k=None):
@@ -406,13 +427,21 @@ def main():
         first = nsub[0] * group
         nsub[0] += 1
         if args.host_inputs:
-            return ctx.submit_batch_host([dict(raw=raw_h, IR=ir_h, bias1=b_h, bias2=b_h, weight=w_h)] * k, p)
-        return ctx.submit_batch([band_of(first + i) for i in range(k)], p, [n] * k)
+            job = ctx.submit_batch_host([dict(raw=raw_h, IR=ir_h, bias1=b_h, bias2=b_h, weight=w_h)] * k, p)
+        else:
+            job = ctx.submit_batch([band_of(first + i) for i in range(k)], p, [n] * k)
+        job._first = first
+        return job
+
+    fw_by_depth = {}
 
     def take(job, done):
         rs = job.results()
         del done[:]
         done.append(rs[-1])              # the report needs the kernel times (below) and one result, not all of them
+        for j, r in enumerate(rs):       # widths the widening froze at, by the depth of the band (what the bounds are inherited across)
+            dp = band_depth[int(order[(job._first + j) % nseeds])] if nseeds > 1 else band_depth[0]
+            fw_by_depth.setdefault(dp, set()).add(int(r.frozen_w))
         nredone[0] += sum(int(r.redone) for r in rs)
         nrescored[0] += sum(int(r.rescored) for r in rs)
         st = sum(r.timing['stencil'] for r in rs)        # the group's launch: its chromosomes' shares add up to it
@@ -443,12 +472,14 @@ def main():
 
     barrier()
     del stencil_ms[:]
+    fw_by_depth.clear()
     nredone[0] = nrescored[0] = 0
     t0 = time.perf_counter()
     results = run(args.steps * batch // group)
     barrier()
     elapsed = time.perf_counter() - t0
     nredone_timed, nrescored_timed = nredone[0], nrescored[0]
+    fw_timed = {str(k): sorted(v) for k, v in sorted(fw_by_depth.items())}
     assert len(stencil_ms) >= args.steps * batch // group // TIMED_EVERY
     stencil_ms = list(stencil_ms)
     R = results[-1]
@@ -468,9 +499,32 @@ def main():
         phases = {k: float(sum(r.timing[k] for r in Rs)) / len(Rs) for k in Rs[0].timing}       # per chromosome of a group
         phases['total'] = float(Rs[-1].timing['total']) / len(Rs)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=args.coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # ---- extra measurements of the default run (single GPU): the same workload with the memory of earlier chromosomes switched
+    # off (option spec = 0: no record bound, the plan's own halo - every chromosome as if it were the first), and the
+    # whole-genome configurations (BASELINE configs[2], configs[3]) as lines of their own under `extra`
+    extra = {}
+    no_bound = None
+    if world == 1 and not args.no_extra and not args.stencil_only:
+        ctx.set_option('spec', 0)
+        nb_steps = max(1, args.steps // 5)
+        run(max(2, depth) * 2)
+        barrier()
+        t1 = time.perf_counter()
+        run(nb_steps * batch // group)
+        barrier()
+        no_bound = px_per_step * batch * nb_steps / (time.perf_counter() - t1)
+        ctx.set_option('spec', 1)
+        if args.config == 'chr1_10kb':
+            for name in ('wg_10kb_union', 'wg_5kb'):
+                o = run_genome(args, CONFIGS[name], ctx, rank, world, local, None, emit=False, steps=3, warmup=1)
+                extra[name] = {'value': o['value'], 'unit': o['unit'], 'ms_per_step': o['ms_per_step'], 'steps': o['steps'],
+                               'workload': o['config']['workload'], 'band_px_per_step': o['config']['band_px_per_step'],
+                               'redone_in_full': o['config']['redone_in_full_rank0'], 'rescored': o['config']['rescored_rank0'],
+                               'frozen_w': o['config']['frozen_w_rank0'], 'roofline_frac': o['roofline']['frac'],
+                               'kernel_ms': o['roofline']['kernel_ms']}
 
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
@@ -482,8 +536,10 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': cfg['workload'], 'name': args.config, 'band_px_per_step': px_per_step * batch,
                        'chromosomes_per_step': batch, 'chromosomes_per_launch': group, 'band_px_per_chromosome': px_per_step,
-                       'seeds': nseeds,
-                       'ms_per_chromosome': ms_step / batch, 'ranks_seen': args.ranks_seen,
+                       'distinct_bands': nseeds, 'depths': depths,
+                       'frozen_w_by_depth': fw_timed,
+                       'no_bound_value': no_bound,
+                       'ms_per_chromosome': ms_step / batch, 'ranks_seen': args.ranks_seen, 'collective_backend': args.backend,
                        'candidates': R.ncand, 'significant_px': int(sum(s['x'].size for s in R.sets)),
                        'px_with_p_le_sig': R.nsurv_sig, 'records_copied_back': R.nsurv_cut,
                        # candidates resolved beyond the width the widening freezes at are dropped by the scoring kernel; the
@@ -506,6 +562,7 @@ def main():
                                           'frac': 4.0 * px_per_step * group / (st * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          'hbm_frac_measured': None},
             'phases_ms': phases,
+            'extra': extra,
         }
         try:        # HBM traffic per launch of the dominant kernel, measured off-line with rocprofv3 --pmc (profiles/)
             tr = json.load(open(os.path.join(REPO, 'profiles', 'traffic.json'))).get(args.config)
@@ -518,6 +575,10 @@ def main():
             pass
         if world == 1 and args.cpu_rows > 0:
             out['cpu_baseline'] = cpu_baseline(cfg, min(args.cpu_rows, n), args.cpu_allcores_rows)
+            ac = out['cpu_baseline'].get('all_cores')
+            if ac:          # (also as scalars: parsers that keep only the flat keys of cpu_baseline)
+                out['cpu_baseline']['value_all'] = ac['value']
+                out['cpu_baseline']['cores_all'] = ac['cores']
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

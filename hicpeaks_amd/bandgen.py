@@ -37,11 +37,17 @@ def device_band(n, num, ld, mw, depth=60.0, alpha=1.0, nloops=200, seed=0, nan_f
         rr = torch.arange(r0, r1, device=device).unsqueeze(1)
         blk[(rr + torch.arange(num, device=device).unsqueeze(0)) >= n] = 0
         raw[r0:r1, :num] = blk
-    band = raw[:, :num].to(torch.float64)
-    rowsum = band.sum(dim=1)
+    # marginals of the symmetric matrix restricted to the band (counts are integers: the f64 sums are exact in any order)
     colsum = torch.zeros(n, dtype=torch.float64, device=device)
-    for kk in range(1, num):
-        colsum[kk:] += band[: n - kk, kk]
+    rowsum = torch.zeros(n, dtype=torch.float64, device=device)
+    kk = torch.arange(num, device=device)
+    for r0 in range(0, n, rows):
+        r1 = min(n, r0 + rows)
+        blk = raw[r0:r1, :num].to(torch.float64)
+        rowsum[r0:r1] = blk.sum(dim=1)
+        cc = torch.arange(r0, r1, device=device).unsqueeze(1) + kk.unsqueeze(0)
+        sel = (cc < n) & (kk.unsqueeze(0) >= 1)
+        colsum.index_add_(0, cc[sel], blk[sel])
     weight = 1.0 / torch.sqrt(rowsum + colsum + 1.0)
     nbad = int(round(n * nan_frac))
     if nbad > 0:
@@ -53,17 +59,33 @@ def device_band(n, num, ld, mw, depth=60.0, alpha=1.0, nloops=200, seed=0, nan_f
             weight[idx] = float('nan')
     if not want_expected:        # the library derives IR and the biases on the device (hpk_band.IR = NULL)
         return raw, weight, None, None
-    # IR[d] = mean over the diagonal of the balanced values, stored pixels in masked bins left out (pyHICCUPS:150-156)
-    IR = torch.zeros(num, dtype=torch.float64, device=device)
-    for d in range(mw, min(num, n)):
-        m = n - d
-        cnt = band[:m, d]
-        diag = (cnt * weight[:m]) * weight[d:d + m]
-        nan = torch.isnan(diag) & (cnt != 0)
-        diag = torch.where(cnt == 0, torch.zeros_like(diag), diag)
-        good = ~nan
-        IR[d] = diag[good].sum() / good.sum()
+    IR = expected_on_device(raw, weight, n, num, mw)
     ok = ~((weight == 0) | torch.isnan(weight))
     biases = torch.zeros_like(weight)
     biases[ok] = 1.0 / weight[ok]
     return raw, weight, IR, biases
+
+
+def expected_on_device(raw, weight, n, num, mw, rows=8192):
+    """IR[d] = mean over diagonal d of the balanced values (raw * w_r) * w_c, stored pixels in masked bins left out of both
+    the sum and the count, zero-count pixels counted as 0 (scripts/pyHICCUPS:150-156), in row slabs."""
+    import torch
+    device = raw.device
+    kk = torch.arange(num, device=device)
+    tot = torch.zeros(num, dtype=torch.float64, device=device)
+    cnt = torch.zeros(num, dtype=torch.float64, device=device)
+    for r0 in range(0, n, rows):
+        r1 = min(n, r0 + rows)
+        c = raw[r0:r1, :num].to(torch.float64)
+        cc = torch.arange(r0, r1, device=device).unsqueeze(1) + kk.unsqueeze(0)
+        inside = cc < n
+        diag = (c * weight[r0:r1].unsqueeze(1)) * weight[cc.clamp(max=n - 1)]
+        good = inside & ~(torch.isnan(diag) & (c != 0))
+        diag = torch.where(good & (c != 0), diag, torch.zeros_like(diag))
+        tot += diag.sum(dim=0)
+        cnt += good.sum(dim=0).to(torch.float64)
+    IR = tot / cnt          # (a diagonal without a single unmasked pixel: 0 / 0 = NaN, as numpy's mean of nothing)
+    IR[:mw] = 0.0
+    if num > n:
+        IR[n:] = 0.0
+    return IR

@@ -35,6 +35,16 @@ import os
 import sys
 
 
+def _add_deterministic(group):
+    group.add_argument('--deterministic', action='store_true',
+                       help='Every chromosome under the plan\'s own tile geometry: the output does not depend on the order of the '
+                            'chromosomes, on how they are batched or on --nproc / the number of GPUs (like the reference, whose '
+                            'result is independent of its map order, scripts/pyHICCUPS:192-210).  By default a chromosome\'s tiles '
+                            'are laid out for the width at which the widening of the chromosomes before it stopped, and its E / p / q '
+                            'values can differ in the 14th digit with what was scored before it (coordinates and counts never do); '
+                            'costs ~20-30 %% of the kernel time.')
+
+
 def _hiccups_parser():
     """Flags of scripts/pyHICCUPS:12-81 (same names and defaults) plus --device / --balanced-on-host."""
     from . import __version__, __reference__
@@ -65,6 +75,7 @@ def _hiccups_parser():
     g2.add_argument('--maxapart', type=int, default=10000000, help='Maximum genomic distance between two loci.')
     g2.add_argument('--nproc', type=int, default=1, help='Number of worker processes (one per GPU; clamped to the GPUs present).')
     g2.add_argument('--device', type=int, default=None, help='GPU ordinal (default: local rank / worker index).')
+    _add_deterministic(g2)
     return p
 
 
@@ -89,6 +100,7 @@ def _bhfdr_parser():
     g2.add_argument('--clr-weight-name', default='weight', help='Name of the weight column.')
     g2.add_argument('--nproc', type=int, default=1, help='Number of worker processes (one per GPU; clamped to the GPUs present).')
     g2.add_argument('--device', type=int, default=None, help='GPU ordinal.')
+    _add_deterministic(g2)
     return p
 
 
@@ -149,17 +161,25 @@ def _submit_group(args_dict, mode, items, device, res):
                                       maxapart=a['maxapart'], res=res, ctx=ctx)
 
 
-GROUP_BYTES = 6 << 30        # band bytes of one batch: the device workspaces of a batch are ~8x its bands
+GROUP_BYTES = 3 << 29        # band bytes of one batch (1.5 GiB; the device workspaces of a batch are ~8x its bands)
+GROUP_CHROMS = 8             # ... and chromosomes per batch
 
 
 def _score_queue(args_dict, mode, queue, device):
-    """One GPU worker: takes chromosomes from the shared largest-first queue while it has room, hands them to the GPU in
-    batches (several chromosomes per set of launches, up to GROUP_BYTES of bands), one batch ahead - while batch i is on
-    the GPU, batch i + 1 is read and uploaded and batch i - 1 goes through clustering on the host.  -> {label: table}"""
+    """One GPU worker: takes chromosomes from the shared largest-first queue, hands them to the GPU in batches (several
+    chromosomes per set of launches: up to GROUP_CHROMS chromosomes / GROUP_BYTES of bands, the first one alone so that the GPU
+    starts at once), `pipeline_depth` batches in flight - while batch i is on the GPU, batch i + 1 is read and uploaded and
+    batch i - 1 goes through clustering on the host; a batch is collected before the one after next is submitted, so the
+    bounds a chromosome inherits (record bound, halo, survivors' bound: DESIGN 4.6-4.9) come from the batch before last
+    at the latest.  -> {label: table}"""
     from . import io, _lib
     import collections
     src = io.open_source(args_dict['path'])
     ctx = _lib.default_context(device)
+    # every run starts without memory of the chromosomes an earlier run in this process scored; --deterministic: the plan's
+    # own tile geometry for every chromosome (the record bound stays: it never touches a value)
+    ctx.set_option('reset_hints', 1)
+    ctx.set_option('spec_halo', 0 if args_dict.get('deterministic') else 1)
     depth = ctx.pipeline_depth
     pending, out = collections.deque(), {}
 
@@ -174,12 +194,11 @@ def _score_queue(args_dict, mode, queue, device):
             item = _fetch(args_dict, src, key, ctx)
             group.append(item)
             nbytes += item[1].nbytes
-        # a batch is closed when it is full - or as soon as the GPU has nothing in flight (the first chromosomes start at once)
-        if group and (key is None or nbytes >= GROUP_BYTES or len(group) >= _lib.HPK_MAX_BATCH or not pending):
-            pending.append(([g[0] for g in group], _submit_group(args_dict, mode, group, device, src.binsize)))
-            group, nbytes = [], 0
+        if group and (key is None or nbytes >= GROUP_BYTES or len(group) >= min(GROUP_CHROMS, _lib.HPK_MAX_BATCH) or not pending):
             if len(pending) >= depth:
                 collect()
+            pending.append(([g[0] for g in group], _submit_group(args_dict, mode, group, device, src.binsize)))
+            group, nbytes = [], 0
     while pending:
         collect()
     return out
@@ -199,43 +218,82 @@ def _gpu_count():
 def worker_devices(nproc, device, ngpus):
     """The reference's --nproc counts CPU processes (scripts/pyHICCUPS:192-198); here a worker needs a GPU.  With
     --device every chromosome goes to that one GPU (one worker: a second process on the same GPU only time-slices);
-    otherwise min(nproc, GPUs) workers, worker w on GPU w.  -> (workers, [device per worker])"""
+    otherwise min(nproc, GPUs) workers, worker w on GPU w.  -> (workers, [device per worker])
+    (HPK_CLI_SHARE_GPU=1 - tests on a one-GPU box - keeps --nproc workers and lets them share the GPUs there are.)"""
+    if os.environ.get('HPK_CLI_SHARE_GPU') and nproc > 1:
+        g = max(1, ngpus)
+        return nproc, [device if device is not None else w % g for w in range(nproc)]
     if device is not None:
         return 1, [device]
     n = max(1, min(nproc, ngpus)) if ngpus > 0 else nproc      # no GPU visible: let hpk_create report it
     return n, list(range(n))
 
 
-def _gpu_worker(args_dict, mode, device, sizes, value, results):
+def _gpu_worker(args_dict, mode, device, sizes, value, results, wid=0):
     """One worker process = one GPU: drains the shared queue (a counter over the same largest-first list in every
-    process) and sends back its {label: table}, or the exception that stopped it."""
+    process) and sends back its {label: table}, or what stopped it as (type name, status code, message) strings - an
+    exception object may fail to pickle in the queue's feeder thread, and the parent would wait for ever."""
     from . import parallel
     try:
         queue = parallel.WorkQueue(sizes, parallel.mp_counter(value))
-        results.put((device, _score_queue(args_dict, mode, queue, device), None))
-    except BaseException as e:              # the parent re-raises (HpkError / EmptyStepError pickle, see _lib)
-        results.put((device, None, e))
+        results.put((wid, _score_queue(args_dict, mode, queue, device), None))
+    except BaseException as e:
+        results.put((wid, None, _describe_error(e)))
 
 
-def run_workers(args_dict, mode, sizes, devices):
+def _describe_error(e):
+    """An exception as plain strings / integers (always picklable): (type name, library status or None, message)"""
+    return (type(e).__name__, getattr(e, 'status', None), getattr(e, 'msg', None) or str(e))
+
+
+def _rebuild_error(desc):
+    """(type name, library status, message) of a worker's failure -> the exception the single-process path would have raised"""
+    from . import _lib
+    name, status, msg = desc
+    if name == 'EmptyStepError':
+        return _lib.EmptyStepError(status if status is not None else _lib.ERR_EMPTY_STEP, msg)
+    if name == 'HpkError':
+        return _lib.HpkError(status if status is not None else -1, msg)
+    return RuntimeError('GPU worker failed: %s: %s' % (name, msg))
+
+
+def run_workers(args_dict, mode, sizes, devices, poll=1.0):
     """--nproc N: one process per GPU around one queue (counterpart of Pool(nproc).map(worker, Params),
-    scripts/pyHICCUPS:192-198) -> {label: table} of all chromosomes."""
+    scripts/pyHICCUPS:192-198) -> {label: table} of all chromosomes.  A worker that dies without reporting (a crash in the
+    native library, the kernel's out-of-memory killer) is noticed by its exit code; the others are stopped."""
     import multiprocessing as mp
+    import queue as _queue
     ctxmp = mp.get_context('spawn')
     value = ctxmp.Value('i', 0)
     results = ctxmp.Queue()
-    procs = [ctxmp.Process(target=_gpu_worker, args=(args_dict, mode, d, sizes, value, results)) for d in devices]
+    procs = [ctxmp.Process(target=_gpu_worker, args=(args_dict, mode, d, sizes, value, results, w)) for w, d in enumerate(devices)]
     for p in procs:
         p.start()
-    tables, err = {}, None
-    for _ in procs:
-        _, part, e = results.get()
-        if e is not None:
-            err = err or e
-        else:
-            tables.update(part)
-    for p in procs:
-        p.join()
+    tables, err, reported = {}, None, set()
+    try:
+        while len(reported) < len(procs):
+            try:
+                wid, part, e = results.get(timeout=poll)
+            except _queue.Empty:
+                dead = [w for w, p in enumerate(procs) if w not in reported and not p.is_alive()]
+                if dead:
+                    try:                                    # its result may have arrived between the time-out and the check
+                        wid, part, e = results.get(timeout=poll)
+                    except _queue.Empty:
+                        raise RuntimeError('GPU worker %d (device %s) exited with code %s without reporting a result' % (
+                            dead[0], devices[dead[0]], procs[dead[0]].exitcode))
+                else:
+                    continue
+            reported.add(wid)
+            if e is not None:
+                err = err or _rebuild_error(e)
+            else:
+                tables.update(part)
+    finally:
+        for p in procs:
+            if len(reported) < len(procs) and p.is_alive():
+                p.terminate()
+            p.join()
     if err is not None:
         raise err
     return tables
@@ -261,15 +319,28 @@ def _run(mode, argv):
     a = vars(args)
     rank, world, local = parallel.dist_env()
     logger.info('Calling Peaks ...')
+    logger.info('Tile geometry: {0}'.format('deterministic (the plan\'s own halo for every chromosome: results independent of '
+                                            'chromosome order, batching and the number of workers)' if args.deterministic else
+                                            'adaptive (halo = the width at which the widening of the chromosomes scored before '
+                                            'stopped: E / p / q can differ in the 14th digit between runs that order or batch the '
+                                            'chromosomes differently; --deterministic switches it off)'))
     if world > 1:                                    # torchrun: one rank per GPU, one queue, tables gathered on rank 0
         import torch.distributed as dist
         dist.init_process_group('gloo')              # only the queue's counter and Python objects travel
         dev = local if args.device is None else args.device
         queue = parallel.WorkQueue(sizes, parallel.store_counter())
-        tables = parallel.gather_tables(_score_queue(a, mode, queue, dev), rank, world)
+        try:                                         # a rank that fails still takes part in the gather: its error travels instead of its tables
+            mine = _score_queue(a, mode, queue, dev)
+        except Exception as e:
+            mine = {'__error__': _describe_error(e)}
+        tables = parallel.gather_tables(mine, rank, world)
         dist.destroy_process_group()
         if rank != 0:
+            if '__error__' in mine:
+                raise _rebuild_error(mine['__error__'])
             return 0
+        if '__error__' in tables:
+            raise _rebuild_error(tables['__error__'])
     else:
         # Pool.map over GPU workers (scripts/pyHICCUPS:192-198); one worker runs in this process
         nworkers, devices = worker_devices(args.nproc, args.device, _gpu_count() if args.nproc > 1 else 0)

@@ -327,6 +327,7 @@ int hpk_set_option(hpk_ctx* c, const char* name, int64_t v) {
     else if (k == "gap_kernel" && (v == 0 || v == 1)) o.gap_kernel = (int)v;
     else if (k == "score_div" && v >= 1 && v <= 4096) o.score_div = (int)v;
     else if (k == "dbg_stop" && v >= 0 && v <= 16) o.dbg_stop = (int)v;
+    else if (k == "reset_hints") { c->hint_n = 0; c->hint_bn = 0; }     // forget the bounds learnt from the chromosomes collected so far
     else return fail(c, HPK_ERR_INVALID, "unknown option or value out of range: %s = %lld", name, (long long)v);
     return HPK_OK;
 }
