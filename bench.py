@@ -293,7 +293,7 @@ def main():
     ap.add_argument('--distinct', type=int, default=64,
                     help='distinct bands resident in HBM that a step\'s chromosomes rotate through (seeds 0..N-1; configurations up to 20 M cells per band)')
     ap.add_argument('--depths', default='',
-                    help='comma-separated sequencing depths the distinct bands cycle through (default: the configuration\'s depth x 5/12, 2/3, 1, 3/2)')
+                    help='comma-separated sequencing depths the distinct bands cycle through (default: the configuration\'s depth x 1/4, 2/3, 1, 5/2)')
     ap.add_argument('--no-extra', action='store_true',
                     help='skip the extra measurements of the default run (the same workload without any bound from earlier chromosomes, '
                          'the whole-genome configurations)')
@@ -351,15 +351,15 @@ def main():
     ld = (num + 63) // 64 * 64
     dev = torch.device('cuda', local)
     # The step's chromosomes are DISTINCT bands resident in HBM (--distinct, default 64: 64 x 51 MB = 3.3 GB at 10 kb, past the
-    # 256 MiB Infinity Cache) whose depths cycle through --depths (default: the configuration's depth x 5/12, 2/3, 1, 3/2 -
-    # 25 / 40 / 60 / 90 at 10 kb), so that the widening freezes at different widths from chromosome to chromosome: the record
+    # 256 MiB Infinity Cache) whose depths cycle through --depths (default: the configuration's depth x 1/4, 2/3, 1, 5/2 -
+    # 15 / 40 / 60 / 150 at 10 kb, which freeze at widths 5 / 6 / 6 / 8), so that the widening freezes at different widths from chromosome to chromosome: the record
     # bound, the halo and the survivors' bound are inherited from *other* chromosomes, and the chromosomes
     # that have to be computed or scored once more because of it are inside `value`.  SURVEY 8-D2's recipe and seeds, generated in HBM
     # (bandgen.device_band; the large configurations - 0.4-2 GB per band - keep one band).
     small = n * num <= 20_000_000
     ndist = max(1, args.distinct) if small else 1
     depths = [float(v) for v in args.depths.split(',')] if args.depths else \
-        ([round(cfg['depth'] * f, 1) for f in (5 / 12., 2 / 3., 1.0, 1.5)] if small and ndist >= 4 else [cfg['depth']])
+        ([round(cfg['depth'] * f, 1) for f in (0.25, 2 / 3., 1.0, 2.5)] if small and ndist >= 4 else [cfg['depth']])
     bands, band_depth = [], []
     for sd in range(ndist):
         dp = depths[sd % len(depths)]
@@ -412,10 +412,19 @@ def main():
     batch = args.batch if args.batch > 0 else (1280 if n * num <= 60_000_000 else 16)
     batch = max(group, batch // group * group)          # whole groups
 
+    by_depth = [[b for b in range(ndist) if band_depth[b] == dp] for dp in depths]
+    sample_run = [0]            # > 0: runs of that many library calls per depth ("samples" scored one after the other)
+
+    def band_index(i):
+        if sample_run[0] > 0 and nseeds > 1:
+            pool = by_depth[(i // (group * sample_run[0])) % len(depths)]
+            return pool[i % len(pool)]
+        return int(order[i % nseeds])
+
     def band_of(i):
         if bal_d is not None:
             return ctx._band(n, num, ld, raw_d.data_ptr(), bal_d.data_ptr(), None, ir_d.data_ptr(), b_d.data_ptr(), b_d.data_ptr(), True)
-        r_, w_, i_, b_ = bands[int(order[i % nseeds])]
+        r_, w_, i_, b_ = bands[band_index(i)]
         return ctx._band(n, num, ld, r_.data_ptr(), None, w_.data_ptr(), i_.data_ptr(), b_.data_ptr(), b_.data_ptr(), True)
 
     def submit(timed=None, k=None):
@@ -440,7 +449,7 @@ def main():
         del done[:]
         done.append(rs[-1])              # the report needs the kernel times (below) and one result, not all of them
         for j, r in enumerate(rs):       # widths the widening froze at, by the depth of the band (what the bounds are inherited across)
-            dp = band_depth[int(order[(job._first + j) % nseeds])] if nseeds > 1 else band_depth[0]
+            dp = band_depth[band_index(job._first + j)] if nseeds > 1 else band_depth[0]
             fw_by_depth.setdefault(dp, set()).add(int(r.frozen_w))
         nredone[0] += sum(int(r.redone) for r in rs)
         nrescored[0] += sum(int(r.rescored) for r in rs)
@@ -517,6 +526,19 @@ def main():
         barrier()
         no_bound = px_per_step * batch * nb_steps / (time.perf_counter() - t1)
         ctx.set_option('spec', 1)
+        if nseeds > 1 and len(depths) > 1:
+            # the same chromosomes sample by sample: runs of 5 library calls of one depth each - at every switch to a deeper
+            # sample the first calls run under a bound that is too narrow and are computed once more (hpk_result::redone)
+            sample_run[0] = 5
+            run(2 * depth)
+            barrier()
+            nredone[0] = 0
+            t1 = time.perf_counter()
+            run(nb_steps * batch // group)
+            barrier()
+            extra['sample_runs'] = {'value': px_per_step * batch * nb_steps / (time.perf_counter() - t1), 'unit': 'band px/s',
+                                    'calls_per_sample': 5, 'chromosomes': nb_steps * batch, 'redone_in_full': nredone[0]}
+            sample_run[0] = 0
         if args.config == 'chr1_10kb':
             for name in ('wg_10kb_union', 'wg_5kb'):
                 o = run_genome(args, CONFIGS[name], ctx, rank, world, local, None, emit=False, steps=3, warmup=1)
