@@ -266,7 +266,7 @@ def test_full_size_chr1_bhfdr_vs_oracle(ctx):
     IR, cband, biases = orc.prep_from_band(raw, weight, 5)
     kw = dict(pw=2, ww=5, sig=sig, maxww=maxww, maxapart=maxapart, res=res, min_marginal_peaks=2, onlyanchor=False)
     want = orc.bhfdr(raw, cband, biases, biases, IR, n, num, **kw)
-    assert len(want) >= min_final
+    assert len(want) >= 10
     kwant, vwant = _arrays(want)
     rawf = raw.astype(np.float32)
     c = _lib.Context(0)
