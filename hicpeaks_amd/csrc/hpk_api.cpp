@@ -106,7 +106,8 @@ struct Options {
     int spec_surv_margin = 2;
     int spec_surv_force = -1;   // tests: this bin for every family (too narrow a bound: scored once more)
     int host_threads = 8;       // threads of a batch's host half (hpk_collect_batch), at most one per four chromosomes
-    int fuse = 1;               // bounded single-pair hiccups launches score inside the stencil kernel (no records, no hpk_score)
+    int fuse = 0;               // 1: bounded single-pair hiccups launches score inside the stencil kernel (no records, no hpk_score);
+                                // measured level with the two kernels, so the two-kernel path stays the default
 };
 
 struct hpk_ctx {

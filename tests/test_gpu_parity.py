@@ -136,12 +136,14 @@ def test_golden_parity_scored_inside_the_stencil(name):
         pytest.skip('not a single-pair fixture with a result')
     c = _lib.Context(0)
     try:
+        c.set_option('fuse', 1)
         d1 = {}
         _call(g, c, 'weight', d1)
         d2 = {}
         final = _call(g, c, 'weight', d2)
         R = d2['result']
         fusable = d1['result'].frozen_w - min(g.params['ww']) < 4 and g.params['maxww'] >= 4
+        assert (d1['result'].stencil_kernel == 3) == (g.params['maxww'] - min(g.params['ww']) < 4 and g.params['maxww'] >= 4)
         assert R.record_bound == d1['result'].frozen_w and (R.stencil_kernel == 3) == fusable and not R.redone
         _check_golden(g, R, final)
         # and with the plan's own halo (option spec_halo = 0): the fused kernel under another tile geometry

@@ -69,8 +69,7 @@ def test_reference_at_size(name, ctx):
     d1 = {}
     final = call(rawf, IR, biases, biases, chrom='T', weight=weight, ctx=ctx, detail=d1, **kw)
     R1 = d1['result']
-    # (a (4,7) plan under maxww = 10 has four widths in all: scored inside the stencil from the first call on)
-    assert R1.stencil_kernel == (3 if g.mode == 'hiccups' and len(g.params['pw']) == 1 and g.params['maxww'] - g.mw < 4 else 2)
+    assert R1.stencil_kernel == 2
     assert R1.halo_w == g.params['maxww'] and not R1.redone
     _check_result(g, R1, final)
     # (ii) inside a batch, between two other chromosomes, IR / biases derived on the device, record bound / halo / survivor
@@ -118,7 +117,7 @@ def test_wide_band_vs_oracle(name, ctx):
     d1 = {}
     final = callers.hiccups_band(rawf, IR, biases, biases, chrom='1', weight=weight, ctx=ctx, detail=d1, **kw)
     R1 = d1['result']
-    assert R1.stencil_kernel == (3 if maxww - min(ww) < 4 else 2) and R1.halo_w == maxww
+    assert R1.stencil_kernel == 2 and R1.halo_w == maxww
     _check_against_oracle(R1, final, det, want, pw, ww, sig, min_sig=5, min_final=1)
     prm = _lib.make_params(_lib.MODE_HICCUPS, pw, ww, maxww, sig, cfg['maxapart'], res, 16, 0)
     other, ow, _ = synthetic.synth_band(2500, num, depth=cfg['depth'], nloops=20, seed=78)
