@@ -19,6 +19,16 @@
 #include "hpk_kernels.h"
 #include "hpk_plan.h"
 
+#ifdef HPK_TEST_KERNELS
+#define HPK_NEED_TEST_KERNELS(ctx) do {} while (0)
+#else   // product-only build (make TESTK=): the tests' check kernels and the dense debug outputs are not in the library
+#define HPK_NEED_TEST_KERNELS(ctx) return fail(ctx, HPK_ERR_INVALID, "libhpk.so was built without its test kernels (HPK_TEST_KERNELS)")
+void hpk_launch_dense(const HpkDenseArgs&, hipStream_t) {}
+void hpk_launch_probe(const HpkDenseArgs&, const int32_t*, const int32_t*, int64_t, double*, hipStream_t) {}
+void hpk_launch_brute(const HpkBruteArgs&, hipStream_t) {}
+void hpk_launch_poisson_sf(const double*, const double*, const double*, double*, int64_t, hipStream_t) {}
+#endif
+
 namespace {
 
 std::string g_create_error;
@@ -395,6 +405,7 @@ int hpk_device_info(hpk_ctx* c, char* name, int32_t name_len, int32_t* cus, int6
 }
 
 int hpk_poisson_sf(hpk_ctx* c, const double* k, const double* lam, double* out, int64_t count) {
+    if (c) { HPK_NEED_TEST_KERNELS(c); }
     if (!c || !k || !lam || !out || count < 0) return fail(c, HPK_ERR_INVALID, "bad arguments");
     if (count == 0) return HPK_OK;
     (void)hipSetDevice(c->device);
@@ -505,7 +516,7 @@ int launch_compute(hpk_ctx* c, hpk_job* j, int b0, int nbl, bool solo, bool with
     const bool fused = j->fused && !solo;
     if (with_stencil) {
         if (j->time_stencil) (void)hipEventRecord(L.ev[1], c->stream);
-        if (j->use_s) {
+        {
             HpkStencilArgs sa = full ? j->sa_full : j->sa;
             sa.fuse = fused ? 1 : 0;
             sa.nbands = nbl;
@@ -514,14 +525,6 @@ int launch_compute(hpk_ctx* c, hpk_job* j, int b0, int nbl, bool solo, bool with
             sa.grid = std::max(8, std::min((c->cus / 8) * 8, kall * 8));
             hpk_launch_stencil_batch(sa, dd, j->balf64, c->stream);
             HIPCHK(c, hipGetLastError());
-        } else {
-            for (int b = b0; b < b0 + nbl; ++b) {
-                HpkBandDesc hb = j->bands[b].d;
-                if (solo) hb.wguess = plan.W;
-                const int grid = std::max(8, std::min((c->cus / 8) * 8, hb.chunk * 8));
-                hpk_launch_stencil_old(j->sa, hb, j->balf64, j->simple, grid, c->stream);
-                HIPCHK(c, hipGetLastError());
-            }
         }
         if (j->time_stencil) (void)hipEventRecord(L.ev[2], c->stream);
         if (!j->do_score) {         // no scoring kernel to replay the freeze decision: a one-workgroup kernel per band
@@ -588,22 +591,21 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     if (rc != HPK_OK) return rc;
     const HpkDevPlan& plan = L.plan_host;
     const int W = plan.W, mw = plan.mw, D = plan.D;
-    static_assert(HPK_ROWS_PER_WAVE * (HPK_LC - 1) <= HPK_LISTCAP, "a wave's candidate list must hold its tile rows");
     if (D < mw) return fail(c, HPK_ERR_INVALID, "maxapart / res (%d) is below min(ww) (%d)", D, mw);
-    // Tile geometry under a halo of Wh widths.  Output tile: what the halo leaves of the SAT tile - for the first-generation
-    // kernel at most 4 rows per stencil wave (HPK_LISTCAP ids per wave), for hpk_stencil_s as many rows as its tile-wide
-    // candidate list holds (HPK_TLIST entries; 7 bits of the record entry).  The tiles of a row block reach the
+    // Tile geometry under a halo of Wh widths.  Output tile: what the halo leaves of the SAT tile, as many rows as the kernel's
+    // tile-wide candidate list holds (HPK_TLIST entries; 7 bits of the record entry).  The tiles of a row block reach the
     // last stored diagonal D + maxww (gap rows, callers.py:238) through the last tile's right halo: with a halo below
-    // maxww the chunks themselves have to go further (Dg).
+    // maxww the chunks themselves have to go further (Dg).  The halo is at least 4 (plans with maxww < 4: the widths beyond
+    // maxww have no step, the kernel leaves them out).
     struct Geo { int W, Dg, TR, TC, J, tilecap; size_t upt; };
     // (rows beyond 64 pay on single-pair plans - chr1 @10 kb: 66 rows at a halo of 6, -4.5 % - and cost 2 % on the
     // three-slot union plan, measured with HPK_TR_CAP)
     const int tr_cap_s = plan.single_p >= 0 ? opt.tr_cap : std::min(opt.tr_cap, 64);
-    auto geo_of = [&](int Wh, bool for_s) {
+    auto geo_of = [&](int Wh) {
         Geo g;
-        g.W = Wh; g.Dg = D + (W - Wh);
+        g.W = Wh; g.Dg = D + std::max(0, W - Wh);
         g.TC = HPK_LC - 2 * Wh - 1;
-        g.TR = std::min(HPK_LR - 2 * Wh - 1, for_s ? std::min(tr_cap_s, HPK_TLIST / g.TC) : HPK_ROWS_PER_WAVE * HPK_NWAVES);
+        g.TR = std::min(HPK_LR - 2 * Wh - 1, std::min(tr_cap_s, HPK_TLIST / g.TC));
         g.J = (g.TR + g.Dg - mw + g.TC - 1) / g.TC;
         g.tilecap = g.TR * g.TC;
         g.upt = ((size_t)g.tilecap + HPK_UNIT - 1) / HPK_UNIT;          // at most ceil(tilecap / HPK_UNIT) units per tile
@@ -615,7 +617,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         a.W = g.W; a.mw = mw; a.D = D; a.Dg = g.Dg; a.TR = g.TR; a.TC = g.TC; a.J = g.J; a.tilecap = g.tilecap;
         return a;
     };
-    Geo GF = geo_of(W, false);
+    Geo GF = geo_of(std::max(W, 4));
     j->prm = *prm; j->key = key;
     j->nsets = (plan.mode == HPK_MODE_BHFDR) ? 1 : 2 * plan.npairs;
     j->sums = (prm->flags & HPK_FLAG_DENSE_SUMS) != 0;
@@ -626,6 +628,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     j->balf64 = bands[0].balanced != nullptr;
     j->simple = plan.simple_reads != 0;
     const bool dense = j->dense, sums = j->sums;
+    if (dense) { HPK_NEED_TEST_KERNELS(c); }
     if (dense && nb != 1) return fail(c, HPK_ERR_INVALID, "the dense outputs (HPK_FLAG_DENSE_*) are for single chromosomes");
     for (int b = 0; b < nb; ++b)
         if ((bands[b].balanced != nullptr) != j->balf64)
@@ -647,19 +650,21 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
             if (hw >= 0) wg_all = std::min(W, hw + opt.spec_margin);
         }
         if (opt.spec_force >= 0) wg_all = std::min(W, opt.spec_force);        // tests: a bound that is too narrow
+        if (!j->simple) wg_all = W;     // (plans without a monotone Reads matrix: no width to bound the records by)
     }
     int64_t max_ld = 0;
     int32_t max_n = 0, max_num = 0, max_dn = 0, max_dnum = 0;
     for (int b = 0; b < nb; ++b) {
         max_ld = std::max<int64_t>(max_ld, bands[b].ld); max_n = std::max(max_n, bands[b].n); max_num = std::max(max_num, bands[b].num);
     }
-    j->use_s = hpk_stencil_s_applies(stencil_args_of(GF), j->simple, max_ld, max_n);
-    if (j->use_s) GF = geo_of(W, true);
+    j->use_s = true;
+    if (!hpk_stencil_s_applies(stencil_args_of(GF), max_ld, max_n))
+        return fail(c, HPK_ERR_INVALID, "band outside the stencil's addressing limits (n < 2^27, ld <= 2^21)");
     Geo GS = GF;
-    if (j->use_s && opt.spec_halo && wg_all < W) {
+    if (j->simple && opt.spec_halo && wg_all < W) {
         const int Wh = std::min(W, std::max(std::max(wg_all, (int)plan.wmin), 4));
-        const Geo g = geo_of(Wh, true);
-        if (Wh < W && hpk_stencil_s_applies(stencil_args_of(g), j->simple, max_ld, max_n)) GS = g;
+        const Geo g = geo_of(Wh);
+        if (Wh < W && hpk_stencil_s_applies(stencil_args_of(g), max_ld, max_n)) GS = g;
     }
     // ---- one kernel from band to p-value: bounded single-pair hiccups launches on weight input score inside the stencil
     const int hbins = (opt.rounds <= -2) ? hpk_score_hist_bins((plan.mode == HPK_MODE_BHFDR) ? 1 : 2 * plan.npairs, plan.mode == HPK_MODE_BHFDR) : 0;
@@ -909,6 +914,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     sa.nbands = nb;
     sa.W = GS.W; sa.mw = mw; sa.D = D; sa.Dg = GS.Dg; sa.TR = GS.TR; sa.TC = GS.TC; sa.J = GS.J; sa.tilecap = GS.tilecap;
     sa.single = plan.single_p >= 0 ? 1 : 0;
+    sa.generic = j->simple ? 0 : 1;
     sa.order = opt.tile_order;
     sa.dbg_stop = opt.dbg_stop;
     sa.clk = nullptr;
@@ -1546,6 +1552,7 @@ void hpk_devband_free(hpk_ctx* c, hpk_devband* b) {
 
 int hpk_probe_sums(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, const int32_t* rows, const int32_t* cols,
                    int64_t count, double* out) {
+    if (c) { HPK_NEED_TEST_KERNELS(c); }
     if (!c) return HPK_ERR_INVALID;
     if (!prm || !rows || !cols || !out || count < 0) return fail(c, HPK_ERR_INVALID, "bad arguments");
     hpk_params p2 = *prm;
@@ -1586,6 +1593,7 @@ int hpk_probe_sums(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, cons
 
 int hpk_bruteforce_sums(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, int32_t step, const int32_t* rows,
                         const int32_t* cols, int64_t count, double* out) {
+    if (c) { HPK_NEED_TEST_KERNELS(c); }
     if (!c) return HPK_ERR_INVALID;
     if (!prm || !rows || !cols || !out || count < 0) return fail(c, HPK_ERR_INVALID, "bad arguments");
     int rc = check_band(c, band);

@@ -21,12 +21,10 @@
 #ifndef HPK_NWAVES
 #define HPK_NWAVES 16                   // waves per stencil workgroup (16 or 8)
 #endif
-#define HPK_ROWS_PER_WAVE (64 / HPK_NWAVES)                  // output-tile rows a wave walks in phase 3 (tile rows <= 64)
 // record entry of a candidate: x (7 bits) | y << 7 (7 bits: row of the output tile) | capped raw count << 14 (<= pk_cap < 2^13)
 #define HPK_ENT_Y(e) (((e) >> 7) & 127u)
 #define HPK_ENT_CNT_SHIFT 14
 #define HPK_TLIST 7680                  // entries of hpk_stencil_s's tile-wide candidate list: TR * TC must fit
-#define HPK_LISTCAP (HPK_ROWS_PER_WAVE * 128)               // candidate ids per wave and tile
 
 // One pixel that can still end with q <= sig (40 bytes).
 struct HpkSurv {
@@ -141,6 +139,7 @@ struct HpkStencilArgs {
     int32_t grid;                       // persistent workgroups (multiple of 8, one per CU)
     int32_t single;                     // the plan is a textbook single-pair plan (HpkDevPlan::single_p >= 0)
     int32_t order;                      // tile order within an XCD's run: 0 row-major, 1 column chunks rotated per row block
+    int32_t generic;                    // the plan's Reads matrix is not monotone in the width: steps walked in plan order (general plans only)
     int32_t dbg_stop;                   // profiling ablation: 1 stop after the loads, 2 after the SAT, 4 no candidates, 5 search without box sums
     unsigned long long* clk;            // -DHPK_PHASE_CLOCK builds: [grid][waves][8] cycle sums per phase, or nullptr
     // ---- fused launches only (fuse != 0): what the scoring needs (as HpkScoreArgs)
@@ -187,12 +186,9 @@ struct HpkBruteArgs {
     double* out;                        // [count][5]
 };
 
-int  hpk_stencil_lds_bytes();
-// The second-generation kernel takes plans with a monotone Reads matrix on bands within its addressing limits; it walks
-// the whole batch in one launch.  Other launches go band by band through the first-generation kernel.
-bool hpk_stencil_s_applies(const HpkStencilArgs& a, bool simple, int64_t max_ld, int32_t max_n);
+// hpk_stencil_s walks the whole batch in one launch (bands within its addressing limits, a halo of at least 4)
+bool hpk_stencil_s_applies(const HpkStencilArgs& a, int64_t max_ld, int32_t max_n);
 void hpk_launch_stencil_batch(const HpkStencilArgs& a, const HpkBandDesc* d_bands, bool balf64, hipStream_t st);
-void hpk_launch_stencil_old(const HpkStencilArgs& a, const HpkBandDesc& host_copy_of_band, bool balf64, bool simple, int grid, hipStream_t st);
 void hpk_launch_dense(const HpkDenseArgs& a, hipStream_t st);
 void hpk_launch_probe(const HpkDenseArgs& a, const int32_t* rows, const int32_t* cols, int64_t count, double* out, hipStream_t st);
 void hpk_launch_freeze_tot(const HpkDevPlan* plan, const HpkBandDesc* d_bands, int nbands, hipStream_t st);

@@ -30,6 +30,7 @@
 #include "hpk_kernels.h"
 
 namespace {
+#include "hpk_device.h"
 
 constexpr int LC = HPK_LC;
 constexpr int LR = HPK_LR;
@@ -46,15 +47,6 @@ constexpr int LR = HPK_LR;
 constexpr unsigned PK_SHIFT = HPK_PK_BITS, PK_MASK = (1u << PK_SHIFT) - 1u;
 static_assert((2 * HPK_MAX_W + 1) * (2 * HPK_MAX_W + 1) * HPK_PK_CAP < (1u << PK_SHIFT), "capped raw box sum must fit its field");
 static_assert((2 * HPK_MAX_W + 1) * (2 * HPK_MAX_W + 1) < (1u << (32 - PK_SHIFT)), "valid count of a box must fit its field");
-struct Sat {
-    double* c;          // balanced
-    unsigned* p;        // capped raw | valid << 21
-    unsigned* l;        // candidate lists: HPK_LISTCAP entries per wave
-};
-__device__ __forceinline__ unsigned pack_cell(unsigned ru, bool valid, unsigned cap) {
-    return (ru < cap ? ru : cap) | (valid ? 1u << PK_SHIFT : 0u);
-}
-
 // ------------------------------------------------------------------ wave64 DPP scan (gfx9 DPP controls)
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
 constexpr int DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
@@ -75,18 +67,6 @@ __device__ __forceinline__ void scan_step(double& c, unsigned& r) {
     c += dpp_f64<CTRL, ROWMASK>(c);
     r += dpp_u32<CTRL, ROWMASK>(r);
 }
-// inclusive prefix over the 64 lanes, then shifted right by one lane (= exclusive prefix)
-__device__ __forceinline__ void wave_exclusive_scan(double& c, unsigned& r) {
-    scan_step<DPP_ROW_SHR1, 0xf>(c, r);
-    scan_step<DPP_ROW_SHR2, 0xf>(c, r);
-    scan_step<DPP_ROW_SHR4, 0xf>(c, r);
-    scan_step<DPP_ROW_SHR8, 0xf>(c, r);
-    scan_step<DPP_ROW_BCAST15, 0xa>(c, r);
-    scan_step<DPP_ROW_BCAST31, 0xc>(c, r);
-    c = dpp_f64<DPP_WAVE_SHR1, 0xf>(c);
-    r = dpp_u32<DPP_WAVE_SHR1, 0xf>(r);
-}
-
 // The same with the two row-broadcast steps writing into registers of their own (z[0..1]: rows 1 and 3 of the wave,
 // z[2..3]: rows 2 and 3): the rows a step leaves alone must read 0, and a fresh destination would be zeroed before
 // every step - these keep the zeros they start with (the caller clears them once per tile).
@@ -105,71 +85,6 @@ __device__ __forceinline__ void wave_exclusive_scan_z(double& c, unsigned& r, in
     r += dpp_u32<DPP_ROW_BCAST31, 0xc>(r);
     c = dpp_f64<DPP_WAVE_SHR1, 0xf>(c);
     r = dpp_u32<DPP_WAVE_SHR1, 0xf>(r);
-}
-
-// ------------------------------------------------------------------ box sums on the SAT
-// Four off-cross quadrants (donut support) and the lower-left quadrant at Chebyshev radius rho (per lane)
-// around SAT cell `base` = Y * LC + X.  pixc: the pixel's own balanced value; sc = S(Y, X-1).
-__device__ __forceinline__ void box_ky(const double* __restrict__ Sc, int base, int rho, double pixc, double sc,
-                                       double& kc, double& yc) {
-    const int t = base - (rho + 1) * LC, b = base + rho * LC, m0 = base - LC;
-    const int xl = -(rho + 1), xr = rho;
-    const double tl = Sc[t + xl], tm1 = Sc[t - 1], tm = Sc[t], tr = Sc[t + xr];
-    const double bl = Sc[b + xl], bm1 = Sc[b - 1], bm = Sc[b], br = Sc[b + xr];
-    const double ml0 = Sc[m0 + xl], ml1 = Sc[base + xl], mr0 = Sc[m0 + xr], mr1 = Sc[base + xr];
-    const double top = (tl - tm1) + (tm - tr);
-    const double bot = (br - bm) + (bm1 - bl);
-    const double mid = (ml1 - ml0) + (mr0 - mr1);
-    kc = ((top + bot) + mid) + pixc;
-    yc = (bm1 - bl) - (sc - ml1);
-}
-// the same two boxes on the valid-count field of the packed plane (exact, wrapping): decides whether a tiny f64 box
-// sum is an exact zero (every contributing balanced value is 0) or just small.  Returns the two counts.
-__device__ __noinline__ unsigned long long box_ky_valid(const unsigned* __restrict__ Sv, int base, int rho, unsigned pixv,
-                                                        unsigned sv) {
-    const int t = base - (rho + 1) * LC, b = base + rho * LC, m0 = base - LC;
-    const int xl = -(rho + 1), xr = rho;
-    const unsigned vtl = Sv[t + xl], vtm1 = Sv[t - 1], vtm = Sv[t], vtr = Sv[t + xr];
-    const unsigned vbl = Sv[b + xl], vbm1 = Sv[b - 1], vbm = Sv[b], vbr = Sv[b + xr];
-    const unsigned vml0 = Sv[m0 + xl], vml1 = Sv[base + xl], vmr0 = Sv[m0 + xr], vmr1 = Sv[base + xr];
-    const unsigned kv = vtl - vtm1 + vtm - vtr + vbr - vbm + vbm1 - vbl + vml1 - vml0 + vmr0 - vmr1 + pixv;
-    const unsigned yv = vbm1 - vbl - sv + vml1;
-    return (unsigned long long)(kv >> PK_SHIFT) | (unsigned long long)(yv >> PK_SHIFT) << 32;   // in registers: no scratch
-}
-
-// lower-left box of capped raw counts (radius rho) on the packed plane; sr = S(Y, X-1)
-__device__ __forceinline__ unsigned reads_box(const unsigned* __restrict__ Sr, int base, int rho, unsigned sr) {
-    const int b = base + rho * LC, xl = -(rho + 1);
-    return (Sr[b - 1] - sr - Sr[b + xl] + Sr[base + xl]) & PK_MASK;
-}
-
-// balanced value of pixel (rr, cc) on diagonal k (formed on chip in weight mode): (raw * w_r) * w_c, NaN -> 0
-__device__ __forceinline__ double balanced_of(float raw, double wr, double wc) {
-    double b = ((double)raw * wr) * wc;
-    return (b == b) ? b : 0.0;
-}
-
-// explicit local-expected sums for pixels whose window is clipped by the matrix ends (callers.py:50-96 padding)
-// (returned by value: reference parameters of a call that is not inlined live in scratch memory, and the scoring kernel
-// then stored and re-loaded its expected sums around the - rare - call in every work item)
-__device__ __noinline__ double2 edge_expected(const int32_t* __restrict__ m, int wi, const double* __restrict__ IR, int r,
-                                              int c, int n, int num, int mw) {
-    double ek = 0.0, ey = 0.0;
-    for (int di = -wi; di <= wi; ++di) {
-        for (int dj = -wi; dj <= wi; ++dj) {
-            if (di == 0 || dj == 0) continue;
-            const int adi = di < 0 ? -di : di, adj = dj < 0 ? -dj : dj;
-            const int rho = adi > adj ? adi : adj;
-            const int mm = m[rho];
-            if (mm == 0) continue;
-            const int rr = r + di, cc = c + dj, kk = cc - rr;
-            if (rr < 0 || cc >= n || kk < mw || kk >= num) continue;
-            const double v = (double)mm * IR[kk];
-            ek += v;
-            if (di > 0 && dj < 0) ey += v;
-        }
-    }
-    return make_double2(ek, ey);
 }
 
 // Explicit window sums of one pixel at one step (rare path of the stencil): taken when the summed-area table cannot
@@ -203,100 +118,6 @@ __device__ __noinline__ double2 explicit_sums_wave(const float* __restrict__ raw
     return make_double2(sk, sy);
 }
 
-// Argument block of the first-generation kernel (one band per launch; built on the host from the batch's HpkStencilArgs
-// and the band's descriptor).
-struct HpkStencil1Args {
-    const float*  raw;
-    const double* bal;
-    const double* weight;
-    const HpkDevPlan* plan;
-    unsigned* rec_ent;
-    double2* rec_S;
-    uint8_t* rec_W;
-    unsigned* tile_cnt;
-    uint2* units;
-    unsigned* nunits;
-    int32_t tilecap;
-    int64_t rec_stride;
-    uint8_t* gap;
-    unsigned long long* hist;           // dbg_stop builds only: keeps values live
-    unsigned long long* hist_acc;
-    double risk;
-    int32_t n, num;
-    int64_t ld;
-    int32_t W, mw, D;
-    int32_t TR, TC;
-    int32_t J;
-    int32_t ntiles, chunk;
-    int32_t order;
-    unsigned long long* clk;
-    int32_t dbg_stop;
-};
-// ------------------------------------------------------------------ stencil
-// Band rows of one tile as they sit in registers between the load and the SAT construction: this wave's RPW rows x
-// 128 columns, two cells per lane.
-template <int RPW, bool BALF64>
-struct TileRegs {
-    float raw[RPW][2];
-    double bal[BALF64 ? RPW : 1][2];    // f64 input mode: balanced values as given
-    double wc[2];                       // weight mode: column weights of the two cells
-    double wrow[BALF64 ? 1 : RPW];      // weight mode: row weights
-};
-
-template <int RPW, bool BALF64>
-__device__ __forceinline__ void tile_load(const HpkStencil1Args& a, const float* __restrict__ g_raw, const double* __restrict__ g_bal,
-                                          const double* __restrict__ g_w, int tid, int wave, int lane, TileRegs<RPW, BALF64>& t) {
-    const int rb = tid / a.J, cj = tid - rb * a.J;
-    const int r0 = rb * a.TR;
-    const int c0 = r0 + a.mw + cj * a.TC;
-    const int n = a.n, num = a.num;
-    const int cc0 = c0 - a.W - 1 + 2 * lane;
-    const int rr0 = r0 - a.W - 1 + wave * RPW;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int cc = cc0 + e;
-        t.wc[e] = 0.0;
-        if (!BALF64 && cc >= 0 && cc < n) t.wc[e] = g_w[cc];
-    }
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-        const int rr = rr0 + j;
-        const bool rowok = rr >= 0 && rr < n;
-        if (!BALF64) t.wrow[j] = rowok ? g_w[rr] : 0.0;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int cc = cc0 + e;
-            const int k = cc - rr;
-            const bool inb = rowok && cc < n && k >= 0 && k < num;
-            t.raw[j][e] = 0.f;
-            if (BALF64) t.bal[j][e] = 0.0;
-            if (inb) {
-                const int64_t off = (int64_t)rr * a.ld + k;
-                t.raw[j][e] = g_raw[off];
-                if (BALF64 && k >= a.mw) t.bal[j][e] = g_bal[off];
-            }
-        }
-    }
-}
-
-// XCD-aware persistent tile order: workgroup b runs on XCD b % 8 (observed); XCD x owns the contiguous run of tiles
-// [x * chunk, (x + 1) * chunk) and its workgroups walk it with stride = workgroups per XCD, so tiles processed at
-// the same time on one XCD are neighbours and share their halo rows/columns through that XCD's L2.
-__device__ __forceinline__ int tile_of(const HpkStencil1Args& a, int it) {
-    const int xcd = (int)(blockIdx.x & 7), j = (int)(blockIdx.x >> 3), per = (int)(gridDim.x >> 3);
-    const int k = j + it * per;
-    if (!(k < a.chunk && xcd * a.chunk + k < a.ntiles)) return -1;
-    const int t = xcd * a.chunk + k;
-    if (a.order == 0) return t;
-    // Column chunk 0 holds the near-diagonal pixels (every one a candidate), the last chunks almost none: with the
-    // plain order a workgroup's stride (32) visits only every other column class and half of the workgroups get all
-    // the dense tiles.  Rotating the column chunk by the row block gives every workgroup every class in turn.
-    const int rb = t / a.J, c = t - rb * a.J;
-    int cj = c + rb % a.J;
-    if (cj >= a.J) cj -= a.J;
-    return rb * a.J + cj;
-}
-
 // Per-phase cycle accounting (-DHPK_PHASE_CLOCK builds only; scripts/gpu_phase_clock.sh): every wave sums s_memtime
 // deltas per phase of the tile loop and leaves them in a.clk[(workgroup * NW + wave) * 8 + phase].
 #ifdef HPK_PHASE_CLOCK
@@ -306,420 +127,6 @@ __device__ __forceinline__ int tile_of(const HpkStencil1Args& a, int it) {
 #define HPK_CLK_DECL
 #define HPK_CLK(v)
 #endif
-
-template <int NW, bool BALF64, bool SIMPLE>
-__global__ void __launch_bounds__(NW * 64) hpk_stencil(HpkStencil1Args a, const float* __restrict__ g_raw,
-                                                        const double* __restrict__ g_bal, const double* __restrict__ g_w,
-                                                        double2* __restrict__ g_recS, uint8_t* __restrict__ g_recW) {
-    constexpr int RPW = LR / NW;
-    static_assert(RPW * NW == LR, "rows must split evenly over the waves");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Sat S;
-    S.c = reinterpret_cast<double*>(smem);
-    S.p = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 8);
-    S.l = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 12);
-    // records written into the current tile's region so far: the tile belongs to this workgroup alone, so its waves
-    // reserve their share with an LDS atomic (a global one costs every wave an L2 round trip per tile and a vmcnt(0)
-    // that also waits for the prefetch)
-    unsigned* __restrict__ ltc = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 12 + (size_t)NW * HPK_LISTCAP * 4);
-    if (threadIdx.x == 0) ltc[0] = 0u;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int W = a.W, n = a.n, num = a.num, mw = a.mw, D = a.D;
-
-    // ---- per-workgroup constants.  The widening plan lives in registers: lane s holds step s (HpkDevPlan::packed),
-    // v_readlane / ds_bpermute hand the fields out, so the pixel loops touch memory only for the SAT, the lists and the
-    // stores.  (Keeping it in LDS instead was measured 5 % slower.)
-    const HpkDevPlan* __restrict__ plan = a.plan;
-    const int nsteps = plan->nsteps, nslots = plan->nslots, min_reads = plan->min_reads;
-    const unsigned pkcap_p = (unsigned)__builtin_amdgcn_readfirstlane(plan->pk_cap);
-    int pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0, pk4 = 0, pk5 = 0, pk6 = 0;
-    if (lane < nsteps) {
-        const uint32_t* pk = plan->packed[lane];
-        pk0 = (int)pk[0]; pk1 = (int)pk[1]; pk2 = (int)pk[2]; pk3 = (int)pk[3];
-        pk4 = (int)pk[4]; pk5 = (int)pk[5]; pk6 = (int)pk[6];
-    }
-    // simple-Reads plans: lane (q & 1) * 32 + w of tab[q >> 1] = step of slot q at width w; lane q of wfv = first width
-    int tab0 = 0xff, tab1 = 0xff, wfv = 0;
-    int p0 = 0, wmin = 0;
-    if (SIMPLE) {
-        tab0 = plan->step_of[lane >> 5][lane & 31];
-        tab1 = plan->step_of[2 + (lane >> 5)][lane & 31];
-        wfv = plan->slot_wfirst[lane & (HPK_KSLOTS - 1)];
-        p0 = plan->reads_p0;
-        wmin = plan->wmin;
-    }
-    const unsigned alldone = (1u << nslots) - 1u;
-    unsigned myhist = 0u, mycand = 0u;
-    // gfx9 counts loads and stores on one vmcnt: a compiler-placed wait for any of these one-time loads *inside* the
-    // pixel loops would also drain the stores of the previous pass (measured: 16k cycles per pass).  Passing each
-    // value through an empty asm makes the compiler wait here, once, and treat the registers as plain values after.
-#define HPK_PIN_I(x) asm volatile("" : "+v"(x))
-    HPK_PIN_I(pk0); HPK_PIN_I(pk1); HPK_PIN_I(pk2); HPK_PIN_I(pk3); HPK_PIN_I(pk4); HPK_PIN_I(pk5); HPK_PIN_I(pk6);
-    HPK_PIN_I(tab0); HPK_PIN_I(tab1); HPK_PIN_I(wfv);
-    const int nsteps_p = __builtin_amdgcn_readfirstlane(nsteps), nslots_p = __builtin_amdgcn_readfirstlane(nslots);
-    const int minr_p = __builtin_amdgcn_readfirstlane(min_reads), p0_p = __builtin_amdgcn_readfirstlane(p0);
-    const int wmin_p = __builtin_amdgcn_readfirstlane(wmin);
-
-    // ---- persistent tile loop with register prefetch: while tile `cur` is evaluated out of LDS, the band rows of
-    // the next tile are already on their way into `nxt` (the evaluation itself issues no loads).
-    HPK_CLK_DECL
-    TileRegs<RPW, BALF64> nxt;
-    int tid = tile_of(a, 0);
-    if (tid >= 0) tile_load<RPW, BALF64>(a, g_raw, g_bal, g_w, tid, wave, lane, nxt);
-#pragma unroll 1
-    for (int it = 0; tid >= 0; ++it) {
-    const int rb = tid / a.J, cj = tid - rb * a.J;
-    const int r0 = rb * a.TR;
-    const int c0 = r0 + a.mw + cj * a.TC;
-    const bool empty_tile = c0 >= n || (mw + cj * a.TC - (a.TR - 1)) > D;      // no band pixel inside the matrix
-    const int tid_next = tile_of(a, it + 1);
-    if (empty_tile) {
-        if (tid_next >= 0) tile_load<RPW, BALF64>(a, g_raw, g_bal, g_w, tid_next, wave, lane, nxt);
-        tid = tid_next;
-        continue;
-    }
-
-    // ---- phase 1: balanced values and column totals of this wave's rows (values arrive from the prefetch)
-    const int xx0 = 2 * lane;
-    const int cc0 = c0 - W - 1 + xx0;
-    const int rr0 = r0 - W - 1 + wave * RPW;
-    double balv[RPW][2];
-    double tc[2] = {0.0, 0.0};
-    unsigned tp[2] = {0u, 0u};
-    unsigned pkv[RPW][2];
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const float rv = nxt.raw[j][e];
-            const int k = cc0 + e - (rr0 + j);
-            double bv = 0.0;
-            if (BALF64) { bv = nxt.bal[j][e]; bv = (bv == bv) ? bv : 0.0; }
-            else if (k >= mw) bv = balanced_of(rv, nxt.wrow[BALF64 ? 0 : j], nxt.wc[e]);
-            balv[j][e] = bv;
-            pkv[j][e] = pack_cell((unsigned)rv, bv != 0.0, pkcap_p);
-            tc[e] += bv;
-            tp[e] += pkv[j][e];
-        }
-    }
-    HPK_CLK(ck0)
-    // the prefetch registers are free again: the next tile's rows start moving now, beside this tile's SAT build and
-    // candidate work (nothing below waits for them)
-    if (tid_next >= 0) tile_load<RPW, BALF64>(a, g_raw, g_bal, g_w, tid_next, wave, lane, nxt);
-    if (a.dbg_stop == 1) {
-        if (tc[0] + tc[1] == -1.0 && tp[0] + tp[1] == 77u) a.hist[0] = 1ull;     // keep the loads live
-        tid = tid_next;
-        continue;
-    }
-    // column totals of this wave's row segment -> LDS (aliases the SAT; consumed before the SAT is written)
-    *reinterpret_cast<double2*>(&S.c[wave * LC + xx0]) = make_double2(tc[0], tc[1]);
-    *reinterpret_cast<uint2*>(&S.p[wave * LC + xx0]) = make_uint2(tp[0], tp[1]);
-    __syncthreads();
-    double ac[2] = {0.0, 0.0};           // running column sums of row-prefixed values = SAT of the rows above
-    unsigned ar[2] = {0u, 0u};
-    for (int w2 = 0; w2 < wave; ++w2) {
-        const double2 t = *reinterpret_cast<const double2*>(&S.c[w2 * LC + xx0]);
-        const uint2 u = *reinterpret_cast<const uint2*>(&S.p[w2 * LC + xx0]);
-        ac[0] += t.x; ac[1] += t.y; ar[0] += u.x; ar[1] += u.y;
-    }
-    __syncthreads();
-    HPK_CLK(ck1)
-    {   // prefix of the segment base along the row
-        double pc = ac[0] + ac[1]; unsigned pr = ar[0] + ar[1];
-        const double l1c = pc; const unsigned l1r = pr;
-        wave_exclusive_scan(pc, pr);
-        ac[0] = pc + ac[0]; ar[0] = pr + ar[0];
-        ac[1] = pc + l1c;   ar[1] = pr + l1r;
-    }
-    // ---- phase 2: row prefix by DPP scan, column prefix by running sums, one LDS write per cell
-#pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-        const unsigned r0u = pkv[j][0], r1u = pkv[j][1];
-        const double c0v = balv[j][0], c1v = balv[j][1];
-        const double l1c = c0v + c1v; const unsigned l1r = r0u + r1u;
-        double pc = l1c; unsigned pr = l1r;
-        wave_exclusive_scan(pc, pr);
-        ac[0] += pc + c0v; ar[0] += pr + r0u;
-        ac[1] += pc + l1c; ar[1] += pr + l1r;
-        const int o = (wave * RPW + j) * LC + xx0;
-        *reinterpret_cast<double2*>(&S.c[o]) = make_double2(ac[0], ac[1]);
-        *reinterpret_cast<uint2*>(&S.p[o]) = make_uint2(ar[0], ar[1]);
-    }
-    HPK_CLK(ck2)
-    __syncthreads();
-    HPK_CLK(ck3)
-    if (a.dbg_stop == 2) {
-        if (S.c[threadIdx.x] == -1.0) a.hist[0] = 1ull;
-        __syncthreads();
-        tid = tid_next;
-        continue;
-    }
-    const double tiny_thr = 1e-9 * S.c[LR * LC - 1];
-    // Gap rows (callers.py:238: rows of the balanced upper band that sum to 0): the valid-count field gives the exact
-    // row sum of this tile's columns; the last tile of a row block also covers the maxww diagonals beyond D in its
-    // right halo.  The flags start at 0 ("no signal seen"); any tile that sees a non-zero balanced value in row r
-    // sets rowlive[r] (plain byte stores of the same value: no atomics needed).  gap = !rowlive.
-    if ((int)threadIdx.x < a.TR && r0 + (int)threadIdx.x < n) {
-        const bool last = (cj == a.J - 1) || (c0 + a.TC >= n) || (mw + (cj + 1) * a.TC - (a.TR - 1)) > D;
-        const int Y = (int)threadIdx.x + W + 1;
-        const int xe = last ? LC - 1 : W + a.TC, xs = W;
-        const unsigned rs = S.p[Y * LC + xe] - S.p[(Y - 1) * LC + xe] - S.p[Y * LC + xs] + S.p[(Y - 1) * LC + xs];
-        if ((rs >> PK_SHIFT) != 0u) a.gap[r0 + (int)threadIdx.x] = 1;
-    }
-
-    // ---- phase 3: candidates of the tile.  Work is proportional to the candidates (non-zero pixels), not to the
-    // band pixels:
-    //   (L) each wave walks its rows (y = wave, wave + NW, ...), takes every pixel's (capped) count out of the packed
-    //       SAT and appends the candidates' ids (row slot << 7 | x) to its list in LDS (ballot + mbcnt offsets);
-    //   (A) per batch of 64 candidates: first step whose Reads reach min_local_reads - three u32 SAT reads per
-    //       radius, for "simple" plans without a step loop;
-    //   (B) donut / lower-left sums once per slot with per-lane radii (each lane fetches its own step's box terms
-    //       with ds_bpermute), scattered 17-byte stores for the candidates only.
-    // Output per slot and candidate pixel: (bS_K, bS_Y) f64 + resolving step + 1 (u8); pixels with a zero count are
-    // never written (nothing reads them).  The local expected, biases and division belong to the scoring kernel.
-    unsigned* __restrict__ lst = S.l + wave * HPK_LISTCAP;            // this wave's list: at most 4 rows x TC entries
-    int cnt = 0;
-#pragma unroll 1
-    for (int yi = 0; wave + NW * yi < a.TR; ++yi) {
-        const int y = wave + NW * yi;
-        const int r = r0 + y;
-        if (r >= n) break;
-        const int Yb = (y + W + 1) * LC + W + 1;
-#pragma unroll 1
-        for (int e = 0; e < 2; ++e) {
-            const int x = e * 64 + lane;
-            const int c = c0 + x;
-            const int d = c - r;
-            const bool inb = x < a.TC && c < n && d >= mw && d <= D && d < num;
-            const int base = Yb + (x < a.TC ? x : a.TC - 1);          // clamped: every lane reads inside the tile
-            const unsigned pix = S.p[base] - S.p[base - LC] - S.p[base - 1] + S.p[base - LC - 1];
-            const bool cnd = inb && (pix & PK_MASK) != 0u && a.dbg_stop != 4;
-            const unsigned long long M = __ballot(cnd);
-            if (M == 0ull) continue;
-            const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(M >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M, 0u));
-            if (cnd) lst[cnt + below] = (unsigned)x | ((unsigned)(wave + NW * yi) << 7) | ((pix & PK_MASK) << HPK_ENT_CNT_SHIFT);
-            cnt += __popcll(M);
-        }
-    }
-    // this wave's share of the tile's record region
-    unsigned woff = 0u;
-    if (cnt > 0) {
-        if (lane == 0) woff = atomicAdd(ltc, (unsigned)cnt);
-        woff = (unsigned)__builtin_amdgcn_readfirstlane((int)woff);
-    }
-    const int64_t rec0 = (int64_t)tid * a.tilecap + woff;
-    if (lane == 0) mycand += (unsigned)cnt;
-
-    const int nbatch = (cnt + 63) >> 6;
-    HPK_CLK(ck4)
-#ifdef HPK_PHASE_CLOCK
-    ck7 += (unsigned long long)nbatch;
-#endif
-#pragma unroll 1
-    for (int kb = 0; kb < nbatch; ++kb) {
-        const bool cand = kb * 64 + lane < cnt;
-        const unsigned id = cand ? lst[kb * 64 + lane] : 0u;
-        const int x = (int)(id & 127u);
-        const int y = (int)HPK_ENT_Y(id);
-        if (cand && a.dbg_stop != 7) a.rec_ent[rec0 + kb * 64 + lane] = id;
-        const int r = r0 + y;
-        const int d = c0 + x - r;
-        const int base = (y + W + 1) * LC + W + 1 + x;       // idle lanes: id 0 -> a valid interior cell
-        // S(Y, X-1) of the planes, the pixel's own balanced value, and the first Reads boxes: one batch of reads
-        const unsigned sr = S.p[base - 1];
-        const double sc = S.c[base - 1];
-        const double pixc = cand ? (S.c[base] - S.c[base - LC]) - (sc - S.c[base - LC - 1]) : 0.0;
-        unsigned sstar = 0xffffffffu;           // resolving step index, 8 bits per slot (0xff = none)
-        // ---- (A) resolving step per slot
-        if (SIMPLE) {
-            // first width w* whose lower-left rings p0+1 .. w hold >= min_local_reads counts.  Rings are only ever
-            // added, so Reads is monotone in w: the narrowest and the widest box are read together (most candidates
-            // pass the first, far-from-diagonal ones often fail even the last), the lanes in between bisect.
-            const unsigned b0 = (p0_p > 0) ? reads_box(S.p, base, p0_p, sr) : 0u;
-            const unsigned bf = reads_box(S.p, base, wmin_p, sr);
-            const unsigned bl = reads_box(S.p, base, W, sr);
-            int wstar = 255;
-            if (cand && bf - b0 >= (unsigned)minr_p) wstar = wmin_p;
-            else if (cand && bl - b0 >= (unsigned)minr_p) wstar = W;
-            int lo = wmin_p, hi = W;            // invariant for bisecting lanes: Reads(lo) < min <= Reads(hi)
-            bool bis = cand && wstar == W && hi - lo > 1;
-            while (__ballot(bis) != 0ull) {
-                const int mid = (lo + hi) >> 1;
-                const unsigned bm = reads_box(S.p, base, bis ? mid : wmin_p, sr);
-                if (bis) {
-                    if (bm - b0 >= (unsigned)minr_p) hi = mid; else lo = mid;
-                    wstar = hi;
-                    bis = hi - lo > 1;
-                }
-            }
-            if (a.dbg_stop == 6 && cand) wstar = wmin_p;
-#pragma unroll 1
-            for (int q = 0; q < nslots_p; ++q) {
-                const int wf = __builtin_amdgcn_readlane(wfv, q);
-                const int wq = wstar > wf ? wstar : wf;
-                int sq = __shfl((q >> 1) ? tab1 : tab0, ((q & 1) << 5) + (wq & 31));
-                if (!cand || wstar == 255) sq = 0xff;
-                sstar = (sstar & ~(0xffu << (8 * q))) | ((unsigned)(sq & 0xff) << (8 * q));
-                // histogram: one ballot per distinct resolving step present in the wave
-                unsigned long long left = __ballot(sq != 0xff);
-                while (left != 0ull) {
-                    const int ln = __ffsll((long long)left) - 1;
-                    const int sv0 = __builtin_amdgcn_readlane(sq, ln);
-                    const unsigned long long same = __ballot(sq == sv0);
-                    if (lane == sv0) myhist += (unsigned)__popcll(same);
-                    left &= ~same;
-                }
-            }
-        } else {
-            // generic plans: walk the steps (uniform), Reads recomputed when the step's Reads matrix changes
-            unsigned done = cand ? 0u : alldone;
-            int cur_rid = -1;
-            unsigned reads = 0u;
-#pragma unroll 1
-            for (int s2 = 0; s2 < nsteps_p; ++s2) {
-                const unsigned w0 = (unsigned)__builtin_amdgcn_readlane(pk0, s2);
-                const int slot = (int)(w0 & 3u), rid = (int)((w0 >> 10) & 63u), nrt = (int)((w0 >> 16) & 15u);
-                const bool need = ((done >> slot) & 1u) == 0u;
-                if (__ballot(need) == 0ull) continue;
-                if (rid != cur_rid) {
-                    cur_rid = rid;
-                    const unsigned long long rt = (unsigned long long)(unsigned)__builtin_amdgcn_readlane(pk1, s2) |
-                                                  (unsigned long long)(unsigned)__builtin_amdgcn_readlane(pk2, s2) << 32;
-                    unsigned acc = 0u;
-                    for (int j = 0; j < nrt; ++j) {
-                        const unsigned t = (unsigned)(rt >> (16 * j)) & 0xffffu;
-                        acc += (unsigned)(int)(signed char)(t >> 8) * reads_box(S.p, base, (int)(t & 0xffu), sr);
-                    }
-                    reads = acc;
-                }
-                const bool hit = need && (reads >= (unsigned)minr_p);
-                const unsigned long long hitmask = __ballot(hit);
-                if (lane == s2) myhist += (unsigned)__popcll(hitmask);
-                if (hit) {
-                    sstar = (sstar & ~(0xffu << (8 * slot))) | ((unsigned)s2 << (8 * slot));
-                    done |= 1u << slot;
-                }
-                if (__ballot(done != alldone) == 0ull) break;
-            }
-        }
-        if (a.dbg_stop == 5) sstar = 0xffffffffu;
-        // ---- (B) sums at the resolving step, once per slot; outputs are stored right away
-#pragma unroll 1
-        for (int q = 0; q < nslots_p; ++q) {
-            const int sq = (int)((sstar >> (8 * q)) & 0xffu);
-            const bool act = cand && sq != 0xff;
-            double SK = 0.0, SY = 0.0;
-            if (__ballot(act) != 0ull) {
-                const int src = act ? sq : 0;
-                const unsigned w0 = (unsigned)__shfl(pk0, src);
-                const unsigned k0 = (unsigned)__shfl(pk3, src), k1 = (unsigned)__shfl(pk4, src);
-                const unsigned k2 = (unsigned)__shfl(pk5, src), k3 = (unsigned)__shfl(pk6, src);
-                const int nkt = act ? (int)((w0 >> 20) & 15u) : 0;
-#pragma unroll 1
-                for (int j = 0; j < HPK_PK_KT; ++j) {
-                    const bool on = j < nkt;
-                    if (__ballot(on) == 0ull) break;
-                    const unsigned kw = (j < 2) ? k0 : (j < 4) ? k1 : (j < 6) ? k2 : k3;
-                    const unsigned t = (kw >> (16 * (j & 1))) & 0xffffu;
-                    const int rho = on ? (int)(t & 0xffu) : 1;      // idle lanes read a harmless box
-                    const double cf = on ? (double)(int)(signed char)(t >> 8) : 0.0;
-                    double kc, yc;
-                    box_ky(S.c, base, rho, pixc, sc, kc, yc);
-                    SK += cf * kc; SY += cf * yc;
-                }
-                // A lower-left cell on ring rho lies at least rho + 1 diagonals nearer to the main diagonal: with
-                // rho_min the smallest ring of this step, the whole lower-left support is off the band (bS_Y = 0
-                // exactly) for d < mw + rho_min + 1.
-                if (d - (int)((w0 >> 24) & 31u) - 1 < mw) SY = 0.0;
-                // A box whose balanced values are all 0 must come out as exact 0 (as the reference's CSR adds do);
-                // the f64 SAT leaves rounding residue of at most ~1e-13 of the tile total there.  Sums below 1e-9
-                // of the tile total are re-examined on the exact valid-count field of the packed plane.
-                // ... and sums below a.risk (2^-12) of the window's largest table entry carry that entry's rounding noise (relative
-                // error ~ 1e-15 x entry / sum): those with non-zero cells are redone by adding the window cells themselves,
-                // the whole wave on one pixel at a time (explicit_sums_wave).
-                const double thr = fmax(tiny_thr, S.c[base + W * LC + W] * a.risk);
-                const bool tiny = act && (SK <= thr || (SY <= thr && SY != 0.0));
-                if (__ballot(tiny) != 0ull) {
-                    if (tiny) {
-                        const unsigned sv = sr;
-                        const unsigned pv = S.p[base] - S.p[base - LC] - sv + S.p[base - LC - 1];
-                        unsigned VK = 0u, VY = 0u;
-#pragma unroll 1
-                        for (int j = 0; j < nkt; ++j) {
-                            const unsigned kw = (j < 2) ? k0 : (j < 4) ? k1 : (j < 6) ? k2 : k3;
-                            const unsigned t = (kw >> (16 * (j & 1))) & 0xffffu;
-                            const unsigned long long kyv = box_ky_valid(S.p, base, (int)(t & 0xffu), pv, sv);
-                            VK += (unsigned)(int)(signed char)(t >> 8) * (unsigned)kyv;
-                            VY += (unsigned)(int)(signed char)(t >> 8) * (unsigned)(kyv >> 32);
-                        }
-                        if (VK == 0u) { SK = 0.0; SY = 0.0; }
-                        else if (VY == 0u) SY = 0.0;
-                    }
-                    unsigned long long todo = __ballot(tiny && SK != 0.0);
-                    while (todo != 0ull) {
-                        const int src = __ffsll((long long)todo) - 1;
-                        todo &= todo - 1ull;
-                        const int er = __builtin_amdgcn_readlane(r, src), ec = __builtin_amdgcn_readlane(c0 + x, src);
-                        const int es = __builtin_amdgcn_readlane(sq, src);
-                        const double2 ex = explicit_sums_wave(g_raw, g_bal, g_w, plan->steps[es].m, W, er, ec, n, num, a.ld, mw, lane);
-                        if (lane == src) { SK = ex.x; SY = (SY == 0.0) ? 0.0 : ex.y; }
-                    }
-                }
-            }
-            if (a.dbg_stop == 7) { if (SK == -1.0 && SY == -7.0 && sq == 1234) a.hist[0] = 1ull; }
-            else if (cand) {
-                const int64_t o = q * a.rec_stride + rec0 + kb * 64 + lane;
-                g_recS[o] = make_double2(act ? SK : 0.0, act ? SY : 0.0);
-                g_recW[o] = act ? (uint8_t)(sq + 1) : (uint8_t)0;
-            }
-        }
-    }
-    HPK_CLK(ck5)
-    __syncthreads();                 // every wave is done with this tile's SAT
-    HPK_CLK(ck6)
-    if (wave == 0) {
-        // The tile's records become work for the scoring kernel: one entry per 256 records, appended to the global
-        // list with one atomic per tile (tiles finish at ~15-25 per microsecond, well under the same-address rate).
-        // ltc is next touched two barriers from here.
-        const volatile HpkStencil1Args* ka = (const volatile HpkStencil1Args*)(const void*)__builtin_amdgcn_kernarg_segment_ptr();
-        const unsigned c = ltc[0];
-        const unsigned nu = (c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT;
-        if (nu != 0u) {
-            unsigned off = 0u;
-            if (lane == 0) off = atomicAdd(const_cast<unsigned*>(ka->nunits), nu);
-            off = (unsigned)__builtin_amdgcn_readfirstlane((int)off);
-            if ((unsigned)lane < nu) const_cast<uint2*>(ka->units)[off + lane] = make_uint2((unsigned)tid, (unsigned)lane | (c << 8));
-        }
-        if (lane == 0) { a.tile_cnt[tid] = c; ltc[0] = 0u; }
-    }
-    tid = tid_next;
-    }   // tile loop
-
-    // Resolve histogram: 40k same-address atomics (one per wave and tile) serialise at ~90 per microsecond in L2 -
-    // 0.46 ms, several times the kernel itself.  Instead the waves of the workgroup meet in LDS (the SAT is dead now)
-    // and the workgroup adds its counts to the chromosome's totals once.
-#ifdef HPK_PHASE_CLOCK
-    if (a.clk && lane == 0) {
-        unsigned long long* o = a.clk + ((size_t)blockIdx.x * NW + wave) * 8;
-        o[0] = ck0; o[1] = ck1; o[2] = ck2; o[3] = ck3; o[4] = ck4; o[5] = ck5; o[6] = ck6; o[7] = ck7;
-    }
-#endif
-    unsigned* red = reinterpret_cast<unsigned*>(smem);
-    red[wave * (HPK_MAX_STEPS + 1) + lane] = myhist;
-    if (lane == 0) red[wave * (HPK_MAX_STEPS + 1) + HPK_MAX_STEPS] = mycand;
-    __syncthreads();
-    if (threadIdx.x <= HPK_MAX_STEPS) {
-        unsigned tot = 0u;
-        for (int w2 = 0; w2 < NW; ++w2) tot += red[w2 * (HPK_MAX_STEPS + 1) + threadIdx.x];
-        // the counts go straight into the chromosome's totals (one word per cache line); whoever needs the freeze decision
-        // replays it on them (hpk_score's prologue, hpk_freeze_tot)
-        if (tot) atomicAdd(&a.hist_acc[threadIdx.x * HPK_ACC_STRIDE], (unsigned long long)tot);
-    }
-}
-
-__device__ __noinline__ double poisson_sf(double k, double lam, const double* __restrict__ sfe, double sigcap);      // (below)
 
 // ------------------------------------------------------------------ stencil for "simple Reads" plans
 // Second-generation stencil kernel: same tile geometry, SAT planes and record output as hpk_stencil above (which stays
@@ -751,8 +158,6 @@ __device__ __noinline__ double poisson_sf(double k, double lam, const double* __
 // (selects on the inputs instead of ifs around the arithmetic).
 // (HPK_TLIST, hpk_kernels.h: the tile-wide candidate list holds TR * TC entries - 64 x 119 at a halo of 4, 66 x 115 at 6)
 using rsrc_t = __amdgpu_buffer_rsrc_t;
-// a band descriptor's pointer field (global address space, see HPK_GP) as an ordinary pointer
-template <class T> __device__ __forceinline__ T* gptr(HPK_GP(T) p) { return (T*)p; }
 constexpr unsigned OOB_OFF = 0x7ffffff0u;   // beyond every buffer's num_records (all < 2^31): the load returns 0
 
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
@@ -769,25 +174,6 @@ __device__ __forceinline__ constexpr int sat_row(int wave, int j) { return 5 * w
 
 // the lane mask of a predicate as the compiler holds it (HIP's __ballot goes through an int: v_cndmask + v_cmp per call)
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-// box sums on the column-reversed table P(Y, X) = sum over rows <= Y, columns >= X (hpk_stencil_s).
-// Lower-left box of capped raw counts at radius rho: rows (Y, Y + rho], columns [X - rho, X - 1]; sr = P(Y, X).
-__device__ __forceinline__ unsigned reads_box_m(const unsigned* __restrict__ Pr, int base, int rho, unsigned sr) {
-    const int b = base + rho * LC;
-    return (Pr[b - rho] - Pr[b] - Pr[base - rho] + sr) & PK_MASK;
-}
-// Four off-cross quadrants (donut support) and the lower-left quadrant at Chebyshev radius rho (per lane) around cell
-// `base` = Y * LC + X.  pixc: the pixel's own balanced value; sc = P(Y, X).
-__device__ __forceinline__ void box_ky_m(const double* __restrict__ P, int base, int rho, double pixc, double sc, double& kc, double& yc) {
-    const int t = base - (rho + 1) * LC, b = base + rho * LC, m0 = base - LC;
-    const double tl = P[t - rho], tm = P[t], tm1 = P[t + 1], tr = P[t + rho + 1];
-    const double bl = P[b - rho], bm = P[b], bm1 = P[b + 1], br = P[b + rho + 1];
-    const double ml1 = P[base - rho], ml0 = P[m0 - rho], mr1 = P[base + rho + 1], mr0 = P[m0 + rho + 1];
-    const double bot = (bl - bm) + (bm1 - br);          // rows <= Y + rho, columns [X - rho, X - 1] and [X + 1, X + rho]
-    const double top = (tl - tm) + (tm1 - tr);          // rows <= Y - rho - 1, same columns
-    const double mid = (ml1 - mr1) - (ml0 - mr0);       // row Y, columns [X - rho, X + rho]
-    kc = ((bot - top) - mid) + pixc;
-    yc = (bl - bm) - (ml1 - sc);
-}
 // The same two on LDS byte addresses (phase 3 of hpk_stencil_s): per read one add of an offset to the cell's own address
 // instead of index arithmetic plus a scale, neighbours through the instruction's immediate.  pb = address of P(Y, X) in
 // the packed plane, cb = in the f64 plane (both include the workgroup's LDS base).
@@ -1028,6 +414,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
                 const uint32_t* pk = plan->packed[lane_k];
                 pl[lane_k * 8 + 0] = pk[0]; pl[lane_k * 8 + 1] = pk[3]; pl[lane_k * 8 + 2] = pk[4]; pl[lane_k * 8 + 3] = pk[5];
                 pl[lane_k * 8 + 4] = pk[6];
+                pl[lane_k * 8 + 5] = pk[1]; pl[lane_k * 8 + 6] = pk[2];          // (general plans: the Reads box terms of the step)
             }
             stepof[lane_k] = plan->step_of[lane_k >> 5][lane_k & 31];
             stepof[64 + lane_k] = plan->step_of[2 + (lane_k >> 5)][lane_k & 31];
@@ -1055,6 +442,12 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     const int sp_p = __builtin_amdgcn_readfirstlane(plan->single_p);     // SINGLE: the peak width
     const unsigned pkcap_p = (unsigned)__builtin_amdgcn_readfirstlane(plan->pk_cap);
     const int fr_p = SINGLE ? 0 : __builtin_amdgcn_readfirstlane(plan->first_rho);   // general plans: the box every step starts with
+    // Plans whose Reads matrix is not monotone in the width (pairs listed in decreasing order, callers.py:15-23 sorts the steps
+    // by width then peak width): no "first sufficient width" - the steps are walked in plan order, per slot the first one whose
+    // Reads reach min_local_reads resolves (callers.py:203-217), and the resolve histogram is kept per step.
+    const bool generic_p = !SINGLE && a.generic != 0;
+    // a halo wider than the plan's maxww (maxww < 4: the tiles keep a halo of 4): widths beyond maxww have no step
+    const int planw_p = __builtin_amdgcn_readfirstlane(plan->W);
     const int planW_p = __builtin_amdgcn_readfirstlane(plan->W);       // FUSE: maxww (the local-expected tables' edge depth), not the tiles' halo
     const int sig_e = (int)((unsigned long long)__double_as_longlong(a.sig) >> 52);                  // FUSE: sig > 0, normal
     const unsigned long long sig_m = (unsigned long long)__double_as_longlong(a.sig) & 0xfffffffffffffull;
@@ -1125,7 +518,8 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             if (tix < nsteps) {
                 const HpkDevStep& st = plan->steps[tix];
                 const int wf = plan->slot_wfirst[st.slot];
-                if (st.wi > wf) out = hw[st.wi];
+                if (generic_p) out = hw[tix];                   // (counted per step)
+                else if (st.wi > wf) out = hw[st.wi];
                 else for (int w = 0; w <= wf && w < 64; ++w) out += hw[w];
             } else if (tix == HPK_MAX_STEPS) out = red[NW * 64];
             if (out) atomicAdd(&gptr(hb->hist_acc)[tix * HPK_ACC_STRIDE], (unsigned long long)out);
@@ -1424,10 +818,44 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             pixc = (sc - lds_f64(cb + 8)) - (lds_f64(cb - LC * 8) - lds_f64(cb - LC * 8 + 8));
             amax = lds_f64(cb + (unsigned)(W * (LC - 1) * 8));
         }
+        int wstar = 255;
+        unsigned sstar = 0xffffffffu;           // general plans: resolving step per slot, 8 bits each (0xff = none)
+        if (generic_p) {
+            const unsigned alldone = (1u << nslots_p) - 1u;
+            unsigned done = cand ? 0u : alldone;
+            int cur_rid = -1;
+            unsigned reads = 0u;
+#pragma unroll 1
+            for (int s2 = 0; s2 < nsteps; ++s2) {
+                const unsigned w0 = (unsigned)__builtin_amdgcn_readfirstlane((int)pl[s2 * 8]);
+                const int slot = (int)(w0 & 3u), rid = (int)((w0 >> 10) & 63u), nrt = (int)((w0 >> 16) & 15u);
+                const bool need = ((done >> slot) & 1u) == 0u;
+                if (ballot64(need) == 0ull) continue;
+                if (rid != cur_rid) {                   // the step's Reads matrix: sum of its lower-left box terms
+                    cur_rid = rid;
+                    const unsigned long long rt = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)pl[s2 * 8 + 5]) |
+                                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)pl[s2 * 8 + 6]) << 32;
+                    unsigned acc = 0u;
+                    for (int j = 0; j < nrt; ++j) {
+                        const unsigned t = (unsigned)(rt >> (16 * j)) & 0xffffu;
+                        acc += (unsigned)(int)(signed char)(t >> 8) * reads_box_b(pb, (int)(t & 0xffu), sr);
+                    }
+                    reads = acc & PK_MASK;
+                }
+                const bool hit = need & (reads >= (unsigned)minr_p);
+                const unsigned long long hm = ballot64(hit);
+                if (lane == s2) myhist += (unsigned)__popcll(hm);
+                if (hit) {
+                    sstar = (sstar & ~(0xffu << (8 * slot))) | ((unsigned)s2 << (8 * slot));
+                    done |= 1u << slot;
+                }
+                if (ballot64(done != alldone) == 0ull) break;
+            }
+            wstar = (cand & (sstar != 0xffffffffu)) ? wmin_p : 255;     // (resolved in some slot: gets a record whatever the bound)
+        } else {
         const unsigned b0 = (p0_p > 0) ? reads_box_b(pb, p0_p, sr) : 0u;
         const unsigned bf = reads_box_b(pb, wmin_p, sr);
         const unsigned bl = reads_box_b(pb, W, sr);
-        int wstar = 255;
         wstar = (cand & (bl - b0 >= (unsigned)minr_p)) ? W : wstar;
         wstar = (cand & (bf - b0 >= (unsigned)minr_p)) ? wmin_p : wstar;
         // lanes that pass the widest but not the narrowest box: all widths in between, four at a time (Reads is monotone)
@@ -1475,6 +903,8 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
                 }
             }
         }
+        if (W > planw_p) wstar = wstar > planw_p ? 255 : wstar;        // (a halo beyond maxww: no step at those widths)
+        }   // monotone Reads
         // The candidates that get a record: a batch without any is done here; the others take their (packed) places in the
         // tile's record region from the tile's counter - one LDS atomic per batch, lane 0 (see phase 1), whose return is
         // waited for after the box sums.
@@ -1503,6 +933,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
                 const int wq = wstar > wf ? wstar : wf;
                 sq = (int)stepof[q * 32 + (wq & 31)];
                 sq = ((wstar == 255) | (wq > wg_p)) ? 0xff : sq;      // (a slot whose own first width lies beyond the bound)
+                if (generic_p) sq = wstar == 255 ? 0xff : (int)((sstar >> (8 * q)) & 0xffu);
             }
             const bool act = sq != 0xff;
             double SK = 0.0, SY = 0.0;
@@ -2150,68 +1581,6 @@ __global__ void __launch_bounds__(256) hpk_gap(const float* __restrict__ raw, co
     if (lane == 0) gap[r] = (m == 0ull) ? 0 : 1;        // same "row has signal" flag as the stencil kernel writes
 }
 
-// ------------------------------------------------------------------ Poisson
-// dpois by the saddle-point form (C. Loader, "Fast and accurate computation of binomial probabilities", 2000):
-// pmf(x; lam) = exp(-stirlerr(x) - bd0(x, lam)) / sqrt(2 pi x).  sfe[0..31] = stirlerr(n) for small n (host,
-// long double).
-__device__ __forceinline__ double stirlerr(double x, const double* __restrict__ sfe) {
-    if (x < 32.0) return sfe[(int)x];
-    const double x2 = x * x;
-    return (0.083333333333333333333 - (0.00277777777777777777778 - (0.00079365079365079365079365 -
-            (0.000595238095238095238095238 - 0.0008417508417508417508417508 / x2) / x2) / x2) / x2) / x;
-}
-__device__ __forceinline__ double bd0(double x, double np) {
-    if (fabs(x - np) < 0.1 * (x + np)) {
-        double v = (x - np) / (x + np);
-        double s = (x - np) * v;
-        if (fabs(s) < DBL_MIN) return s;
-        double ej = 2.0 * x * v;
-        v = v * v;
-        for (int j = 1; j < 1000; ++j) {
-            ej *= v;
-            const double s1 = s + ej / (double)((j << 1) + 1);
-            if (s1 == s) return s1;
-            s = s1;
-        }
-    }
-    return x * log(x / np) + np - x;
-}
-__device__ __forceinline__ double dpois(double x, double lam, const double* __restrict__ sfe) {
-    if (x == 0.0) return exp(-lam);
-    return exp(-stirlerr(x, sfe) - bd0(x, lam)) / sqrt(6.283185307179586476925286766559 * x);
-}
-// 1 - cdf(k; lam) formed like the reference forms it (1 - pdtr): through the cdf rounded to f64, so that the
-// far tail quantises to multiples of 2^-53 and reaches exactly 0.
-// sigcap: the scoring kernel only asks "is p <= sig, and if so what is it".  For an integer k below lambda >= 1 the
-// survival is at least P(X >= 2; lambda = 1) = 1 - 2/e = 0.264 (the minimum over lambda >= 1 sits just above lambda = 1 with
-// k = 1), so with sig <= 0.25 such a pixel cannot pass and its lower sum - half of bhfdr's per-pixel series - is not
-// formed: any value above sig will do (1.0).  The table kernel and the test helper pass sigcap = 1: every value exact.
-__device__ __noinline__ double poisson_sf(double k, double lam, const double* __restrict__ sfe, double sigcap) {
-    if (!(lam > 0.0)) return 0.0;
-    if (k < 0.0) return 1.0;
-    k = floor(k);
-    if (sigcap <= 0.25 && k < lam && lam >= 1.0) return 1.0;
-    double cdf;
-    if (k < lam) {                         // lower sum, terms shrink going down from k
-        // (a pmf that underflowed to 0 stays 0 all the way down: without the t > 0 test such a lane - k thousands below a
-        // large lambda - walked every term to j = 0, and the table kernel spent 2 ms in a few hundred such waves)
-        double t = dpois(k, lam, sfe), sum = t, j = k;
-        while (j > 0.0 && t > 0.0) {
-            t *= j / lam; j -= 1.0; sum += t;
-            if (t < sum * 1e-18) break;
-        }
-        cdf = sum < 1.0 ? sum : 1.0;
-    } else {                               // upper tail, terms shrink going up from k + 1
-        double j = k + 1.0, t = dpois(j, lam, sfe), sum = t;
-        for (int it = 0; it < 100000 && t > 0.0; ++it) {        // (t = 0: the tail is 0 to the last bit, no term can change it)
-            j += 1.0; t *= lam / j; sum += t;
-            if (t < sum * 1e-18) break;
-        }
-        cdf = 1.0 - sum;
-    }
-    return 1.0 - cdf;
-}
-
 __global__ void __launch_bounds__(256) hpk_ptab(const double* __restrict__ bounds, const int32_t* __restrict__ off,
                                                 const double* __restrict__ sfe, double* __restrict__ ptab, int total) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2220,13 +1589,6 @@ __global__ void __launch_bounds__(256) hpk_ptab(const double* __restrict__ bound
     while (ch < HPK_NB_TAB && i >= off[ch + 1]) ++ch;      // off[ch] .. off[ch+1]-1 belong to chunk ch (1-based)
     const double k = (double)(i - off[ch]);
     ptab[i] = poisson_sf(k, bounds[ch - 1], sfe, 1.0);
-}
-
-__global__ void __launch_bounds__(256) hpk_poisson_sf_k(const double* __restrict__ k, const double* __restrict__ lam,
-                                                        const double* __restrict__ sfe, double* __restrict__ out,
-                                                        int64_t count) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) out[i] = poisson_sf(k[i], lam[i], sfe, 1.0);
 }
 
 // Fine p-value bins (bhfdr: one family of millions of tests per chromosome, whose cut the eight factor-4 bins of the
@@ -2241,31 +1603,6 @@ __device__ __forceinline__ int fine_bin(double x, int nbins) {
     return k < 0 ? 0 : (k > nbins - 1 ? nbins - 1 : k);
 }
 // ------------------------------------------------------------------ scoring
-// local expected of a pixel at its resolving step: table value in the interior; within maxww of the first rows or the
-// last columns the window is clipped by the matrix end (callers.py:50-96 padding) and the value comes from the edge
-// tables, indexed by the distance to that end; only a pixel clipped on both sides (chromosomes shorter than the
-// band) takes the explicit loop.
-//   etab [(s * 2 + fl) * (D + 1) + d]
-//   eedge[(((side * W + e) * nsteps + s) * 2 + fl) * (D + 1) + d]    side 0: e = r < W,  side 1: e = n - 1 - c < W
-__device__ __forceinline__ void local_expected(const HpkDevPlan* __restrict__ plan, const double* __restrict__ etab,
-                                               const double* __restrict__ eedge, const double* __restrict__ IR, int step,
-                                               int r, int c, int d, int n, int num, int mw, int D, int W, double& EK,
-                                               double& EY) {
-    const bool top = r < W, right = c >= n - W;
-    if (!top && !right) {
-        EK = etab[(int64_t)(step * 2) * (D + 1) + d];
-        EY = etab[(int64_t)(step * 2 + 1) * (D + 1) + d];
-    } else if (top != right) {
-        const int side = top ? 0 : 1, e = top ? r : n - 1 - c;
-        const int64_t o = ((int64_t)((side * W + e) * plan->nsteps + step) * 2) * (D + 1) + d;
-        EK = eedge[o];
-        EY = eedge[o + (D + 1)];
-    } else {
-        const double2 ee = edge_expected(plan->steps[step].m, plan->steps[step].wi, IR, r, c, n, num, mw);
-        EK = ee.x; EY = ee.y;
-    }
-}
-
 // Edge tables.  Clipping by one matrix end removes whole window rows (top: di < -e) or whole window columns (right:
 // dj > e) whatever the diagonal, so the clipped window is again a 1-D stencil over IR: tap t = dj - di + 2wi carries
 // the summed multiplicity of the surviving cells on that anti-diagonal.  One workgroup per (band, side, e, step) and 256
@@ -2951,135 +2288,9 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkBandDesc* __rest
     }
 }
 
-// ------------------------------------------------------------------ dense debug outputs (tests: HPK_FLAG_DENSE_*)
-// Expands the stencil output to (E_K, E_Y), resolving width and (bS_K, bE_K, bS_Y, bE_Y) per slot and pixel.
-__global__ void __launch_bounds__(256) hpk_dense(HpkDenseArgs a) {
-    const HpkDevPlan* __restrict__ plan = a.plan;
-    const int tile = blockIdx.x;
-    const int cnt = (int)a.tile_cnt[tile];
-    const int rb = tile / a.J, cj = tile - rb * a.J;
-    const int r0 = rb * a.TR, c0 = r0 + a.mw + cj * a.TC;
-    const int64_t slot_stride = (int64_t)a.n * a.ldo;
-    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
-        const int64_t ri = (int64_t)tile * a.tilecap + i;
-        const unsigned ent = a.rec_ent[ri];
-        const int r = r0 + (int)HPK_ENT_Y(ent);
-        const int c = c0 + (int)(ent & 127u);
-        const int d = c - r;
-        const int64_t o = (int64_t)r * a.ldo + d;
-        for (int q = 0; q < plan->nslots; ++q) {
-            const int stp = (int)a.rec_W[q * a.rec_stride + ri];
-            double2 e = make_double2(0.0, 0.0);
-            double4 sm = make_double4(0.0, 0.0, 0.0, 0.0);
-            uint8_t w = 0;
-            if (stp != 0) {
-                const double2 s2 = a.rec_S[q * a.rec_stride + ri];
-                double EK, EY;
-                local_expected(plan, a.etab, a.eedge, a.IR, stp - 1, r, c, d, a.n, a.num, a.mw, a.D, plan->W, EK, EY);
-                const double ir = a.IR[d], b1r = a.b1[r], b2c = a.b2[c];
-                e.x = (EK != 0.0) ? ((ir * (s2.x / EK)) * b1r) * b2c : 0.0;
-                e.y = (EY != 0.0) ? ((ir * (s2.y / EY)) * b1r) * b2c : 0.0;
-                sm = make_double4(s2.x, EK, s2.y, EY);
-                w = (uint8_t)plan->steps[stp - 1].wi;
-            }
-            a.dE[q * slot_stride + o] = e;
-            a.dW[q * slot_stride + o] = w;
-            if (a.dS) a.dS[q * slot_stride + o] = sm;
-        }
-    }
-}
-
-// ------------------------------------------------------------------ record look-up at sampled pixels (tests)
-// One wave per query pixel: finds the pixel's record in its tile's region (scan of the entries), then reports per
-// slot (bS_K, bE_K, bS_Y, bE_Y, resolving width); width -1: the pixel is not a candidate (zero count or off the band).
-__global__ void __launch_bounds__(64) hpk_probe(HpkDenseArgs a, const int32_t* __restrict__ rows, const int32_t* __restrict__ cols,
-                                                int64_t count, double* __restrict__ out) {
-    const HpkDevPlan* __restrict__ plan = a.plan;
-    const int64_t qi = blockIdx.x;
-    if (qi >= count) return;
-    const int lane = threadIdx.x;
-    const int r = rows[qi], c = cols[qi], d = c - r;
-    const int nslots = plan->nslots;
-    double* o = out + qi * (int64_t)nslots * 5;
-    long long found = -1;
-    if (r >= 0 && r < a.n && c < a.n && d >= a.mw && d <= a.D) {
-        const int rb = r / a.TR, r0 = rb * a.TR, cj = (c - r0 - a.mw) / a.TC;
-        const int tile = rb * a.J + cj;
-        const int x = c - (r0 + a.mw + cj * a.TC), y = r - r0;
-        const unsigned key = (unsigned)x | ((unsigned)y << 7);
-        const int cnt = (int)a.tile_cnt[tile];
-        for (int i0 = 0; i0 < cnt; i0 += 64) {
-            const int i = i0 + lane;
-            const bool hit = i < cnt && (a.rec_ent[(int64_t)tile * a.tilecap + i] & ((1u << HPK_ENT_CNT_SHIFT) - 1u)) == key;
-            const unsigned long long m = __ballot(hit);
-            if (m) { found = (long long)tile * a.tilecap + i0 + (__ffsll((long long)m) - 1); break; }
-        }
-    }
-    if (lane != 0) return;
-    for (int q = 0; q < nslots; ++q) {
-        double* oq = o + q * 5;
-        oq[0] = oq[1] = oq[2] = oq[3] = 0.0;
-        oq[4] = found < 0 ? -1.0 : 0.0;
-        if (found < 0) continue;
-        const int stp = (int)a.rec_W[q * a.rec_stride + found];
-        if (stp == 0) continue;
-        const double2 s2 = a.rec_S[q * a.rec_stride + found];
-        double EK, EY;
-        local_expected(plan, a.etab, a.eedge, a.IR, stp - 1, r, c, d, a.n, a.num, a.mw, a.D, plan->W, EK, EY);
-        oq[0] = s2.x; oq[1] = EK; oq[2] = s2.y; oq[3] = EY; oq[4] = (double)plan->steps[stp - 1].wi;
-    }
-}
-
-// ------------------------------------------------------------------ brute-force check (tests only)
-__global__ void __launch_bounds__(64) hpk_brute(HpkBruteArgs a) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.count) return;
-    const HpkDevStep& st = a.plan->steps[a.step];
-    const int r = a.rows[i], c = a.cols[i];
-    const int n = a.n, num = a.num, mw = a.plan->mw, W = a.plan->W;
-    double SK = 0.0, EK = 0.0, SY = 0.0, EY = 0.0, RD = 0.0;
-    for (int di = -W; di <= W; ++di) {
-        for (int dj = -W; dj <= W; ++dj) {
-            if (di == 0 || dj == 0) continue;
-            const int adi = di < 0 ? -di : di, adj = dj < 0 ? -dj : dj;
-            const int rho = adi > adj ? adi : adj;
-            const int m = st.m[rho], mr = st.mr[rho];
-            if (m == 0 && mr == 0) continue;
-            const int rr = r + di, cc = c + dj, kk = cc - rr;
-            if (rr < 0 || rr >= n || cc < 0 || cc >= n || kk < 0 || kk >= num) continue;
-            const float rv = a.raw[(int64_t)rr * a.ld + kk];
-            const bool ll = di > 0 && dj < 0;
-            if (ll) RD += (double)mr * (double)rv;
-            if (kk < mw) continue;
-            double b;
-            if (a.bal) { b = a.bal[(int64_t)rr * a.ld + kk]; b = (b == b) ? b : 0.0; }
-            else b = balanced_of(rv, a.weight[rr], a.weight[cc]);
-            const double x = a.IR[kk];
-            SK += (double)m * b; EK += (double)m * x;
-            if (ll) { SY += (double)m * b; EY += (double)m * x; }
-        }
-    }
-    double* o = a.out + i * 5;
-    o[0] = SK; o[1] = EK; o[2] = SY; o[3] = EY; o[4] = RD;
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------ launchers
-int hpk_stencil_lds_bytes() { return LR * LC * 12 + HPK_NWAVES * HPK_LISTCAP * 4 + 16; }
-
-template <int NW, bool BALF64, bool SIMPLE>
-static void launch_stencil_t(const HpkStencil1Args& a, int grid, hipStream_t st) {
-    auto kern = hpk_stencil<NW, BALF64, SIMPLE>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  hpk_stencil_lds_bytes());
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), hpk_stencil_lds_bytes(), st, a, a.raw, a.bal, a.weight, a.rec_S, a.rec_W);
-}
-
 int hpk_stencil_s_lds_bytes() { return LR * LC * 12 + HPK_TLIST * 4 + 128 + HPK_MAX_STEPS * 32 + HPK_KSLOTS * 32; }
 
 template <bool BALF64, bool SINGLE, bool FUSE = false>
@@ -3094,10 +2305,10 @@ static void launch_stencil_s_t(const HpkStencilArgs& a, const HpkBandDesc* d_ban
     hipLaunchKernelGGL(kern, dim3(a.grid), dim3(1024), hpk_stencil_s_lds_bytes(), st, a, d_bands);
 }
 
-// Simple-Reads plans within the buffer-addressing limits of hpk_stencil_s (32-bit byte offsets inside one tile's rows,
-// weights addressed from element 0) go to the second-generation kernel; everything else to hpk_stencil.
-bool hpk_stencil_s_applies(const HpkStencilArgs& a, bool simple, int64_t max_ld, int32_t max_n) {
-    return simple && HPK_NWAVES == 16 && max_ld <= (int64_t)(1 << 21) && max_n < (1 << 27) && a.W >= 4 && a.TR * a.TC <= HPK_TLIST;
+// The buffer-addressing limits of hpk_stencil_s: 32-bit byte offsets inside one tile's rows, weights addressed from element 0;
+// a halo of at least 4 (plans with maxww < 4 keep a halo of 4: widths beyond maxww have no step).
+bool hpk_stencil_s_applies(const HpkStencilArgs& a, int64_t max_ld, int32_t max_n) {
+    return max_ld <= (int64_t)(1 << 21) && max_n < (1 << 27) && a.W >= 4 && a.TR * a.TC <= HPK_TLIST;
 }
 
 // what a launch must be for the fused variant: hiccups, one (pw, ww) pair, a record bound within HPK_FUSE_NCL widths of the
@@ -3112,33 +2323,6 @@ void hpk_launch_stencil_batch(const HpkStencilArgs& a, const HpkBandDesc* d_band
     if (a.fuse) { launch_stencil_s_t<false, true, true>(a, d_bands, st); return; }
     if (balf64) { if (single) launch_stencil_s_t<true, true>(a, d_bands, st); else launch_stencil_s_t<true, false>(a, d_bands, st); }
     else        { if (single) launch_stencil_s_t<false, true>(a, d_bands, st); else launch_stencil_s_t<false, false>(a, d_bands, st); }
-}
-
-void hpk_launch_stencil_old(const HpkStencilArgs& a, const HpkBandDesc& hb, bool balf64, bool simple, int grid, hipStream_t st) {
-    HpkStencil1Args o;
-    // (C-style casts: in the device pass of this file the descriptor's fields are global-address-space pointers)
-    unsigned char* small = (unsigned char*)hb.small;
-    o.raw = (const float*)hb.raw; o.bal = (const double*)hb.bal; o.weight = (const double*)hb.weight; o.plan = a.plan;
-    o.rec_ent = (unsigned*)hb.rec_ent; o.rec_S = (double2*)hb.rec_S; o.rec_W = (uint8_t*)hb.rec_W; o.tile_cnt = (unsigned*)hb.tile_cnt;
-    o.units = (uint2*)hb.units; o.nunits = reinterpret_cast<unsigned*>(small + HPK_OFF_NUNITS);
-    o.tilecap = a.tilecap; o.rec_stride = hb.rec_stride; o.gap = (uint8_t*)hb.gap;
-    o.hist = reinterpret_cast<unsigned long long*>(small + HPK_OFF_HIST);
-    o.hist_acc = (unsigned long long*)hb.hist_acc; o.risk = a.risk; o.n = hb.n; o.num = hb.num; o.ld = hb.ld;
-    o.W = a.W; o.mw = a.mw; o.D = a.D; o.TR = a.TR; o.TC = a.TC; o.J = a.J; o.ntiles = hb.ntiles; o.chunk = hb.chunk;
-    o.order = a.order; o.clk = a.clk; o.dbg_stop = a.dbg_stop;
-    constexpr int NW = HPK_NWAVES;
-    if (balf64) { if (simple) launch_stencil_t<NW, true, true>(o, grid, st); else launch_stencil_t<NW, true, false>(o, grid, st); }
-    else        { if (simple) launch_stencil_t<NW, false, true>(o, grid, st); else launch_stencil_t<NW, false, false>(o, grid, st); }
-}
-
-void hpk_launch_dense(const HpkDenseArgs& a, hipStream_t st) {
-    if (a.ntiles <= 0) return;
-    hipLaunchKernelGGL(hpk_dense, dim3(a.ntiles), dim3(256), 0, st, a);
-}
-
-void hpk_launch_probe(const HpkDenseArgs& a, const int32_t* rows, const int32_t* cols, int64_t count, double* out, hipStream_t st) {
-    if (count <= 0) return;
-    hipLaunchKernelGGL(hpk_probe, dim3((unsigned)count), dim3(64), 0, st, a, rows, cols, count, out);
 }
 
 void hpk_launch_freeze_tot(const HpkDevPlan* plan, const HpkBandDesc* d_bands, int nbands, hipStream_t st) {
@@ -3279,11 +2463,6 @@ void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe
     hipLaunchKernelGGL(hpk_ptab, dim3((total + 255) / 256), dim3(256), 0, st, bounds, off, sfe, ptab, total);
 }
 
-void hpk_launch_poisson_sf(const double* k, const double* lam, const double* sfe, double* out, int64_t count,
-                           hipStream_t st) {
-    hipLaunchKernelGGL(hpk_poisson_sf_k, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, k, lam, sfe, out, count);
-}
-
 void hpk_launch_coo_scatter(const int64_t* bin1, const int64_t* bin2, const void* count, int count_f64, int64_t nnz, int n, int num,
                             int64_t ld, float* raw, unsigned long long* info, hipStream_t st) {
     if (nnz <= 0) return;
@@ -3292,6 +2471,3 @@ void hpk_launch_coo_scatter(const int64_t* bin1, const int64_t* bin2, const void
                        n, num, ld, raw, info);
 }
 
-void hpk_launch_brute(const HpkBruteArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(hpk_brute, dim3((unsigned)((a.count + 63) / 64)), dim3(64), 0, st, a);
-}
