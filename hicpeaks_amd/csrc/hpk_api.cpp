@@ -1451,21 +1451,64 @@ int hpk_score_band(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, hpk_
     return hpk_collect(c, job, out);
 }
 
-int64_t hpk_band_from_coo(const int64_t* bin1, const int64_t* bin2, const void* count, int32_t count_f64, int64_t nnz,
-                          int32_t n, int32_t num, int64_t ld, float* raw) {
-    if (!bin1 || !bin2 || !count || !raw || nnz < 0 || n <= 0 || num <= 0 || ld < num) return HPK_ERR_INVALID;
-    const int32_t* ci = static_cast<const int32_t*>(count);
-    const double* cd = static_cast<const double*>(count);
-    int64_t stored = 0;
-    for (int64_t t = 0; t < nnz; ++t) {
+namespace {
+// pixels [t0, t1) into the band; returns the pixels stored, -1 on a bin outside the chromosome; *sorted is cleared when the rows
+// (smaller bin of a pixel) do not come in non-decreasing order
+int64_t band_scatter(const int64_t* bin1, const int64_t* bin2, const int32_t* ci, const double* cd, int64_t t0, int64_t t1,
+                     int32_t n, int32_t num, int64_t ld, float* raw, bool* sorted) {
+    int64_t stored = 0, last = -1;
+    for (int64_t t = t0; t < t1; ++t) {
         const int64_t a = bin1[t] < bin2[t] ? bin1[t] : bin2[t], b = bin1[t] < bin2[t] ? bin2[t] : bin1[t];
-        if (a < 0 || b >= n) return HPK_ERR_INVALID;        // a bin outside the chromosome: the caller's offsets are off
+        if (a < 0 || b >= n) return -1;                     // a bin outside the chromosome: the caller's offsets are off
+        if (a < last && sorted) *sorted = false;
+        last = a;
         const int64_t k = b - a;
         if (k >= num) continue;                             // beyond the band
-        raw[a * ld + k] += count_f64 ? (float)cd[t] : (float)ci[t];
+        raw[a * ld + k] += cd ? (float)cd[t] : (float)ci[t];
         ++stored;
     }
     return stored;
+}
+}  // namespace
+
+// One O(nnz) pass.  A large pixel table whose rows come in order (cooler's pixel table is sorted by bin1, bin2) is cut at row
+// changes into one stretch per thread: the stretches write disjoint band rows, repeats of a cell stay in one stretch.  A table that
+// turns out not to be in row order is done again by one thread (repeats may then meet anywhere).
+int64_t hpk_band_from_coo(const int64_t* bin1, const int64_t* bin2, const void* count, int32_t count_f64, int64_t nnz,
+                          int32_t n, int32_t num, int64_t ld, float* raw) {
+    if (!bin1 || !bin2 || !count || !raw || nnz < 0 || n <= 0 || num <= 0 || ld < num) return HPK_ERR_INVALID;
+    const int32_t* ci = count_f64 ? nullptr : static_cast<const int32_t*>(count);
+    const double* cd = count_f64 ? static_cast<const double*>(count) : nullptr;
+    int nt = (int)std::min<int64_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), nnz / (4 << 20));
+    if (nt > 1) {
+        std::vector<int64_t> cut(nt + 1);
+        cut[0] = 0; cut[nt] = nnz;
+        auto row = [&](int64_t t) { return bin1[t] < bin2[t] ? bin1[t] : bin2[t]; };
+        for (int i = 1; i < nt; ++i) {
+            int64_t t = std::max(nnz * i / nt, cut[i - 1]);
+            while (t < nnz && t > 0 && row(t) == row(t - 1)) ++t;          // to the next row change
+            cut[i] = t;
+        }
+        std::vector<int64_t> got(nt, 0);
+        std::vector<char> ok(nt, 1);
+        std::vector<std::thread> pool;
+        auto work = [&](int i) {
+            bool srt = true;
+            got[i] = band_scatter(bin1, bin2, ci, cd, cut[i], cut[i + 1], n, num, ld, raw, &srt);
+            // (the stretch itself in row order, and it starts at or behind the row the stretch before ended on)
+            if (!srt || (i > 0 && cut[i] < nnz && cut[i] > 0 && row(cut[i]) < row(cut[i] - 1))) ok[i] = 0;
+        };
+        for (int i = 1; i < nt; ++i) pool.emplace_back(work, i);
+        work(0);
+        for (std::thread& t : pool) t.join();
+        bool all = true;
+        int64_t stored = 0;
+        for (int i = 0; i < nt; ++i) { if (got[i] < 0) return HPK_ERR_INVALID; all = all && ok[i]; stored += got[i]; }
+        if (all) return stored;
+        for (int64_t r = 0; r < n; ++r) std::memset(raw + r * ld, 0, sizeof(float) * (size_t)num);      // not in row order: once more, serially
+    }
+    const int64_t stored = band_scatter(bin1, bin2, ci, cd, 0, nnz, n, num, ld, raw, nullptr);
+    return stored < 0 ? HPK_ERR_INVALID : stored;
 }
 
 struct hpk_devband { float* raw = nullptr; double* weight = nullptr; double* bias = nullptr; size_t raw_bytes = 0, w_bytes = 0; };
