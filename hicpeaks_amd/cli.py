@@ -131,20 +131,35 @@ def select_chroms(chromnames, chroms):
     return out
 
 
-def _fetch(args_dict, src, key, ctx=None):
-    """One chromosome's band as the library wants it (the first half of worker(), scripts/pyHICCUPS:139-166, without the
-    per-diagonal extraction): (label, raw f32 [n, num], weight f64 [n], biases or None).  From a cooler, with a context:
-    the pixel table goes to the GPU as it is and the band is built there (raw = a DeviceBand, weights and biases with it) -
-    no dense band on the host, a fifth to a twentieth of its bytes over the bus."""
+def _read(args_dict, src, key, use_pixels):
+    """What one chromosome needs from the file (the first half of worker(), scripts/pyHICCUPS:139-166, without the
+    per-diagonal extraction) - HDF5 reads and chunk inflation only, no GPU call: runs on the reader thread."""
     num = args_dict['maxapart'] // src.binsize + args_dict['maxww'] + 1
-    if ctx is not None and hasattr(src, 'fetch_pixels') and not os.environ.get('HPK_HOST_BANDS'):
-        i, j, cnt, n, w, b = src.fetch_pixels(key, args_dict['clr_weight_name'])
-        if 20 * i.size <= 4 * n * num:          # (a band denser than one stored pixel in five cells is smaller than its pixel table)
-            return key.lstrip('chr'), ctx.devband(i, j, cnt, n, num, w, b), None, None
-        from . import band as _band
-        return key.lstrip('chr'), _band.band_from_coo(i, j, cnt, n, num), w, b
-    raw, w, b = src.fetch(key, num, args_dict['clr_weight_name'])
-    return key.lstrip('chr'), raw, w, b
+    if use_pixels:
+        return ('pixels', num) + tuple(src.fetch_pixels(key, args_dict['clr_weight_name']))
+    return ('band', num) + tuple(src.fetch(key, num, args_dict['clr_weight_name']))
+
+
+def _to_item(key, got, ctx):
+    """-> (label, raw f32 [n, num] or a DeviceBand, weight f64 [n] or None, biases or None).  A sparse pixel table goes to
+    the GPU as it is and the band is built there (hpk_devband_create: a fifth to a twentieth of the dense band's bytes over
+    the bus); a band denser than one stored pixel in five cells is smaller than its pixel table: built on the host
+    (hpk_band_from_coo, threaded) and uploaded with the batch."""
+    label = key.lstrip('chr')
+    if got[0] == 'band':
+        _, num, raw, w, b = got
+        return label, raw, w, b
+    _, num, i, j, cnt, n, w, b = got
+    if 20 * i.size <= 4 * n * num:
+        return label, ctx.devband(i, j, cnt, n, num, w, b), None, None
+    from . import band as _band
+    return label, _band.band_from_coo(i, j, cnt, n, num), w, b
+
+
+def _fetch(args_dict, src, key, ctx=None):
+    """One chromosome's band as the library wants it, read and prepared in the calling thread."""
+    use_pixels = ctx is not None and hasattr(src, 'fetch_pixels') and not os.environ.get('HPK_HOST_BANDS')
+    return _to_item(key, _read(args_dict, src, key, use_pixels), ctx)
 
 
 def _submit_group(args_dict, mode, items, device, res):
@@ -174,7 +189,8 @@ def _score_queue(args_dict, mode, queue, device):
     at the latest.  -> {label: table}"""
     from . import io, _lib
     import collections
-    src = io.open_source(args_dict['path'])
+    import queue as _queue
+    import threading
     ctx = _lib.default_context(device)
     # every run starts without memory of the chromosomes an earlier run in this process scored; --deterministic: the plan's
     # own tile geometry for every chromosome (the record bound stays: it never touches a value)
@@ -183,24 +199,50 @@ def _score_queue(args_dict, mode, queue, device):
     depth = ctx.pipeline_depth
     pending, out = collections.deque(), {}
 
+    # The reader: a thread of its own takes chromosomes from the queue and reads them (HDF5 + chunk inflation release the
+    # GIL), two ahead at most, so that chromosome i + 1 is read while chromosome i's batch is on the GPU and chromosome
+    # i - 1 goes through clustering.  It opens its own handle on the file and makes no GPU call (a context belongs to one thread).
+    fetched = _queue.Queue(maxsize=2)
+    info = {}
+
+    def reader():
+        try:
+            src = io.open_source(args_dict['path'])
+            info['binsize'] = src.binsize
+            use_pixels = hasattr(src, 'fetch_pixels') and not os.environ.get('HPK_HOST_BANDS')
+            for key in queue:
+                fetched.put((key, _read(args_dict, src, key, use_pixels)))
+            fetched.put(None)
+        except BaseException as e:          # (re-raised by the consumer)
+            fetched.put(e)
+
+    th = threading.Thread(target=reader, name='hpk-reader', daemon=True)
+    th.start()
+
     def collect():
         labels, call = pending.popleft()
         for label, table in zip(labels, call.results()):
             out[label] = table
 
     group, nbytes = [], 0
-    for key in itertools.chain(queue, [None]):
-        if key is not None:
-            item = _fetch(args_dict, src, key, ctx)
+    while True:
+        got = fetched.get()
+        if isinstance(got, BaseException):
+            raise got
+        if got is not None:
+            item = _to_item(got[0], got[1], ctx)
             group.append(item)
             nbytes += item[1].nbytes
-        if group and (key is None or nbytes >= GROUP_BYTES or len(group) >= min(GROUP_CHROMS, _lib.HPK_MAX_BATCH) or not pending):
+        if group and (got is None or nbytes >= GROUP_BYTES or len(group) >= min(GROUP_CHROMS, _lib.HPK_MAX_BATCH) or not pending):
             if len(pending) >= depth:
                 collect()
-            pending.append(([g[0] for g in group], _submit_group(args_dict, mode, group, device, src.binsize)))
+            pending.append(([g[0] for g in group], _submit_group(args_dict, mode, group, device, info['binsize'])))
             group, nbytes = [], 0
+        if got is None:
+            break
     while pending:
         collect()
+    th.join()
     return out
 
 

@@ -16,8 +16,8 @@ Backends: `h5py` when importable; otherwise the HDF5 C library itself through ct
 
 Balancing conventions (cooler.Cooler.matrix, not under /root/reference and not installed here - SURVEY 8-C2 - so taken from
 cooler's documentation, not verified against the package): balanced = count * w[bin1] * w[bin2]; the 4DN-style columns
-"KR", "VC", "VC_SQRT" are *divisive* (balanced = count / (w[bin1] * w[bin2])) unless the column's `divisive_weights`
-attribute says otherwise.
+"KR", "VC", "VC_SQRT" / "SQRT_VC" are *divisive* (balanced = count / (w[bin1] * w[bin2])) - decided by the column's name, as
+cooler.matrix(balance=name) decides it; a bin whose divisive weight is 0 is treated as masked (cooler would form count / 0).
 """
 import ctypes as C
 import ctypes.util
@@ -25,7 +25,7 @@ import os
 
 import numpy as np
 
-DIVISIVE_NAMES = ('KR', 'VC', 'VC_SQRT')
+DIVISIVE_NAMES = ('KR', 'VC', 'VC_SQRT', 'SQRT_VC')      # (cooler's own list spells the last one SQRT_VC; both are taken)
 
 
 def parse_uri(uri):
@@ -342,6 +342,7 @@ class CoolFile(object):
                 raise IOError('%s%s is not a cooler: %s is missing' % (self.path, '::' + self.group if self.group != '/' else '', need))
         self.binsize = self.h.attr('.', 'bin-size')
         if self.binsize is None:
+            self.h.close()
             raise IOError('cooler without a fixed bin-size (variable-size bins are not supported)')
         self.binsize = int(self.binsize)
         self.chromnames = self.h.read('chroms/name', kind='s')
@@ -362,9 +363,10 @@ class CoolFile(object):
         if not self.h.exists(col):
             raise KeyError('no bin column %r (balance the cooler first, or pick --clr-weight-name)' % name)
         w = self.h.read(col, lo, hi, kind='f')
-        div = self.h.attr(col, 'divisive_weights')
-        divisive = bool(div) if div is not None else (name in DIVISIVE_NAMES)
-        return w, divisive
+        # by the column's NAME, as cooler.Cooler.matrix(balance=name) decides it - the call the reference makes
+        # (scripts/pyHICCUPS:143) - and as the `cooler`-package backend of hicpeaks_amd.io decides it: one rule whatever is
+        # installed.  (A `divisive_weights` attribute on the column is not consulted: cooler.matrix does not read it either.)
+        return w, name in DIVISIVE_NAMES
 
     def pixels(self, chrom):
         """The intra-chromosomal pixels of `chrom`, bins relative to its first bin: (bin1 i8, bin2 i8, count) - what

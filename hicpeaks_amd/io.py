@@ -93,7 +93,7 @@ class CoolerSource(BandSource):
     package's own reader of the format (hicpeaks_amd/cool.py: h5py or libhdf5).
 
     Balancing (scripts/pyHICCUPS:143 `Lib.matrix(balance=<column>)`): balanced = count * w[bin1] * w[bin2]; for a
-    *divisive* column (cooler: 'KR', 'VC', 'VC_SQRT', or the column's divisive_weights attribute) count / (w[bin1] *
+    *divisive* column (by its name, as cooler.matrix decides: 'KR', 'VC', 'VC_SQRT' / 'SQRT_VC' - the same rule in both backends) count / (w[bin1] *
     w[bin2]) - `fetch` then hands over 1 / column as the weights, and, as third value, the biases the reference forms
     from the column as stored (1 / column, 0 where it is 0 / NaN: scripts/pyHICCUPS:163-166 does not know about
     divisive columns), so that the corrected expected comes out as the reference's does."""

@@ -43,24 +43,27 @@ def stages(uri, chroms, a, ctx):
     res = src.binsize
     num = a.maxapart // res + a.maxww + 1
     out = {}
+    from hicpeaks_amd import cli
+    args_dict = dict(maxapart=a.maxapart, maxww=a.maxww, clr_weight_name='weight')
     for c in chroms:
         key = 'chr' + c
         t0 = time.perf_counter()
-        lo, hi = src.f.extent(key)
-        i, j, cnt = src.f.pixels(key)
-        w, _ = src.f.weights(key, 'weight')
+        got = cli._read(args_dict, src, key, not a.host_bands)       # HDF5 chunks -> inflate -> the chromosome's pixel table
         t1 = time.perf_counter()
-        if a.host_bands:        # dense band on the host (hpk_band_from_coo), uploaded with the call
-            raw = band.band_from_coo(i, j, cnt, hi - lo, num, dtype=np.float32)
-        else:                   # the pixel table goes to the GPU, the band is built there (hpk_devband_create)
-            raw, w = ctx.devband(i, j, cnt, hi - lo, num, w), None
+        if a.host_bands:
+            raw, w = got[2], got[3]
+            npx = int((raw != 0).sum())
+        else:                   # sparse: the pixel table goes to the GPU and the band is built there; dense: threaded host scatter
+            _, raw, w, _b = cli._to_item(key, got, ctx)
+            npx = int(got[2].size)
+        n = int(raw.shape[0])
         t2 = time.perf_counter()
         call = callers.hiccups_batch_submit([(c, raw, w, None)], pw=[a.pw], ww=[a.ww], maxww=a.maxww, sig=0.1, sumq=0.01,
                                             double_fold=1.75, single_fold=2, maxapart=a.maxapart, res=res, use_raw=False,
                                             min_marginal_peaks=2, onlyanchor=False, min_local_reads=16, ctx=ctx)
         table = call.results()[0]
         t3 = time.perf_counter()
-        out[c] = (t1 - t0, t2 - t1, t3 - t2, int(len(cnt)), len(table), hi - lo)
+        out[c] = (t1 - t0, t2 - t1, t3 - t2, npx, len(table), n)
     return out, t_open
 
 
@@ -75,6 +78,8 @@ def main():
     ap.add_argument('--file', default='/tmp/hpk_e2e.mcool')
     ap.add_argument('--depth', type=float, default=25.0)
     ap.add_argument('--host-bands', action='store_true', help='build the dense bands on the host (band_from_coo) instead of on the GPU')
+    ap.add_argument('--deep', action='store_true',
+                    help='the file is a deep map written by scripts/make_cool_deep.py (--depth, pixels beyond the band included)')
     a = ap.parse_args()
     from hicpeaks_amd import _lib, synthetic
     num = a.maxapart // a.res + a.maxww + 1
@@ -85,9 +90,14 @@ def main():
     if not os.path.exists(a.file):
         t0 = time.perf_counter()
         env = dict(os.environ, PYTHONDONTWRITEBYTECODE='1')
-        subprocess.check_call(['/opt/conda/bin/python3.9', os.path.join(REPO, 'scripts', 'make_cool.py'), a.file, '--genome', 'hg38',
-                               '--res', str(a.res), '--num', str(num), '--group', group, '--depth', str(a.depth), '--chroms'] + a.chroms,
-                              env=env, stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
+        if a.deep:
+            subprocess.check_call(['/opt/conda/bin/python3.9', os.path.join(REPO, 'scripts', 'make_cool_deep.py'), a.file, '--res', str(a.res),
+                                   '--num', str(num), '--depth', str(a.depth), '--far', '--chroms'] + a.chroms,
+                                  env=env, stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
+        else:
+            subprocess.check_call(['/opt/conda/bin/python3.9', os.path.join(REPO, 'scripts', 'make_cool.py'), a.file, '--genome', 'hg38',
+                                   '--res', str(a.res), '--num', str(num), '--group', group, '--depth', str(a.depth), '--chroms'] + a.chroms,
+                                  env=env, stderr=subprocess.DEVNULL, stdout=subprocess.DEVNULL)
         print('# wrote %s (%.1f MB, gzip-6 chunks as cooler writes them) in %.0f s' % (a.file, os.path.getsize(a.file) / 1e6,
                                                                                      time.perf_counter() - t0))
     sizes = synthetic.hg38_bins(a.res)
