@@ -255,7 +255,7 @@ class _H5C(object):
             lo, hi = max(start, ci * cs), min(stop, ci * cs + cs)
             out[lo - start:hi - start] = v[lo - ci * cs:hi - ci * cs]
 
-        nthr = threads or int(os.environ.get('HPK_READ_THREADS', 0)) or min(16, os.cpu_count() or 1)
+        nthr = threads or int(os.environ.get('HPK_READ_THREADS', 0)) or min(64, os.cpu_count() or 1)      # (16 | 32 | 64 | 128 threads: no difference on the 256-core GPU box, profiles/r04_host_e2e_deep.txt)
         if nthr > 1 and len(raws) > 1:
             if _H5C._pool is None or _H5C._pool_n != nthr:
                 _H5C._pool, _H5C._pool_n = ThreadPoolExecutor(nthr), nthr

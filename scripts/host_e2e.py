@@ -104,7 +104,7 @@ def main():
     scale = sum(sizes.values()) / float(sum(sizes[c] for c in a.chroms))
     ctx = _lib.default_context(0)
     print('# backend of hicpeaks_amd.cool: %s; GPU: %s' % ('h5py' if _have('h5py') else 'libhdf5 through ctypes', ctx.info()['name']))
-    for label in ('cold', 'warm', 'warm'):
+    for label in (('cold', 'warm') if a.deep else ('cold', 'warm', 'warm')):
         cold = label == 'cold'
         if cold and not drop_caches():
             print('# (page cache could not be dropped: no cold pass)')
