@@ -81,7 +81,8 @@ class _H5C(object):
                    H5Pget_chunk=(C.c_int, [hid, C.c_int, C.POINTER(hs)]), H5Pget_nfilters=(C.c_int, [hid]),
                    H5Pget_filter2=(C.c_int, [hid, C.c_uint, C.POINTER(C.c_uint), C.POINTER(C.c_size_t), C.POINTER(C.c_uint),
                                              C.c_size_t, C.c_char_p, C.POINTER(C.c_uint)]),
-                   H5Tget_sign=(C.c_int, [hid]), H5Tget_order=(C.c_int, [hid]))
+                   H5Tget_sign=(C.c_int, [hid]), H5Tget_order=(C.c_int, [hid]), H5free_memory=(he, [C.c_void_p]),
+                   H5Tget_cset=(C.c_int, [hid]), H5Tset_cset=(he, [hid, C.c_int]))
         # raw chunk access (HDF5 >= 1.10.5): lets the gzip streams of a big read be inflated on several threads
         cls.have_chunks = all(hasattr(L, f) for f in ('H5Dget_chunk_info_by_coord', 'H5Dread_chunk'))
         if cls.have_chunks:
@@ -153,10 +154,11 @@ class _H5C(object):
             ft = L.H5Dget_type(d)
             cls, size = L.H5Tget_class(ft), L.H5Tget_size(ft)
             varstr = cls == 3 and L.H5Tis_variable_str(ft) > 0
+            cset = L.H5Tget_cset(ft) if cls == 3 else 0          # (ASCII | UTF-8: HDF5 does not convert between the two)
             L.H5Tclose(ft)
             if kind is None:
                 kind = {0: 'i', 1: 'f', 3: 's', 8: 'i'}.get(cls)        # H5T_INTEGER, FLOAT, STRING, ENUM
-            if kind is None or varstr:
+            if kind is None:
                 raise TypeError('%s: unsupported HDF5 type class %d' % (name, cls))
             sp = L.H5Dget_space(d)
             dims = (C.c_uint64 * 4)()
@@ -168,9 +170,15 @@ class _H5C(object):
             a = 0 if start is None else max(0, min(int(start), n))
             b = n if stop is None else max(a, min(int(stop), n))
             cnt = b - a
-            if kind == 's':
+            if kind == 's' and varstr:          # variable-length strings (h5py's default for str data): an array of char*
+                mt = L.H5Tcopy(self.T_C_S1)
+                L.H5Tset_size(mt, C.c_size_t(-1).value)                 # H5T_VARIABLE
+                L.H5Tset_cset(mt, cset)
+                out = np.zeros(cnt, dtype=np.uint64)
+            elif kind == 's':
                 mt = L.H5Tcopy(self.T_C_S1)
                 L.H5Tset_size(mt, size)
+                L.H5Tset_cset(mt, cset)
                 out = np.zeros(cnt, dtype='S%d' % size)
             else:
                 mt = self.T_I64 if kind == 'i' else self.T_F64
@@ -182,10 +190,16 @@ class _H5C(object):
                 rc = L.H5Dread(d, mt, ms, sp, 0, out.ctypes.data)
                 L.H5Sclose(ms)
                 if rc < 0:
-                    raise IOError('H5Dread failed on %s' % name)
+                    raise IOError('H5Dread failed on %s (a compression filter this HDF5 library does not have? cooler itself writes gzip)' % name)
             L.H5Sclose(sp)
             if kind == 's':
                 L.H5Tclose(mt)
+                if varstr:
+                    strs = [C.string_at(int(p)).decode() if p else '' for p in out]
+                    for p in out:
+                        if p:
+                            L.H5free_memory(C.c_void_p(int(p)))
+                    return strs
                 return [v.decode() for v in out]
             return out
         finally:
@@ -283,6 +297,26 @@ class _H5C(object):
             if cls == 1:
                 v = C.c_double(0)
                 return float(v.value) if L.H5Aread(a, self.T_F64, C.byref(v)) >= 0 else default
+            if cls == 3:                            # string (fixed or variable length)
+                t = L.H5Aget_type(a)
+                var, size, cset = L.H5Tis_variable_str(t) > 0, int(L.H5Tget_size(t)), L.H5Tget_cset(t)
+                L.H5Tclose(t)
+                mt = L.H5Tcopy(self.T_C_S1)
+                L.H5Tset_cset(mt, cset)
+                try:
+                    if var:
+                        L.H5Tset_size(mt, C.c_size_t(-1).value)
+                        p = C.c_void_p(0)
+                        if L.H5Aread(a, mt, C.byref(p)) < 0 or not p.value:
+                            return default
+                        v = C.string_at(p.value).decode()
+                        L.H5free_memory(p)
+                        return v
+                    L.H5Tset_size(mt, size + 1)
+                    buf = C.create_string_buffer(size + 1)
+                    return buf.value.decode() if L.H5Aread(a, mt, buf) >= 0 else default
+                finally:
+                    L.H5Tclose(mt)
             return default
         finally:
             L.H5Aclose(a)
@@ -345,6 +379,12 @@ class CoolFile(object):
             self.h.close()
             raise IOError('cooler without a fixed bin-size (variable-size bins are not supported)')
         self.binsize = int(self.binsize)
+        # 'symmetric-upper' (cooler's default; also assumed when the attribute is missing): the pixel table lists every contact
+        # once, bin1 <= bin2.  'square': both triangles are stored - the lower one is left out (cooler.matrix hands the matrix
+        # over as stored, and scripts/pyHICCUPS:147 takes its upper diagonals)
+        mode = self.h.attr('.', 'storage-mode')
+        mode = mode.decode() if isinstance(mode, bytes) else mode
+        self.square = isinstance(mode, str) and mode.lower() == 'square'
         self.chromnames = self.h.read('chroms/name', kind='s')
         self.chrom_offset = self.h.read('indexes/chrom_offset', kind='i')
         self._cid = {c: i for i, c in enumerate(self.chromnames)}
@@ -378,6 +418,8 @@ class CoolFile(object):
         b2 = self.h.read_big('pixels/bin2_id', p0, p1, 'i')
         cnt = self.h.read_big('pixels/count', p0, p1, None)
         keep = b2 < hi                                  # pixels are sorted by bin1: the trans ones have bin2 beyond the chromosome
+        if self.square:
+            keep &= b2 >= b1                            # (and, both triangles stored: trans pixels also lie before it)
         if not keep.all():
             b1, b2, cnt = b1[keep], b2[keep], cnt[keep]
         return b1 - lo, b2 - lo, cnt

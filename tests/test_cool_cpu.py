@@ -165,3 +165,48 @@ def test_chunkwise_reading_across_chunk_borders(tmp_path):
         assert i.size == n and (j >= i).all() and c.min() >= 1
     finally:
         f.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Legal variations of the schema (scripts/make_cool_variants.py -> tests/golden/cool_variants/): the same small map written
+# the ways real files are - other integer / float widths, plain-integer bins/chrom, variable-length names, contiguous and
+# differently chunked data sets, an unsummed merge (repeated pixels), both triangles stored, no balancing column.
+VARIANTS = os.path.join(GOLDEN_DIR, 'cool_variants')
+V_CHROMS = [('chr1', 120), ('chrX', 64)]
+V_NUM = 31
+
+
+def _v_expected(i, n):
+    raw, w, _ = synthetic.synth_band(n, V_NUM, depth=30.0, nloops=3, seed=70 + i, loop_dist=(8, 14))
+    rr = np.arange(n)[:, None]
+    raw[(rr + np.arange(V_NUM)[None, :]) >= n] = 0
+    return raw, w
+
+
+@pytest.mark.parametrize('kind', ['plain', 'merged', 'floats', 'square'])
+def test_schema_variants_read_the_same_map(kind):
+    src = io.open_source(os.path.join(VARIANTS, kind + '.cool'))
+    assert src.binsize == 10000 and src.chromnames == [c for c, _ in V_CHROMS]
+    for i, (c, n) in enumerate(V_CHROMS):
+        want_raw, want_w = _v_expected(i, n)
+        raw, w, b = src.fetch(c, V_NUM)
+        assert raw.shape == (n, V_NUM) and b is None
+        np.testing.assert_array_equal(raw, want_raw)          # repeats summed, the lower triangle and the trans pixels left out
+        if kind == 'floats':                                   # (a float32 weight column: the stored values, widened)
+            np.testing.assert_array_equal(w, want_w.astype(np.float32).astype(np.float64))
+        else:
+            np.testing.assert_array_equal(w, want_w)
+        # the pixel table itself (what the device-side band builder takes) gives the same band
+        pi, pj, pc, pn, pw_, pb = src.fetch_pixels(c)
+        assert pn == n and pb is None
+        np.testing.assert_array_equal(hband.band_from_coo(pi, pj, pc, n, V_NUM), want_raw)
+
+
+def test_missing_weight_column_is_a_clear_error():
+    """scripts/pyHICCUPS:143 fails inside cooler with a KeyError on an unbalanced file; here the message says what to do"""
+    src = io.open_source(os.path.join(VARIANTS, 'noweight.cool'))
+    with pytest.raises(KeyError) as ei:
+        src.fetch('chr1', V_NUM)
+    assert 'weight' in str(ei.value) and 'balance' in str(ei.value)
+    with pytest.raises(KeyError):
+        src.fetch_pixels('chrX', 'KR')
