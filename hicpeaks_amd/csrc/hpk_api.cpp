@@ -140,6 +140,7 @@ struct hpk_ctx {
     hipStream_t aux = nullptr;
     DevBuf cooA, cooB, cooC;
     std::vector<std::pair<size_t, void*>> pool;
+    std::vector<struct hpk_devband*> live_bands;    // handed out by hpk_devband_create and not freed yet: hpk_destroy frees them
     // The widths the widening froze at (freeze_replay) in the chromosomes collected last with these parameters: the next
     // stencil writes records up to the widest of them only (HpkBandDesc::wguess); a chromosome that freezes later is
     // redone in full.
@@ -352,6 +353,7 @@ void hpk_destroy(hpk_ctx* c) {
     (void)hipDeviceSynchronize();
     DevBuf* all[] = {&c->d_bounds, &c->d_off, &c->d_sfe, &c->d_ptab, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD, &c->cooA, &c->cooB, &c->cooC};
     for (DevBuf* b : all) b->release();
+    while (!c->live_bands.empty()) hpk_devband_free(c, c->live_bands.back());      // (bands their owner did not free: into the pool, freed below)
     for (auto& e : c->pool) (void)hipFree(e.second);
     c->pool.clear();
     if (c->aux) { (void)hipStreamDestroy(c->aux); c->aux = nullptr; }
@@ -1526,7 +1528,14 @@ hipError_t pool_alloc(hpk_ctx* c, size_t bytes, void** p, size_t* got) {
         return hipSuccess;
     }
     *got = bytes;
-    return hipMalloc(p, bytes);
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory && !c->pool.empty()) {     // the blocks kept for reuse go back to the device, then once more
+        (void)hipGetLastError();
+        for (auto& b : c->pool) (void)hipFree(b.second);
+        c->pool.clear();
+        e = hipMalloc(p, bytes);
+    }
+    return e;
 }
 void pool_free(hpk_ctx* c, void* p, size_t bytes) {
     if (!p) return;
@@ -1581,13 +1590,17 @@ int64_t hpk_devband_create(hpk_ctx* c, const int64_t* bin1, const int64_t* bin2,
     band->raw = b->raw; band->weight = b->weight;
     band->bias1 = b->bias; band->bias2 = b->bias;
     band->on_device = 1;
+    c->live_bands.push_back(b);
     *out = b;
     return rc;
 }
 
 void hpk_devband_free(hpk_ctx* c, hpk_devband* b) {
     if (!b) return;
-    if (c) (void)hipSetDevice(c->device);
+    if (c) {
+        (void)hipSetDevice(c->device);
+        c->live_bands.erase(std::remove(c->live_bands.begin(), c->live_bands.end(), b), c->live_bands.end());
+    }
     pool_free(c, b->raw, b->raw_bytes);
     pool_free(c, b->weight, b->w_bytes);
     delete b;

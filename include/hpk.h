@@ -260,16 +260,13 @@ int  hpk_poisson_sf(hpk_ctx* ctx, const double* k, const double* lam, double* ou
 int  hpk_bruteforce_sums(hpk_ctx* ctx, const hpk_band* band, const hpk_params* params, int32_t step,
                          const int32_t* rows, const int32_t* cols, int64_t count, double* out);
 
-/* The production kernels' own sums at `count` sampled pixels without the dense debug outputs (which need
- * [nslots][n][D+1] arrays - gigabytes at 5 kb / 1 kb resolution): runs the stencil, looks the pixels up in the
- * candidate records; out is [count][nslots][5] = (bS_K, bE_K, bS_Y, bE_Y, resolving width); width 0 = never
- * resolved, -1 = not a candidate (zero count or outside min(ww) <= d <= maxapart/res). */
 /* Device-side band builder (row F2, the GPU counterpart of hpk_band_from_coo): the pixels of one chromosome travel as they
  * are - 20 bytes per stored pixel instead of 4 bytes per band cell, a fifth to a twentieth of the dense band - and are
  * scatter-added into a zero-filled band raw[n][ld] (ld = num rounded up to 64) in device memory owned by the library;
  * `weight` (f64[n], host) and, if not NULL, `bias` (f64[n], host: see hpk_band, IR-only derivation) are uploaded with
  * them.  *band is filled in for hpk_submit_band / hpk_submit_batch (on_device = 1, IR = NULL: derived on the device).  The
- * memory stays valid until hpk_devband_free (after the job that used it was collected).  Counts are integers below
+ * memory stays valid until hpk_devband_free (after the job that used it was collected) or hpk_destroy, which frees the bands
+ * still alive (a hpk_devband must not be freed after its context).  Counts are integers below
  * 2^24: the f32 sums are exact whatever the order of the adds.  Returns the number of stored pixels, or a negative
  * status (HPK_ERR_INVALID: a bin outside [0, n)). */
 typedef struct hpk_devband hpk_devband;
@@ -278,6 +275,10 @@ int64_t hpk_devband_create(hpk_ctx* ctx, const int64_t* bin1, const int64_t* bin
                            hpk_devband** out, hpk_band* band);
 void hpk_devband_free(hpk_ctx* ctx, hpk_devband* b);
 
+/* The production kernels' own sums at `count` sampled pixels without the dense debug outputs (which need
+ * [nslots][n][D+1] arrays - gigabytes at 5 kb / 1 kb resolution): runs the stencil, looks the pixels up in the
+ * candidate records; out is [count][nslots][5] = (bS_K, bE_K, bS_Y, bE_Y, resolving width); width 0 = never
+ * resolved, -1 = not a candidate (zero count or outside min(ww) <= d <= maxapart/res). */
 int  hpk_probe_sums(hpk_ctx* ctx, const hpk_band* band, const hpk_params* params, const int32_t* rows,
                     const int32_t* cols, int64_t count, double* out);
 
