@@ -1,0 +1,165 @@
+// The f64 prefix sums of the stencil's summed-area table on the vector pipe (DPP wave scan, what hpk_stencil_s does) against the
+// matrix pipe (v_mfma_f64_16x16x4_f64 against triangular ones-matrices), in isolation and at the stencil's occupancy
+// (1024 threads per CU = 4 waves per SIMD).  VERDICT r3 asked for one honest A/B before anything is built on it.
+//
+//   hipcc -O3 --offload-arch=gfx950 scripts/ubench/scan_ab.hip -o /tmp/scan_ab && /tmp/scan_ab
+//
+// Cells are f64.  "dpp": a wave scans a 128-cell table row (two cells per lane: in-lane add, six DPP steps + shift, as
+// wave_exclusive_scan_z in hpk_kernels.hip) and adds it to the running column sums - 128 cells of a 2-D table per iteration.
+// "mfma": a wave forms the 2-D table of a 16 x 16 block as L (V U): four MFMA steps (k = 16 in fours) for X = V U - V as the
+// A operand -, a 16 x 16 transpose of X through LDS from the accumulator layout to the B layout, four more for L X; 256 cells
+// per iteration.  "mfma-only": the eight MFMA steps without the transpose.  "both": dpp and mfma-only work of independent
+// data interleaved in one wave (does the matrix pipe run beside the vector pipe?).  Times are per CU-resident workgroup.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+typedef double double4v __attribute__((ext_vector_type(4)));
+
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_excl_scan(double c) {
+    c += dpp_f64<0x111, 0xf>(c);
+    c += dpp_f64<0x112, 0xf>(c);
+    c += dpp_f64<0x114, 0xf>(c);
+    c += dpp_f64<0x118, 0xf>(c);
+    c += dpp_f64<0x142, 0xa>(c);
+    c += dpp_f64<0x143, 0xc>(c);
+    return dpp_f64<0x138, 0xf>(c);
+}
+
+__global__ void __launch_bounds__(1024) k_dpp(double* out, int iters) {
+    const int lane = threadIdx.x & 63;
+    double v0 = 1.0 + lane * 1e-3, v1 = 0.5 + lane * 1e-4, a0 = 0.0, a1 = 0.0;
+    for (int i = 0; i < iters; ++i) {
+        const double l1 = v0 + v1;
+        const double p = wave_excl_scan(l1);
+        a0 += p + v0;
+        a1 += p + l1;
+        v0 += 1e-9; v1 += 1e-9;
+        asm volatile("" : "+v"(v0), "+v"(v1));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1;
+}
+
+// ones on and below (lower = true) / on and above the diagonal, in the A-operand layout of v_mfma_f64_16x16x4_f64:
+// lane l holds A[i = l % 16][k = l / 16 + 4 kk]
+__device__ __forceinline__ double tri_a(int lane, int kk, bool lower) {
+    const int i = lane & 15, k = (lane >> 4) + 4 * kk;
+    return (lower ? k <= i : k >= i) ? 1.0 : 0.0;
+}
+// ... and in the B layout: lane l holds B[k = l / 16 + 4 kk][j = l % 16]
+__device__ __forceinline__ double tri_b(int lane, int kk, bool upper) {
+    const int j = lane & 15, k = (lane >> 4) + 4 * kk;
+    return (upper ? k <= j : k >= j) ? 1.0 : 0.0;
+}
+
+template <bool TRANSPOSE>
+__global__ void __launch_bounds__(1024) k_mfma(double* out, int iters) {
+    __shared__ double xs[16][16 * 17];                  // per wave a 16 x 16 block, rows padded to 17
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double ub[4], la[4], va[4];
+    for (int kk = 0; kk < 4; ++kk) { ub[kk] = tri_b(lane, kk, true); la[kk] = tri_a(lane, kk, true); va[kk] = 1.0 + lane * 1e-3 + kk; }
+    double4v acc = {0.0, 0.0, 0.0, 0.0};
+    double* x = xs[wave];
+    for (int i = 0; i < iters; ++i) {
+        // X = V U (row prefix): V in the A layout, U constant in the B layout
+        double4v xr = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) xr = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], ub[kk], xr, 0, 0, 0);
+        // the accumulator holds X[4 (l / 16) + r][l % 16]; the second product wants X as B: X[l / 16 + 4 kk][l % 16] - the rows
+        // a lane holds change: through LDS (TRANSPOSE) or, for the bound, taken as they are
+        double xb[4];
+        if (TRANSPOSE) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) x[(4 * (lane >> 4) + r) * 17 + (lane & 15)] = xr[r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);         // lgkmcnt(0)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) xb[kk] = x[((lane >> 4) + 4 * kk) * 17 + (lane & 15)];
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) xb[kk] = xr[kk];
+        }
+        // S = L X (column prefix): L constant in the A layout
+        double4v s = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) s = __builtin_amdgcn_mfma_f64_16x16x4f64(la[kk], xb[kk], s, 0, 0, 0);
+        acc += s;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { va[kk] += 1e-9; asm volatile("" : "+v"(va[kk])); }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3];
+}
+
+__global__ void __launch_bounds__(1024) k_both(double* out, int iters) {
+    const int lane = threadIdx.x & 63;
+    double ub[4], la[4], va[4];
+    for (int kk = 0; kk < 4; ++kk) { ub[kk] = tri_b(lane, kk, true); la[kk] = tri_a(lane, kk, true); va[kk] = 1.0 + lane * 1e-3 + kk; }
+    double4v acc = {0.0, 0.0, 0.0, 0.0};
+    double v0 = 1.0 + lane * 1e-3, v1 = 0.5 + lane * 1e-4, a0 = 0.0, a1 = 0.0;
+    for (int i = 0; i < iters; ++i) {
+        double4v xr = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) xr = __builtin_amdgcn_mfma_f64_16x16x4f64(va[kk], ub[kk], xr, 0, 0, 0);
+        // two table rows on the vector pipe beside the block on the matrix pipe: the same 256 cells' worth
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const double l1 = v0 + v1;
+            const double p = wave_excl_scan(l1);
+            a0 += p + v0; a1 += p + l1;
+            v0 += 1e-9; v1 += 1e-9;
+            asm volatile("" : "+v"(v0), "+v"(v1));
+        }
+        double4v s = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) s = __builtin_amdgcn_mfma_f64_16x16x4f64(la[kk], xr[kk], s, 0, 0, 0);
+        acc += s;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { va[kk] += 1e-9; asm volatile("" : "+v"(va[kk])); }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc[0] + acc[1] + acc[2] + acc[3] + a0 + a1;
+}
+
+template <class K>
+static double run(K kern, int grid, int iters, double* d_out) {
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), 0, 0, d_out, iters / 10);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), 0, 0, d_out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms;
+}
+
+int main() {
+    hipDeviceProp_t pr;
+    hipGetDeviceProperties(&pr, 0);
+    const int cus = pr.multiProcessorCount, iters = 20000;
+    const double ghz = pr.clockRate / 1e6;
+    double* d_out;
+    hipMalloc(&d_out, sizeof(double) * 1024 * cus);
+    printf("# %s, %d CUs, %.2f GHz; one 1024-thread workgroup per CU (4 waves per SIMD), %d iterations per wave\n", pr.gcnArchName, cus, ghz, iters);
+    struct { const char* name; double ms; int cells; } r[4];
+    r[0] = {"dpp        (128-cell row per wave and iteration: DPP scan + column sums)", run(k_dpp, cus, iters, d_out), 128};
+    r[1] = {"mfma       (16 x 16 block: 4 MFMA, LDS transpose, 4 MFMA)", run(k_mfma<true>, cus, iters, d_out), 256};
+    r[2] = {"mfma-only  (the 8 MFMA without the transpose: a bound)", run(k_mfma<false>, cus, iters, d_out), 256};
+    r[3] = {"both       (8 MFMA and two dpp rows of other data, interleaved in one wave)", run(k_both, cus, iters, d_out), 512};
+    for (int i = 0; i < 4; ++i) {
+        const double cyc = r[i].ms * 1e-3 * ghz * 1e9 / iters;          // cycles per iteration of a wave (16 waves share the CU)
+        printf("%-80s %8.3f ms  %7.1f cycles / iteration / wave  %6.2f cells / cycle / CU\n", r[i].name, r[i].ms, cyc, 16.0 * r[i].cells / cyc);
+    }
+    // one stencil tile: 80 x 128 = 10 240 cells of f64 table
+    printf("# a tile's 10 240 table cells: dpp %.0f cycles of the CU, mfma %.0f, mfma-only %.0f\n", 10240.0 / (16.0 * r[0].cells / (r[0].ms * 1e-3 * ghz * 1e9 / iters)),
+           10240.0 / (16.0 * r[1].cells / (r[1].ms * 1e-3 * ghz * 1e9 / iters)), 10240.0 / (16.0 * r[2].cells / (r[2].ms * 1e-3 * ghz * 1e9 / iters)));
+    hipFree(d_out);
+    return 0;
+}
