@@ -9,8 +9,8 @@
 #include <stdint.h>
 #include "hpk_plan.h"
 
-#define HPK_LC 128                      // SAT columns per tile (two cells per lane)
-#define HPK_LR 80                       // SAT rows per tile: 80 * 128 * 12 B = 120 KiB + 32 KiB of candidate lists
+#define HPK_LC 160                      // SAT columns per tile: a table row per DPP row of 16 lanes, ten consecutive cells per lane
+#define HPK_LR 64                       // SAT rows per tile (four per wave): 64 * 160 * 12 B = 120 KiB + 30 KiB of candidate list
 #ifndef HPK_UNIT
 #define HPK_UNIT 128                    // records per scoring work unit (128 measured best of 128 | 256 | 512) (a tile has at most 64 x 127 records: <= 61 units of 128)
 #endif
@@ -21,8 +21,10 @@
 #ifndef HPK_NWAVES
 #define HPK_NWAVES 16                   // waves per stencil workgroup (16 or 8)
 #endif
-// record entry of a candidate: x (7 bits) | y << 7 (7 bits: row of the output tile) | capped raw count << 14 (<= pk_cap < 2^13)
-#define HPK_ENT_Y(e) (((e) >> 7) & 127u)
+// record entry of a candidate: x (8 bits) | y << 8 (6 bits: row of the output tile) | capped raw count << 14 (<= pk_cap < 2^13)
+#define HPK_ENT_X(e) ((e) & 255u)
+#define HPK_ENT_YSHIFT 8
+#define HPK_ENT_Y(e) (((e) >> HPK_ENT_YSHIFT) & 63u)
 #define HPK_ENT_CNT_SHIFT 14
 #define HPK_TLIST 7680                  // entries of hpk_stencil_s's tile-wide candidate list: TR * TC must fit
 
@@ -87,7 +89,7 @@ struct HpkBandDesc {
     HPK_GP(const double) weight;               // f64[n] or nullptr
     HPK_GP(const double) bal;                  // f64 band or nullptr
     // compact candidate records, one region of `tilecap` records per tile
-    //   rec_ent[tile * tilecap + i]                    x | row of the output tile << 7 | min(raw, pk_cap) << 13
+    //   rec_ent[tile * tilecap + i]                    x | row of the output tile << 8 | min(raw, pk_cap) << 14
     //   rec_S[slot * rec_stride + tile * tilecap + i]  (bS_K, bS_Y) at the resolving step
     //   rec_W[slot * rec_stride + tile * tilecap + i]  resolving step + 1, 0 = unresolved
     HPK_GP(unsigned) rec_ent;
@@ -133,7 +135,7 @@ struct HpkStencilArgs {
     int32_t nbands;
     int32_t W, mw, D;                   // W: halo of the tiles = widest width the search looks at (<= the plan's maxww, see Dg)
     int32_t Dg;                         // last diagonal the tiles must cover for the gap rows: D + (maxww - W)
-    int32_t TR, TC;                     // output tile = min(HPK_LR - 2W - 1, 64) x (HPK_LC - 2W - 1)
+    int32_t TR, TC;                     // output tile = (HPK_LR - 2W - 1) x (HPK_LC - 2W - 1), rows capped by the candidate list (HPK_TLIST)
     int32_t J;                          // column chunks per row block
     int32_t tilecap;
     int32_t grid;                       // persistent workgroups (multiple of 8, one per CU)

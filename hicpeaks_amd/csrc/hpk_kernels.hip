@@ -1,24 +1,25 @@
 // HIP kernels for gfx950 (MI355X / CDNA4).  Wave = 64 lanes; one stencil workgroup owns the LDS of a CU
-// (152 of 160 KiB).
+// (158 of 160 KiB).
 //
 //   hpk_ir_partial / hpk_ir_final   1-D expected IR[d] and biases from raw + weights   scripts/pyHICCUPS:149-166
 //   hpk_etab_edge   local-expected tables (interior + clipped windows), zero-fill duty     callers.py:66-72, 175-198
-//   hpk_stencil     donut (K) + lower-left (Y) local sums, adaptive widening, gap rows,    callers.py:132-232, 440-513,
+//   hpk_stencil_s   donut (K) + lower-left (Y) local sums, adaptive widening, gap rows,    callers.py:132-232, 440-513,
 //                   scoring work list                                                      238
 //   hpk_freeze      frozen_w / break decision from the resolve histogram                   callers.py:208-229, 505-511
 //   hpk_score       corrected expected -> lambda chunk -> Poisson p -> survivors           callers.py:238-271, 517-540
 //   hpk_thr_count / hpk_thr_compact   Benjamini-Hochberg cut on the survivor list          callers.py:273-279, 545-553
 //   hpk_publish     result head -> mapped pinned host memory
 //   hpk_ptab        Poisson survival table for the chunk bounds                            callers.py:268-270
-//   hpk_gap, hpk_brute, hpk_dense, hpk_poisson_sf_k   independent checks / dense debug outputs (tests)
+//   hpk_gap         gap rows of callers that hand over more diagonals than the band          callers.py:238
+//   (hpk_brute, hpk_dense, hpk_probe, hpk_poisson_sf_k: hpk_testkernels.hip)
 //
 // Stencil design.  The tile is built in true matrix coordinates (r, c): an output tile of TR x TC pixels
 // plus a halo of maxww (+1 row/column for the prefix origin) is read from band storage - rows are
-// contiguous in c, so every wave reads 128 consecutive floats of one band row - and turned into a
-// summed-area table (SAT) of 12-byte cells {f64 balanced, u32 capped raw count | valid flag << 21} in LDS.  Each wave owns
-// RPW consecutive rows x 128 columns (two cells per lane): the prefix along a row is an in-register DPP
-// scan, the prefix down the columns is a running sum in registers, so the SAT is written to LDS exactly
-// once and never read back during construction.  With the SAT every quadrant box of the (p, w) window is
+// contiguous in c - and turned into a summed-area table (SAT) of 12-byte cells {f64 balanced, u32 capped raw
+// count | valid flag << 21} in LDS, 64 rows x 160 columns.  A table row belongs to one DPP row of 16 lanes, ten
+// consecutive cells per lane, four table rows per wave: the prefix along a row is nine adds inside the lane and a
+// four-step scan over 16 lanes, written straight to LDS; the prefix down the columns is a second pass through LDS
+// (a thread per column and chunk of rows).  With the SAT every quadrant box of the (p, w) window is
 // four cell reads, independent of w.  u32 sums wrap but their differences are exact; the valid count
 // tells an all-zero balanced box (exact 0, as the reference's CSR adds give) from floating-point residue
 // of the f64 SAT.
@@ -26,6 +27,7 @@
 #include <stdint.h>
 #include <float.h>
 #include <stdlib.h>
+#include <type_traits>
 #define HPK_KERNEL_TU
 #include "hpk_kernels.h"
 
@@ -49,7 +51,7 @@ static_assert((2 * HPK_MAX_W + 1) * (2 * HPK_MAX_W + 1) * HPK_PK_CAP < (1u << PK
 static_assert((2 * HPK_MAX_W + 1) * (2 * HPK_MAX_W + 1) < (1u << (32 - PK_SHIFT)), "valid count of a box must fit its field");
 // ------------------------------------------------------------------ wave64 DPP scan (gfx9 DPP controls)
 constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
-constexpr int DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
 
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ unsigned dpp_u32(unsigned x) {
@@ -62,29 +64,31 @@ __device__ __forceinline__ double dpp_f64(double x) {
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xf, true);
     return __hiloint2double(hi, lo);
 }
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ void scan_step(double& c, unsigned& r) {
-    c += dpp_f64<CTRL, ROWMASK>(c);
-    r += dpp_u32<CTRL, ROWMASK>(r);
+// Exclusive prefix over the 16 lanes of every DPP row (a table row of hpk_stencil_s): four row_shr steps and a shift; lanes
+// without a source read 0.  f64 has no DPP form on gfx9: two moves and an add per step.
+__device__ __forceinline__ double row16_exclusive_scan(double c) {
+    c += dpp_f64<DPP_ROW_SHR1, 0xf>(c);
+    c += dpp_f64<DPP_ROW_SHR2, 0xf>(c);
+    c += dpp_f64<DPP_ROW_SHR4, 0xf>(c);
+    c += dpp_f64<DPP_ROW_SHR8, 0xf>(c);
+    return dpp_f64<DPP_ROW_SHR1, 0xf>(c);
 }
-// The same with the two row-broadcast steps writing into registers of their own (z[0..1]: rows 1 and 3 of the wave,
-// z[2..3]: rows 2 and 3): the rows a step leaves alone must read 0, and a fresh destination would be zeroed before
-// every step - these keep the zeros they start with (the caller clears them once per tile).
-__device__ __forceinline__ void wave_exclusive_scan_z(double& c, unsigned& r, int (&z)[4]) {
-    scan_step<DPP_ROW_SHR1, 0xf>(c, r);
-    scan_step<DPP_ROW_SHR2, 0xf>(c, r);
-    scan_step<DPP_ROW_SHR4, 0xf>(c, r);
-    scan_step<DPP_ROW_SHR8, 0xf>(c, r);
-    z[0] = __builtin_amdgcn_update_dpp(z[0], __double2loint(c), DPP_ROW_BCAST15, 0xa, 0xf, false);
-    z[1] = __builtin_amdgcn_update_dpp(z[1], __double2hiint(c), DPP_ROW_BCAST15, 0xa, 0xf, false);
-    c += __hiloint2double(z[1], z[0]);
+__device__ __forceinline__ unsigned row16_exclusive_scan(unsigned r) {
+    r += dpp_u32<DPP_ROW_SHR1, 0xf>(r);
+    r += dpp_u32<DPP_ROW_SHR2, 0xf>(r);
+    r += dpp_u32<DPP_ROW_SHR4, 0xf>(r);
+    r += dpp_u32<DPP_ROW_SHR8, 0xf>(r);
+    return dpp_u32<DPP_ROW_SHR1, 0xf>(r);
+}
+// Inclusive prefix over the 64 lanes of the wave (the lanes' candidate counts)
+__device__ __forceinline__ unsigned wave_inclusive_scan(unsigned r) {
+    r += dpp_u32<DPP_ROW_SHR1, 0xf>(r);
+    r += dpp_u32<DPP_ROW_SHR2, 0xf>(r);
+    r += dpp_u32<DPP_ROW_SHR4, 0xf>(r);
+    r += dpp_u32<DPP_ROW_SHR8, 0xf>(r);
     r += dpp_u32<DPP_ROW_BCAST15, 0xa>(r);
-    z[2] = __builtin_amdgcn_update_dpp(z[2], __double2loint(c), DPP_ROW_BCAST31, 0xc, 0xf, false);
-    z[3] = __builtin_amdgcn_update_dpp(z[3], __double2hiint(c), DPP_ROW_BCAST31, 0xc, 0xf, false);
-    c += __hiloint2double(z[3], z[2]);
     r += dpp_u32<DPP_ROW_BCAST31, 0xc>(r);
-    c = dpp_f64<DPP_WAVE_SHR1, 0xf>(c);
-    r = dpp_u32<DPP_WAVE_SHR1, 0xf>(r);
+    return r;
 }
 
 // Explicit window sums of one pixel at one step (rare path of the stencil): taken when the summed-area table cannot
@@ -128,37 +132,27 @@ __device__ __noinline__ double2 explicit_sums_wave(const float* __restrict__ raw
 #define HPK_CLK(v)
 #endif
 
-// ------------------------------------------------------------------ stencil for "simple Reads" plans
-// Second-generation stencil kernel: same tile geometry, SAT planes and record output as hpk_stencil above (which stays
-// for plans whose Reads matrix is not monotone in the width, and for maxww < 4).  What the phase clocks and the ISA of
-// the first kernel showed (profiles/r02_phase_clock.txt), and what is different here:
-//   * the next tile's band rows were fetched by ten branch-wrapped loads and five *serialised* scalar weight loads - a
-//     quarter of the kernel's time: here every prefetch load is a bounds-checked buffer load (cells outside the
-//     matrix or the stored diagonals read 0, no branches), the row weights arrive in one vector load and are handed
-//     out with v_readlane;
-//   * the SAT rows of the waves above were summed by a serial loop of up to fifteen dependent LDS reads after the
-//     wave's own scans: here every wave first builds the SAT *of its own rows* in registers, publishes only its last
-//     row, four waves turn those into exclusive prefixes (plain column sums, no scans), and the wave adds its base
-//     while it stores the SAT;
-//   * the candidate lists were built after the SAT from four LDS reads per pixel, one dependent round trip per half
-//     row: here they come out of the registers of phase 1 (ballot + mbcnt) in the same pass, into ONE tile-wide list
-//     (a row's slice is reserved with an LDS atomic whose return is only consumed after the row's scan), whose
-//     batches are dealt round-robin to the sixteen waves;
-//   * the SAT ran left to right.  In the tiles next to the main diagonal the contact counts fall by two orders of
-//     magnitude from left to right, so every table entry of the far pixels carried the near pixels' mass and a box
-//     sum of the far pixels was a small difference of large numbers.  Here the row direction of the table is
-//     reversed (entry (Y, X) = sum over rows <= Y and columns >= X): the large values no longer sit under the small
-//     boxes, and the exact fallback below is left for genuine outliers;
-//   * a batch of 64 candidates went through ~12 dependent LDS round trips with per-batch ballot loops for the resolve
-//     histogram: here the Reads boxes are read together, the histogram is kept per *width* with one ballot per width
-//     (converted to steps once per workgroup), the plan sits in LDS;
-//   * the scoring work list was appended with a returning global atomic that the tile's first wave waited for before
-//     the next tile could pass its first barrier: here the append of tile i is finished while tile i + 1 ends.
+// ------------------------------------------------------------------ the stencil kernel
+// hpk_stencil_s, per tile (1024 threads = 16 waves, one persistent workgroup per CU):
+//   * the next tile's band elements are requested a tile ahead: ten consecutive elements per lane in three buffer loads
+//     (elements outside the matrix or the stored diagonals are zeroed where they are used), the lane's row weight, and -
+//     160 threads - the tile's column weights, which go through a small LDS table;
+//   * phase 1 (rows): balanced values and packed cells of the lane's ten cells, the row prefix of both planes (nine adds
+//     in the lane, a scan over the 16 lanes of the DPP row that holds the table row), written straight to the tables; the
+//     candidates - cells with a count inside a range of cells that the lane works out once per tile - go to ONE tile-wide
+//     list (the wave's slice is reserved with an LDS atomic whose return is consumed after the f64 prefix);
+//   * phase 2 (columns): a thread per column and chunk of rows sums its chunk in registers, parks the chunk's total and,
+//     behind a barrier, writes its cells back with the totals of the chunks above;
+//   * the table's row direction is reversed (entry (Y, X) = sum over rows <= Y and columns >= X): next to the main
+//     diagonal the counts fall by two orders of magnitude from left to right, and the large values must not sit under the
+//     far pixels' boxes (the exact fallback below is left for genuine outliers);
+//   * phase 3: batches of 64 candidates dealt round-robin to the waves; the Reads boxes that decide most candidates are
+//     read together, the resolve histogram is kept per *width* (converted to steps once per workgroup), the plan sits in
+//     LDS; the scoring work list's append of tile i is finished while tile i + 1 ends.
 // The code is written branch-free where the compiler would otherwise wrap every cell in its own exec-mask branch
 // (selects on the inputs instead of ifs around the arithmetic).
-// (HPK_TLIST, hpk_kernels.h: the tile-wide candidate list holds TR * TC entries - 64 x 119 at a halo of 4, 66 x 115 at 6)
+// (HPK_TLIST, hpk_kernels.h: the tile-wide candidate list holds TR * TC entries - 50 x 151 at a halo of 4, 51 x 147 at 6)
 using rsrc_t = __amdgpu_buffer_rsrc_t;
-constexpr unsigned OOB_OFF = 0x7ffffff0u;   // beyond every buffer's num_records (all < 2^31): the load returns 0
 
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
@@ -169,9 +163,6 @@ __device__ __forceinline__ float ldbuf_f32(rsrc_t r, unsigned off, unsigned soff
 __device__ __forceinline__ double ldbuf_f64(rsrc_t r, unsigned off, unsigned soff) {
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, (int)soff, 0));
 }
-// SAT row of a wave's j-th row: five consecutive rows per wave (one row group per wave: sixteen group totals to prefix)
-__device__ __forceinline__ constexpr int sat_row(int wave, int j) { return 5 * wave + j; }
-
 // the lane mask of a predicate as the compiler holds it (HIP's __ballot goes through an int: v_cndmask + v_cmp per call)
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 // The same two on LDS byte addresses (phase 3 of hpk_stencil_s): per read one add of an offset to the cell's own address
@@ -191,14 +182,14 @@ __device__ __forceinline__ unsigned reads_box_b(unsigned pb, int rho, unsigned s
     return (lds_u32(pb + (dn - lf)) - lds_u32(pb + dn) - lds_u32(pb - lf) + sr) & PK_MASK;
 }
 __device__ __forceinline__ void box_ky_b(unsigned cb, int rho, double pixc, double sc, double& kc, double& yc) {
-    unsigned r8 = (unsigned)rho << 3, rL = (unsigned)rho << 10;      // LC * 8 = 1024
-    static_assert(LC * 8 == 1024, "row pitch of the f64 plane");
+    constexpr unsigned PITCH = LC * 8;                               // row pitch of the f64 plane
+    unsigned r8 = (unsigned)rho << 3, rL = (unsigned)rho * PITCH;
     asm volatile("" : "+v"(r8), "+v"(rL));                           // (sums of the two, not multiplies of rho)
-    const unsigned up = cb - 1024u;                                  // row Y - 1
+    const unsigned up = cb - PITCH;                                  // row Y - 1
     const unsigned u = rL + r8, d = rL - r8, at = up - rL, ab = cb + rL, al = up - r8, ar = up + r8;
     const double tl = lds_f64(up - u), tm = lds_f64(at), tm1 = lds_f64(at + 8), tr = lds_f64(up - d + 8);
     const double bl = lds_f64(cb + d), bm = lds_f64(ab), bm1 = lds_f64(ab + 8), br = lds_f64(cb + u + 8);
-    const double ml0 = lds_f64(al), ml1 = lds_f64(al + 1024), mr0 = lds_f64(ar + 8), mr1 = lds_f64(ar + 8 + 1024);
+    const double ml0 = lds_f64(al), ml1 = lds_f64(al + PITCH), mr0 = lds_f64(ar + 8), mr1 = lds_f64(ar + 8 + PITCH);
     const double bot = (bl - bm) + (bm1 - br);          // rows <= Y + rho, columns [X - rho, X - 1] and [X + 1, X + rho]
     const double top = (tl - tm) + (tm1 - tr);          // rows <= Y - rho - 1, same columns
     const double mid = (ml1 - mr1) - (ml0 - mr0);       // row Y, columns [X - rho, X + rho]
@@ -210,13 +201,14 @@ __device__ __forceinline__ void box_ky_b(unsigned cb, int rho, double pixc, doub
 // it; yc as in box_ky_b - with P(Y, X), so that a lower-left box over empty rows stays an exact 0 (its four corners are
 // pairwise the same numbers); big: the largest table entry the sums touch (what their rounding noise scales with).
 __device__ __forceinline__ void box_ky_d(unsigned cb, int rho, double sc, double& kc, double& yc, double& big) {
-    unsigned r8 = (unsigned)rho << 3, rL = (unsigned)rho << 10;
+    constexpr unsigned PITCH = LC * 8;
+    unsigned r8 = (unsigned)rho << 3, rL = (unsigned)rho * PITCH;
     asm volatile("" : "+v"(r8), "+v"(rL));
-    const unsigned up = cb - 1024u;
+    const unsigned up = cb - PITCH;
     const unsigned u = rL + r8, d = rL - r8, at = up - rL, ab = cb + rL, al = up - r8, ar = up + r8;
     const double tl = lds_f64(up - u), tm = lds_f64(at), tm1 = lds_f64(at + 8), tr = lds_f64(up - d + 8);
     const double bl = lds_f64(cb + d), bm = lds_f64(ab), bm1 = lds_f64(ab + 8), br = lds_f64(cb + u + 8);
-    const double ml0 = lds_f64(al), ml1 = lds_f64(al + 1024), mr0 = lds_f64(ar + 8), mr1 = lds_f64(ar + 8 + 1024);
+    const double ml0 = lds_f64(al), ml1 = lds_f64(al + PITCH), mr0 = lds_f64(ar + 8), mr1 = lds_f64(ar + 8 + PITCH);
     const double bot = (bl - bm) + (bm1 - br);
     const double top = (tl - tm) + (tm1 - tr);
     const double mid = (ml1 - mr1) - (ml0 - mr0);
@@ -234,71 +226,89 @@ __device__ __noinline__ unsigned long long box_ky_valid_m(const unsigned* __rest
     return (unsigned long long)(kv >> PK_SHIFT) | (unsigned long long)(yv >> PK_SHIFT) << 32;
 }
 
+// What a lane holds of the next tile while the current one is worked on.  Tile geometry of hpk_stencil_s: SAT row Y <->
+// matrix row r0 - W - 1 + Y (row 0 is the table's origin row); SAT column X <-> matrix column c0 - W + X (columns run the
+// other way: X = LC - 1 is the origin side).  Output pixel (y, x) of the tile sits at (Y, X) = (y + W + 1, x + W).
+// A table row belongs to one DPP row of 16 lanes: lane l of wave w holds the cells X = 159 - 10 (l % 16) - e, e = 0..9, of
+// SAT row Y = 4 w + l / 16 - ten consecutive band elements, fetched as they lie in memory (mem[i] <-> e = 9 - i).  The row
+// prefix is then nine adds inside the lane and a scan over 16 lanes (row_shr steps only), for four table rows at a time.
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
+typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v4u32 ldbuf_v4(rsrc_t r, unsigned off) { return __builtin_bit_cast(v4u32, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0)); }
+__device__ __forceinline__ v2u32 ldbuf_v2(rsrc_t r, unsigned off) { return __builtin_bit_cast(v2u32, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0)); }
+
 template <bool BALF64>
 struct TileRegsS {
-    float raw[5][2];
-    double bal[BALF64 ? 5 : 1][2];      // f64 input mode: balanced values as given
-    double wc[2];                       // weight mode: column weights of the lane's two cells
-    double wrow;                        // weight mode: lane j (j < 5) holds the weight of the wave's row j
+    unsigned raw[10];                   // f32 bit patterns, memory order
+    double bal[BALF64 ? 10 : 1];        // f64 input mode: balanced values as given, memory order
+    double wrow;                        // weight mode: weight of the lane's table row
+    double wcol;                        // weight mode, threads 0..LC-1: weight of SAT column X = thread (goes to the LDS table)
 };
 
-// Tile geometry of hpk_stencil_s.  SAT row Y <-> matrix row r0 - W - 1 + Y (row 0 is the table's origin row);
-// SAT column X <-> matrix column c0 - W + X (columns run the other way: X = 127 is the origin side).  Output pixel
-// (y, x) of the tile sits at (Y, X) = (y + W + 1, x + W).  Lane l holds the cells X = 127 - 2l (e = 0) and 126 - 2l
-// (e = 1) of each of its wave's rows, so that the wave scan runs from high to low columns.
 template <bool BALF64>
 __device__ __forceinline__ void tile_load_s(const HpkStencilArgs& a, const HpkBandDesc* __restrict__ bd, int rb, int cj, int wave,
                                             int lane, TileRegsS<BALF64>& t) {
-    const int bn = bd->n, bnum = bd->num;
+    const int bn = bd->n;
     const int64_t bld = bd->ld;
     const int r0 = rb * a.TR;
     const int rt0 = r0 - a.W - 1;                          // matrix row of SAT row 0 (negative in the first row block)
-    const int rb0 = rt0 > 0 ? rt0 : 0;                     // the tile's buffer starts at this matrix row
+    // The tile's buffer: one row more than the tile has on either side, where the band has them - a wide load of the tile's
+    // first row may start in the row before (negative diagonals), one of its last row may run on into the next.
+    const int rb0 = rt0 > 1 ? rt0 - 1 : 0;
     int rows = bn - rb0;
-    rows = rows > 96 ? 96 : rows;
+    rows = rows > LR + 2 ? LR + 2 : rows;
     const unsigned ldu = (unsigned)bld;
     const int koff = a.mw + cj * a.TC + 1;                 // diagonal of SAT cell (0, 0): (c0 - W) - (r0 - W - 1)
-    const int k4l = (koff + 127 - 2 * lane) * 4;           // byte offset within a band row of the lane's cell e = 0 at SAT row 0
+    const int Y = 4 * wave + (lane >> 4);
+    const int XL = (LC - 10) - 10 * (lane & 15);           // the lane's lowest column (cell e = 9)
     const rsrc_t rraw = make_rsrc(gptr(bd->raw) + (int64_t)rb0 * bld, (unsigned)rows * ldu * 4u);
-    rsrc_t rbal = rraw;
-    if (BALF64) rbal = make_rsrc(gptr(bd->bal) + (int64_t)rb0 * bld, (unsigned)rows * ldu * 8u);
     if (!BALF64) {
         const rsrc_t rw = make_rsrc(gptr(bd->weight), (unsigned)bn * 8u);
-        const int cc0 = rt0 + koff + 127 - 2 * lane;       // matrix column of cell e = 0; columns < 0 or >= n read 0
-#pragma unroll
-        for (int e = 0; e < 2; ++e) t.wc[e] = ldbuf_f64(rw, (unsigned)(cc0 - e) * 8u, 0u);
-        const int Yl = sat_row(wave, lane & 7);            // (lanes 5-7: rows of the next wave, never used)
-        t.wrow = ldbuf_f64(rw, (unsigned)(rt0 + Yl) * 8u, 0u);
-        // (a masked bin's weight is NaN, scripts/pyHICCUPS:163-166; phase 1 turns it into 0 - three values per lane and
-        // tile - so that the products of its pixels are zeros without a NaN test per cell)
+        // (a masked bin's weight is NaN, scripts/pyHICCUPS:163-166; it is turned into 0 where it is used - once per table
+        // column and once per lane - so that the products of its pixels are zeros without a NaN test per cell)
+        if (wave < 3) t.wcol = ldbuf_f64(rw, (unsigned)(rt0 + koff + wave * 64 + lane) * 8u, 0u);    // columns < 0 or >= n read 0
+        t.wrow = ldbuf_f64(rw, (unsigned)(rt0 + Y) * 8u, 0u);
     }
-    // The wave's rows are consecutive: row offset and row length step by constants.  A row above the matrix or below its
-    // end gets length 0 - every lane then reads out of bounds (0), whatever the row offset says.
-    const int Y0 = sat_row(wave, 0), rr0 = rt0 + Y0;
-    const unsigned ld4 = ldu * 4u;
-    unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(rr0 - rb0) * ld4));
-    int limn = __builtin_amdgcn_readfirstlane(bn - rr0);             // columns left of the matrix end in row rr0
-    const unsigned k4w = (unsigned)(k4l - 4 * Y0);
+    // Ten consecutive elements of band row rt0 + Y from diagonal koff + XL - Y on.  Elements outside the matrix or the stored
+    // diagonals are zeroed where they are used (phase 1 knows the row's limits); a start below the row (negative diagonal)
+    // reads the tail of the row before or - first row of the buffer, rows above the matrix - out of bounds (0); rows at or
+    // beyond the matrix end are out of bounds.  Wide loads: a stored element never shares one with bytes beyond the band
+    // (rows of 16 elements or more; narrower bands take ten loads).
+    // (matrix row 0 has no row before: the lanes whose ten elements straddle the start of the band take single loads too)
+    const int flat = (rt0 + Y - rb0) * (int)ldu + (koff + XL - Y);
+    const unsigned off = (unsigned)flat * 4u;
+    const bool wide = ldu >= 16u && !(flat < 0 && flat > -10);
+    if (wide) {
+        const v4u32 q0 = ldbuf_v4(rraw, off), q1 = ldbuf_v4(rraw, off + 16u);
+        const v2u32 q2 = ldbuf_v2(rraw, off + 32u);
+        t.raw[0] = q0.x; t.raw[1] = q0.y; t.raw[2] = q0.z; t.raw[3] = q0.w;
+        t.raw[4] = q1.x; t.raw[5] = q1.y; t.raw[6] = q1.z; t.raw[7] = q1.w;
+        t.raw[8] = q2.x; t.raw[9] = q2.y;
+    } else {
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        // a cell holds data iff 0 <= k < lim: inside the stored diagonals and left of the matrix end (column r + k < n)
-        int lim = limn - j;
-        lim = lim < bnum ? lim : bnum;
-        lim = lim > 0 ? lim : 0;
-        lim = rr0 + j >= 0 ? lim : 0;
-        asm volatile("" : "+s"(lim));                       // (a scalar select per row, not a lane mask ANDed per cell)
-        const unsigned lim4 = (unsigned)lim * 4u;
+        for (int i = 0; i < 10; ++i) {
+            unsigned o1 = off + 4u * (unsigned)i;
+            asm volatile("" : "+v"(o1));        // (opaque: the compiler would merge the ten into wide loads again)
+            t.raw[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rraw, (int)o1, 0, 0);
+        }
+    }
+    if (BALF64) {
+        const rsrc_t rbal = make_rsrc(gptr(bd->bal) + (int64_t)rb0 * bld, (unsigned)rows * ldu * 8u);
+        if (wide) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const unsigned k4 = k4w - (unsigned)(4 * e + 4 * j);
-            t.raw[j][e] = ldbuf_f32(rraw, k4 < lim4 ? k4 : OOB_OFF, soff);
-            if (BALF64) {
-                const unsigned mw4 = (unsigned)a.mw * 4u;
-                const unsigned span = lim4 > mw4 ? lim4 - mw4 : 0u;
-                t.bal[j][e] = ldbuf_f64(rbal, (k4 - mw4) < span ? k4 * 2u : OOB_OFF, soff * 2u);
+            for (int i = 0; i < 5; ++i) {
+                const v4u32 d = ldbuf_v4(rbal, off * 2u + 16u * (unsigned)i);
+                t.bal[2 * i] = __hiloint2double((int)d.y, (int)d.x);
+                t.bal[2 * i + 1] = __hiloint2double((int)d.w, (int)d.z);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                unsigned o1 = off * 2u + 8u * (unsigned)i;
+                asm volatile("" : "+v"(o1));
+                t.bal[i] = ldbuf_f64(rbal, o1, 0u);
             }
         }
-        soff += ld4;
     }
 }
 
@@ -344,10 +354,14 @@ struct TileWalk {
         done = false;
         locate(a, bands, true);
     }
+    // Column chunk of the tile: rotated by the row block, and by the number of this walk's strides below the row block -
+    // when the stride is a multiple of J (J = 4 on 32 workgroups per XCD) the row block's own rotation stands still, and a
+    // workgroup would meet one density class only.  (A function of the row block alone: the J tiles of a row block still
+    // take the J chunks.  Two scalar divisions per tile, in the one wave that walks.)
     __device__ __forceinline__ int cj(const HpkStencilArgs& a) const {
         if (a.order == 0) return ck;
-        const int c = ck + rm;
-        return c >= a.J ? c - a.J : c;
+        const int c = ck + rm + (rbk / (dr > 0 ? dr : 1)) % a.J;
+        return c >= a.J ? (c >= 2 * a.J ? c - 2 * a.J : c - a.J) : c;
     }
     __device__ __forceinline__ void step(const HpkStencilArgs& a, const HpkBandDesc* __restrict__ bands) {
         k += dk; rbk += dr; ck += dc; rm += drm; nt += 1;
@@ -375,10 +389,10 @@ struct TileWalk {
 // holds the workgroup's family counters, one set per width class (hpk_kernels.h: HPK_FUSE_NCL).
 template <bool BALF64, bool SINGLE, bool FUSE>
 __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const HpkBandDesc* __restrict__ bands) {
-    constexpr int NW = 16, RPW = 5;
+    constexpr int NW = 16;
     constexpr int NCL = HPK_FUSE_NCL, NBT1 = HPK_NB_TAB + 1;
     static_assert(!FUSE || (SINGLE && !BALF64), "the fused variant is built for single-pair plans on weight input");
-    static_assert(LR == 80 && LC == 128, "tile geometry of the simple-plan kernel");
+    static_assert(LR == 4 * NW && LC == 160, "tile geometry: four table rows per wave, ten cells per lane");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* __restrict__ Sc = reinterpret_cast<double*>(smem);
     unsigned* __restrict__ Sp = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 8);
@@ -389,6 +403,9 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     // then step_of[slot][width] as bytes
     unsigned* __restrict__ pl = tcount + 32;                          // [HPK_MAX_STEPS][8]
     unsigned char* __restrict__ stepof = reinterpret_cast<unsigned char*>(pl + HPK_MAX_STEPS * 8);   // [HPK_KSLOTS][32]
+    double* __restrict__ wct = reinterpret_cast<double*>(stepof + HPK_KSLOTS * 32);      // [LC] column weights of the tile (NaN -> 0)
+    double* __restrict__ ctot = wct + LC;                              // [3][LC] phase 2: totals of the f64 plane's row chunks
+    unsigned* __restrict__ utot = reinterpret_cast<unsigned*>(ctot + 3 * LC);            // [LC] ... of the packed plane's first chunk
     // FUSE: 16-bit list entries in the first half of the list region; in the second half the workgroup's scoring state
     unsigned* __restrict__ fm = lst + HPK_TLIST / 2;                  // [NCL][2][NBT1] tests per family and width class
     unsigned* __restrict__ fh = fm + NCL * 2 * NBT1;                  // [NCL][2][NBT1][8] p <= sig by log bin
@@ -550,7 +567,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     const unsigned cbw = bw;
     const int band = (int)(cbw & 0xffffu);
     const HpkBandDesc* __restrict__ bd = bands + band;
-    const int n = bd->n;
+    const int n = bd->n, bnum = bd->num;
     const int Dm = a.D < bd->num - 1 ? a.D : bd->num - 1;   // last diagonal that holds band pixels
     // Records are written for candidates whose first sufficient width is at most the band's wguess, packed (a tile's
     // record i is no longer its list entry i): the widening stops at a width that only the whole chromosome's histogram
@@ -567,6 +584,11 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     tile_load_s<BALF64>(a, bd, rb, cj, wave_k, lane_k, nxt);
     if (hband >= 0) flush_hist(bands + hband);
     hband = band;
+    if (!BALF64) {                      // the first tile's column weights (the tiles after it: behind their predecessor's tables)
+        const int tix = wave_k * 64 + lane_k;
+        if (tix < LC) wct[tix] = nxt.wcol == nxt.wcol ? nxt.wcol : 0.0;
+        __syncthreads();
+    }
 #pragma unroll 1
     do {
     // Everything below that depends only on (wave, lane) is the same for every tile, and the compiler would hoist it
@@ -592,7 +614,13 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     }
     tpar ^= 1;
     if (empty_tile) {
-        if (pre_next) tile_load_s<BALF64>(a, bd, rb_next, cj_next, wave, lane, nxt);
+        if (pre_next) {
+            tile_load_s<BALF64>(a, bd, rb_next, cj_next, wave, lane, nxt);
+            if (!BALF64 && wave < 3) {
+                const int tix = wave * 64 + lane;
+                if (tix < LC) wct[tix] = nxt.wcol == nxt.wcol ? nxt.wcol : 0.0;
+            }
+        }
         have = have_next; rb = rb_next; cj = cj_next; bw = bw_next;
         __syncthreads();                // (rare: the far end of the chromosome) wave 0's word before it is read
         tnext = lds_u32(lds0 + (unsigned)((unsigned char*)tseq - smem) + (unsigned)tpar * 4u);
@@ -600,183 +628,198 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         continue;
     }
     unsigned* __restrict__ tcnt = tcount + par;
-    // ---- phase 1: balanced values and packed cells of the wave's five rows, the candidates among them, and the SAT of
-    // the wave's own rows (row prefix by DPP scan, column prefix by running sums down the wave's rows)
-    const int xx0 = 126 - 2 * lane;                                     // SAT column of the lane's cell e = 1 (e = 0: xx0 + 1)
-    const int kl = mw + cj * TC + 1 + xx0 + 1;                          // diagonal of the lane's cell e = 0 at SAT row 0
-    const int xo = xx0 + 1 - W;                                         // output column of cell e = 0 (e = 1: xo - 1)
-    unsigned offx[2];
-    offx[0] = (unsigned)xo < (unsigned)TC ? 0u : 0x80000000u;
-    offx[1] = (unsigned)(xo - 1) < (unsigned)TC ? 0u : 0x80000000u;
-    asm volatile("" : "+v"(offx[0]), "+v"(offx[1]));
-    double satc[RPW][2];
-    unsigned satp[RPW][2];
-    int zdpp[4] = {0, 0, 0, 0};
-    // weights of masked bins (NaN, scripts/pyHICCUPS:163-166) count as 0: their pixels' balanced values are the zeros the
-    // reference turns its NaNs into (pyHICCUPS:157), everything else - negative weights included - is the reference's product
-    double wcz[2] = {0.0, 0.0}, wrz = 0.0;
-    if (!BALF64) {
-        wcz[0] = nxt.wc[0] == nxt.wc[0] ? nxt.wc[0] : 0.0;
-        wcz[1] = nxt.wc[1] == nxt.wc[1] ? nxt.wc[1] : 0.0;
-        wrz = nxt.wrow == nxt.wrow ? nxt.wrow : 0.0;
+    // ---- phase 1 (rows): balanced values and packed cells of the lane's ten cells, the candidates among them, and the row
+    // prefix of both planes - nine adds inside the lane, a scan over the 16 lanes of the DPP row that holds the table row -
+    // written straight to the tables.  Four table rows per wave, all 64 in one pass.
+    {
+    const int Y = 4 * wave + (lane >> 4);                               // the lane's table row
+    const int XH = (LC - 1) - 10 * (lane & 15);                         // SAT column of the lane's cell e = 0 (cell e: XH - e)
+    const int rr = r0 - W - 1 + Y;                                      // its matrix row
+    const int y = Y - (W + 1);                                          // its row of the output tile
+    const int kH = mw + cj * TC + 1 + XH - Y;                           // diagonal of cell e = 0 (cell e: kH - e)
+    const int xo = XH - W;                                              // output column of cell e = 0 (cell e: xo - e)
+    // the row's stored elements: diagonals [0, lim) - inside the stored diagonals and left of the matrix end (column r + k < n);
+    // rows above the matrix or beyond its end have none
+    int lim = n - rr;
+    lim = lim < bnum ? lim : bnum;
+    lim = rr >= 0 ? lim : 0;
+    lim = lim > 0 ? lim : 0;
+    // Candidates: cells with a count, inside the tile's columns (0 <= xo - e < TC), on a row of the output tile (rows at or
+    // beyond n read 0) and on a diagonal that holds band pixels (0 <= kH - e - mw <= Dm - mw): a range of e per lane -
+    // bit 9 - e of cmask - times the cells' own "count != 0" bits.
+    unsigned cmask;
+    {
+        const int A = kH - mw;
+        int elo = A - (Dm - mw), ehi = A < xo ? A : xo;
+        elo = elo > xo - TC + 1 ? elo : xo - TC + 1;
+        elo = elo > 0 ? elo : 0;
+        ehi = ehi < 9 ? ehi : 9;
+        const unsigned m = ((2u << (9 - elo)) - 1u) & ~((1u << (9 - ehi)) - 1u);        // bits 9 - ehi .. 9 - elo
+        cmask = ((unsigned)y < (unsigned)TR && elo <= ehi) ? m : 0u;
     }
-    double ac[2] = {0.0, 0.0};
-    unsigned ar[2] = {0u, 0u};
+    // weights of masked bins (NaN, scripts/pyHICCUPS:163-166) count as 0: their pixels' balanced values are the zeros the
+    // reference turns its NaNs into (pyHICCUPS:157), everything else - negative weights included - is the reference's product.
+    // Column weights: the tile's LDS table (NaNs already 0), memory order like the prefetched elements.
+    double wr = 0.0, wcm[10];
+    if (!BALF64) {
+        wr = nxt.wrow == nxt.wrow ? nxt.wrow : 0.0;
 #pragma unroll
-    for (int j = 0; j < RPW; ++j) {
-        const int Y = sat_row(wave, j);
-        double wr = 0.0;
-        if (!BALF64) wr = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(wrz), j),
-                                           __builtin_amdgcn_readlane(__double2loint(wrz), j));
-        const int y = Y - (W + 1);
-        // rows outside the output tile have no candidates: their diagonal bound is 0 (rows at or beyond n read 0)
-        unsigned kbound = (unsigned)y < (unsigned)TR ? (unsigned)(Dm - mw) + 1u : 0u;
-        asm volatile("" : "+s"(kbound));                        // (one scalar select, not a lane mask ANDed per cell)
-        double bv[2];
-        unsigned pk[2];
-        // candidates of the row: the list slice is reserved now, the entries are written after the row's scan
-        unsigned long long M[2];
-        bool cdv[2];
-        unsigned entv[2];
-        unsigned slot = 0u;
+        for (int i = 0; i < 5; ++i) {
+            const double2 w2 = *reinterpret_cast<const double2*>(&wct[XH - 9 + 2 * i]);
+            wcm[2 * i] = w2.x; wcm[2 * i + 1] = w2.y;
+        }
+    }
+    const unsigned span = lim > mw ? (unsigned)(lim - mw) : 0u;         // f64 input: balanced values exist on diagonals [mw, lim)
+    double bv[10];
+    unsigned pk[10];
+    unsigned cm = 0u;                                                   // cells with a count: bit 9 - e
+    // Tiles inside the band - every cell of every lane of the wave a stored element with a balanced value - skip the two
+    // range selects per cell.
+#define HPK_CELLS(MASKED)                                                                                                      \
+    _Pragma("unroll") for (int e = 0; e < 10; ++e) {                                                                           \
+        const int i = 9 - e;                                                                                                   \
+        const int k = kH - e, km = k - mw;                              /* diagonal, diagonal - min(ww) */                     \
+        unsigned rb32 = nxt.raw[i];                                                                                            \
+        if (MASKED) rb32 = (unsigned)k < (unsigned)lim ? rb32 : 0u;                                                            \
+        float rv = __uint_as_float(rb32);                                                                                      \
+        const unsigned ru = (unsigned)rv;                                                                                      \
+        const unsigned rc = ru < pkcap_p ? ru : pkcap_p;                                                                       \
+        if (BALF64) {                                                                                                          \
+            /* as given: the caller zeroed the NaNs (hpk.h), signs are kept (callers.py:78) */                                 \
+            bv[e] = (!(MASKED) || (unsigned)km < span) ? nxt.bal[i] : 0.0;                                                     \
+        } else {                                                                                                               \
+            if (MASKED) {                                                                                                      \
+                rv = km >= 0 ? rv : 0.f;                                /* balanced values exist from diagonal min(ww) on */   \
+                asm volatile("" : "+v"(rv));                            /* (select on the f32, not on the converted f64) */    \
+            }                                                                                                                  \
+            /* (raw * w_r) * w_c with NaN weights as 0: NaN -> 0, signs are kept.  Two rounded products, as numpy forms */      \
+            /* them (scripts/pyHICCUPS:150-152): not to be contracted with the prefix adds that follow */                       \
+            bv[e] = ((double)rv * wr) * wcm[i];                                                                                \
+            asm volatile("" : "+v"(bv[e]));                                                                                    \
+        }                                                                                                                      \
+        pk[e] = rc | (bv[e] != 0.0 ? 1u << PK_SHIFT : 0u);                                                                     \
+        /* cm = 2 cm + (count != 0): a compare and an add with carry */                                                        \
+        asm("v_cmp_ne_u32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(cm) : "v"(ru) : "vcc");             \
+    }
+    {
+        const bool inner = (kH - 9 >= mw) & (kH < lim);
+        if (ballot64(!inner) == 0ull) { HPK_CELLS(false) }
+        else { HPK_CELLS(true) }
+    }
+#undef HPK_CELLS
+    cm &= cmask;
+    // the lane's slice of the tile-wide list: behind the candidates of the lanes before it, in the wave's slice
+    const unsigned cnt = (unsigned)__popc(cm);
+    const unsigned inc = wave_inclusive_scan(cnt);
+    const unsigned nrow = (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
+    unsigned slot = 0u;
+    {
+        // hipcc's atomic optimiser would wait for the returned value on the spot; issued by hand, the LDS round
+        // trip runs beside the f64 prefix.  All lanes would add the same count into the same word: lane 0 only, by
+        // narrowing exec around the instruction (every lane is active here) instead of a branch on a lane mask.
+        const unsigned addr = (unsigned)(size_t)tcnt;
+        asm volatile("s_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %1, %2\n\ts_mov_b64 exec, -1"
+                     : "=&v"(slot) : "v"(addr), "v"(nrow) : "memory");
+    }
+    // row prefix of the f64 plane (cell e = 0 first: from the origin side)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            float rv = nxt.raw[j][e];
-            const int km = kl - e - Y - mw;                               // diagonal - min(ww)
-            const unsigned ru = (unsigned)rv;
-            const unsigned rc = ru < pkcap_p ? ru : pkcap_p;
-            if (BALF64) {
-                bv[e] = nxt.bal[j][e];                                  // as given: the caller zeroed the NaNs (hpk.h), signs are kept (callers.py:78)
-            } else {
-                rv = km >= 0 ? rv : 0.f;                                // balanced values exist from diagonal min(ww) on
-                asm volatile("" : "+v"(rv));                            // (select on the f32, not on the converted f64)
-                // (raw * w_r) * w_c with NaN weights as 0: NaN -> 0, signs are kept.  Two rounded products, as numpy forms
-                // them (scripts/pyHICCUPS:150-152): not to be contracted with the prefix adds that follow
-                bv[e] = ((double)rv * wr) * wcz[e];
-                asm volatile("" : "+v"(bv[e]));
-            }
-            pk[e] = rc | (bv[e] != 0.0 ? 1u << PK_SHIFT : 0u);
-            // (no branch on the row: the predicate flows straight into the ballot; rows outside the output tile give 0)
-            // one compare decides: a zero count or a column outside the output tile sets the top bit of the diagonal
-            const unsigned kt = (unsigned)km | offx[e] | ((ru - 1u) & 0x80000000u);
-            cdv[e] = kt < kbound;
-            M[e] = ballot64(cdv[e]);
-            entv[e] = FUSE ? (unsigned)(xo - e) : (unsigned)(xo - e) | (rc << HPK_ENT_CNT_SHIFT);
-        }
-        const unsigned nrow = (unsigned)(__popcll(M[0]) + __popcll(M[1]));
-        {
-            // hipcc's atomic optimiser would wait for the returned value on the spot; issued by hand, the LDS round
-            // trip runs beside the row's scan.  All lanes would add the same count into the same word: lane 0 only, by
-            // narrowing exec around the instruction (every lane is active here) instead of a branch on a lane mask.
-            const unsigned addr = (unsigned)(size_t)tcnt;
-            asm volatile("s_mov_b64 exec, 1\n\tds_add_rtn_u32 %0, %1, %2\n\ts_mov_b64 exec, -1"
-                         : "=&v"(slot) : "v"(addr), "v"(nrow) : "memory");
-        }
-        // row prefix of the two cells (cell e = 0 first), exclusive over the lanes
-        const double l1c = bv[0] + bv[1];
-        const unsigned l1r = pk[0] + pk[1];
-        double pc = l1c;
-        unsigned pr = l1r;
-        wave_exclusive_scan_z(pc, pr, zdpp);
-        if (j == 0) {                                           // the wave's rows start their own sums
-            ac[0] = pc + bv[0]; ar[0] = pr + pk[0];
-            ac[1] = pc + l1c;   ar[1] = pr + l1r;
-        } else {
-            ac[0] += pc + bv[0]; ar[0] += pr + pk[0];
-            ac[1] += pc + l1c;   ar[1] += pr + l1r;
-        }
-        satc[j][0] = ac[0]; satc[j][1] = ac[1];
-        satp[j][0] = ar[0]; satp[j][1] = ar[1];
-        // the wave's last row = the column-wise total of its rows, already row-prefixed: what the waves below add
-        if (j == RPW - 1) {
-            const int o = sat_row(wave, 1) * LC + xx0;             // parked in a row this wave owns
-            *reinterpret_cast<double2*>(&Sc[o]) = make_double2(ac[1], ac[0]);
-            *reinterpret_cast<uint2*>(&Sp[o]) = make_uint2(ar[1], ar[0]);
-        }
-        if (nrow != 0u) {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(slot) :: "memory");
-            // entries in the order of the scan (descending column): cell e = 0 of a lane, then its cell e = 1
-            const unsigned yy = (unsigned)y << 7;
-            const unsigned at = (unsigned)__builtin_amdgcn_readfirstlane((int)slot) +
-                                __builtin_amdgcn_mbcnt_hi((unsigned)(M[0] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M[0], 0u)) +
-                                __builtin_amdgcn_mbcnt_hi((unsigned)(M[1] >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)M[1], 0u));
+    for (int e = 1; e < 10; ++e) bv[e] += bv[e - 1];
+    {
+        const double ex = row16_exclusive_scan(bv[9]);
+        double* __restrict__ dst = &Sc[Y * LC + XH - 9];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            *reinterpret_cast<double2*>(&dst[2 * i]) = make_double2(bv[9 - 2 * i] + ex, bv[8 - 2 * i] + ex);
+    }
+    if (nrow != 0u) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(slot) :: "memory");
+        // entries in the order of the rows, inside a row by descending column
+        const unsigned at0 = (unsigned)__builtin_amdgcn_readfirstlane((int)slot) + (inc - cnt);
+        const unsigned ebase = (unsigned)xo | ((unsigned)y << HPK_ENT_YSHIFT);
+#pragma unroll
+        for (int e = 0; e < 10; ++e) {
+            const bool cd = ((cm >> (9 - e)) & 1u) != 0u;
+            const unsigned at = at0 + (unsigned)__popc(cm >> (10 - e));        // (e = 0: cm has ten bits)
             if constexpr (FUSE) {
-                const unsigned la = lds0 + (unsigned)(LR * LC * 12) + at * 2u;   // 16-bit entries: x | y << 7
-                if (cdv[0]) lds_st_u16(la, entv[0] | yy);
-                if (cdv[1]) lds_st_u16(la + (cdv[0] ? 2u : 0u), entv[1] | yy);
+                if (cd) lds_st_u16(lds0 + (unsigned)(LR * LC * 12) + at * 2u, ebase - (unsigned)e);       // 16-bit entries: x | y << 8
             } else {
-                const unsigned la = lds0 + (unsigned)(LR * LC * 12) + at * 4u;   // &lst[at]
-                if (cdv[0]) lds_st_u32(la, entv[0] | yy);
-                if (cdv[1]) lds_st_u32(la + (cdv[0] ? 4u : 0u), entv[1] | yy);
+                if (cd) lds_st_u32(lds0 + (unsigned)(LR * LC * 12) + at * 4u, (ebase - (unsigned)e) | ((pk[e] & PK_MASK) << HPK_ENT_CNT_SHIFT));
             }
         }
+    }
+    // ... and of the packed plane
+#pragma unroll
+    for (int e = 1; e < 10; ++e) pk[e] += pk[e - 1];
+    {
+        const unsigned ex = row16_exclusive_scan(pk[9]);
+        unsigned* __restrict__ dst = &Sp[Y * LC + XH - 9];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            *reinterpret_cast<uint2*>(&dst[2 * i]) = make_uint2(pk[9 - 2 * i] + ex, pk[8 - 2 * i] + ex);
+    }
     }
     HPK_CLK(ck0)
-    // The next tile's rows start moving now, from every wave.  (With 32 row groups the prefix stage behind the barrier
-    // was long and the waves not in it issued their loads there; with 16 it is short, and on the wide-band
-    // configurations - few candidates, the tile is all table building - the earlier request is worth 2 %.)
-    if (pre_next && (!BALF64 || wave < 8)) tile_load_s<BALF64>(a, bd, rb_next, cj_next, wave, lane, nxt);
+    // The next tile's rows start moving now, from every wave.
+    if (pre_next) tile_load_s<BALF64>(a, bd, rb_next, cj_next, wave, lane, nxt);
     __syncthreads();
     HPK_CLK(ck1)
-    // (f64 input: the waves that sit out the prefix stage request their rows there - thirty registers fewer to hold
-    // across the barrier)
-    if (BALF64 && pre_next && wave >= 8) tile_load_s<BALF64>(a, bd, rb_next, cj_next, wave, lane, nxt);
-    // ---- exclusive prefixes over the 16 waves' row groups, per column: plain sums in wave order.  Waves 0-3: the f64
-    // plane, 32 columns each; waves 4-7: the packed plane.  Lanes 0-31 walk groups 0-7 of their column, lanes 32-63 groups
-    // 8-15, which start from the first half's total.  Group g parked its total in SAT row 5g + 1 and gets its base in row 5g.
-    if (wave < 8) {
-        const int col = (wave & 3) * 32 + (lane & 31);
-        const int g0 = lane >= 32 ? 8 : 0;
-        if (wave < 4) {
-            double v[8];
+    // ---- phase 2 (columns): the tables hold row prefixes; the prefix down the columns runs through LDS.  f64 plane: waves
+    // 0-9, a thread per column and chunk of 16 rows; packed plane: waves 10-14, chunks of 32 rows.  A thread sums its chunk in
+    // registers, parks the chunk's total, and - behind a barrier - writes its cells back with the totals of the chunks above.
+    unsigned creg[32];
+    {
+        if (wave < 10) {
+            const int tix = wave * 64 + lane;
+            const int ch = tix >= 2 * LC ? (tix >= 3 * LC ? 3 : 2) : (tix >= LC ? 1 : 0), col = tix - ch * LC;
+            const double* __restrict__ src = &Sc[(16 * ch) * LC + col];
+            double v[16];
 #pragma unroll
-            for (int g = 0; g < 8; ++g) v[g] = Sc[(5 * (g0 + g) + 1) * LC + col];
-            double tot = v[0];
+            for (int i = 0; i < 16; ++i) v[i] = src[i * LC];
 #pragma unroll
-            for (int g = 1; g < 8; ++g) tot += v[g];
-            // the second half starts from the first half's total.  (ds_bpermute on the loop's own lane number: __shfl()
-            // takes its own, which is hoisted out of every loop and - in the f64 variant - spilled: the reload's vmcnt(0)
-            // then waits here for the whole prefetch of the next tile)
-            const int src4 = (lane & 31) << 2;
-            double run = __hiloint2double(__builtin_amdgcn_ds_bpermute(src4, __double2hiint(tot)),
-                                          __builtin_amdgcn_ds_bpermute(src4, __double2loint(tot)));
-            run = g0 ? run : 0.0;
+            for (int i = 1; i < 16; ++i) v[i] += v[i - 1];
+            if (ch < 3) ctot[ch * LC + col] = v[15];
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                Sc[(5 * (g0 + g)) * LC + col] = run;
-                run += v[g];
-            }
+            for (int i = 0; i < 16; ++i) { creg[2 * i] = (unsigned)__double2loint(v[i]); creg[2 * i + 1] = (unsigned)__double2hiint(v[i]); }
         } else {
-            unsigned v[8];
+            // (wave 15 has no chunk: it reads along with wave 14 and writes nothing - every path defines the registers)
+            const int tix = ((wave < 15 ? wave : 14) - 10) * 64 + lane;
+            const int ch = tix >= LC ? 1 : 0, col = tix - ch * LC;
+            const unsigned* __restrict__ src = &Sp[(32 * ch) * LC + col];
 #pragma unroll
-            for (int g = 0; g < 8; ++g) v[g] = Sp[(5 * (g0 + g) + 1) * LC + col];
-            unsigned tot = v[0];
+            for (int i = 0; i < 32; ++i) creg[i] = src[i * LC];
 #pragma unroll
-            for (int g = 1; g < 8; ++g) tot += v[g];
-            unsigned run = (unsigned)__builtin_amdgcn_ds_bpermute((lane & 31) << 2, (int)tot);
-            run = g0 ? run : 0u;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                Sp[(5 * (g0 + g)) * LC + col] = run;
-                run += v[g];
-            }
+            for (int i = 1; i < 32; ++i) creg[i] += creg[i - 1];
+            if (ch == 0 && wave < 15) utot[col] = creg[31];
         }
     }
     __syncthreads();
     HPK_CLK(ck2)
-    // ---- phase 2: add the groups' bases and store the SAT
     {
-        const int oa = sat_row(wave, 0) * LC + xx0;
-        const double2 bs = *reinterpret_cast<const double2*>(&Sc[oa]);
-        const uint2 us = *reinterpret_cast<const uint2*>(&Sp[oa]);
+        if (wave < 10) {
+            const int tix = wave * 64 + lane;
+            const int ch = tix >= 2 * LC ? (tix >= 3 * LC ? 3 : 2) : (tix >= LC ? 1 : 0), col = tix - ch * LC;
+            // (plain sums in chunk order)
+            double base = ch >= 1 ? ctot[col] : 0.0;
+            base += ch >= 2 ? ctot[LC + col] : 0.0;
+            base += ch >= 3 ? ctot[2 * LC + col] : 0.0;
+            double* __restrict__ dst = &Sc[(16 * ch) * LC + col];
 #pragma unroll
-        for (int j = 0; j < RPW; ++j) {
-            const int o = sat_row(wave, j) * LC + xx0;
-            *reinterpret_cast<double2*>(&Sc[o]) = make_double2(satc[j][1] + bs.x, satc[j][0] + bs.y);
-            *reinterpret_cast<uint2*>(&Sp[o]) = make_uint2(satp[j][1] + us.x, satp[j][0] + us.y);
+            for (int i = 0; i < 16; ++i) dst[i * LC] = __hiloint2double((int)creg[2 * i + 1], (int)creg[2 * i]) + base;
+        } else if (wave < 15) {
+            const int tix = (wave - 10) * 64 + lane;
+            const int ch = tix >= LC ? 1 : 0, col = tix - ch * LC;
+            const unsigned base = ch == 1 ? utot[col] : 0u;
+            unsigned* __restrict__ dst = &Sp[(32 * ch) * LC + col];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) dst[i * LC] = creg[i] + base;
         }
     }
     __syncthreads();
+    // the next tile's column weights are in: into the LDS table (nobody reads it before the barrier that ends this tile)
+    if (!BALF64 && pre_next && wave < 3) {
+        const int tix = wave * 64 + lane;
+        if (tix < LC) wct[tix] = nxt.wcol == nxt.wcol ? nxt.wcol : 0.0;
+    }
     HPK_CLK(ck3)
     const int total = (int)*tcnt;
     // gap rows (callers.py:238): rows of the tile's columns (the last tile of a row block: up to the end of its halo)
@@ -804,7 +847,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         const int i = b * 64 + lane;
         const bool cand = i < total;
         const unsigned id = lst[cand ? i : 0];
-        const int x = (int)(id & 127u);
+        const int x = (int)HPK_ENT_X(id);
         const int y = (int)HPK_ENT_Y(id);
         const int base = (y + W + 1) * LC + W + x;
         // one round of reads: P(Y, X) of both planes, the pixel's own value, the three Reads boxes that decide most
@@ -1062,8 +1105,8 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             const int i = b * 64 + lane;
             const bool cand = i < total;
             const unsigned id = lds_u16(l16 + (unsigned)(cand ? i : 0) * 2u);
-            const int x = (int)(id & 127u);
-            const int y = (int)((id >> 7) & 127u);
+            const int x = (int)HPK_ENT_X(id);
+            const int y = (int)HPK_ENT_Y(id);
             const int base = (y + W + 1) * LC + W + x;
             const unsigned pb = lds0 + (unsigned)(LR * LC * 8) + (unsigned)base * 4u;
             const unsigned sr = lds_u32(pb);
@@ -1118,7 +1161,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             const bool act = k0 + lane < wcur;
             const unsigned slot = ((((unsigned)k0 >> 6) * (unsigned)NW + (unsigned)wave) << 6) | (unsigned)lane;
             const unsigned ent = lds_u16(l16 + (act ? slot : ((unsigned)wave << 6)) * 2u);
-            const int x = (int)(ent & 127u), y = (int)((ent >> 7) & 127u);
+            const int x = (int)HPK_ENT_X(ent), y = (int)HPK_ENT_Y(ent);
             const int cls = act ? (int)(ent >> 14) : 0;     // width class = step of the single-pair plan
             const int wst = wmin_p + cls;
             const int base = (y + W + 1) * LC + W + x;
@@ -1819,7 +1862,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
     auto issue_round2 = [&](const Geo& g) {
         const bool cn = g.i0 + lane < g.cnt;
         const unsigned e = cn ? ent_b : 0u;
-        const int r = g.r0 + (int)HPK_ENT_Y(e), c = g.c0 + (int)(e & 127u), d = c - r;
+        const int r = g.r0 + (int)HPK_ENT_Y(e), c = g.c0 + (int)HPK_ENT_X(e), d = c - r;
         ir_b = b_IR[cn ? (unsigned)d : 0u];
         b2_b = b_b2[cn ? (unsigned)c : 0u];
         b1_b = b_b1[cn ? (unsigned)r : 0u];
@@ -1861,7 +1904,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
             // parked in scratch) across it.
             if (!cand) ent = 0u;
             const int r = g.r0 + (int)HPK_ENT_Y(ent);
-            const int c = g.c0 + (int)(ent & 127u);
+            const int c = g.c0 + (int)HPK_ENT_X(ent);
             const int d = c - r;
             // which local-expected table serves this pixel (interior / clipped by one matrix end / both: explicit)
             const bool top = cand && r < W, right = cand && c >= b_n - W;
@@ -2291,7 +2334,7 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkBandDesc* __rest
 }  // namespace
 
 // ------------------------------------------------------------------ launchers
-int hpk_stencil_s_lds_bytes() { return LR * LC * 12 + HPK_TLIST * 4 + 128 + HPK_MAX_STEPS * 32 + HPK_KSLOTS * 32; }
+int hpk_stencil_s_lds_bytes() { return LR * LC * 12 + HPK_TLIST * 4 + 128 + HPK_MAX_STEPS * 32 + HPK_KSLOTS * 32 + LC * 8 * 4 + LC * 4; }
 
 template <bool BALF64, bool SINGLE, bool FUSE = false>
 static void launch_stencil_s_t(const HpkStencilArgs& a, const HpkBandDesc* d_bands, hipStream_t st) {

@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256) hpk_dense(HpkDenseArgs a) {
         const int64_t ri = (int64_t)tile * a.tilecap + i;
         const unsigned ent = a.rec_ent[ri];
         const int r = r0 + (int)HPK_ENT_Y(ent);
-        const int c = c0 + (int)(ent & 127u);
+        const int c = c0 + (int)HPK_ENT_X(ent);
         const int d = c - r;
         const int64_t o = (int64_t)r * a.ldo + d;
         for (int q = 0; q < plan->nslots; ++q) {
@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(64) hpk_probe(HpkDenseArgs a, const int32_t* _
         const int rb = r / a.TR, r0 = rb * a.TR, cj = (c - r0 - a.mw) / a.TC;
         const int tile = rb * a.J + cj;
         const int x = c - (r0 + a.mw + cj * a.TC), y = r - r0;
-        const unsigned key = (unsigned)x | ((unsigned)y << 7);
+        const unsigned key = (unsigned)x | ((unsigned)y << HPK_ENT_YSHIFT);
         const int cnt = (int)a.tile_cnt[tile];
         for (int i0 = 0; i0 < cnt; i0 += 64) {
             const int i = i0 + lane;

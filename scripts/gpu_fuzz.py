@@ -96,7 +96,9 @@ def one_case(seed, ctx):
             w = R.dense_w[slot][vx, vy - vx].astype(np.int64)
             w = np.where(w > R.frozen_w, 0, w)
             if not np.array_equal(w, loc['wres'][pi]):
-                return 'MISMATCH-widths', desc, 'slot %d: %d differ' % (slot, int((w != loc['wres'][pi]).sum()))
+                bad = np.nonzero(w != loc['wres'][pi])[0][:4]
+                where = ', '.join('(r %d, c %d): %d, oracle %d' % (vx[i], vy[i], w[i], loc['wres'][pi][i]) for i in bad)
+                return 'MISMATCH-widths', desc, 'slot %d: %d differ; %s' % (slot, int((w != loc['wres'][pi]).sum()), where)
     # The production path once more: no dense outputs, so the stencil writes records up to a width bound only - first
     # the width this very case froze at (taken over from the call above), then a bound forced to the narrowest width
     # (option spec_force: the widening freezes later, the library notices and computes the case again in full).

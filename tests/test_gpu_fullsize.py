@@ -92,7 +92,8 @@ def test_full_size_wide_band(name, ctx):
     inband = (kk[None, :] >= mw) & (kk[None, :] <= D) & ((rr[:, None] + kk[None, :]) < n)
     assert R.ncand == int(((raw_d != 0) & inband).sum().item())
     assert R.band_px == hband.band_pixels(n, num, mw, D)
-    assert R.tiles == -(-n // 59) * -(-(59 + D - mw) // 107) and -(-(59 + D - mw) // 107) >= 19      # ~20 column chunks
+    TR, TC = 64 - 2 * W - 1, 160 - 2 * W - 1            # table of 64 x 160 cells less the halo (hpk_kernels.h)
+    assert R.tiles == -(-n // TR) * -(-(TR + D - mw) // TC) and -(-(TR + D - mw) // TC) >= 14     # ~15 column chunks
     ex = [e for _, _, _, e in R.steps]
     assert ex == sorted(ex, reverse=True) and ex[0]
     assert all(wi <= R.frozen_w for _, wi, _, e in R.steps if e)
@@ -237,7 +238,8 @@ def test_full_size_chr1_vs_oracle(name, ctx):
     # (i) one call, IR / biases given, weights on the chip
     d1 = {}
     final = callers.hiccups_band(rawf, IR, biases, biases, chrom='1', weight=weight, ctx=ctx, detail=d1, **kw)
-    assert d1['result'].stencil_kernel == 2 and d1['result'].tiles == -(-n // 59) * -(-(59 + cfg['maxapart'] // res - min(ww)) // 107)
+    TR, TC = 64 - 2 * maxww - 1, 160 - 2 * maxww - 1    # table of 64 x 160 cells less the halo (hpk_kernels.h)
+    assert d1['result'].stencil_kernel == 2 and d1['result'].tiles == -(-n // TR) * -(-(TR + cfg['maxapart'] // res - min(ww)) // TC)
     _check_against_oracle(d1['result'], final, det, want, pw, ww, sig)
     # (ii) the same chromosome between two others in one batch, IR / biases derived on the device
     prm = _lib.make_params(_lib.MODE_HICCUPS, pw, ww, maxww, sig, cfg['maxapart'], res, 16, 0)
