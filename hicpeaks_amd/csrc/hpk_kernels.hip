@@ -821,7 +821,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         if (tix < LC) wct[tix] = nxt.wcol == nxt.wcol ? nxt.wcol : 0.0;
     }
     HPK_CLK(ck3)
-    const int total = (int)*tcnt;
+    const int total = a.dbg_stop == 2 ? 0 : (int)*tcnt;         // (profiling ablation 2: the tables only, no batches)
     // gap rows (callers.py:238): rows of the tile's columns (the last tile of a row block: up to the end of its halo)
     // without a non-zero balanced value - exact on the valid-count field
     const int tx = wave * 64 + lane;             // (not threadIdx.x: its address arithmetic would be hoisted and spilled)
