@@ -17,6 +17,8 @@ def table_arrays(t):
 def one_case(seed, ctx):
     rng = np.random.default_rng(seed)
     maxww = int(rng.integers(3, 21))
+    if os.environ.get('HPK_FUZZ_NARROW'):       # bands of 8-14 diagonals: a band row is shorter than the stencil's wide loads
+        maxww = 3 + maxww % 2
     npairs = int(rng.integers(1, 4))
     ww = sorted(set(int(v) for v in rng.integers(2, maxww + 3, npairs)))     # a pair may be wider than maxww
     pw = [int(rng.integers(0, max(1, w))) for w in ww]
@@ -26,6 +28,8 @@ def one_case(seed, ctx):
     res = 10000
     n = int(rng.integers(150, 1400)) if rng.random() < 0.8 else int(rng.integers(25, 150))     # some shorter than the band
     D = int(rng.integers(max(ww) + 2, 160))
+    if os.environ.get('HPK_FUZZ_NARROW'):
+        D = int(rng.integers(max(ww) + 2, max(ww) + 4))
     if os.environ.get('HPK_FUZZ_BIG'):          # many tiles: several row blocks per XCD chunk, 3-5 column chunks
         n, D = int(rng.integers(2000, 5000)), int(rng.integers(200, 520))
     if os.environ.get('HPK_FUZZ_WIDE'):         # bands as wide as the 5 kb / 1 kb configurations: 12-20 column chunks

@@ -634,6 +634,25 @@ def test_random_parameter_sets_against_oracle(ctx):
     assert tally.get('ok', 0) >= 30, tally
 
 
+def test_narrow_bands_against_oracle(ctx, monkeypatch):
+    """Bands of 8-14 diagonals (scripts/gpu_fuzz.py with HPK_FUZZ_NARROW): a band row is shorter than the ten consecutive
+    elements a lane of the stencil fetches in wide loads, so every lane takes single loads and most of them straddle rows;
+    chromosomes shorter than a tile and the first rows of the matrix (no row before them) come with it."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location('gpu_fuzz', os.path.join(os.path.dirname(__file__), '..', 'scripts',
+                                                                          'gpu_fuzz.py'))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    monkeypatch.setenv('HPK_FUZZ_NARROW', '1')
+    tally = {}
+    for seed in range(900, 960):
+        status, desc, note = fz.one_case(seed, ctx)
+        assert not status.startswith('MISMATCH'), (status, desc, note)
+        assert desc.get('D', 0) + desc.get('maxww', 0) + 1 <= 16 or status == 'invalid-input', desc
+        tally[status] = tally.get(status, 0) + 1
+    assert tally.get('ok', 0) >= 20, tally
+
+
 @pytest.mark.parametrize('spec_halo', [1, 0])
 def test_record_bound_from_the_previous_chromosome(spec_halo):
     """The stencil writes records up to a width bound taken from the chromosome collected last with the same
