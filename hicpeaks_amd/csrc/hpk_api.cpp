@@ -307,6 +307,7 @@ int hpk_create(int device, hpk_ctx** out) {
     o.spec = env_int("HPK_SPEC", o.spec);
     o.spec_margin = env_int("HPK_SPEC_MARGIN", o.spec_margin);
     o.spec_halo = env_int("HPK_SPEC_HALO", o.spec_halo);
+    o.spec_force = env_int("HPK_SPEC_FORCE", o.spec_force);     // (measurements: a record bound of one's choosing)
     o.host_threads = std::max(1, std::min(64, env_int("HPK_HOST_THREADS", o.host_threads)));
     o.spec_surv = env_int("HPK_SPEC_SURV", o.spec_surv) ? 1 : 0;
     o.spec_surv_margin = std::max(0, env_int("HPK_SPEC_SURV_MARGIN", o.spec_surv_margin));
