@@ -73,7 +73,7 @@ struct Lane {
     int nev = 0;
     bool busy = false;
     // workspaces (grow only), pooled over the bands of a batch
-    DevBuf raw, bal, weight, IR, b1, b2, plan, etab, eedge, recE, recS, recW, dE, dW, dS, small, surv, surv2, survx, survx2, cux, psum, pnan, units, desc, kmin;
+    DevBuf raw, bal, weight, IR, b1, b2, plan, etab, eedge, recE, recS, recW, dE, dW, dS, small, surv, surv2, survx, survx2, cux, psum, pnan, units, desc, kmin, classtab;
     void* h_head = nullptr;             // pinned: per band counters | row flags | first survivors
     size_t h_head_cap = 0;
     void* h_desc = nullptr;             // pinned staging of the band descriptors
@@ -84,7 +84,7 @@ struct Lane {
     HpkDevPlan plan_host;
     void release() {
         DevBuf* all[] = {&raw, &bal, &weight, &IR, &b1, &b2, &plan, &etab, &eedge, &recE, &recS, &recW, &dE, &dW, &dS, &small,
-                         &surv, &surv2, &survx, &survx2, &cux, &psum, &pnan, &units, &desc, &kmin};
+                         &surv, &surv2, &survx, &survx2, &cux, &psum, &pnan, &units, &desc, &kmin, &classtab};
         for (DevBuf* b : all) b->release();
         if (h_head) { (void)hipHostFree(h_head); h_head = nullptr; h_head_cap = 0; }
         if (h_desc) { (void)hipHostFree(h_desc); h_desc = nullptr; h_desc_cap = 0; }
@@ -105,6 +105,7 @@ struct Options {
     int spec_margin = 0;
     int spec_force = -1;
     int tr_cap = 127;           // most rows of an hpk_stencil_s output tile (A/B: 64 = the first-generation kernel's limit)
+    int spec_class = 1;         // record bound per chromosome by depth class (hpk_band_class) under the batch's bound
     int spec_halo = 1;          // tiles laid out for the record bound's halo instead of maxww's (hpk_stencil_s launches)
     int risk_log2 = 12;
     int tile_order = 1;
@@ -147,6 +148,9 @@ struct hpk_ctx {
     hpk_params hint_key;
     int hint_w[4] = {-1, -1, -1, -1};
     int hint_n = 0;
+    // ... and per depth class (hpk_band_class) the width the last chromosome of the class froze at (-1: none seen): a band's own
+    // record bound under the batch's
+    signed char class_w[HPK_NCLASS];
     long long spec_reruns = 0;
     // ... and the histogram bins their Benjamini-Hochberg cuts fell into, per family (HPK_OFF_TBIN): the smallest bin of the
     // last collections, minus a margin, bounds the survivor records the next scoring launches write (HpkScoreArgs::kmin)
@@ -283,6 +287,7 @@ int hpk_create(int device, hpk_ctx** out) {
         return fail(nullptr, HPK_ERR_NO_DEVICE, "device %d is %s; libhpk is built for gfx950 only", device, prop.gcnArchName);
     if ((e = hipSetDevice(device)) != hipSuccess) return fail(nullptr, HPK_ERR_HIP, "hipSetDevice -> %s", hipGetErrorName(e));
     hpk_ctx* c = new hpk_ctx();
+    std::memset(c->class_w, -1, sizeof(c->class_w));
     c->device = device;
     std::snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
     c->cus = prop.multiProcessorCount;
@@ -307,6 +312,7 @@ int hpk_create(int device, hpk_ctx** out) {
     o.spec = env_int("HPK_SPEC", o.spec);
     o.spec_margin = env_int("HPK_SPEC_MARGIN", o.spec_margin);
     o.spec_halo = env_int("HPK_SPEC_HALO", o.spec_halo);
+    o.spec_class = env_int("HPK_SPEC_CLASS", o.spec_class) ? 1 : 0;
     o.spec_force = env_int("HPK_SPEC_FORCE", o.spec_force);     // (measurements: a record bound of one's choosing)
     o.host_threads = std::max(1, std::min(64, env_int("HPK_HOST_THREADS", o.host_threads)));
     o.spec_surv = env_int("HPK_SPEC_SURV", o.spec_surv) ? 1 : 0;
@@ -343,7 +349,9 @@ int hpk_set_option(hpk_ctx* c, const char* name, int64_t v) {
     else if (k == "score_div" && v >= 1 && v <= 4096) o.score_div = (int)v;
     else if (k == "dbg_stop" && v >= 0 && v <= 16) o.dbg_stop = (int)v;
     else if (k == "fuse" && (v == 0 || v == 1)) o.fuse = (int)v;
-    else if (k == "reset_hints") { c->hint_n = 0; c->hint_bn = 0; }     // forget the bounds learnt from the chromosomes collected so far
+    else if (k == "spec_class" && (v == 0 || v == 1)) o.spec_class = (int)v;
+    else if (k == "class_force" && v >= -1 && v <= 127) std::memset(c->class_w, (int)v, sizeof(c->class_w));     // tests: every depth class claims this width
+    else if (k == "reset_hints") { c->hint_n = 0; c->hint_bn = 0; std::memset(c->class_w, -1, sizeof(c->class_w)); }     // forget the bounds learnt from the chromosomes collected so far
     else return fail(c, HPK_ERR_INVALID, "unknown option or value out of range: %s = %lld", name, (long long)v);
     return HPK_OK;
 }
@@ -477,6 +485,7 @@ struct BandSlot {
     size_t small_off = 0, head_off = 0; // inside Lane::small / Lane::h_head
     size_t dense_elems = 0;
     bool redone = false, overflowed = false, finished = false, rescored = false;
+    int cls = -1;                       // depth class hpk_band_class put the band in (-1: not classified)
     bool rest_fetched = false;          // the survivors beyond the inline head already sit in `rest` (overflow rerun)
     std::vector<HpkSurv> rest;
     int status = HPK_OK;
@@ -493,7 +502,7 @@ struct hpk_job {
     HpkScoreArgs sc, sc_full;
     int nsets = 0, rounds_eff = 0, gmax = 0;
     bool sums = false, dense = false, do_score = true, phases = false, simple = false, use_s = false, balf64 = false,
-         time_stencil = true, fused = false;
+         time_stencil = true, fused = false, use_class = false;
     size_t max_zero = 0, max_head = 0;
     double t_begin = 0.0;
     uint8_t kmin_host[HPK_NFAM];        // the survivor bound of the batch's scoring launches (HpkScoreArgs::kmin), if any
@@ -900,6 +909,20 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     }
     hpk_launch_etab(L.plan.as<HpkDevPlan>(), L.desc.as<HpkBandDesc>(), nb, plan.nsteps, D, W, j->max_zero, L.up);
     HIPCHK(c, hipGetLastError());
+    // Record bound per chromosome: the batch's bound comes from the widest freeze of the last collections; a band of a shallower
+    // sample freezes earlier, and what it writes beyond its own width is read and dropped by the scoring kernel.  hpk_band_class
+    // sorts the bands into depth classes on the device and gives each the width its class froze at last (verified at collection
+    // like the batch's bound: a chromosome that froze later is computed once more).
+    j->use_class = opt.spec && opt.spec_class && j->simple && j->do_score && !dense && !fuse_job && wg_all < W && wg_all > (int)plan.wmin;
+    if (j->use_class) {
+        signed char tab[HPK_NCLASS];
+        if (c->hint_n > 0 && std::memcmp(&key, &c->hint_key, sizeof(key)) == 0) std::memcpy(tab, c->class_w, sizeof(tab));
+        else std::memset(tab, -1, sizeof(tab));
+        HIPCHK(c, L.classtab.reserve(HPK_NCLASS));
+        HIPCHK(c, hipMemcpyAsync(L.classtab.p, tab, HPK_NCLASS, hipMemcpyHostToDevice, L.up));
+        hpk_launch_band_class(L.desc.as<HpkBandDesc>(), nb, mw, D, L.classtab.as<signed char>(), wg_all, opt.spec_margin, (int)plan.wmin, L.up);
+        HIPCHK(c, hipGetLastError());
+    }
     HIPCHK(c, hipEventRecord(L.ev_up, L.up));
     HIPCHK(c, hipStreamWaitEvent(c->stream, L.ev_up, 0));
     if (dense) {   // pixels outside the band are never written by the kernel
@@ -1179,6 +1202,10 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
             const unsigned char* hsmall = static_cast<const unsigned char*>(L.h_head) + s.head_off;
             const int32_t fz = *reinterpret_cast<const int32_t*>(hsmall + HPK_OFF_FROZEN);
             const int32_t er = *reinterpret_cast<const int32_t*>(hsmall + HPK_OFF_ERR);
+            if (j->use_class && !s.redone) {        // the bound the band ran under (hpk_band_class; gone after a full recomputation)
+                const unsigned v = *reinterpret_cast<const unsigned*>(hsmall + HPK_OFF_BCLASS);
+                if (v & 0x10000u) { s.cls = (int)((v >> 8) & 255u); s.d.wguess = (int32_t)(v & 255u); }
+            }
             // once more from the band, on its own, under the plan's geometry and through the two-kernel path, with a record for
             // every resolved candidate (the band's second descriptor, prepared at submission)
             auto full_redo = [&](bool all_survivors) -> int {
@@ -1287,6 +1314,7 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
     double px_all = 0.0;
     for (const BandSlot& s : j->bands) px_all += (double)std::max<int64_t>(s.band_px, 1);
     int fz_max = -1;
+    std::vector<std::pair<int, int>> cls_seen;      // (depth class, width the chromosome froze at) of the batch's chromosomes
     // The host half of a chromosome (sorting its survivors, Benjamini-Hochberg, result arrays: ~0.06 ms) is independent of
     // the others': a large batch spreads it over a few threads - the kernels of the next batch take 0.1 ms per chromosome,
     // and the host half must stay well below that.  HIP is only called from this thread: survivors beyond the inline heads
@@ -1338,9 +1366,11 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
         R.ms_tighten = ms_ti * share; R.ms_gap = ms_gap * share;
         R.ms_total = (float)(now_ms() - j->t_begin);
         if (j->do_score) fz_max = std::max(fz_max, (int)R.frozen_w);
+        if (j->use_class && s.cls >= 0 && s.cls < HPK_NCLASS && R.frozen_w >= 0) cls_seen.emplace_back(s.cls, (int)R.frozen_w);
     }
     if (fz_max >= 0) {          // the next stencils' record bound: the widest freeze of the last few collections
-        if (c->hint_n == 0 || std::memcmp(&j->key, &c->hint_key, sizeof(j->key)) != 0) { c->hint_n = 0; c->hint_bn = 0; c->hint_key = j->key; }
+        if (c->hint_n == 0 || std::memcmp(&j->key, &c->hint_key, sizeof(j->key)) != 0) { c->hint_n = 0; c->hint_bn = 0; c->hint_key = j->key; std::memset(c->class_w, -1, sizeof(c->class_w)); }
+        for (const auto& cf : cls_seen) c->class_w[cf.first] = (signed char)std::min(cf.second, 127);
         if (j->rounds_eff <= -100) {        // ... and the bins of the families' cuts (smallest over the batch)
             uint8_t bins[HPK_NFAM];
             std::memset(bins, 255, sizeof(bins));

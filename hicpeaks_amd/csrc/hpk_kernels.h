@@ -47,7 +47,8 @@ struct HpkSurv {
 #define HPK_OFF_FROZEN  (HPK_OFF_HIST + 8 * (HPK_MAX_STEPS + 1))            // i32
 #define HPK_OFF_ERR     (HPK_OFF_FROZEN + 8)                                // i32
 #define HPK_OFF_EXEC    (HPK_OFF_ERR + 8)                                   // i32[64]
-#define HPK_OFF_NUNITS  (HPK_OFF_EXEC + 4 * HPK_MAX_STEPS)                  // u32 (+ pad): survives the overflow rerun
+#define HPK_OFF_NUNITS  (HPK_OFF_EXEC + 4 * HPK_MAX_STEPS)                  // u32 (+ HPK_OFF_BCLASS): survives the overflow rerun
+#define HPK_OFF_BCLASS  (HPK_OFF_NUNITS + 4)                                // u32: 0x10000 | depth class << 8 | the record bound hpk_band_class gave the band (0: none)
 #define HPK_OFF_NSURV   (HPK_OFF_NUNITS + 8)                                // u64[HPK_NREG * HPK_REG_STRIDE] ... from here on reset by the rerun
 #define HPK_OFF_NVALID  (HPK_OFF_NSURV + 8 * HPK_NREG * HPK_REG_STRIDE)     // u64[16]
 #define HPK_OFF_EMAX    (HPK_OFF_NVALID + 8 * 2 * HPK_MAX_PAIRS)            // u64[16]
@@ -215,6 +216,12 @@ void hpk_launch_tighten(const HpkBandDesc* d_bands, int nbands, double sig, int 
 void hpk_launch_publish(const HpkBandDesc* d_bands, int nbands, int nsets, bool full, size_t max_head_bytes, hipStream_t st);
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,
                      hipStream_t st);
+// Record bound per chromosome by depth class (hpk_band_class): class = quarter octave of the band's mean count per pixel (every
+// 64th row sampled), bound = table[class] + margin (table: the width chromosomes of that class froze at, -1 unknown) clamped to
+// [wmin, wg_all]; written into the descriptor's wguess and into the counter block (HPK_OFF_BCLASS).  Runs before the stencil.
+#define HPK_NCLASS 64
+void hpk_launch_band_class(HpkBandDesc* d_bands, int nbands, int mw, int D, const signed char* table, int wg_all, int margin, int wmin,
+                           hipStream_t st);
 void hpk_launch_poisson_sf(const double* k, const double* lam, const double* sfe, double* out, int64_t count,
                            hipStream_t st);
 void hpk_launch_brute(const HpkBruteArgs& a, hipStream_t st);

@@ -1505,6 +1505,52 @@ __global__ void __launch_bounds__(256) hpk_ir_final(const HpkBandDesc* __restric
     const long long denom = (long long)(n - k) - (long long)nn;
     gptr(bd->IR)[k] = (k >= mw && n - k > 0) ? s / (double)denom : 0.0;       // 0/0 -> NaN like numpy's mean of an empty slice
 }
+// ------------------------------------------------------------------ record bound by depth class
+// The width at which a chromosome's widening freezes grows with its depth; a context that serves chromosomes of several
+// samples would otherwise write every band's records up to the deepest sample's width (hpk_api.cpp: the bound is verified at
+// collection whatever it was).  One workgroup per band: the mean count per band pixel over every 64th row, its quarter octave.
+__global__ void __launch_bounds__(256) hpk_band_class(HpkBandDesc* __restrict__ bands, int mw, int D, const signed char* __restrict__ table,
+                                                      int wg_all, int margin, int wmin) {
+    HpkBandDesc* bd = bands + blockIdx.x;
+    const int n = bd->n, num = bd->num;
+    const int64_t ld = bd->ld;
+    const int Dm = D < num - 1 ? D : num - 1;
+    const float* __restrict__ raw = gptr(bd->raw);
+    double sum = 0.0;
+    for (int r = 0; r < n; r += 64) {
+        const int kmax = Dm < n - 1 - r ? Dm : n - 1 - r;
+        for (int k = mw + (int)threadIdx.x; k <= kmax; k += 256) sum += (double)raw[(int64_t)r * ld + k];
+    }
+    __shared__ double red[256];
+    red[threadIdx.x] = sum;
+    __syncthreads();
+    for (int m = 128; m > 0; m >>= 1) {
+        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        long long cells = 0;
+        for (int r = 0; r < n; r += 64) {
+            const int kmax = Dm < n - 1 - r ? Dm : n - 1 - r;
+            cells += kmax >= mw ? kmax - mw + 1 : 0;
+        }
+        int cls = 0;
+        if (cells > 0 && red[0] > 0.0) {
+            cls = (int)floor(4.0 * log2(red[0] / (double)cells)) + 32;
+            cls = cls < 0 ? 0 : (cls > HPK_NCLASS - 1 ? HPK_NCLASS - 1 : cls);
+        }
+        const int t = (int)table[cls];
+        int wg = wg_all;
+        if (t >= 0) {
+            wg = t + margin;
+            wg = wg < wmin ? wmin : wg;
+            wg = wg < wg_all ? wg : wg_all;
+        }
+        bd->wguess = wg;
+        *reinterpret_cast<unsigned*>(gptr(bd->small) + HPK_OFF_BCLASS) = 0x10000u | ((unsigned)cls << 8) | (unsigned)wg;
+    }
+}
+
 // ------------------------------------------------------------------ freeze
 // The reference's frozen_w / break logic on the chromosome's totals (callers.py:208-229, 505-511), one thread.
 // hist[s] = candidates resolved at step s, hist[HPK_HIST_NCAND] = all candidates; executed may be nullptr.
@@ -2504,6 +2550,11 @@ void hpk_launch_publish(const HpkBandDesc* d_bands, int nbands, int nsets, bool 
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,
                      hipStream_t st) {
     hipLaunchKernelGGL(hpk_ptab, dim3((total + 255) / 256), dim3(256), 0, st, bounds, off, sfe, ptab, total);
+}
+
+void hpk_launch_band_class(HpkBandDesc* d_bands, int nbands, int mw, int D, const signed char* table, int wg_all, int margin, int wmin,
+                           hipStream_t st) {
+    if (nbands > 0) hipLaunchKernelGGL(hpk_band_class, dim3(nbands), dim3(256), 0, st, d_bands, mw, D, table, wg_all, margin, wmin);
 }
 
 void hpk_launch_coo_scatter(const int64_t* bin1, const int64_t* bin2, const void* count, int count_f64, int64_t nnz, int n, int num,

@@ -232,7 +232,9 @@ int  hpk_collect_batch(hpk_ctx* ctx, hpk_job* job, hpk_result** outs, int32_t* s
  * p-value histogram the cut is derived from [default], -1: a histogram pass of its own, 0..4: exact counting rounds),
  * "surv_cap" (survivor slots per region, 0 = sized from the band; tests force the overflow rerun with it), "spec" (0: no
  * record bound from earlier chromosomes), "spec_margin" (widths added to the bound), "spec_force" (>= 0: this bound;
- * tests), "spec_surv" (0: a survivor record for every p <= sig; 1 [default]: only up to the histogram bin the families' cuts fell
+ * tests), "spec_class" (1 [default]: under the batch's bound every chromosome writes records only up to the width chromosomes of
+ * its depth class - quarter octaves of the mean count per band pixel, sorted on the device - froze at last; verified like the
+ * batch's bound, hpk_result::record_bound is the chromosome's own; 0: one bound per batch), "class_force" (tests), "spec_surv" (0: a survivor record for every p <= sig; 1 [default]: only up to the histogram bin the families' cuts fell
  * into in the chromosomes before, minus "spec_surv_margin" bins - verified, hpk_result::redone bit 1), "spec_surv_force" (tests),
  * "host_threads" (threads of a batch's host half), "spec_halo" (0: tiles always under maxww's halo - runs of one chromosome are then bit-identical whatever the bound), "risk_log2" (exact-fallback threshold 2^-x), "tile_order", "gap_kernel" (1: gap rows by the row kernel),
  * "score_div" (tiles per scoring workgroup of a batch), "dbg_stop" (profiling ablation), "fuse" (1: bounded single-pair hiccups

@@ -653,6 +653,57 @@ def test_narrow_bands_against_oracle(ctx, monkeypatch):
     assert tally.get('ok', 0) >= 20, tally
 
 
+def test_record_bound_by_depth_class():
+    """Chromosomes of samples of different depth in one context: the batch's tiles are laid out for the widest freeze seen,
+    but every chromosome writes records only up to the width its own depth class (hpk_band_class: quarter octaves of the mean
+    count per band pixel) froze at last.  Verified at collection like the batch's bound: a class that claims too narrow a
+    width (option class_force) has its chromosomes computed once more; results never depend on any of it."""
+    from hicpeaks_amd import synthetic
+    n, res, maxapart, maxww = 3000, 10000, 2000000, 10
+    num = maxapart // res + maxww + 1
+    prm = _lib.make_params(_lib.MODE_HICCUPS, [2], [5], maxww, 0.1, maxapart, res, 16, 0)
+    bands, want = {}, {}
+    for depth in (15.0, 60.0, 150.0, 400.0):
+        raw, weight, _ = synthetic.synth_band(n, num, depth=depth, nloops=40, seed=31)
+        bands[depth] = (raw.astype(np.float32), weight)
+        c0 = _lib.Context(0)
+        want[depth] = c0.score_host(bands[depth][0], None, None, None, prm, weight=weight)
+        c0.close()
+    fw = {d: want[d].frozen_w for d in bands}
+    ok = [d for d in bands if fw[d] < maxww]
+    a = min(ok, key=lambda d: fw[d])
+    b = max(ok, key=lambda d: fw[d])
+    assert fw[a] < fw[b], fw                      # two depths that freeze at different widths below maxww
+    batch = [dict(raw=bands[d][0], weight=bands[d][1]) for d in (a, b, a, b)]
+    c = _lib.Context(0)
+    try:
+        first = c.submit_batch_host(batch, prm).results()
+        second = c.submit_batch_host(batch, prm).results()
+        third = c.submit_batch_host(batch, prm).results()
+        for got, d in zip(first + second + third, (a, b, a, b) * 3):
+            _same_result(got, want[d])
+        # from the second batch on the bound exists, from the third every class is known: each chromosome under its own width,
+        # the tiles under the widest
+        for got, d in zip(third, (a, b, a, b)):
+            assert got.record_bound == fw[d] and not got.redone and got.halo_w == fw[b], (d, got.record_bound, fw, got.halo_w)
+        c.set_option('spec_class', 0)
+        flat = c.submit_batch_host(batch, prm).results()
+        assert all(g.record_bound == fw[b] and not g.redone for g in flat)
+        c.set_option('spec_class', 1)
+        c.set_option('class_force', 5)             # every class claims min(ww): too narrow for a chromosome that froze later
+        forced = c.submit_batch_host(batch, prm).results()
+        assert any(g.redone for g in forced)
+        for got, d in zip(forced, (a, b, a, b)):
+            assert bool(got.redone) == (fw[d] > 5) and got.record_bound == (maxww if fw[d] > 5 else 5), (d, fw[d], got.redone, got.record_bound)
+            _same_result(got, want[d])
+        again = c.submit_batch_host(batch, prm).results()       # the classes have learnt their widths again
+        for got, d in zip(again, (a, b, a, b)):
+            assert got.record_bound == fw[d] and not got.redone
+            _same_result(got, want[d])
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize('spec_halo', [1, 0])
 def test_record_bound_from_the_previous_chromosome(spec_halo):
     """The stencil writes records up to a width bound taken from the chromosome collected last with the same
