@@ -151,6 +151,7 @@ struct hpk_ctx {
     // ... and per depth class (hpk_band_class) the width the last chromosome of the class froze at (-1: none seen): a band's own
     // record bound under the batch's
     signed char class_w[HPK_NCLASS];
+    signed char class_w1[HPK_NCLASS];   // ... and the one before it: the band's bound is the wider of the two
     long long spec_reruns = 0;
     // ... and the histogram bins their Benjamini-Hochberg cuts fell into, per family (HPK_OFF_TBIN): the smallest bin of the
     // last collections, minus a margin, bounds the survivor records the next scoring launches write (HpkScoreArgs::kmin)
@@ -287,7 +288,7 @@ int hpk_create(int device, hpk_ctx** out) {
         return fail(nullptr, HPK_ERR_NO_DEVICE, "device %d is %s; libhpk is built for gfx950 only", device, prop.gcnArchName);
     if ((e = hipSetDevice(device)) != hipSuccess) return fail(nullptr, HPK_ERR_HIP, "hipSetDevice -> %s", hipGetErrorName(e));
     hpk_ctx* c = new hpk_ctx();
-    std::memset(c->class_w, -1, sizeof(c->class_w));
+    { std::memset(c->class_w, -1, sizeof(c->class_w)); std::memset(c->class_w1, -1, sizeof(c->class_w1)); }
     c->device = device;
     std::snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
     c->cus = prop.multiProcessorCount;
@@ -350,8 +351,8 @@ int hpk_set_option(hpk_ctx* c, const char* name, int64_t v) {
     else if (k == "dbg_stop" && v >= 0 && v <= 16) o.dbg_stop = (int)v;
     else if (k == "fuse" && (v == 0 || v == 1)) o.fuse = (int)v;
     else if (k == "spec_class" && (v == 0 || v == 1)) o.spec_class = (int)v;
-    else if (k == "class_force" && v >= -1 && v <= 127) std::memset(c->class_w, (int)v, sizeof(c->class_w));     // tests: every depth class claims this width
-    else if (k == "reset_hints") { c->hint_n = 0; c->hint_bn = 0; std::memset(c->class_w, -1, sizeof(c->class_w)); }     // forget the bounds learnt from the chromosomes collected so far
+    else if (k == "class_force" && v >= -1 && v <= 127) { std::memset(c->class_w, (int)v, sizeof(c->class_w)); std::memset(c->class_w1, (int)v, sizeof(c->class_w1)); }     // tests: every depth class claims this width
+    else if (k == "reset_hints") { c->hint_n = 0; c->hint_bn = 0; { std::memset(c->class_w, -1, sizeof(c->class_w)); std::memset(c->class_w1, -1, sizeof(c->class_w1)); } }     // forget the bounds learnt from the chromosomes collected so far
     else return fail(c, HPK_ERR_INVALID, "unknown option or value out of range: %s = %lld", name, (long long)v);
     return HPK_OK;
 }
@@ -916,7 +917,8 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     j->use_class = opt.spec && opt.spec_class && j->simple && j->do_score && !dense && !fuse_job && wg_all < W && wg_all > (int)plan.wmin;
     if (j->use_class) {
         signed char tab[HPK_NCLASS];
-        if (c->hint_n > 0 && std::memcmp(&key, &c->hint_key, sizeof(key)) == 0) std::memcpy(tab, c->class_w, sizeof(tab));
+        if (c->hint_n > 0 && std::memcmp(&key, &c->hint_key, sizeof(key)) == 0)
+            for (int i = 0; i < HPK_NCLASS; ++i) tab[i] = std::max(c->class_w[i], c->class_w1[i]);
         else std::memset(tab, -1, sizeof(tab));
         HIPCHK(c, L.classtab.reserve(HPK_NCLASS));
         HIPCHK(c, hipMemcpyAsync(L.classtab.p, tab, HPK_NCLASS, hipMemcpyHostToDevice, L.up));
@@ -1369,8 +1371,8 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
         if (j->use_class && s.cls >= 0 && s.cls < HPK_NCLASS && R.frozen_w >= 0) cls_seen.emplace_back(s.cls, (int)R.frozen_w);
     }
     if (fz_max >= 0) {          // the next stencils' record bound: the widest freeze of the last few collections
-        if (c->hint_n == 0 || std::memcmp(&j->key, &c->hint_key, sizeof(j->key)) != 0) { c->hint_n = 0; c->hint_bn = 0; c->hint_key = j->key; std::memset(c->class_w, -1, sizeof(c->class_w)); }
-        for (const auto& cf : cls_seen) c->class_w[cf.first] = (signed char)std::min(cf.second, 127);
+        if (c->hint_n == 0 || std::memcmp(&j->key, &c->hint_key, sizeof(j->key)) != 0) { c->hint_n = 0; c->hint_bn = 0; c->hint_key = j->key; { std::memset(c->class_w, -1, sizeof(c->class_w)); std::memset(c->class_w1, -1, sizeof(c->class_w1)); } }
+        for (const auto& cf : cls_seen) { c->class_w1[cf.first] = c->class_w[cf.first]; c->class_w[cf.first] = (signed char)std::min(cf.second, 127); }
         if (j->rounds_eff <= -100) {        // ... and the bins of the families' cuts (smallest over the batch)
             uint8_t bins[HPK_NFAM];
             std::memset(bins, 255, sizeof(bins));
