@@ -1509,7 +1509,7 @@ __global__ void __launch_bounds__(256) hpk_ir_final(const HpkBandDesc* __restric
 // The width at which a chromosome's widening freezes grows with its depth; a context that serves chromosomes of several
 // samples would otherwise write every band's records up to the deepest sample's width (hpk_api.cpp: the bound is verified at
 // collection whatever it was).  One workgroup per band: the mean count per band pixel over every 64th row, its quarter octave.
-__global__ void __launch_bounds__(256) hpk_band_class(HpkBandDesc* __restrict__ bands, int mw, int D, const signed char* __restrict__ table,
+__global__ void __launch_bounds__(1024) hpk_band_class(HpkBandDesc* __restrict__ bands, int mw, int D, const signed char* __restrict__ table,
                                                       int wg_all, int margin, int wmin) {
     HpkBandDesc* bd = bands + blockIdx.x;
     const int n = bd->n, num = bd->num;
@@ -1517,14 +1517,15 @@ __global__ void __launch_bounds__(256) hpk_band_class(HpkBandDesc* __restrict__ 
     const int Dm = D < num - 1 ? D : num - 1;
     const float* __restrict__ raw = gptr(bd->raw);
     double sum = 0.0;
-    for (int r = 0; r < n; r += 64) {
+    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    for (int r = 64 * wave; r < n; r += 64 * 16) {      // (a wave per sampled row: sixteen rows in flight)
         const int kmax = Dm < n - 1 - r ? Dm : n - 1 - r;
-        for (int k = mw + (int)threadIdx.x; k <= kmax; k += 256) sum += (double)raw[(int64_t)r * ld + k];
+        for (int k = mw + lane; k <= kmax; k += 64) sum += (double)raw[(int64_t)r * ld + k];
     }
-    __shared__ double red[256];
+    __shared__ double red[1024];
     red[threadIdx.x] = sum;
     __syncthreads();
-    for (int m = 128; m > 0; m >>= 1) {
+    for (int m = 512; m > 0; m >>= 1) {
         if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
         __syncthreads();
     }
@@ -2554,7 +2555,7 @@ void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe
 
 void hpk_launch_band_class(HpkBandDesc* d_bands, int nbands, int mw, int D, const signed char* table, int wg_all, int margin, int wmin,
                            hipStream_t st) {
-    if (nbands > 0) hipLaunchKernelGGL(hpk_band_class, dim3(nbands), dim3(256), 0, st, d_bands, mw, D, table, wg_all, margin, wmin);
+    if (nbands > 0) hipLaunchKernelGGL(hpk_band_class, dim3(nbands), dim3(1024), 0, st, d_bands, mw, D, table, wg_all, margin, wmin);
 }
 
 void hpk_launch_coo_scatter(const int64_t* bin1, const int64_t* bin2, const void* count, int count_f64, int64_t nnz, int n, int num,
