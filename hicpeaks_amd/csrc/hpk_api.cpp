@@ -505,6 +505,7 @@ struct hpk_job {
     bool sums = false, dense = false, do_score = true, phases = false, simple = false, use_s = false, balf64 = false,
          time_stencil = true, fused = false, use_class = false;
     size_t max_zero = 0, max_head = 0;
+    signed char class_tab[HPK_NCLASS];  // the depth classes' widths as uploaded for this batch (source of an asynchronous copy: lives with the job)
     double t_begin = 0.0;
     uint8_t kmin_host[HPK_NFAM];        // the survivor bound of the batch's scoring launches (HpkScoreArgs::kmin), if any
     ~hpk_job() { for (BandSlot& b : bands) delete b.box; }
@@ -916,10 +917,10 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     // like the batch's bound: a chromosome that froze later is computed once more).
     j->use_class = opt.spec && opt.spec_class && j->simple && j->do_score && !dense && !fuse_job && wg_all < W && wg_all > (int)plan.wmin;
     if (j->use_class) {
-        signed char tab[HPK_NCLASS];
+        signed char* tab = j->class_tab;
         if (c->hint_n > 0 && std::memcmp(&key, &c->hint_key, sizeof(key)) == 0)
             for (int i = 0; i < HPK_NCLASS; ++i) tab[i] = std::max(c->class_w[i], c->class_w1[i]);
-        else std::memset(tab, -1, sizeof(tab));
+        else std::memset(tab, -1, HPK_NCLASS);
         HIPCHK(c, L.classtab.reserve(HPK_NCLASS));
         HIPCHK(c, hipMemcpyAsync(L.classtab.p, tab, HPK_NCLASS, hipMemcpyHostToDevice, L.up));
         hpk_launch_band_class(L.desc.as<HpkBandDesc>(), nb, mw, D, L.classtab.as<signed char>(), wg_all, opt.spec_margin, (int)plan.wmin, L.up);
