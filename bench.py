@@ -575,7 +575,7 @@ def main():
             # kernel writes compact records for the candidates only, so two more figures keep the books honest:
             # compact_4Bpx (the §8-D3 figure for a compacting mode: the 4 B/px that must be read) and hbm_frac_measured
             # (counter traffic per launch / kernel time / peak - what the memory system actually carries).
-            'roofline': {'bound': 'hbm', 'kernel': {1: 'hpk_stencil', 2: 'hpk_stencil_s', 3: 'hpk_stencil_s<fused: scores inside>'}[R.stencil_kernel], 'achieved': achieved,
+            'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil_s', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                          'kernel_ms': st, 'kernel_ms_per_chromosome': st / group,
                          'algorithmic_bytes_per_launch': BYTES_PER_PX * px_per_step * group,

@@ -117,8 +117,6 @@ struct Options {
     int spec_surv_margin = 2;
     int spec_surv_force = -1;   // tests: this bin for every family (too narrow a bound: scored once more)
     int host_threads = 8;       // threads of a batch's host half (hpk_collect_batch), at most one per four chromosomes
-    int fuse = 0;               // 1: bounded single-pair hiccups launches score inside the stencil kernel (no records, no hpk_score);
-                                // measured level with the two kernels, so the two-kernel path stays the default
 };
 
 struct hpk_ctx {
@@ -325,7 +323,6 @@ int hpk_create(int device, hpk_ctx** out) {
     o.score_div = std::max(1, env_int("HPK_SCORE_DIV", o.score_div));
     o.dbg_stop = env_int("HPK_DBG_STOP", o.dbg_stop);
     o.host_prof = env_int("HPK_HOST_PROF", o.host_prof);
-    o.fuse = env_int("HPK_FUSE", o.fuse) ? 1 : 0;
     *out = c;
     return HPK_OK;
 }
@@ -349,7 +346,6 @@ int hpk_set_option(hpk_ctx* c, const char* name, int64_t v) {
     else if (k == "gap_kernel" && (v == 0 || v == 1)) o.gap_kernel = (int)v;
     else if (k == "score_div" && v >= 1 && v <= 4096) o.score_div = (int)v;
     else if (k == "dbg_stop" && v >= 0 && v <= 16) o.dbg_stop = (int)v;
-    else if (k == "fuse" && (v == 0 || v == 1)) o.fuse = (int)v;
     else if (k == "spec_class" && (v == 0 || v == 1)) o.spec_class = (int)v;
     else if (k == "class_force" && v >= -1 && v <= 127) { std::memset(c->class_w, (int)v, sizeof(c->class_w)); std::memset(c->class_w1, (int)v, sizeof(c->class_w1)); }     // tests: every depth class claims this width
     else if (k == "reset_hints") { c->hint_n = 0; c->hint_bn = 0; { std::memset(c->class_w, -1, sizeof(c->class_w)); std::memset(c->class_w1, -1, sizeof(c->class_w1)); } }     // forget the bounds learnt from the chromosomes collected so far
@@ -481,8 +477,7 @@ struct BandSlot {
     int32_t n = 0, num = 0, ntiles = 0;
     int32_t ntiles_full = 0;            // tiles under the plan's own halo (the geometry of a chromosome computed once more)
     int64_t ld = 0, cap = 0, band_px = 0, ldo = 0;
-    size_t off_rowlive = 0, off_inl = 0, head_bytes = 0, off_hacc = 0, off_tc = 0, off_cnt = 0, off_cu = 0, off_cls = 0, zero_bytes = 0;
-    bool fused = false;                 // scored inside the stencil kernel (no candidate records exist for it)
+    size_t off_rowlive = 0, off_inl = 0, head_bytes = 0, off_hacc = 0, off_tc = 0, off_cnt = 0, off_cu = 0, zero_bytes = 0;
     size_t small_off = 0, head_off = 0; // inside Lane::small / Lane::h_head
     size_t dense_elems = 0;
     bool redone = false, overflowed = false, finished = false, rescored = false;
@@ -503,7 +498,7 @@ struct hpk_job {
     HpkScoreArgs sc, sc_full;
     int nsets = 0, rounds_eff = 0, gmax = 0;
     bool sums = false, dense = false, do_score = true, phases = false, simple = false, use_s = false, balf64 = false,
-         time_stencil = true, fused = false, use_class = false;
+         time_stencil = true, use_class = false;
     size_t max_zero = 0, max_head = 0;
     signed char class_tab[HPK_NCLASS];  // the depth classes' widths as uploaded for this batch (source of an asynchronous copy: lives with the job)
     double t_begin = 0.0;
@@ -525,14 +520,10 @@ int launch_compute(hpk_ctx* c, hpk_job* j, int b0, int nbl, bool solo, bool with
     const HpkBandDesc* dd = lane_desc(L, j, b0, solo);
     // a chromosome computed once more (its record bound was too narrow) runs under the plan's own halo and tile geometry
     const bool full = solo && j->bands[b0].redone;
-    // the batch's own launches of a fused job: the stencil scores, hpk_fuse_combine decides the freeze and adds up the width
-    // classes that count; a chromosome computed once more always takes the two-kernel path
-    const bool fused = j->fused && !solo;
     if (with_stencil) {
         if (j->time_stencil) (void)hipEventRecord(L.ev[1], c->stream);
         {
             HpkStencilArgs sa = full ? j->sa_full : j->sa;
-            sa.fuse = fused ? 1 : 0;
             sa.nbands = nbl;
             int kall = 0;
             for (int b = b0; b < b0 + nbl; ++b) kall += j->bands[b].d.chunk;
@@ -547,13 +538,7 @@ int launch_compute(hpk_ctx* c, hpk_job* j, int b0, int nbl, bool solo, bool with
         }
         if (j->phases) (void)hipEventRecord(L.ev[3], c->stream);
     }
-    if (fused) {
-        hpk_launch_fuse_combine(L.plan.as<HpkDevPlan>(), dd, nbl, c->stream);
-        HIPCHK(c, hipGetLastError());
-        if (j->phases) (void)hipEventRecord(L.ev[4], c->stream);
-        hpk_launch_tighten(dd, nbl, j->prm.sig, j->rounds_eff, j->nsets, j->sc.kmin, c->stream, true);
-        HIPCHK(c, hipGetLastError());
-    } else if (j->do_score) {
+    if (j->do_score) {
         HpkScoreArgs sc = full ? j->sc_full : j->sc;
         if (all_survivors) sc.kmin = nullptr;       // (a chromosome whose cut lay above the bound of its survivor records)
         sc.gridx = 0;           // the widest row of scoring workgroups among the bands launched (HpkBandDesc::score_wgs)
@@ -680,10 +665,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         const Geo g = geo_of(Wh);
         if (Wh < W && hpk_stencil_s_applies(stencil_args_of(g), max_ld, max_n)) GS = g;
     }
-    // ---- one kernel from band to p-value: bounded single-pair hiccups launches on weight input score inside the stencil
     const int hbins = (opt.rounds <= -2) ? hpk_score_hist_bins((plan.mode == HPK_MODE_BHFDR) ? 1 : 2 * plan.npairs, plan.mode == HPK_MODE_BHFDR) : 0;
-    const bool fuse_job = opt.fuse && j->use_s && j->do_score && !dense && !j->balf64 && hpk_stencil_fusable(plan, wg_all, hbins);
-    j->fused = fuse_job;
     // ---- geometry, sizes and offsets of every band's slices
     const int TR = GS.TR, TC = GS.TC, J_ = GS.J, tilecap = GS.tilecap;
     (void)TC;
@@ -731,8 +713,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         s.off_tc = up256(s.off_hacc + 8 * (size_t)(HPK_MAX_STEPS + 1) * HPK_ACC_STRIDE);
         s.off_cnt = up256(s.off_tc + sizeof(unsigned) * tiles_max);
         s.off_cu = up256(s.off_cnt + sizeof(unsigned) * HPK_NFAM * HPK_TIGHTEN_MAX);
-        s.off_cls = up256(s.off_cu + sizeof(unsigned) * (size_t)(cap / HPK_SCH * HPK_NREG + 1));
-        s.zero_bytes = (s.off_cls + (fuse_job ? (size_t)HPK_CLS_BYTES : 0) + 4095) / 4096 * 4096;
+        s.zero_bytes = (up256(s.off_cu + sizeof(unsigned) * (size_t)(cap / HPK_SCH * HPK_NREG + 1)) + 4095) / 4096 * 4096;
         s.small_off = tot_small; tot_small += s.zero_bytes;
         s.head_off = tot_head; tot_head += up256(s.head_bytes);
         off_rec[b] = tot_rec; tot_rec += rec_max;
@@ -763,8 +744,6 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         d.cap = cap; d.zero_bytes = s.zero_bytes; d.off_rowlive = (uint32_t)s.off_rowlive; d.off_inl = (uint32_t)s.off_inl;
         d.derive = derive ? (bands[b].bias1 ? 2 : 1) : 0;       // 1: IR and biases, 2: IR only
         d.score_wgs = wgs;
-        d.off_cls = (uint32_t)s.off_cls;
-        s.fused = fuse_job;
     }
 
     // ---- workspaces
@@ -915,7 +894,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     // sample freezes earlier, and what it writes beyond its own width is read and dropped by the scoring kernel.  hpk_band_class
     // sorts the bands into depth classes on the device and gives each the width its class froze at last (verified at collection
     // like the batch's bound: a chromosome that froze later is computed once more).
-    j->use_class = opt.spec && opt.spec_class && j->simple && j->do_score && !dense && !fuse_job && wg_all < W && wg_all > (int)plan.wmin;
+    j->use_class = opt.spec && opt.spec_class && j->simple && j->do_score && !dense && wg_all < W && wg_all > (int)plan.wmin;
     if (j->use_class) {
         signed char* tab = j->class_tab;
         if (c->hint_n > 0 && std::memcmp(&key, &c->hint_key, sizeof(key)) == 0)
@@ -991,10 +970,6 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
             if (opt.host_prof) std::fprintf(stderr, "[hpk host] survivor bound: bins %d %d %d ... (hbins %d)\n", km[1], km[2], km[HPK_NB + 2], hbins);
         }
     }
-    sa.bounds = sc.bounds; sa.ptab = sc.ptab; sa.ptab_off = sc.ptab_off; sa.sfe = sc.sfe; sa.kmin = sc.kmin; sa.sig = sc.sig;
-    sa.fuse = fuse_job ? 1 : 0;
-    j->sa_full.bounds = sc.bounds; j->sa_full.ptab = sc.ptab; j->sa_full.ptab_off = sc.ptab_off; j->sa_full.sfe = sc.sfe;
-    j->sa_full.sig = sc.sig;
     j->sc_full = sc;
     j->sc_full.tilecap = GF.tilecap; j->sc_full.TR = GF.TR; j->sc_full.TC = GF.TC; j->sc_full.J = GF.J; j->sc_full.W = GF.W;
     return launch_compute(c, j, 0, nb, false, true);
@@ -1016,7 +991,7 @@ int finish_band(hpk_ctx* c, hpk_job* j, int b, std::string* err = nullptr) {
     for (int r = 0; r < n; ++r) box->gap[r] = hsmall[s.off_rowlive + r] ? 0 : 1;
     R.band_px = s.band_px;
     R.stencil_tiles = s.ntiles;
-    R.stencil_kernel = j->use_s ? (s.fused ? 3 : 2) : 1;
+    R.stencil_kernel = 2;
     R.batch_bands = (int32_t)j->bands.size();
 
     const unsigned long long* h_hist = reinterpret_cast<const unsigned long long*>(hsmall + HPK_OFF_HIST);
@@ -1217,7 +1192,6 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
                 s.d.rec_stride = (int64_t)s.ntiles_full * j->sa_full.tilecap;
                 s.ntiles = s.ntiles_full;
                 s.redone = true;
-                s.fused = false;
                 c->spec_reruns += 1;
                 HIPCHK(c, hipMemsetAsync(s.d.small, 0, s.zero_bytes, c->stream));
                 return launch_compute(c, j, b, 1, true, true, all_survivors);
@@ -1235,12 +1209,6 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
                 // more, with a record for every p <= sig
                 s.rescored = true;
                 c->surv_rescored += 1;
-                if (s.fused) {          // (scored inside the stencil: there are no candidate records to score again)
-                    int rc = full_redo(true);
-                    if (rc != HPK_OK) return rc;
-                    again = true;
-                    continue;
-                }
                 HpkBandDesc* hd = static_cast<HpkBandDesc*>(L.h_desc) + nb + b;
                 *hd = s.d;
                 hd->k0 = 0;             // (the band's own scoring grid: its survivor regions were sized for that many waves)
@@ -1257,12 +1225,6 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
             for (int rg = 0; rg < HPK_NREG; ++rg)
                 ns = std::max(ns, reinterpret_cast<const unsigned long long*>(hsmall + HPK_OFF_NSURV)[rg * HPK_REG_STRIDE]);
             if ((int64_t)ns <= s.cap) continue;
-            if (s.fused) {              // a survivor region of a fused band overflowed: through the two-kernel path, which has its own rerun
-                int rc = full_redo(s.rescored);
-                if (rc != HPK_OK) return rc;
-                again = true;
-                continue;
-            }
             if (s.overflowed) { s.status = fail(c, HPK_ERR_NOMEM, "survivor buffer overflow"); s.err = c->err; continue; }
             // a survivor region overflowed: the scoring once more with room for everything, on buffers of its own; one
             // band at a time (they share the lane's spare buffers), its survivors beyond the inline head are fetched at once

@@ -54,24 +54,11 @@ struct HpkSurv {
 #define HPK_OFF_EMAX    (HPK_OFF_NVALID + 8 * 2 * HPK_MAX_PAIRS)            // u64[16]
 #define HPK_OFF_NOUT    (HPK_OFF_EMAX + 8 * 2 * HPK_MAX_PAIRS)              // u64
 #define HPK_OFF_SPECFAIL (HPK_OFF_NOUT + 8)                                 // u32 (+ pad): a family's cut lies above the bound its survivors were written to
-#define HPK_OFF_CLSMAX  (HPK_OFF_SPECFAIL + 4)                              // i32: fused launches - widest width class that counts (frozen_w - wmin), see HPK_FUSE_NCL
 #define HPK_OFF_TBIN    (HPK_OFF_SPECFAIL + 8)                              // u8[HPK_NFAM]: histogram bin of every family's cut (hpk_thr_compact)
 #define HPK_OFF_FAM_M   (HPK_OFF_TBIN + (HPK_NFAM + 15) / 16 * 16)          // u32[HPK_NFAM]
 #define HPK_OFF_FAM_F   (HPK_OFF_FAM_M + 4 * HPK_NFAM)                      // u32[HPK_NFAM]
 #define HPK_SMALL_BYTES (HPK_OFF_FAM_F + 4 * HPK_NFAM)
 #define HPK_HEAD_INLINE 4096            // compacted survivors that travel to the host with the counters
-
-// Fused launches (hpk_stencil_s<., ., true>: the stencil scores its candidates itself): a candidate's statistics
-// count only if its first sufficient width is at most the width the widening freezes at - which the whole chromosome's
-// histogram decides after the launch.  The kernel therefore keeps every per-family counter once per width class
-// (class = first sufficient width - the plan's narrowest width, 0 .. HPK_FUSE_NCL - 1; the launch's record bound makes sure
-// there are no more) in a block of the band's counter area (HpkBandDesc::off_cls):
-//   u32 m[NCL][2][HPK_NB + 1] | u32 hist[NCL][2][HPK_NB + 1][8] | u64 emax[NCL][2]
-// and hpk_fuse_combine, which replays the freeze decision, adds up the classes that count into the ordinary counters.
-#define HPK_FUSE_NCL 4
-#define HPK_CLS_M_WORDS (HPK_FUSE_NCL * 2 * (HPK_NB + 1))
-#define HPK_CLS_H_WORDS (HPK_CLS_M_WORDS * 8)
-#define HPK_CLS_BYTES   (4 * HPK_CLS_M_WORDS + 4 * HPK_CLS_H_WORDS + 8 * HPK_FUSE_NCL * 2)
 
 // Pointers inside a band descriptor are declared in the global address space for device code: a pointer read out of
 // memory is otherwise a generic pointer to the compiler, which then issues flat_load / flat_store (counted on vmcnt
@@ -125,8 +112,7 @@ struct HpkBandDesc {
     uint32_t off_rowlive, off_inl;      // offsets of the row flags / inline survivors inside `small`
     int32_t derive;                     // 1: IR and biases are derived on the device from raw + weight, 2: IR only, 0: given
     int32_t score_wgs;                  // scoring workgroups that take part for this band (the rest of the grid row exits)
-    uint32_t off_cls;                   // offset of the width-class counters inside `small` (fused launches)
-    uint32_t pad_;
+    uint32_t pad_[2];
 };
 
 // Geometry and parameters common to all bands of a batch (kernel argument of the stencil).
@@ -145,15 +131,6 @@ struct HpkStencilArgs {
     int32_t generic;                    // the plan's Reads matrix is not monotone in the width: steps walked in plan order (general plans only)
     int32_t dbg_stop;                   // profiling ablation: 1 stop after the loads, 2 after the SAT, 4 no candidates, 5 search without box sums
     unsigned long long* clk;            // -DHPK_PHASE_CLOCK builds: [grid][waves][8] cycle sums per phase, or nullptr
-    // ---- fused launches only (fuse != 0): what the scoring needs (as HpkScoreArgs)
-    const double* bounds;               // [HPK_NB] chunk upper bounds
-    const double* ptab;                 // Poisson survival table
-    const int32_t* ptab_off;            // [HPK_NB_TAB + 2]
-    const double* sfe;
-    const uint8_t* kmin;                // [HPK_NFAM] or nullptr
-    double sig;
-    int32_t fuse;
-    int32_t pad_;
 };
 
 struct HpkScoreArgs {
@@ -195,9 +172,6 @@ void hpk_launch_stencil_batch(const HpkStencilArgs& a, const HpkBandDesc* d_band
 void hpk_launch_dense(const HpkDenseArgs& a, hipStream_t st);
 void hpk_launch_probe(const HpkDenseArgs& a, const int32_t* rows, const int32_t* cols, int64_t count, double* out, hipStream_t st);
 void hpk_launch_freeze_tot(const HpkDevPlan* plan, const HpkBandDesc* d_bands, int nbands, hipStream_t st);
-// fused launches: freeze decision + the width classes that count added up into the bands' ordinary counters
-void hpk_launch_fuse_combine(const HpkDevPlan* plan, const HpkBandDesc* d_bands, int nbands, hipStream_t st);
-bool hpk_stencil_fusable(const HpkDevPlan& plan, int wguess, int hbins);
 // IR / biases of the bands with `derive` set (scripts/pyHICCUPS:149-166); max_n / max_num: largest band of the batch
 void hpk_launch_prep(const HpkBandDesc* d_bands, int nbands, int max_n, int max_num, int mw, hipStream_t st);
 // expected tables + zero-fill of the counter blocks; max_zero: largest zero_bytes of the batch
@@ -210,8 +184,7 @@ void hpk_launch_score(const HpkScoreArgs& a, const HpkBandDesc* d_bands, int nba
 // then compaction of the records with p <= thr[f] (count in the band's HPK_OFF_NOUT).
 int  hpk_thr_hist_bins(int nsets);       // bins per family of the one-pass tightening (rounds < 0)
 int  hpk_score_hist_bins(int nsets, bool bhfdr);     // bins per family of the histogram hpk_score keeps (rounds <= -100): 8 | 4, bhfdr 64 fine ones
-void hpk_launch_tighten(const HpkBandDesc* d_bands, int nbands, double sig, int rounds, int nsets, const uint8_t* kmin, hipStream_t st,
-                        bool fused = false);
+void hpk_launch_tighten(const HpkBandDesc* d_bands, int nbands, double sig, int rounds, int nsets, const uint8_t* kmin, hipStream_t st);
 // result heads -> mapped pinned host memory: full = the whole head (no scoring ran), otherwise the stretches a chromosome fills
 void hpk_launch_publish(const HpkBandDesc* d_bands, int nbands, int nsets, bool full, size_t max_head_bytes, hipStream_t st);
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,

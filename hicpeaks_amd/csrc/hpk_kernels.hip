@@ -379,19 +379,9 @@ struct TileWalk {
     __device__ __forceinline__ unsigned bword() const { return (unsigned)band | ((unsigned)(nt >> 13) << 16); }
 };
 
-// FUSE (hiccups, one (pw, ww) pair, weight input, a record bound within HPK_FUSE_NCL widths of the plan's
-// narrowest): the kernel scores its candidates itself - corrected expected, lambda chunk, Poisson p, family counters and
-// survivor records as hpk_score forms them (callers.py:238-271) - instead of handing their sums to a second kernel through
-// 21-byte records.  Phase 3 then runs in two passes per wave: the search for the first sufficient width over the wave's
-// batches of the tile-wide candidate list, which packs the candidates that count (first sufficient width <= the bound) back
-// into the wave's own list slots, and box sums + scoring over the packed ones only.  The list holds 16-bit entries
-// (x | y << 7 | width class << 14; the count comes out of the packed plane), and the half of the list region this frees
-// holds the workgroup's family counters, one set per width class (hpk_kernels.h: HPK_FUSE_NCL).
-template <bool BALF64, bool SINGLE, bool FUSE>
+template <bool BALF64, bool SINGLE>
 __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const HpkBandDesc* __restrict__ bands) {
     constexpr int NW = 16;
-    constexpr int NCL = HPK_FUSE_NCL, NBT1 = HPK_NB_TAB + 1;
-    static_assert(!FUSE || (SINGLE && !BALF64), "the fused variant is built for single-pair plans on weight input");
     static_assert(LR == 4 * NW && LC == 160, "tile geometry: four table rows per wave, ten cells per lane");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double* __restrict__ Sc = reinterpret_cast<double*>(smem);
@@ -406,15 +396,6 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     double* __restrict__ wct = reinterpret_cast<double*>(stepof + HPK_KSLOTS * 32);      // [LC] column weights of the tile (NaN -> 0)
     double* __restrict__ ctot = wct + LC;                              // [3][LC] phase 2: totals of the f64 plane's row chunks
     unsigned* __restrict__ utot = reinterpret_cast<unsigned*>(ctot + 3 * LC);            // [LC] ... of the packed plane's first chunk
-    // FUSE: 16-bit list entries in the first half of the list region; in the second half the workgroup's scoring state
-    unsigned* __restrict__ fm = lst + HPK_TLIST / 2;                  // [NCL][2][NBT1] tests per family and width class
-    unsigned* __restrict__ fh = fm + NCL * 2 * NBT1;                  // [NCL][2][NBT1][8] p <= sig by log bin
-    unsigned long long* __restrict__ femax = reinterpret_cast<unsigned long long*>(fh + NCL * 2 * NBT1 * 8);   // [NCL][2]
-    double* __restrict__ lbnd = reinterpret_cast<double*>(femax + NCL * 2);      // [NBT1 + 5] chunk bounds 2^(i/3)
-    int* __restrict__ lpto = reinterpret_cast<int*>(lbnd + NBT1 + 5);            // [NBT1 + 2] offsets of the Poisson table
-    unsigned char* __restrict__ lkm = reinterpret_cast<unsigned char*>(lpto + NBT1 + 3);    // [2][NBT1] survivor bound (histogram bin) per family
-    static_assert((NCL * 2 * NBT1 * 9 * 4) % 8 == 0 && NCL * 2 * NBT1 * 9 * 4 + NCL * 2 * 8 + (NBT1 + 5) * 8 + (NBT1 + 3) * 4 + 2 * NBT1 <= HPK_TLIST * 2,
-                  "the fused kernel's counters must fit the freed half of the list region");
 
     const int lane_k = threadIdx.x & 63;
     const int wave_k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -437,14 +418,6 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             stepof[64 + lane_k] = plan->step_of[2 + (lane_k >> 5)][lane_k & 31];
             if (lane_k < 2) { tcount[lane_k] = 0u; tcount[4 + lane_k] = 0u; }     // list entries | records written, tiles alternate
         }
-        if constexpr (FUSE) {
-            const int t = (int)threadIdx.x;
-            for (int i = t; i < NCL * 2 * NBT1 * 9; i += 1024) fm[i] = 0u;          // fm and fh are contiguous
-            if (t < NCL * 2) femax[t] = 0ull;
-            if (t < NBT1 + 5) lbnd[t] = a.bounds[t];
-            if (t < NBT1 + 1) lpto[t] = a.ptab_off[t];
-            if (t < 2 * NBT1) lkm[t] = a.kmin ? a.kmin[(t / NBT1) * (HPK_NB + 1) + t % NBT1] : (unsigned char)0;
-        }
         for (int s = 0; s < nsteps; ++s) {
             const int k = (__builtin_amdgcn_readlane(pk0, s) >> 20) & 15;
             maxnkt = k > maxnkt ? k : maxnkt;
@@ -465,9 +438,6 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     const bool generic_p = !SINGLE && a.generic != 0;
     // a halo wider than the plan's maxww (maxww < 4: the tiles keep a halo of 4): widths beyond maxww have no step
     const int planw_p = __builtin_amdgcn_readfirstlane(plan->W);
-    const int planW_p = __builtin_amdgcn_readfirstlane(plan->W);       // FUSE: maxww (the local-expected tables' edge depth), not the tiles' halo
-    const int sig_e = (int)((unsigned long long)__double_as_longlong(a.sig) >> 52);                  // FUSE: sig > 0, normal
-    const unsigned long long sig_m = (unsigned long long)__double_as_longlong(a.sig) & 0xfffffffffffffull;
     // Resolve histogram of the band the workgroup is in: flushed into the band's totals when the walk enters the next
     // band (and after the last tile), see the top of the tile loop.
     unsigned myhist = 0u;                 // lane w: candidates whose first sufficient width is w
@@ -541,22 +511,6 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             } else if (tix == HPK_MAX_STEPS) out = red[NW * 64];
             if (out) atomicAdd(&gptr(hb->hist_acc)[tix * HPK_ACC_STRIDE], (unsigned long long)out);
         }
-        if constexpr (FUSE) {
-            // the workgroup's family counters of this band, per width class, into the band's class block (every wave has
-            // passed the barriers above: nobody is still scoring the band's last tile)
-            unsigned* gm = reinterpret_cast<unsigned*>(gptr(hb->small) + hb->off_cls);
-            unsigned* gh = gm + HPK_CLS_M_WORDS;
-            unsigned long long* ge = reinterpret_cast<unsigned long long*>(gh + HPK_CLS_H_WORDS);
-            for (int i = tix; i < NCL * 2 * NBT1; i += 1024) {
-                const unsigned v = fm[i];
-                if (v) { const int cs = i / NBT1, ch = i - cs * NBT1; atomicAdd(&gm[cs * (HPK_NB + 1) + ch], v); fm[i] = 0u; }
-            }
-            for (int i = tix; i < NCL * 2 * NBT1 * 8; i += 1024) {
-                const unsigned v = fh[i];
-                if (v) { const int f = i >> 3, cs = f / NBT1, ch = f - cs * NBT1; atomicAdd(&gh[(cs * (HPK_NB + 1) + ch) * 8 + (i & 7)], v); fh[i] = 0u; }
-            }
-            if (tix < NCL * 2) { const unsigned long long v = femax[tix]; if (v) { atomicMax(&ge[tix], v); femax[tix] = 0ull; } }
-        }
         __syncthreads();                // (the next tile's phase 1 parks its totals where `red` sits)
         myhist = 0u; mycand = 0u;
     };
@@ -574,12 +528,6 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     // decides (frozen_w, freeze_replay), wider candidates and unresolved ones are dropped by the scoring kernel anyway,
     // and the caller knows a bound from the chromosomes before (hpk_api.cpp; 255 = every candidate, as the dense outputs want).
     const int wg_p = bd->wguess;
-    // FUSE: the band's scoring inputs (hpk_score's): 1-D expected, biases, local-expected tables, survivor regions
-    const double* __restrict__ gIR = gptr(bd->IR);
-    const double* __restrict__ gb1 = gptr(bd->b1);
-    const double* __restrict__ gb2 = gptr(bd->b2);
-    const double* __restrict__ getab = gptr(bd->etab);
-    const double* __restrict__ geedge = gptr(bd->eedge);
     // the band's first tile: nothing is prefetched across a boundary; the flush of the band before runs beside the loads
     tile_load_s<BALF64>(a, bd, rb, cj, wave_k, lane_k, nxt);
     if (hband >= 0) flush_hist(bands + hband);
@@ -740,11 +688,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         for (int e = 0; e < 10; ++e) {
             const bool cd = ((cm >> (9 - e)) & 1u) != 0u;
             const unsigned at = at0 + (unsigned)__popc(cm >> (10 - e));        // (e = 0: cm has ten bits)
-            if constexpr (FUSE) {
-                if (cd) lds_st_u16(lds0 + (unsigned)(LR * LC * 12) + at * 2u, ebase - (unsigned)e);       // 16-bit entries: x | y << 8
-            } else {
-                if (cd) lds_st_u32(lds0 + (unsigned)(LR * LC * 12) + at * 4u, (ebase - (unsigned)e) | ((pk[e] & PK_MASK) << HPK_ENT_CNT_SHIFT));
-            }
+            if (cd) lds_st_u32(lds0 + (unsigned)(LR * LC * 12) + at * 4u, (ebase - (unsigned)e) | ((pk[e] & PK_MASK) << HPK_ENT_CNT_SHIFT));
         }
     }
     // ... and of the packed plane
@@ -838,7 +782,6 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     const int64_t tbase = (int64_t)tid * a.tilecap;
     unsigned* __restrict__ ent_t = gptr(bd->rec_ent) + tbase;
     HPK_CLK(ck4)
-    if constexpr (!FUSE) {
 #pragma unroll 1
     for (int b = wave; b * 64 < total; b += NW) {
 #ifdef HPK_PHASE_CLOCK
@@ -1092,253 +1035,13 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             }
         }
     }
-    } else {
-        // ================= FUSE: the search over this wave's batches packs the candidates that count into the wave's own
-        // list slots; box sums and scoring then run over the packed ones
-        const unsigned l16 = lds0 + (unsigned)(LR * LC * 12);
-        int wcur = 0;                                   // candidates that count, found by this wave in this tile
-#pragma unroll 1
-        for (int b = wave; b * 64 < total; b += NW) {
-#ifdef HPK_PHASE_CLOCK
-            ck7 += 1ull;
-#endif
-            const int i = b * 64 + lane;
-            const bool cand = i < total;
-            const unsigned id = lds_u16(l16 + (unsigned)(cand ? i : 0) * 2u);
-            const int x = (int)HPK_ENT_X(id);
-            const int y = (int)HPK_ENT_Y(id);
-            const int base = (y + W + 1) * LC + W + x;
-            const unsigned pb = lds0 + (unsigned)(LR * LC * 8) + (unsigned)base * 4u;
-            const unsigned sr = lds_u32(pb);
-            const unsigned b0 = (p0_p > 0) ? reads_box_b(pb, p0_p, sr) : 0u;
-            const unsigned bf = reads_box_b(pb, wmin_p, sr);
-            const unsigned bl = reads_box_b(pb, W, sr);
-            int wstar = 255;
-            wstar = (cand & (bl - b0 >= (unsigned)minr_p)) ? W : wstar;
-            wstar = (cand & (bf - b0 >= (unsigned)minr_p)) ? wmin_p : wstar;
-            if (W - wmin_p > 1 && ballot64(wstar == W) != 0ull) {
-#pragma unroll 1
-                for (int wa = wmin_p + 1; wa < W; wa += 4) {
-                    const unsigned dn = (unsigned)wa * (unsigned)(LC * 4), lf = (unsigned)wa * 4u;
-                    unsigned a1 = pb + dn, a2 = pb + (dn - lf), a3 = pb - (lf + 12u);
-                    asm volatile("" : "+v"(a1), "+v"(a2), "+v"(a3));
-                    unsigned rd[4];
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        rd[t] = (lds_u32(a2 + t * (LC * 4 - 4)) - lds_u32(a1 + t * (LC * 4)) - lds_u32(a3 + (3 - t) * 4) + sr) & PK_MASK;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        wstar = ((wa + t < W) & (wstar == W) & (rd[t] - b0 >= (unsigned)minr_p)) ? wa + t : wstar;
-                }
-            }
-            {   // resolve histogram by width (see the two-kernel path above)
-                const unsigned off = (unsigned)(wstar - wmin_p);
-                const unsigned long long inc = 1ull << ((off & 3u) * 16u);
-                hpack0 += off < 4u ? inc : 0ull;
-                hpack1 += (off - 4u) < 4u ? inc : 0ull;
-                if (W - wmin_p >= 8 && ballot64((off >= 8u) & (wstar != 255)) != 0ull) {
-#pragma unroll 1
-                    for (int w = wmin_p + 8; w <= W; ++w) {
-                        const unsigned c = (unsigned)__popcll(ballot64(wstar == w));
-                        if (lane == w) myhist += c;
-                    }
-                }
-            }
-            const bool live = cand & (wstar <= wg_p);
-            const unsigned long long lm = ballot64(live);
-            if (lm != 0ull) {
-                const unsigned pos = (unsigned)wcur + __builtin_amdgcn_mbcnt_hi((unsigned)(lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm, 0u));
-                const unsigned slot = (((pos >> 6) * (unsigned)NW + (unsigned)wave) << 6) | (pos & 63u);
-                if (live) lds_st_u16(l16 + slot * 2u, id | ((unsigned)(wstar - wmin_p) << 14));
-                wcur += (int)__popcll(lm);
-            }
-        }
-        // ---- box sums at the first sufficient width and scoring, 64 packed candidates at a time
-        if (a.dbg_stop == 9) wcur = 0;                   // profiling ablation: search and packing only
-        const int region = (int)(((unsigned)blockIdx.x * (unsigned)NW + (unsigned)wave) % (unsigned)HPK_NREG);
-#pragma unroll 1
-        for (int k0 = 0; k0 < wcur; k0 += 64) {
-            const bool act = k0 + lane < wcur;
-            const unsigned slot = ((((unsigned)k0 >> 6) * (unsigned)NW + (unsigned)wave) << 6) | (unsigned)lane;
-            const unsigned ent = lds_u16(l16 + (act ? slot : ((unsigned)wave << 6)) * 2u);
-            const int x = (int)HPK_ENT_X(ent), y = (int)HPK_ENT_Y(ent);
-            const int cls = act ? (int)(ent >> 14) : 0;     // width class = step of the single-pair plan
-            const int wst = wmin_p + cls;
-            const int base = (y + W + 1) * LC + W + x;
-            const unsigned cb = lds0 + (unsigned)base * 8u, pb = lds0 + (unsigned)(LR * LC * 8) + (unsigned)base * 4u;
-            const int r = r0 + y, c = c0 + x, d = c - r;
-            // the scoring's inputs travel while the box sums are formed: 1-D expected, biases, the step's local expected
-            // (interior table; the edge tables for windows clipped by one matrix end, hpk_score's rules)
-            const unsigned du = act ? (unsigned)d : 0u;
-            const double ir = gIR[du], b1r = gb1[act ? (unsigned)r : 0u], b2c = gb2[act ? (unsigned)c : 0u];
-            const bool top = act & (r < planW_p), right = act & (c >= n - planW_p);
-            const bool edge = top != right;
-            const double* __restrict__ tab = edge ? geedge : getab;
-            const unsigned tstride = 2u * (unsigned)(a.D + 1);
-            const unsigned tb = edge ? (unsigned)(((top ? 0 : 1) * planW_p + (top ? r : n - 1 - c)) * nsteps) * tstride : 0u;
-            const unsigned to = tb + (unsigned)cls * tstride + du;
-            double EK = tab[to], EY = tab[to + (unsigned)(a.D + 1)];
-            const double sc = lds_f64(cb);
-            double SK, SY, amax;
-            if (sp_p > 0) {                              // Box(w*) - Box(p): see box_ky_d
-                double kcw, ycw, kcp, ycp, bigp;
-                box_ky_d(cb, wst, sc, kcw, ycw, amax);
-                box_ky_d(cb, sp_p, sc, kcp, ycp, bigp);
-                SK = kcw - kcp; SY = ycw - ycp;
-            } else {
-                const double pixc = (sc - lds_f64(cb + 8)) - (lds_f64(cb - LC * 8) - lds_f64(cb - LC * 8 + 8));
-                amax = lds_f64(cb + (unsigned)(W * (LC - 1) * 8));
-                box_ky_b(cb, wst, pixc, sc, SK, SY);
-            }
-            SK = act ? SK : 0.0; SY = act ? SY : 0.0;
-            SY = (d - (sp_p + 1) - 1 < mw) ? 0.0 : SY;  // lower-left support off the band: exact 0
-            {
-                // sums that are small against the window's largest table entry: exact zero test, then the explicit window
-                // (see the two-kernel path above)
-                const double thr = amax * a.risk;
-                const bool risky = act & ((SK < thr) | ((SY < thr) & (SY != 0.0)));
-                if (ballot64(risky) != 0ull) {
-                    if (risky) {
-                        const unsigned sr = lds_u32(pb);
-                        const unsigned pv = sr - Sp[base + 1] - Sp[base - LC] + Sp[base - LC + 1];
-                        const unsigned long long vw = box_ky_valid_m(Sp, base, wst, pv, sr);
-                        const unsigned long long vp = sp_p > 0 ? box_ky_valid_m(Sp, base, sp_p, pv, sr) : 0ull;
-                        const unsigned VK = (unsigned)vw - (unsigned)vp, VY = (unsigned)(vw >> 32) - (unsigned)(vp >> 32);
-                        if (VK == 0u) { SK = 0.0; SY = 0.0; }
-                        else if (VY == 0u) SY = 0.0;
-                    }
-                    unsigned long long todo = ballot64(risky && SK != 0.0 && ((SK < thr) | ((SY < thr) & (SY != 0.0))));
-                    while (todo != 0ull) {
-                        const int src = __ffsll((long long)todo) - 1;
-                        todo &= todo - 1ull;
-                        const int er = __builtin_amdgcn_readlane(r, src), ec = __builtin_amdgcn_readlane(c, src);
-                        const int es = __builtin_amdgcn_readlane(cls, src);
-                        const double2 ex = explicit_sums_wave(gptr(bd->raw), gptr(bd->bal), gptr(bd->weight), plan->steps[es].m, W, er, ec, n, bd->num, bd->ld, mw, lane);
-                        if (lane == src) { SK = ex.x; SY = (SY == 0.0) ? 0.0 : ex.y; }
-                    }
-                }
-            }
-            if (a.dbg_stop == 8) {                       // profiling ablation: box sums over the packed candidates, no scoring
-                if (SK == -1.0 && SY == -7.0 && EK == 1234.5 && ir == 3.25 && b1r == b2c) femax[0] = 1ull;
-                continue;
-            }
-            // ---- scoring (hpk_score's rules, callers.py:238-271).  The pixel's count: its cell of the packed plane, re-read from
-            // the band where it sits at the cap
-            const unsigned cntc = (lds_u32(pb) - lds_u32(pb + 4u) - lds_u32(pb - (unsigned)(LC * 4)) + lds_u32(pb - (unsigned)(LC * 4) + 4u)) & PK_MASK;
-            float rawpix = (float)cntc;
-            if (ballot64(act & (cntc >= pkcap_p)) != 0ull) {
-                if (act & (cntc >= pkcap_p)) rawpix = gptr(bd->raw)[(int64_t)r * bd->ld + d];
-            }
-            const double O = (double)rawpix;
-            const int kO = (int)O;
-            if (ballot64(top & right) != 0ull) {       // both matrix ends in one window (chromosomes shorter than the band)
-                if (top & right) {
-                    const double2 ee = edge_expected(plan->steps[cls].m, plan->steps[cls].wi, gIR, r, c, n, bd->num, mw);
-                    EK = ee.x; EY = ee.y;
-                }
-            }
-            EK = act ? EK : 0.0;
-            EY = act ? EY : 0.0;
-            // callers.py:244-249: E = ((IR[d] * (bS / bE)) * B1[x]) * B2[y] where bE != 0
-            const double eK = (EK != 0.0) ? ((ir * (SK / EK)) * b1r) * b2c : 0.0;
-            const double eY = (EY != 0.0) ? ((ir * (SY / EY)) * b1r) * b2c : 0.0;
-#pragma unroll
-            for (int fl = 0; fl < 2; ++fl) {
-                const double E = fl ? eY : eK;
-                const bool valid = E > 0.0;                                         // callers.py:250
-                const unsigned long long eb = (unsigned long long)__double_as_longlong(E);
-                const int ex = (int)(eb >> 52) - 1023;                              // (E > 0: no sign bit)
-                const bool ge1 = valid & (ex >= 0);
-                const bool far = ge1 & (ex >= 15);                                  // lambda beyond the Poisson table: rare
-                // chunk of E: boundaries 2^(i/3), membership strict on both sides (callers.py:38) - E on a boundary belongs to
-                // no chunk; E < 1 is chunk 1
-                const int i0b = (ge1 & !far) ? 3 * ex : 0;
-                const double bq = lbnd[i0b], bA = lbnd[i0b + 1], bB = lbnd[i0b + 2];
-                const int lo = ge1 ? 3 * ex + 1 + (E >= bA ? 1 : 0) + (E >= bB ? 1 : 0) : 0;
-                const bool onb = ge1 & ((E == bq) | (E == bA) | (E == bB));
-                int chunk = (valid & !onb & !far) ? lo + 1 : 0;
-                const int ct = chunk > 1 ? chunk : 1;
-                const int pbase = lpto[ct], plen = lpto[ct + 1] - pbase;
-                double p = a.ptab[(unsigned)(pbase + (kO < plen ? kO : 0))];        // p = 1 - cdf(floor(O); chunk's upper bound), callers.py:268-270
-                p = kO < plen ? p : 0.0;
-                p = chunk != 0 ? p : 1.0;
-                bool gl = false;                        // this lane's counters live in global memory (chunks beyond the table)
-                int kmin_l = (int)lkm[fl * NBT1 + chunk];
-                if (ballot64(far) != 0ull) {
-                    if (far) {
-                        const int e3 = 3 * ex;
-                        const bool big = e3 + 2 >= HPK_NB;
-                        const int j0 = big ? 0 : e3;
-                        const double q0 = a.bounds[j0], qA = a.bounds[j0 + 1], qB = a.bounds[j0 + 2];
-                        const int lo2 = big ? HPK_NB : e3 + 1 + (E >= qA ? 1 : 0) + (E >= qB ? 1 : 0);
-                        const bool inch = lo2 < HPK_NB && !(!big && (E == q0 || E == qA || E == qB));
-                        chunk = inch ? lo2 + 1 : 0;
-                        p = inch ? poisson_sf(O, a.bounds[chunk - 1], a.sfe, a.sig) : 1.0;
-                        kmin_l = a.kmin ? (int)a.kmin[fl * (HPK_NB + 1) + chunk] : 0;
-                        gl = true;
-                    }
-                }
-                const int fam = cls * 2 + fl;
-                if (ballot64(valid) != 0ull) {
-                    // Emax of the set (E > 0: the bit pattern orders like the value); tests per family - family 0 collects the
-                    // valid pixels without a chunk
-                    const unsigned long long ebits = valid ? eb : 0ull;
-                    const bool beats = ebits > femax[fam];
-                    if (ballot64(beats) != 0ull) { if (beats) atomicMax(&femax[fam], ebits); }
-                    if (valid) {
-                        if (!gl) atomicAdd(&fm[fam * NBT1 + chunk], 1u);
-                        else atomicAdd(&reinterpret_cast<unsigned*>(gptr(bd->small) + bd->off_cls)[fam * (HPK_NB + 1) + chunk], 1u);
-                    }
-                }
-                // only p <= sig can reach q <= sig; a pixel without a chunk keeps p = 1 (callers.py:259-260)
-                const double psel = (valid & (chunk != 0)) ? p : 2.0;
-                const bool surv = psel <= a.sig;
-                if (ballot64(surv) != 0ull) {
-                    bool wr = false;
-                    if (surv) {
-                        // floor(log2(sig / p)) from the two exponents and a mantissa compare, bins a factor 4 wide (hpk_score)
-                        const unsigned long long pbits = (unsigned long long)__double_as_longlong(p);
-                        int k = sig_e - (int)(pbits >> 52) - ((pbits & 0xfffffffffffffull) > sig_m ? 1 : 0);
-                        k >>= HPK_HSHIFT;
-                        k = (pbits >> 52) == 0ull ? 7 : k;
-                        k = k < 0 ? 0 : (k > 7 ? 7 : k);
-                        if (!gl) atomicAdd(&fh[(fam * NBT1 + chunk) * 8 + k], 1u);
-                        else atomicAdd(&(reinterpret_cast<unsigned*>(gptr(bd->small) + bd->off_cls) + HPK_CLS_M_WORDS)[(fam * (HPK_NB + 1) + chunk) * 8 + k], 1u);
-                        wr = k >= kmin_l;
-                    }
-                    const unsigned long long wm = ballot64(wr);
-                    if (wm != 0ull) {
-                        // survivor records: exactly as many slots as the batch needs from the wave's region (dense regions)
-                        unsigned char* const small = gptr(bd->small);
-                        const int64_t b_cap = bd->cap;
-                        unsigned long long nb = 0ull;
-                        if (lane == 0) nb = atomicAdd(&reinterpret_cast<unsigned long long*>(small + HPK_OFF_NSURV)[region * HPK_REG_STRIDE], (unsigned long long)__popcll(wm));
-                        const unsigned long long basei = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)nb) |
-                                                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(nb >> 32)) << 32;
-                        if (wr) {
-                            const unsigned long long idx = basei + (unsigned long long)__builtin_amdgcn_mbcnt_hi((unsigned)(wm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)wm, 0u));
-                            if ((int64_t)idx < b_cap) {
-                                HpkSurv rec;
-                                rec.x = r; rec.y = c; rec.O = rawpix; rec.set = (uint8_t)fl; rec.chunk = (uint8_t)chunk;
-                                rec.flag = (fl == 0 && eY == 0.0) ? 1 : 0;           // callers.py:330
-                                rec.pad = (uint8_t)cls; rec.E = E; rec.p = p; rec.bal = 0.0;   // balanced value: filled by hpk_thr_compact
-                                gptr(bd->surv)[(int64_t)region * b_cap + (int64_t)idx] = rec;
-                            }
-                        }
-                    }
-                }
-            }
-        }
-    }
     HPK_CLK(ck5)
     // (written by wave 0 at the top of this round, three barriers ago: in flight across the barrier below)
     tnext = lds_u32(lds0 + (unsigned)((unsigned char*)tseq - smem) + (unsigned)tpar * 4u);
     bnext = lds_u32(lds0 + (unsigned)((unsigned char*)tband - smem) + (unsigned)tpar * 4u);
     __syncthreads();                 // every wave is done with this tile's SAT and list
     HPK_CLK(ck6)
-    if (FUSE) {
-        if (wave == 0 && lane == 0) mycand += (unsigned)total;         // no records, no work list
-    } else if (wave == 0) {
+    if (wave == 0) {
         // scoring work list: one entry per HPK_UNIT records.  The slot reservation (a returning atomic on one global
         // counter) of this tile is only consumed when the next tile ends.
         if (pend_tid >= 0) {
@@ -1598,57 +1301,6 @@ __global__ void __launch_bounds__(128) hpk_freeze_tot(const HpkDevPlan* __restri
     freeze_replay(plan, hist, swi, sslot, reinterpret_cast<int32_t*>(small + HPK_OFF_EXEC), fw, e);
     *reinterpret_cast<int32_t*>(small + HPK_OFF_FROZEN) = fw;
     *reinterpret_cast<int32_t*>(small + HPK_OFF_ERR) = e;
-}
-
-// Fused launches (hpk_stencil_s<., ., true>): the freeze decision as above, then the family counters of the width classes that
-// count - first sufficient width <= frozen_w - added up into the band's ordinary counters (tests per family, p <= sig per
-// family, the p-value histogram the cut is derived from, Emax per set), where hpk_thr_compact, hpk_publish and the host find
-// them as if hpk_score had written them.  One workgroup per band.
-__global__ void __launch_bounds__(256) hpk_fuse_combine(const HpkDevPlan* __restrict__ plan, const HpkBandDesc* __restrict__ bands) {
-    const HpkBandDesc* __restrict__ bd = bands + blockIdx.x;
-    __shared__ unsigned long long hist[HPK_MAX_STEPS + 1];
-    __shared__ int swi[HPK_MAX_STEPS], sslot[HPK_MAX_STEPS];
-    __shared__ int lcm;
-    unsigned char* small = gptr(bd->small);
-    if ((int)threadIdx.x < plan->nsteps) { swi[threadIdx.x] = plan->steps[threadIdx.x].wi; sslot[threadIdx.x] = plan->steps[threadIdx.x].slot; }
-    if (threadIdx.x <= HPK_MAX_STEPS) {
-        hist[threadIdx.x] = gptr(bd->hist_acc)[threadIdx.x * HPK_ACC_STRIDE];
-        reinterpret_cast<unsigned long long*>(small + HPK_OFF_HIST)[threadIdx.x] = hist[threadIdx.x];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int fw, e;
-        freeze_replay(plan, hist, swi, sslot, reinterpret_cast<int32_t*>(small + HPK_OFF_EXEC), fw, e);
-        *reinterpret_cast<int32_t*>(small + HPK_OFF_FROZEN) = fw;
-        *reinterpret_cast<int32_t*>(small + HPK_OFF_ERR) = e;
-        int cm = fw - plan->wmin;
-        cm = cm < 0 ? 0 : (cm > HPK_FUSE_NCL - 1 ? HPK_FUSE_NCL - 1 : cm);
-        *reinterpret_cast<int32_t*>(small + HPK_OFF_CLSMAX) = cm;
-        lcm = cm;
-    }
-    __syncthreads();
-    const int cm = lcm;
-    const unsigned* __restrict__ gm = reinterpret_cast<const unsigned*>(small + bd->off_cls);
-    const unsigned* __restrict__ gh = gm + HPK_CLS_M_WORDS;
-    const unsigned long long* __restrict__ ge = reinterpret_cast<const unsigned long long*>(gh + HPK_CLS_H_WORDS);
-    unsigned* __restrict__ fam_m = reinterpret_cast<unsigned*>(small + HPK_OFF_FAM_M);
-    unsigned* __restrict__ fam_f = reinterpret_cast<unsigned*>(small + HPK_OFF_FAM_F);
-    unsigned* __restrict__ cnt = gptr(bd->cnt);
-    for (int i = threadIdx.x; i < 2 * (HPK_NB + 1); i += blockDim.x) {           // family = (set, chunk)
-        unsigned m = 0u, f = 0u, h[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
-        for (int c = 0; c <= cm; ++c) {
-            m += gm[c * 2 * (HPK_NB + 1) + i];
-            for (int k = 0; k < 8; ++k) h[k] += gh[(c * 2 * (HPK_NB + 1) + i) * 8 + k];
-        }
-        for (int k = 0; k < 8; ++k) { cnt[i * 8 + k] = h[k]; f += h[k]; }
-        fam_m[i] = m;
-        fam_f[i] = f;
-    }
-    if (threadIdx.x < 2) {
-        unsigned long long e = 0ull;
-        for (int c = 0; c <= cm; ++c) e = ge[c * 2 + threadIdx.x] > e ? ge[c * 2 + threadIdx.x] : e;
-        reinterpret_cast<unsigned long long*>(small + HPK_OFF_EMAX)[threadIdx.x] = e;
-    }
 }
 
 // ------------------------------------------------------------------ gap rows
@@ -2297,12 +1949,9 @@ __global__ void __launch_bounds__(256) hpk_thr_count(const HpkBandDesc* __restri
 }
 // The first `inl` survivors of the cut go to out_head (which travels to the host together with the counters), the rest
 // to out_rest.
-// fused: the band's survivors were written by hpk_stencil_s<., ., true> - the regions are filled densely (no chunk fill counts)
-// and a record counts only if its width class (HpkSurv::pad) is at most the band's HPK_OFF_CLSMAX.
 __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkBandDesc* __restrict__ bands, int rounds, double sig, int nfam,
-                                                       const uint8_t* __restrict__ kmin, int fused) {
+                                                       const uint8_t* __restrict__ kmin) {
     HPK_THR_BAND_ARGS
-    const unsigned clsmax = fused ? (unsigned)*reinterpret_cast<const int32_t*>(small + HPK_OFF_CLSMAX) : 255u;
     const unsigned int* __restrict__ cnt = gptr(bd->cnt);
     HpkSurv* __restrict__ out_head = reinterpret_cast<HpkSurv*>(small + bd->off_inl);
     const unsigned long long inl = HPK_HEAD_INLINE;
@@ -2350,9 +1999,9 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkBandDesc* __rest
         uint2 q0 = make_uint2(0u, 0u), q1 = q0, q2 = q0, q3 = q0;
         double b = 0.0;
         if (i < n) {
-            if (fused || (unsigned)(i & (HPK_SCH - 1)) < chunk_used[(rb + i) >> HPK_SCH_LOG2]) {
+            if ((unsigned)(i & (HPK_SCH - 1)) < chunk_used[(rb + i) >> HPK_SCH_LOG2]) {
                 const HpkSurv& src = surv[rb + i];
-                keep = src.p <= lthr[(int)src.set * (HPK_NB + 1) + (int)src.chunk] && (unsigned)src.pad <= clsmax;
+                keep = src.p <= lthr[(int)src.set * (HPK_NB + 1) + (int)src.chunk];
                 if (keep) {                               // the other 30 bytes only for the few that stay
                     const uint2* s2 = reinterpret_cast<const uint2*>(&src);
                     q0 = s2[0]; q1 = s2[1]; q2 = s2[2]; q3 = s2[3];       // x, y | O, set chunk flag pad | E | p
@@ -2383,9 +2032,9 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkBandDesc* __rest
 // ------------------------------------------------------------------ launchers
 int hpk_stencil_s_lds_bytes() { return LR * LC * 12 + HPK_TLIST * 4 + 128 + HPK_MAX_STEPS * 32 + HPK_KSLOTS * 32 + LC * 8 * 4 + LC * 4; }
 
-template <bool BALF64, bool SINGLE, bool FUSE = false>
+template <bool BALF64, bool SINGLE>
 static void launch_stencil_s_t(const HpkStencilArgs& a, const HpkBandDesc* d_bands, hipStream_t st) {
-    auto kern = hpk_stencil_s<BALF64, SINGLE, FUSE>;
+    auto kern = hpk_stencil_s<BALF64, SINGLE>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2401,26 +2050,14 @@ bool hpk_stencil_s_applies(const HpkStencilArgs& a, int64_t max_ld, int32_t max_
     return max_ld <= (int64_t)(1 << 21) && max_n < (1 << 27) && a.W >= 4 && a.TR * a.TC <= HPK_TLIST;
 }
 
-// what a launch must be for the fused variant: hiccups, one (pw, ww) pair, a record bound within HPK_FUSE_NCL widths of the
-// plan's narrowest step, the eight factor-4 bins of hpk_score's histogram (the caller adds: weight input, hpk_stencil_s)
-bool hpk_stencil_fusable(const HpkDevPlan& plan, int wguess, int hbins) {
-    return plan.mode == HPK_MODE_HICCUPS && plan.single_p >= 0 && plan.npairs == 1 && hbins == 8 && wguess >= plan.wmin &&
-           wguess - plan.wmin < HPK_FUSE_NCL && wguess <= plan.W && plan.nsteps == plan.W - plan.wmin + 1;
-}
-
 void hpk_launch_stencil_batch(const HpkStencilArgs& a, const HpkBandDesc* d_bands, bool balf64, hipStream_t st) {
     const bool single = a.single != 0;
-    if (a.fuse) { launch_stencil_s_t<false, true, true>(a, d_bands, st); return; }
     if (balf64) { if (single) launch_stencil_s_t<true, true>(a, d_bands, st); else launch_stencil_s_t<true, false>(a, d_bands, st); }
     else        { if (single) launch_stencil_s_t<false, true>(a, d_bands, st); else launch_stencil_s_t<false, false>(a, d_bands, st); }
 }
 
 void hpk_launch_freeze_tot(const HpkDevPlan* plan, const HpkBandDesc* d_bands, int nbands, hipStream_t st) {
     hipLaunchKernelGGL(hpk_freeze_tot, dim3(nbands), dim3(128), 0, st, plan, d_bands);
-}
-
-void hpk_launch_fuse_combine(const HpkDevPlan* plan, const HpkBandDesc* d_bands, int nbands, hipStream_t st) {
-    hipLaunchKernelGGL(hpk_fuse_combine, dim3(nbands), dim3(256), 0, st, plan, d_bands);
 }
 
 void hpk_launch_gap(const float* raw, const double* bal, const double* weight, int32_t n, int32_t num, int64_t ld,
@@ -2464,13 +2101,12 @@ void hpk_launch_score(const HpkScoreArgs& a, const HpkBandDesc* d_bands, int nba
 
 int hpk_thr_hist_bins(int nsets) { return nsets * (HPK_NB + 1) <= 1032 ? 16 : 8; }   // LDS of hpk_thr_hist <= 83 KB
 
-void hpk_launch_tighten(const HpkBandDesc* d_bands, int nbands, double sig, int rounds, int nsets, const uint8_t* kmin, hipStream_t st,
-                        bool fused) {
+void hpk_launch_tighten(const HpkBandDesc* d_bands, int nbands, double sig, int rounds, int nsets, const uint8_t* kmin, hipStream_t st) {
     if (rounds > HPK_TIGHTEN_MAX) rounds = HPK_TIGHTEN_MAX;
     const int nfam = nsets * (HPK_NB + 1);          // families in use: (set, chunk)
     const dim3 grid(8, HPK_NREG, nbands);
     if (rounds <= -100) {       // the histogram came with the scoring kernel: only the compaction is left
-        hipLaunchKernelGGL(hpk_thr_compact, grid, dim3(256), 0, st, d_bands, rounds, sig, nfam, kmin, fused ? 1 : 0);
+        hipLaunchKernelGGL(hpk_thr_compact, grid, dim3(256), 0, st, d_bands, rounds, sig, nfam, kmin);
         return;
     }
     const uint8_t* none = nullptr;
@@ -2483,12 +2119,12 @@ void hpk_launch_tighten(const HpkBandDesc* d_bands, int nbands, double sig, int 
             attr_done = true;
         }
         hipLaunchKernelGGL(hpk_thr_hist, grid, dim3(256), lds, st, d_bands, nbins, sig, nfam);
-        hipLaunchKernelGGL(hpk_thr_compact, grid, dim3(256), 0, st, d_bands, -nbins, sig, nfam, none, 0);
+        hipLaunchKernelGGL(hpk_thr_compact, grid, dim3(256), 0, st, d_bands, -nbins, sig, nfam, none);
         return;
     }
     for (int r = 0; r < rounds; ++r)
         hipLaunchKernelGGL(hpk_thr_count, grid, dim3(256), 0, st, d_bands, r, sig, nfam);
-    hipLaunchKernelGGL(hpk_thr_compact, grid, dim3(256), 0, st, d_bands, rounds, sig, nfam, none, 0);
+    hipLaunchKernelGGL(hpk_thr_compact, grid, dim3(256), 0, st, d_bands, rounds, sig, nfam, none);
 }
 
 void hpk_launch_prep(const HpkBandDesc* d_bands, int nbands, int max_n, int max_num, int mw, hipStream_t st) {

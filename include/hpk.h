@@ -160,9 +160,8 @@ typedef struct {
 
     /* timing, milliseconds (HIP events on the ctx stream; wall for host parts) */
     float ms_h2d, ms_stencil, ms_freeze, ms_score, ms_tighten, ms_gap, ms_d2h, ms_host_bh, ms_total;
-    int32_t stencil_kernel;    /* stencil kernel that ran: 1 = first generation, any plan; 2 = second generation, simple-Reads plans;
-                                  3 = second generation scoring its candidates itself (hpk_set_option "fuse" = 1: no candidate
-                                  records, no scoring kernel; single-pair hiccups launches under a record bound) */
+    int32_t stencil_kernel;    /* stencil kernel that ran: always 2 = hpk_stencil_s (the one generation there is; the field is kept
+                                  for ABI v2 callers) */
     int32_t record_bound;      /* the stencil wrote records for candidates resolved up to this width (255: all of them;
                                   HPK_FLAG_DENSE_*, HPK_FLAG_NO_SCORE); see hpk_submit_band */
     int32_t redone;            /* bit 0: the widening froze beyond the bound taken from the previous chromosome and the
@@ -237,8 +236,7 @@ int  hpk_collect_batch(hpk_ctx* ctx, hpk_job* job, hpk_result** outs, int32_t* s
  * batch's bound, hpk_result::record_bound is the chromosome's own; 0: one bound per batch), "class_force" (tests), "spec_surv" (0: a survivor record for every p <= sig; 1 [default]: only up to the histogram bin the families' cuts fell
  * into in the chromosomes before, minus "spec_surv_margin" bins - verified, hpk_result::redone bit 1), "spec_surv_force" (tests),
  * "host_threads" (threads of a batch's host half), "spec_halo" (0: tiles always under maxww's halo - runs of one chromosome are then bit-identical whatever the bound), "risk_log2" (exact-fallback threshold 2^-x), "tile_order", "gap_kernel" (1: gap rows by the row kernel),
- * "score_div" (tiles per scoring workgroup of a batch), "dbg_stop" (profiling ablation), "fuse" (1: bounded single-pair hiccups
- * launches score inside the stencil kernel - identical results, measured no faster; default 0), "reset_hints" (forget the bounds
+ * "score_div" (tiles per scoring workgroup of a batch), "dbg_stop" (profiling ablation), "reset_hints" (forget the bounds
  * learnt from the chromosomes collected so far).  Returns HPK_ERR_INVALID for an
  * unknown name or a value out of range. */
 int  hpk_set_option(hpk_ctx* ctx, const char* name, int64_t value);
