@@ -453,6 +453,8 @@ def main():
             fw_by_depth.setdefault(dp, set()).add(int(r.frozen_w))
         nredone[0] += sum(int(r.redone) for r in rs)
         nrescored[0] += sum(int(r.rescored) for r in rs)
+        for k_ in ('tiles', 'lean_tiles', 'lean_redone', 'lean_explicit'):
+            lean_ct[k_] += sum(int(getattr(r, k_)) for r in rs)
         st = sum(r.timing['stencil'] for r in rs)        # the group's launch: its chromosomes' shares add up to it
         if st > 0:
             stencil_ms.append(st)
@@ -469,6 +471,7 @@ def main():
 
     stencil_ms = []
     nredone, nrescored = [0], [0]
+    lean_ct = collections.Counter()
     R = None
     run(depth)              # set-up, not a step: every lane allocates its workspaces (GBs on the large configurations) once
     for R in run(max(args.warmup, 1) * batch // group if args.warmup > 0 else 0):
@@ -483,11 +486,13 @@ def main():
     del stencil_ms[:]
     fw_by_depth.clear()
     nredone[0] = nrescored[0] = 0
+    lean_ct.clear()
     t0 = time.perf_counter()
     results = run(args.steps * batch // group)
     barrier()
     elapsed = time.perf_counter() - t0
     nredone_timed, nrescored_timed = nredone[0], nrescored[0]
+    lean_timed = dict(lean_ct)
     fw_timed = {str(k): sorted(v) for k, v in sorted(fw_by_depth.items())}
     assert len(stencil_ms) >= args.steps * batch // group // TIMED_EVERY
     stencil_ms = list(stencil_ms)
@@ -568,6 +573,10 @@ def main():
                        # stencil leaves their records out, bounded by the previous pass's frozen width (HPK_SPEC=0: no bound)
                        'record_bound_w': R.record_bound, 'frozen_w': R.frozen_w, 'passes_redone_in_full': nredone_timed,
                        'passes_rescored': nrescored_timed,
+                       # tiles of the timed region built without their f64 plane (hpk_stencil_s, lean tiles), of those computed once
+                       # more in full, candidates of lean tiles whose sums were formed cell by cell
+                       'tiles': lean_timed.get('tiles', 0), 'lean_tiles': lean_timed.get('lean_tiles', 0),
+                       'lean_redone': lean_timed.get('lean_redone', 0), 'lean_explicit': lean_timed.get('lean_explicit', 0),
                        'parallelism': 'one chromosome per GPU, no collective', 'pipeline_depth': depth,
                        'sync_call_ms': float(np.median(lat)) if lat else None,
                        'stencil_only': bool(args.stencil_only), 'host_inputs': bool(args.host_inputs), 'balanced_f64': bool(args.balanced_f64)},

@@ -86,7 +86,8 @@ class Result(C.Structure):
                 ('ms_h2d', C.c_float), ('ms_stencil', C.c_float), ('ms_freeze', C.c_float), ('ms_score', C.c_float),
                 ('ms_tighten', C.c_float), ('ms_gap', C.c_float), ('ms_d2h', C.c_float), ('ms_host_bh', C.c_float), ('ms_total', C.c_float),
                 ('stencil_kernel', C.c_int32), ('record_bound', C.c_int32), ('redone', C.c_int32), ('nsurv_sig', C.c_int64), ('nsurv_cut', C.c_int64),
-                ('stencil_tiles', C.c_int64), ('band_px', C.c_int64), ('batch_bands', C.c_int32), ('halo_w', C.c_int32)]
+                ('stencil_tiles', C.c_int64), ('band_px', C.c_int64), ('batch_bands', C.c_int32), ('halo_w', C.c_int32),
+                ('lean_tiles', C.c_int32), ('lean_redone', C.c_int32), ('lean_explicit', C.c_int64)]
 
 
 def build(force=False, quiet=True):
@@ -239,6 +240,9 @@ class BandResult(object):
         self.rescored = bool(r.redone & 2)           # the survivor bound was too narrow: scoring and cut ran twice
         self.redone = bool(r.redone & 1)                 # the bound from the previous chromosome was too narrow: computed twice
         self.halo_w = int(r.halo_w)                  # halo of the stencil tiles: maxww, or the record bound (spec_halo)
+        self.lean_tiles = int(r.lean_tiles)          # tiles built without their f64 plane | of those computed once more | candidates summed cell by cell
+        self.lean_redone = int(r.lean_redone)
+        self.lean_explicit = int(r.lean_explicit)
         self.batch_bands = int(r.batch_bands)        # chromosomes that shared this one's launches (kernel times are its share)
         self.nsig = int(r.nsig)                      # pixels reported over all sets
         self.nsurv_sig, self.nsurv_cut = int(r.nsurv_sig), int(r.nsurv_cut)

@@ -117,6 +117,9 @@ struct Options {
     int spec_surv_margin = 2;
     int spec_surv_force = -1;   // tests: this bin for every family (too narrow a bound: scored once more)
     int host_threads = 8;       // threads of a batch's host half (hpk_collect_batch), at most one per four chromosomes
+    int lean = 1;               // tiles of the column chunks hpk_band_class expects no resolving candidate in are built without their f64 plane
+    int lean_max = 24;          // ... candidates of such a tile that do count and get their sums cell by cell; more: the tile is computed once more
+    int lean_frac_pct = 50;     // ... a chunk is lean when the mean Reads of its nearest pixels is at most this share of min_local_reads
 };
 
 struct hpk_ctx {
@@ -323,6 +326,9 @@ int hpk_create(int device, hpk_ctx** out) {
     o.score_div = std::max(1, env_int("HPK_SCORE_DIV", o.score_div));
     o.dbg_stop = env_int("HPK_DBG_STOP", o.dbg_stop);
     o.host_prof = env_int("HPK_HOST_PROF", o.host_prof);
+    o.lean = env_int("HPK_LEAN", o.lean) ? 1 : 0;
+    o.lean_max = std::max(0, std::min(4096, env_int("HPK_LEAN_MAX", o.lean_max)));
+    o.lean_frac_pct = std::max(0, std::min(400, env_int("HPK_LEAN_FRAC", o.lean_frac_pct)));
     *out = c;
     return HPK_OK;
 }
@@ -347,6 +353,9 @@ int hpk_set_option(hpk_ctx* c, const char* name, int64_t v) {
     else if (k == "score_div" && v >= 1 && v <= 4096) o.score_div = (int)v;
     else if (k == "dbg_stop" && v >= 0 && v <= 16) o.dbg_stop = (int)v;
     else if (k == "spec_class" && (v == 0 || v == 1)) o.spec_class = (int)v;
+    else if (k == "lean" && (v == 0 || v == 1)) o.lean = (int)v;
+    else if (k == "lean_max" && v >= 0 && v <= 4096) o.lean_max = (int)v;
+    else if (k == "lean_frac_pct" && v >= 0 && v <= 100000) o.lean_frac_pct = (int)v;       // (tests: a large share makes every chunk lean)
     else if (k == "class_force" && v >= -1 && v <= 127) { std::memset(c->class_w, (int)v, sizeof(c->class_w)); std::memset(c->class_w1, (int)v, sizeof(c->class_w1)); }     // tests: every depth class claims this width
     else if (k == "reset_hints") { c->hint_n = 0; c->hint_bn = 0; { std::memset(c->class_w, -1, sizeof(c->class_w)); std::memset(c->class_w1, -1, sizeof(c->class_w1)); } }     // forget the bounds learnt from the chromosomes collected so far
     else return fail(c, HPK_ERR_INVALID, "unknown option or value out of range: %s = %lld", name, (long long)v);
@@ -494,11 +503,13 @@ struct hpk_job {
     int lane = -1;
     hpk_params prm, key;
     std::vector<BandSlot> bands;
-    HpkStencilArgs sa, sa_full;         // tile geometry of the batch's launches | of a chromosome computed once more on its own
-    HpkScoreArgs sc, sc_full;
-    int nsets = 0, rounds_eff = 0, gmax = 0;
+    HpkStencilArgs sa;
+    HpkScoreArgs sc;
+    HpkGeo gs, gf;                      // tile geometry of the batch's launches (a band may lay its tiles out for a narrower halo of its own:
+                                        // hpk_band_class) | of a chromosome computed once more on its own: the plan's
+    int nsets = 0, rounds_eff = 0, gmax = 0, tr_cap = 127;
     bool sums = false, dense = false, do_score = true, phases = false, simple = false, use_s = false, balf64 = false,
-         time_stencil = true, use_class = false;
+         time_stencil = true, use_class = false, use_lean = false;
     size_t max_zero = 0, max_head = 0;
     signed char class_tab[HPK_NCLASS];  // the depth classes' widths as uploaded for this batch (source of an asynchronous copy: lives with the job)
     double t_begin = 0.0;
@@ -518,12 +529,10 @@ int launch_compute(hpk_ctx* c, hpk_job* j, int b0, int nbl, bool solo, bool with
     Lane& L = c->lane[j->lane];
     const HpkDevPlan& plan = L.plan_host;
     const HpkBandDesc* dd = lane_desc(L, j, b0, solo);
-    // a chromosome computed once more (its record bound was too narrow) runs under the plan's own halo and tile geometry
-    const bool full = solo && j->bands[b0].redone;
     if (with_stencil) {
         if (j->time_stencil) (void)hipEventRecord(L.ev[1], c->stream);
         {
-            HpkStencilArgs sa = full ? j->sa_full : j->sa;
+            HpkStencilArgs sa = j->sa;
             sa.nbands = nbl;
             int kall = 0;
             for (int b = b0; b < b0 + nbl; ++b) kall += j->bands[b].d.chunk;
@@ -539,7 +548,7 @@ int launch_compute(hpk_ctx* c, hpk_job* j, int b0, int nbl, bool solo, bool with
         if (j->phases) (void)hipEventRecord(L.ev[3], c->stream);
     }
     if (j->do_score) {
-        HpkScoreArgs sc = full ? j->sc_full : j->sc;
+        HpkScoreArgs sc = j->sc;
         if (all_survivors) sc.kmin = nullptr;       // (a chromosome whose cut lay above the bound of its survivor records)
         sc.gridx = 0;           // the widest row of scoring workgroups among the bands launched (HpkBandDesc::score_wgs)
         for (int b = b0; b < b0 + nbl; ++b) sc.gridx = std::max(sc.gridx, solo ? j->gmax : j->bands[b].d.score_wgs);
@@ -596,27 +605,12 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     // last stored diagonal D + maxww (gap rows, callers.py:238) through the last tile's right halo: with a halo below
     // maxww the chunks themselves have to go further (Dg).  The halo is at least 4 (plans with maxww < 4: the widths beyond
     // maxww have no step, the kernel leaves them out).
-    struct Geo { int W, Dg, TR, TC, J, tilecap; size_t upt; };
     // (rows beyond 64 pay on single-pair plans - chr1 @10 kb: 66 rows at a halo of 6, -4.5 % - and cost 2 % on the
     // three-slot union plan, measured with HPK_TR_CAP)
     const int tr_cap_s = plan.single_p >= 0 ? opt.tr_cap : std::min(opt.tr_cap, 64);
-    auto geo_of = [&](int Wh) {
-        Geo g;
-        g.W = Wh; g.Dg = D + std::max(0, W - Wh);
-        g.TC = HPK_LC - 2 * Wh - 1;
-        g.TR = std::min(HPK_LR - 2 * Wh - 1, std::min(tr_cap_s, HPK_TLIST / g.TC));
-        g.J = (g.TR + g.Dg - mw + g.TC - 1) / g.TC;
-        g.tilecap = g.TR * g.TC;
-        g.upt = ((size_t)g.tilecap + HPK_UNIT - 1) / HPK_UNIT;          // at most ceil(tilecap / HPK_UNIT) units per tile
-        return g;
-    };
-    auto stencil_args_of = [&](const Geo& g) {
-        HpkStencilArgs a;
-        std::memset(&a, 0, sizeof(a));
-        a.W = g.W; a.mw = mw; a.D = D; a.Dg = g.Dg; a.TR = g.TR; a.TC = g.TC; a.J = g.J; a.tilecap = g.tilecap;
-        return a;
-    };
-    Geo GF = geo_of(std::max(W, 4));
+    auto geo_of = [&](int Wh) { return hpk_geo_of(Wh, W, D, mw, tr_cap_s); };
+    auto upt_of = [](const HpkGeo& g) { return ((size_t)g.tilecap + HPK_UNIT - 1) / HPK_UNIT; };      // at most ceil(tilecap / HPK_UNIT) units per tile
+    const HpkGeo GF = geo_of(std::max(W, 4));
     j->prm = *prm; j->key = key;
     j->nsets = (plan.mode == HPK_MODE_BHFDR) ? 1 : 2 * plan.npairs;
     j->sums = (prm->flags & HPK_FLAG_DENSE_SUMS) != 0;
@@ -657,19 +651,28 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         max_ld = std::max<int64_t>(max_ld, bands[b].ld); max_n = std::max(max_n, bands[b].n); max_num = std::max(max_num, bands[b].num);
     }
     j->use_s = true;
-    if (!hpk_stencil_s_applies(stencil_args_of(GF), max_ld, max_n))
+    if (!hpk_stencil_s_applies(GF, max_ld, max_n))
         return fail(c, HPK_ERR_INVALID, "band outside the stencil's addressing limits (n < 2^27, ld <= 2^21)");
-    Geo GS = GF;
+    HpkGeo GS = GF;
     if (j->simple && opt.spec_halo && wg_all < W) {
         const int Wh = std::min(W, std::max(std::max(wg_all, (int)plan.wmin), 4));
-        const Geo g = geo_of(Wh);
-        if (Wh < W && hpk_stencil_s_applies(stencil_args_of(g), max_ld, max_n)) GS = g;
+        const HpkGeo g = geo_of(Wh);
+        if (Wh < W && hpk_stencil_s_applies(g, max_ld, max_n)) GS = g;
     }
+    j->gs = GS; j->gf = GF; j->tr_cap = tr_cap_s;
+    // Under the batch's bound every band may get a narrower one of its own (hpk_band_class, below), and with it its own halo and tile
+    // geometry - decided on the device, where the bands are: the record regions and work lists are sized for the worst of the
+    // geometries a band can end up with (halos from the plan's narrowest width to the batch's).
+    const bool class_job = opt.spec && opt.spec_class && j->simple && j->do_score && !dense && wg_all < W && wg_all > (int)plan.wmin;
+    const bool band_halo = class_job && opt.spec_halo && GS.W > std::max((int)plan.wmin, 4);
+    std::vector<HpkGeo> geos{GS, GF};
+    if (band_halo) for (int Wh = std::max((int)plan.wmin, 4); Wh < GS.W; ++Wh) geos.push_back(geo_of(Wh));
     const int hbins = (opt.rounds <= -2) ? hpk_score_hist_bins((plan.mode == HPK_MODE_BHFDR) ? 1 : 2 * plan.npairs, plan.mode == HPK_MODE_BHFDR) : 0;
     // ---- geometry, sizes and offsets of every band's slices
     const int TR = GS.TR, TC = GS.TC, J_ = GS.J, tilecap = GS.tilecap;
     (void)TC;
-    const size_t upt = std::max(GS.upt, GF.upt);
+    size_t upt = 0;
+    for (const HpkGeo& g : geos) upt = std::max(upt, upt_of(g));
     const size_t etab_el = std::max<size_t>((size_t)plan.nsteps * 2 * (D + 1), 1);
     const size_t eedge_el = std::max<size_t>((size_t)2 * W * plan.nsteps * 2 * (D + 1), 1);
     j->rounds_eff = (opt.rounds <= -2) ? -100 - hbins : opt.rounds;
@@ -688,8 +691,12 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         s.n = n; s.num = num; s.ld = bands[b].ld;
         s.ntiles = ((n + TR - 1) / TR) * J_;
         s.ntiles_full = ((n + GF.TR - 1) / GF.TR) * GF.J;
-        const size_t tiles_max = (size_t)std::max(s.ntiles, s.ntiles_full);
-        const size_t rec_max = std::max((size_t)s.ntiles * tilecap, (size_t)s.ntiles_full * GF.tilecap);
+        size_t tiles_max = 0, rec_max = 0;
+        for (const HpkGeo& g : geos) {
+            const size_t nt = (size_t)((n + g.TR - 1) / g.TR) * g.J;
+            tiles_max = std::max(tiles_max, nt);
+            rec_max = std::max(rec_max, nt * (size_t)g.tilecap);
+        }
         int64_t band_px = 0;                    // pixels with mw <= d <= D inside the matrix
         for (int d = mw; d <= std::min(D, num - 1); ++d) if (n - d > 0) band_px += n - d;
         s.band_px = band_px;
@@ -743,6 +750,8 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         d.rec_stride = (int64_t)s.ntiles * tilecap;
         d.cap = cap; d.zero_bytes = s.zero_bytes; d.off_rowlive = (uint32_t)s.off_rowlive; d.off_inl = (uint32_t)s.off_inl;
         d.derive = derive ? (bands[b].bias1 ? 2 : 1) : 0;       // 1: IR and biases, 2: IR only
+        d.lean_cj = 0x7fffffff;                                 // (no lean tiles unless hpk_band_class says where)
+        d.W = GS.W; d.Dg = GS.Dg; d.TR = GS.TR; d.TC = GS.TC; d.J = GS.J; d.tilecap = GS.tilecap;
         d.score_wgs = wgs;
     }
 
@@ -870,6 +879,8 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
             hd[nb + b].ntiles = j->bands[b].ntiles_full;
             hd[nb + b].chunk = (j->bands[b].ntiles_full + 7) / 8;
             hd[nb + b].rec_stride = (int64_t)j->bands[b].ntiles_full * GF.tilecap;
+            hd[nb + b].W = GF.W; hd[nb + b].Dg = GF.Dg; hd[nb + b].TR = GF.TR; hd[nb + b].TC = GF.TC; hd[nb + b].J = GF.J;
+            hd[nb + b].tilecap = GF.tilecap;
             hd[nb + b].score_wgs = j->gmax;
         }
         HIPCHK(c, hipMemcpyAsync(L.desc.p, hd, desc_bytes, hipMemcpyHostToDevice, L.up));
@@ -894,15 +905,30 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     // sample freezes earlier, and what it writes beyond its own width is read and dropped by the scoring kernel.  hpk_band_class
     // sorts the bands into depth classes on the device and gives each the width its class froze at last (verified at collection
     // like the batch's bound: a chromosome that froze later is computed once more).
-    j->use_class = opt.spec && opt.spec_class && j->simple && j->do_score && !dense && wg_all < W && wg_all > (int)plan.wmin;
-    if (j->use_class) {
-        signed char* tab = j->class_tab;
-        if (c->hint_n > 0 && std::memcmp(&key, &c->hint_key, sizeof(key)) == 0)
-            for (int i = 0; i < HPK_NCLASS; ++i) tab[i] = std::max(c->class_w[i], c->class_w1[i]);
-        else std::memset(tab, -1, HPK_NCLASS);
-        HIPCHK(c, L.classtab.reserve(HPK_NCLASS));
-        HIPCHK(c, hipMemcpyAsync(L.classtab.p, tab, HPK_NCLASS, hipMemcpyHostToDevice, L.up));
-        hpk_launch_band_class(L.desc.as<HpkBandDesc>(), nb, mw, D, L.classtab.as<signed char>(), wg_all, opt.spec_margin, (int)plan.wmin, L.up);
+    j->use_class = class_job;
+    // Lean tiles: the same kernel tells, per band, from which column chunk on the tiles hold (next to) no candidate that resolves
+    // within the band's bound; hpk_stencil_s builds those without their f64 plane.  Weight input, a monotone Reads matrix, records
+    // under a bound (no dense outputs), and not under spec_halo = 0, whose runs promise bit-identical values whatever the
+    // context scored before (which tiles are lean depends on the bound, and their few sums are formed cell by cell).
+    j->use_lean = opt.lean && opt.lean_max > 0 && opt.spec_halo && j->simple && j->do_score && !dense && !j->balf64 && wg_all != 255;
+    if (j->use_class || j->use_lean) {
+        HpkClassArgs ca;
+        std::memset(&ca, 0, sizeof(ca));
+        if (j->use_class) {
+            signed char* tab = j->class_tab;
+            if (c->hint_n > 0 && std::memcmp(&key, &c->hint_key, sizeof(key)) == 0)
+                for (int i = 0; i < HPK_NCLASS; ++i) tab[i] = std::max(c->class_w[i], c->class_w1[i]);
+            else std::memset(tab, -1, HPK_NCLASS);
+            HIPCHK(c, L.classtab.reserve(HPK_NCLASS));
+            HIPCHK(c, hipMemcpyAsync(L.classtab.p, tab, HPK_NCLASS, hipMemcpyHostToDevice, L.up));
+            ca.table = L.classtab.as<signed char>();
+        }
+        ca.mw = mw; ca.D = D; ca.wg_all = wg_all; ca.margin = opt.spec_margin; ca.wmin = (int)plan.wmin;
+        ca.lean = j->use_lean ? 1 : 0;
+        ca.halo = band_halo ? 1 : 0; ca.planW = W; ca.tr_cap = tr_cap_s;
+        ca.p0 = plan.reads_p0; ca.minr = plan.min_reads;
+        ca.lean_frac = (float)opt.lean_frac_pct / 100.f;
+        hpk_launch_band_class(L.desc.as<HpkBandDesc>(), nb, ca, L.up);
         HIPCHK(c, hipGetLastError());
     }
     HIPCHK(c, hipEventRecord(L.ev_up, L.up));
@@ -920,12 +946,13 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     sa.plan = L.plan.as<HpkDevPlan>();
     sa.risk = std::ldexp(1.0, -opt.risk_log2);
     sa.nbands = nb;
-    sa.W = GS.W; sa.mw = mw; sa.D = D; sa.Dg = GS.Dg; sa.TR = GS.TR; sa.TC = GS.TC; sa.J = GS.J; sa.tilecap = GS.tilecap;
+    sa.mw = mw; sa.D = D;
     sa.single = plan.single_p >= 0 ? 1 : 0;
     sa.generic = j->simple ? 0 : 1;
     sa.order = opt.tile_order;
     sa.dbg_stop = opt.dbg_stop;
     sa.clk = nullptr;
+    sa.lean_max = j->use_lean ? opt.lean_max : 0;
 #ifdef HPK_PHASE_CLOCK
     if (std::getenv("HPK_CLK_DUMP")) {
         HIPCHK(c, c->tmpD.reserve(sizeof(unsigned long long) * 8 * HPK_NWAVES * 1024));
@@ -933,12 +960,8 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         sa.clk = c->tmpD.as<unsigned long long>();
     }
 #endif
-    j->sa_full = sa;
-    j->sa_full.W = GF.W; j->sa_full.Dg = GF.Dg; j->sa_full.TR = GF.TR; j->sa_full.TC = GF.TC; j->sa_full.J = GF.J;
-    j->sa_full.tilecap = GF.tilecap;
     HpkScoreArgs& sc = j->sc;
     std::memset(&sc, 0, sizeof(sc));
-    sc.tilecap = GS.tilecap; sc.TR = GS.TR; sc.TC = GS.TC; sc.J = GS.J; sc.W = GS.W;
     sc.plan = sa.plan;
     sc.bounds = c->d_bounds.as<double>(); sc.ptab = c->d_ptab.as<double>();
     sc.ptab_off = c->d_off.as<int32_t>(); sc.sfe = c->d_sfe.as<double>(); sc.sig = prm->sig;
@@ -970,8 +993,6 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
             if (opt.host_prof) std::fprintf(stderr, "[hpk host] survivor bound: bins %d %d %d ... (hbins %d)\n", km[1], km[2], km[HPK_NB + 2], hbins);
         }
     }
-    j->sc_full = sc;
-    j->sc_full.tilecap = GF.tilecap; j->sc_full.TR = GF.TR; j->sc_full.TC = GF.TC; j->sc_full.J = GF.J; j->sc_full.W = GF.W;
     return launch_compute(c, j, 0, nb, false, true);
 }
 
@@ -998,8 +1019,12 @@ int finish_band(hpk_ctx* c, hpk_job* j, int b, std::string* err = nullptr) {
     const int32_t h_frozen = *reinterpret_cast<const int32_t*>(hsmall + HPK_OFF_FROZEN);
     const int32_t h_err = *reinterpret_cast<const int32_t*>(hsmall + HPK_OFF_ERR);
     R.record_bound = s.d.wguess;
-    R.halo_w = s.redone ? j->sa_full.W : j->sa.W;
+    R.halo_w = s.d.W;
     R.redone = (s.redone ? 1 : 0) | (s.rescored ? 2 : 0);
+    {
+        const unsigned* lc = reinterpret_cast<const unsigned*>(hsmall + HPK_OFF_LEAN);
+        R.lean_tiles = (int32_t)lc[0]; R.lean_redone = (int32_t)lc[1]; R.lean_explicit = (int64_t)lc[2];
+    }
     const int32_t* h_exec = reinterpret_cast<const int32_t*>(hsmall + HPK_OFF_EXEC);
     const unsigned long long h_nsurv = *reinterpret_cast<const unsigned long long*>(hsmall + HPK_OFF_NOUT);
     const unsigned long long* h_emax = reinterpret_cast<const unsigned long long*>(hsmall + HPK_OFF_EMAX);
@@ -1056,7 +1081,7 @@ int finish_band(hpk_ctx* c, hpk_job* j, int b, std::string* err = nullptr) {
         const HpkBandDesc& d = s.d;
         HpkDenseArgs da;
         da.rec_ent = d.rec_ent; da.rec_S = d.rec_S; da.rec_W = d.rec_W; da.tile_cnt = d.tile_cnt;
-        da.tilecap = j->sa.tilecap; da.rec_stride = d.rec_stride; da.ntiles = s.ntiles; da.TR = j->sa.TR; da.TC = j->sa.TC; da.J = j->sa.J;
+        da.tilecap = d.tilecap; da.rec_stride = d.rec_stride; da.ntiles = s.ntiles; da.TR = d.TR; da.TC = d.TC; da.J = d.J;
         da.plan = j->sa.plan; da.etab = d.etab; da.eedge = d.eedge;
         da.IR = d.IR; da.b1 = d.b1; da.b2 = d.b2; da.n = n; da.num = s.num; da.ldo = s.ldo; da.mw = mw; da.D = D;
         da.dE = L.dE.as<double2>(); da.dW = L.dW.as<uint8_t>(); da.dS = sums ? L.dS.as<double4>() : nullptr;
@@ -1182,14 +1207,24 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
             const int32_t er = *reinterpret_cast<const int32_t*>(hsmall + HPK_OFF_ERR);
             if (j->use_class && !s.redone) {        // the bound the band ran under (hpk_band_class; gone after a full recomputation)
                 const unsigned v = *reinterpret_cast<const unsigned*>(hsmall + HPK_OFF_BCLASS);
-                if (v & 0x10000u) { s.cls = (int)((v >> 8) & 255u); s.d.wguess = (int32_t)(v & 255u); }
+                if (v & 0x10000u) {
+                    s.cls = (int)((v >> 8) & 255u); s.d.wguess = (int32_t)(v & 255u);
+                    const int halo = (int)((v >> 20) & 31u);           // the band's own halo, and the tile geometry that goes with it
+                    if (halo >= 4 && halo != s.d.W) {
+                        const HpkGeo g = hpk_geo_of(halo, plan.W, plan.D, plan.mw, j->tr_cap);
+                        s.d.W = g.W; s.d.Dg = g.Dg; s.d.TR = g.TR; s.d.TC = g.TC; s.d.J = g.J; s.d.tilecap = g.tilecap;
+                        s.ntiles = ((s.n + g.TR - 1) / g.TR) * g.J;
+                        s.d.ntiles = s.ntiles; s.d.chunk = (s.ntiles + 7) / 8; s.d.rec_stride = (int64_t)s.ntiles * g.tilecap;
+                    }
+                }
             }
             // once more from the band, on its own, under the plan's geometry and through the two-kernel path, with a record for
             // every resolved candidate (the band's second descriptor, prepared at submission)
             auto full_redo = [&](bool all_survivors) -> int {
                 s.d.wguess = plan.W;
                 s.d.ntiles = s.ntiles_full; s.d.chunk = (s.ntiles_full + 7) / 8;
-                s.d.rec_stride = (int64_t)s.ntiles_full * j->sa_full.tilecap;
+                s.d.rec_stride = (int64_t)s.ntiles_full * j->gf.tilecap;
+                s.d.W = j->gf.W; s.d.Dg = j->gf.Dg; s.d.TR = j->gf.TR; s.d.TC = j->gf.TC; s.d.J = j->gf.J; s.d.tilecap = j->gf.tilecap;
                 s.ntiles = s.ntiles_full;
                 s.redone = true;
                 c->spec_reruns += 1;
@@ -1626,7 +1661,7 @@ int hpk_probe_sums(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, cons
         HpkDenseArgs da;
         std::memset(&da, 0, sizeof(da));
         da.rec_ent = d.rec_ent; da.rec_S = d.rec_S; da.rec_W = d.rec_W; da.tile_cnt = d.tile_cnt;
-        da.tilecap = job->sa.tilecap; da.rec_stride = d.rec_stride; da.ntiles = s.ntiles; da.TR = job->sa.TR; da.TC = job->sa.TC; da.J = job->sa.J;
+        da.tilecap = d.tilecap; da.rec_stride = d.rec_stride; da.ntiles = s.ntiles; da.TR = d.TR; da.TC = d.TC; da.J = d.J;
         da.plan = job->sa.plan; da.etab = d.etab; da.eedge = d.eedge;
         da.IR = d.IR; da.b1 = d.b1; da.b2 = d.b2; da.n = s.n; da.num = s.num; da.ldo = s.ldo;
         da.mw = plan.mw; da.D = plan.D;

@@ -49,7 +49,8 @@ struct HpkSurv {
 #define HPK_OFF_EXEC    (HPK_OFF_ERR + 8)                                   // i32[64]
 #define HPK_OFF_NUNITS  (HPK_OFF_EXEC + 4 * HPK_MAX_STEPS)                  // u32 (+ HPK_OFF_BCLASS): survives the overflow rerun
 #define HPK_OFF_BCLASS  (HPK_OFF_NUNITS + 4)                                // u32: 0x10000 | depth class << 8 | the record bound hpk_band_class gave the band (0: none)
-#define HPK_OFF_NSURV   (HPK_OFF_NUNITS + 8)                                // u64[HPK_NREG * HPK_REG_STRIDE] ... from here on reset by the rerun
+#define HPK_OFF_LEAN    (HPK_OFF_NUNITS + 8)                                // u32[4]: tiles built without the f64 plane | of those, computed once more in full | candidates summed cell by cell | -
+#define HPK_OFF_NSURV   (HPK_OFF_NUNITS + 24)                               // u64[HPK_NREG * HPK_REG_STRIDE] ... from here on reset by the rerun
 #define HPK_OFF_NVALID  (HPK_OFF_NSURV + 8 * HPK_NREG * HPK_REG_STRIDE)     // u64[16]
 #define HPK_OFF_EMAX    (HPK_OFF_NVALID + 8 * 2 * HPK_MAX_PAIRS)            // u64[16]
 #define HPK_OFF_NOUT    (HPK_OFF_EMAX + 8 * 2 * HPK_MAX_PAIRS)              // u64
@@ -69,6 +70,25 @@ struct HpkSurv {
 #else
 #define HPK_GP(T) T*
 #endif
+
+// Tile geometry of hpk_stencil_s under a halo of Wh widths.  Output tile: what the halo leaves of the 64 x 160 table, as many
+// rows as the tile-wide candidate list holds (HPK_TLIST entries; 6 bits of the record entry).  The tiles of a row block reach
+// the last stored diagonal D + maxww (gap rows, callers.py:238) through the last tile's right halo: with a halo below maxww
+// the chunks themselves have to go further (Dg).  One function for the host (sizes, the batch's default) and the device
+// (hpk_band_class: every band's own halo).
+struct HpkGeo { int32_t W, Dg, TR, TC, J, tilecap; };
+__host__ __device__ inline HpkGeo hpk_geo_of(int Wh, int planW, int D, int mw, int tr_cap) {
+    HpkGeo g;
+    g.W = Wh; g.Dg = D + (planW > Wh ? planW - Wh : 0);
+    g.TC = HPK_LC - 2 * Wh - 1;
+    int tr = HPK_LR - 2 * Wh - 1;
+    tr = tr < tr_cap ? tr : tr_cap;
+    tr = tr < HPK_TLIST / g.TC ? tr : HPK_TLIST / g.TC;
+    g.TR = tr;
+    g.J = (g.TR + g.Dg - mw + g.TC - 1) / g.TC;
+    g.tilecap = g.TR * g.TC;
+    return g;
+}
 
 // One band of a batch as the kernels see it (device memory, written by the host before the launches).
 struct HpkBandDesc {
@@ -112,7 +132,13 @@ struct HpkBandDesc {
     uint32_t off_rowlive, off_inl;      // offsets of the row flags / inline survivors inside `small`
     int32_t derive;                     // 1: IR and biases are derived on the device from raw + weight, 2: IR only, 0: given
     int32_t score_wgs;                  // scoring workgroups that take part for this band (the rest of the grid row exits)
-    uint32_t pad_[2];
+    int32_t lean_cj;                    // tiles of column chunks >= lean_cj are built without the f64 plane (hpk_band_class; >= J: none)
+    // the band's own tile geometry (hpk_geo_of): the batch's, or - hpk_band_class - the one of the band's own record bound
+    int32_t W;                          // halo of the tiles = widest width the search looks at (<= the plan's maxww, see Dg)
+    int32_t Dg;                         // last diagonal the tiles must cover for the gap rows: D + (maxww - W)
+    int32_t TR, TC;                     // output tile
+    int32_t J;                          // column chunks per row block
+    int32_t tilecap;                    // records per tile region (TR x TC)
 };
 
 // Geometry and parameters common to all bands of a batch (kernel argument of the stencil).
@@ -120,23 +146,19 @@ struct HpkStencilArgs {
     const HpkDevPlan* plan;
     double risk;                        // box sums below risk x (largest table entry of the window) are redone exactly
     int32_t nbands;
-    int32_t W, mw, D;                   // W: halo of the tiles = widest width the search looks at (<= the plan's maxww, see Dg)
-    int32_t Dg;                         // last diagonal the tiles must cover for the gap rows: D + (maxww - W)
-    int32_t TR, TC;                     // output tile = (HPK_LR - 2W - 1) x (HPK_LC - 2W - 1), rows capped by the candidate list (HPK_TLIST)
-    int32_t J;                          // column chunks per row block
-    int32_t tilecap;
+    int32_t mw, D;                      // (the tile geometry is the band's: HpkBandDesc::W ... tilecap)
     int32_t grid;                       // persistent workgroups (multiple of 8, one per CU)
     int32_t single;                     // the plan is a textbook single-pair plan (HpkDevPlan::single_p >= 0)
     int32_t order;                      // tile order within an XCD's run: 0 row-major, 1 column chunks rotated per row block
     int32_t generic;                    // the plan's Reads matrix is not monotone in the width: steps walked in plan order (general plans only)
     int32_t dbg_stop;                   // profiling ablation: 1 stop after the loads, 2 after the SAT, 4 no candidates, 5 search without box sums
     unsigned long long* clk;            // -DHPK_PHASE_CLOCK builds: [grid][waves][8] cycle sums per phase, or nullptr
+    int32_t lean_max;                   // lean tiles (HpkBandDesc::lean_cj): most candidates summed cell by cell before the tile is computed once more in full; 0: no lean tiles
+    int32_t pad_;
 };
 
 struct HpkScoreArgs {
-    int32_t tilecap;
-    int32_t TR, TC, J, W;               // tile geometry
-    const HpkDevPlan* plan;
+    const HpkDevPlan* plan;             // (tile geometry: the band's, HpkBandDesc)
     const double* bounds;               // [HPK_NB] chunk upper bounds
     const double* ptab;                 // Poisson survival table
     const int32_t* ptab_off;            // [HPK_NB_TAB + 2]
@@ -167,7 +189,7 @@ struct HpkBruteArgs {
 };
 
 // hpk_stencil_s walks the whole batch in one launch (bands within its addressing limits, a halo of at least 4)
-bool hpk_stencil_s_applies(const HpkStencilArgs& a, int64_t max_ld, int32_t max_n);
+bool hpk_stencil_s_applies(const HpkGeo& g, int64_t max_ld, int32_t max_n);
 void hpk_launch_stencil_batch(const HpkStencilArgs& a, const HpkBandDesc* d_bands, bool balf64, hipStream_t st);
 void hpk_launch_dense(const HpkDenseArgs& a, hipStream_t st);
 void hpk_launch_probe(const HpkDenseArgs& a, const int32_t* rows, const int32_t* cols, int64_t count, double* out, hipStream_t st);
@@ -193,8 +215,19 @@ void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe
 // 64th row sampled), bound = table[class] + margin (table: the width chromosomes of that class froze at, -1 unknown) clamped to
 // [wmin, wg_all]; written into the descriptor's wguess and into the counter block (HPK_OFF_BCLASS).  Runs before the stencil.
 #define HPK_NCLASS 64
-void hpk_launch_band_class(HpkBandDesc* d_bands, int nbands, int mw, int D, const signed char* table, int wg_all, int margin, int wmin,
-                           hipStream_t st);
+// ... and, same kernel, same sampled rows: from which column chunk on a band's tiles are expected to hold (next to) no candidate
+// that resolves within the band's bound - the mean Reads of the chunk's nearest pixels is at most lean_frac x min_local_reads -
+// and are built without their f64 plane (HpkBandDesc::lean_cj, hpk_stencil_s).
+struct HpkClassArgs {
+    const signed char* table;           // [HPK_NCLASS] or nullptr: no depth classes, every band keeps the batch's bound
+    int32_t mw, D, wg_all, margin, wmin;
+    int32_t lean;                       // 0: no lean tiles (lean_cj = J)
+    int32_t halo;                       // 1: every band's tiles laid out for its own bound's halo (hpk_geo_of); 0: the batch's geometry stays
+    int32_t planW, tr_cap;              // hpk_geo_of's inputs
+    int32_t p0, minr;                   // Reads = lower-left rings p0 + 1 .. w against min_local_reads
+    float lean_frac;
+};
+void hpk_launch_band_class(HpkBandDesc* d_bands, int nbands, const HpkClassArgs& a, hipStream_t st);
 void hpk_launch_poisson_sf(const double* k, const double* lam, const double* sfe, double* out, int64_t count,
                            hipStream_t st);
 void hpk_launch_brute(const HpkBruteArgs& a, hipStream_t st);

@@ -131,6 +131,21 @@ __device__ __noinline__ double2 explicit_sums_wave(const float* __restrict__ raw
 #define HPK_CLK_DECL
 #define HPK_CLK(v)
 #endif
+#ifndef HPK_EARLY_LEAN
+#define HPK_EARLY_LEAN 1
+#endif
+#ifndef HPK_EARLY_FULL
+#define HPK_EARLY_FULL 0
+#endif
+// -DHPK_CLK_P1 (with HPK_PHASE_CLOCK): phase 1 split - slot 0 wait for the prefetched rows, 1 cells, 2 candidate list, 3 row prefixes
+// and stores; 4 = everything between phase 1 and the batches
+#ifdef HPK_CLK_P1
+#define HPK_CLKP(v) HPK_CLK(v)
+#define HPK_CLKQ(v) HPK_CLK(ck4)
+#else
+#define HPK_CLKP(v)
+#define HPK_CLKQ(v) HPK_CLK(v)
+#endif
 
 // ------------------------------------------------------------------ the stencil kernel
 // hpk_stencil_s, per tile (1024 threads = 16 waves, one persistent workgroup per CU):
@@ -250,15 +265,15 @@ __device__ __forceinline__ void tile_load_s(const HpkStencilArgs& a, const HpkBa
                                             int lane, TileRegsS<BALF64>& t) {
     const int bn = bd->n;
     const int64_t bld = bd->ld;
-    const int r0 = rb * a.TR;
-    const int rt0 = r0 - a.W - 1;                          // matrix row of SAT row 0 (negative in the first row block)
+    const int r0 = rb * bd->TR;
+    const int rt0 = r0 - bd->W - 1;                        // matrix row of SAT row 0 (negative in the first row block)
     // The tile's buffer: one row more than the tile has on either side, where the band has them - a wide load of the tile's
     // first row may start in the row before (negative diagonals), one of its last row may run on into the next.
     const int rb0 = rt0 > 1 ? rt0 - 1 : 0;
     int rows = bn - rb0;
     rows = rows > LR + 2 ? LR + 2 : rows;
     const unsigned ldu = (unsigned)bld;
-    const int koff = a.mw + cj * a.TC + 1;                 // diagonal of SAT cell (0, 0): (c0 - W) - (r0 - W - 1)
+    const int koff = a.mw + cj * bd->TC + 1;               // diagonal of SAT cell (0, 0): (c0 - W) - (r0 - W - 1)
     const int Y = 4 * wave + (lane >> 4);
     const int XL = (LC - 10) - 10 * (lane & 15);           // the lane's lowest column (cell e = 9)
     const rsrc_t rraw = make_rsrc(gptr(bd->raw) + (int64_t)rb0 * bld, (unsigned)rows * ldu * 4u);
@@ -320,6 +335,7 @@ __device__ __forceinline__ void tile_load_s(const HpkStencilArgs& a, const HpkBa
 // band switch recomputes them with a division (rare).
 struct TileWalk {
     int k, band, kb, chunkb, ntb;       // index in the XCD's run; current band, its first index, its chunk and tile count
+    int J;                              // column chunks per row block of the current band (every band has its own tile geometry)
     int rbk, ck, rm;                    // row block, column chunk before rotation, row block mod J
     int dk, dr, dc, drm;                // per step: index stride, its quotient and remainder by J, quotient mod J
     int nt;                             // tiles handed out so far (see bword)
@@ -334,11 +350,13 @@ struct TileWalk {
                 const HpkBandDesc* __restrict__ nb = bands + __builtin_amdgcn_readfirstlane(band);
                 chunkb = nb->chunk;
                 ntb = nb->ntiles;
+                J = nb->J;
+                dr = dk / J; dc = dk - dr * J; drm = dr % J;
                 fresh = true;
             }
             const int t = xcd * chunkb + (k - kb);
             if (t < ntb) {
-                if (fresh) { rbk = t / a.J; ck = t - rbk * a.J; rm = rbk % a.J; }
+                if (fresh) { rbk = t / J; ck = t - rbk * J; rm = rbk % J; }
                 return;
             }
             // (the last XCD's run of a band can be shorter than the others': on to the next band)
@@ -347,7 +365,8 @@ struct TileWalk {
     }
     __device__ __forceinline__ void init(const HpkStencilArgs& a, const HpkBandDesc* __restrict__ bands) {
         dk = (int)(gridDim.x >> 3);
-        dr = dk / a.J; dc = dk - dr * a.J; drm = dr % a.J;
+        J = bands[0].J;
+        dr = dk / J; dc = dk - dr * J; drm = dr % J;
         k = (int)(blockIdx.x >> 3);
         band = 0; kb = 0; chunkb = bands[0].chunk; ntb = bands[0].ntiles;
         rbk = 0; ck = 0; rm = 0; nt = 0;
@@ -360,14 +379,14 @@ struct TileWalk {
     // take the J chunks.  Two scalar divisions per tile, in the one wave that walks.)
     __device__ __forceinline__ int cj(const HpkStencilArgs& a) const {
         if (a.order == 0) return ck;
-        const int c = ck + rm + (rbk / (dr > 0 ? dr : 1)) % a.J;
-        return c >= a.J ? (c >= 2 * a.J ? c - 2 * a.J : c - a.J) : c;
+        const int c = ck + rm + (rbk / (dr > 0 ? dr : 1)) % J;
+        return c >= J ? (c >= 2 * J ? c - 2 * J : c - J) : c;
     }
     __device__ __forceinline__ void step(const HpkStencilArgs& a, const HpkBandDesc* __restrict__ bands) {
         k += dk; rbk += dr; ck += dc; rm += drm; nt += 1;
-        if (ck >= a.J) { ck -= a.J; rbk += 1; rm += 1; }
-        if (rm >= a.J) rm -= a.J;
-        if (rm >= a.J) rm -= a.J;
+        if (ck >= J) { ck -= J; rbk += 1; rm += 1; }
+        if (rm >= J) rm -= J;
+        if (rm >= J) rm -= J;
         locate(a, bands, false);
     }
     // what wave 0 publishes for the others: row block << 8 | column chunk, ~0 = no more tiles
@@ -397,9 +416,19 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     double* __restrict__ ctot = wct + LC;                              // [3][LC] phase 2: totals of the f64 plane's row chunks
     unsigned* __restrict__ utot = reinterpret_cast<unsigned*>(ctot + 3 * LC);            // [LC] ... of the packed plane's first chunk
 
+    // Lean tiles (weight input): far from the diagonal a tile holds candidates but next to none that resolves within the
+    // band's bound, and its f64 plane would be built for nothing.  Tiles of the column chunks from HpkBandDesc::lean_cj on
+    // (hpk_band_class: where the mean Reads of the chunk's nearest pixels stays far below min_local_reads) build the packed
+    // plane only - no conversions, products, f64 scan, a third of the table traffic; the valid flags from "count, row weight
+    // and column weight all non-zero" (hpk_band_class rules out weights small enough for a product to underflow) - and run
+    // the search; the few candidates that do resolve get their sums cell by cell from the band (explicit_sums_wave), and a
+    // tile with more than a.lean_max of them is computed once more in full (the next pass of the tile loop).
+    constexpr bool LEAN_OK = !BALF64;
+    unsigned* __restrict__ tflag = tcount + 16;                       // [2] a lean tile met more candidates that count than lean_max
+    unsigned* __restrict__ wcz = tcount + 20;                         // [5 + 1] bit X: column weight X of the tile is non-zero
     const int lane_k = threadIdx.x & 63;
     const int wave_k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int W = a.W, mw = a.mw, TR = a.TR, TC = a.TC;
+    const int mw = a.mw;
 
     const HpkDevPlan* __restrict__ plan = a.plan;
     const int nsteps = plan->nsteps, nslots = plan->nslots;
@@ -416,7 +445,8 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             }
             stepof[lane_k] = plan->step_of[lane_k >> 5][lane_k & 31];
             stepof[64 + lane_k] = plan->step_of[2 + (lane_k >> 5)][lane_k & 31];
-            if (lane_k < 2) { tcount[lane_k] = 0u; tcount[4 + lane_k] = 0u; }     // list entries | records written, tiles alternate
+            if (lane_k < 2) { tcount[lane_k] = 0u; tcount[4 + lane_k] = 0u; tcount[16 + lane_k] = 0u; }     // list entries | records written | lean tile gives up, tiles alternate
+            if (lane_k < 6) tcount[20 + lane_k] = 0u;
         }
         for (int s = 0; s < nsteps; ++s) {
             const int k = (__builtin_amdgcn_readlane(pk0, s) >> 20) & 15;
@@ -443,6 +473,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     unsigned myhist = 0u;                 // lane w: candidates whose first sufficient width is w
     unsigned long long hpack0 = 0ull, hpack1 = 0ull;      // this lane's candidates by width min(ww) + k: 16 bits each, k = 0..3 | 4..7
     unsigned mycand = 0u;
+    unsigned mylean = 0u, myexpl = 0u;    // lean tiles | of those computed once more << 16 (wave 0, lane 0); candidates summed cell by cell (per wave, lane 0)
     // the per-lane width counts, summed over the wave, into lane min(ww) + k of myhist
     auto fold_hpack = [&]() {
 #pragma unroll
@@ -454,12 +485,12 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         }
         hpack0 = 0ull; hpack1 = 0ull;
     };
+    TileRegsS<BALF64> nxt;
     // scoring work list: the append of a tile is completed one tile later (the atomic's return is not waited for)
     int pend_tid = -1, pend_band = 0;
     unsigned pend_c = 0u, pend_off = 0u;
 
     HPK_CLK_DECL
-    TileRegsS<BALF64> nxt;
     int par = 0;                        // which of the two list counters the current tile uses
     // The tile walk is the same scalar arithmetic in every wave, and all sixteen would queue for the one scalar unit
     // with it at the top of every tile: wave 0 alone walks, one tile ahead, and publishes the next tile through LDS
@@ -511,8 +542,24 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             } else if (tix == HPK_MAX_STEPS) out = red[NW * 64];
             if (out) atomicAdd(&gptr(hb->hist_acc)[tix * HPK_ACC_STRIDE], (unsigned long long)out);
         }
+        if constexpr (LEAN_OK) {
+            unsigned* lc = reinterpret_cast<unsigned*>(gptr(hb->small) + HPK_OFF_LEAN);
+            if (tix == 0 && mylean) { atomicAdd(&lc[0], mylean & 0xffffu); if (mylean >> 16) atomicAdd(&lc[1], mylean >> 16); }
+            if (lane_k == 0 && myexpl) atomicAdd(&lc[2], myexpl);
+            mylean = 0u; myexpl = 0u;
+        }
         __syncthreads();                // (the next tile's phase 1 parks its totals where `red` sits)
         myhist = 0u; mycand = 0u;
+    };
+    // the tile's column weights (NaN -> 0) into the LDS table, and which of them are non-zero as a bit mask (waves 0..2)
+    auto put_wct = [&](int wv, int ln) {
+        const int tix = wv * 64 + ln;
+        const double w = nxt.wcol == nxt.wcol ? nxt.wcol : 0.0;
+        if (tix < LC) wct[tix] = w;
+        if constexpr (LEAN_OK) {
+            const unsigned long long nz = ballot64((tix < LC) & (w != 0.0));
+            if (ln == 0) { wcz[2 * wv] = (unsigned)nz; wcz[2 * wv + 1] = (unsigned)(nz >> 32); }
+        }
     };
     int hband = -1;                     // band whose resolve counts are pending in myhist / hpack / mycand
 #pragma unroll 1
@@ -528,15 +575,20 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     // decides (frozen_w, freeze_replay), wider candidates and unresolved ones are dropped by the scoring kernel anyway,
     // and the caller knows a bound from the chromosomes before (hpk_api.cpp; 255 = every candidate, as the dense outputs want).
     const int wg_p = bd->wguess;
+    // the band's tile geometry (hpk_geo_of)
+    const int W = bd->W, TR = bd->TR, TC = bd->TC, J_p = bd->J, Dg_p = bd->Dg, tilecap_p = bd->tilecap;
+    const int lean_cj_p = (LEAN_OK && a.lean_max > 0) ? bd->lean_cj : 0x7fffffff;
     // the band's first tile: nothing is prefetched across a boundary; the flush of the band before runs beside the loads
     tile_load_s<BALF64>(a, bd, rb, cj, wave_k, lane_k, nxt);
     if (hband >= 0) flush_hist(bands + hband);
     hband = band;
     if (!BALF64) {                      // the first tile's column weights (the tiles after it: behind their predecessor's tables)
-        const int tix = wave_k * 64 + lane_k;
-        if (tix < LC) wct[tix] = nxt.wcol == nxt.wcol ? nxt.wcol : 0.0;
+        if (wave_k < 3) put_wct(wave_k, lane_k);
         __syncthreads();
     }
+    bool redo = false;                  // the next pass of the tile loop computes the same tile once more, in full
+    int redo_tn = 0;
+    unsigned redo_bn = 0u;
 #pragma unroll 1
     do {
     // Everything below that depends only on (wave, lane) is the same for every tile, and the compiler would hoist it
@@ -545,29 +597,33 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     int wave = wave_k, lane = lane_k;
     asm volatile("" : "+s"(wave));
     asm volatile("" : "+v"(lane));
-    const int tid = rb * a.J + cj;
+    const int tid = rb * J_p + cj;
     const int r0 = rb * TR;
     const int c0 = r0 + mw + cj * TC;
     // (a.Dg, not a.D: with a halo below maxww the stored diagonals beyond D - read for the gap rows only, callers.py:238 -
     // reach further than the last candidates' tile sees)
-    const bool empty_tile = c0 >= n || (mw + cj * TC - (TR - 1)) > a.Dg;      // no stored pixel inside the matrix
-    const int tn = __builtin_amdgcn_readfirstlane((int)tnext);
-    const unsigned bw_next = (unsigned)__builtin_amdgcn_readfirstlane((int)bnext);
+    const bool empty_tile = c0 >= n || (mw + cj * TC - (TR - 1)) > Dg_p;      // no stored pixel inside the matrix
+    // (a pass that computes its tile once more - a lean tile that met too many candidates that count - keeps the walk where it is:
+    // the tile after it is the one the first pass saw)
+    const bool is_redo = LEAN_OK && redo;
+    const int tn = is_redo ? redo_tn : __builtin_amdgcn_readfirstlane((int)tnext);
+    const unsigned bw_next = is_redo ? redo_bn : (unsigned)__builtin_amdgcn_readfirstlane((int)bnext);
     const bool have_next = tn != -1;
     const bool pre_next = have_next && bw_next == cbw;         // the next tile is this band's: its rows are prefetched
     const int rb_next = (int)((unsigned)tn >> 8), cj_next = tn & 255;
-    if (wave == 0) {                    // the tile after the next one, for everybody's next round
-        tw.step(a, bands);
-        if (lane == 0) { tseq[tpar ^ 1] = tw.word(a); tband[tpar ^ 1] = tw.bword(); }
+    if (!is_redo) {
+        if (wave == 0) {                // the tile after the next one, for everybody's next round
+            tw.step(a, bands);
+            if (lane == 0) { tseq[tpar ^ 1] = tw.word(a); tband[tpar ^ 1] = tw.bword(); }
+        }
+        tpar ^= 1;
     }
-    tpar ^= 1;
-    if (empty_tile) {
+    const bool lean = LEAN_OK && !is_redo && cj >= lean_cj_p;
+    // (profiling ablations 10 / 11: the lean tiles alone / the full tiles alone)
+    if (empty_tile || (a.dbg_stop == 10 && !lean) || (a.dbg_stop == 11 && lean)) {
         if (pre_next) {
             tile_load_s<BALF64>(a, bd, rb_next, cj_next, wave, lane, nxt);
-            if (!BALF64 && wave < 3) {
-                const int tix = wave * 64 + lane;
-                if (tix < LC) wct[tix] = nxt.wcol == nxt.wcol ? nxt.wcol : 0.0;
-            }
+            if (!BALF64 && wave < 3) put_wct(wave, lane);
         }
         have = have_next; rb = rb_next; cj = cj_next; bw = bw_next;
         __syncthreads();                // (rare: the far end of the chromosome) wave 0's word before it is read
@@ -575,11 +631,35 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         bnext = lds_u32(lds0 + (unsigned)((unsigned char*)tband - smem) + (unsigned)tpar * 4u);
         continue;
     }
+    if (is_redo) {                      // the tile's rows once more (the registers hold the next tile's), its column weights
+        tile_load_s<BALF64>(a, bd, rb, cj, wave, lane, nxt);
+        if (!BALF64 && wave < 3) put_wct(wave, lane);
+        __syncthreads();
+    }
     unsigned* __restrict__ tcnt = tcount + par;
+    // Phases 1 and 2 exist twice - with and without the f64 plane (L: lean tile) - as two separate stretches of code with their own
+    // registers: the two variants woven into one (a branch per phase) left the register allocator with merged live ranges of
+    // the cell, weight and column arrays, and hundreds of spills.
+    auto phase12 = [&](auto leanc) __attribute__((always_inline)) {
+    constexpr bool L = LEAN_OK && decltype(leanc)::value;
+    // The tile's rows leave the prefetch registers first, and - EARLY - the next tile's are requested at once: a tile's loads take a
+    // couple of microseconds to come back, and requested only behind phase 1 the waves that finish it last wait for them at the top of
+    // the next tile while the others wait at the first barrier.
+    constexpr bool EARLY = !BALF64 && (L ? (HPK_EARLY_LEAN != 0) : (HPK_EARLY_FULL != 0));
+    const TileRegsS<BALF64> cur = nxt;
+    unsigned cm_out = 0u;               // lean tiles: the lane's candidates (bit 9 - e), for the scan that follows the tables
+    if (EARLY) {
+        asm volatile("" :: "v"(cur.raw[0]), "v"(cur.raw[9]) : "memory");
+        if (pre_next) tile_load_s<BALF64>(a, bd, rb_next, cj_next, wave, lane, nxt);
+    }
     // ---- phase 1 (rows): balanced values and packed cells of the lane's ten cells, the candidates among them, and the row
     // prefix of both planes - nine adds inside the lane, a scan over the 16 lanes of the DPP row that holds the table row -
     // written straight to the tables.  Four table rows per wave, all 64 in one pass.
     {
+#ifdef HPK_CLK_P1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HPK_CLK(ck0)
+#endif
     const int Y = 4 * wave + (lane >> 4);                               // the lane's table row
     const int XH = (LC - 1) - 10 * (lane & 15);                         // SAT column of the lane's cell e = 0 (cell e: XH - e)
     const int rr = r0 - W - 1 + Y;                                      // its matrix row
@@ -610,11 +690,13 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     // Column weights: the tile's LDS table (NaNs already 0), memory order like the prefetched elements.
     double wr = 0.0, wcm[10];
     if (!BALF64) {
-        wr = nxt.wrow == nxt.wrow ? nxt.wrow : 0.0;
+        wr = cur.wrow == cur.wrow ? cur.wrow : 0.0;
+        if (!L) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const double2 w2 = *reinterpret_cast<const double2*>(&wct[XH - 9 + 2 * i]);
-            wcm[2 * i] = w2.x; wcm[2 * i + 1] = w2.y;
+            for (int i = 0; i < 5; ++i) {
+                const double2 w2 = *reinterpret_cast<const double2*>(&wct[XH - 9 + 2 * i]);
+                wcm[2 * i] = w2.x; wcm[2 * i + 1] = w2.y;
+            }
         }
     }
     const unsigned span = lim > mw ? (unsigned)(lim - mw) : 0u;         // f64 input: balanced values exist on diagonals [mw, lim)
@@ -627,14 +709,14 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     _Pragma("unroll") for (int e = 0; e < 10; ++e) {                                                                           \
         const int i = 9 - e;                                                                                                   \
         const int k = kH - e, km = k - mw;                              /* diagonal, diagonal - min(ww) */                     \
-        unsigned rb32 = nxt.raw[i];                                                                                            \
+        unsigned rb32 = cur.raw[i];                                                                                            \
         if (MASKED) rb32 = (unsigned)k < (unsigned)lim ? rb32 : 0u;                                                            \
         float rv = __uint_as_float(rb32);                                                                                      \
         const unsigned ru = (unsigned)rv;                                                                                      \
         const unsigned rc = ru < pkcap_p ? ru : pkcap_p;                                                                       \
         if (BALF64) {                                                                                                          \
             /* as given: the caller zeroed the NaNs (hpk.h), signs are kept (callers.py:78) */                                 \
-            bv[e] = (!(MASKED) || (unsigned)km < span) ? nxt.bal[i] : 0.0;                                                     \
+            bv[e] = (!(MASKED) || (unsigned)km < span) ? cur.bal[i] : 0.0;                                                     \
         } else {                                                                                                               \
             if (MASKED) {                                                                                                      \
                 rv = km >= 0 ? rv : 0.f;                                /* balanced values exist from diagonal min(ww) on */   \
@@ -649,19 +731,57 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         /* cm = 2 cm + (count != 0): a compare and an add with carry */                                                        \
         asm("v_cmp_ne_u32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(cm) : "v"(ru) : "vcc");             \
     }
+    // Lean tile: capped counts only; a cell's balanced value is non-zero where its count, its row weight and its column weight
+    // are (bit 9 - e of vm: the counts' mask times the column weights' - ten bits of the tile's wcz - times the row's; masked
+    // cells: times "diagonal >= min(ww)")
+#define HPK_CELLS_LEAN(MASKED)                                                                                                 \
+    _Pragma("unroll") for (int e = 0; e < 10; ++e) {                                                                           \
+        const int i = 9 - e;                                                                                                   \
+        const int k = kH - e;                                                                                                  \
+        unsigned rb32 = cur.raw[i];                                                                                            \
+        if (MASKED) rb32 = (unsigned)k < (unsigned)lim ? rb32 : 0u;                                                            \
+        const unsigned ru = (unsigned)__uint_as_float(rb32);                                                                   \
+        pk[e] = ru < pkcap_p ? ru : pkcap_p;                                                                                   \
+        asm("v_cmp_ne_u32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(cm) : "v"(ru) : "vcc");             \
+    }
     {
         const bool inner = (kH - 9 >= mw) & (kH < lim);
-        if (ballot64(!inner) == 0ull) { HPK_CELLS(false) }
-        else { HPK_CELLS(true) }
+        const bool all_inner = ballot64(!inner) == 0ull;
+        if (L) {
+            if (all_inner) { HPK_CELLS_LEAN(false) }
+            else { HPK_CELLS_LEAN(true) }
+            const unsigned lo = (unsigned)(XH - 9);                         // the lane's lowest column
+            const unsigned w0 = wcz[lo >> 5], w1 = wcz[(lo >> 5) + 1];
+            unsigned vm = cm & (unsigned)((((unsigned long long)w1 << 32) | (unsigned long long)w0) >> (lo & 31u));
+            vm = wr != 0.0 ? vm : 0u;
+            if (!all_inner) {
+                const int A = kH - mw;                                      // cells e <= A lie on diagonals >= min(ww)
+                const unsigned km = A >= 9 ? 0x3ffu : (A < 0 ? 0u : (0x3ffu & ~((1u << (9 - A)) - 1u)));
+                vm &= km;
+            }
+#pragma unroll
+            for (int e = 0; e < 10; ++e) pk[e] |= ((vm >> (9 - e)) & 1u) << PK_SHIFT;
+        } else {
+            if (all_inner) { HPK_CELLS(false) }
+            else { HPK_CELLS(true) }
+        }
     }
 #undef HPK_CELLS
+#undef HPK_CELLS_LEAN
     cm &= cmask;
+    HPK_CLKP(ck1)
     // the lane's slice of the tile-wide list: behind the candidates of the lanes before it, in the wave's slice
     const unsigned cnt = (unsigned)__popc(cm);
     const unsigned inc = wave_inclusive_scan(cnt);
     const unsigned nrow = (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
     unsigned slot = 0u;
-    {
+    if (L) {
+        // a lean tile keeps no list: its candidates are counted, and each lane goes through its own after the tables (the scan
+        // below: next to none passes the widest Reads box)
+        const unsigned addr = (unsigned)(size_t)tcnt;
+        asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" :: "v"(addr), "v"(nrow) : "memory");
+        cm_out = cm;
+    } else {
         // hipcc's atomic optimiser would wait for the returned value on the spot; issued by hand, the LDS round
         // trip runs beside the f64 prefix.  All lanes would add the same count into the same word: lane 0 only, by
         // narrowing exec around the instruction (every lane is active here) instead of a branch on a lane mask.
@@ -670,16 +790,16 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
                      : "=&v"(slot) : "v"(addr), "v"(nrow) : "memory");
     }
     // row prefix of the f64 plane (cell e = 0 first: from the origin side)
+    if (!(L)) {
 #pragma unroll
-    for (int e = 1; e < 10; ++e) bv[e] += bv[e - 1];
-    {
+        for (int e = 1; e < 10; ++e) bv[e] += bv[e - 1];
         const double ex = row16_exclusive_scan(bv[9]);
         double* __restrict__ dst = &Sc[Y * LC + XH - 9];
 #pragma unroll
         for (int i = 0; i < 5; ++i)
             *reinterpret_cast<double2*>(&dst[2 * i]) = make_double2(bv[9 - 2 * i] + ex, bv[8 - 2 * i] + ex);
     }
-    if (nrow != 0u) {
+    if (!L && nrow != 0u) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(slot) :: "memory");
         // entries in the order of the rows, inside a row by descending column
         const unsigned at0 = (unsigned)__builtin_amdgcn_readfirstlane((int)slot) + (inc - cnt);
@@ -691,6 +811,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             if (cd) lds_st_u32(lds0 + (unsigned)(LR * LC * 12) + at * 4u, (ebase - (unsigned)e) | ((pk[e] & PK_MASK) << HPK_ENT_CNT_SHIFT));
         }
     }
+    HPK_CLKP(ck2)
     // ... and of the packed plane
 #pragma unroll
     for (int e = 1; e < 10; ++e) pk[e] += pk[e - 1];
@@ -702,16 +823,30 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             *reinterpret_cast<uint2*>(&dst[2 * i]) = make_uint2(pk[9 - 2 * i] + ex, pk[8 - 2 * i] + ex);
     }
     }
-    HPK_CLK(ck0)
+    HPK_CLKP(ck3)
+    HPK_CLKQ(ck0)
     // The next tile's rows start moving now, from every wave.
-    if (pre_next) tile_load_s<BALF64>(a, bd, rb_next, cj_next, wave, lane, nxt);
+    if (!EARLY && pre_next) tile_load_s<BALF64>(a, bd, rb_next, cj_next, wave, lane, nxt);
     __syncthreads();
-    HPK_CLK(ck1)
+    HPK_CLKQ(ck1)
     // ---- phase 2 (columns): the tables hold row prefixes; the prefix down the columns runs through LDS.  f64 plane: waves
     // 0-9, a thread per column and chunk of 16 rows; packed plane: waves 10-14, chunks of 32 rows.  A thread sums its chunk in
     // registers, parks the chunk's total, and - behind a barrier - writes its cells back with the totals of the chunks above.
     unsigned creg[32];
-    {
+    unsigned* __restrict__ utot3 = reinterpret_cast<unsigned*>(ctot);       // lean tiles: [3][LC] totals of the packed plane's 16-row chunks
+    if (L) {
+        // the packed plane alone: waves 0-9, a thread per column and chunk of 16 rows
+        if (wave < 10) {
+            const int tix = wave * 64 + lane;
+            const int ch = tix >= 2 * LC ? (tix >= 3 * LC ? 3 : 2) : (tix >= LC ? 1 : 0), col = tix - ch * LC;
+            const unsigned* __restrict__ src = &Sp[(16 * ch) * LC + col];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) creg[i] = src[i * LC];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) creg[i] += creg[i - 1];
+            if (ch < 3) utot3[ch * LC + col] = creg[15];
+        }
+    } else {
         if (wave < 10) {
             const int tix = wave * 64 + lane;
             const int ch = tix >= 2 * LC ? (tix >= 3 * LC ? 3 : 2) : (tix >= LC ? 1 : 0), col = tix - ch * LC;
@@ -737,8 +872,19 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         }
     }
     __syncthreads();
-    HPK_CLK(ck2)
-    {
+    HPK_CLKQ(ck2)
+    if (L) {
+        if (wave < 10) {
+            const int tix = wave * 64 + lane;
+            const int ch = tix >= 2 * LC ? (tix >= 3 * LC ? 3 : 2) : (tix >= LC ? 1 : 0), col = tix - ch * LC;
+            unsigned base = ch >= 1 ? utot3[col] : 0u;
+            base += ch >= 2 ? utot3[LC + col] : 0u;
+            base += ch >= 3 ? utot3[2 * LC + col] : 0u;
+            unsigned* __restrict__ dst = &Sp[(16 * ch) * LC + col];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dst[i * LC] = creg[i] + base;
+        }
+    } else {
         if (wave < 10) {
             const int tix = wave * 64 + lane;
             const int ch = tix >= 2 * LC ? (tix >= 3 * LC ? 3 : 2) : (tix >= LC ? 1 : 0), col = tix - ch * LC;
@@ -759,37 +905,34 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         }
     }
     __syncthreads();
+    return cm_out;
+    };
+    const unsigned cm_lean = lean ? phase12(std::true_type{}) : phase12(std::false_type{});
     // the next tile's column weights are in: into the LDS table (nobody reads it before the barrier that ends this tile)
-    if (!BALF64 && pre_next && wave < 3) {
-        const int tix = wave * 64 + lane;
-        if (tix < LC) wct[tix] = nxt.wcol == nxt.wcol ? nxt.wcol : 0.0;
-    }
-    HPK_CLK(ck3)
+    if (!BALF64 && pre_next && wave < 3) put_wct(wave, lane);
+    HPK_CLKQ(ck3)
     const int total = a.dbg_stop == 2 ? 0 : (int)*tcnt;         // (profiling ablation 2: the tables only, no batches)
     // gap rows (callers.py:238): rows of the tile's columns (the last tile of a row block: up to the end of its halo)
     // without a non-zero balanced value - exact on the valid-count field
     const int tx = wave * 64 + lane;             // (not threadIdx.x: its address arithmetic would be hoisted and spilled)
     if (tx < TR && r0 + tx < n) {
-        const bool last = (cj == a.J - 1) || (c0 + TC >= n) || (mw + (cj + 1) * TC - (TR - 1)) > a.Dg;
+        const bool last = (cj == J_p - 1) || (c0 + TC >= n) || (mw + (cj + 1) * TC - (TR - 1)) > Dg_p;
         const int Y = tx + W + 1;
         unsigned rs = Sp[Y * LC + W] - Sp[(Y - 1) * LC + W];
         const int xe = last ? W : W + TC;        // last: nothing is taken off (the two reads below cancel)
         rs -= last ? 0u : Sp[Y * LC + xe] - Sp[(Y - 1) * LC + xe];
         if ((rs >> PK_SHIFT) != 0u) gptr(bd->gap)[r0 + tx] = 1;
     }
-    if (tx == 0) { tcount[par ^ 1] = 0u; tcount[4 + (par ^ 1)] = 0u; }    // the next tile's counters (its atomics start after the barrier below)
+    if (tx == 0) { tcount[par ^ 1] = 0u; tcount[4 + (par ^ 1)] = 0u; tflag[par ^ 1] = 0u; }    // the next tile's counters (its atomics start after the barrier below)
     // ---- phase 3: batches of 64 candidates, dealt round-robin to the waves
-    const int64_t tbase = (int64_t)tid * a.tilecap;
+    const int64_t tbase = (int64_t)tid * tilecap_p;
     unsigned* __restrict__ ent_t = gptr(bd->rec_ent) + tbase;
     HPK_CLK(ck4)
-#pragma unroll 1
-    for (int b = wave; b * 64 < total; b += NW) {
+    // one batch: up to 64 candidates (entry `id` where `cand`) - first sufficient width, resolve counts, record, sums
+    auto batch = [&](const unsigned id, const bool cand, const bool lean) __attribute__((always_inline)) {
 #ifdef HPK_PHASE_CLOCK
         ck7 += 1ull;
 #endif
-        const int i = b * 64 + lane;
-        const bool cand = i < total;
-        const unsigned id = lst[cand ? i : 0];
         const int x = (int)HPK_ENT_X(id);
         const int y = (int)HPK_ENT_Y(id);
         const int base = (y + W + 1) * LC + W + x;
@@ -798,9 +941,9 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         const unsigned cb = lds0 + (unsigned)base * 8u, pb = lds0 + (unsigned)(LR * LC * 8) + (unsigned)base * 4u;
         const unsigned sr = lds_u32(pb);
         const bool diffp = SINGLE && sp_p > 0;                      // Box(w*) - Box(p): see box_ky_d
-        const double sc = lds_f64(cb);
+        const double sc = lean ? 0.0 : lds_f64(cb);
         double pixc = 0.0, amax = 0.0;
-        if (SINGLE && !diffp) {
+        if (SINGLE && !diffp && !lean) {
             pixc = (sc - lds_f64(cb + 8)) - (lds_f64(cb - LC * 8) - lds_f64(cb - LC * 8 + 8));
             amax = lds_f64(cb + (unsigned)(W * (LC - 1) * 8));
         }
@@ -867,11 +1010,12 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         // by one ballot per width.
         // (The f64-input variants are out of registers - their prefetch holds 30 instead of 16 - and keep the ballots.)
         if (!BALF64) {
-            const unsigned off = (unsigned)(wstar - wmin_p);              // 255 - min(ww) >= 8 for "no sufficient width"
+            // (a pass that computes its tile once more does not count: the tile's first pass did)
+            const unsigned off = is_redo ? 255u : (unsigned)(wstar - wmin_p);     // 255 - min(ww) >= 8 for "no sufficient width"
             const unsigned long long inc = 1ull << ((off & 3u) * 16u);
             hpack0 += off < 4u ? inc : 0ull;
             hpack1 += (off - 4u) < 4u ? inc : 0ull;
-            if (W - wmin_p >= 8 && ballot64((off >= 8u) & (wstar != 255)) != 0ull) {
+            if (W - wmin_p >= 8 && ballot64((off >= 8u) & (off != 255u) & (wstar != 255)) != 0ull) {
 #pragma unroll 1
                 for (int w = wmin_p + 8; w <= W; ++w) {
                     const unsigned c = (unsigned)__popcll(ballot64(wstar == w));
@@ -896,7 +1040,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         // waited for after the box sums.
         const bool live = cand & (wstar <= wg_p);
         const unsigned long long lm = ballot64(live);
-        if (lm == 0ull) continue;
+        if (lm == 0ull) return;
         unsigned rslot = 0u;
         {
             const unsigned addr = (unsigned)(size_t)(tcount + 4 + par);
@@ -905,6 +1049,17 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
                          : "=&v"(rslot) : "v"(addr), "v"(nl) : "memory");
         }
         wstar = live ? wstar : 255;                 // (candidates beyond the bound count as unresolved from here on)
+        if (LEAN_OK && lean) {
+            // a lean tile has no f64 table: up to a.lean_max candidates that count get their sums cell by cell below; a batch
+            // that would go beyond gives the tile up - it is computed once more in full, and writes its records then
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rslot) :: "memory");
+            const unsigned before = (unsigned)__builtin_amdgcn_readfirstlane((int)rslot), nl = (unsigned)__popcll(lm);
+            if (before + nl > (unsigned)a.lean_max) {
+                if (lane == 0) tflag[par] = 1u;
+                return;
+            }
+            myexpl += nl;
+        }
         // general plans: the innermost box is the same in every step of every slot - formed once per candidate
         double kc0 = 0.0, yc0 = 0.0, big0 = 0.0;
         if (!SINGLE && fr_p > 0) box_ky_d(cb, fr_p, sc, kc0, yc0, big0);
@@ -923,7 +1078,17 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             }
             const bool act = sq != 0xff;
             double SK = 0.0, SY = 0.0;
-            if (ballot64(act) != 0ull) {
+            if (LEAN_OK && lean) {
+                unsigned long long todo = ballot64(act);
+                while (todo != 0ull) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1ull;
+                    const int er = __builtin_amdgcn_readlane(r0 + y, src), ec = __builtin_amdgcn_readlane(c0 + x, src);
+                    const int es = __builtin_amdgcn_readlane(sq, src);
+                    const double2 ex = explicit_sums_wave(gptr(bd->raw), gptr(bd->bal), gptr(bd->weight), plan->steps[es].m, W, er, ec, n, bd->num, bd->ld, mw, lane);
+                    if (lane == src) { SK = ex.x; SY = ex.y; }
+                }
+            } else if (ballot64(act) != 0ull) {
                 unsigned w0 = 0u, k0 = 0u, k1 = 0u, k2 = 0u, k3 = 0u;
                 int nkt = 0, rho_min;
                 if (SINGLE) {
@@ -1034,6 +1199,39 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
                 gptr(bd->rec_W)[o] = act ? (uint8_t)(sq + 1) : (uint8_t)0;
             }
         }
+    };
+    if (LEAN_OK && lean) {
+        // ---- lean tile: no list.  Every lane goes through its own candidates (bit 9 - e of the mask phase 1 left) and tests
+        // the widest Reads box - what decides "resolves within the bound at all"; the few that pass are a batch of their own.
+        if (a.dbg_stop != 2) {
+            const int Y = 4 * wave + (lane >> 4), XH = (LC - 1) - 10 * (lane & 15);
+            const unsigned prow = lds0 + (unsigned)(LR * LC * 8) + (unsigned)(Y * LC + XH) * 4u;      // P(Y, XH) of the packed plane; cell e: - 4 e
+            unsigned bits = cm_lean;
+#pragma unroll 1
+            while (ballot64(bits != 0u) != 0ull) {
+                const bool on = bits != 0u;
+                const int bpos = on ? 31 - __clz((int)bits) : 0;            // bit 9 - e, descending columns first
+                bits = on ? bits & ~(1u << bpos) : 0u;
+                const int e = 9 - bpos;
+                const unsigned pb = prow - 4u * (unsigned)e;
+                const unsigned sr = lds_u32(pb);
+                const unsigned bl = reads_box_b(pb, W, sr);
+                // (Reads = widest box - box p0 >= min_local_reads needs the widest box alone to reach it)
+                if (ballot64(on & (bl >= (unsigned)minr_p)) == 0ull) continue;
+                const unsigned b0 = (p0_p > 0) ? reads_box_b(pb, p0_p, sr) : 0u;
+                const bool hit = on & (bl - b0 >= (unsigned)minr_p);
+                if (ballot64(hit) == 0ull) continue;
+                const unsigned cnt = (sr - lds_u32(pb + 4u) - lds_u32(pb - (unsigned)(LC * 4)) + lds_u32(pb - (unsigned)(LC * 4) + 4u)) & PK_MASK;
+                batch((unsigned)(XH - e - W) | ((unsigned)(Y - (W + 1)) << HPK_ENT_YSHIFT) | (cnt << HPK_ENT_CNT_SHIFT), hit, true);
+            }
+        }
+    } else {
+#pragma unroll 1
+        for (int b = wave; b * 64 < total; b += NW) {
+            const int i = b * 64 + lane;
+            const bool cand = i < total;
+            batch(lst[cand ? i : 0], cand, false);
+        }
     }
     HPK_CLK(ck5)
     // (written by wave 0 at the top of this round, three barriers ago: in flight across the barrier below)
@@ -1041,6 +1239,9 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     bnext = lds_u32(lds0 + (unsigned)((unsigned char*)tband - smem) + (unsigned)tpar * 4u);
     __syncthreads();                 // every wave is done with this tile's SAT and list
     HPK_CLK(ck6)
+    // a lean tile that met more candidates that count than the cell-by-cell path takes: once more, in full
+    bool need_redo = false;
+    if (LEAN_OK && lean) need_redo = __builtin_amdgcn_readfirstlane((int)lds_u32(lds0 + (unsigned)((unsigned char*)tflag - smem) + (unsigned)par * 4u)) != 0;
     if (wave == 0) {
         // scoring work list: one entry per HPK_UNIT records.  The slot reservation (a returning atomic on one global
         // counter) of this tile is only consumed when the next tile ends.
@@ -1050,16 +1251,22 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             if ((unsigned)lane < nu) gptr(bands[pend_band].units)[off + lane] = make_uint2((unsigned)pend_tid, (unsigned)lane | (pend_c << 8));
         }
         pend_tid = -1;
-        const unsigned nrec = (unsigned)__builtin_amdgcn_readfirstlane((int)tcount[4 + par]);    // records of this tile
-        if (nrec > 0u) {
-            pend_tid = tid;
-            pend_band = band;
-            pend_c = nrec;
-            if (lane == 0) pend_off = atomicAdd(reinterpret_cast<unsigned*>(gptr(bd->small) + HPK_OFF_NUNITS), (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT);
+        if (!need_redo) {
+            const unsigned nrec = (unsigned)__builtin_amdgcn_readfirstlane((int)tcount[4 + par]);    // records of this tile
+            if (nrec > 0u) {
+                pend_tid = tid;
+                pend_band = band;
+                pend_c = nrec;
+                if (lane == 0) pend_off = atomicAdd(reinterpret_cast<unsigned*>(gptr(bd->small) + HPK_OFF_NUNITS), (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT);
+            }
+            if (lane == 0) gptr(bd->tile_cnt)[tid] = nrec;
         }
-        if (lane == 0) { gptr(bd->tile_cnt)[tid] = nrec; mycand += (unsigned)total; }
+        // (the candidates and their resolve counts: once per tile, by its first pass)
+        if (!is_redo) mycand += (unsigned)total;
+        if (LEAN_OK && lean) mylean += need_redo ? 0x10001u : 1u;
     }
-    have = have_next; rb = rb_next; cj = cj_next; bw = bw_next;
+    if (need_redo) { redo = true; redo_tn = tn; redo_bn = bw_next; }
+    else { redo = false; have = have_next; rb = rb_next; cj = cj_next; bw = bw_next; }
     par ^= 1;
     } while (have && bw == cbw);   // tile loop of the band
     }   // bands
@@ -1208,51 +1415,125 @@ __global__ void __launch_bounds__(256) hpk_ir_final(const HpkBandDesc* __restric
     const long long denom = (long long)(n - k) - (long long)nn;
     gptr(bd->IR)[k] = (k >= mw && n - k > 0) ? s / (double)denom : 0.0;       // 0/0 -> NaN like numpy's mean of an empty slice
 }
-// ------------------------------------------------------------------ record bound by depth class
+// ------------------------------------------------------------------ record bound by depth class, lean column chunks
 // The width at which a chromosome's widening freezes grows with its depth; a context that serves chromosomes of several
 // samples would otherwise write every band's records up to the deepest sample's width (hpk_api.cpp: the bound is verified at
-// collection whatever it was).  One workgroup per band: the mean count per band pixel over every 64th row, its quarter octave.
-__global__ void __launch_bounds__(1024) hpk_band_class(HpkBandDesc* __restrict__ bands, int mw, int D, const signed char* __restrict__ table,
-                                                      int wg_all, int margin, int wmin) {
+// collection whatever it was).  One workgroup per band: the counts of every 64th row, summed per diagonal (integers: the
+// same sums whatever the order of the adds); their mean over the band's pixels, its quarter octave = the depth class.
+// From the same sums: the column chunks whose tiles the stencil builds without their f64 plane (hpk_stencil_s, lean tiles).  A
+// candidate counts if its Reads - the lower-left rings p0 + 1 .. w of the raw counts, w up to the band's bound - reach
+// min_local_reads (callers.py:197-217); for the pixels of chunk c nearest to the diagonal the mean of that sum follows from
+// the per-diagonal means, and chunks from the first one on after which it stays below lean_frac x min_local_reads are lean
+// (a prediction, verified tile by tile: a lean tile with more than a handful of candidates that count is computed once more).
+// Lean tiles take "count, row weight and column weight non-zero" for "balanced value non-zero": not with weights so small
+// that a product of two underflows (none in practice; checked here).
+#define HPK_CLS_KMAX 4096                           // diagonals profiled (beyond: the last profiled one stands for the rest)
+__global__ void __launch_bounds__(1024) hpk_band_class(HpkBandDesc* __restrict__ bands, HpkClassArgs a) {
     HpkBandDesc* bd = bands + blockIdx.x;
     const int n = bd->n, num = bd->num;
     const int64_t ld = bd->ld;
-    const int Dm = D < num - 1 ? D : num - 1;
+    const int mw = a.mw;
+    const int Dm = a.D < num - 1 ? a.D : num - 1;
     const float* __restrict__ raw = gptr(bd->raw);
-    double sum = 0.0;
-    const int wave = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
-    for (int r = 64 * wave; r < n; r += 64 * 16) {      // (a wave per sampled row: sixteen rows in flight)
-        const int kmax = Dm < n - 1 - r ? Dm : n - 1 - r;
-        for (int k = mw + lane; k <= kmax; k += 64) sum += (double)raw[(int64_t)r * ld + k];
-    }
-    __shared__ double red[1024];
-    red[threadIdx.x] = sum;
+    __shared__ unsigned long long S[HPK_CLS_KMAX];  // per diagonal: sum of the sampled rows' counts
+    __shared__ unsigned long long tot;
+    __shared__ int lean_from, tiny_w, wg_s;
+    const int t = (int)threadIdx.x;
+    // every 64th row; chromosomes beyond 32 768 bins: every 128th, 192nd ... (at most 512 sampled rows)
+    const int RS = 64 * ((n + 32767) / 32768);
+    const int KP = num < HPK_CLS_KMAX ? num : HPK_CLS_KMAX;
+    for (int k = t; k < KP; k += 1024) S[k] = 0ull;
+    if (t == 0) { tot = 0ull; lean_from = 0; tiny_w = 0; }
     __syncthreads();
-    for (int m = 512; m > 0; m >>= 1) {
-        if ((int)threadIdx.x < m) red[threadIdx.x] += red[threadIdx.x + m];
-        __syncthreads();
+    {
+        // thread -> (diagonal, group of sampled rows): consecutive threads read consecutive diagonals of one row
+        const int KPr = (KP + 63) & ~63;
+        const int G = KPr <= 1024 ? 1024 / KPr : 1;
+        for (int idx = t; idx < KPr * G; idx += 1024) {
+            const int g = idx / KPr, k = idx - g * KPr;
+            if (k >= KP) continue;
+            unsigned long long acc = 0ull;
+            for (int r = RS * g; r + k < n; r += RS * G) acc += (unsigned long long)raw[(int64_t)r * ld + k];
+            if (acc) atomicAdd(&S[k], acc);
+            if (k >= mw && k <= Dm && acc) atomicAdd(&tot, acc);
+        }
+        if (Dm >= HPK_CLS_KMAX) {       // (bands wider than the profile: the class still sees every band diagonal)
+            unsigned long long acc = 0ull;
+            for (int k = HPK_CLS_KMAX + t; k <= Dm; k += 1024)
+                for (int r = 0; r + k < n; r += RS) acc += (unsigned long long)raw[(int64_t)r * ld + k];
+            if (acc) atomicAdd(&tot, acc);
+        }
+        if (a.lean && gptr(bd->weight)) {
+            const double* __restrict__ w = gptr(bd->weight);
+            bool tiny = false;
+            for (int i = t; i < n; i += 1024) { const double v = fabs(w[i]); tiny = tiny || (v != 0.0 && v < 1e-150); }
+            if (tiny) tiny_w = 1;
+        }
     }
-    if (threadIdx.x == 0) {
+    __syncthreads();
+    if (t == 0) {
         long long cells = 0;
-        for (int r = 0; r < n; r += 64) {
+        for (int r = 0; r < n; r += RS) {
             const int kmax = Dm < n - 1 - r ? Dm : n - 1 - r;
             cells += kmax >= mw ? kmax - mw + 1 : 0;
         }
         int cls = 0;
-        if (cells > 0 && red[0] > 0.0) {
-            cls = (int)floor(4.0 * log2(red[0] / (double)cells)) + 32;
+        if (cells > 0 && tot > 0ull) {
+            cls = (int)floor(4.0 * log2((double)tot / (double)cells)) + 32;
             cls = cls < 0 ? 0 : (cls > HPK_NCLASS - 1 ? HPK_NCLASS - 1 : cls);
         }
-        const int t = (int)table[cls];
-        int wg = wg_all;
-        if (t >= 0) {
-            wg = t + margin;
-            wg = wg < wmin ? wmin : wg;
-            wg = wg < wg_all ? wg : wg_all;
+        int wg = a.wg_all;
+        if (a.table) {
+            const int tb = (int)a.table[cls];
+            if (tb >= 0) {
+                wg = tb + a.margin;
+                wg = wg < a.wmin ? a.wmin : wg;
+                wg = wg < a.wg_all ? wg : a.wg_all;
+            }
+            bd->wguess = wg;
+            // ... and the band's tiles are laid out for that bound's halo (at least 4, at least the plan's narrowest width)
+            int halo = bd->W;
+            if (a.halo) {
+                int Wh = wg > a.wmin ? wg : a.wmin;
+                Wh = Wh > 4 ? Wh : 4;
+                if (Wh < bd->W) {
+                    const HpkGeo g = hpk_geo_of(Wh, a.planW, a.D, mw, a.tr_cap);
+                    bd->W = g.W; bd->Dg = g.Dg; bd->TR = g.TR; bd->TC = g.TC; bd->J = g.J; bd->tilecap = g.tilecap;
+                    bd->ntiles = ((n + g.TR - 1) / g.TR) * g.J;
+                    bd->chunk = (bd->ntiles + 7) / 8;
+                    bd->rec_stride = (int64_t)bd->ntiles * g.tilecap;
+                    halo = Wh;
+                }
+            }
+            *reinterpret_cast<unsigned*>(gptr(bd->small) + HPK_OFF_BCLASS) = 0x10000u | ((unsigned)halo << 20) | ((unsigned)cls << 8) | (unsigned)wg;
         }
-        bd->wguess = wg;
-        *reinterpret_cast<unsigned*>(gptr(bd->small) + HPK_OFF_BCLASS) = 0x10000u | ((unsigned)cls << 8) | (unsigned)wg;
+        wg_s = wg;
     }
+    __syncthreads();
+    const int gTR = bd->TR, gTC = bd->TC, gJ = bd->J;      // (thread 0's writes: behind the barrier)
+    int lean_cj = 0x7fffffff;
+    if (a.lean && !tiny_w && gptr(bd->weight)) {
+        const int wg = wg_s;
+        // mean count of a pixel on diagonal k: S[k] over the sampled rows that hold it
+        auto mu = [&](int k) -> double {
+            if (k < 0) return 0.0;                  // below the main diagonal: not stored, not counted (callers.py:50-96)
+            k = k < KP ? k : KP - 1;
+            const int rows = (n - k + RS - 1) / RS;
+            return rows > 0 ? (double)S[k] / (double)rows : 0.0;
+        };
+        for (int c = t; c < gJ; c += 1024) {
+            int kd = mw + c * gTC - (gTR - 1);       // the chunk's pixels nearest to the diagonal
+            kd = kd < mw ? mw : kd;
+            double lam = 0.0;                        // mean Reads there at the band's bound: lower-left cells (i, j), i, j = 1 .. wg, without the p0 x p0 corner
+            for (int i = 1; i <= wg; ++i)
+                for (int jj = 1; jj <= wg; ++jj)
+                    if (i > a.p0 || jj > a.p0) lam += mu(kd - i - jj);
+            if (!(lam <= (double)a.lean_frac * (double)a.minr)) atomicMax(&lean_from, c + 1);
+        }
+        __syncthreads();
+        lean_cj = lean_from;
+    }
+    if (t == 0) bd->lean_cj = lean_cj;
 }
 
 // ------------------------------------------------------------------ freeze
@@ -1465,6 +1746,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
     const double* __restrict__ b_etab = gptr(bd->etab);
     const double* __restrict__ b_eedge = gptr(bd->eedge);
     const int b_n = bd->n;
+    const int b_J = bd->J, b_TR = bd->TR, b_TC = bd->TC, b_tilecap = bd->tilecap;      // the band's tile geometry
     HpkSurv* __restrict__ b_surv = gptr(bd->surv);
     unsigned long long* __restrict__ b_nsurv = reinterpret_cast<unsigned long long*>(small + HPK_OFF_NSURV);
     const int npairs = ONE ? 1 : plan->npairs;
@@ -1538,12 +1820,12 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
     auto decode = [&](const uint2 un, Geo& g) {
         const int tile = (int)un.x, ub = (int)(un.y & 255u);
         g.cnt = (int)(un.y >> 8);
-        const int rb = tile / a.J, cj = tile - rb * a.J;
-        g.r0 = rb * a.TR;
-        g.c0 = g.r0 + a.mw + cj * a.TC;
+        const int rb = tile / b_J, cj = tile - rb * b_J;
+        g.r0 = rb * b_TR;
+        g.c0 = g.r0 + a.mw + cj * b_TC;
         g.i0 = ub * HPK_UNIT;
         g.iend = (g.i0 + HPK_UNIT < g.cnt) ? g.i0 + HPK_UNIT : g.cnt;
-        g.tbase0 = (int64_t)tile * a.tilecap;
+        g.tbase0 = (int64_t)tile * b_tilecap;
     };
     auto set_pair = [&](Geo& g, const int pj) {
         g.pj = pj;
@@ -2046,8 +2328,8 @@ static void launch_stencil_s_t(const HpkStencilArgs& a, const HpkBandDesc* d_ban
 
 // The buffer-addressing limits of hpk_stencil_s: 32-bit byte offsets inside one tile's rows, weights addressed from element 0;
 // a halo of at least 4 (plans with maxww < 4 keep a halo of 4: widths beyond maxww have no step).
-bool hpk_stencil_s_applies(const HpkStencilArgs& a, int64_t max_ld, int32_t max_n) {
-    return max_ld <= (int64_t)(1 << 21) && max_n < (1 << 27) && a.W >= 4 && a.TR * a.TC <= HPK_TLIST;
+bool hpk_stencil_s_applies(const HpkGeo& g, int64_t max_ld, int32_t max_n) {
+    return max_ld <= (int64_t)(1 << 21) && max_n < (1 << 27) && g.W >= 4 && g.TR * g.TC <= HPK_TLIST;
 }
 
 void hpk_launch_stencil_batch(const HpkStencilArgs& a, const HpkBandDesc* d_bands, bool balf64, hipStream_t st) {
@@ -2189,9 +2471,8 @@ void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe
     hipLaunchKernelGGL(hpk_ptab, dim3((total + 255) / 256), dim3(256), 0, st, bounds, off, sfe, ptab, total);
 }
 
-void hpk_launch_band_class(HpkBandDesc* d_bands, int nbands, int mw, int D, const signed char* table, int wg_all, int margin, int wmin,
-                           hipStream_t st) {
-    if (nbands > 0) hipLaunchKernelGGL(hpk_band_class, dim3(nbands), dim3(1024), 0, st, d_bands, mw, D, table, wg_all, margin, wmin);
+void hpk_launch_band_class(HpkBandDesc* d_bands, int nbands, const HpkClassArgs& a, hipStream_t st) {
+    if (nbands > 0) hipLaunchKernelGGL(hpk_band_class, dim3(nbands), dim3(1024), 0, st, d_bands, a);
 }
 
 void hpk_launch_coo_scatter(const int64_t* bin1, const int64_t* bin2, const void* count, int count_f64, int64_t nnz, int n, int num,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define HPK_ABI_VERSION 2
+#define HPK_ABI_VERSION 3
 #define HPK_MAX_BATCH   256    /* chromosomes per hpk_submit_batch */
 #define HPK_MAX_PAIRS   8      /* (pw, ww) pairs per call */
 #define HPK_MAX_W       20     /* largest supported maxww (reference keyword default, callers.py:45) */
@@ -160,8 +160,7 @@ typedef struct {
 
     /* timing, milliseconds (HIP events on the ctx stream; wall for host parts) */
     float ms_h2d, ms_stencil, ms_freeze, ms_score, ms_tighten, ms_gap, ms_d2h, ms_host_bh, ms_total;
-    int32_t stencil_kernel;    /* stencil kernel that ran: always 2 = hpk_stencil_s (the one generation there is; the field is kept
-                                  for ABI v2 callers) */
+    int32_t stencil_kernel;    /* stencil kernel that ran: always 2 = hpk_stencil_s (the one generation there is) */
     int32_t record_bound;      /* the stencil wrote records for candidates resolved up to this width (255: all of them;
                                   HPK_FLAG_DENSE_*, HPK_FLAG_NO_SCORE); see hpk_submit_band */
     int32_t redone;            /* bit 0: the widening froze beyond the bound taken from the previous chromosome and the
@@ -179,6 +178,12 @@ typedef struct {
                                   kernel, hpk_set_option spec_halo = 1 (default) - the record bound.  Box sums are differences of
                                   table entries summed from the tile's corner, so two runs of one chromosome under different halos
                                   agree to ~1e-13 relative in E / p / q (coordinates, counts and the widening log exactly) */
+    /* ABI v3 */
+    int32_t lean_tiles;        /* tiles built without their f64 plane (far from the diagonal next to no candidate resolves within the
+                                  record bound: hpk_set_option "lean"); the few candidates of such a tile that do count get their
+                                  sums cell by cell from the band */
+    int32_t lean_redone;       /* of those, tiles that met more such candidates than "lean_max" and were computed once more in full */
+    int64_t lean_explicit;     /* candidates whose sums were formed cell by cell in a lean tile */
 } hpk_result;
 
 typedef struct hpk_ctx hpk_ctx;
@@ -236,7 +241,10 @@ int  hpk_collect_batch(hpk_ctx* ctx, hpk_job* job, hpk_result** outs, int32_t* s
  * batch's bound, hpk_result::record_bound is the chromosome's own; 0: one bound per batch), "class_force" (tests), "spec_surv" (0: a survivor record for every p <= sig; 1 [default]: only up to the histogram bin the families' cuts fell
  * into in the chromosomes before, minus "spec_surv_margin" bins - verified, hpk_result::redone bit 1), "spec_surv_force" (tests),
  * "host_threads" (threads of a batch's host half), "spec_halo" (0: tiles always under maxww's halo - runs of one chromosome are then bit-identical whatever the bound), "risk_log2" (exact-fallback threshold 2^-x), "tile_order", "gap_kernel" (1: gap rows by the row kernel),
- * "score_div" (tiles per scoring workgroup of a batch), "dbg_stop" (profiling ablation), "reset_hints" (forget the bounds
+ * "score_div" (tiles per scoring workgroup of a batch), "dbg_stop" (profiling ablation), "lean" (1 [default]: tiles of the column chunks
+ * whose mean Reads stays below "lean_frac_pct" % of min_local_reads - sampled per chromosome on the device - are built without their
+ * f64 plane; up to "lean_max" candidates of such a tile that resolve within the bound get their sums cell by cell, a tile with more
+ * is computed once more in full; weight input only, off under spec_halo = 0), "reset_hints" (forget the bounds
  * learnt from the chromosomes collected so far).  Returns HPK_ERR_INVALID for an
  * unknown name or a value out of range. */
 int  hpk_set_option(hpk_ctx* ctx, const char* name, int64_t value);

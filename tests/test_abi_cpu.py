@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.ABI_SYMBOLS), declared ^ set(_lib.ABI_SYMBOLS)
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.hpk_abi_version() == 2
+    assert lib.hpk_abi_version() == 3
 
 
 def test_ctypes_struct_sizes_match_header(tmp_path):

@@ -151,6 +151,41 @@ def test_golden_parity_under_the_inherited_bound(name):
         c.close()
 
 
+@pytest.mark.parametrize('lean_max', [4096, 3, 1])
+@pytest.mark.parametrize('name', [n for n in golden_names()])
+def test_golden_parity_lean_tiles(name, lean_max):
+    """Every fixture with EVERY tile built without its f64 plane (option lean_frac_pct far above any mean Reads: the
+    prediction of hpk_band_class says "no candidate resolves anywhere").  lean_max = 4096: every candidate that counts gets its
+    sums cell by cell from the band (explicit_sums_wave); 3 / 1: nearly every tile meets more than that and is computed once
+    more in full - counted once, records written once.  Same expectations as the default path."""
+    g = load_golden(name)
+    if 'prep_exception' in g.meta or 'exception' in g.meta:
+        pytest.skip('no result to compare')
+    c = _lib.Context(0)
+    try:
+        c.set_option('lean_frac_pct', 100000)
+        c.set_option('lean_max', lean_max)
+        d = {}
+        final = _call(g, c, 'weight', d)
+        R = d['result']
+        _check_golden(g, R, final)
+        generic = list(g.params['pw']) != sorted(g.params['pw']) if g.mode == 'hiccups' else False
+        # (plans without a monotone Reads matrix have no lean tiles; tiles without a stored pixel are skipped, not built)
+        assert R.lean_tiles <= R.tiles
+        if not generic and R.lean_tiles:
+            resolved = sum(c for _, _, c, ex in R.steps if ex)
+            if lean_max == 4096:
+                assert R.lean_redone == 0 and (R.lean_explicit > 0 or resolved == 0)
+            elif resolved > 200:
+                assert R.lean_redone > 0
+        # once more under the bound this call left behind, tiles laid out for its halo
+        d2 = {}
+        final = _call(g, c, 'weight', d2)
+        _check_golden(g, d2['result'], final)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize('name', ['hiccups_union_shallow', 'hiccups_p2w5_shallow', 'hiccups_swapped_pairs',
                                   'hiccups_p1w3_short', 'hiccups_union_frozen'])
 def test_dense_sums_match_oracle(name, ctx):
@@ -678,9 +713,10 @@ def test_record_bound_by_depth_class():
         for got, d in zip(first + second + third, (a, b, a, b) * 3):
             _same_result(got, want[d])
         # from the second batch on the bound exists, from the third every class is known: each chromosome under its own width,
-        # the tiles under the widest
+        # its tiles laid out for its own bound's halo (at least 4, at least the plan's narrowest width)
         for got, d in zip(third, (a, b, a, b)):
-            assert got.record_bound == fw[d] and not got.redone and got.halo_w == fw[b], (d, got.record_bound, fw, got.halo_w)
+            assert got.record_bound == fw[d] and not got.redone, (d, got.record_bound, fw, got.halo_w)
+            assert got.halo_w == max(fw[d], 5, 4), (d, fw, got.halo_w)
         c.set_option('spec_class', 0)
         flat = c.submit_batch_host(batch, prm).results()
         assert all(g.record_bound == fw[b] and not g.redone for g in flat)
