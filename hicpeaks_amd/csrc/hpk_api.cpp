@@ -73,7 +73,7 @@ struct Lane {
     int nev = 0;
     bool busy = false;
     // workspaces (grow only), pooled over the bands of a batch
-    DevBuf raw, bal, weight, IR, b1, b2, plan, etab, eedge, recE, recS, recW, dE, dW, dS, small, surv, surv2, survx, survx2, cux, psum, pnan, units, desc, kmin, classtab;
+    DevBuf raw, bal, weight, IR, b1, b2, plan, etab, eedge, recE, recS, recW, dE, dW, dS, small, surv, surv2, survx, survx2, cux, psum, pnan, units, desc, kmin, classtab, redoq;
     void* h_head = nullptr;             // pinned: per band counters | row flags | first survivors
     size_t h_head_cap = 0;
     void* h_desc = nullptr;             // pinned staging of the band descriptors
@@ -84,7 +84,7 @@ struct Lane {
     HpkDevPlan plan_host;
     void release() {
         DevBuf* all[] = {&raw, &bal, &weight, &IR, &b1, &b2, &plan, &etab, &eedge, &recE, &recS, &recW, &dE, &dW, &dS, &small,
-                         &surv, &surv2, &survx, &survx2, &cux, &psum, &pnan, &units, &desc, &kmin, &classtab};
+                         &surv, &surv2, &survx, &survx2, &cux, &psum, &pnan, &units, &desc, &kmin, &classtab, &redoq};
         for (DevBuf* b : all) b->release();
         if (h_head) { (void)hipHostFree(h_head); h_head = nullptr; h_head_cap = 0; }
         if (h_desc) { (void)hipHostFree(h_desc); h_desc = nullptr; h_desc_cap = 0; }
@@ -119,7 +119,8 @@ struct Options {
     int host_threads = 8;       // threads of a batch's host half (hpk_collect_batch), at most one per four chromosomes
     int lean = 1;               // tiles of the column chunks hpk_band_class expects no resolving candidate in are built without their f64 plane
     int lean_max = 24;          // ... candidates of such a tile that do count and get their sums cell by cell; more: the tile is computed once more
-    int lean_frac_pct = 50;     // ... a chunk is lean when the mean Reads of its nearest pixels is at most this share of min_local_reads
+    int lean_share_pct = 50;    // ... and a band has lean tiles only if at least this share of its column chunks is lean (below: hpk_stencil_s does them as fast)
+    int lean_frac_pct = 35;     // ... a chunk is lean when the mean Reads of its nearest pixels is at most this share of min_local_reads
 };
 
 struct hpk_ctx {
@@ -329,6 +330,7 @@ int hpk_create(int device, hpk_ctx** out) {
     o.lean = env_int("HPK_LEAN", o.lean) ? 1 : 0;
     o.lean_max = std::max(0, std::min(4096, env_int("HPK_LEAN_MAX", o.lean_max)));
     o.lean_frac_pct = std::max(0, std::min(400, env_int("HPK_LEAN_FRAC", o.lean_frac_pct)));
+    o.lean_share_pct = std::max(0, std::min(100, env_int("HPK_LEAN_SHARE", o.lean_share_pct)));
     *out = c;
     return HPK_OK;
 }
@@ -355,6 +357,7 @@ int hpk_set_option(hpk_ctx* c, const char* name, int64_t v) {
     else if (k == "spec_class" && (v == 0 || v == 1)) o.spec_class = (int)v;
     else if (k == "lean" && (v == 0 || v == 1)) o.lean = (int)v;
     else if (k == "lean_max" && v >= 0 && v <= 4096) o.lean_max = (int)v;
+    else if (k == "lean_share_pct" && v >= 0 && v <= 100) o.lean_share_pct = (int)v;
     else if (k == "lean_frac_pct" && v >= 0 && v <= 100000) o.lean_frac_pct = (int)v;       // (tests: a large share makes every chunk lean)
     else if (k == "class_force" && v >= -1 && v <= 127) { std::memset(c->class_w, (int)v, sizeof(c->class_w)); std::memset(c->class_w1, (int)v, sizeof(c->class_w1)); }     // tests: every depth class claims this width
     else if (k == "reset_hints") { c->hint_n = 0; c->hint_bn = 0; { std::memset(c->class_w, -1, sizeof(c->class_w)); std::memset(c->class_w1, -1, sizeof(c->class_w1)); } }     // forget the bounds learnt from the chromosomes collected so far
@@ -537,7 +540,9 @@ int launch_compute(hpk_ctx* c, hpk_job* j, int b0, int nbl, bool solo, bool with
             int kall = 0;
             for (int b = b0; b < b0 + nbl; ++b) kall += j->bands[b].d.chunk;
             sa.grid = std::max(8, std::min((c->cus / 8) * 8, kall * 8));
-            hpk_launch_stencil_batch(sa, dd, j->balf64, c->stream);
+            if (solo) { sa.lean_max = 0; sa.redoq = nullptr; }      // (a chromosome on its own again: every tile in full)
+            else if (sa.redoq) HIPCHK(c, hipMemsetAsync(sa.redoq, 0, 16, c->stream));
+            hpk_launch_stencil_batch(sa, dd, j->balf64, c->cus, c->stream);
             HIPCHK(c, hipGetLastError());
         }
         if (j->time_stencil) (void)hipEventRecord(L.ev[2], c->stream);
@@ -665,6 +670,11 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     // geometries a band can end up with (halos from the plan's narrowest width to the batch's).
     const bool class_job = opt.spec && opt.spec_class && j->simple && j->do_score && !dense && wg_all < W && wg_all > (int)plan.wmin;
     const bool band_halo = class_job && opt.spec_halo && GS.W > std::max((int)plan.wmin, 4);
+    // Lean tiles: hpk_band_class tells, per band, from which column chunk on the tiles hold (next to) no candidate that resolves within
+    // the band's bound; those are hpk_stencil_lean's, built without their f64 plane.  Weight input, a monotone Reads matrix, records
+    // under a bound (no dense outputs), and not under spec_halo = 0, whose runs promise bit-identical values whatever the
+    // context scored before (which tiles are lean depends on the bound, and their few sums are formed cell by cell).
+    const bool lean_job = opt.lean && opt.lean_max > 0 && opt.spec_halo && j->simple && j->do_score && !dense && !j->balf64 && wg_all != 255;
     std::vector<HpkGeo> geos{GS, GF};
     if (band_halo) for (int Wh = std::max((int)plan.wmin, 4); Wh < GS.W; ++Wh) geos.push_back(geo_of(Wh));
     const int hbins = (opt.rounds <= -2) ? hpk_score_hist_bins((plan.mode == HPK_MODE_BHFDR) ? 1 : 2 * plan.npairs, plan.mode == HPK_MODE_BHFDR) : 0;
@@ -720,7 +730,8 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         s.off_tc = up256(s.off_hacc + 8 * (size_t)(HPK_MAX_STEPS + 1) * HPK_ACC_STRIDE);
         s.off_cnt = up256(s.off_tc + sizeof(unsigned) * tiles_max);
         s.off_cu = up256(s.off_cnt + sizeof(unsigned) * HPK_NFAM * HPK_TIGHTEN_MAX);
-        s.zero_bytes = (up256(s.off_cu + sizeof(unsigned) * (size_t)(cap / HPK_SCH * HPK_NREG + 1)) + 4095) / 4096 * 4096;
+        const size_t off_wnz = up256(s.off_cu + sizeof(unsigned) * (size_t)(cap / HPK_SCH * HPK_NREG + 1));
+        s.zero_bytes = (off_wnz + (lean_job ? sizeof(unsigned) * (size_t)HPK_WNZ_WORDS(n) : 0) + 4095) / 4096 * 4096;
         s.small_off = tot_small; tot_small += s.zero_bytes;
         s.head_off = tot_head; tot_head += up256(s.head_bytes);
         off_rec[b] = tot_rec; tot_rec += rec_max;
@@ -751,6 +762,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         d.cap = cap; d.zero_bytes = s.zero_bytes; d.off_rowlive = (uint32_t)s.off_rowlive; d.off_inl = (uint32_t)s.off_inl;
         d.derive = derive ? (bands[b].bias1 ? 2 : 1) : 0;       // 1: IR and biases, 2: IR only
         d.lean_cj = 0x7fffffff;                                 // (no lean tiles unless hpk_band_class says where)
+        d.off_wnz = lean_job ? (uint32_t)off_wnz : 0u;
         d.W = GS.W; d.Dg = GS.Dg; d.TR = GS.TR; d.TC = GS.TC; d.J = GS.J; d.tilecap = GS.tilecap;
         d.score_wgs = wgs;
     }
@@ -906,11 +918,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     // sorts the bands into depth classes on the device and gives each the width its class froze at last (verified at collection
     // like the batch's bound: a chromosome that froze later is computed once more).
     j->use_class = class_job;
-    // Lean tiles: the same kernel tells, per band, from which column chunk on the tiles hold (next to) no candidate that resolves
-    // within the band's bound; hpk_stencil_s builds those without their f64 plane.  Weight input, a monotone Reads matrix, records
-    // under a bound (no dense outputs), and not under spec_halo = 0, whose runs promise bit-identical values whatever the
-    // context scored before (which tiles are lean depends on the bound, and their few sums are formed cell by cell).
-    j->use_lean = opt.lean && opt.lean_max > 0 && opt.spec_halo && j->simple && j->do_score && !dense && !j->balf64 && wg_all != 255;
+    j->use_lean = lean_job;
     if (j->use_class || j->use_lean) {
         HpkClassArgs ca;
         std::memset(&ca, 0, sizeof(ca));
@@ -928,8 +936,27 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         ca.halo = band_halo ? 1 : 0; ca.planW = W; ca.tr_cap = tr_cap_s;
         ca.p0 = plan.reads_p0; ca.minr = plan.min_reads;
         ca.lean_frac = (float)opt.lean_frac_pct / 100.f;
+        ca.lean_share = opt.lean_share_pct;
         hpk_launch_band_class(L.desc.as<HpkBandDesc>(), nb, ca, L.up);
         HIPCHK(c, hipGetLastError());
+        if (opt.host_prof >= 2 && j->use_lean) {      // debug: the non-zero-weight mask of band 0 against its weights
+            HIPCHK(c, hipStreamSynchronize(L.up));
+            const BandSlot& s0 = j->bands[0];
+            std::vector<unsigned> m(HPK_WNZ_WORDS(s0.n));
+            std::vector<double> w(s0.n);
+            HIPCHK(c, hipMemcpy(m.data(), s0.d.small + s0.d.off_wnz, m.size() * 4, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(w.data(), s0.st.weight, w.size() * 8, hipMemcpyDeviceToHost));
+            int bad = 0, nan = 0;
+            for (int i = 0; i < s0.n; ++i) {
+                const int bit = (m[(i + HPK_WNZ_LEAD) >> 5] >> ((i + HPK_WNZ_LEAD) & 31)) & 1;
+                const int want = (w[i] == w[i] && w[i] != 0.0) ? 1 : 0;
+                nan += w[i] != w[i];
+                if (bit != want && bad++ < 8) std::fprintf(stderr, "[hpk dbg] wnz bin %d bit %d want %d w %g\n", i, bit, want, w[i]);
+            }
+            HpkBandDesc dd;
+            HIPCHK(c, hipMemcpy(&dd, L.desc.as<HpkBandDesc>(), sizeof(dd), hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "[hpk dbg] wnz: %d bins, %d NaN weights, %d wrong bits; lean_cj %d J %d off_wnz %u\n", s0.n, nan, bad, dd.lean_cj, dd.J, dd.off_wnz);
+        }
     }
     HIPCHK(c, hipEventRecord(L.ev_up, L.up));
     HIPCHK(c, hipStreamWaitEvent(c->stream, L.ev_up, 0));
@@ -953,6 +980,13 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     sa.dbg_stop = opt.dbg_stop;
     sa.clk = nullptr;
     sa.lean_max = j->use_lean ? opt.lean_max : 0;
+    sa.redoq = nullptr;
+    if (j->use_lean) {          // the tiles the lean kernel gives up: at most all of them
+        size_t tiles_all = 0;
+        for (int b = 0; b < nb; ++b) tiles_all += (size_t)std::max(j->bands[b].ntiles, j->bands[b].ntiles_full) * 2;
+        HIPCHK(c, L.redoq.reserve(16 + 8 * tiles_all));
+        sa.redoq = L.redoq.as<unsigned>();
+    }
 #ifdef HPK_PHASE_CLOCK
     if (std::getenv("HPK_CLK_DUMP")) {
         HIPCHK(c, c->tmpD.reserve(sizeof(unsigned long long) * 8 * HPK_NWAVES * 1024));

@@ -139,7 +139,13 @@ struct HpkBandDesc {
     int32_t TR, TC;                     // output tile
     int32_t J;                          // column chunks per row block
     int32_t tilecap;                    // records per tile region (TR x TC)
+    // which bins have a non-zero weight (NaN counts as zero), one bit per bin from bit HPK_WNZ_LEAD on, zeros around (hpk_band_class
+    // writes it, hpk_stencil_lean reads ten columns' bits and a row's per lane): offset inside `small`, 0 = none
+    uint32_t off_wnz;
+    uint32_t pad_;
 };
+#define HPK_WNZ_LEAD 64                 // zero bits before bin 0 (tiles reach maxww + 1 bins beyond the matrix' ends)
+#define HPK_WNZ_WORDS(n) (((n) + 31) / 32 + 2 + 12)
 
 // Geometry and parameters common to all bands of a batch (kernel argument of the stencil).
 struct HpkStencilArgs {
@@ -153,8 +159,9 @@ struct HpkStencilArgs {
     int32_t generic;                    // the plan's Reads matrix is not monotone in the width: steps walked in plan order (general plans only)
     int32_t dbg_stop;                   // profiling ablation: 1 stop after the loads, 2 after the SAT, 4 no candidates, 5 search without box sums
     unsigned long long* clk;            // -DHPK_PHASE_CLOCK builds: [grid][waves][8] cycle sums per phase, or nullptr
-    int32_t lean_max;                   // lean tiles (HpkBandDesc::lean_cj): most candidates summed cell by cell before the tile is computed once more in full; 0: no lean tiles
+    int32_t lean_max;                   // lean tiles (hpk_stencil_lean): most candidates summed cell by cell before the tile is handed to hpk_stencil_s; 0: no lean tiles
     int32_t pad_;
+    unsigned* redoq;                    // {tiles queued, tiles taken, -, -, (band, row block << 8 | column chunk) ...}: the tiles hpk_stencil_lean gave up, or nullptr
 };
 
 struct HpkScoreArgs {
@@ -190,7 +197,8 @@ struct HpkBruteArgs {
 
 // hpk_stencil_s walks the whole batch in one launch (bands within its addressing limits, a halo of at least 4)
 bool hpk_stencil_s_applies(const HpkGeo& g, int64_t max_ld, int32_t max_n);
-void hpk_launch_stencil_batch(const HpkStencilArgs& a, const HpkBandDesc* d_bands, bool balf64, hipStream_t st);
+// hpk_stencil_lean over the lean column chunks (a.lean_max > 0), then hpk_stencil_s over the others and the tiles the first gave up
+void hpk_launch_stencil_batch(const HpkStencilArgs& a, const HpkBandDesc* d_bands, bool balf64, int cus, hipStream_t st);
 void hpk_launch_dense(const HpkDenseArgs& a, hipStream_t st);
 void hpk_launch_probe(const HpkDenseArgs& a, const int32_t* rows, const int32_t* cols, int64_t count, double* out, hipStream_t st);
 void hpk_launch_freeze_tot(const HpkDevPlan* plan, const HpkBandDesc* d_bands, int nbands, hipStream_t st);
@@ -226,6 +234,7 @@ struct HpkClassArgs {
     int32_t planW, tr_cap;              // hpk_geo_of's inputs
     int32_t p0, minr;                   // Reads = lower-left rings p0 + 1 .. w against min_local_reads
     float lean_frac;
+    int32_t lean_share;                 // least share (percent) of a band's column chunks that must be lean for the band to have lean tiles at all
 };
 void hpk_launch_band_class(HpkBandDesc* d_bands, int nbands, const HpkClassArgs& a, hipStream_t st);
 void hpk_launch_poisson_sf(const double* k, const double* lam, const double* sfe, double* out, int64_t count,

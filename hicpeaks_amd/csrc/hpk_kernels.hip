@@ -131,11 +131,11 @@ __device__ __noinline__ double2 explicit_sums_wave(const float* __restrict__ raw
 #define HPK_CLK_DECL
 #define HPK_CLK(v)
 #endif
-#ifndef HPK_EARLY_LEAN
-#define HPK_EARLY_LEAN 1
+#ifndef HPK_DYN_BATCH
+#define HPK_DYN_BATCH 1                 // hpk_stencil_s: the batches of a tile beyond the waves' first are dealt dynamically
 #endif
-#ifndef HPK_EARLY_FULL
-#define HPK_EARLY_FULL 0
+#ifndef HPK_SCORE_REUSE
+#define HPK_SCORE_REUSE 1               // hpk_score, several pairs: the candidate's own loads stay for the pairs of a batch
 #endif
 // -DHPK_CLK_P1 (with HPK_PHASE_CLOCK): phase 1 split - slot 0 wait for the prefetched rows, 1 cells, 2 candidate list, 3 row prefixes
 // and stores; 4 = everything between phase 1 and the batches
@@ -329,13 +329,17 @@ __device__ __forceinline__ void tile_load_s(const HpkStencilArgs& a, const HpkBa
 
 // Persistent tile walk over a batch of bands, without divisions inside a band.  XCD x owns, of every band b, the
 // contiguous run of tiles [x * chunk_b, (x + 1) * chunk_b); the runs of the batch's bands laid end to end form the XCD's
-// index space (band b starts at k0_b = sum of the chunks before it), and the XCD's workgroups walk it with the stride of
-// the workgroups per XCD - straight across the band boundaries, so that a batch has one ramp-up and one tail whatever
-// the number of bands.  Inside a band, (row block, column chunk) advance by the stride's quotient and remainder by J; a
-// band switch recomputes them with a division (rare).
+// index space, and the XCD's workgroups walk it with the stride of the workgroups per XCD - straight across the band
+// boundaries, so that a batch has one ramp-up and one tail whatever the number of bands.  Inside a band, (row block, column
+// chunk) advance by the stride's quotient and remainder by J; a band switch recomputes them with a division (rare).
+// A band's tiles are walked by two kernels: MODE 0 (hpk_stencil_s) takes the column chunks below the band's lean_cj, MODE 1
+// (hpk_stencil_lean) the chunks from lean_cj on; the tiles the lean kernel could not finish go through hpk_stencil_s once more,
+// in a small launch of their own that walks the redo queue instead (QueueWalk).
+#define HPK_BW_REDO 0x80000000u         // bword: a tile out of the redo queue (its candidates were counted by the lean kernel)
+template <int MODE>
 struct TileWalk {
     int k, band, kb, chunkb, ntb;       // index in the XCD's run; current band, its first index, its chunk and tile count
-    int J;                              // column chunks per row block of the current band (every band has its own tile geometry)
+    int J, clo;                         // column chunks of the current band this walk takes, the first of them (every band has its own tile geometry)
     int rbk, ck, rm;                    // row block, column chunk before rotation, row block mod J
     int dk, dr, dc, drm;                // per step: index stride, its quotient and remainder by J, quotient mod J
     int nt;                             // tiles handed out so far (see bword)
@@ -348,10 +352,13 @@ struct TileWalk {
                 ++band;
                 if (band >= a.nbands) { done = true; return; }
                 const HpkBandDesc* __restrict__ nb = bands + __builtin_amdgcn_readfirstlane(band);
-                chunkb = nb->chunk;
-                ntb = nb->ntiles;
-                J = nb->J;
-                dr = dk / J; dc = dk - dr * J; drm = dr % J;
+                const int Jr = nb->J, lc = nb->lean_cj;
+                const int jf = lc < Jr ? (lc > 0 ? lc : 0) : Jr;       // chunks that are not lean
+                J = MODE == 0 ? jf : Jr - jf;
+                clo = MODE == 0 ? 0 : jf;
+                ntb = (nb->ntiles / Jr) * J;
+                chunkb = (ntb + 7) / 8;
+                if (J > 0) { dr = dk / J; dc = dk - dr * J; drm = dr % J; }
                 fresh = true;
             }
             const int t = xcd * chunkb + (k - kb);
@@ -365,10 +372,9 @@ struct TileWalk {
     }
     __device__ __forceinline__ void init(const HpkStencilArgs& a, const HpkBandDesc* __restrict__ bands) {
         dk = (int)(gridDim.x >> 3);
-        J = bands[0].J;
-        dr = dk / J; dc = dk - dr * J; drm = dr % J;
+        J = 1; clo = 0; dr = dk; dc = 0; drm = 0;
         k = (int)(blockIdx.x >> 3);
-        band = 0; kb = 0; chunkb = bands[0].chunk; ntb = bands[0].ntiles;
+        band = -1; kb = 0; chunkb = 0; ntb = 0;
         rbk = 0; ck = 0; rm = 0; nt = 0;
         done = false;
         locate(a, bands, true);
@@ -378,9 +384,9 @@ struct TileWalk {
     // workgroup would meet one density class only.  (A function of the row block alone: the J tiles of a row block still
     // take the J chunks.  Two scalar divisions per tile, in the one wave that walks.)
     __device__ __forceinline__ int cj(const HpkStencilArgs& a) const {
-        if (a.order == 0) return ck;
+        if (a.order == 0) return clo + ck;
         const int c = ck + rm + (rbk / (dr > 0 ? dr : 1)) % J;
-        return c >= J ? (c >= 2 * J ? c - 2 * J : c - J) : c;
+        return clo + (c >= J ? (c >= 2 * J ? c - 2 * J : c - J) : c);
     }
     __device__ __forceinline__ void step(const HpkStencilArgs& a, const HpkBandDesc* __restrict__ bands) {
         k += dk; rbk += dr; ck += dc; rm += drm; nt += 1;
@@ -395,10 +401,31 @@ struct TileWalk {
     // its resolve counts whenever this word changes, i.e. at every band boundary and - long runs of tiles on small grids -
     // before a 16-bit counter field can wrap (a wave runs at most 7 batches of a tile, a lane counts at most one
     // candidate per batch), at no cost in the fifteen waves that do not walk
-    __device__ __forceinline__ unsigned bword() const { return (unsigned)band | ((unsigned)(nt >> 13) << 16); }
+    __device__ __forceinline__ unsigned bword() const { return (unsigned)band | (((unsigned)(nt >> 13) & 0x7fffu) << 16); }
+};
+// The same interface over the redo queue {tiles queued, tiles taken, -, -, (band, row block << 8 | column chunk) ...}: workgroup
+// g takes the entries g, g + grid, ... (the queue is complete when the launch starts: hpk_stencil_lean ran before it).
+struct QueueWalk {
+    unsigned qi, qn, qband, qword;
+    int rbk;
+    bool done;
+    __device__ __forceinline__ void fetch(const HpkStencilArgs& a) {
+        done = qi >= qn;
+        if (!done) { qband = a.redoq[4 + 2 * qi]; qword = a.redoq[5 + 2 * qi]; }
+        rbk = (int)(qword >> 8);
+    }
+    __device__ __forceinline__ void init(const HpkStencilArgs& a, const HpkBandDesc* __restrict__) {
+        qn = a.redoq ? a.redoq[0] : 0u;
+        qi = blockIdx.x; qband = 0u; qword = 0u;
+        fetch(a);
+    }
+    __device__ __forceinline__ void step(const HpkStencilArgs& a, const HpkBandDesc* __restrict__) { qi += gridDim.x; fetch(a); }
+    __device__ __forceinline__ int cj(const HpkStencilArgs&) const { return (int)(qword & 255u); }
+    __device__ __forceinline__ unsigned word(const HpkStencilArgs&) const { return done ? ~0u : qword; }
+    __device__ __forceinline__ unsigned bword() const { return qband | HPK_BW_REDO; }
 };
 
-template <bool BALF64, bool SINGLE>
+template <bool BALF64, bool SINGLE, bool QUEUE>
 __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const HpkBandDesc* __restrict__ bands) {
     constexpr int NW = 16;
     static_assert(LR == 4 * NW && LC == 160, "tile geometry: four table rows per wave, ten cells per lane");
@@ -416,16 +443,6 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     double* __restrict__ ctot = wct + LC;                              // [3][LC] phase 2: totals of the f64 plane's row chunks
     unsigned* __restrict__ utot = reinterpret_cast<unsigned*>(ctot + 3 * LC);            // [LC] ... of the packed plane's first chunk
 
-    // Lean tiles (weight input): far from the diagonal a tile holds candidates but next to none that resolves within the
-    // band's bound, and its f64 plane would be built for nothing.  Tiles of the column chunks from HpkBandDesc::lean_cj on
-    // (hpk_band_class: where the mean Reads of the chunk's nearest pixels stays far below min_local_reads) build the packed
-    // plane only - no conversions, products, f64 scan, a third of the table traffic; the valid flags from "count, row weight
-    // and column weight all non-zero" (hpk_band_class rules out weights small enough for a product to underflow) - and run
-    // the search; the few candidates that do resolve get their sums cell by cell from the band (explicit_sums_wave), and a
-    // tile with more than a.lean_max of them is computed once more in full (the next pass of the tile loop).
-    constexpr bool LEAN_OK = !BALF64;
-    unsigned* __restrict__ tflag = tcount + 16;                       // [2] a lean tile met more candidates that count than lean_max
-    unsigned* __restrict__ wcz = tcount + 20;                         // [5 + 1] bit X: column weight X of the tile is non-zero
     const int lane_k = threadIdx.x & 63;
     const int wave_k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int mw = a.mw;
@@ -445,8 +462,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             }
             stepof[lane_k] = plan->step_of[lane_k >> 5][lane_k & 31];
             stepof[64 + lane_k] = plan->step_of[2 + (lane_k >> 5)][lane_k & 31];
-            if (lane_k < 2) { tcount[lane_k] = 0u; tcount[4 + lane_k] = 0u; tcount[16 + lane_k] = 0u; }     // list entries | records written | lean tile gives up, tiles alternate
-            if (lane_k < 6) tcount[20 + lane_k] = 0u;
+            if (lane_k < 2) { tcount[lane_k] = 0u; tcount[4 + lane_k] = 0u; tcount[6 + lane_k] = 0u; }     // list entries | records written | batches dealt, tiles alternate
         }
         for (int s = 0; s < nsteps; ++s) {
             const int k = (__builtin_amdgcn_readlane(pk0, s) >> 20) & 15;
@@ -473,7 +489,6 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     unsigned myhist = 0u;                 // lane w: candidates whose first sufficient width is w
     unsigned long long hpack0 = 0ull, hpack1 = 0ull;      // this lane's candidates by width min(ww) + k: 16 bits each, k = 0..3 | 4..7
     unsigned mycand = 0u;
-    unsigned mylean = 0u, myexpl = 0u;    // lean tiles | of those computed once more << 16 (wave 0, lane 0); candidates summed cell by cell (per wave, lane 0)
     // the per-lane width counts, summed over the wave, into lane min(ww) + k of myhist
     auto fold_hpack = [&]() {
 #pragma unroll
@@ -485,23 +500,24 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         }
         hpack0 = 0ull; hpack1 = 0ull;
     };
-    TileRegsS<BALF64> nxt;
     // scoring work list: the append of a tile is completed one tile later (the atomic's return is not waited for)
     int pend_tid = -1, pend_band = 0;
     unsigned pend_c = 0u, pend_off = 0u;
 
     HPK_CLK_DECL
+    TileRegsS<BALF64> nxt;
     int par = 0;                        // which of the two list counters the current tile uses
     // The tile walk is the same scalar arithmetic in every wave, and all sixteen would queue for the one scalar unit
     // with it at the top of every tile: wave 0 alone walks, one tile ahead, and publishes the next tile through LDS
     // (tseq[2] / tband[2], alternating: row block << 8 | column chunk (~0 = no more tiles) and the band's index).
     unsigned* __restrict__ tseq = tcount + 8;
     unsigned* __restrict__ tband = tcount + 12;
-    TileWalk tw;
+    // (QUEUE: the launch over the tiles hpk_stencil_lean gave up)
+    typename std::conditional<QUEUE, QueueWalk, TileWalk<0>>::type tw;
     tw.init(a, bands);
     bool have = !tw.done;
     int rb = tw.rbk, cj = tw.cj(a);
-    unsigned bw = tw.bword();           // band (low 16 bits) and flush segment of the current tile
+    unsigned bw = tw.bword();           // band (low 16 bits) and flush segment / redo mark of the current tile
     if (wave_k == 0) {
         tw.step(a, bands);
         if (lane_k == 0) { tseq[0] = tw.word(a); tband[0] = tw.bword(); }
@@ -542,24 +558,8 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             } else if (tix == HPK_MAX_STEPS) out = red[NW * 64];
             if (out) atomicAdd(&gptr(hb->hist_acc)[tix * HPK_ACC_STRIDE], (unsigned long long)out);
         }
-        if constexpr (LEAN_OK) {
-            unsigned* lc = reinterpret_cast<unsigned*>(gptr(hb->small) + HPK_OFF_LEAN);
-            if (tix == 0 && mylean) { atomicAdd(&lc[0], mylean & 0xffffu); if (mylean >> 16) atomicAdd(&lc[1], mylean >> 16); }
-            if (lane_k == 0 && myexpl) atomicAdd(&lc[2], myexpl);
-            mylean = 0u; myexpl = 0u;
-        }
         __syncthreads();                // (the next tile's phase 1 parks its totals where `red` sits)
         myhist = 0u; mycand = 0u;
-    };
-    // the tile's column weights (NaN -> 0) into the LDS table, and which of them are non-zero as a bit mask (waves 0..2)
-    auto put_wct = [&](int wv, int ln) {
-        const int tix = wv * 64 + ln;
-        const double w = nxt.wcol == nxt.wcol ? nxt.wcol : 0.0;
-        if (tix < LC) wct[tix] = w;
-        if constexpr (LEAN_OK) {
-            const unsigned long long nz = ballot64((tix < LC) & (w != 0.0));
-            if (ln == 0) { wcz[2 * wv] = (unsigned)nz; wcz[2 * wv + 1] = (unsigned)(nz >> 32); }
-        }
     };
     int hband = -1;                     // band whose resolve counts are pending in myhist / hpack / mycand
 #pragma unroll 1
@@ -577,18 +577,17 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     const int wg_p = bd->wguess;
     // the band's tile geometry (hpk_geo_of)
     const int W = bd->W, TR = bd->TR, TC = bd->TC, J_p = bd->J, Dg_p = bd->Dg, tilecap_p = bd->tilecap;
-    const int lean_cj_p = (LEAN_OK && a.lean_max > 0) ? bd->lean_cj : 0x7fffffff;
+    // a tile out of the redo queue (hpk_stencil_lean gave it up): its candidates and their resolve counts are in the band's totals
+    const bool is_redo = QUEUE;
     // the band's first tile: nothing is prefetched across a boundary; the flush of the band before runs beside the loads
     tile_load_s<BALF64>(a, bd, rb, cj, wave_k, lane_k, nxt);
     if (hband >= 0) flush_hist(bands + hband);
     hband = band;
     if (!BALF64) {                      // the first tile's column weights (the tiles after it: behind their predecessor's tables)
-        if (wave_k < 3) put_wct(wave_k, lane_k);
+        const int tix = wave_k * 64 + lane_k;
+        if (tix < LC) wct[tix] = nxt.wcol == nxt.wcol ? nxt.wcol : 0.0;
         __syncthreads();
     }
-    bool redo = false;                  // the next pass of the tile loop computes the same tile once more, in full
-    int redo_tn = 0;
-    unsigned redo_bn = 0u;
 #pragma unroll 1
     do {
     // Everything below that depends only on (wave, lane) is the same for every tile, and the compiler would hoist it
@@ -603,27 +602,23 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     // (a.Dg, not a.D: with a halo below maxww the stored diagonals beyond D - read for the gap rows only, callers.py:238 -
     // reach further than the last candidates' tile sees)
     const bool empty_tile = c0 >= n || (mw + cj * TC - (TR - 1)) > Dg_p;      // no stored pixel inside the matrix
-    // (a pass that computes its tile once more - a lean tile that met too many candidates that count - keeps the walk where it is:
-    // the tile after it is the one the first pass saw)
-    const bool is_redo = LEAN_OK && redo;
-    const int tn = is_redo ? redo_tn : __builtin_amdgcn_readfirstlane((int)tnext);
-    const unsigned bw_next = is_redo ? redo_bn : (unsigned)__builtin_amdgcn_readfirstlane((int)bnext);
+    const int tn = __builtin_amdgcn_readfirstlane((int)tnext);
+    const unsigned bw_next = (unsigned)__builtin_amdgcn_readfirstlane((int)bnext);
     const bool have_next = tn != -1;
     const bool pre_next = have_next && bw_next == cbw;         // the next tile is this band's: its rows are prefetched
     const int rb_next = (int)((unsigned)tn >> 8), cj_next = tn & 255;
-    if (!is_redo) {
-        if (wave == 0) {                // the tile after the next one, for everybody's next round
-            tw.step(a, bands);
-            if (lane == 0) { tseq[tpar ^ 1] = tw.word(a); tband[tpar ^ 1] = tw.bword(); }
-        }
-        tpar ^= 1;
+    if (wave == 0) {                    // the tile after the next one, for everybody's next round
+        tw.step(a, bands);
+        if (lane == 0) { tseq[tpar ^ 1] = tw.word(a); tband[tpar ^ 1] = tw.bword(); }
     }
-    const bool lean = LEAN_OK && !is_redo && cj >= lean_cj_p;
-    // (profiling ablations 10 / 11: the lean tiles alone / the full tiles alone)
-    if (empty_tile || (a.dbg_stop == 10 && !lean) || (a.dbg_stop == 11 && lean)) {
+    tpar ^= 1;
+    if (empty_tile) {
         if (pre_next) {
             tile_load_s<BALF64>(a, bd, rb_next, cj_next, wave, lane, nxt);
-            if (!BALF64 && wave < 3) put_wct(wave, lane);
+            if (!BALF64 && wave < 3) {
+                const int tix = wave * 64 + lane;
+                if (tix < LC) wct[tix] = nxt.wcol == nxt.wcol ? nxt.wcol : 0.0;
+            }
         }
         have = have_next; rb = rb_next; cj = cj_next; bw = bw_next;
         __syncthreads();                // (rare: the far end of the chromosome) wave 0's word before it is read
@@ -631,35 +626,11 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         bnext = lds_u32(lds0 + (unsigned)((unsigned char*)tband - smem) + (unsigned)tpar * 4u);
         continue;
     }
-    if (is_redo) {                      // the tile's rows once more (the registers hold the next tile's), its column weights
-        tile_load_s<BALF64>(a, bd, rb, cj, wave, lane, nxt);
-        if (!BALF64 && wave < 3) put_wct(wave, lane);
-        __syncthreads();
-    }
     unsigned* __restrict__ tcnt = tcount + par;
-    // Phases 1 and 2 exist twice - with and without the f64 plane (L: lean tile) - as two separate stretches of code with their own
-    // registers: the two variants woven into one (a branch per phase) left the register allocator with merged live ranges of
-    // the cell, weight and column arrays, and hundreds of spills.
-    auto phase12 = [&](auto leanc) __attribute__((always_inline)) {
-    constexpr bool L = LEAN_OK && decltype(leanc)::value;
-    // The tile's rows leave the prefetch registers first, and - EARLY - the next tile's are requested at once: a tile's loads take a
-    // couple of microseconds to come back, and requested only behind phase 1 the waves that finish it last wait for them at the top of
-    // the next tile while the others wait at the first barrier.
-    constexpr bool EARLY = !BALF64 && (L ? (HPK_EARLY_LEAN != 0) : (HPK_EARLY_FULL != 0));
-    const TileRegsS<BALF64> cur = nxt;
-    unsigned cm_out = 0u;               // lean tiles: the lane's candidates (bit 9 - e), for the scan that follows the tables
-    if (EARLY) {
-        asm volatile("" :: "v"(cur.raw[0]), "v"(cur.raw[9]) : "memory");
-        if (pre_next) tile_load_s<BALF64>(a, bd, rb_next, cj_next, wave, lane, nxt);
-    }
     // ---- phase 1 (rows): balanced values and packed cells of the lane's ten cells, the candidates among them, and the row
     // prefix of both planes - nine adds inside the lane, a scan over the 16 lanes of the DPP row that holds the table row -
     // written straight to the tables.  Four table rows per wave, all 64 in one pass.
     {
-#ifdef HPK_CLK_P1
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    HPK_CLK(ck0)
-#endif
     const int Y = 4 * wave + (lane >> 4);                               // the lane's table row
     const int XH = (LC - 1) - 10 * (lane & 15);                         // SAT column of the lane's cell e = 0 (cell e: XH - e)
     const int rr = r0 - W - 1 + Y;                                      // its matrix row
@@ -690,13 +661,11 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     // Column weights: the tile's LDS table (NaNs already 0), memory order like the prefetched elements.
     double wr = 0.0, wcm[10];
     if (!BALF64) {
-        wr = cur.wrow == cur.wrow ? cur.wrow : 0.0;
-        if (!L) {
+        wr = nxt.wrow == nxt.wrow ? nxt.wrow : 0.0;
 #pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const double2 w2 = *reinterpret_cast<const double2*>(&wct[XH - 9 + 2 * i]);
-                wcm[2 * i] = w2.x; wcm[2 * i + 1] = w2.y;
-            }
+        for (int i = 0; i < 5; ++i) {
+            const double2 w2 = *reinterpret_cast<const double2*>(&wct[XH - 9 + 2 * i]);
+            wcm[2 * i] = w2.x; wcm[2 * i + 1] = w2.y;
         }
     }
     const unsigned span = lim > mw ? (unsigned)(lim - mw) : 0u;         // f64 input: balanced values exist on diagonals [mw, lim)
@@ -709,14 +678,14 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     _Pragma("unroll") for (int e = 0; e < 10; ++e) {                                                                           \
         const int i = 9 - e;                                                                                                   \
         const int k = kH - e, km = k - mw;                              /* diagonal, diagonal - min(ww) */                     \
-        unsigned rb32 = cur.raw[i];                                                                                            \
+        unsigned rb32 = nxt.raw[i];                                                                                            \
         if (MASKED) rb32 = (unsigned)k < (unsigned)lim ? rb32 : 0u;                                                            \
         float rv = __uint_as_float(rb32);                                                                                      \
         const unsigned ru = (unsigned)rv;                                                                                      \
         const unsigned rc = ru < pkcap_p ? ru : pkcap_p;                                                                       \
         if (BALF64) {                                                                                                          \
             /* as given: the caller zeroed the NaNs (hpk.h), signs are kept (callers.py:78) */                                 \
-            bv[e] = (!(MASKED) || (unsigned)km < span) ? cur.bal[i] : 0.0;                                                     \
+            bv[e] = (!(MASKED) || (unsigned)km < span) ? nxt.bal[i] : 0.0;                                                     \
         } else {                                                                                                               \
             if (MASKED) {                                                                                                      \
                 rv = km >= 0 ? rv : 0.f;                                /* balanced values exist from diagonal min(ww) on */   \
@@ -731,57 +700,19 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         /* cm = 2 cm + (count != 0): a compare and an add with carry */                                                        \
         asm("v_cmp_ne_u32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(cm) : "v"(ru) : "vcc");             \
     }
-    // Lean tile: capped counts only; a cell's balanced value is non-zero where its count, its row weight and its column weight
-    // are (bit 9 - e of vm: the counts' mask times the column weights' - ten bits of the tile's wcz - times the row's; masked
-    // cells: times "diagonal >= min(ww)")
-#define HPK_CELLS_LEAN(MASKED)                                                                                                 \
-    _Pragma("unroll") for (int e = 0; e < 10; ++e) {                                                                           \
-        const int i = 9 - e;                                                                                                   \
-        const int k = kH - e;                                                                                                  \
-        unsigned rb32 = cur.raw[i];                                                                                            \
-        if (MASKED) rb32 = (unsigned)k < (unsigned)lim ? rb32 : 0u;                                                            \
-        const unsigned ru = (unsigned)__uint_as_float(rb32);                                                                   \
-        pk[e] = ru < pkcap_p ? ru : pkcap_p;                                                                                   \
-        asm("v_cmp_ne_u32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(cm) : "v"(ru) : "vcc");             \
-    }
     {
         const bool inner = (kH - 9 >= mw) & (kH < lim);
-        const bool all_inner = ballot64(!inner) == 0ull;
-        if (L) {
-            if (all_inner) { HPK_CELLS_LEAN(false) }
-            else { HPK_CELLS_LEAN(true) }
-            const unsigned lo = (unsigned)(XH - 9);                         // the lane's lowest column
-            const unsigned w0 = wcz[lo >> 5], w1 = wcz[(lo >> 5) + 1];
-            unsigned vm = cm & (unsigned)((((unsigned long long)w1 << 32) | (unsigned long long)w0) >> (lo & 31u));
-            vm = wr != 0.0 ? vm : 0u;
-            if (!all_inner) {
-                const int A = kH - mw;                                      // cells e <= A lie on diagonals >= min(ww)
-                const unsigned km = A >= 9 ? 0x3ffu : (A < 0 ? 0u : (0x3ffu & ~((1u << (9 - A)) - 1u)));
-                vm &= km;
-            }
-#pragma unroll
-            for (int e = 0; e < 10; ++e) pk[e] |= ((vm >> (9 - e)) & 1u) << PK_SHIFT;
-        } else {
-            if (all_inner) { HPK_CELLS(false) }
-            else { HPK_CELLS(true) }
-        }
+        if (ballot64(!inner) == 0ull) { HPK_CELLS(false) }
+        else { HPK_CELLS(true) }
     }
 #undef HPK_CELLS
-#undef HPK_CELLS_LEAN
     cm &= cmask;
-    HPK_CLKP(ck1)
     // the lane's slice of the tile-wide list: behind the candidates of the lanes before it, in the wave's slice
     const unsigned cnt = (unsigned)__popc(cm);
     const unsigned inc = wave_inclusive_scan(cnt);
     const unsigned nrow = (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
     unsigned slot = 0u;
-    if (L) {
-        // a lean tile keeps no list: its candidates are counted, and each lane goes through its own after the tables (the scan
-        // below: next to none passes the widest Reads box)
-        const unsigned addr = (unsigned)(size_t)tcnt;
-        asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" :: "v"(addr), "v"(nrow) : "memory");
-        cm_out = cm;
-    } else {
+    {
         // hipcc's atomic optimiser would wait for the returned value on the spot; issued by hand, the LDS round
         // trip runs beside the f64 prefix.  All lanes would add the same count into the same word: lane 0 only, by
         // narrowing exec around the instruction (every lane is active here) instead of a branch on a lane mask.
@@ -790,16 +721,16 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
                      : "=&v"(slot) : "v"(addr), "v"(nrow) : "memory");
     }
     // row prefix of the f64 plane (cell e = 0 first: from the origin side)
-    if (!(L)) {
 #pragma unroll
-        for (int e = 1; e < 10; ++e) bv[e] += bv[e - 1];
+    for (int e = 1; e < 10; ++e) bv[e] += bv[e - 1];
+    {
         const double ex = row16_exclusive_scan(bv[9]);
         double* __restrict__ dst = &Sc[Y * LC + XH - 9];
 #pragma unroll
         for (int i = 0; i < 5; ++i)
             *reinterpret_cast<double2*>(&dst[2 * i]) = make_double2(bv[9 - 2 * i] + ex, bv[8 - 2 * i] + ex);
     }
-    if (!L && nrow != 0u) {
+    if (nrow != 0u) {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(slot) :: "memory");
         // entries in the order of the rows, inside a row by descending column
         const unsigned at0 = (unsigned)__builtin_amdgcn_readfirstlane((int)slot) + (inc - cnt);
@@ -811,7 +742,6 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             if (cd) lds_st_u32(lds0 + (unsigned)(LR * LC * 12) + at * 4u, (ebase - (unsigned)e) | ((pk[e] & PK_MASK) << HPK_ENT_CNT_SHIFT));
         }
     }
-    HPK_CLKP(ck2)
     // ... and of the packed plane
 #pragma unroll
     for (int e = 1; e < 10; ++e) pk[e] += pk[e - 1];
@@ -823,30 +753,16 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             *reinterpret_cast<uint2*>(&dst[2 * i]) = make_uint2(pk[9 - 2 * i] + ex, pk[8 - 2 * i] + ex);
     }
     }
-    HPK_CLKP(ck3)
-    HPK_CLKQ(ck0)
+    HPK_CLK(ck0)
     // The next tile's rows start moving now, from every wave.
-    if (!EARLY && pre_next) tile_load_s<BALF64>(a, bd, rb_next, cj_next, wave, lane, nxt);
+    if (pre_next) tile_load_s<BALF64>(a, bd, rb_next, cj_next, wave, lane, nxt);
     __syncthreads();
-    HPK_CLKQ(ck1)
+    HPK_CLK(ck1)
     // ---- phase 2 (columns): the tables hold row prefixes; the prefix down the columns runs through LDS.  f64 plane: waves
     // 0-9, a thread per column and chunk of 16 rows; packed plane: waves 10-14, chunks of 32 rows.  A thread sums its chunk in
     // registers, parks the chunk's total, and - behind a barrier - writes its cells back with the totals of the chunks above.
     unsigned creg[32];
-    unsigned* __restrict__ utot3 = reinterpret_cast<unsigned*>(ctot);       // lean tiles: [3][LC] totals of the packed plane's 16-row chunks
-    if (L) {
-        // the packed plane alone: waves 0-9, a thread per column and chunk of 16 rows
-        if (wave < 10) {
-            const int tix = wave * 64 + lane;
-            const int ch = tix >= 2 * LC ? (tix >= 3 * LC ? 3 : 2) : (tix >= LC ? 1 : 0), col = tix - ch * LC;
-            const unsigned* __restrict__ src = &Sp[(16 * ch) * LC + col];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) creg[i] = src[i * LC];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) creg[i] += creg[i - 1];
-            if (ch < 3) utot3[ch * LC + col] = creg[15];
-        }
-    } else {
+    {
         if (wave < 10) {
             const int tix = wave * 64 + lane;
             const int ch = tix >= 2 * LC ? (tix >= 3 * LC ? 3 : 2) : (tix >= LC ? 1 : 0), col = tix - ch * LC;
@@ -872,19 +788,8 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         }
     }
     __syncthreads();
-    HPK_CLKQ(ck2)
-    if (L) {
-        if (wave < 10) {
-            const int tix = wave * 64 + lane;
-            const int ch = tix >= 2 * LC ? (tix >= 3 * LC ? 3 : 2) : (tix >= LC ? 1 : 0), col = tix - ch * LC;
-            unsigned base = ch >= 1 ? utot3[col] : 0u;
-            base += ch >= 2 ? utot3[LC + col] : 0u;
-            base += ch >= 3 ? utot3[2 * LC + col] : 0u;
-            unsigned* __restrict__ dst = &Sp[(16 * ch) * LC + col];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) dst[i * LC] = creg[i] + base;
-        }
-    } else {
+    HPK_CLK(ck2)
+    {
         if (wave < 10) {
             const int tix = wave * 64 + lane;
             const int ch = tix >= 2 * LC ? (tix >= 3 * LC ? 3 : 2) : (tix >= LC ? 1 : 0), col = tix - ch * LC;
@@ -905,12 +810,12 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         }
     }
     __syncthreads();
-    return cm_out;
-    };
-    const unsigned cm_lean = lean ? phase12(std::true_type{}) : phase12(std::false_type{});
     // the next tile's column weights are in: into the LDS table (nobody reads it before the barrier that ends this tile)
-    if (!BALF64 && pre_next && wave < 3) put_wct(wave, lane);
-    HPK_CLKQ(ck3)
+    if (!BALF64 && pre_next && wave < 3) {
+        const int tix = wave * 64 + lane;
+        if (tix < LC) wct[tix] = nxt.wcol == nxt.wcol ? nxt.wcol : 0.0;
+    }
+    HPK_CLK(ck3)
     const int total = a.dbg_stop == 2 ? 0 : (int)*tcnt;         // (profiling ablation 2: the tables only, no batches)
     // gap rows (callers.py:238): rows of the tile's columns (the last tile of a row block: up to the end of its halo)
     // without a non-zero balanced value - exact on the valid-count field
@@ -923,16 +828,31 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         rs -= last ? 0u : Sp[Y * LC + xe] - Sp[(Y - 1) * LC + xe];
         if ((rs >> PK_SHIFT) != 0u) gptr(bd->gap)[r0 + tx] = 1;
     }
-    if (tx == 0) { tcount[par ^ 1] = 0u; tcount[4 + (par ^ 1)] = 0u; tflag[par ^ 1] = 0u; }    // the next tile's counters (its atomics start after the barrier below)
+    if (tx == 0) { tcount[par ^ 1] = 0u; tcount[4 + (par ^ 1)] = 0u; tcount[6 + (par ^ 1)] = 0u; }    // the next tile's counters (its atomics start after the barrier below)
     // ---- phase 3: batches of 64 candidates, dealt round-robin to the waves
     const int64_t tbase = (int64_t)tid * tilecap_p;
     unsigned* __restrict__ ent_t = gptr(bd->rec_ent) + tbase;
     HPK_CLK(ck4)
-    // one batch: up to 64 candidates (entry `id` where `cand`) - first sufficient width, resolve counts, record, sums
-    auto batch = [&](const unsigned id, const bool cand, const bool lean) __attribute__((always_inline)) {
+#if HPK_DYN_BATCH
+    // the waves' first batches are their own; the others are dealt as the waves come free (a counter in LDS: batches differ -
+    // widths in between, sums redone exactly, records or none - and the tile's last barrier waits for the slowest wave)
+    auto next_batch = [&]() {
+        unsigned v = 0u;
+        if (lane == 0) v = atomicAdd(&tcount[6 + par], 1u);
+        return NW + __builtin_amdgcn_readfirstlane((int)v);
+    };
+#pragma unroll 1
+    for (int b = wave; b * 64 < total; b = next_batch()) {
+#else
+#pragma unroll 1
+    for (int b = wave; b * 64 < total; b += NW) {
+#endif
 #ifdef HPK_PHASE_CLOCK
         ck7 += 1ull;
 #endif
+        const int i = b * 64 + lane;
+        const bool cand = i < total;
+        const unsigned id = lst[cand ? i : 0];
         const int x = (int)HPK_ENT_X(id);
         const int y = (int)HPK_ENT_Y(id);
         const int base = (y + W + 1) * LC + W + x;
@@ -941,9 +861,9 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         const unsigned cb = lds0 + (unsigned)base * 8u, pb = lds0 + (unsigned)(LR * LC * 8) + (unsigned)base * 4u;
         const unsigned sr = lds_u32(pb);
         const bool diffp = SINGLE && sp_p > 0;                      // Box(w*) - Box(p): see box_ky_d
-        const double sc = lean ? 0.0 : lds_f64(cb);
+        const double sc = lds_f64(cb);
         double pixc = 0.0, amax = 0.0;
-        if (SINGLE && !diffp && !lean) {
+        if (SINGLE && !diffp) {
             pixc = (sc - lds_f64(cb + 8)) - (lds_f64(cb - LC * 8) - lds_f64(cb - LC * 8 + 8));
             amax = lds_f64(cb + (unsigned)(W * (LC - 1) * 8));
         }
@@ -1010,7 +930,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         // by one ballot per width.
         // (The f64-input variants are out of registers - their prefetch holds 30 instead of 16 - and keep the ballots.)
         if (!BALF64) {
-            // (a pass that computes its tile once more does not count: the tile's first pass did)
+            // (a tile out of the redo queue does not count: the lean kernel did)
             const unsigned off = is_redo ? 255u : (unsigned)(wstar - wmin_p);     // 255 - min(ww) >= 8 for "no sufficient width"
             const unsigned long long inc = 1ull << ((off & 3u) * 16u);
             hpack0 += off < 4u ? inc : 0ull;
@@ -1040,7 +960,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         // waited for after the box sums.
         const bool live = cand & (wstar <= wg_p);
         const unsigned long long lm = ballot64(live);
-        if (lm == 0ull) return;
+        if (lm == 0ull) continue;
         unsigned rslot = 0u;
         {
             const unsigned addr = (unsigned)(size_t)(tcount + 4 + par);
@@ -1049,17 +969,6 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
                          : "=&v"(rslot) : "v"(addr), "v"(nl) : "memory");
         }
         wstar = live ? wstar : 255;                 // (candidates beyond the bound count as unresolved from here on)
-        if (LEAN_OK && lean) {
-            // a lean tile has no f64 table: up to a.lean_max candidates that count get their sums cell by cell below; a batch
-            // that would go beyond gives the tile up - it is computed once more in full, and writes its records then
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rslot) :: "memory");
-            const unsigned before = (unsigned)__builtin_amdgcn_readfirstlane((int)rslot), nl = (unsigned)__popcll(lm);
-            if (before + nl > (unsigned)a.lean_max) {
-                if (lane == 0) tflag[par] = 1u;
-                return;
-            }
-            myexpl += nl;
-        }
         // general plans: the innermost box is the same in every step of every slot - formed once per candidate
         double kc0 = 0.0, yc0 = 0.0, big0 = 0.0;
         if (!SINGLE && fr_p > 0) box_ky_d(cb, fr_p, sc, kc0, yc0, big0);
@@ -1078,17 +987,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             }
             const bool act = sq != 0xff;
             double SK = 0.0, SY = 0.0;
-            if (LEAN_OK && lean) {
-                unsigned long long todo = ballot64(act);
-                while (todo != 0ull) {
-                    const int src = __ffsll((long long)todo) - 1;
-                    todo &= todo - 1ull;
-                    const int er = __builtin_amdgcn_readlane(r0 + y, src), ec = __builtin_amdgcn_readlane(c0 + x, src);
-                    const int es = __builtin_amdgcn_readlane(sq, src);
-                    const double2 ex = explicit_sums_wave(gptr(bd->raw), gptr(bd->bal), gptr(bd->weight), plan->steps[es].m, W, er, ec, n, bd->num, bd->ld, mw, lane);
-                    if (lane == src) { SK = ex.x; SY = ex.y; }
-                }
-            } else if (ballot64(act) != 0ull) {
+            if (ballot64(act) != 0ull) {
                 unsigned w0 = 0u, k0 = 0u, k1 = 0u, k2 = 0u, k3 = 0u;
                 int nkt = 0, rho_min;
                 if (SINGLE) {
@@ -1199,39 +1098,6 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
                 gptr(bd->rec_W)[o] = act ? (uint8_t)(sq + 1) : (uint8_t)0;
             }
         }
-    };
-    if (LEAN_OK && lean) {
-        // ---- lean tile: no list.  Every lane goes through its own candidates (bit 9 - e of the mask phase 1 left) and tests
-        // the widest Reads box - what decides "resolves within the bound at all"; the few that pass are a batch of their own.
-        if (a.dbg_stop != 2) {
-            const int Y = 4 * wave + (lane >> 4), XH = (LC - 1) - 10 * (lane & 15);
-            const unsigned prow = lds0 + (unsigned)(LR * LC * 8) + (unsigned)(Y * LC + XH) * 4u;      // P(Y, XH) of the packed plane; cell e: - 4 e
-            unsigned bits = cm_lean;
-#pragma unroll 1
-            while (ballot64(bits != 0u) != 0ull) {
-                const bool on = bits != 0u;
-                const int bpos = on ? 31 - __clz((int)bits) : 0;            // bit 9 - e, descending columns first
-                bits = on ? bits & ~(1u << bpos) : 0u;
-                const int e = 9 - bpos;
-                const unsigned pb = prow - 4u * (unsigned)e;
-                const unsigned sr = lds_u32(pb);
-                const unsigned bl = reads_box_b(pb, W, sr);
-                // (Reads = widest box - box p0 >= min_local_reads needs the widest box alone to reach it)
-                if (ballot64(on & (bl >= (unsigned)minr_p)) == 0ull) continue;
-                const unsigned b0 = (p0_p > 0) ? reads_box_b(pb, p0_p, sr) : 0u;
-                const bool hit = on & (bl - b0 >= (unsigned)minr_p);
-                if (ballot64(hit) == 0ull) continue;
-                const unsigned cnt = (sr - lds_u32(pb + 4u) - lds_u32(pb - (unsigned)(LC * 4)) + lds_u32(pb - (unsigned)(LC * 4) + 4u)) & PK_MASK;
-                batch((unsigned)(XH - e - W) | ((unsigned)(Y - (W + 1)) << HPK_ENT_YSHIFT) | (cnt << HPK_ENT_CNT_SHIFT), hit, true);
-            }
-        }
-    } else {
-#pragma unroll 1
-        for (int b = wave; b * 64 < total; b += NW) {
-            const int i = b * 64 + lane;
-            const bool cand = i < total;
-            batch(lst[cand ? i : 0], cand, false);
-        }
     }
     HPK_CLK(ck5)
     // (written by wave 0 at the top of this round, three barriers ago: in flight across the barrier below)
@@ -1239,9 +1105,6 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     bnext = lds_u32(lds0 + (unsigned)((unsigned char*)tband - smem) + (unsigned)tpar * 4u);
     __syncthreads();                 // every wave is done with this tile's SAT and list
     HPK_CLK(ck6)
-    // a lean tile that met more candidates that count than the cell-by-cell path takes: once more, in full
-    bool need_redo = false;
-    if (LEAN_OK && lean) need_redo = __builtin_amdgcn_readfirstlane((int)lds_u32(lds0 + (unsigned)((unsigned char*)tflag - smem) + (unsigned)par * 4u)) != 0;
     if (wave == 0) {
         // scoring work list: one entry per HPK_UNIT records.  The slot reservation (a returning atomic on one global
         // counter) of this tile is only consumed when the next tile ends.
@@ -1251,22 +1114,16 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             if ((unsigned)lane < nu) gptr(bands[pend_band].units)[off + lane] = make_uint2((unsigned)pend_tid, (unsigned)lane | (pend_c << 8));
         }
         pend_tid = -1;
-        if (!need_redo) {
-            const unsigned nrec = (unsigned)__builtin_amdgcn_readfirstlane((int)tcount[4 + par]);    // records of this tile
-            if (nrec > 0u) {
-                pend_tid = tid;
-                pend_band = band;
-                pend_c = nrec;
-                if (lane == 0) pend_off = atomicAdd(reinterpret_cast<unsigned*>(gptr(bd->small) + HPK_OFF_NUNITS), (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT);
-            }
-            if (lane == 0) gptr(bd->tile_cnt)[tid] = nrec;
+        const unsigned nrec = (unsigned)__builtin_amdgcn_readfirstlane((int)tcount[4 + par]);    // records of this tile
+        if (nrec > 0u) {
+            pend_tid = tid;
+            pend_band = band;
+            pend_c = nrec;
+            if (lane == 0) pend_off = atomicAdd(reinterpret_cast<unsigned*>(gptr(bd->small) + HPK_OFF_NUNITS), (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT);
         }
-        // (the candidates and their resolve counts: once per tile, by its first pass)
-        if (!is_redo) mycand += (unsigned)total;
-        if (LEAN_OK && lean) mylean += need_redo ? 0x10001u : 1u;
+        if (lane == 0) { gptr(bd->tile_cnt)[tid] = nrec; mycand += is_redo ? 0u : (unsigned)total; }
     }
-    if (need_redo) { redo = true; redo_tn = tn; redo_bn = bw_next; }
-    else { redo = false; have = have_next; rb = rb_next; cj = cj_next; bw = bw_next; }
+    have = have_next; rb = rb_next; cj = cj_next; bw = bw_next;
     par ^= 1;
     } while (have && bw == cbw);   // tile loop of the band
     }   // bands
@@ -1283,6 +1140,527 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         o[0] = ck0; o[1] = ck1; o[2] = ck2; o[3] = ck3; o[4] = ck4; o[5] = ck5; o[6] = ck6; o[7] = ck7;
     }
 #endif
+}
+
+// The lean kernel's loads of a tile: the lane's ten band elements (as tile_load_s), the non-zero flags of its ten column weights
+// (bit i: column XH - 9 + i) and of its row weight, out of the band's bit mask (HpkBandDesc::off_wnz).
+__device__ __forceinline__ void tile_load_lean(const HpkStencilArgs& a, const HpkBandDesc* __restrict__ bd, int rb, int cj, int wave, int lane,
+                                               unsigned (&raw)[10], unsigned& wbits, bool& wr_nz) {
+    const int bn = bd->n;
+    const int64_t bld = bd->ld;
+    const int W = bd->W;
+    const int r0 = rb * bd->TR;
+    const int rt0 = r0 - W - 1;
+    const int rb0 = rt0 > 1 ? rt0 - 1 : 0;
+    int rows = bn - rb0;
+    rows = rows > LR + 2 ? LR + 2 : rows;
+    const unsigned ldu = (unsigned)bld;
+    const int koff = a.mw + cj * bd->TC + 1;
+    const int Y = 4 * wave + (lane >> 4);
+    const int XL = (LC - 10) - 10 * (lane & 15);
+    const rsrc_t rraw = make_rsrc(gptr(bd->raw) + (int64_t)rb0 * bld, (unsigned)rows * ldu * 4u);
+    const int flat = (rt0 + Y - rb0) * (int)ldu + (koff + XL - Y);
+    const unsigned off = (unsigned)flat * 4u;
+    const bool wide = ldu >= 16u && !(flat < 0 && flat > -10);
+    if (wide) {
+        const v4u32 q0 = ldbuf_v4(rraw, off), q1 = ldbuf_v4(rraw, off + 16u);
+        const v2u32 q2 = ldbuf_v2(rraw, off + 32u);
+        raw[0] = q0.x; raw[1] = q0.y; raw[2] = q0.z; raw[3] = q0.w;
+        raw[4] = q1.x; raw[5] = q1.y; raw[6] = q1.z; raw[7] = q1.w;
+        raw[8] = q2.x; raw[9] = q2.y;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            unsigned o1 = off + 4u * (unsigned)i;
+            asm volatile("" : "+v"(o1));
+            raw[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rraw, (int)o1, 0, 0);
+        }
+    }
+    const unsigned* __restrict__ wnz = reinterpret_cast<const unsigned*>(gptr(bd->small) + bd->off_wnz);
+    const int gc = r0 + a.mw + cj * bd->TC - W + XL + HPK_WNZ_LEAD;      // bit of the lane's lowest column (matrix column c0 - W + X)
+    const unsigned w0 = wnz[gc >> 5], w1 = wnz[(gc >> 5) + 1];
+    wbits = (unsigned)((((unsigned long long)w1 << 32) | (unsigned long long)w0) >> (gc & 31));
+    const int gr = rt0 + Y + HPK_WNZ_LEAD;
+    wr_nz = ((wnz[gr >> 5] >> (gr & 31)) & 1u) != 0u;
+}
+
+// The same loads a tile ahead, without registers: buffer loads that write straight to LDS (`buffer_load ... lds`: the data of lane l
+// lands at the wave's base + 16 l for 16 or 12 bytes per lane, + 4 l for 4: scripts/ubench/lds_dma.hip).  A stage holds, per lane, the four pieces of its ten elements (4 + 4 + 1 + 1) and the three mask
+// words (HPK_LST_*: byte offsets of the parts, each [16 waves][64 lanes]); two stages, so that a tile's loads are requested when the
+// tile before it starts.  (wave-uniform LDS address: lds0-relative byte offset `stage`.)
+#define HPK_LST_A 0
+#define HPK_LST_B 16384
+#define HPK_LST_C 32768
+#define HPK_LST_C2 36864
+#define HPK_LST_D 40960
+#define HPK_LST_E 45056
+#define HPK_LST_F 49152
+#define HPK_LST_BYTES 53248
+typedef __attribute__((address_space(3))) void lds_void_t;
+__device__ __forceinline__ void tile_issue_lean(const HpkStencilArgs& a, const HpkBandDesc* __restrict__ bd, int rb, int cj, int wave, int lane,
+                                                unsigned char* stage) {
+    const int bn = bd->n;
+    const int64_t bld = bd->ld;
+    const int W = bd->W;
+    const int r0 = rb * bd->TR;
+    const int rt0 = r0 - W - 1;
+    const int rb0 = rt0 > 1 ? rt0 - 1 : 0;
+    int rows = bn - rb0;
+    rows = rows > LR + 2 ? LR + 2 : rows;
+    const unsigned ldu = (unsigned)bld;
+    const int koff = a.mw + cj * bd->TC + 1;
+    const int Y = 4 * wave + (lane >> 4);
+    const int XL = (LC - 10) - 10 * (lane & 15);
+    const rsrc_t rraw = make_rsrc(gptr(bd->raw) + (int64_t)rb0 * bld, (unsigned)rows * ldu * 4u);
+    const int flat = (rt0 + Y - rb0) * (int)ldu + (koff + XL - Y);
+    const unsigned off = (unsigned)flat * 4u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rraw, (lds_void_t*)(stage + HPK_LST_A + wave * 1024), 16, (int)off, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rraw, (lds_void_t*)(stage + HPK_LST_B + wave * 1024), 16, (int)(off + 16u), 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rraw, (lds_void_t*)(stage + HPK_LST_C + wave * 256), 4, (int)(off + 32u), 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rraw, (lds_void_t*)(stage + HPK_LST_C2 + wave * 256), 4, (int)(off + 36u), 0, 0, 0);
+    const rsrc_t rw = make_rsrc(gptr(bd->small) + bd->off_wnz, (unsigned)HPK_WNZ_WORDS(bn) * 4u);
+    const int gc = r0 + a.mw + cj * bd->TC - W + XL + HPK_WNZ_LEAD;
+    const int gr = rt0 + Y + HPK_WNZ_LEAD;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(stage + HPK_LST_D + wave * 256), 4, (int)((unsigned)(gc >> 5) * 4u), 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(stage + HPK_LST_E + wave * 256), 4, (int)((unsigned)(gc >> 5) * 4u + 4u), 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_t*)(stage + HPK_LST_F + wave * 256), 4, (int)((unsigned)(gr >> 5) * 4u), 0, 0, 0);
+}
+// ... and what the lane finds in a stage (the wave's own loads: waited for with vmcnt, no barrier).  Lanes whose ten elements would
+// straddle the start of the band (tile_load_s: single loads) and bands narrower than 16 diagonals take the plain loads instead.
+__device__ __forceinline__ void tile_take_lean(const HpkStencilArgs& a, const HpkBandDesc* __restrict__ bd, int rb, int cj, int wave, int lane,
+                                               const unsigned char* stage, unsigned (&raw)[10], unsigned& wbits, bool& wr_nz) {
+    const int W = bd->W;
+    const int r0 = rb * bd->TR;
+    const int rt0 = r0 - W - 1;
+    const int rb0 = rt0 > 1 ? rt0 - 1 : 0;
+    const unsigned ldu = (unsigned)bd->ld;
+    const int koff = a.mw + cj * bd->TC + 1;
+    const int Y = 4 * wave + (lane >> 4);
+    const int XL = (LC - 10) - 10 * (lane & 15);
+    const int flat = (rt0 + Y - rb0) * (int)ldu + (koff + XL - Y);
+    const bool wide = ldu >= 16u && !(flat < 0 && flat > -10);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ballot64(!wide) != 0ull) { tile_load_lean(a, bd, rb, cj, wave, lane, raw, wbits, wr_nz); return; }
+    const int t = wave * 64 + lane;
+    const uint4 q0 = *reinterpret_cast<const uint4*>(stage + HPK_LST_A + t * 16);
+    const uint4 q1 = *reinterpret_cast<const uint4*>(stage + HPK_LST_B + t * 16);
+    raw[0] = q0.x; raw[1] = q0.y; raw[2] = q0.z; raw[3] = q0.w;
+    raw[4] = q1.x; raw[5] = q1.y; raw[6] = q1.z; raw[7] = q1.w;
+    raw[8] = *reinterpret_cast<const unsigned*>(stage + HPK_LST_C + t * 4);
+    raw[9] = *reinterpret_cast<const unsigned*>(stage + HPK_LST_C2 + t * 4);
+    const unsigned w0 = *reinterpret_cast<const unsigned*>(stage + HPK_LST_D + t * 4), w1 = *reinterpret_cast<const unsigned*>(stage + HPK_LST_E + t * 4);
+    const unsigned rw = *reinterpret_cast<const unsigned*>(stage + HPK_LST_F + t * 4);
+    const int gc = r0 + a.mw + cj * bd->TC - W + XL + HPK_WNZ_LEAD;
+    const int gr = rt0 + Y + HPK_WNZ_LEAD;
+    wbits = (unsigned)((((unsigned long long)w1 << 32) | (unsigned long long)w0) >> (gc & 31));
+    wr_nz = ((rw >> (gr & 31)) & 1u) != 0u;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (in registers before the stage is handed to the tile after next)
+}
+
+// ------------------------------------------------------------------ the stencil kernel of the lean column chunks
+// hpk_stencil_lean (weight input, plans with a monotone Reads matrix): far from the diagonal a tile holds candidates but next to
+// none that resolves within the band's bound, and its f64 plane would be built for nothing.  The tiles of the column chunks
+// from HpkBandDesc::lean_cj on (hpk_band_class: where the mean Reads of the chunk's nearest pixels stays far below
+// min_local_reads) are this kernel's: it builds the packed plane only - no conversions, products, f64 scan, a third of the table
+// traffic; the valid flags from "count, row weight and column weight all non-zero" (hpk_band_class rules out weights small
+// enough for a product to underflow) - keeps no candidate list (every lane goes through its own candidates and tests the widest
+// Reads box, what decides "resolves within the bound at all"), and the few candidates that pass get first sufficient width,
+// resolve count and record as in hpk_stencil_s, with their sums formed cell by cell from the band (explicit_sums_wave).  A tile
+// with more than a.lean_max candidates that count is given up: it goes to the redo queue, and hpk_stencil_s - which runs after
+// this kernel - computes it in full.
+template <bool SINGLE>
+__global__ void __launch_bounds__(1024) hpk_stencil_lean(HpkStencilArgs a, const HpkBandDesc* __restrict__ bands) {
+    constexpr int NW = 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* __restrict__ Sp = reinterpret_cast<unsigned*>(smem);                      // [LR][LC] packed plane
+    unsigned* __restrict__ utot3 = Sp + LR * LC;                                        // [3][LC] totals of the 16-row chunks
+    unsigned* __restrict__ tcount = utot3 + 3 * LC;                                     // [32] counters, walk words, column-weight mask
+    unsigned char* __restrict__ stepof = reinterpret_cast<unsigned char*>(tcount + 32);   // [HPK_KSLOTS][32]
+    unsigned char* __restrict__ stage0 = stepof + HPK_KSLOTS * 32;                        // [2][HPK_LST_BYTES] the next tiles' rows on their way (tile_issue_lean)
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_u8_t*)smem;
+    unsigned* __restrict__ tflag = tcount + 16;                       // [2] the tile met more candidates that count than lean_max
+    unsigned* __restrict__ tseq = tcount + 8;
+    unsigned* __restrict__ tband = tcount + 12;
+    const int lane_k = threadIdx.x & 63;
+    const int wave_k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int mw = a.mw;
+    const HpkDevPlan* __restrict__ plan = a.plan;
+    const int nsteps = plan->nsteps, nslots = plan->nslots;
+    if (wave_k == 0) {
+        stepof[lane_k] = plan->step_of[lane_k >> 5][lane_k & 31];
+        stepof[64 + lane_k] = plan->step_of[2 + (lane_k >> 5)][lane_k & 31];
+        if (lane_k < 32) tcount[lane_k] = 0u;
+    }
+    int wf_q[HPK_KSLOTS];
+#pragma unroll
+    for (int q = 0; q < HPK_KSLOTS; ++q) wf_q[q] = __builtin_amdgcn_readfirstlane(plan->slot_wfirst[q]);
+    const int nslots_p = __builtin_amdgcn_readfirstlane(nslots);
+    const int minr_p = __builtin_amdgcn_readfirstlane(plan->min_reads), p0_p = __builtin_amdgcn_readfirstlane(plan->reads_p0);
+    const int wmin_p = __builtin_amdgcn_readfirstlane(plan->wmin);
+    const unsigned pkcap_p = (unsigned)__builtin_amdgcn_readfirstlane(plan->pk_cap);
+    const int planw_p = __builtin_amdgcn_readfirstlane(plan->W);
+    unsigned myhist = 0u;                 // lane w: candidates whose first sufficient width is w
+    unsigned long long hpack0 = 0ull, hpack1 = 0ull;      // this lane's candidates by width min(ww) + k: 16 bits each, k = 0..3 | 4..7
+    unsigned mycand = 0u, mylean = 0u, myexpl = 0u;       // candidates | tiles, of those given up << 16 (wave 0) | candidates summed cell by cell (per wave)
+    auto fold_hpack = [&]() {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            unsigned v = (unsigned)((k < 4 ? hpack0 : hpack1) >> (16 * (k & 3))) & 0xffffu;
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) v += (unsigned)__shfl_xor((int)v, m);
+            if (lane_k == wmin_p + k) myhist += v;
+        }
+        hpack0 = 0ull; hpack1 = 0ull;
+    };
+    int pend_tid = -1, pend_band = 0;
+    unsigned pend_c = 0u, pend_off = 0u;
+    int sp = 0;                         // the stage that holds the current tile's rows
+    int par = 0;
+    TileWalk<1> tw;
+    tw.init(a, bands);
+    bool have = !tw.done;
+    int rb = tw.rbk, cj = tw.cj(a);
+    unsigned bw = tw.bword();
+    if (wave_k == 0) {
+        tw.step(a, bands);
+        if (lane_k == 0) { tseq[0] = tw.word(a); tband[0] = tw.bword(); }
+    }
+    __syncthreads();
+    unsigned tnext = lds_u32(lds0 + (unsigned)((unsigned char*)tseq - smem));
+    unsigned bnext = lds_u32(lds0 + (unsigned)((unsigned char*)tband - smem));
+    int tpar = 0;
+    // the resolve counts of a band (segment) go to that band's totals when the walk leaves it (see hpk_stencil_s)
+    auto flush_hist = [&](const HpkBandDesc* __restrict__ hb) {
+        fold_hpack();
+        unsigned* red = reinterpret_cast<unsigned*>(smem);
+        int tix = wave_k * 64 + lane_k;
+        asm volatile("" : "+v"(tix));
+        __syncthreads();
+        red[tix] = myhist;
+        if (lane_k == 0) red[NW * 64 + wave_k] = mycand;
+        __syncthreads();
+        if (tix < 64) {
+            unsigned tot = 0u;
+            for (int w2 = 0; w2 < NW; ++w2) tot += red[w2 * 64 + tix];
+            red[(NW + 1) * 64 + tix] = tot;
+        }
+        __syncthreads();
+        if (tix <= HPK_MAX_STEPS) {
+            unsigned out = 0u;
+            const unsigned* hw = red + (NW + 1) * 64;
+            if (tix < nsteps) {
+                const HpkDevStep& st = plan->steps[tix];
+                const int wf = plan->slot_wfirst[st.slot];
+                if (st.wi > wf) out = hw[st.wi];
+                else for (int w = 0; w <= wf && w < 64; ++w) out += hw[w];
+            } else if (tix == HPK_MAX_STEPS) out = red[NW * 64];
+            if (out) atomicAdd(&gptr(hb->hist_acc)[tix * HPK_ACC_STRIDE], (unsigned long long)out);
+        }
+        {
+            unsigned* lc = reinterpret_cast<unsigned*>(gptr(hb->small) + HPK_OFF_LEAN);
+            if (tix == 0 && mylean) { atomicAdd(&lc[0], mylean & 0xffffu); if (mylean >> 16) atomicAdd(&lc[1], mylean >> 16); }
+            if (lane_k == 0 && myexpl) atomicAdd(&lc[2], myexpl);
+            mylean = 0u; myexpl = 0u;
+        }
+        __syncthreads();
+        myhist = 0u; mycand = 0u;
+    };
+    int hband = -1;
+#pragma unroll 1
+    while (have) {
+    const unsigned cbw = bw;
+    const int band = (int)(cbw & 0xffffu);
+    const HpkBandDesc* __restrict__ bd = bands + band;
+    const int n = bd->n, bnum = bd->num;
+    const int Dm = a.D < bd->num - 1 ? a.D : bd->num - 1;
+    const int wg_p = bd->wguess;
+    const int W = bd->W, TR = bd->TR, TC = bd->TC, J_p = bd->J, Dg_p = bd->Dg, tilecap_p = bd->tilecap;
+    tile_issue_lean(a, bd, rb, cj, wave_k, lane_k, stage0 + sp * HPK_LST_BYTES);     // the band's first tile: nothing is prefetched across a boundary
+    if (hband >= 0) flush_hist(bands + hband);
+    hband = band;
+#pragma unroll 1
+    do {
+    int wave = wave_k, lane = lane_k;
+    asm volatile("" : "+s"(wave));
+    asm volatile("" : "+v"(lane));
+    const int tid = rb * J_p + cj;
+    const int r0 = rb * TR;
+    const int c0 = r0 + mw + cj * TC;
+    const bool empty_tile = c0 >= n || (mw + cj * TC - (TR - 1)) > Dg_p;
+    const int tn = __builtin_amdgcn_readfirstlane((int)tnext);
+    const unsigned bw_next = (unsigned)__builtin_amdgcn_readfirstlane((int)bnext);
+    const bool have_next = tn != -1;
+    const bool pre_next = have_next && bw_next == cbw;         // the next tile is this band's: its rows are prefetched
+    const int rb_next = (int)((unsigned)tn >> 8), cj_next = tn & 255;
+    if (wave == 0) {
+        tw.step(a, bands);
+        if (lane == 0) { tseq[tpar ^ 1] = tw.word(a); tband[tpar ^ 1] = tw.bword(); }
+    }
+    tpar ^= 1;
+    if (empty_tile) {
+        // (its rows were requested like any tile's: waited for before their stage is written again)
+        if (pre_next) tile_issue_lean(a, bd, rb_next, cj_next, wave, lane, stage0 + (sp ^ 1) * HPK_LST_BYTES);
+        sp ^= 1;
+        have = have_next; rb = rb_next; cj = cj_next; bw = bw_next;
+        __syncthreads();
+        tnext = lds_u32(lds0 + (unsigned)((unsigned char*)tseq - smem) + (unsigned)tpar * 4u);
+        bnext = lds_u32(lds0 + (unsigned)((unsigned char*)tband - smem) + (unsigned)tpar * 4u);
+        continue;
+    }
+    unsigned* __restrict__ tcnt = tcount + par;
+    // the tile's rows out of their stage, and the next tile's requested at once into the other one (a whole tile of lead)
+    unsigned raw[10], wbits;
+    bool wr_nz;
+    tile_take_lean(a, bd, rb, cj, wave, lane, stage0 + sp * HPK_LST_BYTES, raw, wbits, wr_nz);
+    if (pre_next) tile_issue_lean(a, bd, rb_next, cj_next, wave, lane, stage0 + (sp ^ 1) * HPK_LST_BYTES);
+    sp ^= 1;
+    // ---- phase 1 (rows): capped counts and valid flags of the lane's ten cells, the candidates among them (a bit mask the lane
+    // keeps), the row prefix of the packed plane (see hpk_stencil_s: a table row per DPP row of 16 lanes)
+    unsigned cm;
+    const int Y = 4 * wave + (lane >> 4);
+    const int XH = (LC - 1) - 10 * (lane & 15);
+    {
+    const int rr = r0 - W - 1 + Y;
+    const int y = Y - (W + 1);
+    const int kH = mw + cj * TC + 1 + XH - Y;
+    const int xo = XH - W;
+    int lim = n - rr;
+    lim = lim < bnum ? lim : bnum;
+    lim = rr >= 0 ? lim : 0;
+    lim = lim > 0 ? lim : 0;
+    unsigned cmask;
+    {
+        const int A = kH - mw;
+        int elo = A - (Dm - mw), ehi = A < xo ? A : xo;
+        elo = elo > xo - TC + 1 ? elo : xo - TC + 1;
+        elo = elo > 0 ? elo : 0;
+        ehi = ehi < 9 ? ehi : 9;
+        const unsigned m = ((2u << (9 - elo)) - 1u) & ~((1u << (9 - ehi)) - 1u);
+        cmask = ((unsigned)y < (unsigned)TR && elo <= ehi) ? m : 0u;
+    }
+    unsigned pk[10];
+    cm = 0u;
+#define HPK_CELLS_LEAN(MASKED)                                                                                                 \
+    _Pragma("unroll") for (int e = 0; e < 10; ++e) {                                                                           \
+        const int i = 9 - e;                                                                                                   \
+        const int k = kH - e;                                                                                                  \
+        unsigned rb32 = raw[i];                                                                                                \
+        if (MASKED) rb32 = (unsigned)k < (unsigned)lim ? rb32 : 0u;                                                            \
+        const unsigned ru = (unsigned)__uint_as_float(rb32);                                                                   \
+        pk[e] = ru < pkcap_p ? ru : pkcap_p;                                                                                   \
+        asm("v_cmp_ne_u32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(cm) : "v"(ru) : "vcc");             \
+    }
+    {
+        const bool inner = (kH - 9 >= mw) & (kH < lim);
+        const bool all_inner = ballot64(!inner) == 0ull;
+        if (all_inner) { HPK_CELLS_LEAN(false) }
+        else { HPK_CELLS_LEAN(true) }
+        // a cell's balanced value is non-zero where its count, its row weight and its column weight are (masked cells: and its
+        // diagonal is at least min(ww))
+        unsigned vm = cm & wbits;
+        vm = wr_nz ? vm : 0u;
+        if (!all_inner) {
+            const int A = kH - mw;
+            const unsigned km = A >= 9 ? 0x3ffu : (A < 0 ? 0u : (0x3ffu & ~((1u << (9 - A)) - 1u)));
+            vm &= km;
+        }
+#pragma unroll
+        for (int e = 0; e < 10; ++e) pk[e] |= ((vm >> (9 - e)) & 1u) << PK_SHIFT;
+    }
+#undef HPK_CELLS_LEAN
+    cm &= cmask;
+    {   // the tile's candidates are counted (the band's total), not listed
+        const unsigned cnt = (unsigned)__popc(cm);
+        const unsigned nrow = (unsigned)__builtin_amdgcn_readlane((int)wave_inclusive_scan(cnt), 63);
+        const unsigned addr = (unsigned)(size_t)tcnt;
+        asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" :: "v"(addr), "v"(nrow) : "memory");
+    }
+#pragma unroll
+    for (int e = 1; e < 10; ++e) pk[e] += pk[e - 1];
+    {
+        const unsigned ex = row16_exclusive_scan(pk[9]);
+        unsigned* __restrict__ dst = &Sp[Y * LC + XH - 9];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            *reinterpret_cast<uint2*>(&dst[2 * i]) = make_uint2(pk[9 - 2 * i] + ex, pk[8 - 2 * i] + ex);
+    }
+    }
+    __syncthreads();
+    // ---- phase 2 (columns): waves 0-9, a thread per column and chunk of 16 rows
+    {
+        unsigned creg[16];
+        const int tix = wave * 64 + lane;
+        const int ch = tix >= 2 * LC ? (tix >= 3 * LC ? 3 : 2) : (tix >= LC ? 1 : 0), col = tix - ch * LC;
+        if (wave < 10) {
+            const unsigned* __restrict__ src = &Sp[(16 * ch) * LC + col];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) creg[i] = src[i * LC];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) creg[i] += creg[i - 1];
+            if (ch < 3) utot3[ch * LC + col] = creg[15];
+        }
+        __syncthreads();
+        if (wave < 10) {
+            unsigned base = ch >= 1 ? utot3[col] : 0u;
+            base += ch >= 2 ? utot3[LC + col] : 0u;
+            base += ch >= 3 ? utot3[2 * LC + col] : 0u;
+            unsigned* __restrict__ dst = &Sp[(16 * ch) * LC + col];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dst[i * LC] = creg[i] + base;
+        }
+    }
+    __syncthreads();
+    // gap rows (callers.py:238), exact on the valid-count field
+    const int tx = wave * 64 + lane;
+    if (tx < TR && r0 + tx < n) {
+        const bool last = (cj == J_p - 1) || (c0 + TC >= n) || (mw + (cj + 1) * TC - (TR - 1)) > Dg_p;
+        const int Yg = tx + W + 1;
+        unsigned rs = Sp[Yg * LC + W] - Sp[(Yg - 1) * LC + W];
+        const int xe = last ? W : W + TC;
+        rs -= last ? 0u : Sp[Yg * LC + xe] - Sp[(Yg - 1) * LC + xe];
+        if ((rs >> PK_SHIFT) != 0u) gptr(bd->gap)[r0 + tx] = 1;
+    }
+    if (tx == 0) { tcount[par ^ 1] = 0u; tcount[4 + (par ^ 1)] = 0u; tflag[par ^ 1] = 0u; }
+    // ---- the candidates: every lane goes through its own (bit 9 - e of cm) and tests the widest Reads box; the few that pass are
+    // a batch of their own - first sufficient width, resolve count, record, sums cell by cell
+    const int64_t tbase = (int64_t)tid * tilecap_p;
+    unsigned* __restrict__ ent_t = gptr(bd->rec_ent) + tbase;
+    if (a.dbg_stop != 2) {
+        const unsigned prow = lds0 + (unsigned)(Y * LC + XH) * 4u;          // P(Y, XH); cell e: - 4 e
+        unsigned bits = cm;
+#pragma unroll 1
+        while (ballot64(bits != 0u) != 0ull) {
+            const bool on = bits != 0u;
+            const int bpos = on ? 31 - __clz((int)bits) : 0;
+            bits = on ? bits & ~(1u << bpos) : 0u;
+            const int e = 9 - bpos;
+            const unsigned pb = prow - 4u * (unsigned)e;
+            const unsigned sr = lds_u32(pb);
+            const unsigned dnW = (unsigned)W * (unsigned)(LC * 4), lfW = (unsigned)W * 4u;
+            const unsigned bl = (lds_u32(pb + (dnW - lfW)) - lds_u32(pb + dnW) - lds_u32(pb - lfW) + sr) & PK_MASK;
+            // (Reads = widest box - box p0 >= min_local_reads needs the widest box alone to reach it)
+            if (ballot64(on & (bl >= (unsigned)minr_p)) == 0ull) continue;
+            const unsigned b0 = (p0_p > 0) ? ((lds_u32(pb + (unsigned)p0_p * (unsigned)(LC * 4 - 4)) - lds_u32(pb + (unsigned)p0_p * (unsigned)(LC * 4)) - lds_u32(pb - (unsigned)p0_p * 4u) + sr) & PK_MASK) : 0u;
+            const bool cand = on & (bl - b0 >= (unsigned)minr_p);
+            if (ballot64(cand) == 0ull) continue;
+            // ---- one batch (see hpk_stencil_s, phase 3)
+            const unsigned cntc = (sr - lds_u32(pb + 4u) - lds_u32(pb - (unsigned)(LC * 4)) + lds_u32(pb - (unsigned)(LC * 4) + 4u)) & PK_MASK;
+            const int x = XH - e - W, y = Y - (W + 1);
+            const unsigned id = (unsigned)x | ((unsigned)y << HPK_ENT_YSHIFT) | (cntc << HPK_ENT_CNT_SHIFT);
+            int wstar = cand ? W : 255;
+            {
+                const unsigned dnf = (unsigned)wmin_p * (unsigned)(LC * 4), lff = (unsigned)wmin_p * 4u;
+                const unsigned bf = (lds_u32(pb + (dnf - lff)) - lds_u32(pb + dnf) - lds_u32(pb - lff) + sr) & PK_MASK;
+                wstar = (cand & (bf - b0 >= (unsigned)minr_p)) ? wmin_p : wstar;
+            }
+            if (W - wmin_p > 1 && ballot64(wstar == W) != 0ull) {
+#pragma unroll 1
+                for (int wa = wmin_p + 1; wa < W; ++wa) {
+                    const unsigned dn = (unsigned)wa * (unsigned)(LC * 4), lf = (unsigned)wa * 4u;
+                    const unsigned rd = (lds_u32(pb + (dn - lf)) - lds_u32(pb + dn) - lds_u32(pb - lf) + sr) & PK_MASK;
+                    wstar = ((wstar == W) & (rd - b0 >= (unsigned)minr_p)) ? wa : wstar;
+                }
+            }
+            {   // resolve histogram by width (16-bit fields per lane for the first eight widths, a ballot per width beyond)
+                const unsigned off = (unsigned)(wstar - wmin_p);
+                const unsigned long long inc = 1ull << ((off & 3u) * 16u);
+                hpack0 += off < 4u ? inc : 0ull;
+                hpack1 += (off - 4u) < 4u ? inc : 0ull;
+                if (W - wmin_p >= 8 && ballot64((off >= 8u) & (wstar != 255)) != 0ull) {
+#pragma unroll 1
+                    for (int w = wmin_p + 8; w <= W; ++w) {
+                        const unsigned c = (unsigned)__popcll(ballot64(wstar == w));
+                        if (lane == w) myhist += c;
+                    }
+                }
+            }
+            if (W > planw_p) wstar = wstar > planw_p ? 255 : wstar;
+            const bool live = cand & (wstar <= wg_p);
+            const unsigned long long lm = ballot64(live);
+            if (lm == 0ull) continue;
+            // the tile's record region: up to a.lean_max candidates; a batch that would go beyond gives the tile up
+            const unsigned nl = (unsigned)__popcll(lm);
+            unsigned before = 0u;
+            if (lane == 0) before = atomicAdd(&tcount[4 + par], nl);
+            before = (unsigned)__builtin_amdgcn_readfirstlane((int)before);
+            if (before + nl > (unsigned)a.lean_max) {
+                if (lane == 0) tflag[par] = 1u;
+                continue;
+            }
+            myexpl += nl;
+            wstar = live ? wstar : 255;
+            const unsigned ri = before + __builtin_amdgcn_mbcnt_hi((unsigned)(lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm, 0u));
+            if (live) ent_t[ri] = id;
+#pragma unroll 1
+            for (int q = 0; q < (SINGLE ? 1 : nslots_p); ++q) {
+                int sq;
+                if (SINGLE) sq = wstar == 255 ? 0xff : wstar - wmin_p;
+                else {
+                    const int wf = (q == 0) ? wf_q[0] : (q == 1) ? wf_q[1] : (q == 2) ? wf_q[2] : wf_q[3];
+                    const int wq = wstar > wf ? wstar : wf;
+                    sq = (int)stepof[q * 32 + (wq & 31)];
+                    sq = ((wstar == 255) | (wq > wg_p)) ? 0xff : sq;
+                }
+                const bool act = sq != 0xff;
+                double SK = 0.0, SY = 0.0;
+                unsigned long long todo = ballot64(act);
+                while (todo != 0ull) {
+                    const int src = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1ull;
+                    const int er = __builtin_amdgcn_readlane(r0 + y, src), ec = __builtin_amdgcn_readlane(c0 + x, src);
+                    const int es = __builtin_amdgcn_readlane(sq, src);
+                    const double2 ex = explicit_sums_wave(gptr(bd->raw), nullptr, gptr(bd->weight), plan->steps[es].m, W, er, ec, n, bd->num, bd->ld, mw, lane);
+                    if (lane == src) { SK = ex.x; SY = ex.y; }
+                }
+                if (live) {
+                    const int64_t o = q * bd->rec_stride + tbase + ri;
+                    gptr(bd->rec_S)[o] = make_double2(act ? SK : 0.0, act ? SY : 0.0);
+                    gptr(bd->rec_W)[o] = act ? (uint8_t)(sq + 1) : (uint8_t)0;
+                }
+            }
+        }
+    }
+    tnext = lds_u32(lds0 + (unsigned)((unsigned char*)tseq - smem) + (unsigned)tpar * 4u);
+    bnext = lds_u32(lds0 + (unsigned)((unsigned char*)tband - smem) + (unsigned)tpar * 4u);
+    __syncthreads();                 // every wave is done with this tile's table
+    if (wave == 0) {
+        if (pend_tid >= 0) {
+            const unsigned nu = (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT;
+            const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)pend_off);
+            if ((unsigned)lane < nu) gptr(bands[pend_band].units)[off + lane] = make_uint2((unsigned)pend_tid, (unsigned)lane | (pend_c << 8));
+        }
+        pend_tid = -1;
+        const bool given_up = __builtin_amdgcn_readfirstlane((int)tflag[par]) != 0;
+        if (given_up) {
+            // more candidates that count than the cell-by-cell path takes: hpk_stencil_s computes the tile in full (redo queue)
+            if (lane == 0) {
+                const unsigned qi = atomicAdd(&a.redoq[0], 1u);
+                a.redoq[4 + 2 * qi] = (unsigned)band;
+                a.redoq[5 + 2 * qi] = (unsigned)rb << 8 | (unsigned)cj;
+            }
+        } else {
+            const unsigned nrec = (unsigned)__builtin_amdgcn_readfirstlane((int)tcount[4 + par]);
+            if (nrec > 0u) {
+                pend_tid = tid;
+                pend_band = band;
+                pend_c = nrec;
+                if (lane == 0) pend_off = atomicAdd(reinterpret_cast<unsigned*>(gptr(bd->small) + HPK_OFF_NUNITS), (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT);
+            }
+            if (lane == 0) gptr(bd->tile_cnt)[tid] = nrec;
+        }
+        mycand += *tcnt;
+        mylean += given_up ? 0x10001u : 1u;
+    }
+    have = have_next; rb = rb_next; cj = cj_next; bw = bw_next;
+    par ^= 1;
+    } while (have && bw == cbw);
+    }
+    if (hband >= 0) flush_hist(bands + hband);
+    if (wave_k == 0 && pend_tid >= 0) {
+        const unsigned nu = (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT;
+        const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)pend_off);
+        if ((unsigned)lane_k < nu) gptr(bands[pend_band].units)[off + lane_k] = make_uint2((unsigned)pend_tid, (unsigned)lane_k | (pend_c << 8));
+    }
 }
 
 // ------------------------------------------------------------------ band from the pixel table (hpk_devband_create)
@@ -1465,8 +1843,20 @@ __global__ void __launch_bounds__(1024) hpk_band_class(HpkBandDesc* __restrict__
         }
         if (a.lean && gptr(bd->weight)) {
             const double* __restrict__ w = gptr(bd->weight);
+            unsigned* __restrict__ wnz = bd->off_wnz ? reinterpret_cast<unsigned*>(gptr(bd->small) + bd->off_wnz) : nullptr;
             bool tiny = false;
-            for (int i = t; i < n; i += 1024) { const double v = fabs(w[i]); tiny = tiny || (v != 0.0 && v < 1e-150); }
+            for (int i0 = 0; i0 < n; i0 += 1024) {          // (whole waves: the bits of 64 bins are one ballot)
+                const int i = i0 + t;
+                // (on the bit pattern: NaN is above the infinities' 0x7ff0..., and a comparison of fabs(w) with itself is folded away)
+                const unsigned long long ub = i < n ? ((unsigned long long)__double_as_longlong(w[i]) & 0x7fffffffffffffffull) : 0ull;
+                const bool isw = ub != 0ull && ub <= 0x7ff0000000000000ull;         // a weight: non-zero, not NaN
+                tiny = tiny || (isw && ub < 0x20b0000000000000ull);                 // |w| < ~2^-500 (1e-150)
+                const unsigned long long nz = __ballot(isw);
+                if (wnz && (t & 63) == 0 && i < n) {
+                    const int wd = (i + HPK_WNZ_LEAD) >> 5;
+                    wnz[wd] = (unsigned)nz; wnz[wd + 1] = (unsigned)(nz >> 32);
+                }
+            }
             if (tiny) tiny_w = 1;
         }
     }
@@ -1512,7 +1902,7 @@ __global__ void __launch_bounds__(1024) hpk_band_class(HpkBandDesc* __restrict__
     __syncthreads();
     const int gTR = bd->TR, gTC = bd->TC, gJ = bd->J;      // (thread 0's writes: behind the barrier)
     int lean_cj = 0x7fffffff;
-    if (a.lean && !tiny_w && gptr(bd->weight)) {
+    if (a.lean && !tiny_w && gptr(bd->weight) && bd->off_wnz) {
         const int wg = wg_s;
         // mean count of a pixel on diagonal k: S[k] over the sampled rows that hold it
         auto mu = [&](int k) -> double {
@@ -1532,6 +1922,10 @@ __global__ void __launch_bounds__(1024) hpk_band_class(HpkBandDesc* __restrict__
         }
         __syncthreads();
         lean_cj = lean_from;
+        // The lean kernel pays where most of a band is far field (5 kb, 1 kb: 12 of 15 chunks); with one or two lean chunks of
+        // four - 10 kb - hpk_stencil_s does the same tiles as fast itself (their candidates are denser, and it walks them in
+        // batches of 64): a band whose lean share is below a.lean_share stays with it entirely.
+        if ((gJ - lean_cj) * 100 < gJ * a.lean_share) lean_cj = 0x7fffffff;
     }
     if (t == 0) bd->lean_cj = lean_cj;
 }
@@ -1833,9 +2227,11 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
         g.sl = (int64_t)__builtin_amdgcn_readfirstlane(lpair_slot[pj]) * b_rec_stride;
     };
     // first round: entry, first slot's step and sums (idle lanes read the tile's first record: always allocated, never used)
+    // (several pairs: the items of one batch follow each other, pair after pair - the entry, and with it the pixel's 1-D expected
+    // and biases in the second round, are loaded for the first pair and stay for the others)
     auto issue_records = [&](const Geo& g) {
         ri_b = (g.i0 + lane < g.cnt) ? (unsigned)(g.i0 + lane) : 0u;
-        ent_b = (b_rec_ent + g.tbase0)[ri_b];
+        if (ONE || !HPK_SCORE_REUSE || g.pj == 0) ent_b = (b_rec_ent + g.tbase0)[ri_b];
         stp_b = (int)(b_rec_W + g.tbase0 + g.sl)[ri_b];
         s2_b = (b_rec_S + g.tbase0 + g.sl)[ri_b];
     };
@@ -1844,9 +2240,11 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
         const bool cn = g.i0 + lane < g.cnt;
         const unsigned e = cn ? ent_b : 0u;
         const int r = g.r0 + (int)HPK_ENT_Y(e), c = g.c0 + (int)HPK_ENT_X(e), d = c - r;
-        ir_b = b_IR[cn ? (unsigned)d : 0u];
-        b2_b = b_b2[cn ? (unsigned)c : 0u];
-        b1_b = b_b1[cn ? (unsigned)r : 0u];
+        if (ONE || !HPK_SCORE_REUSE || g.pj == 0) {
+            ir_b = b_IR[cn ? (unsigned)d : 0u];
+            b2_b = b_b2[cn ? (unsigned)c : 0u];
+            b1_b = b_b1[cn ? (unsigned)r : 0u];
+        }
         const bool top = cn && r < W, right = cn && c >= b_n - W;
         const double* __restrict__ tab = (top != right) ? b_eedge : b_etab;
         const unsigned tbase = (top != right) ? (unsigned)(((top ? 0 : 1) * W + (top ? r : b_n - 1 - c)) * nsteps_u) * tstride : 0u;
@@ -1946,7 +2344,10 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                     if (more) issue_round2(gn);                 // (bhfdr: one pair; the series below is all arithmetic)
                     if (eK > 0.0) {
                         chunk2[0] = 1;
-                        p2[0] = poisson_sf(O, eK, const_cast<const double*>(ka->sfe), a.sig);      // callers.py:536-540
+                        // callers.py:536-540.  Only p <= sig is ever looked at (the family's size is counted above all pixels); a
+                        // count below its expectation has p = P(X > O) >= P(Poisson(O) > O) >= 0.264 (O >= 1: candidates are
+                        // non-zero pixels), so for sig < 1/4 the series is left out there - half of a chromosome's pixels
+                        if (!(a.sig < 0.25) || O >= eK) p2[0] = poisson_sf(O, eK, const_cast<const double*>(ka->sfe), a.sig);
                     }
                 } else {
                     // Chunk of E: boundaries lbounds[i] = 2^(i/3); membership is strict on both sides (callers.py:38), so E
@@ -2040,7 +2441,11 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                         const bool beats = ebits > lemax[set];
                         if (__ballot(beats) != 0ull) { if (beats) atomicMax(&lemax[set], ebits); }
                         // tests per family; family 0 of a set collects its valid pixels without a chunk (the host adds the
-                        // families up to the set's number of valid pixels)
+                        // families up to the set's number of valid pixels).  (One LDS atomic per lane, onto the handful of words a
+                        // wave's chunks share: served one lane at a time, and still the cheapest form - one add of the lanes' count
+                        // per distinct chunk, a leader's chunk at a time, costs the kernel 5 % with one round and 17 % with three:
+                        // it is bound by the instructions it issues, and the LDS pipe has nothing else to do here.  Round 5,
+                        // profiles/r05_score_ab.txt.)
                         if (valid) atomicAdd(&lm[set][chunk], 1u);
                     }
                     if (sm != 0ull) {
@@ -2314,9 +2719,9 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkBandDesc* __rest
 // ------------------------------------------------------------------ launchers
 int hpk_stencil_s_lds_bytes() { return LR * LC * 12 + HPK_TLIST * 4 + 128 + HPK_MAX_STEPS * 32 + HPK_KSLOTS * 32 + LC * 8 * 4 + LC * 4; }
 
-template <bool BALF64, bool SINGLE>
+template <bool BALF64, bool SINGLE, bool QUEUE = false>
 static void launch_stencil_s_t(const HpkStencilArgs& a, const HpkBandDesc* d_bands, hipStream_t st) {
-    auto kern = hpk_stencil_s<BALF64, SINGLE>;
+    auto kern = hpk_stencil_s<BALF64, SINGLE, QUEUE>;
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2332,10 +2737,36 @@ bool hpk_stencil_s_applies(const HpkGeo& g, int64_t max_ld, int32_t max_n) {
     return max_ld <= (int64_t)(1 << 21) && max_n < (1 << 27) && g.W >= 4 && g.TR * g.TC <= HPK_TLIST;
 }
 
-void hpk_launch_stencil_batch(const HpkStencilArgs& a, const HpkBandDesc* d_bands, bool balf64, hipStream_t st) {
+int hpk_stencil_lean_lds_bytes() { return LR * LC * 4 + 3 * LC * 4 + 128 + HPK_KSLOTS * 32 + 2 * HPK_LST_BYTES; }
+
+template <bool SINGLE>
+static void launch_stencil_lean_t(const HpkStencilArgs& a, const HpkBandDesc* d_bands, int cus, hipStream_t st) {
+    auto kern = hpk_stencil_lean<SINGLE>;
+    static int per_cu = 0;
+    if (per_cu == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 1024, hpk_stencil_lean_lds_bytes()) != hipSuccess || nb <= 0) nb = 1;
+        per_cu = nb > 2 ? 2 : nb;
+    }
+    HpkStencilArgs al = a;
+    al.grid = std::max(8, (cus * per_cu) / 8 * 8);          // persistent: the workgroups resident at once
+    hipLaunchKernelGGL(kern, dim3(al.grid), dim3(1024), hpk_stencil_lean_lds_bytes(), st, al, d_bands);
+}
+
+void hpk_launch_stencil_batch(const HpkStencilArgs& a, const HpkBandDesc* d_bands, bool balf64, int cus, hipStream_t st) {
     const bool single = a.single != 0;
+    const bool lean = !balf64 && a.lean_max > 0 && a.redoq && !a.generic;
+    if (lean) {
+        if (single) launch_stencil_lean_t<true>(a, d_bands, cus, st); else launch_stencil_lean_t<false>(a, d_bands, cus, st);
+    }
     if (balf64) { if (single) launch_stencil_s_t<true, true>(a, d_bands, st); else launch_stencil_s_t<true, false>(a, d_bands, st); }
     else        { if (single) launch_stencil_s_t<false, true>(a, d_bands, st); else launch_stencil_s_t<false, false>(a, d_bands, st); }
+    if (lean) {
+        // the tiles the lean kernel gave up (none, as a rule: the launch finds its queue empty), in full
+        HpkStencilArgs aq = a;
+        aq.grid = std::min(a.grid, 64);
+        if (single) launch_stencil_s_t<false, true, true>(aq, d_bands, st); else launch_stencil_s_t<false, false, true>(aq, d_bands, st);
+    }
 }
 
 void hpk_launch_freeze_tot(const HpkDevPlan* plan, const HpkBandDesc* d_bands, int nbands, hipStream_t st) {

@@ -160,7 +160,7 @@ typedef struct {
 
     /* timing, milliseconds (HIP events on the ctx stream; wall for host parts) */
     float ms_h2d, ms_stencil, ms_freeze, ms_score, ms_tighten, ms_gap, ms_d2h, ms_host_bh, ms_total;
-    int32_t stencil_kernel;    /* stencil kernel that ran: always 2 = hpk_stencil_s (the one generation there is) */
+    int32_t stencil_kernel;    /* stencil kernel that ran: always 2: the one stencil generation there is */
     int32_t record_bound;      /* the stencil wrote records for candidates resolved up to this width (255: all of them;
                                   HPK_FLAG_DENSE_*, HPK_FLAG_NO_SCORE); see hpk_submit_band */
     int32_t redone;            /* bit 0: the widening froze beyond the bound taken from the previous chromosome and the
