@@ -229,7 +229,7 @@ def run_genome(args, cfg, ctx, rank, world, local, dist, emit=True, steps=None, 
                        'rescored_rank0': int(sum(t[6] for t in last)),
                        'parallelism': 'chromosomes dealt largest-first to the GPUs, no collective',
                        'whole_genome_wall_ms': elapsed / steps * 1e3, 'host_inputs': bool(args.host_inputs)},
-            'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil_s', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil_s (+ hpk_stencil_lean)', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel_ms': st_ms / nlaunch,
                          'launches_timed': nlaunch, 'launches': len(results),
                          'algorithmic_bytes_per_launch': BYTES_PER_PX * st_px / nlaunch},
@@ -301,6 +301,10 @@ def main():
     ap.add_argument('--no-probes', action='store_true',
                     help='skip the single-chromosome latency probes and the phase-timed launches after the timed region (profiling '
                          'runs: every stencil launch of the process then carries a whole group)')
+    ap.add_argument('--structure', action='store_true',
+                    help='bands with structure on top of the distance decay (synthetic.structure_fields: TAD blocks, a compartment '
+                         'checkerboard, dense far-field patches) - what the record bounds, depth classes and lean column chunks are '
+                         'not tuned on; the line reports what they did (passes_redone_in_full, passes_rescored, lean_redone)')
     ap.add_argument('--cpu-allcores-rows', type=int, default=3000,
                     help='rows per process of the all-cores CPU baseline leg (0 = skip)')
     args = ap.parse_args()
@@ -363,7 +367,8 @@ def main():
     bands, band_depth = [], []
     for sd in range(ndist):
         dp = depths[sd % len(depths)]
-        raw_d, w_d, ir_d, b_d = bandgen.device_band(n, num, ld, mw, depth=dp, nloops=cfg['nloops'], seed=ndist * rank + sd, device=dev)
+        raw_d, w_d, ir_d, b_d = bandgen.device_band(n, num, ld, mw, depth=dp, nloops=cfg['nloops'], seed=ndist * rank + sd, device=dev,
+                                                    structure={} if args.structure else None)
         bands.append((raw_d, w_d, ir_d, b_d))
         band_depth.append(dp)
     nseeds = ndist
@@ -579,12 +584,13 @@ def main():
                        'lean_redone': lean_timed.get('lean_redone', 0), 'lean_explicit': lean_timed.get('lean_explicit', 0),
                        'parallelism': 'one chromosome per GPU, no collective', 'pipeline_depth': depth,
                        'sync_call_ms': float(np.median(lat)) if lat else None,
-                       'stencil_only': bool(args.stencil_only), 'host_inputs': bool(args.host_inputs), 'balanced_f64': bool(args.balanced_f64)},
+                       'stencil_only': bool(args.stencil_only), 'host_inputs': bool(args.host_inputs), 'balanced_f64': bool(args.balanced_f64),
+                       'structure': bool(args.structure)},
             # frac: SURVEY.md §8-D3 convention, 20 B per band pixel per pair (4 B read + 2 x 8 B local expected written).  The
             # kernel writes compact records for the candidates only, so two more figures keep the books honest:
             # compact_4Bpx (the §8-D3 figure for a compacting mode: the 4 B/px that must be read) and hbm_frac_measured
             # (counter traffic per launch / kernel time / peak - what the memory system actually carries).
-            'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil_s', 'achieved': achieved,
+            'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil_s (+ hpk_stencil_lean)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
                          'kernel_ms': st, 'kernel_ms_per_chromosome': st / group,
                          'algorithmic_bytes_per_launch': BYTES_PER_PX * px_per_step * group,
@@ -592,9 +598,25 @@ def main():
                          'compact_4Bpx': {'achieved': 4.0 * px_per_step * group / (st * 1e-3) / 1e9,
                                           'frac': 4.0 * px_per_step * group / (st * 1e-3) / 1e9 / HBM_PEAK_GBS},
                          'hbm_frac_measured': None},
+            # per chromosome, from two launches AFTER the timed region with events between the kernels (HPK_FLAG_PHASE_TIMING:
+            # five more event pairs, ~3 us of idle GPU each - the stages come out 15-30 % above what they take in the timed
+            # region, whose launches run without them; roofline.kernel_ms is the timed region's own figure): the split, not the sum
             'phases_ms': phases,
+            'phases_note': 'instrumented launches after the timed region (events between the kernels): +15-30 %, for the split only',
             'extra': extra,
         }
+        if phases.get('score'):
+            # The second kernel, hpk_score (a gather kernel: issue- and latency-bound), against the same roof.  Algorithmic
+            # bytes per scored candidate and pair: its record (4 B entry + 1 B step + 16 B sums) and what its expected value is
+            # formed from (IR[d], B1[r], B2[c], two local-expected table entries: 40 B); candidates = those resolved at the
+            # executed steps.  Time: the instrumented launch above (an upper bound of the timed region's).
+            nrec = float(sum(c_ for _, _, c_, ex in R.steps if ex))
+            sbytes = nrec * 61.0
+            sach = sbytes / (phases['score'] * 1e-3) / 1e9
+            out['roofline_score'] = {'bound': 'hbm', 'kernel': 'hpk_score', 'achieved': sach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                     'frac': sach / HBM_PEAK_GBS, 'traffic': None, 'kernel_ms_per_chromosome': phases['score'],
+                                     'candidates_scored_per_chromosome': nrec, 'algorithmic_bytes_per_candidate': 61.0,
+                                     'time_source': 'instrumented launch (phases_ms.score)'}
         try:        # HBM traffic per launch of the dominant kernel, measured off-line with rocprofv3 --pmc (profiles/)
             tr = json.load(open(os.path.join(REPO, 'profiles', 'traffic.json'))).get(args.config)
             if tr:
@@ -602,6 +624,8 @@ def main():
                 out['roofline']['traffic'] = tr['traffic_bytes'] * group
                 out['roofline']['traffic_source'] = tr['source']
                 out['roofline']['hbm_frac_measured'] = tr['traffic_bytes'] * group / (st * 1e-3) / 1e9 / HBM_PEAK_GBS
+                if 'roofline_score' in out and tr.get('score_traffic_bytes'):
+                    out['roofline_score']['traffic'] = tr['score_traffic_bytes']      # per chromosome, like its time
         except Exception:
             pass
         if world == 1 and args.cpu_rows > 0:

@@ -8,8 +8,18 @@ import numpy as np
 
 
 def device_band(n, num, ld, mw, depth=60.0, alpha=1.0, nloops=200, seed=0, nan_frac=0.025, enrich=8.0, device='cuda',
-                want_expected=True):
+                want_expected=True, structure=None):
+    """structure: None, or keyword arguments of `synthetic.structure_fields` - TAD blocks, a compartment checkerboard and dense
+    far-field patches multiply the rate (the same fields as the host generator's, applied slab by slab)."""
     import torch
+    from . import synthetic
+    fields = None
+    if structure is not None:
+        fields = {}
+        for key, v in synthetic.structure_fields(n, num, seed, **structure).items():
+            fields[key] = v.tolist() if key == 'patches' else torch.from_numpy(np.ascontiguousarray(v)).to(device)
+        if 'tad_id' in fields:
+            fields['tad_id'] = fields['tad_id'].long()
     g = torch.Generator(device=device)
     g.manual_seed(int(seed))
     k = torch.arange(num, device=device, dtype=torch.float32)
@@ -33,6 +43,10 @@ def device_band(n, num, ld, mw, depth=60.0, alpha=1.0, nloops=200, seed=0, nan_f
                         rr, kk = r + dr, d + dc - dr
                         if r0 <= rr < r1 and 0 <= kk < num:
                             rate[rr - r0, kk] *= enrich
+        if fields is not None:
+            rr_ = torch.arange(r0, r1, device=device).unsqueeze(1).expand(r1 - r0, num)
+            cc_ = (rr_ + torch.arange(num, device=device).unsqueeze(0)).clamp(max=n - 1)
+            rate = rate * synthetic.structure_gain(fields, rr_, cc_, xp=torch)
         blk = torch.poisson(rate, generator=g)
         rr = torch.arange(r0, r1, device=device).unsqueeze(1)
         blk[(rr + torch.arange(num, device=device).unsqueeze(0)) >= n] = 0

@@ -180,7 +180,7 @@ GROUP_BYTES = 3 << 29        # band bytes of one batch (1.5 GiB; the device work
 GROUP_CHROMS = 8             # ... and chromosomes per batch
 
 
-def _score_queue(args_dict, mode, queue, device):
+def _score_queue(args_dict, mode, queue, device, shared=False):
     """One GPU worker: takes chromosomes from the shared largest-first queue, hands them to the GPU in batches (several
     chromosomes per set of launches: up to GROUP_CHROMS chromosomes / GROUP_BYTES of bands, the first one alone so that the GPU
     starts at once), `pipeline_depth` batches in flight - while batch i is on the GPU, batch i + 1 is read and uploaded and
@@ -195,29 +195,66 @@ def _score_queue(args_dict, mode, queue, device):
     # every run starts without memory of the chromosomes an earlier run in this process scored; --deterministic: the plan's
     # own tile geometry for every chromosome (the record bound stays: it never touches a value)
     ctx.set_option('reset_hints', 1)
-    ctx.set_option('spec_halo', 0 if args_dict.get('deterministic') else 1)
+    if args_dict.get('deterministic'):
+        ctx.set_option('spec_halo', 0)
+    elif 'HPK_SPEC_HALO' not in os.environ:         # (the cached context may come from a --deterministic run; the environment's choice stands)
+        ctx.set_option('spec_halo', 1)
     depth = ctx.pipeline_depth
     pending, out = collections.deque(), {}
 
     # The reader: a thread of its own takes chromosomes from the queue and reads them (HDF5 + chunk inflation release the
     # GIL), two ahead at most, so that chromosome i + 1 is read while chromosome i's batch is on the GPU and chromosome
     # i - 1 goes through clustering.  It opens its own handle on the file and makes no GPU call (a context belongs to one thread).
-    fetched = _queue.Queue(maxsize=2)
+    # (several workers on one queue - `shared` -: one chromosome ahead only, so that a worker does not sit on chromosomes
+    # another GPU could start on; the largest-first order is what balances the tail)
+    fetched = _queue.Queue(maxsize=1 if shared else 2)
     info = {}
+    stop = threading.Event()            # the consumer gave up (an exception on its side): the reader takes no more chromosomes
+
+    def put(item):
+        while not stop.is_set():
+            try:
+                fetched.put(item, timeout=0.2)
+                return True
+            except _queue.Full:
+                pass
+        return False
 
     def reader():
+        src = None
         try:
             src = io.open_source(args_dict['path'])
             info['binsize'] = src.binsize
             use_pixels = hasattr(src, 'fetch_pixels') and not os.environ.get('HPK_HOST_BANDS')
             for key in queue:
-                fetched.put((key, _read(args_dict, src, key, use_pixels)))
-            fetched.put(None)
+                if stop.is_set() or not put((key, _read(args_dict, src, key, use_pixels))):
+                    return
+            put(None)
         except BaseException as e:          # (re-raised by the consumer)
-            fetched.put(e)
+            put(e)
+        finally:
+            close = getattr(src, 'close', None)
+            if close is not None:
+                close()
 
     th = threading.Thread(target=reader, name='hpk-reader', daemon=True)
     th.start()
+    try:
+        return _consume(args_dict, mode, device, ctx, depth, fetched, info, pending, out, collections)
+    finally:
+        # whatever ended the loop: the reader stops taking chromosomes off the (shared) queue, is not left blocked on a full
+        # hand-over queue, and closes its file
+        stop.set()
+        while th.is_alive():
+            try:
+                fetched.get_nowait()
+            except _queue.Empty:
+                pass
+            th.join(timeout=0.05)
+
+
+def _consume(args_dict, mode, device, ctx, depth, fetched, info, pending, out, collections):
+    from . import _lib
 
     def collect():
         labels, call = pending.popleft()
@@ -242,7 +279,6 @@ def _score_queue(args_dict, mode, queue, device):
             break
     while pending:
         collect()
-    th.join()
     return out
 
 
@@ -278,7 +314,7 @@ def _gpu_worker(args_dict, mode, device, sizes, value, results, wid=0):
     from . import parallel
     try:
         queue = parallel.WorkQueue(sizes, parallel.mp_counter(value))
-        results.put((wid, _score_queue(args_dict, mode, queue, device), None))
+        results.put((wid, _score_queue(args_dict, mode, queue, device, shared=True), None))
     except BaseException as e:
         results.put((wid, None, _describe_error(e)))
 
@@ -372,7 +408,7 @@ def _run(mode, argv):
         dev = local if args.device is None else args.device
         queue = parallel.WorkQueue(sizes, parallel.store_counter())
         try:                                         # a rank that fails still takes part in the gather: its error travels instead of its tables
-            mine = _score_queue(a, mode, queue, dev)
+            mine = _score_queue(a, mode, queue, dev, shared=world > 1)
         except Exception as e:
             mine = {'__error__': _describe_error(e)}
         tables = parallel.gather_tables(mine, rank, world)

@@ -107,6 +107,9 @@ class _H5C(object):
         self.f = L.H5Fopen(str(path).encode(), 0, 0)            # H5F_ACC_RDONLY, H5P_DEFAULT
         if self.f < 0:
             raise IOError('cannot open %s as an HDF5 file' % path)
+        self.path = str(path)
+        self.fd = -1                    # a descriptor of our own on the file (read_big: the chunks are pread by the decoding threads)
+        self.fd_ok = None               # ... once a chunk read that way has been seen to equal H5Dread_chunk's (None: not checked yet)
         self.g = L.H5Gopen2(self.f, group.encode(), 0)
         if self.g < 0:
             L.H5Fclose(self.f)
@@ -120,6 +123,9 @@ class _H5C(object):
         if getattr(self, 'f', -1) >= 0:
             L.H5Fclose(self.f)
             self.f = -1
+        if getattr(self, 'fd', -1) >= 0:
+            os.close(self.fd)
+            self.fd = -1
 
     def exists(self, name):
         L = self.lib()
@@ -207,17 +213,24 @@ class _H5C(object):
 
     PARALLEL_MIN = 1 << 20          # elements from which a read goes chunk by chunk (below: one H5Dread)
 
-    def read_big(self, name, start, stop, kind, threads=None):
+    @staticmethod
+    def _minus(a, bias):
+        if bias:
+            a -= bias
+        return a
+
+    def read_big(self, name, start, stop, kind, threads=None, bias=0):
         """`read` for the long slices of the pixel table: the data set's chunks are fetched as stored (H5Dread_chunk: the
         library itself is not thread-safe, so this part stays serial - it is a copy out of the page cache) and inflated /
-        un-shuffled on a thread pool (zlib and numpy release the GIL).  cooler writes its columns gzip-compressed with the
-        shuffle filter in chunks; the decoding is 90 % of what reading a chromosome costs.  Anything unexpected - another
-        filter, big-endian data, an old libhdf5 - falls back to `read`."""
+        un-shuffled / widened by libhpk's host threads (hpk_decode_chunks; HPK_READ_PYTHON=1 or no library: a Python thread pool
+        - zlib and numpy release the GIL).  cooler writes its columns gzip-compressed with the shuffle filter in chunks; the
+        decoding is 90 % of what reading a chromosome costs.  Anything unexpected - another filter, big-endian data, an old
+        libhdf5 - falls back to `read`."""
         import zlib
         from concurrent.futures import ThreadPoolExecutor
         L = self.lib()
         if not self.have_chunks or stop - start < self.PARALLEL_MIN:
-            return self.read(name, start, stop, kind)
+            return self._minus(self.read(name, start, stop, kind), bias)
         d = self._open(name)
         try:
             pl = L.H5Dget_create_plist(d)
@@ -237,27 +250,77 @@ class _H5C(object):
             L.H5Tclose(ft)
             ok = ok and filt in ([1], [2, 1]) and little and tcls in (0, 1, 8) and size in (1, 2, 4, 8)     # deflate | shuffle + deflate
             if not ok:
-                return self.read(name, start, stop, kind)
+                return self._minus(self.read(name, start, stop, kind), bias)
             if kind is None:
                 kind = 'f' if tcls == 1 else 'i'
             dt = np.dtype(('<f%d' % size) if tcls == 1 else ('<%s%d' % ('i' if signed else 'u', size)))
             cs = int(cs[0])
             shuffle = filt[0] == 2
-            raws = []
-            for ci in range(start // cs, (stop - 1) // cs + 1):
+            # Where the chunks are (H5Dget_chunk_info_by_coord: the library is not thread-safe, this loop stays serial - it reads
+            # the chunk index only).  The chunks themselves are then pread, inflated, un-shuffled and widened by libhpk's host threads
+            # straight into the result (hpk_decode_chunks_fd: no Python object, no allocation per chunk); the first chunk a file is
+            # read this way is compared with H5Dread_chunk's copy once (a user block or a driver that moves the addresses would show).
+            c0, c1 = start // cs, (stop - 1) // cs + 1
+            lens, addrs = [], []
+            for ci in range(c0, c1):
                 off = (C.c_uint64 * 1)(ci * cs)
                 mask, addr, nbytes = C.c_uint(0), C.c_uint64(0), C.c_uint64(0)
                 if L.H5Dget_chunk_info_by_coord(d, off, C.byref(mask), C.byref(addr), C.byref(nbytes)) < 0 or mask.value != 0 \
                         or nbytes.value == 0:
-                    return self.read(name, start, stop, kind)
-                buf = C.create_string_buffer(nbytes.value)
+                    return self._minus(self.read(name, start, stop, kind), bias)
+                lens.append(int(nbytes.value))
+                addrs.append(int(addr.value))
+            nthr = threads or int(os.environ.get('HPK_READ_THREADS', 0)) or min(64, os.cpu_count() or 1)
+            lib = None
+            if not os.environ.get('HPK_READ_PYTHON'):
+                try:
+                    from . import _lib
+                    lib = _lib.load()
+                except Exception:          # (the reader also serves hosts where the library is not built: the Python pool below)
+                    lib = None
+            kd = 2 if tcls == 1 else (0 if signed else 1)
+            out = np.empty(stop - start, dtype=np.int64 if kind == 'i' else np.float64)
+
+            def read_chunk(k):
+                buf = np.empty(lens[k], dtype=np.uint8)
                 fm = C.c_uint32(0)
-                if L.H5Dread_chunk(d, 0, off, C.byref(fm), buf) < 0 or fm.value != 0:
-                    return self.read(name, start, stop, kind)
-                raws.append((ci, buf))
+                if L.H5Dread_chunk(d, 0, (C.c_uint64 * 1)((c0 + k) * cs), C.byref(fm), C.c_void_p(buf.ctypes.data)) < 0 or fm.value != 0:
+                    return None
+                return buf
+
+            if lib is not None and not os.environ.get('HPK_READ_NO_PREAD') and self.fd_ok is not False:
+                if self.fd < 0:
+                    try:
+                        self.fd = os.open(self.path, os.O_RDONLY)
+                    except OSError:
+                        self.fd_ok = False
+                if self.fd >= 0 and self.fd_ok is None:
+                    ref = read_chunk(0)
+                    self.fd_ok = ref is not None and os.pread(self.fd, lens[0], addrs[0]) == ref.tobytes()
+                if self.fd_ok:
+                    rc = lib.hpk_decode_chunks_fd(self.fd, (C.c_uint64 * len(addrs))(*addrs), (C.c_uint64 * len(lens))(*lens), len(lens), c0, cs,
+                                                  size, kd, 1 if shuffle else 0, start, stop, out.ctypes.data, 0 if kind == 'i' else 1, int(bias), nthr)
+                    if rc == 0:
+                        return out
+                    return self._minus(self.read(name, start, stop, kind), bias)
+            # the chunks as stored, into one arena (H5Dread_chunk, serial: a copy out of the page cache)
+            arena = np.empty(sum(lens) + 64, dtype=np.uint8)
+            base, pos, offs = arena.ctypes.data, 0, []
+            for k in range(len(lens)):
+                fm = C.c_uint32(0)
+                if L.H5Dread_chunk(d, 0, (C.c_uint64 * 1)((c0 + k) * cs), C.byref(fm), C.c_void_p(base + pos)) < 0 or fm.value != 0:
+                    return self._minus(self.read(name, start, stop, kind), bias)
+                offs.append(base + pos)
+                pos += lens[k]
         finally:
             L.H5Dclose(d)
-        out = np.empty(stop - start, dtype=np.int64 if kind == 'i' else np.float64)
+        if lib is not None:
+            rc = lib.hpk_decode_chunks((C.c_void_p * len(offs))(*offs), (C.c_uint64 * len(lens))(*lens), len(offs), c0, cs, size, kd,
+                                       1 if shuffle else 0, start, stop, out.ctypes.data, 0 if kind == 'i' else 1, int(bias), nthr)
+            if rc == 0:
+                return out
+            return self._minus(self.read(name, start, stop, kind), bias)
+        raws = [(c0 + k, arena[o - base:o - base + n_]) for k, (o, n_) in enumerate(zip(offs, lens))]
 
         def decode(item):
             ci, buf = item
@@ -269,7 +332,6 @@ class _H5C(object):
             lo, hi = max(start, ci * cs), min(stop, ci * cs + cs)
             out[lo - start:hi - start] = v[lo - ci * cs:hi - ci * cs]
 
-        nthr = threads or int(os.environ.get('HPK_READ_THREADS', 0)) or min(64, os.cpu_count() or 1)      # (16 | 32 | 64 | 128 threads: no difference on the 256-core GPU box, profiles/r04_host_e2e_deep.txt)
         if nthr > 1 and len(raws) > 1:
             if _H5C._pool is None or _H5C._pool_n != nthr:
                 _H5C._pool, _H5C._pool_n = ThreadPoolExecutor(nthr), nthr
@@ -277,7 +339,7 @@ class _H5C(object):
         else:
             for it in raws:
                 decode(it)
-        return out
+        return self._minus(out, bias)
 
     def attr(self, obj, name, default=None):
         """Scalar integer / float / boolean-like attribute of the group (obj = '.') or of a data set."""
@@ -344,8 +406,11 @@ class _H5Py(object):
             return [x.decode() if isinstance(x, bytes) else str(x) for x in v]
         return v.astype(np.float64 if (kind == 'f' or (kind is None and v.dtype.kind == 'f')) else np.int64)
 
-    def read_big(self, name, start, stop, kind, threads=None):
-        return self.read(name, start, stop, kind)
+    def read_big(self, name, start, stop, kind, threads=None, bias=0):
+        v = self.read(name, start, stop, kind)
+        if bias:
+            v -= bias
+        return v
 
     def attr(self, obj, name, default=None):
         o = self.g if obj == '.' else self.g[obj]
@@ -414,12 +479,13 @@ class CoolFile(object):
         lo, hi = self.extent(chrom)
         off = self.h.read('indexes/bin1_offset', lo, hi + 1, kind='i')
         p0, p1 = int(off[0]), int(off[-1])
-        b1 = self.h.read_big('pixels/bin1_id', p0, p1, 'i')
-        b2 = self.h.read_big('pixels/bin2_id', p0, p1, 'i')
+        # (bin ids relative to the chromosome's first bin as they are decoded: no second pass over 800 MB arrays)
+        b1 = self.h.read_big('pixels/bin1_id', p0, p1, 'i', bias=lo)
+        b2 = self.h.read_big('pixels/bin2_id', p0, p1, 'i', bias=lo)
         cnt = self.h.read_big('pixels/count', p0, p1, None)
-        keep = b2 < hi                                  # pixels are sorted by bin1: the trans ones have bin2 beyond the chromosome
+        keep = b2 < hi - lo                             # pixels are sorted by bin1: the trans ones have bin2 beyond the chromosome
         if self.square:
             keep &= b2 >= b1                            # (and, both triangles stored: trans pixels also lie before it)
         if not keep.all():
             b1, b2, cnt = b1[keep], b2[keep], cnt[keep]
-        return b1 - lo, b2 - lo, cnt
+        return b1, b2, cnt

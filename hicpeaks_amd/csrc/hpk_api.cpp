@@ -645,6 +645,12 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         if (opt.spec && c->hint_n > 0 && std::memcmp(&key, &c->hint_key, sizeof(key)) == 0) {
             int hw = -1;
             for (int i = 0; i < c->hint_n; ++i) hw = std::max(hw, c->hint_w[i]);
+            // ... and no narrower than the widest width a depth class is known to freeze at: hpk_band_class gives a band its class'
+            // width only up to the batch's bound, and a chromosome of a deeper sample than the last collections' would run under a
+            // bound it is known to exceed (computed once more, every time).  Every band lays its tiles out for its own bound, so a
+            // wide batch bound costs the shallow ones nothing.
+            if (opt.spec_class)
+                for (int i = 0; i < HPK_NCLASS; ++i) hw = std::max(hw, (int)std::max(c->class_w[i], c->class_w1[i]));
             if (hw >= 0) wg_all = std::min(W, hw + opt.spec_margin);
         }
         if (opt.spec_force >= 0) wg_all = std::min(W, opt.spec_force);        // tests: a bound that is too narrow
@@ -1538,15 +1544,19 @@ int64_t band_scatter(const int64_t* bin1, const int64_t* bin2, const int32_t* ci
 }
 }  // namespace
 
-// One O(nnz) pass.  A large pixel table whose rows come in order (cooler's pixel table is sorted by bin1, bin2) is cut at row
-// changes into one stretch per thread: the stretches write disjoint band rows, repeats of a cell stay in one stretch.  A table that
-// turns out not to be in row order is done again by one thread (repeats may then meet anywhere).
+// One O(nnz) scatter.  A large pixel table whose rows come in order (cooler's pixel table is sorted by bin1, bin2) is cut at row
+// changes into one stretch per thread: the stretches write disjoint band rows, repeats of a cell stay in one stretch.  Whether the
+// table is in row order (and every bin inside the chromosome) is found out first, by the same threads reading only; a table
+// that is not goes to one thread (repeats may then meet anywhere).  HPK_COO_MIN_PER_THREAD: pixels per thread below which the
+// table is not split (default 4 Mi; tests).
 int64_t hpk_band_from_coo(const int64_t* bin1, const int64_t* bin2, const void* count, int32_t count_f64, int64_t nnz,
                           int32_t n, int32_t num, int64_t ld, float* raw) {
     if (!bin1 || !bin2 || !count || !raw || nnz < 0 || n <= 0 || num <= 0 || ld < num) return HPK_ERR_INVALID;
     const int32_t* ci = count_f64 ? nullptr : static_cast<const int32_t*>(count);
     const double* cd = count_f64 ? static_cast<const double*>(count) : nullptr;
-    int nt = (int)std::min<int64_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), nnz / (4 << 20));
+    int64_t per_thread = 4 << 20;
+    if (const char* e = std::getenv("HPK_COO_MIN_PER_THREAD")) per_thread = std::max<int64_t>(1, std::atoll(e));
+    const int nt = (int)std::min<int64_t>(std::min(16u, std::max(1u, std::thread::hardware_concurrency())), nnz / per_thread);
     if (nt > 1) {
         std::vector<int64_t> cut(nt + 1);
         cut[0] = 0; cut[nt] = nnz;
@@ -1556,23 +1566,36 @@ int64_t hpk_band_from_coo(const int64_t* bin1, const int64_t* bin2, const void* 
             while (t < nnz && t > 0 && row(t) == row(t - 1)) ++t;          // to the next row change
             cut[i] = t;
         }
-        std::vector<int64_t> got(nt, 0);
-        std::vector<char> ok(nt, 1);
-        std::vector<std::thread> pool;
-        auto work = [&](int i) {
-            bool srt = true;
-            got[i] = band_scatter(bin1, bin2, ci, cd, cut[i], cut[i + 1], n, num, ld, raw, &srt);
-            // (the stretch itself in row order, and it starts at or behind the row the stretch before ended on)
-            if (!srt || (i > 0 && cut[i] < nnz && cut[i] > 0 && row(cut[i]) < row(cut[i] - 1))) ok[i] = 0;
+        // read-only: every stretch in row order, starting at or behind the row the stretch before ended on, every bin inside
+        std::vector<char> state(nt, 0);             // 0 in order, 1 not in row order, 2 a bin outside the chromosome
+        auto check = [&](int i) {
+            int64_t last = cut[i] > 0 ? row(cut[i] - 1) : -1;
+            for (int64_t t = cut[i]; t < cut[i + 1]; ++t) {
+                const int64_t a = bin1[t] < bin2[t] ? bin1[t] : bin2[t], b = bin1[t] < bin2[t] ? bin2[t] : bin1[t];
+                if (a < 0 || b >= n) { state[i] = 2; return; }
+                if (a < last) state[i] = 1;
+                last = a;
+            }
         };
-        for (int i = 1; i < nt; ++i) pool.emplace_back(work, i);
-        work(0);
-        for (std::thread& t : pool) t.join();
-        bool all = true;
-        int64_t stored = 0;
-        for (int i = 0; i < nt; ++i) { if (got[i] < 0) return HPK_ERR_INVALID; all = all && ok[i]; stored += got[i]; }
-        if (all) return stored;
-        for (int64_t r = 0; r < n; ++r) std::memset(raw + r * ld, 0, sizeof(float) * (size_t)num);      // not in row order: once more, serially
+        {
+            std::vector<std::thread> pool;
+            for (int i = 1; i < nt; ++i) pool.emplace_back(check, i);
+            check(0);
+            for (std::thread& t : pool) t.join();
+        }
+        bool sorted = true;
+        for (int i = 0; i < nt; ++i) { if (state[i] == 2) return HPK_ERR_INVALID; sorted = sorted && state[i] == 0; }
+        if (sorted) {
+            std::vector<int64_t> got(nt, 0);
+            std::vector<std::thread> pool;
+            auto work = [&](int i) { got[i] = band_scatter(bin1, bin2, ci, cd, cut[i], cut[i + 1], n, num, ld, raw, nullptr); };
+            for (int i = 1; i < nt; ++i) pool.emplace_back(work, i);
+            work(0);
+            for (std::thread& t : pool) t.join();
+            int64_t stored = 0;
+            for (int i = 0; i < nt; ++i) { if (got[i] < 0) return HPK_ERR_INVALID; stored += got[i]; }
+            return stored;
+        }
     }
     const int64_t stored = band_scatter(bin1, bin2, ci, cd, 0, nnz, n, num, ld, raw, nullptr);
     return stored < 0 ? HPK_ERR_INVALID : stored;

@@ -1,0 +1,113 @@
+// Host-only helper of the cooler reader (hicpeaks_amd/cool.py): the chunks of a pixel-table column as HDF5 stores them - deflate,
+// optionally behind the byte-shuffle filter - inflated, un-shuffled and widened to int64 / f64 on a pool of threads with scratch
+// buffers of their own.  The reference reads the same columns through cooler / h5py (scripts/pyHICCUPS:142-143), whose filter
+// pipeline runs one chunk at a time under HDF5's global lock; the Python-level pool this replaces (zlib.decompress + numpy
+// transposes) gave every chunk three fresh megabyte-sized allocations - mmap / munmap under the process' one address-space lock,
+// which is what stopped it from scaling past ~16 threads (profiles/r05_host_e2e_deep.txt).
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/hpk.h"
+
+namespace {
+
+template <class T, class O>
+void widen(const unsigned char* p, int64_t lo, int64_t hi, O* out, O bias) {
+    const T* v = reinterpret_cast<const T*>(p);
+    for (int64_t i = lo; i < hi; ++i) out[i - lo] = (O)v[i] - bias;
+}
+
+template <class O>
+bool widen_any(const unsigned char* p, int32_t size, int32_t kind, int64_t lo, int64_t hi, O* out, O bias) {
+    if (kind == 2) {
+        if (size == 4) widen<float, O>(p, lo, hi, out, bias); else if (size == 8) widen<double, O>(p, lo, hi, out, bias); else return false;
+    } else if (kind == 1) {
+        if (size == 1) widen<uint8_t, O>(p, lo, hi, out, bias); else if (size == 2) widen<uint16_t, O>(p, lo, hi, out, bias);
+        else if (size == 4) widen<uint32_t, O>(p, lo, hi, out, bias); else if (size == 8) widen<uint64_t, O>(p, lo, hi, out, bias); else return false;
+    } else {
+        if (size == 1) widen<int8_t, O>(p, lo, hi, out, bias); else if (size == 2) widen<int16_t, O>(p, lo, hi, out, bias);
+        else if (size == 4) widen<int32_t, O>(p, lo, hi, out, bias); else if (size == 8) widen<int64_t, O>(p, lo, hi, out, bias); else return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+namespace {
+int decode_impl(const void* const* src, int fd, const uint64_t* file_off, const uint64_t* src_len, int64_t nchunks, int64_t first_chunk,
+                int64_t chunk_elems, int32_t elem_size, int32_t kind, int32_t shuffle, int64_t start, int64_t stop, void* out,
+                int32_t out_f64, int64_t bias, int32_t threads) {
+    if ((!src && (fd < 0 || !file_off)) || !src_len || !out || nchunks < 0 || chunk_elems <= 0 || stop < start || kind < 0 || kind > 2) return HPK_ERR_INVALID;
+    if (elem_size != 1 && elem_size != 2 && elem_size != 4 && elem_size != 8) return HPK_ERR_INVALID;
+    const size_t cbytes = (size_t)chunk_elems * (size_t)elem_size;
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(threads > 0 ? threads : (int)std::thread::hardware_concurrency(), nchunks));
+    std::atomic<int64_t> next{0};
+    std::atomic<int> bad{0};
+    auto work = [&]() {
+        std::vector<unsigned char> plain(cbytes), inter(shuffle && elem_size > 1 ? cbytes : 0), stored;
+        for (;;) {
+            const int64_t i = next.fetch_add(1);
+            if (i >= nchunks || bad.load()) break;
+            const Bytef* in = src ? static_cast<const Bytef*>(src[i]) : nullptr;
+            if (!src) {             // the chunk as stored, read by this thread (pread: no file position shared)
+                stored.resize((size_t)src_len[i]);
+                size_t have = 0;
+                while (have < stored.size()) {
+                    const ssize_t r = pread(fd, stored.data() + have, stored.size() - have, (off_t)(file_off[i] + have));
+                    if (r <= 0) break;
+                    have += (size_t)r;
+                }
+                if (have != stored.size()) { bad.store(1); break; }
+                in = stored.data();
+            }
+            uLongf got = (uLongf)cbytes;
+            if (uncompress(plain.data(), &got, in, (uLong)src_len[i]) != Z_OK || got == 0 || got % (size_t)elem_size) {
+                bad.store(1);
+                break;
+            }
+            const int64_t ne = (int64_t)(got / (size_t)elem_size);          // (the file's last chunk is stored whole, too)
+            const unsigned char* p = plain.data();
+            if (shuffle && elem_size > 1) {
+                // HDF5's shuffle filter: byte b of element e sits at plane b, position e
+                for (int b = 0; b < elem_size; ++b) {
+                    const unsigned char* sp = plain.data() + (size_t)b * (size_t)ne;
+                    unsigned char* dp = inter.data() + b;
+                    for (int64_t e = 0; e < ne; ++e) dp[(size_t)e * (size_t)elem_size] = sp[e];
+                }
+                p = inter.data();
+            }
+            const int64_t c0 = (first_chunk + i) * chunk_elems;
+            const int64_t lo = std::max(start, c0), hi = std::min(stop, c0 + ne);
+            if (hi <= lo) continue;
+            const bool ok = out_f64 ? widen_any<double>(p, elem_size, kind, lo - c0, hi - c0, static_cast<double*>(out) + (lo - start), (double)bias)
+                                    : widen_any<int64_t>(p, elem_size, kind, lo - c0, hi - c0, static_cast<int64_t*>(out) + (lo - start), bias);
+            if (!ok) { bad.store(1); break; }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+    work();
+    for (std::thread& t : pool) t.join();
+    return bad.load() ? HPK_ERR_INVALID : HPK_OK;
+}
+}  // namespace
+
+extern "C" int hpk_decode_chunks(const void* const* src, const uint64_t* src_len, int64_t nchunks, int64_t first_chunk, int64_t chunk_elems,
+                                 int32_t elem_size, int32_t kind, int32_t shuffle, int64_t start, int64_t stop, void* out,
+                                 int32_t out_f64, int64_t bias, int32_t threads) {
+    if (!src) return HPK_ERR_INVALID;
+    return decode_impl(src, -1, nullptr, src_len, nchunks, first_chunk, chunk_elems, elem_size, kind, shuffle, start, stop, out, out_f64, bias, threads);
+}
+
+extern "C" int hpk_decode_chunks_fd(int32_t fd, const uint64_t* file_off, const uint64_t* src_len, int64_t nchunks, int64_t first_chunk,
+                                    int64_t chunk_elems, int32_t elem_size, int32_t kind, int32_t shuffle, int64_t start, int64_t stop,
+                                    void* out, int32_t out_f64, int64_t bias, int32_t threads) {
+    return decode_impl(nullptr, fd, file_off, src_len, nchunks, first_chunk, chunk_elems, elem_size, kind, shuffle, start, stop, out, out_f64, bias, threads);
+}

@@ -122,7 +122,7 @@ __device__ __noinline__ double2 explicit_sums_wave(const float* __restrict__ raw
     return make_double2(sk, sy);
 }
 
-// Per-phase cycle accounting (-DHPK_PHASE_CLOCK builds only; scripts/gpu_phase_clock.sh): every wave sums s_memtime
+// Per-phase cycle accounting (-DHPK_PHASE_CLOCK builds only; scripts/measure/gpu_phase_clock.sh): every wave sums s_memtime
 // deltas per phase of the tile loop and leaves them in a.clk[(workgroup * NW + wave) * 8 + phase].
 #ifdef HPK_PHASE_CLOCK
 #define HPK_CLK_DECL unsigned long long ck0 = 0, ck1 = 0, ck2 = 0, ck3 = 0, ck4 = 0, ck5 = 0, ck6 = 0, ck7 = 0, ckt = __builtin_readcyclecounter();
@@ -1185,7 +1185,7 @@ __device__ __forceinline__ void tile_load_lean(const HpkStencilArgs& a, const Hp
 }
 
 // The same loads a tile ahead, without registers: buffer loads that write straight to LDS (`buffer_load ... lds`: the data of lane l
-// lands at the wave's base + 16 l for 16 or 12 bytes per lane, + 4 l for 4: scripts/ubench/lds_dma.hip).  A stage holds, per lane, the four pieces of its ten elements (4 + 4 + 1 + 1) and the three mask
+// lands at the wave's base + 16 l for 16 or 12 bytes per lane, + 4 l for 4: scripts/measure/ubench/lds_dma.hip).  A stage holds, per lane, the four pieces of its ten elements (4 + 4 + 1 + 1) and the three mask
 // words (HPK_LST_*: byte offsets of the parts, each [16 waves][64 lanes]); two stages, so that a tile's loads are requested when the
 // tile before it starts.  (wave-uniform LDS address: lds0-relative byte offset `stage`.)
 #define HPK_LST_A 0

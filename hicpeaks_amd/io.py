@@ -115,14 +115,30 @@ class CoolerSource(BandSource):
         lo, hi = self.clr.extent(chrom) if self.clr is not None else self.f.extent(chrom)
         return hi - lo
 
+    def close(self):
+        f = getattr(self, 'f', None)
+        if f is not None:
+            f.close()
+            self.f = None
+
+    def _clr_pixels(self, chrom):
+        """the chromosome's pixels through the `cooler` package, every pixel once: a file in storage mode 'square' lists both
+        triangles ((i, j) and (j, i)), and the band builders fold them onto one cell - the lower one is dropped, as the
+        package's own reader does (cool.CoolFile.pixels)."""
+        lo, hi = self.clr.extent(chrom)
+        px = self.clr.matrix(balance=False, as_pixels=True, join=False).fetch(chrom)
+        i, j, cnt = px['bin1_id'].values - lo, px['bin2_id'].values - lo, px['count'].values
+        if getattr(self.clr, 'storage_mode', 'symmetric-upper') == 'square':
+            keep = j >= i
+            i, j, cnt = i[keep], j[keep], cnt[keep]
+        return lo, hi, i, j, cnt
+
     def fetch_pixels(self, chrom, weight_name='weight'):
         """-> (bin1, bin2, count, n, weight f64 [n], biases f64 [n] or None): the pixel table itself, for the device-side band
         builder (hpk_devband_create); same balancing conventions as `fetch`."""
         if self.clr is not None:
             from . import cool
-            lo, hi = self.clr.extent(chrom)
-            px = self.clr.matrix(balance=False, as_pixels=True, join=False).fetch(chrom)
-            i, j, cnt = px['bin1_id'].values - lo, px['bin2_id'].values - lo, px['count'].values
+            lo, hi, i, j, cnt = self._clr_pixels(chrom)
             w = self.clr.bins().fetch(chrom)[weight_name].values.astype(np.float64)
             divisive = weight_name in cool.DIVISIVE_NAMES
         else:
@@ -138,9 +154,7 @@ class CoolerSource(BandSource):
         """-> (raw f32 [n, num], weight f64 [n], biases f64 [n] or None)"""
         if self.clr is not None:
             from . import cool
-            lo, hi = self.clr.extent(chrom)
-            px = self.clr.matrix(balance=False, as_pixels=True, join=False).fetch(chrom)
-            i, j, cnt = px['bin1_id'].values - lo, px['bin2_id'].values - lo, px['count'].values
+            lo, hi, i, j, cnt = self._clr_pixels(chrom)
             col = self.clr.bins().fetch(chrom)[weight_name]
             w = col.values.astype(np.float64)
             divisive = weight_name in cool.DIVISIVE_NAMES

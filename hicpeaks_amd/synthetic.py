@@ -12,9 +12,71 @@ used everywhere in this package: ``raw[r, k]`` holds the count of pixel
 import numpy as np
 
 
+def structure_fields(n, num, seed, tads=True, compartments=True, patches=6):
+    """What a real map has and a Poisson band does not (README.rst:129-233 runs on real maps; the sample data is not in the
+    image): per-bin fields from which the rate of pixel (r, c) is multiplied by
+
+      * a TAD gain where r and c lie in the same block of a random partition into blocks of 20 .. 200 bins (x 2 .. 4),
+      * a compartment factor - bins carry a sign in runs of 50 .. 300 bins; same sign x 1.6, opposite x 0.6 - a checkerboard
+        that reaches the far field,
+      * the gain (x 6 .. 10) of a few dense far-field rectangles of 30 .. 120 bins a side, at distances beyond a third of the band.
+
+    Returns a dict of small arrays (uploadable as they are: `hicpeaks_amd.bandgen` applies them on the device, slab by slab)."""
+    rng = np.random.default_rng(1000003 * int(seed) + 17)
+    f = {}
+    if tads:
+        ids, gains, pos = np.zeros(n, np.int32), [], 0
+        while pos < n:
+            size = int(rng.integers(20, 201))
+            ids[pos:pos + size] = len(gains)
+            gains.append(float(rng.uniform(2.0, 4.0)))
+            pos += size
+        f['tad_id'], f['tad_gain'] = ids, np.array(gains, np.float32)
+    if compartments:
+        comp, pos, sign = np.zeros(n, np.int8), 0, 1
+        while pos < n:
+            size = int(rng.integers(50, 301))
+            comp[pos:pos + size] = sign
+            sign = -sign
+            pos += size
+        f['comp'] = comp
+    if patches:
+        rects = []
+        for _ in range(int(patches)):
+            h, w = int(rng.integers(30, 121)), int(rng.integers(30, 121))
+            d = int(rng.integers(max(1, num // 3), max(num // 3 + 1, num - 1)))
+            r = int(rng.integers(0, max(1, n - d - w)))
+            rects.append((r, r + h, r + d, r + d + w, float(rng.uniform(6.0, 10.0))))
+        f['patches'] = np.array(rects, np.float64).reshape(-1, 5)
+    return f
+
+
+def structure_gain(fields, r, c, xp=np):
+    """Rate multiplier of the pixels (r, c) - arrays of one shape, c clipped into the matrix by the caller - under
+    `structure_fields`; `xp` = numpy, or torch with the fields as tensors on the pixels' device."""
+    is_np = xp is np
+    g = np.ones(r.shape, dtype=np.float32) if is_np else xp.ones(r.shape, dtype=xp.float32, device=r.device)
+
+    def const(v):
+        return np.float32(v) if is_np else xp.tensor(v, dtype=xp.float32, device=r.device)
+    if 'tad_id' in fields:
+        same = fields['tad_id'][r] == fields['tad_id'][c]
+        g = xp.where(same, fields['tad_gain'][fields['tad_id'][r]], g)
+    if 'comp' in fields:
+        g = g * xp.where(fields['comp'][r] == fields['comp'][c], const(1.6), const(0.6))
+    if 'patches' in fields:
+        for r0, r1, c0, c1, gain in (fields['patches'].tolist() if hasattr(fields['patches'], 'tolist') else fields['patches']):
+            inside = (r >= r0) & (r < r1) & (c >= c0) & (c < c1)
+            g = xp.where(inside, g * float(gain), g)
+    return g
+
+
 def synth_band(n, num, depth=60.0, alpha=1.0, nloops=20, seed=0,
-               nan_frac=0.025, enrich=8.0, loop_dist=None, dtype=np.int32):
+               nan_frac=0.025, enrich=8.0, loop_dist=None, dtype=np.int32, structure=None):
     """Return ``(raw, weight, loops)``.
+
+    structure  None, or keyword arguments of `structure_fields` (e.g. ``{}`` for all three kinds): TAD blocks, a compartment
+            checkerboard and dense far-field patches on top of the distance decay.
 
     raw     int array [n, num]: Poisson(depth * (1 + k) ** -alpha) per diagonal k, with
             `nloops` planted 3x3 enrichments (x `enrich` over the local rate).
@@ -27,6 +89,11 @@ def synth_band(n, num, depth=60.0, alpha=1.0, nloops=20, seed=0,
     k = np.arange(num, dtype=np.float64)
     lam = depth * (1.0 + k) ** (-alpha)
     lam2d = np.broadcast_to(lam, (n, num)).copy()
+    if structure is not None:
+        fields = structure_fields(n, num, seed, **structure)
+        rr_ = np.broadcast_to(np.arange(n)[:, None], (n, num))
+        cc_ = np.minimum(rr_ + np.arange(num)[None, :], n - 1)
+        lam2d *= structure_gain(fields, rr_, cc_)
     loops = []
     if nloops > 0:
         lo_d, hi_d = loop_dist if loop_dist is not None else (10, max(11, num - 15))

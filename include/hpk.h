@@ -299,6 +299,23 @@ int  hpk_probe_sums(hpk_ctx* ctx, const hpk_band* band, const hpk_params* params
 int64_t hpk_band_from_coo(const int64_t* bin1, const int64_t* bin2, const void* count, int32_t count_f64, int64_t nnz,
                           int32_t n, int32_t num, int64_t ld, float* raw);
 
+/* Host-only helper of the cooler reader (no device needed; counterpart of the chunk filter pipeline behind
+ * `Lib.matrix(balance=False).fetch(key)`, scripts/pyHICCUPS:142): `nchunks` consecutive chunks of a one-dimensional HDF5 data set,
+ * as stored (deflate, behind the byte-shuffle filter if `shuffle`; src[i] / src_len[i]: chunk first_chunk + i, which holds the
+ * elements [(first_chunk + i) * chunk_elems, ...)), are inflated, un-shuffled and widened on `threads` threads (0: all cores)
+ * into out[0 .. stop - start) = elements [start, stop) minus `bias` (bin ids relative to a chromosome's first bin) as int64
+ * (out_f64 = 0) or f64.  elem_size 1 / 2 / 4 / 8; kind 0 signed,
+ * 1 unsigned integers, 2 floats; little-endian.  HPK_ERR_INVALID: a chunk that does not inflate to whole elements. */
+int  hpk_decode_chunks(const void* const* src, const uint64_t* src_len, int64_t nchunks, int64_t first_chunk, int64_t chunk_elems,
+                       int32_t elem_size, int32_t kind, int32_t shuffle, int64_t start, int64_t stop, void* out, int32_t out_f64,
+                       int64_t bias, int32_t threads);
+/* The same with the chunks read by the decoding threads themselves: pread(fd, ..., file_off[i]) of src_len[i] bytes each (the
+ * chunks' addresses in the file, as H5Dget_chunk_info_by_coord reports them) - the HDF5 library, which is not thread-safe, is
+ * then only asked where the chunks are. */
+int  hpk_decode_chunks_fd(int32_t fd, const uint64_t* file_off, const uint64_t* src_len, int64_t nchunks, int64_t first_chunk,
+                          int64_t chunk_elems, int32_t elem_size, int32_t kind, int32_t shuffle, int64_t start, int64_t stop,
+                          void* out, int32_t out_f64, int64_t bias, int32_t threads);
+
 #ifdef __cplusplus
 }
 #endif

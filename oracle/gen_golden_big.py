@@ -50,6 +50,14 @@ CASES = {
                        gg.P(pw=[2], ww=[5], maxapart=5000000)),
     'wide_5kb_p4w7': ('hiccups', dict(n=6000, num=2011, depth=25.0, nloops=80, seed=0),
                       gg.P(pw=[4], ww=[7], maxapart=10000000, res=5000)),
+    # round 5: inputs with structure (synthetic.structure_fields: TAD blocks, a compartment checkerboard, dense far-field
+    # patches) - what the speculations of the HIP path (record bounds, depth classes, lean column chunks) are NOT tuned on
+    'struct_chr21_10kb_p2w5': ('hiccups', dict(n=4671, num=211, depth=40.0, nloops=60, seed=5, structure={}),
+                               gg.P(pw=[2], ww=[5], maxapart=2000000)),
+    'struct_chr21_10kb_union': ('hiccups', dict(n=4671, num=511, depth=40.0, nloops=60, seed=6, structure={}),
+                                gg.P(pw=[1, 2, 4], ww=[3, 5, 7], maxapart=5000000)),
+    'struct_chr21_10kb_bhfdr': ('bhfdr', dict(n=4671, num=211, depth=40.0, nloops=60, seed=7, structure={}),
+                                gg.P(pw=2, ww=5, maxapart=2000000, min_marginal_peaks=3)),
 }
 
 M63 = (1 << 63) - 1

@@ -42,12 +42,16 @@ def one_case(seed, ctx):
     depth = float(rng.choice([2.0, 8.0, 25.0, 60.0, 400.0, 5000.0]))
     min_reads = int(rng.choice([1, 8, 16, 25, 200, 1000]))
     sig = float(rng.choice([0.01, 0.05, 0.1, 0.3]))
-    raw, weight, _ = synthetic.synth_band(n, num, depth=depth, nloops=int(rng.integers(0, 25)), seed=seed)
+    # a quarter of the cases (all of them under HPK_FUZZ_STRUCT): TAD blocks, a compartment checkerboard and dense far-field patches
+    # on top of the distance decay (synthetic.structure_fields)
+    struct = bool(os.environ.get('HPK_FUZZ_STRUCT')) or seed % 4 == 3
+    raw, weight, _ = synthetic.synth_band(n, num, depth=depth, nloops=int(rng.integers(0, 25)), seed=seed,
+                                          structure={} if struct else None)
     if raw.min() < 0 or raw.max() >= (1 << 24):      # outside the domain (counts, exact in f32): a generator artefact, not a case
         return 'invalid-input', dict(seed=seed), 'counts outside [0, 2^24)'
     mode = 'bhfdr' if rng.random() < 0.2 else 'hiccups'
     inp = str(rng.choice(['weight', 'balanced', 'derive']))       # weights + IR | f64 balanced band + IR | weights only
-    desc = dict(seed=seed, mode=mode, inp=inp, n=n, D=D, maxww=maxww, pw=pw, ww=ww, depth=depth, min_reads=min_reads, sig=sig)
+    desc = dict(seed=seed, mode=mode, inp=inp, n=n, D=D, maxww=maxww, pw=pw, ww=ww, depth=depth, min_reads=min_reads, sig=sig, struct=struct)
     mw = min(ww) if mode == 'hiccups' else ww[0]
     try:
         IR, cband, biases = orc.prep_from_band(raw, weight, mw)
@@ -106,9 +110,15 @@ def one_case(seed, ctx):
     # The production path once more: no dense outputs, so the stencil writes records up to a width bound only - first
     # the width this very case froze at (taken over from the call above), then a bound forced to the narrowest width
     # (option spec_force: the widening freezes later, the library notices and computes the case again in full).
-    for force in (None, mw):
+    # ... and (weight input) with every column chunk declared lean: hpk_stencil_lean over all tiles, the candidates that count
+    # summed cell by cell (lean_max 4096) or nearly every tile handed back to hpk_stencil_s through the redo queue (lean_max 2)
+    passes = [(None, None), (mw, None)] + ([(None, 4096 if seed % 2 else 2)] if inp != 'balanced' else [])
+    for force, lean_max in passes:
         if force is not None:
             ctx.set_option('spec_force', force)
+        if lean_max is not None:
+            ctx.set_option('lean_frac_pct', 100000)
+            ctx.set_option('lean_max', lean_max)
         try:
             d2 = dict()
             if mode == 'hiccups':
@@ -121,10 +131,13 @@ def one_case(seed, ctx):
                                            ctx=ctx, detail=d2, **(dict(balanced=cband) if inp == 'balanced' else dict(weight=weight)))
         finally:
             ctx.set_option('spec_force', -1)
+            if lean_max is not None:
+                ctx.set_option('lean_frac_pct', 35)
+                ctx.set_option('lean_max', 24)
         k2, v2 = table_arrays(again)
         # (the bounded run's tiles carry the bound's halo: sums from other tile corners, equal to rounding)
         if not (np.array_equal(k2, k) and np.allclose(v2, v, rtol=1e-10, atol=1e-12)):
-            return 'MISMATCH-record-bound', desc, 'bound %s' % (force or 'own')
+            return 'MISMATCH-record-bound', desc, 'bound %s lean_max %s' % (force or 'own', lean_max)
     return 'ok', desc, '%d pixels' % len(k)
 
 

@@ -1,11 +1,11 @@
 #!/usr/bin/env python
-"""gpurun_out/<tag>/ (scripts/gpu_profile_round.sh) -> the summaries kept under profiles/: <tag>_bench.json,
+"""gpurun_out/<tag>/ (scripts/measure/profile_round.sh) -> the summaries kept under profiles/: <tag>_bench.json,
 <tag>_bench_other_configs.jsonl, <tag>_kernel_stats.csv, <tag>_pmc_summary.txt and traffic.json (HBM bytes per stencil
 launch = 2 x FETCH_SIZE + WRITE_SIZE, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md / the calibration in
 profiles/r01_pmc_summary.txt).  usage: collect_profiles.py <tag> [--no-copy]"""
 import csv, glob, json, os, shutil, sys, collections
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tag = sys.argv[1]
 copy = '--no-copy' not in sys.argv
 out = os.path.join(REPO, 'gpurun_out', tag)
@@ -13,16 +13,18 @@ prof = os.path.join(REPO, 'profiles')
 
 
 def pmc_means(d, pat):
-    acc = collections.defaultdict(list)
+    """counter -> (mean per launch, launches).  The stencil is up to three kernels per launch of a batch since round 5
+    (hpk_stencil_lean, hpk_stencil_s, hpk_stencil_s over the redo queue): `hpk_stencil` = the sum of their means."""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in sorted(glob.glob(os.path.join(d, '**', '*_counter_collection.csv'), recursive=True)):
         for row in csv.DictReader(open(f)):
             if pat in row['Kernel_Name']:
-                acc[row['Counter_Name']].append(float(row['Counter_Value']))
-    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+                acc[row['Counter_Name']][row['Kernel_Name']].append(float(row['Counter_Value']))
+    return {k: (sum(sum(v) / len(v) for v in byk.values()), max(len(v) for v in byk.values())) for k, byk in acc.items()}
 
 
 have_raw = bool(glob.glob(os.path.join(out, '**', '*_counter_collection.csv'), recursive=True))
-lines = ['# rocprofv3 --pmc passes of scripts/gpu_profile_round.sh %s, mean per dispatch' % tag]
+lines = ['# rocprofv3 --pmc passes of scripts/measure/profile_round.sh %s, mean per dispatch' % tag]
 traffic = {'_comment': 'HBM traffic per stencil launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes; KiB; FETCH_SIZE '
                        'doubled per the gfx950 note in MI355X_MICROARCH.md, calibrated in profiles/r01_pmc_summary.txt); bench.py copies '
                        'the entry of the configuration it runs into roofline.traffic'}
@@ -47,6 +49,8 @@ for cfg in ('chr1_10kb', 'chr1_10kb_union', 'chr1_5kb', 'deep_1kb'):
         traffic[cfg] = {'traffic_bytes': tb, 'source': 'profiles/%s_pmc_summary.txt' % tag,
                         'note': 'hpk_stencil*, per chromosome of a launch: 2 x FETCH_SIZE + WRITE_SIZE'}
         lines.append('%-16s stencil HBM traffic per chromosome: %.1f MB' % (cfg, tb / 1e6))
+    if cfg in traffic and ('hpk_score', 'FETCH_SIZE') in vals and ('hpk_score', 'WRITE_SIZE') in vals:
+        traffic[cfg]['score_traffic_bytes'] = int((2 * vals[('hpk_score', 'FETCH_SIZE')][0] + vals[('hpk_score', 'WRITE_SIZE')][0]) * 1024)
 Gs = group_of('sq')
 for kern in ('hpk_stencil', 'hpk_score'):
     lines.append('## %s (chr1_10kb), SQ / TCC counters per launch of %d chromosomes' % (kern, Gs))

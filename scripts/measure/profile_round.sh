@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round profile: bench JSON lines + rocprofv3 kernel trace/stats + PMC (FETCH_SIZE / WRITE_SIZE in separate passes, per
-# configuration).  Everything lands in gpurun_out/$TAG; scripts/collect_profiles.py copies the summaries to profiles/.
+# configuration).  Everything lands in gpurun_out/$TAG; scripts/measure/collect_profiles.py copies the summaries to profiles/.
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
@@ -13,10 +13,15 @@ for c in chr1_10kb_union chr1_5kb deep_1kb wg_10kb_union wg_5kb; do
 done
 timeout 600 python bench.py --balanced-f64 --steps 5 --warmup 1 --cpu-rows 0 2>/dev/null | tail -1 > $OUT/bench_chr1_10kb_balanced_f64.json
 HPK_SPEC=0 timeout 600 python bench.py --cpu-rows 0 --no-extra 2>/dev/null | tail -1 > $OUT/bench_chr1_10kb_no_record_bound.json
-# one depth (round 3's workload: 64 distinct bands, all of depth 60), and the fused kernel (option fuse = 1) on both workloads
+# one depth (round 3's workload: 64 distinct bands, all of depth 60); the lean kernel off (every tile through hpk_stencil_s); bands
+# with structure (TAD blocks, compartments, far-field patches); the seam's general f64 variant (union plan on an f64 balanced band)
 timeout 600 python bench.py --depths 60 --cpu-rows 0 --no-extra 2>/dev/null | tail -1 > $OUT/bench_chr1_10kb_depth60.json
-HPK_FUSE=1 timeout 600 python bench.py --depths 60 --cpu-rows 0 --no-extra 2>/dev/null | tail -1 > $OUT/bench_chr1_10kb_depth60_fused.json
-HPK_FUSE=1 timeout 600 python bench.py --cpu-rows 0 --no-extra 2>/dev/null | tail -1 > $OUT/bench_chr1_10kb_fused.json
+HPK_LEAN=0 timeout 600 python bench.py --cpu-rows 0 --no-extra 2>/dev/null | tail -1 > $OUT/bench_chr1_10kb_no_lean_kernel.json
+HPK_LEAN=0 timeout 600 python bench.py --config chr1_5kb --steps 5 --warmup 1 --cpu-rows 0 --no-extra 2>/dev/null | tail -1 > $OUT/bench_chr1_5kb_no_lean_kernel.json
+timeout 600 python bench.py --structure --cpu-rows 0 --no-extra 2>/dev/null | tail -1 > $OUT/bench_chr1_10kb_structure.json
+timeout 600 python bench.py --config chr1_5kb --structure --steps 5 --warmup 1 --cpu-rows 0 --no-extra 2>/dev/null | tail -1 > $OUT/bench_chr1_5kb_structure.json
+timeout 600 python bench.py --config chr1_10kb_union --structure --steps 5 --warmup 1 --cpu-rows 0 --no-extra 2>/dev/null | tail -1 > $OUT/bench_chr1_10kb_union_structure.json
+timeout 600 python bench.py --config chr1_10kb_union --balanced-f64 --steps 5 --warmup 1 --cpu-rows 0 --no-extra 2>/dev/null | tail -1 > $OUT/bench_chr1_10kb_union_balanced_f64.json
 timeout 600 python bench.py --config chr1_10kb_bhfdr --steps 5 --warmup 1 --cpu-rows 0 2>/dev/null | tail -1 > $OUT/bench_chr1_10kb_bhfdr.json
 timeout 600 python bench.py --host-inputs --steps 3 --warmup 1 --batch 20 --cpu-rows 0 2>/dev/null | tail -1 > $OUT/bench_chr1_10kb_host_inputs.json
 cd /tmp && export TMPDIR=/tmp
@@ -43,7 +48,7 @@ for cnt in "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ
   rocprofv3 --kernel-trace --pmc $cnt -d $OUT/pmc_sq_$nm -o c --output-format csv -- python $R/bench.py $PB > $OUT/pmc_sq_$nm.log 2>&1
 done
 cd $R
-python scripts/collect_profiles.py $TAG --no-copy
+python scripts/measure/collect_profiles.py $TAG --no-copy
 # the raw traces are tens of MB (gpurun copies back at most 64 MiB): keep the summaries and the tails of the logs
 for f in $OUT/*.log; do tail -5 $f > $f.tail; rm $f; done
 rm -rf $OUT/trace $OUT/pmc_*/

@@ -61,6 +61,7 @@ def check_population(g, t, vx, vy, E, O, p, q, chunk=None, reject=None):
     if reject is not None:
         near = near | reject
     firm = np.abs(q - 2 * sig) > 1e-8
+    assert int((~firm).sum()) <= 3, int((~firm).sum())
     kx, ky = g[pre + 'kx'].astype(np.int64), g[pre + 'ky'].astype(np.int64)
     got = set(zip(vx[near & firm].tolist(), vy[near & firm].tolist()))
     maybe = set(zip(vx[~firm].tolist(), vy[~firm].tolist()))
@@ -88,6 +89,9 @@ def check_survivors(g, t, s, bh=False):
     kx, ky, kq = g[pre + 'kx'].astype(np.int64), g[pre + 'ky'].astype(np.int64), g[pre + 'kq']
     sel = g[pre + 'kreject'] if bh else (kq <= sig)
     firm = np.abs(kq - sig) > 1e-8
+    # (pixels within 1e-8 of the threshold may fall on either side: there must be next to none of them - a drift of the
+    # q-values towards the threshold would otherwise hide behind the mask)
+    assert int((~firm).sum()) <= 3, int((~firm).sum())
     want = set(zip(kx[sel & firm].tolist(), ky[sel & firm].tolist()))
     maybe = set(zip(kx[~firm].tolist(), ky[~firm].tolist()))
     got = set(zip(s['x'].tolist(), s['y'].tolist()))

@@ -136,3 +136,31 @@ def test_band_from_coo_wide_integer_counts():
         band.band_from_coo(i, j, np.array([1, 2, 1 << 33], dtype=np.int64), 4, 3)
     with pytest.raises(ValueError):
         band.band_from_coo(i, j, np.array([1, 2, 1 << 24], dtype=np.uint32), 4, 3)
+
+
+def test_band_from_coo_threaded_path(monkeypatch):
+    """The threaded scatter of hpk_band_from_coo (large pixel tables in row order are cut at row changes, one stretch per thread;
+    the threshold per thread is lowered through HPK_COO_MIN_PER_THREAD): a sorted table gives the serial result; a shuffled one
+    is recognised by the read-only pass and scattered by one thread, repeats and all; a bin outside the chromosome is an error."""
+    n, num = 900, 61
+    raw, _, _ = synthetic.synth_band(n, num, depth=30.0, nloops=5, seed=5)
+    i, j, v = synthetic.band_to_coo(raw)                 # row-major: in row order
+    i, j, v = np.concatenate([i, i[:500]]), np.concatenate([j, j[:500]]), np.concatenate([v, v[:500]])      # repeats ...
+    o = np.argsort(i, kind='stable')
+    i, j, v = i[o], j[o], v[o]                           # ... kept in row order
+    monkeypatch.delenv('HPK_COO_MIN_PER_THREAD', raising=False)
+    serial = band.band_from_coo(i, j, v, n, num)
+    monkeypatch.setenv('HPK_COO_MIN_PER_THREAD', '1000')
+    assert i.size // 1000 >= 2
+    np.testing.assert_array_equal(band.band_from_coo(i, j, v, n, num), serial)
+    np.testing.assert_array_equal(band.band_from_coo(j, i, v, n, num), serial)        # either orientation
+    p = np.random.default_rng(3).permutation(i.size)
+    np.testing.assert_array_equal(band.band_from_coo(i[p], j[p], v[p], n, num), serial)
+    bad = j.copy()
+    bad[i.size // 2] = n
+    from hicpeaks_amd import _lib
+    with pytest.raises(_lib.HpkError):
+        band.band_from_coo(i, bad, v, n, num)
+    monkeypatch.delenv('HPK_COO_MIN_PER_THREAD')
+    with pytest.raises(_lib.HpkError):
+        band.band_from_coo(i, bad, v, n, num)

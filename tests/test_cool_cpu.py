@@ -124,6 +124,11 @@ def test_chunkwise_reading_equals_h5dread():
             m = h.shape(name)[0]
             for a, b in ((0, m), (3, m - 5), (m // 2, m // 2 + 1)):
                 np.testing.assert_array_equal(h.read_big(name, a, b, kind, threads=2), h.read(name, a, b, kind))
+                os.environ['HPK_READ_PYTHON'] = '1'         # (the Python pool, what a host without the library falls back to)
+                try:
+                    np.testing.assert_array_equal(h.read_big(name, a, b, kind, threads=2), h.read(name, a, b, kind))
+                finally:
+                    del os.environ['HPK_READ_PYTHON']
         i, j, c = f.pixels('chrA')
         h.PARALLEL_MIN = 1 << 60
         i2, j2, c2 = f.pixels('chrA')
@@ -160,6 +165,14 @@ def test_chunkwise_reading_across_chunk_borders(tmp_path):
         for a, b in ((0, n), (5, 300000), ((1 << 18) - 3, (1 << 18) + (1 << 19) + 7), (n - 10, n)):
             for name, kind in (('pixels/bin1_id', 'i'), ('pixels/bin2_id', 'i'), ('pixels/count', None)):
                 np.testing.assert_array_equal(h.read_big(name, a, b, kind, threads=4), h.read(name, a, b, kind))
+        # (above: the chunks pread and decoded by libhpk's threads; here: read by H5Dread_chunk and decoded by libhpk | by the Python pool)
+        assert h.fd_ok is True
+        for var in ('HPK_READ_NO_PREAD', 'HPK_READ_PYTHON'):
+            os.environ[var] = '1'
+            try:
+                np.testing.assert_array_equal(h.read_big('pixels/bin2_id', 5, n - 7, 'i', threads=4), h.read('pixels/bin2_id', 5, n - 7, 'i'))
+            finally:
+                del os.environ[var]
         h.PARALLEL_MIN = old
         i, j, c = f.pixels('chr21')
         assert i.size == n and (j >= i).all() and c.min() >= 1
@@ -210,3 +223,95 @@ def test_missing_weight_column_is_a_clear_error():
     assert 'weight' in str(ei.value) and 'balance' in str(ei.value)
     with pytest.raises(KeyError):
         src.fetch_pixels('chrX', 'KR')
+
+
+def test_cooler_package_backend_drops_the_lower_triangle_of_square_files(monkeypatch):
+    """The `cooler`-package backend (not installable here: a stand-in `cooler` module with the calls io.CoolerSource makes) on a
+    file in storage mode 'square': `clr.matrix(as_pixels=True).fetch()` hands back both triangles, and the band builders would
+    fold (i, j) and (j, i) onto one cell - every off-diagonal count doubled.  Both backends give the same band."""
+    import sys
+    import types
+    n = V_CHROMS[0][1]
+    want_raw, want_w = _v_expected(0, n)
+    r, k = np.nonzero(want_raw)
+    up = (r.astype(np.int64) + 100, (r + k).astype(np.int64) + 100, want_raw[r, k].astype(np.int64))     # (bins offset: a second chromosome)
+    off = up[0] != up[1]
+    both = tuple(np.concatenate([a, b[off]]) for a, b in zip(up, (up[1], up[0], up[2])))
+
+    class Col(dict):
+        def __getitem__(self, key):
+            return types.SimpleNamespace(values=dict.__getitem__(self, key))
+
+    class Fetcher:
+        def __init__(self, table):
+            self.table = table
+
+        def fetch(self, chrom):
+            return self.table
+
+    class FakeCooler:
+        binsize = 10000
+        chromnames = ['chr1']
+
+        def __init__(self, uri, mode):
+            self.storage_mode = mode
+
+        def extent(self, chrom):
+            return 100, 100 + n
+
+        def matrix(self, balance, as_pixels, join):
+            assert balance is False and as_pixels and not join
+            px = both if self.storage_mode == 'square' else up
+            return Fetcher(Col(bin1_id=px[0], bin2_id=px[1], count=px[2]))
+
+        def bins(self):
+            return Fetcher(Col(weight=want_w))
+
+    for mode in ('square', 'symmetric-upper'):
+        fake = types.ModuleType('cooler')
+        fake.Cooler = lambda uri, mode=mode: FakeCooler(uri, mode)
+        monkeypatch.setitem(sys.modules, 'cooler', fake)
+        src = io.CoolerSource('whatever.cool')
+        assert src.clr is not None
+        raw, w, b = src.fetch('chr1', V_NUM)
+        np.testing.assert_array_equal(raw, want_raw)
+        np.testing.assert_array_equal(w, want_w)
+        pi, pj, pc, pn, pw_, pb = src.fetch_pixels('chr1')
+        np.testing.assert_array_equal(hband.band_from_coo(pi, pj, pc, n, V_NUM), want_raw)
+
+
+def test_hpk_decode_chunks_against_zlib_and_numpy():
+    """libhpk's host-side chunk decoder (include/hpk.h: hpk_decode_chunks - inflate, un-shuffle, widen on threads) against zlib +
+    numpy on chunks written the way HDF5's deflate / shuffle filters store them: every element width and kind, with and
+    without shuffle, ranges that start and end inside chunks, both output types; a damaged chunk is an error."""
+    import ctypes as C
+    import zlib
+    from hicpeaks_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    cs, n = 1000, 3500
+    for dt, kind in ((np.int32, 0), (np.uint16, 1), (np.float32, 2), (np.int64, 0), (np.float64, 2), (np.uint8, 1), (np.int8, 0)):
+        v = rng.integers(0, 100, n).astype(dt)
+        size = np.dtype(dt).itemsize
+        for shuffle in (0, 1):
+            chunks = []
+            for c in range(0, n, cs):
+                a = np.zeros(cs, dt)
+                a[:min(cs, n - c)] = v[c:c + cs]
+                b = a.view(np.uint8)
+                if shuffle and size > 1:
+                    b = np.ascontiguousarray(b.reshape(-1, size).T).reshape(-1)
+                chunks.append(zlib.compress(b.tobytes(), 6))
+            for start, stop in ((0, n), (7, 2999), (1000, 2000), (999, 1001)):
+                c0, c1 = start // cs, (stop - 1) // cs + 1
+                bufs = [np.frombuffer(chunks[i], dtype=np.uint8) for i in range(c0, c1)]
+                src = (C.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
+                sl = (C.c_uint64 * len(bufs))(*[b.size for b in bufs])
+                for of in (0, 1):
+                    out = np.empty(stop - start, np.float64 if of else np.int64)
+                    assert lib.hpk_decode_chunks(src, sl, len(bufs), c0, cs, size, kind, shuffle, start, stop, out.ctypes.data, of, 7, 3) == 0
+                    np.testing.assert_array_equal(out, v[start:stop].astype(out.dtype) - 7)
+    bad = np.frombuffer(b'not a deflate stream at all', dtype=np.uint8)
+    out = np.empty(10, np.int64)
+    assert lib.hpk_decode_chunks((C.c_void_p * 1)(bad.ctypes.data), (C.c_uint64 * 1)(bad.size), 1, 0, cs, 4, 0, 1, 0, 10,
+                                 out.ctypes.data, 0, 0, 1) == _lib.ERR_INVALID

@@ -186,6 +186,7 @@ def _check_against_oracle(R, final, det, want, pw, ww, sig, min_sig=100, min_fin
         assert s['nvalid'] == o['vx'].size
         q, vx, vy = o['q'], o['vx'], o['vy']
         firm = np.abs(q - sig) > 1e-8                       # (pixels sitting on the threshold may fall either way)
+        assert int((~firm).sum()) <= 3, int((~firm).sum())  # (next to none of them)
         sel = q <= sig
         wantpx = set(zip(vx[sel & firm].tolist(), vy[sel & firm].tolist()))
         maybe = set(zip(vx[~firm].tolist(), vy[~firm].tolist()))
@@ -215,7 +216,7 @@ def _check_against_oracle(R, final, det, want, pw, ww, sig, min_sig=100, min_fin
 
 
 # BASELINE configs[3]'s largest chromosome, chr1 @5 kb, (4,7), 10 Mb band (n = 49 792, num = 2011): the oracle needs ~10 GB
-# of host memory and 1-4 minutes of a core - run with HPK_SLOW=1 (scripts/gpu_slow_tests.sh, profiles/r03_slow_tests.txt)
+# of host memory and 1-4 minutes of a core - run with HPK_SLOW=1 (scripts/measure/gpu_slow_tests.sh, profiles/r03_slow_tests.txt)
 SLOW = {'chr1_5kb_p4w7': dict(n=49792, res=5000, maxapart=10000000, pw=[4], ww=[7], depth=25.0, nloops=800, seed=0)}
 
 

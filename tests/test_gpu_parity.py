@@ -56,7 +56,8 @@ def _check_set(s, vx, vy, E, O, p, q, sig, reject=None):
     """library survivors (q <= sig) against the full per-pixel arrays of the reference"""
     assert s['nvalid'] == vx.size
     sel = (q <= sig) if reject is None else reject
-    firm = np.abs(q - sig) > 1e-8                       # ignore pixels sitting on the threshold
+    firm = np.abs(q - sig) > 1e-8                       # ignore pixels sitting on the threshold ...
+    assert int((~firm).sum()) <= 3, int((~firm).sum())  # ... of which there must be next to none (a drift towards it would hide here)
     want = set(zip(vx[sel & firm].tolist(), vy[sel & firm].tolist()))
     maybe = set(zip(vx[~firm].tolist(), vy[~firm].tolist()))
     got = set(zip(s['x'].tolist(), s['y'].tolist()))

@@ -48,11 +48,21 @@ def _check_result(g, R, final):
     want = g.meta['lines'].splitlines()
     got = sorted(lines.splitlines(), key=lambda l: (int(l.split('\t')[1]), int(l.split('\t')[4])))
     assert len(got) == len(want)
+    # (the rule of tests/test_gpu_cli.py: a '%.3g' field may differ from the reference's string only where the value sits on a
+    # rounding edge of its third digit - by one unit of that digit -, and next to none may: at most 1 field in 500)
+    fields = tipped = 0
     for a, b in zip(got, want):
         fa, fb = a.split('\t'), b.split('\t')
         assert fa[:10] == fb[:10]
         for u, v in zip(fa[10:], fb[10:]):
-            assert u == v or abs(float(u) - float(v)) <= 1.01e-2 * abs(float(v)), (a, b)
+            fields += 1
+            if u == v:
+                continue
+            tipped += 1
+            fv = float(v)
+            ulp3 = 10.0 ** (np.floor(np.log10(abs(fv))) - 2) if fv != 0.0 else 0.0
+            assert abs(float(u) - fv) <= 1.01 * ulp3, (a, b)
+    assert tipped <= max(1, fields // 500), (tipped, fields)
 
 
 @pytest.mark.parametrize('name', refbig.names())
@@ -125,5 +135,8 @@ def test_wide_band_vs_oracle(name, ctx):
     Rs = ctx.submit_batch_host(items, prm).results()
     assert Rs[1].record_bound == R1.frozen_w and not Rs[1].redone
     assert Rs[1].halo_w == max(Rs[1].record_bound, min(ww), 4)
+    # a band this wide is mostly far field: most of its column chunks are lean by the library's own prediction, and go
+    # through hpk_stencil_lean (no option forced here) - with few tiles handed back, if any
+    assert Rs[1].lean_tiles > Rs[1].tiles // 2 and Rs[1].lean_redone <= Rs[1].lean_tiles // 20, (Rs[1].lean_tiles, Rs[1].lean_redone, Rs[1].tiles)
     fin2, _ = callers._finish_hiccups(Rs[1], n, '1', pw, ww, sig, 0.01, 1.75, 2, res, False, 2, False)
     _check_against_oracle(Rs[1], fin2, det, want, pw, ww, sig, min_sig=5, min_final=1)
