@@ -135,7 +135,8 @@ struct hpk_ctx {
     std::vector<double> h_bounds;
     std::vector<int32_t> h_off;
     std::vector<double> h_sfe;
-    DevBuf d_bounds, d_off, d_sfe, d_ptab;
+    DevBuf d_bounds, d_off, d_sfe, d_ptab, d_kcrit;
+    double kcrit_sig = -1.0;            // the sig d_kcrit was built for (hpk_kcrit; rebuilt with the tables)
     bool tables_dirty = true;           // the Poisson table is (re)built before the first launch that needs it
     Lane lane[HPK_LANES];
     DevBuf tmpA, tmpB, tmpC, tmpD;
@@ -228,6 +229,7 @@ int upload_tables(hpk_ctx* c) {
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->tables_dirty = false;
+    c->kcrit_sig = -1.0;
     return HPK_OK;
 }
 
@@ -369,7 +371,7 @@ void hpk_destroy(hpk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DevBuf* all[] = {&c->d_bounds, &c->d_off, &c->d_sfe, &c->d_ptab, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD, &c->cooA, &c->cooB, &c->cooC};
+    DevBuf* all[] = {&c->d_bounds, &c->d_off, &c->d_sfe, &c->d_ptab, &c->d_kcrit, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD, &c->cooA, &c->cooB, &c->cooC};
     for (DevBuf* b : all) b->release();
     while (!c->live_bands.empty()) hpk_devband_free(c, c->live_bands.back());      // (bands their owner did not free: into the pool, freed below)
     for (auto& e : c->pool) (void)hipFree(e.second);
@@ -555,6 +557,7 @@ int launch_compute(hpk_ctx* c, hpk_job* j, int b0, int nbl, bool solo, bool with
     if (j->do_score) {
         HpkScoreArgs sc = j->sc;
         if (all_survivors) sc.kmin = nullptr;       // (a chromosome whose cut lay above the bound of its survivor records)
+        if (solo) sc.kcrit = nullptr;               // (a later submission may have rebuilt the critical counts for another sig: look every p up)
         sc.gridx = 0;           // the widest row of scoring workgroups among the bands launched (HpkBandDesc::score_wgs)
         for (int b = b0; b < b0 + nbl; ++b) sc.gridx = std::max(sc.gridx, solo ? j->gmax : j->bands[b].d.score_wgs);
         hpk_launch_score(sc, dd, nbl, plan.mode == HPK_MODE_BHFDR, c->stream);
@@ -1006,6 +1009,15 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     sc.bounds = c->d_bounds.as<double>(); sc.ptab = c->d_ptab.as<double>();
     sc.ptab_off = c->d_off.as<int32_t>(); sc.sfe = c->d_sfe.as<double>(); sc.sig = prm->sig;
     sc.mw = mw; sc.D = D;
+    if (plan.mode == HPK_MODE_HICCUPS && !(prm->sig >= 1.0)) {      // the critical counts of this sig (cached: one tiny launch per change)
+        if (c->kcrit_sig != prm->sig) {
+            HIPCHK(c, c->d_kcrit.reserve(sizeof(int32_t) * (HPK_NB_TAB + 2)));
+            hpk_launch_kcrit(c->d_ptab.as<double>(), c->d_off.as<int32_t>(), prm->sig, c->d_kcrit.as<int32_t>(), c->stream);
+            HIPCHK(c, hipGetLastError());
+            c->kcrit_sig = prm->sig;
+        }
+        sc.kcrit = c->d_kcrit.as<int32_t>();
+    }
     sc.hbins = hbins; sc.nsets_half = plan.npairs;
     // Survivor records: p <= sig is what can reach q <= sig, but the Benjamini-Hochberg cut of a family lies orders of
     // magnitude below sig (sig x rejections / tests), and the chromosomes collected last with these parameters say in which

@@ -106,7 +106,7 @@ struct HpkBandDesc {
     int64_t rec_stride;                 // ntiles * tilecap
     int64_t ld;
     HPK_GP(unsigned) tile_cnt;                 // [ntiles] records per tile
-    HPK_GP(uint2) units;                       // scoring work list {tile, unit | records of the tile << 8}, appended at tile end
+    HPK_GP(uint2) units;                       // scoring work list {row block << 8 | column chunk, unit | records of the tile << 8}, appended at tile end
     HPK_GP(unsigned char) small;               // the band's counter block (HPK_OFF_*)
     HPK_GP(uint8_t) gap;                       // [n] preset to 0; set for rows with a non-zero balanced value (gap = !flag)
     HPK_GP(unsigned long long) hist_acc;       // [(HPK_MAX_STEPS + 1) * HPK_ACC_STRIDE] zeroed resolve totals the stencil workgroups add to
@@ -176,6 +176,7 @@ struct HpkScoreArgs {
     int32_t nsets_half;                 // (pw, ww) pairs of the call: the launcher sizes the histogram's LDS with it
     int32_t gridx;                      // workgroups per band
     const uint8_t* kmin;                // [HPK_NFAM] or nullptr: survivor records only for p-values in histogram bin >= kmin[family]
+    const int32_t* kcrit;               // [HPK_NB_TAB + 2] or nullptr: per chunk of the Poisson table the smallest count with p <= sig (hpk_kcrit)
 };
 
 struct HpkDenseArgs {
@@ -219,6 +220,7 @@ void hpk_launch_tighten(const HpkBandDesc* d_bands, int nbands, double sig, int 
 void hpk_launch_publish(const HpkBandDesc* d_bands, int nbands, int nsets, bool full, size_t max_head_bytes, hipStream_t st);
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,
                      hipStream_t st);
+void hpk_launch_kcrit(const double* ptab, const int32_t* off, double sig, int32_t* kcrit, hipStream_t st);
 // Record bound per chromosome by depth class (hpk_band_class): class = quarter octave of the band's mean count per pixel (every
 // 64th row sampled), bound = table[class] + margin (table: the width chromosomes of that class froze at, -1 unknown) clamped to
 // [wmin, wg_all]; written into the descriptor's wguess and into the counter block (HPK_OFF_BCLASS).  Runs before the stencil.

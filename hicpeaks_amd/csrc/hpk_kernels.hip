@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     };
     // scoring work list: the append of a tile is completed one tile later (the atomic's return is not waited for)
     int pend_tid = -1, pend_band = 0;
-    unsigned pend_c = 0u, pend_off = 0u;
+    unsigned pend_c = 0u, pend_off = 0u, pend_rc = 0u;      // (pend_rc: the tile as the work list names it, row block << 8 | column chunk)
 
     HPK_CLK_DECL
     TileRegsS<BALF64> nxt;
@@ -1111,12 +1111,13 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
         if (pend_tid >= 0) {
             const unsigned nu = (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT;
             const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)pend_off);
-            if ((unsigned)lane < nu) gptr(bands[pend_band].units)[off + lane] = make_uint2((unsigned)pend_tid, (unsigned)lane | (pend_c << 8));
+            if ((unsigned)lane < nu) gptr(bands[pend_band].units)[off + lane] = make_uint2(pend_rc, (unsigned)lane | (pend_c << 8));
         }
         pend_tid = -1;
         const unsigned nrec = (unsigned)__builtin_amdgcn_readfirstlane((int)tcount[4 + par]);    // records of this tile
         if (nrec > 0u) {
             pend_tid = tid;
+            pend_rc = (unsigned)rb << 8 | (unsigned)cj;
             pend_band = band;
             pend_c = nrec;
             if (lane == 0) pend_off = atomicAdd(reinterpret_cast<unsigned*>(gptr(bd->small) + HPK_OFF_NUNITS), (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT);
@@ -1132,7 +1133,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     if (wave == 0 && pend_tid >= 0) {
         const unsigned nu = (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT;
         const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)pend_off);
-        if ((unsigned)lane < nu) gptr(bands[pend_band].units)[off + lane] = make_uint2((unsigned)pend_tid, (unsigned)lane | (pend_c << 8));
+        if ((unsigned)lane < nu) gptr(bands[pend_band].units)[off + lane] = make_uint2(pend_rc, (unsigned)lane | (pend_c << 8));
     }
 #ifdef HPK_PHASE_CLOCK
     if (a.clk && lane == 0) {
@@ -1313,7 +1314,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_lean(HpkStencilArgs a, const
         hpack0 = 0ull; hpack1 = 0ull;
     };
     int pend_tid = -1, pend_band = 0;
-    unsigned pend_c = 0u, pend_off = 0u;
+    unsigned pend_c = 0u, pend_off = 0u, pend_rc = 0u;      // (pend_rc: the tile as the work list names it, row block << 8 | column chunk)
     int sp = 0;                         // the stage that holds the current tile's rows
     int par = 0;
     TileWalk<1> tw;
@@ -1627,7 +1628,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_lean(HpkStencilArgs a, const
         if (pend_tid >= 0) {
             const unsigned nu = (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT;
             const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)pend_off);
-            if ((unsigned)lane < nu) gptr(bands[pend_band].units)[off + lane] = make_uint2((unsigned)pend_tid, (unsigned)lane | (pend_c << 8));
+            if ((unsigned)lane < nu) gptr(bands[pend_band].units)[off + lane] = make_uint2(pend_rc, (unsigned)lane | (pend_c << 8));
         }
         pend_tid = -1;
         const bool given_up = __builtin_amdgcn_readfirstlane((int)tflag[par]) != 0;
@@ -1642,6 +1643,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_lean(HpkStencilArgs a, const
             const unsigned nrec = (unsigned)__builtin_amdgcn_readfirstlane((int)tcount[4 + par]);
             if (nrec > 0u) {
                 pend_tid = tid;
+                pend_rc = (unsigned)rb << 8 | (unsigned)cj;
                 pend_band = band;
                 pend_c = nrec;
                 if (lane == 0) pend_off = atomicAdd(reinterpret_cast<unsigned*>(gptr(bd->small) + HPK_OFF_NUNITS), (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT);
@@ -1659,7 +1661,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_lean(HpkStencilArgs a, const
     if (wave_k == 0 && pend_tid >= 0) {
         const unsigned nu = (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT;
         const unsigned off = (unsigned)__builtin_amdgcn_readfirstlane((int)pend_off);
-        if ((unsigned)lane_k < nu) gptr(bands[pend_band].units)[off + lane_k] = make_uint2((unsigned)pend_tid, (unsigned)lane_k | (pend_c << 8));
+        if ((unsigned)lane_k < nu) gptr(bands[pend_band].units)[off + lane_k] = make_uint2(pend_rc, (unsigned)lane_k | (pend_c << 8));
     }
 }
 
@@ -2008,6 +2010,19 @@ __global__ void __launch_bounds__(256) hpk_ptab(const double* __restrict__ bound
     ptab[i] = poisson_sf(k, bounds[ch - 1], sfe, 1.0);
 }
 
+// Critical counts of the table's chunks for one sig: kcrit[ch] = the smallest count k whose table entry 1 - cdf(k; chunk's upper
+// bound) is <= sig (the entries fall with k; beyond the table they are 0), so that hpk_score looks a p-value up only where it can
+// be <= sig.  sig >= 1: 0 (everything is looked up).
+__global__ void __launch_bounds__(64) hpk_kcrit(const double* __restrict__ ptab, const int32_t* __restrict__ off, double sig, int32_t* __restrict__ kcrit) {
+    const int ch = threadIdx.x + 1;
+    if (threadIdx.x == 0) { kcrit[0] = 0; kcrit[HPK_NB_TAB + 1] = 0; }
+    if (ch > HPK_NB_TAB) return;
+    const int base = off[ch], len = off[ch + 1] - base;
+    int k = 0;
+    while (k < len && !(ptab[base + k] <= sig)) ++k;
+    kcrit[ch] = k;
+}
+
 // Fine p-value bins (bhfdr: one family of millions of tests per chromosome, whose cut the eight factor-4 bins of the
 // lambda-chunk families bracket only within a factor ~20: 55 000 records copied back for 3 300 pixels): four bins per
 // octave of x = sig / p, edges at 2^e x {1, 1.25, 1.5, 1.75}, the last bin open.  Any binning that is monotone in the
@@ -2111,6 +2126,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
     __shared__ int lstepw[HPK_MAX_STEPS];
     __shared__ int lpair_slot[HPK_MAX_PAIRS], lpair_wi[HPK_MAX_PAIRS];
     __shared__ int lptoff[HPK_NB_TAB + 2];
+    __shared__ int lkcrit[HPK_NB_TAB + 2];      // per chunk of the table: the smallest count whose p is <= sig (hpk_kcrit)
     // Survivor records are only written for p-values at or below a per-family bound, given as a histogram bin (p <= sig
     // 4^-kmin): the cut of the chromosomes before lies orders of magnitude below sig, and 99 % of the p <= sig records
     // used to be written only for the compaction to drop them.  The histogram and the family counts still see every
@@ -2159,7 +2175,11 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
     if (threadIdx.x < NSETS_LDS) lemax[threadIdx.x] = 0ull;
     if (threadIdx.x < HPK_MAX_STEPS) lstepw[threadIdx.x] = (threadIdx.x < plan->nsteps) ? plan->steps[threadIdx.x].wi : 0;
     if (threadIdx.x < HPK_MAX_PAIRS) { lpair_slot[threadIdx.x] = plan->pair_slot[threadIdx.x]; lpair_wi[threadIdx.x] = plan->pair_wi[threadIdx.x]; }
-    if (threadIdx.x < HPK_NB_TAB + 2) lptoff[threadIdx.x] = const_cast<const int32_t*>(ka->ptab_off)[threadIdx.x];
+    if (threadIdx.x < HPK_NB_TAB + 2) {
+        lptoff[threadIdx.x] = const_cast<const int32_t*>(ka->ptab_off)[threadIdx.x];
+        const int32_t* kc = const_cast<const int32_t*>(ka->kcrit);
+        lkcrit[threadIdx.x] = kc ? kc[threadIdx.x] : 0;          // (no table of critical counts: every p-value is looked up)
+    }
     // The width the widening froze at.  The stencil's workgroups added their resolve counts into the chromosome's totals;
     // every workgroup here replays the reference's decision on them (a handful of steps, one thread), the first one
     // also leaves totals, executed flags and the "empty step" verdict for the host.  (It used to be the tail of the
@@ -2212,9 +2232,10 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
     double2 s2_b = make_double2(0.0, 0.0);
     double ir_b = 0.0, b1_b = 0.0, b2_b = 0.0, EK_b = 0.0, EY_b = 0.0;
     auto decode = [&](const uint2 un, Geo& g) {
-        const int tile = (int)un.x, ub = (int)(un.y & 255u);
+        // (the tile by row block << 8 | column chunk: no division by the band's own J per unit)
+        const int rb = (int)(un.x >> 8), cj = (int)(un.x & 255u), ub = (int)(un.y & 255u);
+        const int tile = rb * b_J + cj;
         g.cnt = (int)(un.y >> 8);
-        const int rb = tile / b_J, cj = tile - rb * b_J;
         g.r0 = rb * b_TR;
         g.c0 = g.r0 + a.mw + cj * b_TC;
         g.i0 = ub * HPK_UNIT;
@@ -2245,9 +2266,14 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
             b2_b = b_b2[cn ? (unsigned)c : 0u];
             b1_b = b_b1[cn ? (unsigned)r : 0u];
         }
+        // (windows clipped by one matrix end - pixels within maxww of it - take their expected sums from the edge tables: rare)
         const bool top = cn && r < W, right = cn && c >= b_n - W;
-        const double* __restrict__ tab = (top != right) ? b_eedge : b_etab;
-        const unsigned tbase = (top != right) ? (unsigned)(((top ? 0 : 1) * W + (top ? r : b_n - 1 - c)) * nsteps_u) * tstride : 0u;
+        const double* __restrict__ tab = b_etab;
+        unsigned tbase = 0u;
+        if (__ballot(top != right) != 0ull) {
+            tab = (top != right) ? b_eedge : b_etab;
+            tbase = (top != right) ? (unsigned)(((top ? 0 : 1) * W + (top ? r : b_n - 1 - c)) * nsteps_u) * tstride : 0u;
+        }
         int stp = cn ? stp_b : 0;
         const int stepw = lstepw[stp > 0 ? stp - 1 : 0];
         asm volatile("" : "+v"(stp));
@@ -2358,6 +2384,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                     unsigned odd = 0u;
                     int len2[2];
                     unsigned at2[2];
+                    bool crit2[2];
 #pragma unroll
                     for (int fl = 0; fl < 2; ++fl) {
                         const double E = fl ? eY : eK;
@@ -2384,13 +2411,18 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                         const int base = lptoff[ct];
                         len2[fl] = lptoff[ct + 1] - base;
                         at2[fl] = (unsigned)(base + (kO < len2[fl] ? kO : 0));
+                        crit2[fl] = kO >= lkcrit[ct];
                     }
                     if (__ballot(odd != 0u) == 0ull) {
-                        p2[0] = a.ptab[at2[0]];
-                        p2[1] = a.ptab[at2[1]];
-                        if (more) issue_round2(gn);      // behind this batch's table reads, ahead of their use
-                        p2[0] = kO < len2[0] ? p2[0] : 0.0;
-                        p2[1] = kO < len2[1] ? p2[1] : 0.0;
+                        // Only p <= sig is ever looked at (the family sizes count every valid pixel), p falls with the count, and
+                        // sig is one number per call: a pixel whose count stays below its chunk's critical count - the smallest
+                        // one whose table entry is <= sig (hpk_kcrit) - keeps the placeholder 1, and the table - a third
+                        // dependent round trip to memory per batch - is read for the one pixel in a thousand that can survive.
+                        if (more) issue_round2(gn);
+                        if (__ballot(crit2[0] | crit2[1]) != 0ull) {
+                            if (crit2[0]) p2[0] = kO < len2[0] ? a.ptab[at2[0]] : 0.0;
+                            if (crit2[1]) p2[1] = kO < len2[1] ? a.ptab[at2[1]] : 0.0;
+                        }
                     } else {
 #pragma unroll 1
                         for (int fl = 0; fl < 2; ++fl) {
@@ -2895,6 +2927,11 @@ void hpk_launch_publish(const HpkBandDesc* d_bands, int nbands, int nsets, bool 
     unsigned gx = (units / (full ? 1u : 3u) + 255u) / 256u;
     gx = gx < 1u ? 1u : gx;
     hipLaunchKernelGGL(hpk_publish, dim3(gx, nbands), dim3(256), 0, st, d_bands, nsets, full ? 1 : 0);
+}
+
+void hpk_launch_kcrit(const double* ptab, const int32_t* off, double sig, int32_t* kcrit, hipStream_t st) {
+    static_assert(HPK_NB_TAB <= 64, "one thread per chunk of the Poisson table");
+    hipLaunchKernelGGL(hpk_kcrit, dim3(1), dim3(64), 0, st, ptab, off, sig, kcrit);
 }
 
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,
