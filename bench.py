@@ -516,6 +516,8 @@ def main():
         for _ in range(2):
             Rs = submit(True).results()
         phases = {k: float(sum(r.timing[k] for r in Rs)) / len(Rs) for k in Rs[0].timing}       # per chromosome of a group
+        # (candidates resolved at the executed steps, per chromosome of the same group: what its scoring launch worked on)
+        phase_scored = float(sum(c_ for r in Rs for _, _, c_, ex in r.steps if ex)) / len(Rs)
         phases['total'] = float(Rs[-1].timing['total']) / len(Rs)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=args.coll_device)
@@ -609,8 +611,8 @@ def main():
             # The second kernel, hpk_score (a gather kernel: issue- and latency-bound), against the same roof.  Algorithmic
             # bytes per scored candidate and pair: its record (4 B entry + 1 B step + 16 B sums) and what its expected value is
             # formed from (IR[d], B1[r], B2[c], two local-expected table entries: 40 B); candidates = those resolved at the
-            # executed steps.  Time: the instrumented launch above (an upper bound of the timed region's).
-            nrec = float(sum(c_ for _, _, c_, ex in R.steps if ex))
+            # executed steps, mean over the chromosomes of the instrumented launch.  Time: the instrumented launch above (an upper bound of the timed region's).
+            nrec = phase_scored         # (the mean over the instrumented group - depths differ by an order of magnitude in candidates)
             sbytes = nrec * 61.0
             sach = sbytes / (phases['score'] * 1e-3) / 1e9
             out['roofline_score'] = {'bound': 'hbm', 'kernel': 'hpk_score', 'achieved': sach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -117,6 +117,7 @@ struct Options {
     int spec_surv_margin = 2;
     int spec_surv_force = -1;   // tests: this bin for every family (too narrow a bound: scored once more)
     int host_threads = 8;       // threads of a batch's host half (hpk_collect_batch), at most one per four chromosomes
+    int kcrit = 1;              // hpk_score forms a p-value only where the count reaches the critical count of its chunk (hiccups) / of its lambda's cell (bhfdr)
     int lean = 1;               // tiles of the column chunks hpk_band_class expects no resolving candidate in are built without their f64 plane
     int lean_max = 24;          // ... candidates of such a tile that do count and get their sums cell by cell; more: the tile is computed once more
     int lean_share_pct = 50;    // ... and a band has lean tiles only if at least this share of its column chunks is lean (below: hpk_stencil_s does them as fast)
@@ -135,8 +136,9 @@ struct hpk_ctx {
     std::vector<double> h_bounds;
     std::vector<int32_t> h_off;
     std::vector<double> h_sfe;
-    DevBuf d_bounds, d_off, d_sfe, d_ptab, d_kcrit;
+    DevBuf d_bounds, d_off, d_sfe, d_ptab, d_kcrit, d_kclam;
     double kcrit_sig = -1.0;            // the sig d_kcrit was built for (hpk_kcrit; rebuilt with the tables)
+    double kclam_sig = -1.0;            // ... and d_kclam (bhfdr: hpk_kcrit_lam)
     bool tables_dirty = true;           // the Poisson table is (re)built before the first launch that needs it
     Lane lane[HPK_LANES];
     DevBuf tmpA, tmpB, tmpC, tmpD;
@@ -230,6 +232,7 @@ int upload_tables(hpk_ctx* c) {
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->tables_dirty = false;
     c->kcrit_sig = -1.0;
+    c->kclam_sig = -1.0;
     return HPK_OK;
 }
 
@@ -329,6 +332,7 @@ int hpk_create(int device, hpk_ctx** out) {
     o.score_div = std::max(1, env_int("HPK_SCORE_DIV", o.score_div));
     o.dbg_stop = env_int("HPK_DBG_STOP", o.dbg_stop);
     o.host_prof = env_int("HPK_HOST_PROF", o.host_prof);
+    o.kcrit = env_int("HPK_KCRIT", o.kcrit) ? 1 : 0;
     o.lean = env_int("HPK_LEAN", o.lean) ? 1 : 0;
     o.lean_max = std::max(0, std::min(4096, env_int("HPK_LEAN_MAX", o.lean_max)));
     o.lean_frac_pct = std::max(0, std::min(400, env_int("HPK_LEAN_FRAC", o.lean_frac_pct)));
@@ -353,6 +357,7 @@ int hpk_set_option(hpk_ctx* c, const char* name, int64_t v) {
     else if (k == "spec_force" && v >= -1 && v <= 255) o.spec_force = (int)v;     // (clamped to maxww where it is used)
     else if (k == "risk_log2" && v >= 0 && v <= 60) o.risk_log2 = (int)v;
     else if (k == "tile_order" && (v == 0 || v == 1)) o.tile_order = (int)v;
+    else if (k == "kcrit" && (v == 0 || v == 1)) o.kcrit = (int)v;
     else if (k == "gap_kernel" && (v == 0 || v == 1)) o.gap_kernel = (int)v;
     else if (k == "score_div" && v >= 1 && v <= 4096) o.score_div = (int)v;
     else if (k == "dbg_stop" && v >= 0 && v <= 16) o.dbg_stop = (int)v;
@@ -371,7 +376,7 @@ void hpk_destroy(hpk_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    DevBuf* all[] = {&c->d_bounds, &c->d_off, &c->d_sfe, &c->d_ptab, &c->d_kcrit, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD, &c->cooA, &c->cooB, &c->cooC};
+    DevBuf* all[] = {&c->d_bounds, &c->d_off, &c->d_sfe, &c->d_ptab, &c->d_kcrit, &c->d_kclam, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD, &c->cooA, &c->cooB, &c->cooC};
     for (DevBuf* b : all) b->release();
     while (!c->live_bands.empty()) hpk_devband_free(c, c->live_bands.back());      // (bands their owner did not free: into the pool, freed below)
     for (auto& e : c->pool) (void)hipFree(e.second);
@@ -998,7 +1003,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     }
 #ifdef HPK_PHASE_CLOCK
     if (std::getenv("HPK_CLK_DUMP")) {
-        HIPCHK(c, c->tmpD.reserve(sizeof(unsigned long long) * 8 * HPK_NWAVES * 1024));
+        HIPCHK(c, c->tmpD.reserve(sizeof(unsigned long long) * (8 * HPK_NWAVES * 1024 + 8)));
         HIPCHK(c, hipMemsetAsync(c->tmpD.p, 0, sizeof(unsigned long long) * 8 * HPK_NWAVES * 1024, c->stream));
         sa.clk = c->tmpD.as<unsigned long long>();
     }
@@ -1009,7 +1014,8 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     sc.bounds = c->d_bounds.as<double>(); sc.ptab = c->d_ptab.as<double>();
     sc.ptab_off = c->d_off.as<int32_t>(); sc.sfe = c->d_sfe.as<double>(); sc.sig = prm->sig;
     sc.mw = mw; sc.D = D;
-    if (plan.mode == HPK_MODE_HICCUPS && !(prm->sig >= 1.0)) {      // the critical counts of this sig (cached: one tiny launch per change)
+    if (!opt.kcrit) {
+    } else if (plan.mode == HPK_MODE_HICCUPS && !(prm->sig >= 1.0)) {      // the critical counts of this sig (cached: one tiny launch per change)
         if (c->kcrit_sig != prm->sig) {
             HIPCHK(c, c->d_kcrit.reserve(sizeof(int32_t) * (HPK_NB_TAB + 2)));
             hpk_launch_kcrit(c->d_ptab.as<double>(), c->d_off.as<int32_t>(), prm->sig, c->d_kcrit.as<int32_t>(), c->stream);
@@ -1017,7 +1023,22 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
             c->kcrit_sig = prm->sig;
         }
         sc.kcrit = c->d_kcrit.as<int32_t>();
+    } else if (plan.mode == HPK_MODE_BHFDR && prm->sig < 0.25) {   // bhfdr: critical counts on a grid over lambda, likewise
+        if (c->kclam_sig != prm->sig) {
+            HIPCHK(c, c->d_kclam.reserve(sizeof(int32_t) * HPK_KCL_N));
+            hpk_launch_kcrit_lam(c->d_sfe.as<double>(), prm->sig, c->d_kclam.as<int32_t>(), c->stream);
+            HIPCHK(c, hipGetLastError());
+            c->kclam_sig = prm->sig;
+        }
+        sc.kcrit = c->d_kclam.as<int32_t>();
     }
+#ifdef HPK_PHASE_CLOCK
+    if (std::getenv("HPK_CLK_DUMP")) {          // hpk_score's accumulators: behind the stencil's region of tmpD
+        sc.clk = c->tmpD.as<unsigned long long>() + (size_t)8 * HPK_NWAVES * 1024;
+        HIPCHK(c, hipMemsetAsync(sc.clk, 0, 8 * 8, c->stream));
+        HIPCHK(c, hipMemsetAsync(sc.clk + 6, 0xff, 8, c->stream));
+    }
+#endif
     sc.hbins = hbins; sc.nsets_half = plan.npairs;
     // Survivor records: p <= sig is what can reach q <= sig, but the Benjamini-Hochberg cut of a family lies orders of
     // magnitude below sig (sig x rejections / tests), and the chromosomes collected last with these parameters say in which
@@ -1350,6 +1371,10 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
         std::vector<unsigned long long> h((size_t)8 * HPK_NWAVES * 1024);
         HIPCHK(c, hipMemcpy(h.data(), c->tmpD.p, h.size() * 8, hipMemcpyDeviceToHost));
         if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
+        unsigned long long s8[8];
+        HIPCHK(c, hipMemcpy(s8, c->tmpD.as<unsigned long long>() + (size_t)8 * HPK_NWAVES * 1024, sizeof(s8), hipMemcpyDeviceToHost));
+        if (s8[3]) std::fprintf(stderr, "hpk_score clock (100 MHz ticks): waves %llu items %llu; per wave prologue %.1f loop %.1f epilogue %.1f, longest %llu; first start to last end %llu\n",
+                                s8[3], s8[4], (double)s8[0] / s8[3], (double)s8[1] / s8[3], (double)s8[2] / s8[3], s8[5], s8[7] - s8[6]);
     }
 #endif
     // kernel times: events around the batch's launches, split over its chromosomes by band pixels

@@ -176,8 +176,16 @@ struct HpkScoreArgs {
     int32_t nsets_half;                 // (pw, ww) pairs of the call: the launcher sizes the histogram's LDS with it
     int32_t gridx;                      // workgroups per band
     const uint8_t* kmin;                // [HPK_NFAM] or nullptr: survivor records only for p-values in histogram bin >= kmin[family]
-    const int32_t* kcrit;               // [HPK_NB_TAB + 2] or nullptr: per chunk of the Poisson table the smallest count with p <= sig (hpk_kcrit)
+    const int32_t* kcrit;               // hiccups: [HPK_NB_TAB + 2] or nullptr: per chunk of the Poisson table the smallest count with p <= sig (hpk_kcrit);
+                                        // bhfdr: [HPK_KCL_N] or nullptr: the same per cell of a grid over lambda (hpk_kcrit_lam)
+    unsigned long long* clk;            // -DHPK_PHASE_CLOCK builds: [8] accumulators of hpk_score (prologue, loop, epilogue ticks; waves; items; longest wave), else nullptr
 };
+
+// bhfdr's critical counts: lambda in [2^HPK_KCL_E0, 2^(HPK_KCL_E0 + HPK_KCL_N / 16)) on a grid of 16 cells per octave - cell =
+// the top 16 bits of the double (sign 0, exponent, four mantissa bits) minus HPK_KCL_G0; a cell's entry belongs to its lower edge
+#define HPK_KCL_N 512
+#define HPK_KCL_E0 (-16)
+#define HPK_KCL_G0 ((1023 + HPK_KCL_E0) << 4)
 
 struct HpkDenseArgs {
     const unsigned* rec_ent; const double2* rec_S; const uint8_t* rec_W; const unsigned* tile_cnt;
@@ -221,6 +229,7 @@ void hpk_launch_publish(const HpkBandDesc* d_bands, int nbands, int nsets, bool 
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,
                      hipStream_t st);
 void hpk_launch_kcrit(const double* ptab, const int32_t* off, double sig, int32_t* kcrit, hipStream_t st);
+void hpk_launch_kcrit_lam(const double* sfe, double sig, int32_t* kcrit, hipStream_t st);
 // Record bound per chromosome by depth class (hpk_band_class): class = quarter octave of the band's mean count per pixel (every
 // 64th row sampled), bound = table[class] + margin (table: the width chromosomes of that class froze at, -1 unknown) clamped to
 // [wmin, wg_all]; written into the descriptor's wguess and into the counter block (HPK_OFF_BCLASS).  Runs before the stencil.

@@ -2023,6 +2023,24 @@ __global__ void __launch_bounds__(64) hpk_kcrit(const double* __restrict__ ptab,
     kcrit[ch] = k;
 }
 
+// bhfdr scores every pixel at its own lambda = E, so its critical counts sit on a grid over lambda (HPK_KCL_*): kcrit[g] = the
+// smallest count k with poisson_sf(k; lower edge of cell g) <= sig (1 + 1e-9).  The survival function grows with lambda, so a
+// pixel of cell g whose count is below kcrit[g] has p > sig whatever its lambda inside the cell (the margin is nine orders of
+// magnitude above the series' rounding) and keeps the placeholder 1 without the series being formed.  Bisection: p falls with k.
+__global__ void __launch_bounds__(64) hpk_kcrit_lam(const double* __restrict__ sfe, double sig, int32_t* __restrict__ kcrit) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= HPK_KCL_N) return;
+    const double lam = __longlong_as_double((long long)((unsigned long long)(g + HPK_KCL_G0) << 48));
+    const double cap = sig * (1.0 + 1e-9);
+    int lo = 0, hi = (int)(lam + 40.0 * sqrt(lam) + 64.0);          // p(hi) is 0 to the last bit
+    if (poisson_sf((double)lo, lam, sfe, 1.0) <= cap) { kcrit[g] = 0; return; }
+    while (hi - lo > 1) {                   // p(lo) > cap >= p(hi)
+        const int mid = lo + (hi - lo) / 2;
+        if (poisson_sf((double)mid, lam, sfe, 1.0) <= cap) hi = mid; else lo = mid;
+    }
+    kcrit[g] = hi;
+}
+
 // Fine p-value bins (bhfdr: one family of millions of tests per chromosome, whose cut the eight factor-4 bins of the
 // lambda-chunk families bracket only within a factor ~20: 55 000 records copied back for 3 300 pixels): four bins per
 // octave of x = sig / p, edges at 2^e x {1, 1.25, 1.5, 1.75}, the last bin open.  Any binning that is monotone in the
@@ -2112,11 +2130,16 @@ __global__ void __launch_bounds__(HPK_ET_THREADS) hpk_etab_edge(const HpkDevPlan
 // whole life and are flushed once.  Chunk boundaries sit in LDS; the chunk of E is 3 * exponent(E) plus two
 // comparisons against the reference's own boundary values.
 // blockIdx.y = band of the batch; a band's units are walked by the first `score_wgs` workgroups of its grid row.
+#define HPK_BQ 128                      // hpk_score, bhfdr: entries of a wave's ring of pending pixels (< 64 left behind + 64 new)
 template <bool BH, bool ONE>  // BH: bhfdr (one set, per-pixel lambda = E); otherwise hiccups (lambda chunks); ONE: a single (pw, ww) pair
 __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDesc* __restrict__ bands) {
     const HpkBandDesc* __restrict__ bd = bands + blockIdx.y;
     const int nwg = bd->score_wgs;
     if ((int)blockIdx.x >= nwg) return;
+#ifdef HPK_PHASE_CLOCK
+    const unsigned long long sck0 = __builtin_readcyclecounter();
+    unsigned long long sck_items = 0ull;
+#endif
     // per-pair counters: a single-pair launch (every hiccups() run with one (pw, ww), every bhfdr()) needs two sets only
     constexpr int NSETS_LDS = ONE ? 2 : 2 * HPK_MAX_PAIRS;
     __shared__ unsigned int lm[NSETS_LDS][HPK_NB + 1];
@@ -2127,6 +2150,13 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
     __shared__ int lpair_slot[HPK_MAX_PAIRS], lpair_wi[HPK_MAX_PAIRS];
     __shared__ int lptoff[HPK_NB_TAB + 2];
     __shared__ int lkcrit[HPK_NB_TAB + 2];      // per chunk of the table: the smallest count whose p is <= sig (hpk_kcrit)
+    // bhfdr: critical counts on the grid over lambda (hpk_kcrit_lam), and per wave a ring of the pixels whose series is still to
+    // be formed - the few whose count reaches their cell's critical count wait here until a wave-full of them is there, so
+    // that the series (the bulk of this kernel's arithmetic in this mode) runs on full waves, once per ~ten batches
+    __shared__ int lkcl[BH ? HPK_KCL_N : 1];
+    __shared__ double qE[BH ? 4 * HPK_BQ : 1];
+    __shared__ float qO[BH ? 4 * HPK_BQ : 1];
+    __shared__ int qr[BH ? 4 * HPK_BQ : 1], qc[BH ? 4 * HPK_BQ : 1];
     // Survivor records are only written for p-values at or below a per-family bound, given as a histogram bin (p <= sig
     // 4^-kmin): the cut of the chromosomes before lies orders of magnitude below sig, and 99 % of the p <= sig records
     // used to be written only for the compaction to drop them.  The histogram and the family counts still see every
@@ -2177,8 +2207,12 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
     if (threadIdx.x < HPK_MAX_PAIRS) { lpair_slot[threadIdx.x] = plan->pair_slot[threadIdx.x]; lpair_wi[threadIdx.x] = plan->pair_wi[threadIdx.x]; }
     if (threadIdx.x < HPK_NB_TAB + 2) {
         lptoff[threadIdx.x] = const_cast<const int32_t*>(ka->ptab_off)[threadIdx.x];
-        const int32_t* kc = const_cast<const int32_t*>(ka->kcrit);
+        const int32_t* kc = BH ? nullptr : const_cast<const int32_t*>(ka->kcrit);
         lkcrit[threadIdx.x] = kc ? kc[threadIdx.x] : 0;          // (no table of critical counts: every p-value is looked up)
+    }
+    if (BH) {
+        const int32_t* kc = const_cast<const int32_t*>(ka->kcrit);
+        for (int i = threadIdx.x; i < HPK_KCL_N; i += blockDim.x) lkcl[i] = kc ? kc[i] : 0;      // (none: every series is formed)
     }
     // The width the widening froze at.  The stencil's workgroups added their resolve counts into the chromosome's totals;
     // every workgroup here replays the reference's decision on them (a handful of steps, one thread), the first one
@@ -2202,6 +2236,9 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
     }
 
     const int lane = threadIdx.x & 63;
+#ifdef HPK_PHASE_CLOCK
+    const unsigned long long sck1 = __builtin_readcyclecounter();
+#endif
     const int nsteps_u = plan->nsteps;
     const int frozen = lfrozen;
     const unsigned pkcap = (unsigned)plan->pk_cap;
@@ -2215,7 +2252,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
     // Work unit = 4 consecutive 64-record batches of one tile's record region; units are dealt round-robin to all
     // waves of the grid (tiles differ a lot in candidate count), reads are coalesced.
     const unsigned nunits = *reinterpret_cast<const unsigned*>(small + HPK_OFF_NUNITS);     // work list appended by hpk_stencil: non-empty units only
-    const unsigned gw = (unsigned)((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    const unsigned gw = (unsigned)__builtin_amdgcn_readfirstlane((int)((((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6)));    // wave-uniform, and known to be
     const unsigned nwv = (unsigned)(((int64_t)nwg * blockDim.x) >> 6);
     // One batch ahead.  While a batch is scored the records of the next one - of the same work unit or of the wave's
     // next unit - are on their way, and as soon as this batch's Poisson-table reads are issued the next batch's second
@@ -2287,6 +2324,70 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
         EY_b = tab[to + (unsigned)(a.D + 1)];
         stp_b = stp;
     };
+    // The survivors of a wave's pixels (wave-uniform call: surv somewhere): family count, histogram bin, record.
+    auto survivors = [&](const bool surv, const int set, const int chunk, const int flag, const int r, const int c, const float rawpix,
+                         const double E, const double p) {
+        bool wr = surv;
+        if (surv) {
+            atomicAdd(&lf[set][chunk], 1u);
+            if (hbins) {
+                // floor(log2(sig / p)) from the two exponents and a mantissa compare (p = 0, subnormal: last bin)
+                const unsigned long long pb = (unsigned long long)__double_as_longlong(p);
+                int k = sig_e - (int)(pb >> 52) - ((pb & 0xfffffffffffffull) > sig_m ? 1 : 0);
+                k >>= HPK_HSHIFT;                                 // bins a factor 2^(2^HPK_HSHIFT) wide
+                k = (pb >> 52) == 0ull ? hbins - 1 : k;
+                k = k < 0 ? 0 : (k > hbins - 1 ? hbins - 1 : k);
+                if (BH && hbins > 16) k = fine_bin(a.sig / p, hbins);     // (bhfdr: four bins per octave)
+                if (chunk <= HPK_NB_TAB) atomicAdd(&lhist[(set * (HPK_NB_TAB + 1) + chunk) * hbins + k], 1u);
+                else atomicAdd(&gptr(kb->cnt)[(set * (HPK_NB + 1) + chunk) * hbins + k], 1u);
+                wr = k >= (int)lkmin[set * (HPK_NB + 1) + chunk];
+            }
+        }
+        const unsigned long long wm = __ballot(wr);
+        if (wm == 0ull) return;
+        // per-wave reservation of survivor slots
+        const unsigned scnt = (unsigned)__popcll(wm);
+        if (wused + scnt > HPK_SCH) {            // wave-uniform: retire the chunk, take a new one
+            if (have_chunk && lane == 0 && (int64_t)wbase < b_cap) gptr(kb->chunk_used)[(rbase + (int64_t)wbase) / HPK_SCH] = wused;
+            have_chunk = true;
+            unsigned long long nb = 0ull;
+            if (lane == 0) nb = atomicAdd(&b_nsurv[region * HPK_REG_STRIDE], (unsigned long long)HPK_SCH);
+            wbase = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)nb) |
+                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(nb >> 32)) << 32;
+            wused = 0u;
+        }
+        const unsigned long long basei = wbase + wused;
+        wused += scnt;
+        if (wr) {
+            const unsigned long long idx = basei + (unsigned long long)__popcll(wm & ((1ull << lane) - 1ull));
+            if ((int64_t)idx < b_cap) {
+                HpkSurv rec;
+                rec.x = r; rec.y = c; rec.O = rawpix; rec.set = (uint8_t)set; rec.chunk = (uint8_t)chunk;
+                rec.flag = (uint8_t)flag;                        // callers.py:330
+                rec.pad = 0; rec.E = E; rec.p = p; rec.bal = 0.0;       // balanced value: filled by hpk_thr_compact
+                b_surv[rbase + (int64_t)idx] = rec;
+            }
+        }
+    };
+    // bhfdr: the wave's ring of pending pixels (qhead / qcount are wave-uniform)
+    const int qbase = BH ? (int)(threadIdx.x >> 6) * HPK_BQ : 0;
+    int qhead = 0, qcount = 0;
+    auto drain = [&](const int nq) {                   // the series of the ring's first nq <= 64 pixels, their survivors
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool act = lane < nq;
+        const int qi = qbase + ((qhead + lane) & (HPK_BQ - 1));
+        const double E = act ? qE[qi] : 1.0;
+        const float o = act ? qO[qi] : 0.0f;
+        const int rr = act ? qr[qi] : 0, cc = act ? qc[qi] : 0;
+        double p = 1.0;
+        if (act) p = poisson_sf((double)o, E, const_cast<const double*>(ka->sfe), a.sig);      // callers.py:536-540
+        const bool surv = act && p <= a.sig;
+        if (__ballot(surv) != 0ull) survivors(surv, 0, 1, rr < 0 ? 1 : 0, rr & 0x7fffffff, cc, o, E, p);
+        qhead = (qhead + nq) & (HPK_BQ - 1);
+        qcount -= nq;
+        __builtin_amdgcn_wave_barrier();
+    };
     if (gw < nunits) {
         Geo gn;
         decode(b_units[gw], gn);
@@ -2297,6 +2398,9 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
         issue_round2(gn);
         bool more = true;
         while (more) {
+#ifdef HPK_PHASE_CLOCK
+            ++sck_items;
+#endif
             const Geo g = gn;
             const int i0 = g.i0;
             const bool cand = i0 + lane < g.cnt;
@@ -2367,14 +2471,31 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                 double p2[2] = {1.0, 1.0};
                 const int kO = (int)O;
                 if (BH) {
-                    if (more) issue_round2(gn);                 // (bhfdr: one pair; the series below is all arithmetic)
-                    if (eK > 0.0) {
-                        chunk2[0] = 1;
-                        // callers.py:536-540.  Only p <= sig is ever looked at (the family's size is counted above all pixels); a
-                        // count below its expectation has p = P(X > O) >= P(Poisson(O) > O) >= 0.264 (O >= 1: candidates are
-                        // non-zero pixels), so for sig < 1/4 the series is left out there - half of a chromosome's pixels
-                        if (!(a.sig < 0.25) || O >= eK) p2[0] = poisson_sf(O, eK, const_cast<const double*>(ka->sfe), a.sig);
+                    if (more) issue_round2(gn);                 // (bhfdr: one pair; everything below is arithmetic and LDS)
+                    // callers.py:517-540.  The family's size counts every valid pixel; only p <= sig is ever looked at beyond that, and
+                    // a pixel whose count stays below the critical count of its lambda's cell (hpk_kcrit_lam) has p > sig: it keeps
+                    // the placeholder.  The others - a few per batch - queue up for their series (drain).
+                    const bool valid = eK > 0.0;
+                    const unsigned long long vm = __ballot(valid);
+                    if (vm != 0ull) {
+                        const unsigned long long ebits = valid ? (unsigned long long)__double_as_longlong(eK) : 0ull;
+                        const bool beats = ebits > lemax[0];
+                        if (__ballot(beats) != 0ull) { if (beats) atomicMax(&lemax[0], ebits); }
+                        if (lane == 0) atomicAdd(&lm[0][1], (unsigned)__popcll(vm));            // one family: chunk 1
+                        const unsigned gi = (unsigned)((int)((unsigned long long)__double_as_longlong(eK) >> 48) - HPK_KCL_G0);
+                        const int kc = (valid && gi < (unsigned)HPK_KCL_N) ? lkcl[gi] : 0;        // (outside the grid: formed)
+                        const bool need = valid && kO >= kc;
+                        const unsigned long long nm = __ballot(need);
+                        if (nm != 0ull) {
+                            if (need) {
+                                const int qi = qbase + ((qhead + qcount + (int)__popcll(nm & ((1ull << lane) - 1ull))) & (HPK_BQ - 1));
+                                qE[qi] = eK; qO[qi] = rawpix; qr[qi] = r | (eY == 0.0 ? (int)0x80000000 : 0); qc[qi] = c;
+                            }
+                            qcount += (int)__popcll(nm);
+                            if (qcount >= 64) drain(64);
+                        }
                     }
+                    continue;
                 } else {
                     // Chunk of E: boundaries lbounds[i] = 2^(i/3); membership is strict on both sides (callers.py:38), so E
                     // sitting on a boundary belongs to no chunk.  E in [2^k, 2^(k+1)) has lbounds[3k .. 3k+2] at or below
@@ -2480,54 +2601,16 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                         // profiles/r05_score_ab.txt.)
                         if (valid) atomicAdd(&lm[set][chunk], 1u);
                     }
-                    if (sm != 0ull) {
-                        bool wr = surv;
-                        if (surv) {
-                            atomicAdd(&lf[set][chunk], 1u);
-                            if (hbins) {
-                                // floor(log2(sig / p)) from the two exponents and a mantissa compare (p = 0, subnormal: last bin)
-                                const unsigned long long pb = (unsigned long long)__double_as_longlong(p);
-                                int k = sig_e - (int)(pb >> 52) - ((pb & 0xfffffffffffffull) > sig_m ? 1 : 0);
-                                k >>= HPK_HSHIFT;                                 // bins a factor 2^(2^HPK_HSHIFT) wide
-                                k = (pb >> 52) == 0ull ? hbins - 1 : k;
-                                k = k < 0 ? 0 : (k > hbins - 1 ? hbins - 1 : k);
-                                if (BH && hbins > 16) k = fine_bin(a.sig / p, hbins);     // (bhfdr: four bins per octave)
-                                if (chunk <= HPK_NB_TAB) atomicAdd(&lhist[(set * (HPK_NB_TAB + 1) + chunk) * hbins + k], 1u);
-                                else atomicAdd(&gptr(kb->cnt)[(set * (HPK_NB + 1) + chunk) * hbins + k], 1u);
-                                wr = k >= (int)lkmin[set * (HPK_NB + 1) + chunk];
-                            }
-                        }
-                        const unsigned long long wm = __ballot(wr);
-                        if (wm == 0ull) continue;
-                        // per-wave reservation of survivor slots
-                        const unsigned scnt = (unsigned)__popcll(wm);
-                        if (wused + scnt > HPK_SCH) {            // wave-uniform: retire the chunk, take a new one
-                            if (have_chunk && lane == 0 && (int64_t)wbase < b_cap) gptr(kb->chunk_used)[(rbase + (int64_t)wbase) / HPK_SCH] = wused;
-                            have_chunk = true;
-                            unsigned long long nb = 0ull;
-                            if (lane == 0) nb = atomicAdd(&b_nsurv[region * HPK_REG_STRIDE], (unsigned long long)HPK_SCH);
-                            wbase = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)nb) |
-                                    (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(nb >> 32)) << 32;
-                            wused = 0u;
-                        }
-                        const unsigned long long basei = wbase + wused;
-                        wused += scnt;
-                        if (wr) {
-                            const unsigned long long idx = basei + (unsigned long long)__popcll(wm & ((1ull << lane) - 1ull));
-                            if ((int64_t)idx < b_cap) {
-                                HpkSurv rec;
-                                rec.x = r; rec.y = c; rec.O = rawpix; rec.set = (uint8_t)set; rec.chunk = (uint8_t)chunk;
-                                rec.flag = (fl == 0 && eY == 0.0) ? 1 : 0;           // callers.py:330
-                                rec.pad = 0; rec.E = E; rec.p = p; rec.bal = 0.0;       // balanced value: filled by hpk_thr_compact
-                                b_surv[rbase + (int64_t)idx] = rec;
-                            }
-                        }
-                    }
+                    if (sm != 0ull) survivors(surv, set, chunk, (fl == 0 && eY == 0.0) ? 1 : 0, r, c, rawpix, E, p);
                 }
             }
         }
+        if (BH) { while (qcount > 0) drain(qcount < 64 ? qcount : 64); }
     }
     if (have_chunk && lane == 0 && (int64_t)wbase < b_cap) gptr(kb->chunk_used)[(rbase + (int64_t)wbase) / HPK_SCH] = wused;
+#ifdef HPK_PHASE_CLOCK
+    const unsigned long long sck2 = __builtin_readcyclecounter();
+#endif
     __syncthreads();
     for (int i = threadIdx.x; i < nsets * (HPK_NB + 1); i += blockDim.x) {
         const unsigned v = (&lm[0][0])[i], f = (&lf[0][0])[i];
@@ -2544,6 +2627,14 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
             atomicAdd(&gptr(kb->cnt)[(st * (HPK_NB + 1) + ch) * hbins + k], v);
         }
     }
+#ifdef HPK_PHASE_CLOCK
+    if (a.clk && lane == 0) {
+        const unsigned long long sck3 = __builtin_readcyclecounter();
+        atomicAdd(&a.clk[0], sck1 - sck0); atomicAdd(&a.clk[1], sck2 - sck1); atomicAdd(&a.clk[2], sck3 - sck2);
+        atomicAdd(&a.clk[3], 1ull); atomicAdd(&a.clk[4], sck_items); atomicMax(&a.clk[5], sck3 - sck0);
+        atomicMin(&a.clk[6], sck0); atomicMax(&a.clk[7], sck3);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------ BH cut tightening on the survivor list
@@ -2851,7 +2942,11 @@ void hpk_launch_tighten(const HpkBandDesc* d_bands, int nbands, double sig, int 
     const int nfam = nsets * (HPK_NB + 1);          // families in use: (set, chunk)
     const dim3 grid(8, HPK_NREG, nbands);
     if (rounds <= -100) {       // the histogram came with the scoring kernel: only the compaction is left
-        hipLaunchKernelGGL(hpk_thr_compact, grid, dim3(256), 0, st, d_bands, rounds, sig, nfam, kmin);
+        // (hiccups' survivor lists are short - a few hundred records per region once the bound of the chromosomes before is in,
+        // a thousand without - and 32 768 workgroups per 64 chromosomes, nearly all of them leaving at once, took 0.18 ms; bhfdr's
+        // one family keeps tens of thousands per region)
+        const dim3 gridc(nsets == 1 ? 8 : 2, HPK_NREG, nbands);
+        hipLaunchKernelGGL(hpk_thr_compact, gridc, dim3(256), 0, st, d_bands, rounds, sig, nfam, kmin);
         return;
     }
     const uint8_t* none = nullptr;
@@ -2932,6 +3027,10 @@ void hpk_launch_publish(const HpkBandDesc* d_bands, int nbands, int nsets, bool 
 void hpk_launch_kcrit(const double* ptab, const int32_t* off, double sig, int32_t* kcrit, hipStream_t st) {
     static_assert(HPK_NB_TAB <= 64, "one thread per chunk of the Poisson table");
     hipLaunchKernelGGL(hpk_kcrit, dim3(1), dim3(64), 0, st, ptab, off, sig, kcrit);
+}
+
+void hpk_launch_kcrit_lam(const double* sfe, double sig, int32_t* kcrit, hipStream_t st) {
+    hipLaunchKernelGGL(hpk_kcrit_lam, dim3(HPK_KCL_N / 64), dim3(64), 0, st, sfe, sig, kcrit);
 }
 
 void hpk_launch_ptab(const double* bounds, const int32_t* off, const double* sfe, double* ptab, int32_t total,

@@ -244,7 +244,9 @@ int  hpk_collect_batch(hpk_ctx* ctx, hpk_job* job, hpk_result** outs, int32_t* s
  * "score_div" (tiles per scoring workgroup of a batch), "dbg_stop" (profiling ablation), "lean" (1 [default]: tiles of the column chunks
  * whose mean Reads stays below "lean_frac_pct" % of min_local_reads - sampled per chromosome on the device - are built without their
  * f64 plane; up to "lean_max" candidates of such a tile that resolve within the bound get their sums cell by cell, a tile with more
- * is computed once more in full; weight input only, off under spec_halo = 0), "reset_hints" (forget the bounds
+ * is computed once more in full; weight input only, off under spec_halo = 0), "kcrit" (1 [default]: the scoring kernel forms a
+ * p-value only where the pixel's count reaches the critical count - the smallest one with p <= sig - of its lambda chunk (hiccups)
+ * or of its lambda's cell on a grid of 16 per octave (bhfdr); 0: every p-value is formed; same results), "reset_hints" (forget the bounds
  * learnt from the chromosomes collected so far).  Returns HPK_ERR_INVALID for an
  * unknown name or a value out of range. */
 int  hpk_set_option(hpk_ctx* ctx, const char* name, int64_t value);

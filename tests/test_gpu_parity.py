@@ -640,6 +640,46 @@ def test_bh_cut_variants_agree(ctx, mode):
     assert quiet.timing['stencil'] == 0 and quiet.nsurv_cut == want.nsurv_cut
 
 
+@pytest.mark.parametrize('mode', ['hiccups', 'bhfdr'])
+@pytest.mark.parametrize('sig', [0.001, 0.01, 0.05, 0.2, 0.3])
+def test_critical_counts_drop_no_p_value_at_or_below_sig(mode, sig):
+    """hpk_score forms a p-value only where the count reaches the critical count of the pixel's lambda chunk (hiccups: hpk_kcrit)
+    or of its lambda's cell (bhfdr: hpk_kcrit_lam, the pixels that do queue up for their series); switched off (option kcrit = 0)
+    every p-value is formed.  Same survivors, the same number of p <= sig, the same cut - for several sig (bhfdr builds no table
+    from sig = 0.25 on), with and without the survivors' bound."""
+    from hicpeaks_amd import synthetic
+    n, res, maxapart, maxww = 3000, 10000, 2000000, 10
+    num = maxapart // res + maxww + 1
+    raw, weight, _ = synthetic.synth_band(n, num, depth=50.0, nloops=40, seed=21, structure={})
+    raw = raw.astype(np.float32)
+    if mode == 'hiccups':
+        prm = _lib.make_params(_lib.MODE_HICCUPS, [1, 2], [3, 5], maxww, sig, maxapart, res, 16, 0)
+    else:
+        prm = _lib.make_params(_lib.MODE_BHFDR, [2], [5], maxww, sig, maxapart, res, 16, 0)
+    c = _lib.Context(0)
+    c.set_option('spec_halo', 0)            # (bit-identical sums run to run: this test is about which p-values are formed)
+    try:
+        c.set_option('kcrit', 0)
+        want = c.score_host(raw, None, None, None, prm, weight=weight)
+        want2 = c.score_host(raw, None, None, None, prm, weight=weight)       # (under the survivors' bound of the first)
+        c.set_option('kcrit', 1)
+        got = c.score_host(raw, None, None, None, prm, weight=weight)
+        assert want.nsurv_sig > 100
+        for r in (want2, got):
+            _same_result(r, want)
+            assert r.nsurv_sig == want.nsurv_sig and r.nsurv_cut == want.nsurv_cut
+        c.set_option('spec_surv', 0)
+        got = c.score_host(raw, None, None, None, prm, weight=weight)
+        _same_result(got, want)
+        assert got.nsurv_sig == want.nsurv_sig
+        rs = c.submit_batch_host([dict(raw=raw, weight=weight) for _ in range(3)], prm).results()
+        for r in rs:
+            _same_result(r, want)
+            assert r.nsurv_sig == want.nsurv_sig
+    finally:
+        c.close()
+
+
 def test_random_parameter_sets_against_oracle(ctx):
     """A slice of scripts/gpu_fuzz.py (random chromosomes, maxww 3..20, one to three pairs in any order, thresholds,
     hiccups and bhfdr): final tables and resolving widths equal the oracle's, and both sides raise together.  The full
