@@ -2706,8 +2706,47 @@ __global__ void __launch_bounds__(256) hpk_thr_hist(const HpkBandDesc* __restric
     for (int i = threadIdx.x; i < nfam * nbins; i += blockDim.x) if (lh[i]) atomicAdd(&hist[i], lh[i]);
 }
 // bound per family from the histogram (see hpk_thr_hist; absolute: the bins of hpk_score, edges sig 2^-k instead of T_0 2^-k)
+// (fine bins - bhfdr: one family of millions of tests, 64 bins - take a wave per family with tests, a lane per bin: the thread per
+// family below walked 64 bins of global memory per round of its fixed-point iteration, one dependent load after the other, in
+// every workgroup of the compaction - 0.6 ms per 64 chromosomes)
+__device__ __forceinline__ void thr_table_hist_fine(double* lthr, const unsigned int* __restrict__ fam_m, const unsigned int* __restrict__ fam_f,
+                                                    const unsigned int* __restrict__ hist, int nbins, double sig, int nfam) {
+    __shared__ int nact, act[HPK_NFAM];
+    if (threadIdx.x == 0) nact = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nfam; i += blockDim.x) {
+        const unsigned m = fam_m[i];
+        const double t0 = thr_t0(m, fam_f[i], sig);
+        lthr[i] = t0;
+        if (m && t0 > 0.0) act[atomicAdd(&nact, 1)] = i;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int q = wave; q < nact; q += nw) {
+        const int i = act[q];
+        const double m = (double)fam_m[i];
+        // suf = p-values in the bins from this lane's on (whole numbers below 2^53: any order of adding them is exact)
+        double suf = lane < nbins ? (double)hist[(size_t)i * nbins + lane] : 0.0;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double o = __shfl_down(suf, d);
+            suf += lane + d < 64 ? o : 0.0;
+        }
+        double t = lthr[i];
+        for (int it = 0; it < 2 * nbins; ++it) {
+            const int k = fine_bin(sig / (t * (1.0 + 1e-12)), nbins);
+            const double c = __shfl(suf, k);
+            const double tn = fmin(t, sig * (c / m) * (1.0 + 1e-9));
+            if (!(tn < t)) break;
+            t = tn;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) lthr[i] = t;
+    }
+}
 __device__ __forceinline__ void thr_table_hist(double* lthr, const unsigned int* __restrict__ fam_m, const unsigned int* __restrict__ fam_f,
                                                const unsigned int* __restrict__ hist, int nbins, double sig, int nfam, bool absolute) {
+    if (absolute && nbins > 16) { thr_table_hist_fine(lthr, fam_m, fam_f, hist, nbins, sig, nfam); return; }
     for (int i = threadIdx.x; i < nfam; i += blockDim.x) {
         const unsigned m = fam_m[i];
         const double t0 = thr_t0(m, fam_f[i], sig);
