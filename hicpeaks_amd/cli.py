@@ -33,6 +33,7 @@ import logging
 import logging.handlers
 import os
 import sys
+import time
 
 
 def _add_deterministic(group):
@@ -131,6 +132,32 @@ def select_chroms(chromnames, chroms):
     return out
 
 
+# HPK_CLI_TIMELINE=<file>: every stage of every chromosome as "thread stage chromosome start end" (seconds since the first
+# event) - where a run's wall time goes (scripts/measure/gpu_r05_e2e_timeline.sh)
+_TL = [] if os.environ.get('HPK_CLI_TIMELINE') else None
+
+
+class _Stage:
+    def __init__(self, what, key):
+        self.what, self.key = what, key
+
+    def __enter__(self):
+        self.t0 = time.perf_counter()
+
+    def __exit__(self, *exc):
+        if _TL is not None:
+            import threading
+            _TL.append((threading.current_thread().name, self.what, str(self.key), self.t0, time.perf_counter()))
+
+
+def _dump_timeline():
+    if _TL:
+        t0 = min(e[3] for e in _TL)
+        with open(os.environ['HPK_CLI_TIMELINE'], 'w') as f:
+            for th, what, key, a, b in sorted(_TL, key=lambda e: e[3]):
+                f.write('%-12s %-8s %-6s %8.3f %8.3f\n' % (th, what, key, a - t0, b - t0))
+
+
 def _read(args_dict, src, key, use_pixels):
     """What one chromosome needs from the file (the first half of worker(), scripts/pyHICCUPS:139-166, without the
     per-diagonal extraction) - HDF5 reads and chunk inflation only, no GPU call: runs on the reader thread."""
@@ -226,8 +253,14 @@ def _score_queue(args_dict, mode, queue, device, shared=False):
             src = io.open_source(args_dict['path'])
             info['binsize'] = src.binsize
             use_pixels = hasattr(src, 'fetch_pixels') and not os.environ.get('HPK_HOST_BANDS')
+            if use_pixels and hasattr(src, 'enable_pool') and not os.environ.get('HPK_READ_NO_POOL'):
+                info['release'] = src.enable_pool()       # (the consumer hands a chromosome's pixel columns back: _consume)
             for key in queue:
-                if stop.is_set() or not put((key, _read(args_dict, src, key, use_pixels))):
+                if stop.is_set():
+                    return
+                with _Stage('read', key):
+                    got = _read(args_dict, src, key, use_pixels)
+                if not put((key, got)):
                     return
             put(None)
         except BaseException as e:          # (re-raised by the consumer)
@@ -258,27 +291,39 @@ def _consume(args_dict, mode, device, ctx, depth, fetched, info, pending, out, c
 
     def collect():
         labels, call = pending.popleft()
-        for label, table in zip(labels, call.results()):
-            out[label] = table
+        with _Stage('collect', labels[0]):
+            for label, table in zip(labels, call.results()):
+                out[label] = table
 
     group, nbytes = [], 0
     while True:
-        got = fetched.get()
+        # (nothing read yet: the host half of the oldest batch in flight - clustering, the tables - goes here instead of behind the
+        # last chromosome; the bounds the next batches inherit only get fresher)
+        while pending and fetched.empty():
+            collect()
+        with _Stage('wait', '-'):
+            got = fetched.get()
         if isinstance(got, BaseException):
             raise got
         if got is not None:
-            item = _to_item(got[0], got[1], ctx)
+            with _Stage('band', got[0]):
+                item = _to_item(got[0], got[1], ctx)
+                if got[1][0] == 'pixels' and info.get('release'):
+                    info['release'](*got[1][2:5])           # the band is built (on the GPU or the host): the columns serve the next chromosome
+            got = (got[0], None)
             group.append(item)
             nbytes += item[1].nbytes
         if group and (got is None or nbytes >= GROUP_BYTES or len(group) >= min(GROUP_CHROMS, _lib.HPK_MAX_BATCH) or not pending):
             if len(pending) >= depth:
                 collect()
-            pending.append(([g[0] for g in group], _submit_group(args_dict, mode, group, device, info['binsize'])))
+            with _Stage('submit', group[0][0]):
+                pending.append(([g[0] for g in group], _submit_group(args_dict, mode, group, device, info['binsize'])))
             group, nbytes = [], 0
         if got is None:
             break
     while pending:
         collect()
+    _dump_timeline()
     return out
 
 

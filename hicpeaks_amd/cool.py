@@ -39,6 +39,45 @@ def parse_uri(uri):
 
 
 # ----------------------------------------------------------------------------- libhdf5 through ctypes
+class ArrayPool(object):
+    """Result arrays of `read_big` that are handed back (`give`) instead of freed: a chromosome's pixel columns are 0.4-0.8 GB
+    each at depth, and an array of that size is a mapping of its own - every chromosome paid first-touch faults for its three
+    columns and a `munmap` of as many when they were dropped, under the process' one address-space lock and the GIL (a fifth of
+    the command line's wall time on a 10^9-pixel file, profiles/r05_cli_timeline.txt).  Largest-first order: what the first
+    chromosomes allocate serves all the others.  Thread-safe (the reader thread takes, the scoring thread gives)."""
+
+    def __init__(self):
+        import threading
+        self.lock = threading.Lock()
+        self.free = {}              # dtype -> [arrays]
+        self.owned = set()          # ids of the arrays handed out
+
+    def take(self, dtype, n):
+        dtype = np.dtype(dtype)
+        with self.lock:
+            fl = self.free.setdefault(dtype, [])
+            fit = [k for k in range(len(fl)) if fl[k].size >= n]
+            if fit:
+                a = fl.pop(min(fit, key=lambda k: fl[k].size))
+            else:
+                if fl:                                  # (none large enough: the smallest one goes instead of piling up)
+                    fl.pop(min(range(len(fl)), key=lambda k: fl[k].size))
+                a = None
+        if a is None:
+            a = np.empty(max(int(n), 1), dtype=dtype)
+            with self.lock:
+                self.owned.add(id(a))
+        return a[:n]
+
+    def give(self, *arrays):
+        for v in arrays:
+            a = v.base if isinstance(v, np.ndarray) and v.base is not None else v
+            if isinstance(a, np.ndarray):
+                with self.lock:
+                    if id(a) in self.owned and not any(a is b for b in self.free.get(a.dtype, [])):
+                        self.free[a.dtype].append(a)
+
+
 class _H5C(object):
     """The dozen HDF5 C calls a cooler needs.  Data sets are read as native int64 / float64 / fixed strings (HDF5 converts
     whatever the file holds, enums included), whole or as a [start, stop) slice of the first dimension."""
@@ -219,8 +258,9 @@ class _H5C(object):
             a -= bias
         return a
 
-    def read_big(self, name, start, stop, kind, threads=None, bias=0):
-        """`read` for the long slices of the pixel table: the data set's chunks are fetched as stored (H5Dread_chunk: the
+    def read_big(self, name, start, stop, kind, threads=None, bias=0, pool=None):
+        """(kind 'i4': an integer column as int32 where its stored type fits - the counts; `pool`: result arrays from an ArrayPool)
+        `read` for the long slices of the pixel table: the data set's chunks are fetched as stored (H5Dread_chunk: the
         library itself is not thread-safe, so this part stays serial - it is a copy out of the page cache) and inflated /
         un-shuffled / widened by libhpk's host threads (hpk_decode_chunks; HPK_READ_PYTHON=1 or no library: a Python thread pool
         - zlib and numpy release the GIL).  cooler writes its columns gzip-compressed with the shuffle filter in chunks; the
@@ -229,6 +269,9 @@ class _H5C(object):
         import zlib
         from concurrent.futures import ThreadPoolExecutor
         L = self.lib()
+        want32 = kind == 'i4'
+        if want32:
+            kind = None                 # (a float column stays what it is)
         if not self.have_chunks or stop - start < self.PARALLEL_MIN:
             return self._minus(self.read(name, start, stop, kind), bias)
         d = self._open(name)
@@ -279,7 +322,10 @@ class _H5C(object):
                 except Exception:          # (the reader also serves hosts where the library is not built: the Python pool below)
                     lib = None
             kd = 2 if tcls == 1 else (0 if signed else 1)
-            out = np.empty(stop - start, dtype=np.int64 if kind == 'i' else np.float64)
+            want32 = want32 and lib is not None and kind == 'i' and tcls != 1 and size <= (4 if signed else 2)
+            odt = np.int32 if want32 else (np.int64 if kind == 'i' else np.float64)
+            omode = 2 if want32 else (0 if kind == 'i' else 1)
+            out = pool.take(odt, stop - start) if pool is not None else np.empty(stop - start, dtype=odt)
 
             def read_chunk(k):
                 buf = np.empty(lens[k], dtype=np.uint8)
@@ -299,9 +345,11 @@ class _H5C(object):
                     self.fd_ok = ref is not None and os.pread(self.fd, lens[0], addrs[0]) == ref.tobytes()
                 if self.fd_ok:
                     rc = lib.hpk_decode_chunks_fd(self.fd, (C.c_uint64 * len(addrs))(*addrs), (C.c_uint64 * len(lens))(*lens), len(lens), c0, cs,
-                                                  size, kd, 1 if shuffle else 0, start, stop, out.ctypes.data, 0 if kind == 'i' else 1, int(bias), nthr)
+                                                  size, kd, 1 if shuffle else 0, start, stop, out.ctypes.data, omode, int(bias), nthr)
                     if rc == 0:
                         return out
+                    if pool is not None:
+                        pool.give(out)
                     return self._minus(self.read(name, start, stop, kind), bias)
             # the chunks as stored, into one arena (H5Dread_chunk, serial: a copy out of the page cache)
             arena = np.empty(sum(lens) + 64, dtype=np.uint8)
@@ -316,9 +364,11 @@ class _H5C(object):
             L.H5Dclose(d)
         if lib is not None:
             rc = lib.hpk_decode_chunks((C.c_void_p * len(offs))(*offs), (C.c_uint64 * len(lens))(*lens), len(offs), c0, cs, size, kd,
-                                       1 if shuffle else 0, start, stop, out.ctypes.data, 0 if kind == 'i' else 1, int(bias), nthr)
+                                       1 if shuffle else 0, start, stop, out.ctypes.data, omode, int(bias), nthr)
             if rc == 0:
                 return out
+            if pool is not None:
+                pool.give(out)
             return self._minus(self.read(name, start, stop, kind), bias)
         raws = [(c0 + k, arena[o - base:o - base + n_]) for k, (o, n_) in enumerate(zip(offs, lens))]
 
@@ -406,8 +456,8 @@ class _H5Py(object):
             return [x.decode() if isinstance(x, bytes) else str(x) for x in v]
         return v.astype(np.float64 if (kind == 'f' or (kind is None and v.dtype.kind == 'f')) else np.int64)
 
-    def read_big(self, name, start, stop, kind, threads=None, bias=0):
-        v = self.read(name, start, stop, kind)
+    def read_big(self, name, start, stop, kind, threads=None, bias=0, pool=None):
+        v = self.read(name, start, stop, None if kind == 'i4' else kind)
         if bias:
             v -= bias
         return v
@@ -453,6 +503,7 @@ class CoolFile(object):
         self.chromnames = self.h.read('chroms/name', kind='s')
         self.chrom_offset = self.h.read('indexes/chrom_offset', kind='i')
         self._cid = {c: i for i, c in enumerate(self.chromnames)}
+        self.pool = None                # an ArrayPool: `pixels` takes its arrays from it, `release` hands them back
 
     def close(self):
         self.h.close()
@@ -480,12 +531,22 @@ class CoolFile(object):
         off = self.h.read('indexes/bin1_offset', lo, hi + 1, kind='i')
         p0, p1 = int(off[0]), int(off[-1])
         # (bin ids relative to the chromosome's first bin as they are decoded: no second pass over 800 MB arrays)
-        b1 = self.h.read_big('pixels/bin1_id', p0, p1, 'i', bias=lo)
-        b2 = self.h.read_big('pixels/bin2_id', p0, p1, 'i', bias=lo)
-        cnt = self.h.read_big('pixels/count', p0, p1, None)
+        # (the counts as int32 where the file stores them so - what the band builders take; the arrays from the pool, if there is one)
+        pool = self.pool
+        b1 = self.h.read_big('pixels/bin1_id', p0, p1, 'i', bias=lo, pool=pool)
+        b2 = self.h.read_big('pixels/bin2_id', p0, p1, 'i', bias=lo, pool=pool)
+        cnt = self.h.read_big('pixels/count', p0, p1, 'i4', pool=pool)
         keep = b2 < hi - lo                             # pixels are sorted by bin1: the trans ones have bin2 beyond the chromosome
         if self.square:
             keep &= b2 >= b1                            # (and, both triangles stored: trans pixels also lie before it)
         if not keep.all():
+            full = (b1, b2, cnt)
             b1, b2, cnt = b1[keep], b2[keep], cnt[keep]
+            if pool is not None:
+                pool.give(*full)
         return b1, b2, cnt
+
+    def release(self, *arrays):
+        """Hands result arrays of `pixels` back for the next chromosome (ArrayPool); the caller no longer touches them."""
+        if self.pool is not None:
+            self.pool.give(*arrays)

@@ -1,5 +1,5 @@
 // Host-only helper of the cooler reader (hicpeaks_amd/cool.py): the chunks of a pixel-table column as HDF5 stores them - deflate,
-// optionally behind the byte-shuffle filter - inflated, un-shuffled and widened to int64 / f64 on a pool of threads with scratch
+// optionally behind the byte-shuffle filter - inflated, un-shuffled and widened to int64 / f64 (small integers: int32) on a pool of threads with scratch
 // buffers of their own.  The reference reads the same columns through cooler / h5py (scripts/pyHICCUPS:142-143), whose filter
 // pipeline runs one chunk at a time under HDF5's global lock; the Python-level pool this replaces (zlib.decompress + numpy
 // transposes) gave every chunk three fresh megabyte-sized allocations - mmap / munmap under the process' one address-space lock,
@@ -46,6 +46,8 @@ int decode_impl(const void* const* src, int fd, const uint64_t* file_off, const 
                 int32_t out_f64, int64_t bias, int32_t threads) {
     if ((!src && (fd < 0 || !file_off)) || !src_len || !out || nchunks < 0 || chunk_elems <= 0 || stop < start || kind < 0 || kind > 2) return HPK_ERR_INVALID;
     if (elem_size != 1 && elem_size != 2 && elem_size != 4 && elem_size != 8) return HPK_ERR_INVALID;
+    // (int32 output: integer columns that fit - signed up to four bytes, unsigned up to two)
+    if (out_f64 < 0 || out_f64 > 2 || (out_f64 == 2 && !((kind == 0 && elem_size <= 4) || (kind == 1 && elem_size <= 2)))) return HPK_ERR_INVALID;
     const size_t cbytes = (size_t)chunk_elems * (size_t)elem_size;
     const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(threads > 0 ? threads : (int)std::thread::hardware_concurrency(), nchunks));
     std::atomic<int64_t> next{0};
@@ -86,11 +88,14 @@ int decode_impl(const void* const* src, int fd, const uint64_t* file_off, const 
             const int64_t c0 = (first_chunk + i) * chunk_elems;
             const int64_t lo = std::max(start, c0), hi = std::min(stop, c0 + ne);
             if (hi <= lo) continue;
-            const bool ok = out_f64 ? widen_any<double>(p, elem_size, kind, lo - c0, hi - c0, static_cast<double*>(out) + (lo - start), (double)bias)
-                                    : widen_any<int64_t>(p, elem_size, kind, lo - c0, hi - c0, static_cast<int64_t*>(out) + (lo - start), bias);
+            const bool ok = out_f64 == 2 ? widen_any<int32_t>(p, elem_size, kind, lo - c0, hi - c0, static_cast<int32_t*>(out) + (lo - start), (int32_t)bias)
+                            : out_f64 ? widen_any<double>(p, elem_size, kind, lo - c0, hi - c0, static_cast<double*>(out) + (lo - start), (double)bias)
+                                      : widen_any<int64_t>(p, elem_size, kind, lo - c0, hi - c0, static_cast<int64_t*>(out) + (lo - start), bias);
             if (!ok) { bad.store(1); break; }
         }
     };
+    // (threads and scratch per call: a pool that outlives the call, each thread keeping its buffers, measured level on the
+    // 10^9-pixel file - 4.16-4.28 s against 4.01-4.26 s end to end, same box - and is not worth its fork and exit hazards)
     std::vector<std::thread> pool;
     for (int t = 1; t < nt; ++t) pool.emplace_back(work);
     work();

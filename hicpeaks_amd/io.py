@@ -121,6 +121,16 @@ class CoolerSource(BandSource):
             f.close()
             self.f = None
 
+    def enable_pool(self):
+        """The pixel columns of `fetch_pixels` from a pool of arrays (cool.ArrayPool) from here on -> the callable that hands a
+        chromosome's columns back once the band is built (thread-safe), or None (the `cooler`-package backend allocates its own)."""
+        f = getattr(self, 'f', None)
+        if f is None:
+            return None
+        from . import cool
+        f.pool = cool.ArrayPool()
+        return f.pool.give
+
     def _clr_pixels(self, chrom):
         """the chromosome's pixels through the `cooler` package, every pixel once: a file in storage mode 'square' lists both
         triangles ((i, j) and (j, i)), and the band builders fold them onto one cell - the lower one is dropped, as the

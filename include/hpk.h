@@ -306,7 +306,7 @@ int64_t hpk_band_from_coo(const int64_t* bin1, const int64_t* bin2, const void* 
  * as stored (deflate, behind the byte-shuffle filter if `shuffle`; src[i] / src_len[i]: chunk first_chunk + i, which holds the
  * elements [(first_chunk + i) * chunk_elems, ...)), are inflated, un-shuffled and widened on `threads` threads (0: all cores)
  * into out[0 .. stop - start) = elements [start, stop) minus `bias` (bin ids relative to a chromosome's first bin) as int64
- * (out_f64 = 0) or f64.  elem_size 1 / 2 / 4 / 8; kind 0 signed,
+ * (out_f64 = 0), f64 (1) or int32 (2: signed columns of up to four bytes, unsigned ones of up to two).  elem_size 1 / 2 / 4 / 8; kind 0 signed,
  * 1 unsigned integers, 2 floats; little-endian.  HPK_ERR_INVALID: a chunk that does not inflate to whole elements. */
 int  hpk_decode_chunks(const void* const* src, const uint64_t* src_len, int64_t nchunks, int64_t first_chunk, int64_t chunk_elems,
                        int32_t elem_size, int32_t kind, int32_t shuffle, int64_t start, int64_t stop, void* out, int32_t out_f64,

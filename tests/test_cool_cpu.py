@@ -134,6 +134,26 @@ def test_chunkwise_reading_equals_h5dread():
         i2, j2, c2 = f.pixels('chrA')
         np.testing.assert_array_equal(i, i2); np.testing.assert_array_equal(j, j2); np.testing.assert_array_equal(c, c2)
         assert n > 0
+        # the same through a pool of result arrays (what the command lines' reader thread does): the columns of one chromosome
+        # serve the next once they are handed back, and the counts arrive as int32 (the file stores them so)
+        h.PARALLEL_MIN = 0
+        f.pool = cool.ArrayPool()
+        bases = set()
+        for rnd in range(2):
+            for ch in f.chromnames:
+                f.pool = None
+                ref = f.pixels(ch)
+                f.pool = pool = getattr(f, '_test_pool', None) or cool.ArrayPool()
+                f._test_pool = pool
+                got = f.pixels(ch)
+                for a, b in zip(got, ref):
+                    np.testing.assert_array_equal(a, b)
+                assert got[2].dtype == np.int32
+                for a in got:
+                    if a.base is not None:
+                        bases.add(id(a.base))
+                f.release(*got)
+        assert sum(len(v) for v in pool.free.values()) <= 3 and len(bases) <= 3 + len(f.chromnames)      # (arrays come back: no pile of them)
     finally:
         h.PARALLEL_MIN = old
         f.close()
@@ -311,7 +331,34 @@ def test_hpk_decode_chunks_against_zlib_and_numpy():
                     out = np.empty(stop - start, np.float64 if of else np.int64)
                     assert lib.hpk_decode_chunks(src, sl, len(bufs), c0, cs, size, kind, shuffle, start, stop, out.ctypes.data, of, 7, 3) == 0
                     np.testing.assert_array_equal(out, v[start:stop].astype(out.dtype) - 7)
+                # int32 output: the integer columns that fit (signed up to four bytes, unsigned up to two), refused for the others
+                out = np.empty(stop - start, np.int32)
+                rc = lib.hpk_decode_chunks(src, sl, len(bufs), c0, cs, size, kind, shuffle, start, stop, out.ctypes.data, 2, 7, 3)
+                if (kind == 0 and size <= 4) or (kind == 1 and size <= 2):
+                    assert rc == 0
+                    np.testing.assert_array_equal(out, v[start:stop].astype(np.int32) - 7)
+                else:
+                    assert rc == _lib.ERR_INVALID
     bad = np.frombuffer(b'not a deflate stream at all', dtype=np.uint8)
     out = np.empty(10, np.int64)
     assert lib.hpk_decode_chunks((C.c_void_p * 1)(bad.ctypes.data), (C.c_uint64 * 1)(bad.size), 1, 0, cs, 4, 0, 1, 0, 10,
                                  out.ctypes.data, 0, 0, 1) == _lib.ERR_INVALID
+
+
+def test_array_pool_hands_arrays_back_by_identity():
+    """cool.ArrayPool: the smallest free array that is large enough, arrays compared by identity (several of one dtype, other
+    sizes, lie in the list), one that is given twice is kept once, none large enough -> a fresh one and the smallest one dropped."""
+    from hicpeaks_amd import cool
+    p = cool.ArrayPool()
+    a, b, c = p.take(np.int64, 100), p.take(np.int64, 50), p.take(np.int64, 80)
+    f = p.take(np.float64, 10)
+    p.give(a, b, c)
+    p.give(a)
+    p.give(np.zeros(5))                                     # (not the pool's: ignored)
+    assert len(p.free[np.dtype(np.int64)]) == 3 and not p.free[np.dtype(np.float64)]
+    d = p.take(np.int64, 60)
+    assert d.base is c.base and d.size == 60
+    e = p.take(np.int64, 200)
+    assert e.size == 200 and len(p.free[np.dtype(np.int64)]) == 1
+    p.give(f)
+    assert p.take(np.float64, 3).base is f.base
