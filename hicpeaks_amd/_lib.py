@@ -35,7 +35,7 @@ ABI_SYMBOLS = ['hpk_create', 'hpk_destroy', 'hpk_last_error', 'hpk_abi_version',
                'hpk_pipeline_depth', 'hpk_submit_band', 'hpk_collect', 'hpk_submit_batch', 'hpk_collect_batch', 'hpk_set_option',
                'hpk_result_free', 'hpk_plan_rings', 'hpk_chunk_bounds', 'hpk_set_chunk_bounds',
                'hpk_device_info', 'hpk_poisson_sf', 'hpk_bruteforce_sums', 'hpk_probe_sums', 'hpk_band_from_coo',
-               'hpk_devband_create', 'hpk_devband_free', 'hpk_decode_chunks', 'hpk_decode_chunks_fd']
+               'hpk_devband_create', 'hpk_devband_free', 'hpk_decode_chunks', 'hpk_decode_chunks_fd', 'hpk_compact_pixels']
 
 
 class HpkError(RuntimeError):
@@ -165,6 +165,9 @@ def load():
     lib.hpk_decode_chunks_fd.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int64, C.c_int32]
     lib.hpk_decode_chunks_fd.restype = C.c_int
+    lib.hpk_compact_pixels.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_int32]
+    lib.hpk_compact_pixels.restype = C.c_int64
     lib.hpk_devband_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(Band)]
     lib.hpk_devband_create.restype = C.c_int64

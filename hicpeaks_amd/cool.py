@@ -536,14 +536,38 @@ class CoolFile(object):
         b1 = self.h.read_big('pixels/bin1_id', p0, p1, 'i', bias=lo, pool=pool)
         b2 = self.h.read_big('pixels/bin2_id', p0, p1, 'i', bias=lo, pool=pool)
         cnt = self.h.read_big('pixels/count', p0, p1, 'i4', pool=pool)
-        keep = b2 < hi - lo                             # pixels are sorted by bin1: the trans ones have bin2 beyond the chromosome
-        if self.square:
-            keep &= b2 >= b1                            # (and, both triangles stored: trans pixels also lie before it)
-        if not keep.all():
-            full = (b1, b2, cnt)
-            b1, b2, cnt = b1[keep], b2[keep], cnt[keep]
-            if pool is not None:
-                pool.give(*full)
+        # pixels are sorted by bin1: a row's trans pixels have bin2 beyond the chromosome (and, both triangles stored, before it).
+        # Long tables: counted and moved by libhpk's host threads (hpk_compact_pixels); short ones, or no library: numpy.
+        full = (b1, b2, cnt)
+        done = False
+        if b1.size >= _H5C.PARALLEL_MIN and b1.dtype == np.int64 and b2.dtype == np.int64 and cnt.dtype.itemsize in (4, 8) \
+                and all(a.flags.c_contiguous for a in full) and not os.environ.get('HPK_READ_PYTHON'):
+            try:
+                from . import _lib
+                lib = _lib.load()
+            except Exception:
+                lib = None
+            if lib is not None:
+                nthr = int(os.environ.get('HPK_READ_THREADS', 0)) or min(64, os.cpu_count() or 1)
+                take = (lambda dt, n: pool.take(dt, n)) if pool is not None else (lambda dt, n: np.empty(n, dtype=dt))
+                kept = lib.hpk_compact_pixels(b1.ctypes.data, b2.ctypes.data, cnt.ctypes.data, cnt.dtype.itemsize, b1.size, hi - lo,
+                                              1 if self.square else 0, None, None, None, nthr)      # (count only: nothing to write to)
+                if kept == b1.size:
+                    done = True
+                elif kept >= 0:
+                    o1, o2, oc = take(np.int64, kept), take(np.int64, kept), take(cnt.dtype, kept)
+                    if lib.hpk_compact_pixels(b1.ctypes.data, b2.ctypes.data, cnt.ctypes.data, cnt.dtype.itemsize, b1.size, hi - lo,
+                                              1 if self.square else 0, o1.ctypes.data, o2.ctypes.data, oc.ctypes.data, nthr) == kept:
+                        b1, b2, cnt = o1, o2, oc
+                        done = True
+        if not done:
+            keep = (b2 < hi - lo) & (b2 >= 0)
+            if self.square:
+                keep &= b2 >= b1
+            if not keep.all():
+                b1, b2, cnt = b1[keep], b2[keep], cnt[keep]
+        if pool is not None and b1 is not full[0]:
+            pool.give(*full)
         return b1, b2, cnt
 
     def release(self, *arrays):

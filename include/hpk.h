@@ -318,6 +318,14 @@ int  hpk_decode_chunks_fd(int32_t fd, const uint64_t* file_off, const uint64_t* 
                           int64_t chunk_elems, int32_t elem_size, int32_t kind, int32_t shuffle, int64_t start, int64_t stop,
                           void* out, int32_t out_f64, int64_t bias, int32_t threads);
 
+/* The pixels of a chromosome's rows that belong to its intra-chromosomal map (counterpart of the selection inside
+ * `Lib.matrix(balance=False, as_pixels=True, join=False).fetch(key)`, scripts/pyHICCUPS:142): of `n` pixels (bin1, bin2, count;
+ * bins relative to the chromosome's first bin, count_size 4 or 8 bytes per count) those with 0 <= bin2 < nbins and, if `square`
+ * (both triangles stored), bin2 >= bin1, in order, into out1 / out2 / outc (no overlap with the input) on `threads` threads.
+ * Returns the number kept; if that is n, or if all three outputs are null (count only), nothing is written.  Host only. */
+int64_t hpk_compact_pixels(const int64_t* bin1, const int64_t* bin2, const void* count, int32_t count_size, int64_t n, int64_t nbins,
+                           int32_t square, int64_t* out1, int64_t* out2, void* outc, int32_t threads);
+
 #ifdef __cplusplus
 }
 #endif

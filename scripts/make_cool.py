@@ -90,6 +90,7 @@ def main():
     ap.add_argument('--depth', type=float, default=40.0)
     ap.add_argument('--group', default='/')
     ap.add_argument('--chroms', nargs='*', default=None)
+    ap.add_argument('--trans', type=int, default=0, help="--genome: this many trans pixels per chromosome (but the last), as a real map's rows carry")
     a = ap.parse_args()
     if os.path.exists(a.out):
         os.remove(a.out)
@@ -102,7 +103,18 @@ def main():
             raw, w, _ = synthetic.synth_band(n, a.num, depth=a.depth, nloops=max(1, n // 60), seed=100 + i)
             bands[c], weights[c] = raw, w
             print(c, n, int((raw != 0).sum()), file=sys.stderr)
-        nnz = write_cool(a.out, a.group, a.res, chroms, bands, weights)
+        trans = None
+        if a.trans > 0 and len(chroms) > 1:        # trans pixels: rows in every chromosome but the last, columns in a later one
+            rng = np.random.default_rng(10)
+            offs = np.concatenate([[0], np.cumsum([n for _, n in chroms])])
+            keys = []
+            for i in range(len(chroms) - 1):
+                t1 = rng.integers(offs[i], offs[i + 1], a.trans).astype(np.int64)
+                t2 = rng.integers(offs[i + 1], offs[-1], a.trans).astype(np.int64)
+                keys.append(t1 * (1 << 32) + t2)
+            key = np.unique(np.concatenate(keys))
+            trans = (key >> 32, key & ((1 << 32) - 1), rng.integers(1, 5, key.size))
+        nnz = write_cool(a.out, a.group, a.res, chroms, bands, weights, trans=trans)
     else:
         chroms = [('chrA', 400), ('chrB', 57), ('chrC', 260)]
         bands, weights, kr = {}, {}, {}

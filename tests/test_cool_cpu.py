@@ -362,3 +362,78 @@ def test_array_pool_hands_arrays_back_by_identity():
     assert e.size == 200 and len(p.free[np.dtype(np.int64)]) == 1
     p.give(f)
     assert p.take(np.float64, 3).base is f.base
+
+
+def test_hpk_compact_pixels_against_numpy():
+    """libhpk's threaded selection of a chromosome's own pixels (hpk_compact_pixels: bin2 inside the chromosome, upper triangle of
+    files that store both) against the numpy mask it replaces - int32 / int64 / f64 counts, nothing to drop, everything to
+    drop, the count-only call - and through CoolFile.pixels on a table long enough to take that path."""
+    import ctypes as C
+    from hicpeaks_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    n, nbins = 300000, 1000
+    b1 = np.sort(rng.integers(0, nbins, n)).astype(np.int64)
+    for square in (0, 1):
+        for cdt in (np.int32, np.int64, np.float64):
+            for hi in (nbins, 3 * nbins, 1):
+                b2 = rng.integers(0, hi, n).astype(np.int64) if square else (b1 + rng.integers(0, hi, n)).astype(np.int64)
+                cnt = rng.integers(1, 50, n).astype(cdt)
+                keep = (b2 < nbins) & (b2 >= 0)
+                if square:
+                    keep &= b2 >= b1
+                want = int(keep.sum())
+                args = (b1.ctypes.data, b2.ctypes.data, cnt.ctypes.data, cnt.dtype.itemsize, n, nbins, square)
+                assert lib.hpk_compact_pixels(*args, None, None, None, 5) == want
+                o1, o2, oc = np.full(n, -1, np.int64), np.full(n, -1, np.int64), np.zeros(n, cdt)
+                assert lib.hpk_compact_pixels(*args, o1.ctypes.data, o2.ctypes.data, oc.ctypes.data, 5) == want
+                if want < n:
+                    np.testing.assert_array_equal(o1[:want], b1[keep]); np.testing.assert_array_equal(o2[:want], b2[keep])
+                    np.testing.assert_array_equal(oc[:want], cnt[keep])
+                    assert (o1[want:] == -1).all()
+                else:
+                    assert (o1 == -1).all()                 # (everything kept: nothing written)
+    assert lib.hpk_compact_pixels(b1.ctypes.data, b1.ctypes.data, b1.ctypes.data, 2, n, nbins, 0, None, None, None, 1) == _lib.ERR_INVALID
+
+
+def test_long_pixel_table_with_trans_pixels(tmp_path):
+    """A map whose rows carry trans pixels (as every real one does), long enough for the chunk-wise reader and the threaded
+    selection (hpk_compact_pixels): the chromosome's own pixels, with and without the pool of arrays, equal what numpy selects
+    from the table read in one piece."""
+    import subprocess
+    from hicpeaks_amd import cool
+    conda = '/opt/conda/bin/python3.9'
+    if not os.path.exists(conda):
+        pytest.skip('no interpreter with h5py to write the file')
+    path = str(tmp_path / 'trans.mcool')
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rc = subprocess.call([conda, os.path.join(repo, 'scripts', 'make_cool.py'), path, '--genome', 'hg38', '--res', '5000', '--num', '1200',
+                          '--group', '/resolutions/5000', '--depth', '25', '--chroms', '21', '22', '--trans', '400000'],
+                         env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    if rc != 0:
+        pytest.skip('make_cool.py could not write the file here')
+    f = cool.CoolFile(path + '::/resolutions/5000')
+    h = f.h
+    if not isinstance(h, cool._H5C) or not h.have_chunks:
+        pytest.skip('h5py backend or an HDF5 library without H5Dread_chunk')
+    try:
+        lo, hi = f.extent('chr21')
+        off = h.read('indexes/bin1_offset', lo, hi + 1, kind='i')
+        p0, p1 = int(off[0]), int(off[-1])
+        assert p1 - p0 > h.PARALLEL_MIN
+        r1, r2, rc_ = (h.read('pixels/' + nm, p0, p1, kind='i') for nm in ('bin1_id', 'bin2_id', 'count'))
+        keep = r2 < hi
+        assert 0 < keep.sum() < keep.size                       # trans pixels there, and dropped
+        for pooled in (False, True):
+            f.pool = cool.ArrayPool() if pooled else None
+            for rnd in range(2):
+                i, j, c = f.pixels('chr21')
+                np.testing.assert_array_equal(i, r1[keep] - lo); np.testing.assert_array_equal(j, r2[keep] - lo)
+                np.testing.assert_array_equal(c, rc_[keep])
+                f.release(i, j, c)
+            if pooled:
+                assert sum(len(v) for v in f.pool.free.values()) <= 6       # (full and selected columns: handed back, not piled up)
+        i, j, c = f.pixels('chr22')                             # the last chromosome: nothing to drop
+        assert i.size == h.shape('pixels/bin1_id')[0] - p1 and (j >= i).all()
+    finally:
+        f.close()
