@@ -78,12 +78,26 @@ class ArrayPool(object):
                         self.free[a.dtype].append(a)
 
 
+def _h5_locked(fn):
+    """libhdf5 is not thread-safe (and ctypes releases the GIL around every call into it): one call sequence at a time, whatever
+    the file - `read_big` lets go of the lock while its chunks are decoded, which is when another column's look-ups run."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kw):
+        with _H5C._h5lock:
+            return fn(self, *args, **kw)
+    return wrapper
+
+
 class _H5C(object):
     """The dozen HDF5 C calls a cooler needs.  Data sets are read as native int64 / float64 / fixed strings (HDF5 converts
     whatever the file holds, enums included), whole or as a [start, stop) slice of the first dimension."""
 
     _lib = None
     _pool, _pool_n = None, 0            # decoding threads of read_big
+    import threading as _threading
+    _h5lock = _threading.RLock()
 
     @classmethod
     def lib(cls):
@@ -166,6 +180,7 @@ class _H5C(object):
             os.close(self.fd)
             self.fd = -1
 
+    @_h5_locked
     def exists(self, name):
         L = self.lib()
         cur = ''
@@ -181,6 +196,7 @@ class _H5C(object):
             raise KeyError(name)
         return d
 
+    @_h5_locked
     def shape(self, name):
         L = self.lib()
         d = self._open(name)
@@ -191,6 +207,7 @@ class _H5C(object):
         L.H5Dclose(d)
         return tuple(int(dims[i]) for i in range(nd))
 
+    @_h5_locked
     def read(self, name, start=None, stop=None, kind=None):
         """kind: 'i' -> int64, 'f' -> float64, 's' -> list of str, None -> by the data set's class"""
         L = self.lib()
@@ -258,6 +275,7 @@ class _H5C(object):
             a -= bias
         return a
 
+    @_h5_locked
     def read_big(self, name, start, stop, kind, threads=None, bias=0, pool=None):
         """(kind 'i4': an integer column as int32 where its stored type fits - the counts; `pool`: result arrays from an ArrayPool)
         `read` for the long slices of the pixel table: the data set's chunks are fetched as stored (H5Dread_chunk: the
@@ -344,8 +362,12 @@ class _H5C(object):
                     ref = read_chunk(0)
                     self.fd_ok = ref is not None and os.pread(self.fd, lens[0], addrs[0]) == ref.tobytes()
                 if self.fd_ok:
-                    rc = lib.hpk_decode_chunks_fd(self.fd, (C.c_uint64 * len(addrs))(*addrs), (C.c_uint64 * len(lens))(*lens), len(lens), c0, cs,
-                                                  size, kd, 1 if shuffle else 0, start, stop, out.ctypes.data, omode, int(bias), nthr)
+                    self._h5lock.release()          # (no HDF5 call in here: the chunks are pread and decoded by libhpk's threads)
+                    try:
+                        rc = lib.hpk_decode_chunks_fd(self.fd, (C.c_uint64 * len(addrs))(*addrs), (C.c_uint64 * len(lens))(*lens), len(lens), c0, cs,
+                                                      size, kd, 1 if shuffle else 0, start, stop, out.ctypes.data, omode, int(bias), nthr)
+                    finally:
+                        self._h5lock.acquire()
                     if rc == 0:
                         return out
                     if pool is not None:
@@ -363,8 +385,12 @@ class _H5C(object):
         finally:
             L.H5Dclose(d)
         if lib is not None:
-            rc = lib.hpk_decode_chunks((C.c_void_p * len(offs))(*offs), (C.c_uint64 * len(lens))(*lens), len(offs), c0, cs, size, kd,
-                                       1 if shuffle else 0, start, stop, out.ctypes.data, omode, int(bias), nthr)
+            self._h5lock.release()
+            try:
+                rc = lib.hpk_decode_chunks((C.c_void_p * len(offs))(*offs), (C.c_uint64 * len(lens))(*lens), len(offs), c0, cs, size, kd,
+                                           1 if shuffle else 0, start, stop, out.ctypes.data, omode, int(bias), nthr)
+            finally:
+                self._h5lock.acquire()
             if rc == 0:
                 return out
             if pool is not None:
@@ -391,6 +417,7 @@ class _H5C(object):
                 decode(it)
         return self._minus(out, bias)
 
+    @_h5_locked
     def attr(self, obj, name, default=None):
         """Scalar integer / float / boolean-like attribute of the group (obj = '.') or of a data set."""
         L = self.lib()
@@ -504,8 +531,12 @@ class CoolFile(object):
         self.chrom_offset = self.h.read('indexes/chrom_offset', kind='i')
         self._cid = {c: i for i, c in enumerate(self.chromnames)}
         self.pool = None                # an ArrayPool: `pixels` takes its arrays from it, `release` hands them back
+        self._colpool = None            # three threads, one per pixel column of a long read
 
     def close(self):
+        if self._colpool is not None:
+            self._colpool.shutdown(wait=True)
+            self._colpool = None
         self.h.close()
 
     def extent(self, chrom):
@@ -533,9 +564,17 @@ class CoolFile(object):
         # (bin ids relative to the chromosome's first bin as they are decoded: no second pass over 800 MB arrays)
         # (the counts as int32 where the file stores them so - what the band builders take; the arrays from the pool, if there is one)
         pool = self.pool
-        b1 = self.h.read_big('pixels/bin1_id', p0, p1, 'i', bias=lo, pool=pool)
-        b2 = self.h.read_big('pixels/bin2_id', p0, p1, 'i', bias=lo, pool=pool)
-        cnt = self.h.read_big('pixels/count', p0, p1, 'i4', pool=pool)
+        cols = (('pixels/bin1_id', 'i', lo), ('pixels/bin2_id', 'i', lo), ('pixels/count', 'i4', 0))
+        if isinstance(self.h, _H5C) and p1 - p0 >= _H5C.PARALLEL_MIN and not os.environ.get('HPK_READ_SERIAL'):
+            # the three columns at once: a column is a few hundred chunks, i.e. a handful per decoding thread - more threads per
+            # column buy nothing, three columns side by side do (the HDF5 look-ups of one run while the others are decoded)
+            if self._colpool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._colpool = ThreadPoolExecutor(3, thread_name_prefix='hpk-column')
+            futs = [self._colpool.submit(self.h.read_big, nm, p0, p1, kd, bias=bs, pool=pool) for nm, kd, bs in cols]
+            b1, b2, cnt = [f.result() for f in futs]
+        else:
+            b1, b2, cnt = [self.h.read_big(nm, p0, p1, kd, bias=bs, pool=pool) for nm, kd, bs in cols]
         # pixels are sorted by bin1: a row's trans pixels have bin2 beyond the chromosome (and, both triangles stored, before it).
         # Long tables: counted and moved by libhpk's host threads (hpk_compact_pixels); short ones, or no library: numpy.
         full = (b1, b2, cnt)
