@@ -181,7 +181,14 @@ class PendingBatch(object):
         self._job, self._finishers = job, finishers
 
     def results(self):
-        return [f(R) for f, R in zip(self._finishers, self._job.results())]
+        return self.collect()()
+
+    def collect(self):
+        """Waits for the kernels and the library's host half (hpk_collect_batch) -> a callable that runs the Python half of every
+        chromosome (gap filter, donut / lower-left combination, clustering) and returns the tables; it touches no GPU state and
+        may run on another thread while the caller submits the next batch."""
+        fins, Rs = self._finishers, self._job.results()
+        return lambda: [f(R) for f, R in zip(fins, Rs)]
 
 
 def hiccups_batch_submit(items, pw=[2], ww=[5], maxww=20, sig=0.1, sumq=0.01, double_fold=1.75, single_fold=2,

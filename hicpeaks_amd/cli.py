@@ -289,12 +289,39 @@ def _score_queue(args_dict, mode, queue, device, shared=False):
 def _consume(args_dict, mode, device, ctx, depth, fetched, info, pending, out, collections):
     from . import _lib
 
+    # A batch is collected here (the wait for its kernels and the library's host half: C, this thread's context); the Python half of
+    # its chromosomes - gap filter, combination, clustering - runs on a thread of its own, beside the next chromosomes' band
+    # building and submission, which are C calls too (profiles/r05_cli_timeline.txt: it was half of this thread's time).
+    from concurrent.futures import ThreadPoolExecutor
+    finpool = ThreadPoolExecutor(1, thread_name_prefix='hpk-finish')
+    finishing = []
+
+    def finish(labels, half):
+        with _Stage('finish', labels[0]):
+            return list(zip(labels, half()))
+
     def collect():
         labels, call = pending.popleft()
         with _Stage('collect', labels[0]):
-            for label, table in zip(labels, call.results()):
+            half = call.collect()
+        if os.environ.get('HPK_CLI_FINISH_INLINE'):      # (profiling: everything on this thread)
+            for label, table in finish(labels, half):
                 out[label] = table
+            return
+        finishing.append(finpool.submit(finish, labels, half))
 
+    try:
+        _consume_loop(args_dict, mode, device, ctx, depth, fetched, info, pending, collect, _lib)
+        for fut in finishing:                       # (a finisher's exception surfaces here, like the reference's worker's would)
+            for label, table in fut.result():
+                out[label] = table
+    finally:
+        finpool.shutdown(wait=True, cancel_futures=True)
+    _dump_timeline()
+    return out
+
+
+def _consume_loop(args_dict, mode, device, ctx, depth, fetched, info, pending, collect, _lib):
     group, nbytes = [], 0
     while True:
         # (nothing read yet: the host half of the oldest batch in flight - clustering, the tables - goes here instead of behind the
@@ -323,8 +350,6 @@ def _consume(args_dict, mode, device, ctx, depth, fetched, info, pending, out, c
             break
     while pending:
         collect()
-    _dump_timeline()
-    return out
 
 
 def _gpu_count():

@@ -7,9 +7,10 @@ return values as the reference.  DBSCAN with min_samples=2 on integer pixels is 
 components of the "distance <= eps" graph (every non-isolated point is a core point), so it is done
 here with a union-find instead of importing scikit-learn.
 """
-from collections import Counter
-
 import numpy as np
+
+
+_WALK_ALL_CELLS = False         # tests: local_clustering tests every cell of every anchor rectangle, as the reference does
 
 
 def find_anchors(pos, min_count=3, min_dis=20000, wlen=200000, res=10000):
@@ -18,18 +19,20 @@ def find_anchors(pos, min_count=3, min_dis=20000, wlen=200000, res=10000):
 
     min_dis = max(min_dis // res, 1)
     wlen = min(wlen // res, 10)
-    count = Counter(pos)
-    refidx = range(min(count) - 1, max(count) + 2)          # one empty bin on both sides
-    signal = np.r_[[count[i] for i in refidx]]
+    pos = np.asarray(pos, dtype=np.int64)
+    lo = int(pos.min()) - 1                                 # one empty bin on both sides
+    signal = np.bincount(pos - lo, minlength=int(pos.max()) - lo + 2)
+    refidx = range(lo, lo + signal.size)
     summits = find_peaks(signal, height=min_count, distance=min_dis)[0]
-    by_height = sorted(((signal[i], i) for i in summits), reverse=True)
+    # (the widths of all summits in one call: every peak's is computed on its own, as the reference's call per peak does)
+    wl, wr = peak_widths(signal, summits, rel_height=1, wlen=wlen)[2:4] if len(summits) else ((), ())
+    by_height = sorted(((signal[i], i, k) for k, i in enumerate(summits)), reverse=True)
 
     anchors = set()
     owner = {}                                              # bin -> anchor covering it
-    for _, i in by_height:
-        w = peak_widths(signal, [i], rel_height=1, wlen=wlen)[2:4]
-        lb = refidx[int(np.round(w[0][0]))]
-        rb = refidx[int(np.round(w[1][0]))]
+    for _, i, k in by_height:
+        lb = refidx[int(np.round(wl[k]))]
+        rb = refidx[int(np.round(wr[k]))]
         summit = refidx[i]
         if anchors:
             for b in range(lb, rb + 1):
@@ -129,10 +132,31 @@ def local_clustering(Donuts, LL, res, onlysummit=False, min_count=3, r=20000, su
     r = max(r // res, 1)
     visited = set()
     lookup = set(keys)
+    # The pixels inside every (x anchor, y anchor) rectangle.  The anchors of an axis do not overlap (find_anchors merges those
+    # that do), so a pixel lies in at most one rectangle: the pixels are dealt to their rectangles once, and the rectangles are
+    # visited in the reference's order (callers.py:700-706 walks all pairs and tests every cell of each).
+    xown, yown, disjoint = {}, {}, True
+    for own, anchors in ((xown, x_anchors), (yown, y_anchors)):
+        for a in anchors:
+            for b in range(a[1], a[2] + 1):
+                disjoint = disjoint and b not in own
+                own[b] = a
+    disjoint = disjoint and not _WALK_ALL_CELLS
+    if disjoint:
+        boxes = {}
+        for k in keys:
+            xa, ya = xown.get(k[0]), yown.get(k[1])
+            if xa is not None and ya is not None:
+                boxes.setdefault((xa, ya), []).append((Donuts[k][0], k))
     for xa in x_anchors:
         for ya in y_anchors:
-            inside = [(Donuts[(i, j)][0], (i, j)) for i in range(xa[1], xa[2] + 1) for j in range(ya[1], ya[2] + 1)
-                      if (i, j) in lookup]
+            if disjoint:
+                inside = boxes.get((xa, ya))
+                if inside is None or len(inside) < 2:       # (_cluster_core leaves fewer than two pixels alone)
+                    continue
+            else:
+                inside = [(Donuts[(i, j)][0], (i, j)) for i in range(xa[1], xa[2] + 1) for j in range(ya[1], ya[2] + 1)
+                          if (i, j) in lookup]
             inside.sort(reverse=True)
             _cluster_core(inside, r, visited, final_list)
     rest = [(Donuts[k][0], k) for k in keys if k not in visited]

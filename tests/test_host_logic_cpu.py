@@ -93,6 +93,37 @@ def test_clustering_matches_reference(name):
     assert got == want
 
 
+def test_clustering_rectangles_dealt_once_equal_the_walk_over_all_cells(monkeypatch):
+    """local_clustering deals the pixels to their (x anchor, y anchor) rectangles once instead of testing every cell of every
+    pair of anchors (callers.py:700-706: quadratic in the anchors, a second of Python per large chromosome at depth); the same
+    list, in the same order, as the walk - random clustered pixel sets, three parameter sets, with and without the LL table."""
+    import warnings
+    rng = np.random.default_rng(0)
+    for trial in range(25):
+        n, nclu = int(rng.integers(200, 3000)), int(rng.integers(1, 80))
+        D, L = {}, {}
+        for c in range(nclu):
+            cx = int(rng.integers(0, n)); cy = cx + int(rng.integers(5, 200))
+            for _ in range(int(rng.integers(1, 60))):
+                i, j = cx + int(rng.integers(-4, 5)), cy + int(rng.integers(-4, 5))
+                if i < 0 or j <= i:
+                    continue
+                D[(i, j)] = (float(rng.integers(1, 400)) / 7.0, float(rng.random()), float(rng.random() * 0.02))
+                L[(i, j)] = (float(rng.integers(1, 400)) / 7.0, float(rng.random()), float(rng.random() * 0.02))
+        for k in range(int(rng.integers(0, 30))):
+            i = int(rng.integers(0, n)); j = i + int(rng.integers(3, 300))
+            D[(i, j)] = L[(i, j)] = (float(rng.integers(1, 50)), 0.1, float(rng.random() * 0.02))
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            for res, r, mc, onlys, ll in ((10000, 20000, 3, False, True), (5000, 20000, 2, True, True), (25000, 50000, 3, False, False)):
+                kw = dict(onlysummit=onlys, min_count=mc, r=r, sumq=0.01)
+                got = clustering.local_clustering(D, L if ll else None, res, **kw)
+                monkeypatch.setattr(clustering, '_WALK_ALL_CELLS', True)
+                want = clustering.local_clustering(D, L if ll else None, res, **kw)
+                monkeypatch.setattr(clustering, '_WALK_ALL_CELLS', False)
+                assert got == want and len(want) > 0
+
+
 def test_clustering_components_equal_dbscan():
     from sklearn.cluster import dbscan
     rng = np.random.default_rng(5)
