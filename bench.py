@@ -449,8 +449,16 @@ def main():
 
     fw_by_depth = {}
 
+    call_log = []                       # HPK_BENCH_CALLS=1: (seconds since the first, wait inside results() in ms) of every collection -> stderr
+
     def take(job, done):
+        t_c = time.perf_counter()
         rs = job.results()
+        if os.environ.get('HPK_BENCH_CALLS'):
+            call_log.append((t_c, (time.perf_counter() - t_c) * 1e3, max(r.timing['host_bh'] for r in rs), sum(r.timing['host_bh'] for r in rs),
+                             sum(r.timing['d2h'] for r in rs), max(r.nsurv_cut for r in rs), sum(int(r.redone) for r in rs),
+                             sum(int(r.rescored) for r in rs), sum(int(r.lean_redone) for r in rs), sum(r.timing['stencil'] for r in rs),
+                             sum(r.timing['score'] for r in rs), max(r.timing['total'] for r in rs)))
         del done[:]
         done.append(rs[-1])              # the report needs the kernel times (below) and one result, not all of them
         for j, r in enumerate(rs):       # widths the widening froze at, by the depth of the band (what the bounds are inherited across)
@@ -497,6 +505,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     nredone_timed, nrescored_timed = nredone[0], nrescored[0]
+    if call_log and rank == 0:
+        for t_c, w, hmax, hsum, dsum, nmax, nred, nres, nlr, st_, sc_, tot_ in call_log:
+            print('call at %8.1f ms: results() %7.2f ms; host_bh max %6.2f sum %7.2f, d2h sum %6.2f ms, most survivors %d; redone %d rescored %d lean_redone %d; '
+                  'stencil %.2f score %.2f total %.2f ms' % ((t_c - call_log[0][0]) * 1e3, w, hmax, hsum, dsum, nmax, nred, nres, nlr, st_, sc_, tot_), file=sys.stderr)
     lean_timed = dict(lean_ct)
     fw_timed = {str(k): sorted(v) for k, v in sorted(fw_by_depth.items())}
     assert len(stencil_ms) >= args.steps * batch // group // TIMED_EVERY

@@ -49,6 +49,31 @@ struct DevBuf {
     template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Pinned host memory handed out in pieces and taken back all at once (a lane's survivor lists beyond the inline heads): copies
+// into pageable memory are staged by the runtime, through kernels that queue behind the next batch's persistent workgroups - a
+// collection then waited one or two batch times for a few megabytes (maps with structure: tens of thousands of survivors per
+// chromosome; the bench line came out at 0.37 or 0.74 ms per chromosome by how the copies happened to fall).
+struct PinnedArena {
+    std::vector<std::pair<char*, size_t>> chunks;
+    size_t cur = 0, used = 0;
+    void reset() { cur = 0; used = 0; }
+    void* take(size_t bytes) {
+        bytes = (bytes + 63) & ~(size_t)63;
+        while (cur < chunks.size() && used + bytes > chunks[cur].second) { ++cur; used = 0; }
+        if (cur == chunks.size()) {
+            const size_t cap = std::max(bytes, (size_t)16 << 20);
+            void* p = nullptr;
+            if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+            chunks.emplace_back(static_cast<char*>(p), cap);
+            used = 0;
+        }
+        void* r = chunks[cur].first + used;
+        used += bytes;
+        return r;
+    }
+    void release() { for (auto& ch : chunks) (void)hipHostFree(ch.first); chunks.clear(); reset(); }
+};
+
 double now_ms() {
     using namespace std::chrono;
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
@@ -78,6 +103,7 @@ struct Lane {
     size_t h_head_cap = 0;
     void* h_desc = nullptr;             // pinned staging of the band descriptors
     size_t h_desc_cap = 0;
+    PinnedArena h_rest;                 // pinned: the survivors beyond the inline heads of the batch being collected
     // the device copy of the widening plan is reused while the parameters do not change
     hpk_params plan_key;
     bool plan_valid = false;
@@ -88,6 +114,7 @@ struct Lane {
         for (DevBuf* b : all) b->release();
         if (h_head) { (void)hipHostFree(h_head); h_head = nullptr; h_head_cap = 0; }
         if (h_desc) { (void)hipHostFree(h_desc); h_desc = nullptr; h_desc_cap = 0; }
+        h_rest.release();
         for (int i = 0; i < nev; ++i) (void)hipEventDestroy(ev[i]);
         nev = 0;
         if (ev_up) { (void)hipEventDestroy(ev_up); ev_up = nullptr; }
@@ -116,7 +143,7 @@ struct Options {
     int spec_surv = 1;          // survivor records only up to the cut's histogram bin of the chromosomes before (minus spec_surv_margin bins)
     int spec_surv_margin = 2;
     int spec_surv_force = -1;   // tests: this bin for every family (too narrow a bound: scored once more)
-    int host_threads = 8;       // threads of a batch's host half (hpk_collect_batch), at most one per four chromosomes
+    int host_threads = 8;       // threads of a batch's host half (hpk_collect_batch), at most one per four chromosomes (hpk_create: up to 16 by the host's cores)
     int kcrit = 1;              // hpk_score forms a p-value only where the count reaches the critical count of its chunk (hiccups) / of its lambda's cell (bhfdr)
     int lean = 1;               // tiles of the column chunks hpk_band_class expects no resolving candidate in are built without their f64 plane
     int lean_max = 24;          // ... candidates of such a tile that do count and get their sums cell by cell; more: the tile is computed once more
@@ -322,6 +349,9 @@ int hpk_create(int device, hpk_ctx** out) {
     o.spec_halo = env_int("HPK_SPEC_HALO", o.spec_halo);
     o.spec_class = env_int("HPK_SPEC_CLASS", o.spec_class) ? 1 : 0;
     o.spec_force = env_int("HPK_SPEC_FORCE", o.spec_force);     // (measurements: a record bound of one's choosing)
+    // (up to 16 where the host has the cores: maps with structure leave tens of thousands of survivors per chromosome, a few
+    // milliseconds of sorting each, and the host half of a batch has to stay below its 20 ms of kernels)
+    o.host_threads = std::max(2, std::min(16, (int)std::thread::hardware_concurrency() / 2));
     o.host_threads = std::max(1, std::min(64, env_int("HPK_HOST_THREADS", o.host_threads)));
     o.spec_surv = env_int("HPK_SPEC_SURV", o.spec_surv) ? 1 : 0;
     o.spec_surv_margin = std::max(0, env_int("HPK_SPEC_SURV_MARGIN", o.spec_surv_margin));
@@ -502,7 +532,7 @@ struct BandSlot {
     bool redone = false, overflowed = false, finished = false, rescored = false;
     int cls = -1;                       // depth class hpk_band_class put the band in (-1: not classified)
     bool rest_fetched = false;          // the survivors beyond the inline head already sit in `rest` (overflow rerun)
-    std::vector<HpkSurv> rest;
+    HpkSurv* rest = nullptr;            // ... in the lane's pinned arena (Lane::h_rest)
     int status = HPK_OK;
     std::string err;
     ResultBox* box = nullptr;
@@ -1137,10 +1167,11 @@ int finish_band(hpk_ctx* c, hpk_job* j, int b, std::string* err = nullptr) {
         const size_t ns = (size_t)h_nsurv;
         const HpkSurv* head = reinterpret_cast<const HpkSurv*>(hsmall + s.off_inl);
         if (ns > HPK_HEAD_INLINE && !s.rest_fetched) {
-            s.rest.resize(ns - HPK_HEAD_INLINE);
+            s.rest = static_cast<HpkSurv*>(L.h_rest.take(sizeof(HpkSurv) * (ns - HPK_HEAD_INLINE)));
+            if (!s.rest) return fail(c, HPK_ERR_HIP, "pinned memory for %zu survivor records", ns - HPK_HEAD_INLINE);
             // beyond the inlined head: fetched on the lane's own (idle) copy stream, so the next batch's kernels on the
             // compute stream are not waited for
-            HIPCHK(c, hipMemcpyAsync(s.rest.data(), s.d.surv2, sizeof(HpkSurv) * (ns - HPK_HEAD_INLINE), hipMemcpyDeviceToHost, L.up));
+            HIPCHK(c, hipMemcpyAsync(s.rest, s.d.surv2, sizeof(HpkSurv) * (ns - HPK_HEAD_INLINE), hipMemcpyDeviceToHost, L.up));
             HIPCHK(c, hipStreamSynchronize(L.up));
         }
         auto rec_at = [&](size_t i) -> const HpkSurv& { return i < HPK_HEAD_INLINE ? head[i] : s.rest[i - HPK_HEAD_INLINE]; };
@@ -1190,8 +1221,25 @@ int finish_band(hpk_ctx* c, hpk_job* j, int b, std::string* err = nullptr) {
             std::memcpy(&bits, &sv[i].p, 8);
             keys[i] = Key{(uint32_t)sv[i].set << 8 | sv[i].chunk, (uint32_t)i, bits};
         }
-        std::sort(keys.begin(), keys.end(), [](const Key& a, const Key& b2) {
-            return a.fam != b2.fam ? a.fam < b2.fam : a.pbits < b2.pbits; });
+        // (dealt to their families first - a counting pass over at most 256 x 256 family codes, a few hundred in use -, then every
+        // family sorted by p on its own: tens of thousands of survivors per chromosome on maps with structure, and one sort over all
+        // of them by (family, p) was 40 % of this half)
+        {
+            std::vector<uint32_t> start;
+            uint32_t maxf = 0;
+            for (const Key& k : keys) maxf = std::max(maxf, k.fam);
+            start.assign((size_t)maxf + 2, 0u);
+            for (const Key& k : keys) ++start[(size_t)k.fam + 1];
+            for (size_t f = 1; f < start.size(); ++f) start[f] += start[f - 1];
+            std::vector<Key> dealt(keys.size());
+            std::vector<uint32_t> at(start.begin(), start.end() - 1);
+            for (const Key& k : keys) dealt[at[k.fam]++] = k;
+            for (size_t f = 0; f + 1 < start.size(); ++f)
+                if (start[f + 1] - start[f] > 1)
+                    std::sort(dealt.begin() + start[f], dealt.begin() + start[f + 1], [](const Key& a, const Key& b2) {
+                        return a.pbits != b2.pbits ? a.pbits < b2.pbits : a.idx < b2.idx; });
+            keys.swap(dealt);
+        }
         std::vector<Surv*> order(sv.size());
         for (size_t i = 0; i < sv.size(); ++i) order[i] = &sv[keys[i].idx];
         const double t_h1 = now_ms();
@@ -1236,9 +1284,12 @@ int finish_band(hpk_ctx* c, hpk_job* j, int b, std::string* err = nullptr) {
             i = e;
         }
         const double t_h2 = now_ms();
-        for (int t = 0; t < nsets; ++t)
-            std::sort(kept[t].begin(), kept[t].end(), [](const Surv* a, const Surv* b2) {
-                return a->x != b2->x ? a->x < b2->x : a->y < b2->y; });
+        for (int t = 0; t < nsets; ++t) {           // by (x, y): on flat keys, the records themselves are not touched by the sort
+            std::vector<std::pair<uint64_t, Surv*>> xy(kept[t].size());
+            for (size_t i = 0; i < xy.size(); ++i) xy[i] = {(uint64_t)(uint32_t)kept[t][i]->x << 32 | (uint32_t)kept[t][i]->y, kept[t][i]};
+            std::sort(xy.begin(), xy.end(), [](const std::pair<uint64_t, Surv*>& a, const std::pair<uint64_t, Surv*>& b2) { return a.first < b2.first; });
+            for (size_t i = 0; i < xy.size(); ++i) kept[t][i] = xy[i].second;
+        }
         if (c->opt.host_prof) std::fprintf(stderr, "[hpk host] n=%zu sort=%.3f bh=%.3f\n", sv.size(), t_h1 - t_d2h1, t_h2 - t_h1);
         size_t total = 0;
         for (int t = 0; t < nsets; ++t) total += kept[t].size();
@@ -1270,6 +1321,7 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
     const HpkDevPlan& plan = L.plan_host;
     const int nb = (int)j->bands.size();
     HIPCHK(c, hipEventSynchronize(L.ev_done));           // this batch only; the next one keeps running
+    L.h_rest.reset();                                    // (the lane's previous batch has its survivors in its results by now)
     for (int pass = 0; j->do_score; ++pass) {
         bool again = false;
         for (int b = 0; b < nb; ++b) {
@@ -1355,8 +1407,9 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
             HIPCHK(c, hipEventSynchronize(L.ev_done));
             const unsigned long long nout = *reinterpret_cast<const unsigned long long*>(hsmall + HPK_OFF_NOUT);
             if (nout > HPK_HEAD_INLINE) {
-                s.rest.resize(nout - HPK_HEAD_INLINE);
-                HIPCHK(c, hipMemcpyAsync(s.rest.data(), s.d.surv2, sizeof(HpkSurv) * (nout - HPK_HEAD_INLINE), hipMemcpyDeviceToHost, c->stream));
+                s.rest = static_cast<HpkSurv*>(L.h_rest.take(sizeof(HpkSurv) * (nout - HPK_HEAD_INLINE)));
+                if (!s.rest) return fail(c, HPK_ERR_HIP, "pinned memory for %llu survivor records", nout - HPK_HEAD_INLINE);
+                HIPCHK(c, hipMemcpyAsync(s.rest, s.d.surv2, sizeof(HpkSurv) * (nout - HPK_HEAD_INLINE), hipMemcpyDeviceToHost, c->stream));
                 HIPCHK(c, hipStreamSynchronize(c->stream));
             }
             s.rest_fetched = true;
@@ -1405,8 +1458,9 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
             const unsigned char* hsmall = static_cast<const unsigned char*>(L.h_head) + s.head_off;
             const size_t ns = (size_t)*reinterpret_cast<const unsigned long long*>(hsmall + HPK_OFF_NOUT);
             if (ns > HPK_HEAD_INLINE) {
-                s.rest.resize(ns - HPK_HEAD_INLINE);
-                HIPCHK(c, hipMemcpyAsync(s.rest.data(), s.d.surv2, sizeof(HpkSurv) * (ns - HPK_HEAD_INLINE), hipMemcpyDeviceToHost, L.up));
+                s.rest = static_cast<HpkSurv*>(L.h_rest.take(sizeof(HpkSurv) * (ns - HPK_HEAD_INLINE)));
+                if (!s.rest) return fail(c, HPK_ERR_HIP, "pinned memory for %zu survivor records", ns - HPK_HEAD_INLINE);
+                HIPCHK(c, hipMemcpyAsync(s.rest, s.d.surv2, sizeof(HpkSurv) * (ns - HPK_HEAD_INLINE), hipMemcpyDeviceToHost, L.up));
                 s.rest_fetched = true;
                 fetched = true;
             }
