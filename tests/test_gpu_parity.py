@@ -680,6 +680,39 @@ def test_critical_counts_drop_no_p_value_at_or_below_sig(mode, sig):
         c.close()
 
 
+def test_survivors_beyond_the_inline_heads_in_a_batch():
+    """Maps with structure leave tens of thousands of survivors per chromosome: beyond the 4 096 that travel with a chromosome's
+    counters they are copied on their own - into the lane's pinned arena, for all chromosomes of a batch at once (the threaded host
+    half, eight chromosomes or more) or one by one (smaller batches, single calls).  Every path gives the single call's result,
+    batch after batch on both lanes (the arena is handed out again)."""
+    from hicpeaks_amd import synthetic
+    n, res, maxapart, maxww = 2500, 10000, 2000000, 10
+    num = maxapart // res + maxww + 1
+    prm = _lib.make_params(_lib.MODE_HICCUPS, [1, 2], [3, 5], maxww, 0.1, maxapart, res, 16, 0)
+    bands = []
+    for k in range(3):
+        raw, weight, _ = synthetic.synth_band(n + 100 * k, num, depth=150.0, nloops=40, seed=31 + k, structure={})
+        bands.append((raw.astype(np.float32), weight))
+    c = _lib.Context(0)
+    c.set_option('spec_halo', 0)            # (bit-identical sums whatever the bound: this test is about where the survivors travel)
+    try:
+        want = [c.score_host(r, None, None, None, prm, weight=w) for r, w in bands]
+        assert max(r.nsurv_cut for r in want) > 2 * 4096, [r.nsurv_cut for r in want]
+        again = [c.score_host(r, None, None, None, prm, weight=w) for r, w in bands]         # (under the bounds of the first round)
+        for a, b in zip(again, want):
+            _same_result(a, b)
+        items = [dict(raw=bands[k % 3][0], weight=bands[k % 3][1]) for k in range(10)]
+        for rnd in range(3):                                    # threaded host half; lanes 0, 1, 0
+            jobs = [c.submit_batch_host(items, prm)] + ([c.submit_batch_host(items[:4], prm)] if rnd == 1 else [])
+            for job in jobs:
+                rs = job.results()
+                for k, r in enumerate(rs):
+                    _same_result(r, want[k % 3])
+                    assert r.nsurv_cut == again[k % 3].nsurv_cut
+    finally:
+        c.close()
+
+
 def test_random_parameter_sets_against_oracle(ctx):
     """A slice of scripts/gpu_fuzz.py (random chromosomes, maxww 3..20, one to three pairs in any order, thresholds,
     hiccups and bhfdr): final tables and resolving widths equal the oracle's, and both sides raise together.  The full
