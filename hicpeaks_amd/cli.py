@@ -38,12 +38,16 @@ import time
 
 def _add_deterministic(group):
     group.add_argument('--deterministic', action='store_true',
-                       help='Every chromosome under the plan\'s own tile geometry: the output does not depend on the order of the '
-                            'chromosomes, on how they are batched or on --nproc / the number of GPUs (like the reference, whose '
-                            'result is independent of its map order, scripts/pyHICCUPS:192-210).  By default a chromosome\'s tiles '
-                            'are laid out for the width at which the widening of the chromosomes before it stopped, and its E / p / q '
-                            'values can differ in the 14th digit with what was scored before it (coordinates and counts never do); '
-                            'costs ~20-30 %% of the kernel time.')
+                       help='The default since round 5, kept as a flag: the output does not depend on the order of the chromosomes, on how '
+                            'they are batched or on --nproc / the number of GPUs (like the reference, whose result is independent of its '
+                            'map order, scripts/pyHICCUPS:192-210).  A chromosome\'s tiles are laid out for the width at which its OWN '
+                            'widening stops; one that ran under another layout - taken over from the chromosomes before it - is computed '
+                            'once more.')
+    group.add_argument('--history-dependent', action='store_true',
+                       help='No second pass, and the far field\'s lean tiles: a chromosome keeps the tile layout it inherited from the '
+                            'chromosomes scored before it, and its E / p / q values can differ in the 14th digit between runs that order or '
+                            'batch the chromosomes differently (coordinates and counts never do).  The fastest mode where the GPU is the '
+                            'bottleneck.')
 
 
 def _hiccups_parser():
@@ -219,13 +223,13 @@ def _score_queue(args_dict, mode, queue, device, shared=False):
     import queue as _queue
     import threading
     ctx = _lib.default_context(device)
-    # every run starts without memory of the chromosomes an earlier run in this process scored; --deterministic: the plan's
-    # own tile geometry for every chromosome (the record bound stays: it never touches a value)
+    # every run starts without memory of the chromosomes an earlier run in this process scored
     ctx.set_option('reset_hints', 1)
-    if args_dict.get('deterministic'):
-        ctx.set_option('spec_halo', 0)
-    elif 'HPK_SPEC_HALO' not in os.environ:         # (the cached context may come from a --deterministic run; the environment's choice stands)
-        ctx.set_option('spec_halo', 1)
+    if args_dict.get('history_dependent') and not args_dict.get('deterministic'):
+        if 'HPK_SPEC_HALO' not in os.environ:       # (the environment's choice stands)
+            ctx.set_option('spec_halo', 1)
+    else:
+        ctx.set_option('spec_halo', 2)              # every chromosome under the halo of its own frozen width (hpk.h: spec_halo)
     depth = ctx.pipeline_depth
     pending, out = collections.deque(), {}
 
@@ -467,11 +471,11 @@ def _run(mode, argv):
     a = vars(args)
     rank, world, local = parallel.dist_env()
     logger.info('Calling Peaks ...')
-    logger.info('Tile geometry: {0}'.format('deterministic (the plan\'s own halo for every chromosome: results independent of '
-                                            'chromosome order, batching and the number of workers)' if args.deterministic else
-                                            'adaptive (halo = the width at which the widening of the chromosomes scored before '
-                                            'stopped: E / p / q can differ in the 14th digit between runs that order or batch the '
-                                            'chromosomes differently; --deterministic switches it off)'))
+    logger.info('Tile geometry: {0}'.format('inherited from the chromosomes scored before, no second pass (E / p / q can differ in the 14th '
+                                            'digit between runs that order or batch the chromosomes differently)'
+                                            if args.history_dependent and not args.deterministic else
+                                            'every chromosome under the layout of its own frozen width (results independent of chromosome '
+                                            'order, batching and the number of workers; --history-dependent skips the second pass)'))
     if world > 1:                                    # torchrun: one rank per GPU, one queue, tables gathered on rank 0
         import torch.distributed as dist
         dist.init_process_group('gloo')              # only the queue's counter and Python objects travel

@@ -133,7 +133,8 @@ struct Options {
     int spec_force = -1;
     int tr_cap = 127;           // most rows of an hpk_stencil_s output tile (A/B: 64 = the first-generation kernel's limit)
     int spec_class = 1;         // record bound per chromosome by depth class (hpk_band_class) under the batch's bound
-    int spec_halo = 1;          // tiles laid out for the record bound's halo instead of maxww's (hpk_stencil_s launches)
+    int spec_halo = 1;          // tiles laid out for the record bound's halo instead of maxww's (hpk_stencil_s launches); 2: ... and a chromosome whose
+                                // halo was not the one of its OWN frozen width is computed once more under that one (its values then depend on it alone)
     int risk_log2 = 12;
     int tile_order = 1;
     int gap_kernel = 0;
@@ -379,7 +380,7 @@ int hpk_set_option(hpk_ctx* c, const char* name, int64_t v) {
     else if (k == "surv_cap" && v >= 0) o.surv_cap = v;
     else if (k == "spec" && (v == 0 || v == 1)) o.spec = (int)v;
     else if (k == "spec_margin" && v >= 0 && v <= HPK_MAX_W) o.spec_margin = (int)v;
-    else if (k == "spec_halo" && (v == 0 || v == 1)) o.spec_halo = (int)v;
+    else if (k == "spec_halo" && v >= 0 && v <= 2) o.spec_halo = (int)v;
     else if (k == "host_threads" && v >= 1 && v <= 64) o.host_threads = (int)v;
     else if (k == "spec_surv" && (v == 0 || v == 1)) o.spec_surv = (int)v;
     else if (k == "spec_surv_margin" && v >= 0 && v <= 16) o.spec_surv_margin = (int)v;
@@ -531,6 +532,7 @@ struct BandSlot {
     size_t dense_elems = 0;
     bool redone = false, overflowed = false, finished = false, rescored = false;
     int cls = -1;                       // depth class hpk_band_class put the band in (-1: not classified)
+    bool canon_done = false;            // spec_halo = 2: computed once more under the halo of its own frozen width
     bool rest_fetched = false;          // the survivors beyond the inline head already sit in `rest` (overflow rerun)
     HpkSurv* rest = nullptr;            // ... in the lane's pinned arena (Lane::h_rest)
     int status = HPK_OK;
@@ -549,7 +551,8 @@ struct hpk_job {
                                         // hpk_band_class) | of a chromosome computed once more on its own: the plan's
     int nsets = 0, rounds_eff = 0, gmax = 0, tr_cap = 127;
     bool sums = false, dense = false, do_score = true, phases = false, simple = false, use_s = false, balf64 = false,
-         time_stencil = true, use_class = false, use_lean = false;
+         time_stencil = true, use_class = false, use_lean = false,
+         canon = false;                 // spec_halo = 2: every chromosome ends up under the halo of its own frozen width (collect_impl)
     size_t max_zero = 0, max_head = 0;
     signed char class_tab[HPK_NCLASS];  // the depth classes' widths as uploaded for this batch (source of an asynchronous copy: lives with the job)
     double t_begin = 0.0;
@@ -718,9 +721,12 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     // the band's bound; those are hpk_stencil_lean's, built without their f64 plane.  Weight input, a monotone Reads matrix, records
     // under a bound (no dense outputs), and not under spec_halo = 0, whose runs promise bit-identical values whatever the
     // context scored before (which tiles are lean depends on the bound, and their few sums are formed cell by cell).
-    const bool lean_job = opt.lean && opt.lean_max > 0 && opt.spec_halo && j->simple && j->do_score && !dense && !j->balf64 && wg_all != 255;
+    const bool lean_job = opt.lean && opt.lean_max > 0 && opt.spec_halo == 1 && j->simple && j->do_score && !dense && !j->balf64 && wg_all != 255;
     std::vector<HpkGeo> geos{GS, GF};
     if (band_halo) for (int Wh = std::max((int)plan.wmin, 4); Wh < GS.W; ++Wh) geos.push_back(geo_of(Wh));
+    // (spec_halo = 2: a chromosome may be computed once more under the halo of any width it can freeze at)
+    j->canon = opt.spec_halo == 2 && j->simple && j->do_score && !dense && wg_all != 255;
+    if (j->canon) for (int Wh = std::max((int)plan.wmin, 4); Wh < GF.W; ++Wh) geos.push_back(geo_of(Wh));
     const int hbins = (opt.rounds <= -2) ? hpk_score_hist_bins((plan.mode == HPK_MODE_BHFDR) ? 1 : 2 * plan.npairs, plan.mode == HPK_MODE_BHFDR) : 0;
     // ---- geometry, sizes and offsets of every band's slices
     const int TR = GS.TR, TC = GS.TC, J_ = GS.J, tilecap = GS.tilecap;
@@ -1362,6 +1368,33 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
                 if (rc != HPK_OK) return rc;
                 again = true;
                 continue;
+            }
+            if (j->canon && er == 0 && !s.canon_done) {
+                // (after the rule above: the frozen width is the chromosome's true one from here on)
+                // Values that depend on the chromosome alone: the tiles' halo decides the rounding of the box sums, so the halo has to
+                // be a function of the chromosome - the one of the width its own widening froze at (which no halo changes) -, not of
+                // what the context scored before.  A chromosome that ran under another one is computed once more, on its own, under
+                // that one, with a record for every candidate resolved up to that width.
+                const int hc = std::min((int)j->gf.W, std::max(std::max((int)fz, (int)plan.wmin), 4));
+                if (s.d.W != hc) {
+                    const HpkGeo g = hpk_geo_of(hc, plan.W, plan.D, plan.mw, j->tr_cap);
+                    s.d.wguess = hc >= j->gf.W ? plan.W : std::min((int)plan.W, std::max((int)fz, (int)plan.wmin));
+                    s.d.W = g.W; s.d.Dg = g.Dg; s.d.TR = g.TR; s.d.TC = g.TC; s.d.J = g.J; s.d.tilecap = g.tilecap;
+                    s.ntiles = ((s.n + g.TR - 1) / g.TR) * g.J;
+                    s.d.ntiles = s.ntiles; s.d.chunk = (s.ntiles + 7) / 8; s.d.rec_stride = (int64_t)s.ntiles * g.tilecap;
+                    s.d.lean_cj = 0x7fffffff;
+                    s.redone = true; s.canon_done = true;
+                    c->spec_reruns += 1;
+                    HpkBandDesc* hd = static_cast<HpkBandDesc*>(L.h_desc) + nb + b;
+                    *hd = s.d;
+                    hd->k0 = 0; hd->score_wgs = j->gmax;
+                    HIPCHK(c, hipMemcpyAsync(lane_desc(L, j, b, true), hd, sizeof(HpkBandDesc), hipMemcpyHostToDevice, c->stream));
+                    HIPCHK(c, hipMemsetAsync(s.d.small, 0, s.zero_bytes, c->stream));
+                    int rc = launch_compute(c, j, b, 1, true, true, false);
+                    if (rc != HPK_OK) return rc;
+                    again = true;
+                    continue;
+                }
             }
             if (c->opt.host_prof) std::fprintf(stderr, "[hpk host] band %d specfail %u tbin %d %d %d\n", b, *reinterpret_cast<const unsigned*>(hsmall + HPK_OFF_SPECFAIL), hsmall[HPK_OFF_TBIN + 1], hsmall[HPK_OFF_TBIN + 2], hsmall[HPK_OFF_TBIN + HPK_NB + 2]);
             if (*reinterpret_cast<const unsigned*>(hsmall + HPK_OFF_SPECFAIL) != 0u && !s.rescored) {

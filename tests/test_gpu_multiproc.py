@@ -5,8 +5,8 @@
   * `torchrun --nproc-per-node 2 scripts/pyHICCUPS ... --device 0`: two ranks, the queue's counter in the c10d store, tables
     gathered over gloo,
   * `bench.py` with HPK_BENCH_FORCE_DIST=1 (RCCL init, all-reduce and barrier with one rank) and as two torchrun ranks on one GPU,
-  * --deterministic: byte-identical text whatever the chromosome order, the batching and the number of workers (the
-    reference's output does not depend on its map order, scripts/pyHICCUPS:192-210); without it coordinates and counts
+  * the default (spec_halo = 2; formerly --deterministic): byte-identical text whatever the chromosome order, the batching and the number of workers (the
+    reference's output does not depend on its map order, scripts/pyHICCUPS:192-210); under --history-dependent coordinates and counts
     are identical and the '%.3g' fields flip next to never - the measured rate is asserted to stay below 1 in 500.
 """
 import json
@@ -70,7 +70,7 @@ def test_deterministic_mode_is_order_and_batch_independent(bands, tmp_path, monk
     def run(tag, perm, group, det, nproc=1):
         monkeypatch.setattr(cli, 'GROUP_CHROMS', group)
         out = str(tmp_path / ('%s_%d_%d_%d.bedpe' % (tag, group, det, nproc)))
-        extra = (['--deterministic'] if det else []) + (['--nproc', str(nproc)] if nproc > 1 else [])
+        extra = ([] if det else ['--history-dependent']) + (['--nproc', str(nproc)] if nproc > 1 else [])     # (deterministic: the default)
         assert cli.main_hiccups(_argv(out, arcs[tag], log, extra)) == 0
         return _by_band(out, perm)
 
@@ -89,9 +89,9 @@ def test_deterministic_mode_is_order_and_batch_independent(bands, tmp_path, monk
     monkeypatch.setenv('HPK_CLI_SHARE_GPU', '1')
     assert run('b', perm_b, 2, True, nproc=2) == ref
     monkeypatch.delenv('HPK_CLI_SHARE_GPU')
-    assert 'deterministic' in open(log).read()
-    # the default (adaptive halo): same pixels and counts; statistics equal to rounding, the printed '%.3g' fields flip
-    # next to never
+    assert 'independent of chromosome order' in open(log).read()
+    # --history-dependent (the layout a chromosome inherits, no second pass): same pixels and counts; statistics equal to rounding,
+    # the printed '%.3g' fields flip next to never
     fields = flips = 0
     for tag, perm, group in (('a', perm_a, 8), ('b', perm_b, 8), ('b', perm_b, 1)):
         got = run(tag, perm, group, False)

@@ -680,6 +680,63 @@ def test_critical_counts_drop_no_p_value_at_or_below_sig(mode, sig):
         c.close()
 
 
+@pytest.mark.parametrize('mode', ['hiccups', 'union', 'bhfdr'])
+def test_own_frozen_width_layout_makes_values_independent_of_history(mode):
+    """Option spec_halo = 2 (what the command lines run under): a chromosome's tiles end up laid out for the width at which its OWN
+    widening stopped - if it ran under another layout, inherited from the chromosomes before it (or the plan's, in a fresh
+    context), it is computed once more -, so its E / p / q are a function of the chromosome alone: bit-identical alone in a fresh
+    context, after chromosomes of other depths, and in batches of any order and size.  Chromosomes that freeze at different
+    widths; hpk_result::halo_w is the frozen width's own halo everywhere."""
+    from hicpeaks_amd import synthetic
+    res, maxapart, maxww = 10000, 2000000, 10
+    num = maxapart // res + maxww + 1
+    if mode == 'hiccups':
+        prm = _lib.make_params(_lib.MODE_HICCUPS, [2], [5], maxww, 0.1, maxapart, res, 16, 0)
+    elif mode == 'union':
+        prm = _lib.make_params(_lib.MODE_HICCUPS, [1, 2, 4], [3, 5, 7], maxww, 0.1, maxapart, res, 16, 0)
+    else:
+        prm = _lib.make_params(_lib.MODE_BHFDR, [2], [5], maxww, 0.05, maxapart, res, 16, 0)
+    bands = []
+    for k, (n, depth) in enumerate(((2600, 12.0), (2300, 150.0), (3100, 40.0), (1800, 5.0), (2500, 80.0))):
+        raw, weight, _ = synthetic.synth_band(n, num, depth=depth, nloops=25, seed=61 + k, structure={} if k % 2 else None)
+        bands.append((raw.astype(np.float32), weight))
+
+    def fresh():
+        c = _lib.Context(0)
+        c.set_option('spec_halo', 2)
+        return c
+
+    want = []
+    for r, w in bands:                          # every chromosome alone in a context of its own
+        c = fresh()
+        try:
+            want.append(c.score_host(r, None, None, None, prm, weight=w))
+        finally:
+            c.close()
+    mw = min(prm.ww[i] for i in range(prm.npairs))
+    for R in want:
+        assert R.halo_w == min(maxww, max(R.frozen_w, mw, 4)), (R.halo_w, R.frozen_w)
+    assert len({R.frozen_w for R in want}) >= 2                                 # (different layouts are in play)
+    c = fresh()
+    try:
+        redone = 0
+        for order in ((0, 1, 2, 3, 4), (4, 3, 2, 1, 0), (1, 1, 3, 0, 2, 4, 1)):
+            for k in order:                     # one after the other: each under what the ones before left behind
+                got = c.score_host(bands[k][0], None, None, None, prm, weight=bands[k][1])
+                _same_result(got, want[k])
+                assert got.halo_w == want[k].halo_w
+                redone += int(got.redone)
+        for order in ((0, 1, 2, 3, 4), (3, 1, 4, 0, 2, 1, 3, 0, 2, 4), (2, 2, 2)):
+            items = [dict(raw=bands[k][0], weight=bands[k][1]) for k in order]
+            for got, k in zip(c.submit_batch_host(items, prm).results(), order):
+                _same_result(got, want[k])
+                assert got.halo_w == want[k].halo_w
+                redone += int(got.redone)
+        assert redone > 0                       # (the second pass did fire: the orders above mix depths)
+    finally:
+        c.close()
+
+
 def test_survivors_beyond_the_inline_heads_in_a_batch():
     """Maps with structure leave tens of thousands of survivors per chromosome: beyond the 4 096 that travel with a chromosome's
     counters they are copied on their own - into the lane's pinned arena, for all chromosomes of a batch at once (the threaded host
