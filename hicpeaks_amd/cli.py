@@ -44,7 +44,7 @@ def _add_deterministic(group):
                             'widening stops; one that ran under another layout - taken over from the chromosomes before it - is computed '
                             'once more.')
     group.add_argument('--history-dependent', action='store_true',
-                       help='No second pass, and the far field\'s lean tiles: a chromosome keeps the tile layout it inherited from the '
+                       help='No second pass: a chromosome keeps the tile layout it inherited from the '
                             'chromosomes scored before it, and its E / p / q values can differ in the 14th digit between runs that order or '
                             'batch the chromosomes differently (coordinates and counts never do).  The fastest mode where the GPU is the '
                             'bottleneck.')

@@ -553,6 +553,7 @@ struct hpk_job {
     bool sums = false, dense = false, do_score = true, phases = false, simple = false, use_s = false, balf64 = false,
          time_stencil = true, use_class = false, use_lean = false,
          canon = false;                 // spec_halo = 2: every chromosome ends up under the halo of its own frozen width (collect_impl)
+    HpkClassArgs cargs;                 // hpk_band_class as launched for the batch (use_class || use_lean): the second pass of spec_halo = 2 runs it again, per chromosome
     size_t max_zero = 0, max_head = 0;
     signed char class_tab[HPK_NCLASS];  // the depth classes' widths as uploaded for this batch (source of an asynchronous copy: lives with the job)
     double t_begin = 0.0;
@@ -568,7 +569,7 @@ HpkBandDesc* lane_desc(Lane& L, const hpk_job* j, int b, bool solo) {
 
 // the kernels of bands [b0, b0 + nbl) of a job whose counter blocks are zero: stencil (+ the freeze decision), scoring,
 // cut, copy-back.  solo: band b0 alone, through its second descriptor (records for every resolved candidate).
-int launch_compute(hpk_ctx* c, hpk_job* j, int b0, int nbl, bool solo, bool with_stencil, bool all_survivors = false) {
+int launch_compute(hpk_ctx* c, hpk_job* j, int b0, int nbl, bool solo, bool with_stencil, bool all_survivors = false, bool solo_lean = false) {
     Lane& L = c->lane[j->lane];
     const HpkDevPlan& plan = L.plan_host;
     const HpkBandDesc* dd = lane_desc(L, j, b0, solo);
@@ -580,8 +581,8 @@ int launch_compute(hpk_ctx* c, hpk_job* j, int b0, int nbl, bool solo, bool with
             int kall = 0;
             for (int b = b0; b < b0 + nbl; ++b) kall += j->bands[b].d.chunk;
             sa.grid = std::max(8, std::min((c->cus / 8) * 8, kall * 8));
-            if (solo) { sa.lean_max = 0; sa.redoq = nullptr; }      // (a chromosome on its own again: every tile in full)
-            else if (sa.redoq) HIPCHK(c, hipMemsetAsync(sa.redoq, 0, 16, c->stream));
+            if (solo && !solo_lean) { sa.lean_max = 0; sa.redoq = nullptr; }      // (a chromosome on its own again: every tile in full;
+            else if (sa.redoq) HIPCHK(c, hipMemsetAsync(sa.redoq, 0, 16, c->stream));    //  solo_lean: the second pass of spec_halo = 2, like a batch of one)
             hpk_launch_stencil_batch(sa, dd, j->balf64, c->cus, c->stream);
             HIPCHK(c, hipGetLastError());
         }
@@ -721,7 +722,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     // the band's bound; those are hpk_stencil_lean's, built without their f64 plane.  Weight input, a monotone Reads matrix, records
     // under a bound (no dense outputs), and not under spec_halo = 0, whose runs promise bit-identical values whatever the
     // context scored before (which tiles are lean depends on the bound, and their few sums are formed cell by cell).
-    const bool lean_job = opt.lean && opt.lean_max > 0 && opt.spec_halo == 1 && j->simple && j->do_score && !dense && !j->balf64 && wg_all != 255;
+    const bool lean_job = opt.lean && opt.lean_max > 0 && opt.spec_halo != 0 && j->simple && j->do_score && !dense && !j->balf64 && wg_all != 255;
     std::vector<HpkGeo> geos{GS, GF};
     if (band_halo) for (int Wh = std::max((int)plan.wmin, 4); Wh < GS.W; ++Wh) geos.push_back(geo_of(Wh));
     // (spec_halo = 2: a chromosome may be computed once more under the halo of any width it can freeze at)
@@ -987,6 +988,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         ca.p0 = plan.reads_p0; ca.minr = plan.min_reads;
         ca.lean_frac = (float)opt.lean_frac_pct / 100.f;
         ca.lean_share = opt.lean_share_pct;
+        j->cargs = ca;
         hpk_launch_band_class(L.desc.as<HpkBandDesc>(), nb, ca, L.up);
         HIPCHK(c, hipGetLastError());
         if (opt.host_prof >= 2 && j->use_lean) {      // debug: the non-zero-weight mask of band 0 against its weights
@@ -1390,7 +1392,21 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
                     hd->k0 = 0; hd->score_wgs = j->gmax;
                     HIPCHK(c, hipMemcpyAsync(lane_desc(L, j, b, true), hd, sizeof(HpkBandDesc), hipMemcpyHostToDevice, c->stream));
                     HIPCHK(c, hipMemsetAsync(s.d.small, 0, s.zero_bytes, c->stream));
-                    int rc = launch_compute(c, j, b, 1, true, true, false);
+                    if (j->use_lean) {
+                        // which of its tiles are lean is the chromosome's own affair too: hpk_band_class once more, on this band, with
+                        // its bound forced to the frozen width (the layout is set above), then the lean kernel and the queue pass
+                        // like a batch of one
+                        signed char forced[HPK_NCLASS];
+                        std::memset(forced, (int)(signed char)s.d.wguess, sizeof(forced));
+                        HIPCHK(c, L.classtab.reserve(HPK_NCLASS));
+                        HIPCHK(c, hipMemcpyAsync(L.classtab.p, forced, HPK_NCLASS, hipMemcpyHostToDevice, c->stream));   // (pageable source: staged before the call returns)
+                        HpkClassArgs ca = j->cargs;
+                        ca.table = L.classtab.as<signed char>();
+                        ca.wg_all = s.d.wguess; ca.margin = 0; ca.halo = 0; ca.lean = 1;
+                        hpk_launch_band_class(lane_desc(L, j, b, true), 1, ca, c->stream);
+                        HIPCHK(c, hipGetLastError());
+                    }
+                    int rc = launch_compute(c, j, b, 1, true, true, false, j->use_lean);
                     if (rc != HPK_OK) return rc;
                     again = true;
                     continue;

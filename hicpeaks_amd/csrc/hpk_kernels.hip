@@ -1908,7 +1908,10 @@ __global__ void __launch_bounds__(1024) hpk_band_class(HpkBandDesc* __restrict__
     const int gTR = bd->TR, gTC = bd->TC, gJ = bd->J;      // (thread 0's writes: behind the barrier)
     int lean_cj = 0x7fffffff;
     if (a.lean && !tiny_w && gptr(bd->weight) && bd->off_wnz) {
-        const int wg = wg_s;
+        // (at the width of the band's halo - its bound, or min(ww) / 4 where those are wider: which tiles are lean is then a function of
+        // the band and its tile layout alone, what spec_halo = 2 needs)
+        int wg = wg_s > a.wmin ? wg_s : a.wmin;
+        wg = wg > 4 ? wg : 4;
         // mean count of a pixel on diagonal k: S[k] over the sampled rows that hold it
         auto mu = [&](int k) -> double {
             if (k < 0) return 0.0;                  // below the main diagonal: not stored, not counted (callers.py:50-96)

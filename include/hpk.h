@@ -242,7 +242,7 @@ int  hpk_collect_batch(hpk_ctx* ctx, hpk_job* job, hpk_result** outs, int32_t* s
  * into in the chromosomes before, minus "spec_surv_margin" bins - verified, hpk_result::redone bit 1), "spec_surv_force" (tests),
  * "host_threads" (threads of a batch's host half), "spec_halo" (1 [default]: a chromosome's tiles are laid out for the halo of the bound it inherits; 0: tiles always
  * under maxww's halo - runs of one chromosome are then bit-identical whatever the bound; 2: as 1, and a chromosome whose halo was not the one of the
- * width its OWN widening froze at is computed once more under that one (hpk_result::redone bit 0), no lean tiles: E / p / q are a function of the
+ * width its OWN widening froze at is computed once more under that one, lean tiles included (hpk_result::redone bit 0): E / p / q are a function of the
  * chromosome alone - what the command lines run under), "risk_log2" (exact-fallback threshold 2^-x), "tile_order", "gap_kernel" (1: gap rows by the row kernel),
  * "score_div" (tiles per scoring workgroup of a batch), "dbg_stop" (profiling ablation), "lean" (1 [default]: tiles of the column chunks
  * whose mean Reads stays below "lean_frac_pct" % of min_local_reads - sampled per chromosome on the device - are built without their

@@ -680,7 +680,7 @@ def test_critical_counts_drop_no_p_value_at_or_below_sig(mode, sig):
         c.close()
 
 
-@pytest.mark.parametrize('mode', ['hiccups', 'union', 'bhfdr'])
+@pytest.mark.parametrize('mode', ['hiccups', 'union', 'bhfdr', 'wide'])
 def test_own_frozen_width_layout_makes_values_independent_of_history(mode):
     """Option spec_halo = 2 (what the command lines run under): a chromosome's tiles end up laid out for the width at which its OWN
     widening stopped - if it ran under another layout, inherited from the chromosomes before it (or the plan's, in a fresh
@@ -689,15 +689,22 @@ def test_own_frozen_width_layout_makes_values_independent_of_history(mode):
     widths; hpk_result::halo_w is the frozen width's own halo everywhere."""
     from hicpeaks_amd import synthetic
     res, maxapart, maxww = 10000, 2000000, 10
+    if mode == 'wide':                          # a 2 011-diagonal band: most of its tiles are lean, in either pass
+        res, maxapart = 5000, 10000000
     num = maxapart // res + maxww + 1
     if mode == 'hiccups':
         prm = _lib.make_params(_lib.MODE_HICCUPS, [2], [5], maxww, 0.1, maxapart, res, 16, 0)
+    elif mode == 'wide':
+        prm = _lib.make_params(_lib.MODE_HICCUPS, [4], [7], maxww, 0.05, maxapart, res, 16, 0)
     elif mode == 'union':
         prm = _lib.make_params(_lib.MODE_HICCUPS, [1, 2, 4], [3, 5, 7], maxww, 0.1, maxapart, res, 16, 0)
     else:
         prm = _lib.make_params(_lib.MODE_BHFDR, [2], [5], maxww, 0.05, maxapart, res, 16, 0)
     bands = []
-    for k, (n, depth) in enumerate(((2600, 12.0), (2300, 150.0), (3100, 40.0), (1800, 5.0), (2500, 80.0))):
+    shapes = ((2600, 12.0), (2300, 150.0), (3100, 40.0), (1800, 5.0), (2500, 80.0))
+    if mode == 'wide':
+        shapes = ((3300, 18.0), (3000, 60.0), (3600, 6.0), (2800, 150.0), (3100, 30.0))
+    for k, (n, depth) in enumerate(shapes):
         raw, weight, _ = synthetic.synth_band(n, num, depth=depth, nloops=25, seed=61 + k, structure={} if k % 2 else None)
         bands.append((raw.astype(np.float32), weight))
 
@@ -733,6 +740,8 @@ def test_own_frozen_width_layout_makes_values_independent_of_history(mode):
                 assert got.halo_w == want[k].halo_w
                 redone += int(got.redone)
         assert redone > 0                       # (the second pass did fire: the orders above mix depths)
+        if mode == 'wide':                      # lean tiles in first and second passes alike
+            assert sum(R.lean_tiles > R.tiles // 4 for R in want) >= 3, [(R.lean_tiles, R.tiles) for R in want]
     finally:
         c.close()
 
