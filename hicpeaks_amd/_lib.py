@@ -606,7 +606,12 @@ _default_ctx = {}
 
 
 def default_context(device=0):
-    """Process-wide context per device (the callers are invoked once per chromosome)."""
+    """Process-wide context per device (the callers are invoked once per chromosome) - what `callers.hiccups` / `bhfdr` and the
+    command lines score on.  It runs under spec_halo = 2 (include/hpk.h): a chromosome's E / p / q are a function of the chromosome
+    alone, whatever was scored on the context before it - like the reference's functions, whose results do not depend on the calls
+    made before (HPK_SPEC_HALO in the environment overrides; a Context() of one's own starts with the library's default, 1)."""
     if device not in _default_ctx:
         _default_ctx[device] = Context(device)
+        if 'HPK_SPEC_HALO' not in os.environ:
+            _default_ctx[device].set_option('spec_halo', 2)
     return _default_ctx[device]
