@@ -533,6 +533,7 @@ struct BandSlot {
     bool redone = false, overflowed = false, finished = false, rescored = false;
     int cls = -1;                       // depth class hpk_band_class put the band in (-1: not classified)
     bool canon_done = false;            // spec_halo = 2: computed once more under the halo of its own frozen width
+    signed char forced_tab[HPK_NCLASS]; // ... the depth-class table of that pass: its frozen width for every class
     bool rest_fetched = false;          // the survivors beyond the inline head already sit in `rest` (overflow rerun)
     HpkSurv* rest = nullptr;            // ... in the lane's pinned arena (Lane::h_rest)
     int status = HPK_OK;
@@ -1396,10 +1397,9 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
                         // which of its tiles are lean is the chromosome's own affair too: hpk_band_class once more, on this band, with
                         // its bound forced to the frozen width (the layout is set above), then the lean kernel and the queue pass
                         // like a batch of one
-                        signed char forced[HPK_NCLASS];
-                        std::memset(forced, (int)(signed char)s.d.wguess, sizeof(forced));
+                        std::memset(s.forced_tab, (int)(signed char)s.d.wguess, sizeof(s.forced_tab));      // (source of an asynchronous copy: lives with the job)
                         HIPCHK(c, L.classtab.reserve(HPK_NCLASS));
-                        HIPCHK(c, hipMemcpyAsync(L.classtab.p, forced, HPK_NCLASS, hipMemcpyHostToDevice, c->stream));   // (pageable source: staged before the call returns)
+                        HIPCHK(c, hipMemcpyAsync(L.classtab.p, s.forced_tab, HPK_NCLASS, hipMemcpyHostToDevice, c->stream));
                         HpkClassArgs ca = j->cargs;
                         ca.table = L.classtab.as<signed char>();
                         ca.wg_all = s.d.wguess; ca.margin = 0; ca.halo = 0; ca.lean = 1;
