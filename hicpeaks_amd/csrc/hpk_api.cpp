@@ -138,7 +138,7 @@ struct Options {
     int risk_log2 = 12;
     int tile_order = 1;
     int gap_kernel = 0;
-    int score_div = 8;          // tiles per scoring workgroup of a batch
+    int score_div = 6;          // tiles per scoring workgroup of a batch (4 ... 128 measured: profiles/r05_score_div.txt)
     int dbg_stop = 0;
     int host_prof = 0;
     int spec_surv = 1;          // survivor records only up to the cut's histogram bin of the chromosomes before (minus spec_surv_margin bins)
