@@ -2024,9 +2024,13 @@ __global__ void __launch_bounds__(64) hpk_kcrit(const double* __restrict__ ptab,
     if (threadIdx.x == 0) { kcrit[0] = 0; kcrit[HPK_NB_TAB + 1] = 0; }
     if (ch > HPK_NB_TAB) return;
     const int base = off[ch], len = off[ch + 1] - base;
-    int k = 0;
-    while (k < len && !(ptab[base + k] <= sig)) ++k;
-    kcrit[ch] = k;
+    // (bisection: the entries fall with k - a walk from 0 was up to 33 000 dependent loads on one thread, 5.8 ms of the first call with a sig)
+    int lo = -1, hi = len;                   // entry lo > sig (or lo = -1), entry hi <= sig (or hi = len: none is)
+    while (hi - lo > 1) {
+        const int mid = lo + (hi - lo) / 2;
+        if (ptab[base + mid] <= sig) hi = mid; else lo = mid;
+    }
+    kcrit[ch] = hi;
 }
 
 // bhfdr scores every pixel at its own lambda = E, so its critical counts sit on a grid over lambda (HPK_KCL_*): kcrit[g] = the
