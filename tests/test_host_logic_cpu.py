@@ -157,3 +157,25 @@ def test_gap_keep_matches_loop():
             hi = (v + mw) if (v + mw) < n else (n - 1)
             reg |= set(range(lo, hi))
         assert keep[t] == (not (reg & gaps))
+
+
+def test_default_context_runs_under_the_own_frozen_width_layout(monkeypatch):
+    """The process-wide context the drop-in functions and the command lines score on is switched to spec_halo = 2 when it is made
+    (values that depend on the chromosome alone); HPK_SPEC_HALO in the environment is left standing; one context per device."""
+    from hicpeaks_amd import _lib
+    calls = []
+
+    class Fake(object):
+        def __init__(self, device):
+            self.device = device
+
+        def set_option(self, k, v):
+            calls.append((self.device, k, v))
+
+    monkeypatch.setattr(_lib, 'Context', Fake)
+    monkeypatch.setattr(_lib, '_default_ctx', {})
+    monkeypatch.delenv('HPK_SPEC_HALO', raising=False)
+    c = _lib.default_context(3)
+    assert calls == [(3, 'spec_halo', 2)] and _lib.default_context(3) is c and len(calls) == 1
+    monkeypatch.setenv('HPK_SPEC_HALO', '1')
+    assert _lib.default_context(4).device == 4 and len(calls) == 1
