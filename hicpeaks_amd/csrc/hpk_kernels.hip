@@ -425,6 +425,25 @@ struct QueueWalk {
     __device__ __forceinline__ unsigned bword() const { return qband | HPK_BW_REDO; }
 };
 
+// The walk's state parked in LDS between the steps of the one wave that walks (words; the loads come back as scalars)
+template <class T>
+__device__ __forceinline__ void walk_park(unsigned* __restrict__ l, const T& t, int lane) {
+    static_assert(sizeof(T) % 4 == 0, "walk state in words");
+    unsigned w[sizeof(T) / 4];
+    __builtin_memcpy(w, &t, sizeof(T));
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(T) / 4); ++i) l[i] = w[i];
+    }
+}
+template <class T>
+__device__ __forceinline__ void walk_take(const unsigned* __restrict__ l, T& t) {
+    unsigned w[sizeof(T) / 4];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); ++i) w[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)l[i]);
+    __builtin_memcpy(&t, w, sizeof(T));
+}
+
 template <bool BALF64, bool SINGLE, bool QUEUE>
 __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const HpkBandDesc* __restrict__ bands) {
     constexpr int NW = 16;
@@ -436,8 +455,10 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     double* __restrict__ Sc = reinterpret_cast<double*>(smem);
     unsigned* __restrict__ Sp = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 8);
     unsigned* __restrict__ lst = reinterpret_cast<unsigned*>(smem + (size_t)LR * LC * 12);      // [HPK_TLIST] tile-wide candidate list
-    unsigned* __restrict__ tcount = lst + HPK_TLIST;                  // [2] entries in the list, tiles alternate
-    const unsigned lds0 = (unsigned)(uintptr_t)(lds_u8_t*)smem;        // LDS address of the tables (phase 3 reads by address)
+    unsigned* __restrict__ tcount = lst + HPK_TLIST;       // [2] entries in the list, tiles alternate
+    // (the dynamic LDS of a kernel without static LDS starts at address 0: the addresses phase 3 reads by are immediates)
+    constexpr unsigned lds0 = 0u;
+    if ((unsigned)(uintptr_t)(lds_u8_t*)smem != 0u) __builtin_trap();
     // the widening plan as the batches read it: per step 8 words {w0 (HpkDevPlan::packed[0]), four words of box terms},
     // then step_of[slot][width] as bytes
     unsigned* __restrict__ pl = tcount + 32;                          // [HPK_MAX_STEPS][8]
@@ -445,6 +466,8 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     double* __restrict__ wct = reinterpret_cast<double*>(stepof + HPK_KSLOTS * 32);      // [LC] column weights of the tile (NaN -> 0)
     double* __restrict__ ctot = wct + LC;                              // [3][LC] phase 2: totals of the f64 plane's row chunks
     unsigned* __restrict__ utot = reinterpret_cast<unsigned*>(ctot + 3 * LC);            // [LC] ... of the packed plane's first chunk
+
+    unsigned* __restrict__ twl = utot + LC;                      // [16] the tile walk's state between wave 0's steps
 
     const int lane_k = threadIdx.x & 63;
     const int wave_k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -516,14 +539,19 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     unsigned* __restrict__ tseq = tcount + 8;
     unsigned* __restrict__ tband = tcount + 12;
     // (QUEUE: the launch over the tiles hpk_stencil_lean gave up)
-    typename std::conditional<QUEUE, QueueWalk, TileWalk<0>>::type tw;
-    tw.init(a, bands);
-    bool have = !tw.done;
-    int rb = tw.rbk, cj = tw.cj(a);
-    unsigned bw = tw.bword();           // band (low 16 bits) and flush segment / redo mark of the current tile
-    if (wave_k == 0) {
-        tw.step(a, bands);
-        if (lane_k == 0) { tseq[0] = tw.word(a); tband[0] = tw.bword(); }
+    typedef typename std::conditional<QUEUE, QueueWalk, TileWalk<0>>::type walk_t;
+    bool have;
+    int rb, cj;
+    unsigned bw;                        // band (low 16 bits) and flush segment / redo mark of the current tile
+    {
+        walk_t tw;
+        tw.init(a, bands);
+        have = !tw.done; rb = tw.rbk; cj = tw.cj(a); bw = tw.bword();
+        if (wave_k == 0) {
+            tw.step(a, bands);
+            if (lane_k == 0) { tseq[0] = tw.word(a); tband[0] = tw.bword(); }
+            walk_park(twl, tw, lane_k);
+        }
     }
     __syncthreads();                    // plan, counters and the second tile in LDS
     unsigned tnext = lds_u32(lds0 + (unsigned)((unsigned char*)tseq - smem));
@@ -611,8 +639,11 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     const bool pre_next = have_next && bw_next == cbw;         // the next tile is this band's: its rows are prefetched
     const int rb_next = (int)((unsigned)tn >> 8), cj_next = tn & 255;
     if (wave == 0) {                    // the tile after the next one, for everybody's next round
+        walk_t tw;
+        walk_take(twl, tw);
         tw.step(a, bands);
         if (lane == 0) { tseq[tpar ^ 1] = tw.word(a); tband[tpar ^ 1] = tw.bword(); }
+        walk_park(twl, tw, lane);
     }
     tpar ^= 1;
     if (empty_tile) {
@@ -1281,7 +1312,10 @@ __global__ void __launch_bounds__(1024) hpk_stencil_lean(HpkStencilArgs a, const
     unsigned* __restrict__ tcount = utot3 + 3 * LC;                                     // [32] counters, walk words, column-weight mask
     unsigned char* __restrict__ stepof = reinterpret_cast<unsigned char*>(tcount + 32);   // [HPK_KSLOTS][32]
     unsigned char* __restrict__ stage0 = stepof + HPK_KSLOTS * 32;                        // [2][HPK_LST_BYTES] the next tiles' rows on their way (tile_issue_lean)
-    const unsigned lds0 = (unsigned)(uintptr_t)(lds_u8_t*)smem;
+    unsigned* __restrict__ twl = reinterpret_cast<unsigned*>(stage0 + 2 * HPK_LST_BYTES);     // [16] the tile walk's state between wave 0's steps
+    // (the dynamic LDS of a kernel without static LDS starts at address 0: addresses formed from lds0 are immediates)
+    constexpr unsigned lds0 = 0u;
+    if ((unsigned)(uintptr_t)(lds_u8_t*)smem != 0u) __builtin_trap();
     unsigned* __restrict__ tflag = tcount + 16;                       // [2] the tile met more candidates that count than lean_max
     unsigned* __restrict__ tseq = tcount + 8;
     unsigned* __restrict__ tband = tcount + 12;
@@ -1320,14 +1354,18 @@ __global__ void __launch_bounds__(1024) hpk_stencil_lean(HpkStencilArgs a, const
     unsigned pend_c = 0u, pend_off = 0u, pend_rc = 0u;      // (pend_rc: the tile as the work list names it, row block << 8 | column chunk)
     int sp = 0;                         // the stage that holds the current tile's rows
     int par = 0;
-    TileWalk<1> tw;
-    tw.init(a, bands);
-    bool have = !tw.done;
-    int rb = tw.rbk, cj = tw.cj(a);
-    unsigned bw = tw.bword();
-    if (wave_k == 0) {
-        tw.step(a, bands);
-        if (lane_k == 0) { tseq[0] = tw.word(a); tband[0] = tw.bword(); }
+    bool have;
+    int rb, cj;
+    unsigned bw;
+    {
+        TileWalk<1> tw;
+        tw.init(a, bands);
+        have = !tw.done; rb = tw.rbk; cj = tw.cj(a); bw = tw.bword();
+        if (wave_k == 0) {
+            tw.step(a, bands);
+            if (lane_k == 0) { tseq[0] = tw.word(a); tband[0] = tw.bword(); }
+            walk_park(twl, tw, lane_k);
+        }
     }
     __syncthreads();
     unsigned tnext = lds_u32(lds0 + (unsigned)((unsigned char*)tseq - smem));
@@ -1397,8 +1435,11 @@ __global__ void __launch_bounds__(1024) hpk_stencil_lean(HpkStencilArgs a, const
     const bool pre_next = have_next && bw_next == cbw;         // the next tile is this band's: its rows are prefetched
     const int rb_next = (int)((unsigned)tn >> 8), cj_next = tn & 255;
     if (wave == 0) {
+        TileWalk<1> tw;
+        walk_take(twl, tw);
         tw.step(a, bands);
         if (lane == 0) { tseq[tpar ^ 1] = tw.word(a); tband[tpar ^ 1] = tw.bword(); }
+        walk_park(twl, tw, lane);
     }
     tpar ^= 1;
     if (empty_tile) {
@@ -2889,7 +2930,7 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkBandDesc* __rest
 }  // namespace
 
 // ------------------------------------------------------------------ launchers
-int hpk_stencil_s_lds_bytes() { return LR * LC * 12 + HPK_TLIST * 4 + 128 + HPK_MAX_STEPS * 32 + HPK_KSLOTS * 32 + LC * 8 * 4 + LC * 4; }
+int hpk_stencil_s_lds_bytes() { return LR * LC * 12 + HPK_TLIST * 4 + 128 + HPK_MAX_STEPS * 32 + HPK_KSLOTS * 32 + LC * 8 * 4 + LC * 4 + 64; }
 
 template <bool BALF64, bool SINGLE, bool QUEUE = false>
 static void launch_stencil_s_t(const HpkStencilArgs& a, const HpkBandDesc* d_bands, hipStream_t st) {
@@ -2909,7 +2950,7 @@ bool hpk_stencil_s_applies(const HpkGeo& g, int64_t max_ld, int32_t max_n) {
     return max_ld <= (int64_t)(1 << 21) && max_n < (1 << 27) && g.W >= 4 && g.TR * g.TC <= HPK_TLIST;
 }
 
-int hpk_stencil_lean_lds_bytes() { return LR * LC * 4 + 3 * LC * 4 + 128 + HPK_KSLOTS * 32 + 2 * HPK_LST_BYTES; }
+int hpk_stencil_lean_lds_bytes() { return LR * LC * 4 + 3 * LC * 4 + 128 + HPK_KSLOTS * 32 + 2 * HPK_LST_BYTES + 64; }
 
 template <bool SINGLE>
 static void launch_stencil_lean_t(const HpkStencilArgs& a, const HpkBandDesc* d_bands, int cus, hipStream_t st) {
