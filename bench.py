@@ -58,8 +58,15 @@ CONFIGS = {
 }
 SIG, MIN_READS = 0.05, 16
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-TIMED_EVERY = 4          # launches of the timed region whose stencil kernel is bracketed by HIP events: one in four
-BYTES_PER_PX = 20.0
+TIMED_EVERY = 4          # launches of the timed region whose stencil and scoring kernels are bracketed by HIP events: one in four
+BYTES_PER_PX = 20.0      # SURVEY.md §8-D3's convention for the >= 70 % target: 4 B read + 2 x 8 B of dense local expecteds written
+# the roof the stencil actually leans on: vector issue.  1 024 SIMDs (256 CUs x 4), a wave64 VALU instruction occupies its SIMD
+# 4 cycles (f64, DPP, packed: ~5; profiles/r02_instruction_cost.txt) - priced at 4, so the fraction is a lower bound of the issue
+# slots taken; clock: MI355X's 2.4 GHz peak engine clock (MI355X_MICROARCH.md; under load the chip runs at or below it)
+N_SIMD, VALU_CYCLES, CLOCK_GHZ = 1024, 4.0, 2.4
+FRAC_LABEL = ('frac / frac_20B_equivalent: 20 B per band pixel per pair (SURVEY 8-D3: what a kernel writing dense E_K, E_Y would move) '
+              '/ kernel time / 8 TB/s - how far the instruction stream is from the contract\'s memory floor, NOT HBM utilisation (it can '
+              'exceed 1); frac_measured: the bytes rocprofv3 counted / kernel time / 8 TB/s; roofline_valu: vector issue slots taken')
 
 
 def make_band_host(cfg, seed, n=None):
@@ -113,18 +120,32 @@ def _cpu_worker(job):
 
 def cpu_baseline_all_cores(cfg, rows):
     """Every host core at once, one process per core, each on its own `rows`-row slice: aggregate px/s with the core count
-    stated."""
+    stated.  The numpy port is bound by memory bandwidth long before the box runs out of cores (MI355X host:
+    256 logical cores; 64 processes scored twice what 256 do), so the leg runs at both counts and reports both."""
     import multiprocessing as mp
-    nproc = min(os.cpu_count() or 1, 64)
-    t0 = time.perf_counter()
-    with mp.get_context('spawn').Pool(nproc) as pool:
-        res = pool.map(_cpu_worker, [(cfg, rows, 777 + i) for i in range(nproc)])
-    wall = time.perf_counter() - t0
-    px = sum(r[0] for r in res)
-    busy = max(r[1] for r in res)
-    return dict(value=px / busy, unit='band px/s', cores=nproc, kind='port',
-                sample='%d processes x %d-row slices (%d band px in all), slowest worker %.1f s, wall incl. start-up %.1f s' % (
-                    nproc, rows, px, busy, wall))
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    nall = max(1, avail)                # every core the process may run on (round 5 capped this at 64 of the box's 256)
+    try:                                # ... as long as half the free memory holds them (a worker peaks at ~0.3 GB)
+        free_kb = [int(l.split()[1]) for l in open('/proc/meminfo') if l.startswith('MemAvailable')][0]
+        nall = max(1, min(nall, int(free_kb / 2 / (0.4 * 1024 * 1024))))
+    except Exception:
+        nall = min(nall, 64)
+    legs = []
+    for nproc in sorted(set([min(64, nall), nall])):
+        t0 = time.perf_counter()
+        with mp.get_context('spawn').Pool(nproc) as pool:
+            res = pool.map(_cpu_worker, [(cfg, rows, 777 + i) for i in range(nproc)])
+        wall = time.perf_counter() - t0
+        px = sum(r[0] for r in res)
+        busy = max(r[1] for r in res)
+        legs.append(dict(value=px / busy, unit='band px/s', cores=nproc, cores_available=os.cpu_count(), kind='port',
+                         sample='%d processes x %d-row slices (%d band px in all), slowest worker %.1f s, wall incl. start-up %.1f s' % (
+                             nproc, rows, px, busy, wall)))
+    out = dict(legs[-1])                # the all-cores leg; `best` = the faster of the two
+    out['legs'] = legs
+    out['best'] = max(legs, key=lambda l: l['value'])['value']
+    out['best_cores'] = max(legs, key=lambda l: l['value'])['cores']
+    return out
 
 
 def run_genome(args, cfg, ctx, rank, world, local, dist, emit=True, steps=None, warmup=None):
@@ -140,12 +161,16 @@ def run_genome(args, cfg, ctx, rank, world, local, dist, emit=True, steps=None, 
     num = D + cfg['maxww'] + 1
     ld = (num + 63) // 64 * 64
     sizes = synthetic.hg38_bins(res)
-    mine = parallel.lpt_partition(sizes, world)[rank]
+    parts = parallel.lpt_partition(sizes, world)
+    mine = parts[rank]
+    rank_px = [sum(band.band_pixels(sizes[c], cfg['maxapart'] // cfg['res'] + cfg['maxww'] + 1, min(cfg['ww']), cfg['maxapart'] // cfg['res'])
+                   for c in p_) * len(cfg['pw']) for p_ in parts]
     bands = []
+    gorder = sorted(sizes, key=lambda k: (-sizes[k], str(k)))       # a chromosome's band is the same whichever rank scores it
     for i, c in enumerate(mine):
         n = sizes[c]
         raw_d, w_d, _, _ = bandgen.device_band(n, num, ld, mw, depth=cfg['depth'], nloops=max(1, cfg['nloops'] * n // cfg['n']),
-                                               seed=1000 * rank + i, device=dev, want_expected=False)
+                                               seed=1000 + gorder.index(c), device=dev, want_expected=False)
         if args.host_inputs:       # PCIe-inclusive variant: the bands live in host memory (pageable numpy), as after cooler I/O
             bands.append((c, n, np.ascontiguousarray(raw_d[:, :num].cpu().numpy()), w_d.cpu().numpy()))
             del raw_d, w_d
@@ -199,10 +224,19 @@ def run_genome(args, cfg, ctx, rank, world, local, dist, emit=True, steps=None, 
     drain(pending, results)
     barrier()
     elapsed = time.perf_counter() - t0
+    # what the last pass found on this rank, and - N ranks - on all of them: every chromosome must have been scored by exactly one
+    last_all = [t for rs in results[-((len(bands) + group - 1) // group):] for t in rs]
+    tot = [float(sum(t[2] for t in last_all)), float(sum(t[3] for t in last_all)), float(len(mine))]
+    scored_by = [list(mine)]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=args.coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        t = torch.tensor(tot, dtype=torch.float64, device=args.coll_device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        tot = [float(v) for v in t.tolist()]
+        scored_by = [None] * world
+        dist.all_gather_object(scored_by, list(mine))
     out = None
     if rank == 0:
         # dominant kernel: the stencil launches of this rank that were bracketed by events; achieved = algorithmic bytes
@@ -228,9 +262,16 @@ def run_genome(args, cfg, ctx, rank, world, local, dist, emit=True, steps=None, 
                        # ... and chromosomes whose Benjamini-Hochberg cut lay above the bound of their survivor records
                        'rescored_rank0': int(sum(t[6] for t in last)),
                        'parallelism': 'chromosomes dealt largest-first to the GPUs, no collective',
+                       # the largest-first deal: band px x pairs per rank, and the heaviest rank against the mean
+                       'per_rank_px': rank_px, 'lpt_imbalance': max(rank_px) / (sum(rank_px) / float(len(rank_px))),
+                       # over all ranks (all-reduce / all-gather over the ranks' own results): candidates and significant pixels of the
+                       # genome, and which rank scored which chromosome
+                       'candidates_all_ranks': int(tot[0]), 'significant_px_all_ranks': int(tot[1]), 'chromosomes_scored': int(tot[2]),
+                       'chromosomes_by_rank': scored_by,
                        'whole_genome_wall_ms': elapsed / steps * 1e3, 'host_inputs': bool(args.host_inputs)},
-            'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil_s (+ hpk_stencil_lean)', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel_ms': st_ms / nlaunch,
+            'roofline': {'bound': 'valu-issue', 'bound_by_contract': 'hbm', 'kernel': 'hpk_stencil_s (+ hpk_stencil_lean)', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'frac_20B_equivalent': achieved / HBM_PEAK_GBS, 'frac_measured': None,
+                         'frac_label': FRAC_LABEL, 'traffic': None, 'kernel_ms': st_ms / nlaunch,
                          'launches_timed': nlaunch, 'launches': len(results),
                          'algorithmic_bytes_per_launch': BYTES_PER_PX * st_px / nlaunch},
         }
@@ -240,6 +281,62 @@ def run_genome(args, cfg, ctx, rank, world, local, dist, emit=True, steps=None, 
     if emit and dist is not None:
         dist.destroy_process_group()
     return out
+
+
+def run_genome_cold(args, cfg, ctx, local, reps=5):
+    """What one invocation of the command line meets (scripts/pyHICCUPS:192-210: one genome per process): ONE genome of 23
+    chromosomes scored from a context without history, under the mode the command lines ship (spec_halo = 2: every chromosome under
+    the tile layout of its own frozen width - with nothing inherited, a chromosome whose layout turns out different is computed a
+    second time).  Median of `reps` passes, the context's hints reset before each (workspaces stay allocated); then the same genome
+    again without a reset (warm, also synchronous: one call, collected before the next), and once in a truly fresh context
+    (allocations included)."""
+    import torch
+    from hicpeaks_amd import _lib, band, bandgen, synthetic
+    dev = torch.device('cuda', local)
+    res, mw, D = cfg['res'], min(cfg['ww']), cfg['maxapart'] // cfg['res']
+    num = D + cfg['maxww'] + 1
+    ld = (num + 63) // 64 * 64
+    sizes = synthetic.hg38_bins(res)
+    bands = []
+    for i, c in enumerate(sorted(sizes, key=lambda k: -sizes[k])):
+        n = sizes[c]
+        raw_d, w_d, _, _ = bandgen.device_band(n, num, ld, mw, depth=cfg['depth'], nloops=max(1, cfg['nloops'] * n // cfg['n']),
+                                               seed=i, device=dev, want_expected=False)
+        bands.append((n, raw_d, w_d))
+    torch.cuda.synchronize()
+    prm = _lib.make_params(_lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], cfg['maxww'], SIG, cfg['maxapart'], cfg['res'], MIN_READS,
+                           _lib.FLAG_NO_STENCIL_TIMING)
+    px = sum(band.band_pixels(n, num, mw, D) for n in sizes.values()) * len(cfg['pw'])
+
+    def one(c):
+        bd = [c._band(n, num, ld, r.data_ptr(), None, w.data_ptr(), None, None, None, True) for (n, r, w) in bands]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rs = c.submit_batch(bd, prm, [n for (n, _, _) in bands]).results()
+        ms = (time.perf_counter() - t0) * 1e3
+        return ms, sum(int(r.redone) for r in rs), sum(int(r.rescored) for r in rs), sorted(set(int(r.frozen_w) for r in rs))
+
+    ctx.set_option('spec_halo', 2)
+    one(ctx)                                    # workspaces
+    cold = []
+    for _ in range(reps):
+        ctx.set_option('reset_hints', 1)
+        cold.append(one(ctx))
+    warm = [one(ctx) for _ in range(3)]
+    ctx.set_option('spec_halo', 1)
+    c2 = _lib.Context(local)
+    c2.set_option('spec_halo', 2)
+    fresh = one(c2)
+    c2.close()
+    del bands
+    cm = float(np.median([c_[0] for c_ in cold]))
+    wm = float(np.median([w_[0] for w_ in warm]))
+    k = int(np.argsort([c_[0] for c_ in cold])[len(cold) // 2])
+    return {'workload': cfg['workload'], 'spec_halo': 2, 'band_px_per_genome': px, 'passes': reps,
+            'ms_per_genome': cm, 'value': px / (cm * 1e-3), 'unit': 'band px/s',
+            'passes_redone_in_full': cold[k][1], 'second_passes': cold[k][1], 'rescored': cold[k][2], 'frozen_w': cold[k][3],
+            'ms_per_genome_warm_sync': wm, 'warm_redone': warm[-1][1], 'cold_over_warm': cm / wm,
+            'ms_first_genome_fresh_context': fresh[0], 'fresh_context_redone': fresh[1]}
 
 
 def launch_plan(gpus, env, ngpus_visible):
@@ -305,7 +402,7 @@ def main():
                     help='bands with structure on top of the distance decay (synthetic.structure_fields: TAD blocks, a compartment '
                          'checkerboard, dense far-field patches) - what the record bounds, depth classes and lean column chunks are '
                          'not tuned on; the line reports what they did (passes_redone_in_full, passes_rescored, lean_redone)')
-    ap.add_argument('--cpu-allcores-rows', type=int, default=3000,
+    ap.add_argument('--cpu-allcores-rows', type=int, default=1000,
                     help='rows per process of the all-cores CPU baseline leg (0 = skip)')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -471,6 +568,10 @@ def main():
         st = sum(r.timing['stencil'] for r in rs)        # the group's launch: its chromosomes' shares add up to it
         if st > 0:
             stencil_ms.append(st)
+            sc = sum(r.timing['score'] for r in rs)      # ... and its scoring launch (one more event on the timed calls)
+            if sc > 0:
+                score_ms.append(sc)
+                score_cand.append(sum(c_ for r in rs for _, _, c_, ex in r.steps if ex))
 
     def run(ngroups):
         pending, done = collections.deque(), []
@@ -482,7 +583,7 @@ def main():
             take(pending.popleft(), done)
         return done
 
-    stencil_ms = []
+    stencil_ms, score_ms, score_cand = [], [], []
     nredone, nrescored = [0], [0]
     lean_ct = collections.Counter()
     R = None
@@ -496,7 +597,7 @@ def main():
         torch.cuda.synchronize()
 
     barrier()
-    del stencil_ms[:]
+    del stencil_ms[:], score_ms[:], score_cand[:]
     fw_by_depth.clear()
     nredone[0] = nrescored[0] = 0
     lean_ct.clear()
@@ -512,7 +613,7 @@ def main():
     lean_timed = dict(lean_ct)
     fw_timed = {str(k): sorted(v) for k, v in sorted(fw_by_depth.items())}
     assert len(stencil_ms) >= args.steps * batch // group // TIMED_EVERY
-    stencil_ms = list(stencil_ms)
+    stencil_ms, score_ms_timed, score_cand_timed = list(stencil_ms), list(score_ms), list(score_cand)
     R = results[-1]
     # outside the timed region: latency of one synchronous single-chromosome call (submit + collect), then a group with
     # the per-phase events switched on (they cost ~6 us of idle GPU each, so the timed passes run without them)
@@ -563,7 +664,21 @@ def main():
             extra['sample_runs'] = {'value': px_per_step * batch * nb_steps / (time.perf_counter() - t1), 'unit': 'band px/s',
                                     'calls_per_sample': 5, 'chromosomes': nb_steps * batch, 'redone_in_full': nredone[0]}
             sample_run[0] = 0
+        # the mode the command lines and the drop-in functions ship (spec_halo = 2): the default workload once more under it
+        ctx.set_option('spec_halo', 2)
+        run(max(2, depth) * 2)
+        barrier()
+        nredone[0] = 0
+        t1 = time.perf_counter()
+        run(nb_steps * batch // group)
+        barrier()
+        extra['cli_mode'] = {'value': px_per_step * batch * nb_steps / (time.perf_counter() - t1), 'unit': 'band px/s', 'spec_halo': 2,
+                             'chromosomes': nb_steps * batch, 'redone_in_full': nredone[0],
+                             'note': 'the timed region above runs a Context of its own under the library default (spec_halo = 1)'}
+        ctx.set_option('spec_halo', 1)
         if args.config == 'chr1_10kb':
+            for name in ('wg_10kb_union', 'wg_5kb'):
+                extra[name + '_cold'] = run_genome_cold(args, CONFIGS[name], ctx, local)
             for name in ('wg_10kb_union', 'wg_5kb'):
                 o = run_genome(args, CONFIGS[name], ctx, rank, world, local, None, emit=False, steps=3, warmup=1)
                 extra[name] = {'value': o['value'], 'unit': o['unit'], 'ms_per_step': o['ms_per_step'], 'steps': o['steps'],
@@ -597,15 +712,18 @@ def main():
                        'tiles': lean_timed.get('tiles', 0), 'lean_tiles': lean_timed.get('lean_tiles', 0),
                        'lean_redone': lean_timed.get('lean_redone', 0), 'lean_explicit': lean_timed.get('lean_explicit', 0),
                        'parallelism': 'one chromosome per GPU, no collective', 'pipeline_depth': depth,
+                       'per_rank_px': [px_per_step * batch] * world, 'lpt_imbalance': 1.0,      # (every rank scores its own chromosomes of one shape)
                        'sync_call_ms': float(np.median(lat)) if lat else None,
                        'stencil_only': bool(args.stencil_only), 'host_inputs': bool(args.host_inputs), 'balanced_f64': bool(args.balanced_f64),
                        'structure': bool(args.structure)},
-            # frac: SURVEY.md §8-D3 convention, 20 B per band pixel per pair (4 B read + 2 x 8 B local expected written).  The
-            # kernel writes compact records for the candidates only, so two more figures keep the books honest:
-            # compact_4Bpx (the §8-D3 figure for a compacting mode: the 4 B/px that must be read) and hbm_frac_measured
-            # (counter traffic per launch / kernel time / peak - what the memory system actually carries).
-            'roofline': {'bound': 'hbm', 'kernel': 'hpk_stencil_s (+ hpk_stencil_lean)', 'achieved': achieved,
-                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+            # frac = frac_20B_equivalent: SURVEY.md §8-D3's convention, 20 B per band pixel per pair (4 B read + 2 x 8 B local expected
+            # written) - an "equivalent bytes" figure that measures the kernel against the contract's memory floor, NOT HBM
+            # utilisation: the kernels write compact records for the candidates that can count, so the bytes they really move are
+            # fewer (frac_measured: rocprofv3's counters / kernel time / peak; compact_4Bpx: 8-D3's figure for a compacting mode).
+            # What bounds the kernel is vector issue: roofline_valu below; `bound` names the roof with the larger fraction.
+            'roofline': {'bound': 'hbm', 'bound_by_contract': 'hbm', 'kernel': 'hpk_stencil_s (+ hpk_stencil_lean)', 'achieved': achieved,
+                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'frac_20B_equivalent': achieved / HBM_PEAK_GBS, 'frac_measured': None, 'frac_label': FRAC_LABEL, 'traffic': None,
                          'kernel_ms': st, 'kernel_ms_per_chromosome': st / group,
                          'algorithmic_bytes_per_launch': BYTES_PER_PX * px_per_step * group,
                          'launches_timed': len(stencil_ms), 'launches': args.steps * batch // group,
@@ -619,27 +737,51 @@ def main():
             'phases_note': 'instrumented launches after the timed region (events between the kernels): +15-30 %, for the split only',
             'extra': extra,
         }
-        if phases.get('score'):
-            # The second kernel, hpk_score (a gather kernel: issue- and latency-bound), against the same roof.  Algorithmic
+        if score_ms_timed or phases.get('score'):
+            # The second kernel, hpk_score (a gather kernel: issue-bound), against the same roof.  Algorithmic
             # bytes per scored candidate and pair: its record (4 B entry + 1 B step + 16 B sums) and what its expected value is
             # formed from (IR[d], B1[r], B2[c], two local-expected table entries: 40 B); candidates = those resolved at the
-            # executed steps, mean over the chromosomes of the instrumented launch.  Time: the instrumented launch above (an upper bound of the timed region's).
-            nrec = phase_scored         # (the mean over the instrumented group - depths differ by an order of magnitude in candidates)
+            # executed steps.  Time and candidates: the timed region's own launches (every TIMED_EVERY-th call carries one more
+            # event behind its scoring kernel); without them (stencil-only, no timed call) the instrumented launch after it.
+            if score_ms_timed:
+                sc_ms, nrec, src = float(np.mean(score_ms_timed)) / group, float(np.mean(score_cand_timed)) / group, \
+                    'events on every %dth call of the timed region (%d launches)' % (TIMED_EVERY, len(score_ms_timed))
+            else:
+                sc_ms, nrec, src = phases['score'], phase_scored, 'instrumented launch (phases_ms.score)'
             sbytes = nrec * 61.0
-            sach = sbytes / (phases['score'] * 1e-3) / 1e9
-            out['roofline_score'] = {'bound': 'hbm', 'kernel': 'hpk_score', 'achieved': sach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                                     'frac': sach / HBM_PEAK_GBS, 'traffic': None, 'kernel_ms_per_chromosome': phases['score'],
+            sach = sbytes / (sc_ms * 1e-3) / 1e9
+            out['roofline_score'] = {'bound': 'valu-issue', 'bound_by_contract': 'hbm', 'kernel': 'hpk_score', 'achieved': sach, 'peak': HBM_PEAK_GBS,
+                                     'unit': 'GB/s', 'frac': sach / HBM_PEAK_GBS, 'frac_61B_equivalent': sach / HBM_PEAK_GBS, 'frac_measured': None,
+                                     'traffic': None, 'kernel_ms_per_chromosome': sc_ms,
                                      'candidates_scored_per_chromosome': nrec, 'algorithmic_bytes_per_candidate': 61.0,
-                                     'time_source': 'instrumented launch (phases_ms.score)'}
-        try:        # HBM traffic per launch of the dominant kernel, measured off-line with rocprofv3 --pmc (profiles/)
+                                     'time_source': src}
+        try:        # HBM traffic and vector instructions per launch of the dominant kernel, measured off-line with rocprofv3 --pmc (profiles/)
             tr = json.load(open(os.path.join(REPO, 'profiles', 'traffic.json'))).get(args.config)
             if tr:
-                # (counter traffic is recorded per chromosome; a launch carries a group of them)
+                # (counters are recorded per chromosome; a launch carries a group of them)
                 out['roofline']['traffic'] = tr['traffic_bytes'] * group
                 out['roofline']['traffic_source'] = tr['source']
-                out['roofline']['hbm_frac_measured'] = tr['traffic_bytes'] * group / (st * 1e-3) / 1e9 / HBM_PEAK_GBS
+                fm = tr['traffic_bytes'] * group / (st * 1e-3) / 1e9 / HBM_PEAK_GBS
+                out['roofline']['hbm_frac_measured'] = out['roofline']['frac_measured'] = fm
                 if 'roofline_score' in out and tr.get('score_traffic_bytes'):
                     out['roofline_score']['traffic'] = tr['score_traffic_bytes']      # per chromosome, like its time
+                    out['roofline_score']['frac_measured'] = tr['score_traffic_bytes'] / (out['roofline_score']['kernel_ms_per_chromosome'] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                if tr.get('valu_insts'):
+                    # vector issue: SQ_INSTS_VALU (wave-instructions, per chromosome) x 4 cycles / (1 024 SIMDs x clock x kernel time)
+                    def valu(n_inst, ms):
+                        return n_inst * VALU_CYCLES / (N_SIMD * CLOCK_GHZ * 1e9 * ms * 1e-3)
+                    vf = valu(tr['valu_insts'], st / group)
+                    out['roofline_valu'] = {'bound': 'valu-issue', 'kernel': out['roofline']['kernel'], 'achieved': vf, 'peak': 1.0,
+                                            'unit': 'fraction of the vector issue slots', 'frac': vf,
+                                            'valu_wave_insts_per_chromosome': tr['valu_insts'], 'cycles_per_inst': VALU_CYCLES,
+                                            'simds': N_SIMD, 'clock_ghz': CLOCK_GHZ,
+                                            'valu_lane_insts_per_band_px': tr['valu_insts'] * 64.0 / px_per_step * len(cfg['pw']),
+                                            'floor_ms_per_chromosome': tr['valu_insts'] * VALU_CYCLES / (N_SIMD * CLOCK_GHZ * 1e9) * 1e3,
+                                            'source': tr['source']}
+                    if vf > max(fm, 0.0):
+                        out['roofline']['bound'] = 'valu-issue'
+                    if 'roofline_score' in out and tr.get('score_valu_insts'):
+                        out['roofline_score']['valu_frac'] = valu(tr['score_valu_insts'], out['roofline_score']['kernel_ms_per_chromosome'])
         except Exception:
             pass
         if world == 1 and args.cpu_rows > 0:

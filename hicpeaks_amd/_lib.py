@@ -109,6 +109,30 @@ def build(force=False, quiet=True):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch's ROCm wheels bundle their own libamdhip64.so (soname libamdhip64.so.7, found through
+    an RPATH under its file name), libhpk.so asks for libamdhip64.so.7: whoever comes second gets a second runtime beside the
+    first, and the second one no longer finds the device - `import hicpeaks_amd` before `import torch` used to break torch (round
+    5: handled in tests/conftest.py only).  When torch is installed its bundled runtime is therefore loaded here, globally, before
+    libhpk.so: libhpk's soname request and torch's later load by path both resolve to that one copy - the same arrangement as
+    when torch is imported first.  No torch (the command lines need none): the system's ROCm as linked.  HPK_NO_TORCH_HIP=1: leave
+    the loader alone."""
+    import sys
+    if os.environ.get('HPK_NO_TORCH_HIP') or 'torch' in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec('torch')
+        if spec is None or not spec.origin:
+            return
+        libdir = os.path.join(os.path.dirname(spec.origin), 'lib')
+        hip = os.path.join(libdir, 'libamdhip64.so')
+        if os.path.exists(hip):
+            C.CDLL(hip, mode=C.RTLD_GLOBAL)
+    except Exception:       # (a torch that cannot be located changes nothing: the library loads as linked)
+        pass
+
+
 def load():
     """Load libhpk.so (never builds; `__graft_entry__.build()` / `make -C hicpeaks_amd/csrc` does)."""
     global _lib
@@ -117,6 +141,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise HpkError(ERR_NO_DEVICE, 'libhpk.so is not built (%s); run `make -C hicpeaks_amd/csrc` - there is '
                        'no CPU fallback' % LIB_PATH)
+    _share_torch_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     lib.hpk_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
     lib.hpk_create.restype = C.c_int

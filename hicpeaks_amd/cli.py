@@ -225,11 +225,15 @@ def _score_queue(args_dict, mode, queue, device, shared=False):
     ctx = _lib.default_context(device)
     # every run starts without memory of the chromosomes an earlier run in this process scored
     ctx.set_option('reset_hints', 1)
-    if args_dict.get('history_dependent') and not args_dict.get('deterministic'):
-        if 'HPK_SPEC_HALO' not in os.environ:       # (the environment's choice stands)
-            ctx.set_option('spec_halo', 1)
-    else:
-        ctx.set_option('spec_halo', 2)              # every chromosome under the halo of its own frozen width (hpk.h: spec_halo)
+    # The run's mode, on the process-wide context the drop-in hiccups() / bhfdr() score on as well: set for this run and put back
+    # when it ends (_restore_mode below), so that an in-process --history-dependent run does not leave those functions' values
+    # depending on the calls before.  HPK_SPEC_HALO in the environment wins over either flag (it is what the library started with).
+    if 'HPK_SPEC_HALO' not in os.environ:
+        ctx.set_option('spec_halo', 1 if (args_dict.get('history_dependent') and not args_dict.get('deterministic')) else 2)
+
+    def _restore_mode():
+        if 'HPK_SPEC_HALO' not in os.environ:
+            ctx.set_option('spec_halo', 2)          # _lib.default_context's own mode
     depth = ctx.pipeline_depth
     pending, out = collections.deque(), {}
 
@@ -288,6 +292,7 @@ def _score_queue(args_dict, mode, queue, device, shared=False):
             except _queue.Empty:
                 pass
             th.join(timeout=0.05)
+        _restore_mode()
 
 
 def _consume(args_dict, mode, device, ctx, depth, fetched, info, pending, out, collections):

@@ -50,7 +50,8 @@ class ArrayPool(object):
         import threading
         self.lock = threading.Lock()
         self.free = {}              # dtype -> [arrays]
-        self.owned = set()          # ids of the arrays handed out
+        self.owned = {}             # id -> the array itself, for every array this pool made and still keeps track of (a strong
+                                    # reference: an id cannot be reused by another object while its array is alive)
 
     def take(self, dtype, n):
         dtype = np.dtype(dtype)
@@ -61,12 +62,13 @@ class ArrayPool(object):
                 a = fl.pop(min(fit, key=lambda k: fl[k].size))
             else:
                 if fl:                                  # (none large enough: the smallest one goes instead of piling up)
-                    fl.pop(min(range(len(fl)), key=lambda k: fl[k].size))
+                    gone = fl.pop(min(range(len(fl)), key=lambda k: fl[k].size))
+                    self.owned.pop(id(gone), None)      # ... and is forgotten: freed for good
                 a = None
         if a is None:
             a = np.empty(max(int(n), 1), dtype=dtype)
             with self.lock:
-                self.owned.add(id(a))
+                self.owned[id(a)] = a
         return a[:n]
 
     def give(self, *arrays):
@@ -74,8 +76,8 @@ class ArrayPool(object):
             a = v.base if isinstance(v, np.ndarray) and v.base is not None else v
             if isinstance(a, np.ndarray):
                 with self.lock:
-                    if id(a) in self.owned and not any(a is b for b in self.free.get(a.dtype, [])):
-                        self.free[a.dtype].append(a)
+                    if self.owned.get(id(a)) is a and not any(a is b for b in self.free.get(a.dtype, [])):
+                        self.free.setdefault(a.dtype, []).append(a)
 
 
 def _h5_locked(fn):

@@ -146,6 +146,7 @@ struct Options {
     int spec_surv_force = -1;   // tests: this bin for every family (too narrow a bound: scored once more)
     int host_threads = 8;       // threads of a batch's host half (hpk_collect_batch), at most one per four chromosomes (hpk_create: up to 16 by the host's cores)
     int kcrit = 1;              // hpk_score forms a p-value only where the count reaches the critical count of its chunk (hiccups) / of its lambda's cell (bhfdr)
+    int side_serial = 0;        // measurement (profiles/r06_side_stream.txt): the tables / class kernels of a batch on the compute stream, behind the batch before, instead of beside its scoring on the lane's side stream
     int lean = 1;               // tiles of the column chunks hpk_band_class expects no resolving candidate in are built without their f64 plane
     int lean_max = 24;          // ... candidates of such a tile that do count and get their sums cell by cell; more: the tile is computed once more
     int lean_share_pct = 50;    // ... and a band has lean tiles only if at least this share of its column chunks is lean (below: hpk_stencil_s does them as fast)
@@ -364,6 +365,7 @@ int hpk_create(int device, hpk_ctx** out) {
     o.dbg_stop = env_int("HPK_DBG_STOP", o.dbg_stop);
     o.host_prof = env_int("HPK_HOST_PROF", o.host_prof);
     o.kcrit = env_int("HPK_KCRIT", o.kcrit) ? 1 : 0;
+    o.side_serial = env_int("HPK_SIDE_SERIAL", o.side_serial) ? 1 : 0;
     o.lean = env_int("HPK_LEAN", o.lean) ? 1 : 0;
     o.lean_max = std::max(0, std::min(4096, env_int("HPK_LEAN_MAX", o.lean_max)));
     o.lean_frac_pct = std::max(0, std::min(400, env_int("HPK_LEAN_FRAC", o.lean_frac_pct)));
@@ -602,7 +604,8 @@ int launch_compute(hpk_ctx* c, hpk_job* j, int b0, int nbl, bool solo, bool with
         for (int b = b0; b < b0 + nbl; ++b) sc.gridx = std::max(sc.gridx, solo ? j->gmax : j->bands[b].d.score_wgs);
         hpk_launch_score(sc, dd, nbl, plan.mode == HPK_MODE_BHFDR, c->stream);
         HIPCHK(c, hipGetLastError());
-        if (j->phases) (void)hipEventRecord(L.ev[4], c->stream);
+        // (a call whose stencil is timed also times its scoring kernel: one more event, behind the stencil's second one)
+        if (j->phases || (j->time_stencil && with_stencil)) (void)hipEventRecord(L.ev[4], c->stream);
         hpk_launch_tighten(dd, nbl, j->prm.sig, j->rounds_eff, j->nsets, sc.kmin, c->stream);
         HIPCHK(c, hipGetLastError());
     } else if (j->phases) (void)hipEventRecord(L.ev[4], c->stream);
@@ -959,11 +962,17 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     // lane's side stream like the uploads: for the batch submitted one ahead this executes beside the scoring and cut
     // kernels of the batch before (those leave registers and LDS free; the stencil does not); the compute stream waits
     // for the lot.
+    hipStream_t side = L.up;
+    if (opt.side_serial) {      // (A/B: the same kernels in line on the compute stream, behind the uploads above)
+        HIPCHK(c, hipEventRecord(L.ev_up, L.up));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, L.ev_up, 0));
+        side = c->stream;
+    }
     if (any_derive) {
-        hpk_launch_prep(L.desc.as<HpkBandDesc>(), nb, max_dn, max_dnum, mw, L.up);
+        hpk_launch_prep(L.desc.as<HpkBandDesc>(), nb, max_dn, max_dnum, mw, side);
         HIPCHK(c, hipGetLastError());
     }
-    hpk_launch_etab(L.plan.as<HpkDevPlan>(), L.desc.as<HpkBandDesc>(), nb, plan.nsteps, D, W, j->max_zero, L.up);
+    hpk_launch_etab(L.plan.as<HpkDevPlan>(), L.desc.as<HpkBandDesc>(), nb, plan.nsteps, D, W, j->max_zero, side);
     HIPCHK(c, hipGetLastError());
     // Record bound per chromosome: the batch's bound comes from the widest freeze of the last collections; a band of a shallower
     // sample freezes earlier, and what it writes beyond its own width is read and dropped by the scoring kernel.  hpk_band_class
@@ -980,7 +989,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
                 for (int i = 0; i < HPK_NCLASS; ++i) tab[i] = std::max(c->class_w[i], c->class_w1[i]);
             else std::memset(tab, -1, HPK_NCLASS);
             HIPCHK(c, L.classtab.reserve(HPK_NCLASS));
-            HIPCHK(c, hipMemcpyAsync(L.classtab.p, tab, HPK_NCLASS, hipMemcpyHostToDevice, L.up));
+            HIPCHK(c, hipMemcpyAsync(L.classtab.p, tab, HPK_NCLASS, hipMemcpyHostToDevice, side));
             ca.table = L.classtab.as<signed char>();
         }
         ca.mw = mw; ca.D = D; ca.wg_all = wg_all; ca.margin = opt.spec_margin; ca.wmin = (int)plan.wmin;
@@ -990,7 +999,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         ca.lean_frac = (float)opt.lean_frac_pct / 100.f;
         ca.lean_share = opt.lean_share_pct;
         j->cargs = ca;
-        hpk_launch_band_class(L.desc.as<HpkBandDesc>(), nb, ca, L.up);
+        hpk_launch_band_class(L.desc.as<HpkBandDesc>(), nb, ca, side);
         HIPCHK(c, hipGetLastError());
         if (opt.host_prof >= 2 && j->use_lean) {      // debug: the non-zero-weight mask of band 0 against its weights
             HIPCHK(c, hipStreamSynchronize(L.up));
@@ -1483,6 +1492,7 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
     float ms_st = 0.f, ms_h2d = 0.f, ms_fr = 0.f, ms_sc = 0.f, ms_ti = 0.f, ms_gap = 0.f;
     float ms = 0.f;
     if (j->time_stencil && hipEventElapsedTime(&ms, L.ev[1], L.ev[2]) == hipSuccess) ms_st = ms;
+    if (j->time_stencil && !j->phases && j->do_score && hipEventElapsedTime(&ms, L.ev[2], L.ev[4]) == hipSuccess) ms_sc = ms;
     if (j->phases) {
         if (hipEventElapsedTime(&ms, L.ev[0], L.ev[1]) == hipSuccess) ms_h2d = ms;
         if (hipEventElapsedTime(&ms, L.ev[2], L.ev[3]) == hipSuccess) ms_fr = ms;

@@ -6,7 +6,6 @@
 // which is what stopped it from scaling past ~16 threads (profiles/r05_host_e2e_deep.txt).
 #include <dlfcn.h>
 #include <unistd.h>
-#include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
@@ -68,11 +67,19 @@ bool widen_any(const unsigned char* p, int32_t size, int32_t kind, int64_t lo, i
 
 // libdeflate, if the host has it (loaded at run time: the image ships the library without its header), inflates a chunk about
 // twice as fast as zlib; the same zlib-wrapped streams, checked by its own Adler-32.  HPK_NO_LIBDEFLATE=1: zlib.
+// zlib is loaded at run time as well (`uncompress`): a build host without its development package still builds the library - GPU
+// path included - and a host without either inflater gets HPK_ERR_INVALID here, which sends the reader down its Python path.
 struct Deflate {
     void* (*alloc)() = nullptr;
     int (*zlib_decompress)(void*, const void*, size_t, void*, size_t, size_t*) = nullptr;
     void (*free_)(void*) = nullptr;
+    int (*z_uncompress)(unsigned char*, unsigned long*, const unsigned char*, unsigned long) = nullptr;      // zlib's uncompress: 0 = Z_OK
     Deflate() {
+        {
+            void* z = dlopen("libz.so.1", RTLD_NOW | RTLD_LOCAL);
+            if (!z) z = dlopen("libz.so", RTLD_NOW | RTLD_LOCAL);
+            if (z) z_uncompress = reinterpret_cast<int (*)(unsigned char*, unsigned long*, const unsigned char*, unsigned long)>(dlsym(z, "uncompress"));
+        }
         if (std::getenv("HPK_NO_LIBDEFLATE")) return;
         void* h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
         if (!h) h = dlopen("libdeflate.so", RTLD_NOW | RTLD_LOCAL);
@@ -107,7 +114,7 @@ int decode_impl(const void* const* src, int fd, const uint64_t* file_off, const 
         for (;;) {
             const int64_t i = next.fetch_add(1);
             if (i >= nchunks || bad.load()) break;
-            const Bytef* in = src ? static_cast<const Bytef*>(src[i]) : nullptr;
+            const unsigned char* in = src ? static_cast<const unsigned char*>(src[i]) : nullptr;
             if (!src) {             // the chunk as stored, read by this thread (pread: no file position shared)
                 stored.resize((size_t)src_len[i]);
                 size_t have = 0;
@@ -119,15 +126,20 @@ int decode_impl(const void* const* src, int fd, const uint64_t* file_off, const 
                 if (have != stored.size()) { bad.store(1); break; }
                 in = stored.data();
             }
-            uLongf got = (uLongf)cbytes;
+            unsigned long got = (unsigned long)cbytes;
             bool inflated = false;
             if (dec) {
                 size_t actual = 0;
                 inflated = dl.zlib_decompress(dec, in, (size_t)src_len[i], plain.data(), cbytes, &actual) == 0;
-                got = (uLongf)actual;
+                got = (unsigned long)actual;
             }
-            if (!inflated) { got = (uLongf)cbytes; inflated = uncompress(plain.data(), &got, in, (uLong)src_len[i]) == Z_OK; }
-            if (!inflated || got == 0 || got % (size_t)elem_size) {
+            if (!inflated && dl.z_uncompress) {
+                got = (unsigned long)cbytes;
+                inflated = dl.z_uncompress(plain.data(), &got, in, (unsigned long)src_len[i]) == 0;
+            }
+            // (HDF5 stores every chunk whole, the file's last one too: a chunk that inflates to anything else is corrupt - refused, so
+            // that the caller falls back to H5Dread instead of keeping what an earlier chromosome left in a recycled array)
+            if (!inflated || got != (unsigned long)cbytes) {
                 bad.store(1);
                 break;
             }

@@ -38,12 +38,13 @@ def group_of(name):
 for cfg in ('chr1_10kb', 'chr1_10kb_union', 'chr1_5kb', 'deep_1kb'):
     vals = {}
     G = group_of(cfg)           # chromosomes per launch of the counter passes: figures below are per chromosome
-    for cnt in ('FETCH_SIZE', 'WRITE_SIZE'):
+    for cnt in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_INSTS_VALU'):
         for kern in ('hpk_stencil', 'hpk_score'):
             m = pmc_means(os.path.join(out, 'pmc_%s_%s' % (cfg, cnt)), kern)
             if cnt in m:
                 vals[(kern, cnt)] = (m[cnt][0] / G, m[cnt][1])
-                lines.append('%-16s %-12s %-11s launches=%d of %d chromosomes, per chromosome %.5g KiB' % (cfg, kern, cnt, m[cnt][1], G, m[cnt][0] / G))
+                lines.append('%-16s %-12s %-13s launches=%d of %d chromosomes, per chromosome %.5g %s' % (cfg, kern, cnt, m[cnt][1], G, m[cnt][0] / G,
+                                                                                                      'wave-instructions' if cnt.startswith('SQ_') else 'KiB'))
     if ('hpk_stencil', 'FETCH_SIZE') in vals and ('hpk_stencil', 'WRITE_SIZE') in vals:
         tb = int((2 * vals[('hpk_stencil', 'FETCH_SIZE')][0] + vals[('hpk_stencil', 'WRITE_SIZE')][0]) * 1024)
         traffic[cfg] = {'traffic_bytes': tb, 'source': 'profiles/%s_pmc_summary.txt' % tag,
@@ -51,6 +52,11 @@ for cfg in ('chr1_10kb', 'chr1_10kb_union', 'chr1_5kb', 'deep_1kb'):
         lines.append('%-16s stencil HBM traffic per chromosome: %.1f MB' % (cfg, tb / 1e6))
     if cfg in traffic and ('hpk_score', 'FETCH_SIZE') in vals and ('hpk_score', 'WRITE_SIZE') in vals:
         traffic[cfg]['score_traffic_bytes'] = int((2 * vals[('hpk_score', 'FETCH_SIZE')][0] + vals[('hpk_score', 'WRITE_SIZE')][0]) * 1024)
+    # vector instructions per chromosome (wave-instructions: bench.py's roofline_valu prices them at 4 cycles on 1 024 SIMDs)
+    if cfg in traffic and ('hpk_stencil', 'SQ_INSTS_VALU') in vals:
+        traffic[cfg]['valu_insts'] = int(vals[('hpk_stencil', 'SQ_INSTS_VALU')][0])
+    if cfg in traffic and ('hpk_score', 'SQ_INSTS_VALU') in vals:
+        traffic[cfg]['score_valu_insts'] = int(vals[('hpk_score', 'SQ_INSTS_VALU')][0])
 Gs = group_of('sq')
 for kern in ('hpk_stencil', 'hpk_score'):
     lines.append('## %s (chr1_10kb), SQ / TCC counters per launch of %d chromosomes' % (kern, Gs))
@@ -64,7 +70,17 @@ if have_raw:
         json.dump(traffic, open(os.path.join(out, 'traffic.json'), 'w'), indent=1)
 ks = glob.glob(os.path.join(out, 'trace', '**', '*kernel_stats.csv'), recursive=True)
 if ks:
-    shutil.copy(ks[0], os.path.join(out, 'kernel_stats.csv'))
+    # the product's kernels only (the bench's band generator runs torch kernels of its own: 40 % of round 5's file), percentages
+    # recomputed over what is kept
+    rows = [r for r in csv.DictReader(open(ks[0])) if 'hpk_' in r['Name']]
+    tot = sum(float(r['TotalDurationNs']) for r in rows) or 1.0
+    with open(os.path.join(out, 'kernel_stats.csv'), 'w', newline='') as f:
+        wr = csv.DictWriter(f, fieldnames=list(rows[0].keys()) if rows else ['Name'])
+        wr.writeheader()
+        for r in rows:
+            if 'Percentage' in r:
+                r['Percentage'] = '%.6f' % (100.0 * float(r['TotalDurationNs']) / tot)
+            wr.writerow(r)
 print('\n'.join(lines[:80]))
 if copy:
     shutil.copy(os.path.join(out, 'bench.json'), os.path.join(prof, '%s_bench.json' % tag))

@@ -103,3 +103,23 @@ def test_chunk_bounds_match_numpy():
     assert lib.hpk_chunk_bounds(b.ctypes.data, _lib.HPK_NB) == 0
     want = np.array([np.power(2, ((i - 1) / 3.)) for i in range(1, _lib.HPK_NB + 1)])
     np.testing.assert_allclose(b, want, rtol=4e-16, atol=0)
+
+
+def test_one_hip_runtime_whichever_of_hicpeaks_amd_and_torch_comes_first():
+    """libhpk.so and PyTorch's ROCm wheel each ask for libamdhip64 their own way; two runtimes in one process lose the device for
+    the second (round 5: worked around in the tests' conftest only).  _lib.load() makes both resolve to one copy."""
+    import subprocess
+    import sys
+    code = ('import os, sys\n'
+            'order = sys.argv[1]\n'
+            'if order == "torch_first":\n'
+            '    import torch\n'
+            'from hicpeaks_amd import _lib\n'
+            '_lib.load()\n'
+            'import torch\n'
+            'maps = set(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l)\n'
+            'print(len(maps))\n')
+    for order in ('hpk_first', 'torch_first'):
+        r = subprocess.run([sys.executable, '-c', code, order], cwd=REPO, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        assert r.stdout.decode().split()[-1] == '1', (order, r.stdout.decode())

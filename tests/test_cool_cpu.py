@@ -343,6 +343,15 @@ def test_hpk_decode_chunks_against_zlib_and_numpy():
     out = np.empty(10, np.int64)
     assert lib.hpk_decode_chunks((C.c_void_p * 1)(bad.ctypes.data), (C.c_uint64 * 1)(bad.size), 1, 0, cs, 4, 0, 1, 0, 10,
                                  out.ctypes.data, 0, 0, 1) == _lib.ERR_INVALID
+    # a valid stream that inflates to less than a whole chunk (HDF5 stores every chunk whole): refused - the caller then reads
+    # through H5Dread - instead of leaving part of a (recycled) result array as it was
+    short = np.frombuffer(zlib.compress(np.arange(cs - 8, dtype=np.int32).tobytes(), 6), dtype=np.uint8)
+    full = np.frombuffer(zlib.compress(np.arange(cs, dtype=np.int32).tobytes(), 6), dtype=np.uint8)
+    for bufs in ([short], [full, short, full]):
+        out = np.full(cs * len(bufs), -1, np.int64)
+        src = (C.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
+        sl = (C.c_uint64 * len(bufs))(*[b.size for b in bufs])
+        assert lib.hpk_decode_chunks(src, sl, len(bufs), 0, cs, 4, 0, 0, 0, cs * len(bufs), out.ctypes.data, 0, 0, 1) == _lib.ERR_INVALID
 
 
 def test_array_pool_hands_arrays_back_by_identity():
@@ -362,6 +371,14 @@ def test_array_pool_hands_arrays_back_by_identity():
     assert e.size == 200 and len(p.free[np.dtype(np.int64)]) == 1
     p.give(f)
     assert p.take(np.float64, 3).base is f.base
+    # an array the pool dropped is forgotten (its id may come back with another object), and one of a dtype the pool never
+    # handed out is ignored, not an error
+    assert len(p.owned) == 4                                # a, c (= d's), e, f - not b, which the take of 200 dropped
+    assert id(b.base) not in p.owned
+    p.give(b)
+    assert all(x is not b.base for x in p.free[np.dtype(np.int64)])
+    p.give(np.zeros(4, np.int16).reshape(2, 2)[0])
+    assert np.dtype(np.int16) not in p.free
 
 
 def test_hpk_compact_pixels_against_numpy():

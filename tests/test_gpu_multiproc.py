@@ -167,3 +167,65 @@ def test_bench_two_ranks_on_one_gpu():
     one = _bench({}, [])
     # whole-job value of two ranks time-slicing one GPU: about the single process's (weak scaling arithmetic: world x per-rank work)
     assert 0.4 * one['value'] < out['value'] < 1.6 * one['value']
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The target machine's world size (8 GPUs per node) without a node: eight ranks / eight workers share the one GPU.  What is
+# checked is everything but the collective's transport: the largest-first deal, that every chromosome is scored exactly once,
+# the gathering of the ranks' results, and that the answer does not depend on the number of workers.
+def _bench_genome(env_extra, args, launcher=()):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **env_extra)
+    cmd = [sys.executable] + list(launcher) + [os.path.join(REPO, 'bench.py'), '--config', 'wg_10kb_union', '--steps', '1', '--warmup', '0',
+                                               '--cpu-rows', '0', '--no-extra', '--no-probes'] + list(args)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=REPO)
+    assert r.returncode == 0, (r.stdout.decode()[-2000:], r.stderr.decode()[-3000:])
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_bench_eight_ranks_deal_the_genome():
+    launcher = ['-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+                '--master-port', str(_free_port())]
+    out = _bench_genome({'HPK_BENCH_ONE_GPU': '1'}, ['--gpus', '8'], launcher)
+    c = out['config']
+    assert out['n_gpus'] == 8 and c['ranks_seen'] == 8 and out['scaling'] == 'strong'
+    # every chromosome of the genome scored by exactly one rank
+    names = sorted(synthetic.hg38_bins(10000))
+    assert c['chromosomes_scored'] == 23 and len(c['chromosomes_by_rank']) == 8
+    assert sorted(x for part in c['chromosomes_by_rank'] for x in part) == names
+    # the largest-first deal: the heaviest rank within 5 % of the mean (1.045 on 8 GPUs), chr1 alone on its rank's top
+    px = c['per_rank_px']
+    assert len(px) == 8 and sum(px) == c['band_px_per_step']
+    assert c['lpt_imbalance'] == max(px) / (sum(px) / 8.0) and c['lpt_imbalance'] <= 1.05
+    assert c['chromosomes_by_rank'][0][0] == '1'
+    # ... and the ranks' results add up to the single process's: the same candidates, the same significant pixels (a pixel within
+    # 1e-8 of a threshold may fall either way under another history of layouts: library default spec_halo = 1)
+    one = _bench_genome({}, [])
+    c1 = one['config']
+    assert c1['chromosomes_by_rank'] == [sorted(names, key=lambda k: (-synthetic.hg38_bins(10000)[k], str(k)))]
+    assert c['candidates_all_ranks'] == c1['candidates_all_ranks'] > 10 ** 7
+    assert abs(c['significant_px_all_ranks'] - c1['significant_px_all_ranks']) <= 3 and c1['significant_px_all_ranks'] > 1000
+    assert out['value'] > 0 and one['value'] > 0
+
+
+def test_cli_eight_workers_on_a_genome(tmp_path, monkeypatch):
+    """scripts/pyHICCUPS --nproc 8 on an archive of 23 chromosomes of 23 sizes (hg38's proportions) against --nproc 1"""
+    sizes = synthetic.hg38_bins(10000)
+    chroms = {}
+    for i, c in enumerate(sorted(sizes, key=lambda k: -sizes[k])):
+        n = max(NUM + 40, sizes[c] // 12)
+        chroms['chr' + c] = synthetic.synth_band(n, NUM, depth=DEPTHS[i % len(DEPTHS)], nloops=max(4, n // 80), seed=900 + i)[:2]
+    arc = str(tmp_path / 'genome.npz')
+    io.save_band_archive(arc, RES, chroms)
+    log = str(tmp_path / 'log.txt')
+    one, eight = str(tmp_path / 'one.bedpe'), str(tmp_path / 'eight.bedpe')
+    argv = ['-p', arc, '-C', '#', 'X', '--pw', '2', '--ww', '5', '--maxapart', str(MAXAPART), '--logFile', log]
+    assert cli.main_hiccups(['-O', one] + argv) == 0
+    monkeypatch.setenv('HPK_CLI_SHARE_GPU', '1')
+    assert cli.main_hiccups(['-O', eight, '--nproc', '8'] + argv) == 0
+    text = open(one).read()
+    assert open(eight).read() == text
+    seen = set(l.split('\t')[0] for l in text.splitlines())
+    assert len(text.splitlines()) >= 60 and len(seen) >= 15             # pixels from most of the 23 chromosomes
+    assert '--nproc 8: 8 worker(s)' in open(log).read()

@@ -202,3 +202,30 @@ def test_seam_with_more_diagonals_than_the_command_line_keeps():
     np.testing.assert_array_equal(k, kw)
     if k.size:
         np.testing.assert_allclose(v, vw, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_hicpeaks_amd_before_torch_in_a_fresh_process():
+    """`import hicpeaks_amd` and a scored chromosome first, torch's first touch of the GPU afterwards (round 5: torch then no longer
+    found the device; _lib._share_torch_hip_runtime)."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import numpy as np\n'
+            'from hicpeaks_amd import _lib, synthetic, band\n'
+            'raw, w, _ = synthetic.synth_band(900, 211, depth=60.0, nloops=10, seed=1)\n'
+            'IR, b = band.expected_and_biases(raw, w, 5)\n'
+            'c = _lib.Context(0)\n'
+            'prm = _lib.make_params(_lib.MODE_HICCUPS, [2], [5], 10, 0.05, 2000000, 10000, 16, 0)\n'
+            'R = c.score_host(raw.astype(np.float32), IR, b, b, prm, weight=w)\n'
+            'assert R.ncand > 1000\n'
+            'import torch\n'
+            'assert torch.cuda.is_available()\n'
+            'x = torch.arange(10, device="cuda").sum().item()\n'
+            'assert x == 45\n'
+            'R2 = c.score_host(raw.astype(np.float32), IR, b, b, prm, weight=w)\n'
+            'assert R2.ncand == R.ncand\n'
+            'print("ok")\n')
+    r = subprocess.run([sys.executable, '-c', code], cwd=repo, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0 and r.stdout.decode().split()[-1] == 'ok', r.stderr.decode()[-3000:]
