@@ -1,5 +1,5 @@
 # Repository-level entry points (the library itself: make -C hicpeaks_amd/csrc).
-ROUND ?= r05
+ROUND ?= r06
 GPURUN ?= /usr/local/graft/bin/gpurun
 
 lib:

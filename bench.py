@@ -14,8 +14,9 @@ collective (weak scaling).  Rank 0 prints ONE JSON line.
                (4 B f32 count read + 2 x 8 B f64 local expected written) x the band
                pixels one launch processes (a group of chromosomes) divided by the launch's mean duration from HIP
                events on the library's stream.
-`cpu_baseline`: the numpy oracle (oracle/hiccups_oracle.py, a restatement of the reference's algorithm pinned
-               to it by fixtures) timed on a bounded row sample of the same workload, rank 0, N = 1 only.
+`cpu_baseline`: the library's own back-end #0 (hpk_create(-1): C++ on host threads, parity-gated like the GPU path) on all
+               cores and on one, and the numpy oracle (oracle/hiccups_oracle.py, the restatement the fixtures pin to the
+               reference) on one core - the same chromosome, rank 0, N = 1 only.
 """
 import argparse
 import collections
@@ -80,24 +81,52 @@ def make_band_host(cfg, seed, n=None):
 
 
 def cpu_baseline(cfg, rows, allcores_rows=0):
-    """Oracle on a row sample of the same workload: px/s on one core, and (allcores_rows > 0) on all host cores."""
+    """The CPU path timed beside the GPU's, on the same workload: the library's own back-end #0 - hpk_create(-1),
+    C++ on host threads, parity-gated on the GPU path's fixtures (tests/test_cpu_backend.py), kind "native" - on every core the
+    process may use and on one; and the numpy oracle (kind "port": oracle/hiccups_oracle.py, the restatement the fixtures pin to
+    the reference) on one core.  rows: the slice of the workload (default: the whole chromosome)."""
     from oracle import hiccups_oracle as orc
-    from hicpeaks_amd import band
+    from hicpeaks_amd import _lib, band
     raw, weight, IR, biases, num = make_band_host(cfg, seed=12345, n=rows)
     mw = min(cfg['ww'])
+    px = band.band_pixels(rows, num, mw, cfg['maxapart'] // cfg['res']) * len(cfg['pw'])
+    # ---- native: IR / biases given (as the GPU's timed region has them), band resident in host memory
+    rawf = np.ascontiguousarray(raw.astype(np.float32))
+    prm = _lib.make_params(_lib.MODE_BHFDR if cfg.get('mode') == 'bhfdr' else _lib.MODE_HICCUPS, cfg['pw'], cfg['ww'], cfg['maxww'], SIG,
+                           cfg['maxapart'], cfg['res'], MIN_READS, 0)
+    cpu = _lib.Context(-1)
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+
+    def native(threads, reps):
+        cpu.set_option('cpu_threads', threads)
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            R = cpu.score_host(rawf, IR, biases, biases, prm, weight=weight)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return best, R
+    native(ncores, 1)                               # (Poisson tables, first touch)
+    t_all, R = native(ncores, 3)
+    t_one, _ = native(1, 1)
+    cpu.close()
+    # ---- port: the numpy oracle, one core
     t0 = time.perf_counter()
     IRo, cband, b = orc.prep_from_band(raw, weight, mw)
     t1 = time.perf_counter()
     orc.hiccups(raw, cband, b, b, IRo, rows, num, pw=cfg['pw'], ww=cfg['ww'], maxww=cfg['maxww'], sig=SIG,
                 maxapart=cfg['maxapart'], res=cfg['res'], min_local_reads=MIN_READS, min_marginal_peaks=2,
-                onlyanchor=False)
+                onlyanchor=False) if cfg.get('mode') != 'bhfdr' else None
     t2 = time.perf_counter()
-    px = band.band_pixels(rows, num, mw, cfg['maxapart'] // cfg['res']) * len(cfg['pw'])
-    out = dict(value=px / (t2 - t1), unit='band px/s', cores=1, kind='port',
-               sample='%d-row slice of the workload (%d band px), numpy oracle hiccups() %.1f s (+%.1f s prep)' % (
-                   rows, px, t2 - t1, t1 - t0))
+    out = dict(value=px / t_all, unit='band px/s', cores=ncores, cores_available=os.cpu_count(), kind='native',
+               sample='%d-row slice of the workload (%d band px): libhpk back-end #0 (hpk_create(-1), C++ on %d host threads), best of 3 '
+                      'calls %.3f s; candidates %d, significant %d' % (rows, px, ncores, t_all, R.ncand, R.nsig),
+               one_core=dict(value=px / t_one, unit='band px/s', cores=1, kind='native', sample='the same call on one thread: %.1f s' % t_one))
+    if cfg.get('mode') != 'bhfdr':
+        out['port'] = dict(value=px / (t2 - t1), unit='band px/s', cores=1, kind='port',
+                           sample='numpy oracle hiccups() on the same slice: %.1f s (+%.1f s prep)' % (t2 - t1, t1 - t0))
     if allcores_rows > 0:
-        out['all_cores'] = cpu_baseline_all_cores(cfg, allcores_rows)
+        out['port_all_cores'] = cpu_baseline_all_cores(cfg, allcores_rows)
     return out
 
 
@@ -402,8 +431,8 @@ def main():
                     help='bands with structure on top of the distance decay (synthetic.structure_fields: TAD blocks, a compartment '
                          'checkerboard, dense far-field patches) - what the record bounds, depth classes and lean column chunks are '
                          'not tuned on; the line reports what they did (passes_redone_in_full, passes_rescored, lean_redone)')
-    ap.add_argument('--cpu-allcores-rows', type=int, default=1000,
-                    help='rows per process of the all-cores CPU baseline leg (0 = skip)')
+    ap.add_argument('--cpu-allcores-rows', type=int, default=0,
+                    help='rows per process of the numpy port\'s all-cores leg (one process per core; 0 = skip: the native back-end is the all-cores baseline)')
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
 
@@ -786,10 +815,6 @@ def main():
             pass
         if world == 1 and args.cpu_rows > 0:
             out['cpu_baseline'] = cpu_baseline(cfg, min(args.cpu_rows, n), args.cpu_allcores_rows)
-            ac = out['cpu_baseline'].get('all_cores')
-            if ac:          # (also as scalars: parsers that keep only the flat keys of cpu_baseline)
-                out['cpu_baseline']['value_all'] = ac['value']
-                out['cpu_baseline']['cores_all'] = ac['cores']
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -14,10 +14,14 @@
 #include <numeric>
 #include <string>
 #include <vector>
+#if defined(__linux__)
+#include <sched.h>
+#endif
 
 #include "../../include/hpk.h"
 #include "hpk_kernels.h"
 #include "hpk_plan.h"
+#include "hpk_cpu.h"
 
 #ifdef HPK_TEST_KERNELS
 #define HPK_NEED_TEST_KERNELS(ctx) do {} while (0)
@@ -154,7 +158,9 @@ struct Options {
 };
 
 struct hpk_ctx {
-    int device = -1;
+    int device = -1;                    // HIP device ordinal; -1: back-end #0, the path on host threads (hpk_cpu.cpp) - only ever by request
+    int cpu_threads = 1;                // ... its threads (HPK_CPU_THREADS / option "cpu_threads"; default: every core the process may use)
+    HpkCpuTables cpu_tabs;              // ... and its Poisson tables
     hipStream_t stream = nullptr;       // compute stream: every kernel and the result downloads
     std::string err;
     char name[128] = {0};
@@ -311,6 +317,25 @@ const char* hpk_last_error(const hpk_ctx* ctx) { return ctx ? ctx->err.c_str() :
 int hpk_create(int device, hpk_ctx** out) {
     if (!out) return fail(nullptr, HPK_ERR_INVALID, "out is NULL");
     *out = nullptr;
+    if (device == -1) {
+        // Back-end #0 ("device -1 = CPU"): no HIP call is made.  Never a fallback - a caller gets it by asking for it.
+        hpk_ctx* c = new hpk_ctx();
+        { std::memset(c->class_w, -1, sizeof(c->class_w)); std::memset(c->class_w1, -1, sizeof(c->class_w1)); }
+        c->device = -1;
+        c->cus = 0;
+        c->hbm = 0;
+        int nt = (int)std::thread::hardware_concurrency();
+#if defined(__linux__)
+        { cpu_set_t set; if (sched_getaffinity(0, sizeof(set), &set) == 0) nt = CPU_COUNT(&set); }
+#endif
+        c->cpu_threads = std::max(1, std::min(1024, env_int("HPK_CPU_THREADS", std::max(1, nt))));
+        std::snprintf(c->name, sizeof(c->name), "host threads (back-end #0, %d threads)", c->cpu_threads);
+        fill_bounds(c->h_bounds);
+        fill_sfe(c->h_sfe);
+        c->tables_dirty = true;
+        *out = c;
+        return HPK_OK;
+    }
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -384,6 +409,7 @@ int hpk_set_option(hpk_ctx* c, const char* name, int64_t v) {
     else if (k == "spec_margin" && v >= 0 && v <= HPK_MAX_W) o.spec_margin = (int)v;
     else if (k == "spec_halo" && v >= 0 && v <= 2) o.spec_halo = (int)v;
     else if (k == "host_threads" && v >= 1 && v <= 64) o.host_threads = (int)v;
+    else if (k == "cpu_threads" && v >= 1 && v <= 1024) c->cpu_threads = (int)v;      // back-end #0 (device -1)
     else if (k == "spec_surv" && (v == 0 || v == 1)) o.spec_surv = (int)v;
     else if (k == "spec_surv_margin" && v >= 0 && v <= 16) o.spec_surv_margin = (int)v;
     else if (k == "spec_surv_force" && v >= -1 && v <= 255) o.spec_surv_force = (int)v;      // (clamped to the last bin)
@@ -407,6 +433,7 @@ int hpk_set_option(hpk_ctx* c, const char* name, int64_t v) {
 
 void hpk_destroy(hpk_ctx* c) {
     if (!c) return;
+    if (c->device < 0) { delete c; return; }
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     DevBuf* all[] = {&c->d_bounds, &c->d_off, &c->d_sfe, &c->d_ptab, &c->d_kcrit, &c->d_kclam, &c->tmpA, &c->tmpB, &c->tmpC, &c->tmpD, &c->cooA, &c->cooB, &c->cooC};
@@ -422,7 +449,7 @@ void hpk_destroy(hpk_ctx* c) {
 
 int hpk_set_chunk_bounds(hpk_ctx* c, const double* bounds, int32_t count) {
     if (!c || !bounds || count != HPK_NB) return fail(c, HPK_ERR_INVALID, "need %d bounds", HPK_NB);
-    (void)hipSetDevice(c->device);
+    if (c->device >= 0) (void)hipSetDevice(c->device);
     for (int i = 0; i < HPK_NB; ++i) {
         if (!(bounds[i] > 0.0) || (i && !(bounds[i] > bounds[i - 1]))) return fail(c, HPK_ERR_INVALID, "bounds must increase");
         c->h_bounds[i] = bounds[i];
@@ -465,9 +492,13 @@ int hpk_device_info(hpk_ctx* c, char* name, int32_t name_len, int32_t* cus, int6
 }
 
 int hpk_poisson_sf(hpk_ctx* c, const double* k, const double* lam, double* out, int64_t count) {
-    if (c) { HPK_NEED_TEST_KERNELS(c); }
+    if (c && c->device >= 0) { HPK_NEED_TEST_KERNELS(c); }
     if (!c || !k || !lam || !out || count < 0) return fail(c, HPK_ERR_INVALID, "bad arguments");
     if (count == 0) return HPK_OK;
+    if (c->device < 0) {        // back-end #0: the same series on the host
+        for (int64_t i = 0; i < count; ++i) out[i] = hpk_cpu_poisson_sf(k[i], lam[i], c->h_sfe.data(), 1.0);
+        return HPK_OK;
+    }
     (void)hipSetDevice(c->device);
     { const int rc = upload_tables(c); if (rc != HPK_OK) return rc; }
     const size_t bytes = sizeof(double) * (size_t)count;
@@ -545,7 +576,8 @@ struct BandSlot {
 
 struct hpk_job {
     hpk_ctx* ctx = nullptr;
-    int lane = -1;
+    int lane = -1;                      // (-1: a job of back-end #0 - computed when it is collected, on host threads)
+    HpkDevPlan* cpu_plan = nullptr;
     hpk_params prm, key;
     std::vector<BandSlot> bands;
     HpkStencilArgs sa;
@@ -561,7 +593,7 @@ struct hpk_job {
     signed char class_tab[HPK_NCLASS];  // the depth classes' widths as uploaded for this batch (source of an asynchronous copy: lives with the job)
     double t_begin = 0.0;
     uint8_t kmin_host[HPK_NFAM];        // the survivor bound of the batch's scoring launches (HpkScoreArgs::kmin), if any
-    ~hpk_job() { for (BandSlot& b : bands) delete b.box; }
+    ~hpk_job() { for (BandSlot& b : bands) delete b.box; delete cpu_plan; }
 };
 
 namespace {
@@ -1117,6 +1149,109 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
     return launch_compute(c, j, 0, nb, false, true);
 }
 
+// The host half both back-ends share: lambda chunks (callers.py:30) + Benjamini-Hochberg per family (callers.py:273 / 545) on the
+// pixels with p <= sig that came back, and the result arrays.  h_chist / h_famf: tests per (set, chunk) family and how many of them
+// have p <= sig; h_emax: bit pattern of the largest E per set.
+void assemble_sets(const HpkDevPlan& plan, const hpk_params* prm, int nsets, const unsigned int* h_chist, const unsigned int* h_famf,
+                   const unsigned long long* h_emax, std::vector<Surv>& sv, ResultBox* box, int host_prof, double t_d2h1) {
+    hpk_result& R = box->pub;
+    std::vector<std::vector<Surv*>> kept(nsets);
+    // families = (set, chunk): one sort by (family, p) on flat 16-byte keys (p >= 0, so its bit pattern orders
+    // like its value), then Benjamini-Hochberg on each run
+    struct Key { uint32_t fam, idx; uint64_t pbits; };
+    std::vector<Key> keys(sv.size());
+    for (size_t i = 0; i < sv.size(); ++i) {
+        uint64_t bits;
+        std::memcpy(&bits, &sv[i].p, 8);
+        keys[i] = Key{(uint32_t)sv[i].set << 8 | sv[i].chunk, (uint32_t)i, bits};
+    }
+    // (dealt to their families first - a counting pass over at most 256 x 256 family codes, a few hundred in use -, then every
+    // family sorted by p on its own: tens of thousands of survivors per chromosome on maps with structure, and one sort over all
+    // of them by (family, p) was 40 % of this half)
+    {
+        std::vector<uint32_t> start;
+        uint32_t maxf = 0;
+        for (const Key& k : keys) maxf = std::max(maxf, k.fam);
+        start.assign((size_t)maxf + 2, 0u);
+        for (const Key& k : keys) ++start[(size_t)k.fam + 1];
+        for (size_t f = 1; f < start.size(); ++f) start[f] += start[f - 1];
+        std::vector<Key> dealt(keys.size());
+        std::vector<uint32_t> at(start.begin(), start.end() - 1);
+        for (const Key& k : keys) dealt[at[k.fam]++] = k;
+        for (size_t f = 0; f + 1 < start.size(); ++f)
+            if (start[f + 1] - start[f] > 1)
+                std::sort(dealt.begin() + start[f], dealt.begin() + start[f + 1], [](const Key& a, const Key& b2) {
+                    return a.pbits != b2.pbits ? a.pbits < b2.pbits : a.idx < b2.idx; });
+        keys.swap(dealt);
+    }
+    std::vector<Surv*> order(sv.size());
+    for (size_t i = 0; i < sv.size(); ++i) order[i] = &sv[keys[i].idx];
+    const double t_h1 = now_ms();
+    std::vector<int> numbins(nsets, 0);
+    box->fam.resize((size_t)2 * nsets * (HPK_NB + 1));
+    std::memcpy(box->fam.data(), h_chist, sizeof(uint32_t) * (size_t)nsets * (HPK_NB + 1));
+    std::memcpy(box->fam.data() + (size_t)nsets * (HPK_NB + 1), h_famf, sizeof(uint32_t) * (size_t)nsets * (HPK_NB + 1));
+    for (int t = 0; t < nsets; ++t) {
+        hpk_set& hs = R.sets[t];
+        hs.pair = (plan.mode == HPK_MODE_BHFDR) ? 0 : t / 2;
+        hs.fl = (plan.mode == HPK_MODE_BHFDR) ? 0 : t % 2;
+        // pixels with E > 0: the families of the set added up (family 0 = those without a chunk, not a family of tests)
+        hs.nvalid = 0;
+        for (int ch = 0; ch <= HPK_NB; ++ch) hs.nvalid += (int64_t)h_chist[(size_t)t * (HPK_NB + 1) + ch];
+        box->fam[(size_t)t * (HPK_NB + 1)] = 0u;
+        double emax = 0.0;
+        std::memcpy(&emax, &h_emax[t], 8);
+        hs.emax = emax;
+        int numbin = 0;
+        if (plan.mode == HPK_MODE_HICCUPS && hs.nvalid > 0 && emax > 0.0) {
+            const double nbd = std::ceil(std::log(emax) / std::log(2.0) * 3.0 + 1.0);     // callers.py:30
+            numbin = !(nbd >= 0) ? 0 : (nbd > HPK_NB ? HPK_NB : (int)nbd);
+        }
+        hs.numbin = numbin;
+        hs.chunk_tests = box->fam.data() + (size_t)t * (HPK_NB + 1);
+        hs.chunk_below = box->fam.data() + (size_t)(nsets + t) * (HPK_NB + 1);
+        // chunks beyond numbin do not exist for the reference (their pixels keep p = q = 1, callers.py:259-260)
+        for (int ch = ((plan.mode == HPK_MODE_BHFDR) ? 1 : numbin) + 1; ch <= HPK_NB; ++ch) {
+            box->fam[(size_t)t * (HPK_NB + 1) + ch] = 0u;
+            box->fam[(size_t)(nsets + t) * (HPK_NB + 1) + ch] = 0u;
+        }
+        numbins[t] = (plan.mode == HPK_MODE_BHFDR) ? 1 : numbin;
+    }
+    for (size_t i = 0; i < order.size();) {
+        size_t e = i;
+        while (e < order.size() && order[e]->set == order[i]->set && order[e]->chunk == order[i]->chunk) ++e;
+        const int t = order[i]->set, ch = order[i]->chunk;
+        if (t < nsets && ch >= 1 && ch <= numbins[t]) {        // chunks beyond numbin keep p = q = 1 (callers.py:259-260)
+            bh_family(order.data() + i, e - i, h_chist[(size_t)t * (HPK_NB + 1) + ch], prm->sig, plan.mode == HPK_MODE_BHFDR);
+            for (size_t u = i; u < e; ++u) if (order[u]->keep) kept[t].push_back(order[u]);
+        }
+        i = e;
+    }
+    const double t_h2 = now_ms();
+    for (int t = 0; t < nsets; ++t) {           // by (x, y): on flat keys, the records themselves are not touched by the sort
+        std::vector<std::pair<uint64_t, Surv*>> xy(kept[t].size());
+        for (size_t i = 0; i < xy.size(); ++i) xy[i] = {(uint64_t)(uint32_t)kept[t][i]->x << 32 | (uint32_t)kept[t][i]->y, kept[t][i]};
+        std::sort(xy.begin(), xy.end(), [](const std::pair<uint64_t, Surv*>& a, const std::pair<uint64_t, Surv*>& b2) { return a.first < b2.first; });
+        for (size_t i = 0; i < xy.size(); ++i) kept[t][i] = xy[i].second;
+    }
+    if (host_prof) std::fprintf(stderr, "[hpk host] n=%zu sort=%.3f bh=%.3f\n", sv.size(), t_h1 - t_d2h1, t_h2 - t_h1);
+    size_t total = 0;
+    for (int t = 0; t < nsets; ++t) total += kept[t].size();
+    box->x.reserve(total); box->y.reserve(total); box->O.reserve(total); box->bal.reserve(total);
+    box->E.reserve(total); box->p.reserve(total); box->q.reserve(total); box->oz.reserve(total);
+    for (int t = 0; t < nsets; ++t) {
+        R.sets[t].begin = (int64_t)box->x.size();
+        for (const Surv* p : kept[t]) {
+            box->x.push_back(p->x); box->y.push_back(p->y); box->O.push_back((double)p->O); box->bal.push_back(p->bal);
+            box->E.push_back(p->E); box->p.push_back(p->p); box->q.push_back(p->q); box->oz.push_back(p->flag);
+        }
+        R.sets[t].end = (int64_t)box->x.size();
+    }
+    R.nsig = (int64_t)total;
+    R.x = box->x.data(); R.y = box->y.data(); R.O = box->O.data(); R.bal = box->bal.data();
+    R.E = box->E.data(); R.p = box->p.data(); R.q = box->q.data(); R.other_zero = box->oz.data();
+}
+
 // the host half of one band whose head has landed: widening log, lambda chunks, Benjamini-Hochberg, result arrays
 // (`err`: where a message goes when several chromosomes are finished at once - hpk_ctx::err is the calling thread's)
 int finish_band(hpk_ctx* c, hpk_job* j, int b, std::string* err = nullptr) {
@@ -1228,103 +1363,9 @@ int finish_band(hpk_ctx* c, hpk_job* j, int b, std::string* err = nullptr) {
 
     // ---- lambda chunks (callers.py:30) + Benjamini-Hochberg per family (callers.py:273 / 545)
     R.nsets = do_score ? nsets : 0;
-    std::vector<std::vector<Surv*>> kept(nsets);
-    if (do_score) {
-        // families = (set, chunk): one sort by (family, p) on flat 16-byte keys (p >= 0, so its bit pattern orders
-        // like its value), then Benjamini-Hochberg on each run
-        struct Key { uint32_t fam, idx; uint64_t pbits; };
-        std::vector<Key> keys(sv.size());
-        for (size_t i = 0; i < sv.size(); ++i) {
-            uint64_t bits;
-            std::memcpy(&bits, &sv[i].p, 8);
-            keys[i] = Key{(uint32_t)sv[i].set << 8 | sv[i].chunk, (uint32_t)i, bits};
-        }
-        // (dealt to their families first - a counting pass over at most 256 x 256 family codes, a few hundred in use -, then every
-        // family sorted by p on its own: tens of thousands of survivors per chromosome on maps with structure, and one sort over all
-        // of them by (family, p) was 40 % of this half)
-        {
-            std::vector<uint32_t> start;
-            uint32_t maxf = 0;
-            for (const Key& k : keys) maxf = std::max(maxf, k.fam);
-            start.assign((size_t)maxf + 2, 0u);
-            for (const Key& k : keys) ++start[(size_t)k.fam + 1];
-            for (size_t f = 1; f < start.size(); ++f) start[f] += start[f - 1];
-            std::vector<Key> dealt(keys.size());
-            std::vector<uint32_t> at(start.begin(), start.end() - 1);
-            for (const Key& k : keys) dealt[at[k.fam]++] = k;
-            for (size_t f = 0; f + 1 < start.size(); ++f)
-                if (start[f + 1] - start[f] > 1)
-                    std::sort(dealt.begin() + start[f], dealt.begin() + start[f + 1], [](const Key& a, const Key& b2) {
-                        return a.pbits != b2.pbits ? a.pbits < b2.pbits : a.idx < b2.idx; });
-            keys.swap(dealt);
-        }
-        std::vector<Surv*> order(sv.size());
-        for (size_t i = 0; i < sv.size(); ++i) order[i] = &sv[keys[i].idx];
-        const double t_h1 = now_ms();
-        std::vector<int> numbins(nsets, 0);
-        box->fam.resize((size_t)2 * nsets * (HPK_NB + 1));
-        std::memcpy(box->fam.data(), h_chist, sizeof(uint32_t) * (size_t)nsets * (HPK_NB + 1));
-        std::memcpy(box->fam.data() + (size_t)nsets * (HPK_NB + 1), hsmall + HPK_OFF_FAM_F, sizeof(uint32_t) * (size_t)nsets * (HPK_NB + 1));
-        for (int t = 0; t < nsets; ++t) {
-            hpk_set& hs = R.sets[t];
-            hs.pair = (plan.mode == HPK_MODE_BHFDR) ? 0 : t / 2;
-            hs.fl = (plan.mode == HPK_MODE_BHFDR) ? 0 : t % 2;
-            // pixels with E > 0: the families of the set added up (family 0 = those without a chunk, not a family of tests)
-            hs.nvalid = 0;
-            for (int ch = 0; ch <= HPK_NB; ++ch) hs.nvalid += (int64_t)h_chist[(size_t)t * (HPK_NB + 1) + ch];
-            box->fam[(size_t)t * (HPK_NB + 1)] = 0u;
-            double emax = 0.0;
-            std::memcpy(&emax, &h_emax[t], 8);
-            hs.emax = emax;
-            int numbin = 0;
-            if (plan.mode == HPK_MODE_HICCUPS && hs.nvalid > 0 && emax > 0.0) {
-                const double nbd = std::ceil(std::log(emax) / std::log(2.0) * 3.0 + 1.0);     // callers.py:30
-                numbin = !(nbd >= 0) ? 0 : (nbd > HPK_NB ? HPK_NB : (int)nbd);
-            }
-            hs.numbin = numbin;
-            hs.chunk_tests = box->fam.data() + (size_t)t * (HPK_NB + 1);
-            hs.chunk_below = box->fam.data() + (size_t)(nsets + t) * (HPK_NB + 1);
-            // chunks beyond numbin do not exist for the reference (their pixels keep p = q = 1, callers.py:259-260)
-            for (int ch = ((plan.mode == HPK_MODE_BHFDR) ? 1 : numbin) + 1; ch <= HPK_NB; ++ch) {
-                box->fam[(size_t)t * (HPK_NB + 1) + ch] = 0u;
-                box->fam[(size_t)(nsets + t) * (HPK_NB + 1) + ch] = 0u;
-            }
-            numbins[t] = (plan.mode == HPK_MODE_BHFDR) ? 1 : numbin;
-        }
-        for (size_t i = 0; i < order.size();) {
-            size_t e = i;
-            while (e < order.size() && order[e]->set == order[i]->set && order[e]->chunk == order[i]->chunk) ++e;
-            const int t = order[i]->set, ch = order[i]->chunk;
-            if (t < nsets && ch >= 1 && ch <= numbins[t]) {        // chunks beyond numbin keep p = q = 1 (callers.py:259-260)
-                bh_family(order.data() + i, e - i, h_chist[(size_t)t * (HPK_NB + 1) + ch], prm->sig, plan.mode == HPK_MODE_BHFDR);
-                for (size_t u = i; u < e; ++u) if (order[u]->keep) kept[t].push_back(order[u]);
-            }
-            i = e;
-        }
-        const double t_h2 = now_ms();
-        for (int t = 0; t < nsets; ++t) {           // by (x, y): on flat keys, the records themselves are not touched by the sort
-            std::vector<std::pair<uint64_t, Surv*>> xy(kept[t].size());
-            for (size_t i = 0; i < xy.size(); ++i) xy[i] = {(uint64_t)(uint32_t)kept[t][i]->x << 32 | (uint32_t)kept[t][i]->y, kept[t][i]};
-            std::sort(xy.begin(), xy.end(), [](const std::pair<uint64_t, Surv*>& a, const std::pair<uint64_t, Surv*>& b2) { return a.first < b2.first; });
-            for (size_t i = 0; i < xy.size(); ++i) kept[t][i] = xy[i].second;
-        }
-        if (c->opt.host_prof) std::fprintf(stderr, "[hpk host] n=%zu sort=%.3f bh=%.3f\n", sv.size(), t_h1 - t_d2h1, t_h2 - t_h1);
-        size_t total = 0;
-        for (int t = 0; t < nsets; ++t) total += kept[t].size();
-        box->x.reserve(total); box->y.reserve(total); box->O.reserve(total); box->bal.reserve(total);
-        box->E.reserve(total); box->p.reserve(total); box->q.reserve(total); box->oz.reserve(total);
-        for (int t = 0; t < nsets; ++t) {
-            R.sets[t].begin = (int64_t)box->x.size();
-            for (const Surv* p : kept[t]) {
-                box->x.push_back(p->x); box->y.push_back(p->y); box->O.push_back((double)p->O); box->bal.push_back(p->bal);
-                box->E.push_back(p->E); box->p.push_back(p->p); box->q.push_back(p->q); box->oz.push_back(p->flag);
-            }
-            R.sets[t].end = (int64_t)box->x.size();
-        }
-        R.nsig = (int64_t)total;
-        R.x = box->x.data(); R.y = box->y.data(); R.O = box->O.data(); R.bal = box->bal.data();
-        R.E = box->E.data(); R.p = box->p.data(); R.q = box->q.data(); R.other_zero = box->oz.data();
-    }
+    if (do_score)
+        assemble_sets(plan, prm, nsets, h_chist, reinterpret_cast<const unsigned int*>(hsmall + HPK_OFF_FAM_F), h_emax, sv, box,
+                      c->opt.host_prof, t_d2h1);
     const double t_end = now_ms();
     if (c->opt.host_prof) std::fprintf(stderr, "[hpk host] total host_bh=%.3f d2h=%.3f\n", t_end - t_d2h1, t_d2h1 - t_d2h0);
     R.ms_d2h = (float)(t_d2h1 - t_d2h0);
@@ -1583,6 +1624,92 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
     return HPK_OK;
 }
 
+// ---------------------------------------------------------------------------- back-end #0 (device -1): submit = remember, collect = compute
+int cpu_submit(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk_params* prm) {
+    if (prm->flags & (HPK_FLAG_DENSE_E | HPK_FLAG_DENSE_SUMS))
+        return fail(c, HPK_ERR_INVALID, "the dense debug outputs (HPK_FLAG_DENSE_*) are the device path's");
+    for (int b = 0; b < nb; ++b)
+        if (bands[b].on_device) return fail(c, HPK_ERR_INVALID, "back-end #0 takes host arrays (on_device = 0)");
+    j->cpu_plan = new HpkDevPlan();
+    char msg[256];
+    const int rc = hpk_build_plan(prm, j->cpu_plan, msg);
+    if (rc != HPK_OK) return fail(c, rc, "%s", msg);
+    if (j->cpu_plan->D < j->cpu_plan->mw) return fail(c, HPK_ERR_INVALID, "maxapart / res (%d) is below min(ww) (%d)", j->cpu_plan->D, j->cpu_plan->mw);
+    j->prm = *prm;
+    j->nsets = (j->cpu_plan->mode == HPK_MODE_BHFDR) ? 1 : 2 * j->cpu_plan->npairs;
+    j->do_score = (prm->flags & HPK_FLAG_NO_SCORE) == 0;
+    j->bands.resize((size_t)nb);
+    for (int b = 0; b < nb; ++b) { j->bands[b].in = bands[b]; j->bands[b].n = bands[b].n; j->bands[b].num = bands[b].num; }
+    return HPK_OK;
+}
+
+int cpu_collect(hpk_ctx* c, hpk_job* j) {
+    const HpkDevPlan& plan = *j->cpu_plan;
+    if (c->tables_dirty || !c->cpu_tabs.built) {
+        c->cpu_tabs.bounds = c->h_bounds;
+        c->cpu_tabs.sfe = c->h_sfe;
+        fill_offsets(c->h_bounds, c->cpu_tabs.off);
+        hpk_cpu_build_tables(c->cpu_tabs, c->cpu_threads);
+        c->tables_dirty = false;
+    }
+    const int nb = (int)j->bands.size();
+    for (int b = 0; b < nb; ++b) {
+        BandSlot& s = j->bands[b];
+        HpkCpuOut o;
+        std::string msg;
+        const double t0 = now_ms();
+        int rc = hpk_cpu_band(s.in, j->prm, plan, c->cpu_tabs, c->cpu_threads, o, msg);
+        if (rc != HPK_OK) { s.status = rc; s.err = msg; continue; }
+        ResultBox* box = new ResultBox();
+        std::memset(&box->pub, 0, sizeof(hpk_result));
+        s.box = box;
+        hpk_result& R = box->pub;
+        box->gap.resize((size_t)s.n);
+        for (int r = 0; r < s.n; ++r) box->gap[r] = o.rowlive[r] ? 0 : 1;
+        R.gap = box->gap.data();
+        R.band_px = o.band_px;
+        R.stencil_kernel = 0;               // (no device kernel ran)
+        R.batch_bands = nb;
+        R.record_bound = 255; R.halo_w = plan.W;
+        R.nsteps = plan.nsteps;
+        for (int t = 0; t < plan.nsteps; ++t) {
+            R.step_pi[t] = plan.steps[t].pi; R.step_wi[t] = plan.steps[t].wi;
+            R.step_executed[t] = o.exec[t];
+            R.step_resolved[t] = (o.exec[t] || !j->do_score) ? (int64_t)o.hist[t] : 0;
+        }
+        R.frozen_w = o.frozen;
+        R.nslots = plan.nslots;
+        for (int q = 0; q < plan.nslots; ++q) R.slot_pi[q] = plan.slot_pi[q];
+        R.ncand = (int64_t)o.hist[HPK_HIST_NCAND];
+        R.nsurv_sig = 0;
+        for (uint32_t v : o.fam_f) R.nsurv_sig += v;
+        R.nsurv_cut = (int64_t)o.surv.size();
+        if (o.err != 0) {
+            const HpkDevStep& st = plan.steps[o.err - 1];
+            char m2[256];
+            std::snprintf(m2, sizeof(m2), "step (%d,%d) entered with no unresolved candidate (of %lld); the reference raises here "
+                          "(hicpeaks/callers.py:203-208)", st.pi, st.wi, (long long)R.ncand);
+            s.status = HPK_ERR_EMPTY_STEP; s.err = m2;
+            delete s.box; s.box = nullptr;
+            continue;
+        }
+        R.nsets = j->do_score ? j->nsets : 0;
+        if (j->do_score) {
+            std::vector<Surv> sv(o.surv.size());
+            for (size_t i = 0; i < sv.size(); ++i) {
+                const HpkSurv& rc_ = o.surv[i];
+                sv[i] = Surv{rc_.x, rc_.y, rc_.set, rc_.chunk, rc_.flag, 0, rc_.O, rc_.E, rc_.p, rc_.bal, 1.0};
+            }
+            const double t1 = now_ms();
+            assemble_sets(plan, &j->prm, j->nsets, o.fam_m.data(), o.fam_f.data(), o.emax.data(), sv, box, c->opt.host_prof, t1);
+            R.ms_host_bh = (float)(now_ms() - t1);
+        }
+        R.ms_stencil = (float)o.ms_sums; R.ms_score = (float)o.ms_score;
+        R.ms_total = (float)(now_ms() - t0);
+    }
+    return HPK_OK;
+}
+
 int acquire_lane(hpk_ctx* c) {
     for (int l = 0; l < HPK_LANES; ++l) if (!c->lane[l].busy) return l;
     return -1;
@@ -1602,6 +1729,14 @@ int hpk_submit_batch(hpk_ctx* c, const hpk_band* bands, int32_t nbands, const hp
     for (int b = 0; b < nbands; ++b) {
         const int rc = check_band(c, bands + b);
         if (rc != HPK_OK) return rc;
+    }
+    if (c->device < 0) {        // back-end #0
+        hpk_job* j = new hpk_job();
+        j->ctx = c; j->lane = -1; j->t_begin = now_ms();
+        const int rc = cpu_submit(c, j, bands, nbands, prm);
+        if (rc != HPK_OK) { delete j; return rc; }
+        *job = j;
+        return HPK_OK;
     }
     const int lane = acquire_lane(c);
     if (lane < 0) return fail(c, HPK_ERR_BUSY, "all %d lanes hold a batch in flight: collect one first", HPK_LANES);
@@ -1624,10 +1759,14 @@ int hpk_collect_batch(hpk_ctx* c, hpk_job* job, hpk_result** outs, int32_t* stat
     if (!c || !job || job->ctx != c) return c ? fail(c, HPK_ERR_INVALID, "job does not belong to this context") : HPK_ERR_INVALID;
     const int nb = (int)job->bands.size();
     if (outs) for (int b = 0; b < nb; ++b) outs[b] = nullptr;
-    (void)hipSetDevice(c->device);
-    const int rc = collect_impl(c, job);
-    if (rc != HPK_OK) (void)hipStreamSynchronize(c->stream);
-    c->lane[job->lane].busy = false;
+    int rc;
+    if (c->device < 0) rc = cpu_collect(c, job);
+    else {
+        (void)hipSetDevice(c->device);
+        rc = collect_impl(c, job);
+        if (rc != HPK_OK) (void)hipStreamSynchronize(c->stream);
+        c->lane[job->lane].busy = false;
+    }
     if (rc == HPK_OK) {
         for (int b = 0; b < nb; ++b) {
             BandSlot& s = job->bands[b];
@@ -1785,6 +1924,7 @@ void pool_free(hpk_ctx* c, void* p, size_t bytes) {
 int64_t hpk_devband_create(hpk_ctx* c, const int64_t* bin1, const int64_t* bin2, const void* count, int32_t count_f64, int64_t nnz,
                            int32_t n, int32_t num, const double* weight, const double* bias, hpk_devband** out, hpk_band* band) {
     if (!c) return HPK_ERR_INVALID;
+    if (c->device < 0) return fail(c, HPK_ERR_INVALID, "hpk_devband_create builds a band in device memory: back-end #0 takes host bands (hpk_band_from_coo)");
     if (!out || !band || !weight || nnz < 0 || n <= 0 || num <= 0 || (nnz > 0 && (!bin1 || !bin2 || !count)))
         return fail(c, HPK_ERR_INVALID, "hpk_devband_create: bad arguments");
     *out = nullptr;
@@ -1836,7 +1976,7 @@ int64_t hpk_devband_create(hpk_ctx* c, const int64_t* bin1, const int64_t* bin2,
 void hpk_devband_free(hpk_ctx* c, hpk_devband* b) {
     if (!b) return;
     if (c) {
-        (void)hipSetDevice(c->device);
+        if (c->device >= 0) (void)hipSetDevice(c->device);
         c->live_bands.erase(std::remove(c->live_bands.begin(), c->live_bands.end(), b), c->live_bands.end());
     }
     pool_free(c, b->raw, b->raw_bytes);
@@ -1848,6 +1988,7 @@ int hpk_probe_sums(hpk_ctx* c, const hpk_band* band, const hpk_params* prm, cons
                    int64_t count, double* out) {
     if (c) { HPK_NEED_TEST_KERNELS(c); }
     if (!c) return HPK_ERR_INVALID;
+    if (c->device < 0) return fail(c, HPK_ERR_INVALID, "a check kernel of the device path: not on back-end #0");
     if (!prm || !rows || !cols || !out || count < 0) return fail(c, HPK_ERR_INVALID, "bad arguments");
     hpk_params p2 = *prm;
     p2.flags = HPK_FLAG_NO_SCORE;               // stencil + freeze only; the records stay in the lane's workspaces
@@ -1889,6 +2030,7 @@ int hpk_bruteforce_sums(hpk_ctx* c, const hpk_band* band, const hpk_params* prm,
                         const int32_t* cols, int64_t count, double* out) {
     if (c) { HPK_NEED_TEST_KERNELS(c); }
     if (!c) return HPK_ERR_INVALID;
+    if (c->device < 0) return fail(c, HPK_ERR_INVALID, "a check kernel of the device path: not on back-end #0");
     if (!prm || !rows || !cols || !out || count < 0) return fail(c, HPK_ERR_INVALID, "bad arguments");
     int rc = check_band(c, band);
     if (rc != HPK_OK) return rc;

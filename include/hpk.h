@@ -188,7 +188,13 @@ typedef struct {
 
 typedef struct hpk_ctx hpk_ctx;
 
-/* device >= 0: HIP device ordinal.  Fails with HPK_ERR_NO_DEVICE when it is not a gfx950 GPU. */
+/* device >= 0: HIP device ordinal.  Fails with HPK_ERR_NO_DEVICE when it is not a gfx950 GPU - there is no fallback.
+ * device == -1: back-end #0, the same path as plain C++ on host threads (hpk_cpu.cpp; option "cpu_threads",
+ * HPK_CPU_THREADS; default: every core the process may run on).  It exists to be measured beside the GPU path (bench.py:
+ * cpu_baseline.kind = "native") and to run the parity ladder where there is no GPU; a context is a CPU context only when the
+ * caller asks for one.  It takes host bands (on_device = 0), single chromosomes or batches (scored one after the other when the
+ * job is collected), has no history (every chromosome as if it were the first: record_bound 255, halo_w = maxww, stencil_kernel 0)
+ * and none of the device path's debug entry points (dense outputs, probes, hpk_devband_create: HPK_ERR_INVALID). */
 int  hpk_create(int device, hpk_ctx** out);
 void hpk_destroy(hpk_ctx* ctx);
 const char* hpk_last_error(const hpk_ctx* ctx);      /* ctx may be NULL: last create() failure */
