@@ -566,7 +566,6 @@ struct BandSlot {
     bool redone = false, overflowed = false, finished = false, rescored = false;
     int cls = -1;                       // depth class hpk_band_class put the band in (-1: not classified)
     bool canon_done = false;            // spec_halo = 2: computed once more under the halo of its own frozen width
-    signed char forced_tab[HPK_NCLASS]; // ... the depth-class table of that pass: its frozen width for every class
     bool rest_fetched = false;          // the survivors beyond the inline head already sit in `rest` (overflow rerun)
     HpkSurv* rest = nullptr;            // ... in the lane's pinned arena (Lane::h_rest)
     int status = HPK_OK;
@@ -1381,8 +1380,10 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
     const int nb = (int)j->bands.size();
     HIPCHK(c, hipEventSynchronize(L.ev_done));           // this batch only; the next one keeps running
     L.h_rest.reset();                                    // (the lane's previous batch has its survivors in its results by now)
+    std::vector<int> canon_run;          // spec_halo = 2: the chromosomes of a pass that are computed once more under their own layout
     for (int pass = 0; j->do_score; ++pass) {
         bool again = false;
+        canon_run.clear();
         for (int b = 0; b < nb; ++b) {
             BandSlot& s = j->bands[b];
             if (s.status != HPK_OK) continue;
@@ -1441,23 +1442,10 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
                     HpkBandDesc* hd = static_cast<HpkBandDesc*>(L.h_desc) + nb + b;
                     *hd = s.d;
                     hd->k0 = 0; hd->score_wgs = j->gmax;
-                    HIPCHK(c, hipMemcpyAsync(lane_desc(L, j, b, true), hd, sizeof(HpkBandDesc), hipMemcpyHostToDevice, c->stream));
                     HIPCHK(c, hipMemsetAsync(s.d.small, 0, s.zero_bytes, c->stream));
-                    if (j->use_lean) {
-                        // which of its tiles are lean is the chromosome's own affair too: hpk_band_class once more, on this band, with
-                        // its bound forced to the frozen width (the layout is set above), then the lean kernel and the queue pass
-                        // like a batch of one
-                        std::memset(s.forced_tab, (int)(signed char)s.d.wguess, sizeof(s.forced_tab));      // (source of an asynchronous copy: lives with the job)
-                        HIPCHK(c, L.classtab.reserve(HPK_NCLASS));
-                        HIPCHK(c, hipMemcpyAsync(L.classtab.p, s.forced_tab, HPK_NCLASS, hipMemcpyHostToDevice, c->stream));
-                        HpkClassArgs ca = j->cargs;
-                        ca.table = L.classtab.as<signed char>();
-                        ca.wg_all = s.d.wguess; ca.margin = 0; ca.halo = 0; ca.lean = 1;
-                        hpk_launch_band_class(lane_desc(L, j, b, true), 1, ca, c->stream);
-                        HIPCHK(c, hipGetLastError());
-                    }
-                    int rc = launch_compute(c, j, b, 1, true, true, false, j->use_lean);
-                    if (rc != HPK_OK) return rc;
+                    // (launched below, together with the pass's other chromosomes of this kind: a context without history sends a
+                    // whole batch through here, and twenty-three launches of one took three times the batch's own pass - round 6)
+                    canon_run.push_back(b);
                     again = true;
                     continue;
                 }
@@ -1513,6 +1501,27 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
             }
             s.rest_fetched = true;
             again = true;       // (checked once more: a second overflow is an error)
+        }
+        // the second passes of spec_halo = 2, a run of neighbouring chromosomes per set of launches (their second descriptors lie
+        // side by side): which of a chromosome's tiles are lean is its own affair too - hpk_band_class once more with every band's
+        // bound taken from its descriptor (its frozen width; the layout is set above) -, then the lean kernel, hpk_stencil_s and the
+        // queue pass like any batch
+        for (size_t i = 0; i < canon_run.size();) {
+            size_t e = i + 1;
+            while (e < canon_run.size() && canon_run[e] == canon_run[e - 1] + 1) ++e;
+            const int b0 = canon_run[i], nbl = (int)(e - i);
+            HIPCHK(c, hipMemcpyAsync(lane_desc(L, j, b0, true), static_cast<HpkBandDesc*>(L.h_desc) + nb + b0, sizeof(HpkBandDesc) * (size_t)nbl,
+                                     hipMemcpyHostToDevice, c->stream));
+            if (j->use_lean) {
+                HpkClassArgs ca = j->cargs;
+                ca.table = nullptr; ca.own = 1;
+                ca.margin = 0; ca.halo = 0; ca.lean = 1;
+                hpk_launch_band_class(lane_desc(L, j, b0, true), nbl, ca, c->stream);
+                HIPCHK(c, hipGetLastError());
+            }
+            const int rc = launch_compute(c, j, b0, nbl, true, true, false, j->use_lean);
+            if (rc != HPK_OK) return rc;
+            i = e;
         }
         if (!again) break;
         HIPCHK(c, hipEventSynchronize(L.ev_done));

@@ -246,6 +246,7 @@ struct HpkClassArgs {
     int32_t p0, minr;                   // Reads = lower-left rings p0 + 1 .. w against min_local_reads
     float lean_frac;
     int32_t lean_share;                 // least share (percent) of a band's column chunks that must be lean for the band to have lean tiles at all
+    int32_t own;                        // 1: every band's bound is the wguess its descriptor carries (the second pass of spec_halo = 2: its frozen width), no table
 };
 void hpk_launch_band_class(HpkBandDesc* d_bands, int nbands, const HpkClassArgs& a, hipStream_t st);
 void hpk_launch_poisson_sf(const double* k, const double* lam, const double* sfe, double* out, int64_t count,

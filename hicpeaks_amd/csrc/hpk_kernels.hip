@@ -1918,13 +1918,15 @@ __global__ void __launch_bounds__(1024) hpk_band_class(HpkBandDesc* __restrict__
             cls = (int)floor(4.0 * log2((double)tot / (double)cells)) + 32;
             cls = cls < 0 ? 0 : (cls > HPK_NCLASS - 1 ? HPK_NCLASS - 1 : cls);
         }
-        int wg = a.wg_all;
-        if (a.table) {
-            const int tb = (int)a.table[cls];
-            if (tb >= 0) {
-                wg = tb + a.margin;
-                wg = wg < a.wmin ? a.wmin : wg;
-                wg = wg < a.wg_all ? wg : a.wg_all;
+        int wg = a.own ? bd->wguess : a.wg_all;
+        if (a.table || a.own) {
+            if (!a.own) {
+                const int tb = (int)a.table[cls];
+                if (tb >= 0) {
+                    wg = tb + a.margin;
+                    wg = wg < a.wmin ? a.wmin : wg;
+                    wg = wg < a.wg_all ? wg : a.wg_all;
+                }
             }
             bd->wguess = wg;
             // ... and the band's tiles are laid out for that bound's halo (at least 4, at least the plan's narrowest width)

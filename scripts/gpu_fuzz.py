@@ -14,7 +14,7 @@ def table_arrays(t):
     return np.array(k, dtype=np.int64).reshape(-1, 2), np.array([[float(v) for v in t[x]] for x in k])
 
 
-def one_case(seed, ctx):
+def one_case(seed, ctx, cpu=None):
     rng = np.random.default_rng(seed)
     maxww = int(rng.integers(3, 21))
     if os.environ.get('HPK_FUZZ_NARROW'):       # bands of 8-14 diagonals: a band row is shorter than the stencil's wide loads
@@ -83,6 +83,32 @@ def one_case(seed, ctx):
                                      ctx=ctx, detail=detail, **kw)
     except (ValueError, ZeroDivisionError, _lib.HpkError) as e:
         gerr = e
+    # back-end #0 (hpk_create(-1): the path on host threads) on the same case: the oracle's table, or its exception
+    if cpu is not None:
+        cgot = cerr = None
+        try:
+            if mode == 'hiccups':
+                cgot = callers.hiccups_band(rawf, gIR, gb, gb, chrom='T', pw=pw, ww=ww, maxww=maxww, sig=sig,
+                                            maxapart=maxapart, res=res, min_local_reads=min_reads, min_marginal_peaks=2,
+                                            onlyanchor=False, ctx=cpu, **kw)
+            else:
+                cgot = callers.bhfdr_band(rawf, gIR, gb, gb, chrom='T', pw=pw[0], ww=ww[0], sig=sig,
+                                          maxww=maxww, maxapart=maxapart, res=res, min_marginal_peaks=2, onlyanchor=False,
+                                          ctx=cpu, **kw)
+        except (ValueError, ZeroDivisionError, _lib.HpkError) as e:
+            cerr = e
+        if isinstance(cerr, _lib.HpkError) and not isinstance(cerr, _lib.EmptyStepError):
+            if not isinstance(gerr, _lib.HpkError) or isinstance(gerr, _lib.EmptyStepError):
+                return 'MISMATCH-cpu-unsupported', desc, str(cerr)[:100]
+        elif (werr is None) != (cerr is None):
+            return 'MISMATCH-cpu-exception', desc, 'oracle %r vs back-end #0 %r' % (werr, cerr)
+        elif cerr is None:
+            kc, vc = table_arrays(cgot)
+            kwant, vwant = table_arrays(want)
+            if kc.shape != kwant.shape or not np.array_equal(kc, kwant):
+                return 'MISMATCH-cpu-keys', desc, '%d vs %d pixels' % (len(kc), len(kwant))
+            if kc.size and not np.allclose(vc, vwant, rtol=1e-9, atol=1e-9):
+                return 'MISMATCH-cpu-values', desc, 'max abs diff %g' % np.abs(vc - vwant).max()
     if werr is not None or gerr is not None:
         unsupported = isinstance(gerr, _lib.HpkError) and not isinstance(gerr, _lib.EmptyStepError)
         if unsupported:
@@ -145,11 +171,15 @@ def main():
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
     ctx = _lib.Context(0)
+    cpu = None
+    if os.environ.get('HPK_FUZZ_CPU'):          # ... every case through back-end #0 as well
+        cpu = _lib.Context(-1)
+        cpu.set_option('cpu_threads', int(os.environ.get('HPK_FUZZ_CPU')))
     tally = {}
     t0 = time.time()
     for seed in range(first, first + ncases):
         try:
-            status, desc, note = one_case(seed, ctx)
+            status, desc, note = one_case(seed, ctx, cpu)
         except Exception:
             status, desc, note = 'CRASH', dict(seed=seed), traceback.format_exc()[-600:]
         tally[status] = tally.get(status, 0) + 1
