@@ -18,7 +18,8 @@
  * negative hpk_status; hpk_last_error() gives the message.  The caller owns all inputs (never written),
  * the library owns everything reachable from hpk_result until hpk_result_free().  One hpk_ctx per device
  * and per host thread; calls block until the result is complete (ctypes releases the GIL around them).
- * There is no CPU fallback: hpk_create() fails when no gfx950 device is usable.
+ * There is no CPU fallback: hpk_create(device >= 0) fails when no gfx950 device is usable (device -1 *asks* for back-end #0,
+ * the same path on host threads: see hpk_create).
  *
  * Band layout (both inputs and dense outputs): element (r, k) of a [n][ld] row-major array is matrix
  * pixel (row r, column r + k); entries with r + k >= n are ignored.

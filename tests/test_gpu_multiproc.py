@@ -229,3 +229,30 @@ def test_cli_eight_workers_on_a_genome(tmp_path, monkeypatch):
     seen = set(l.split('\t')[0] for l in text.splitlines())
     assert len(text.splitlines()) >= 60 and len(seen) >= 15             # pixels from most of the 23 chromosomes
     assert '--nproc 8: 8 worker(s)' in open(log).read()
+
+
+def test_history_dependent_run_puts_the_shared_context_back(bands, tmp_path, monkeypatch):
+    """An in-process --history-dependent run scores on the process-wide context the drop-in hiccups() / bhfdr() use too: it must leave
+    that context under spec_halo = 2 again (advisor, round 5), and HPK_SPEC_HALO in the environment wins over either flag."""
+    from hicpeaks_amd import _lib
+    arc = str(tmp_path / 'in.npz')
+    _archive(arc, bands[:3], [0, 1, 2])
+    calls = []
+    real = _lib.Context.set_option
+
+    def spy(self, name, value):
+        calls.append((name, int(value)))
+        return real(self, name, value)
+    monkeypatch.setattr(_lib.Context, 'set_option', spy)
+    log = str(tmp_path / 'log.txt')
+    assert cli.main_hiccups(_argv(str(tmp_path / 'a.bedpe'), arc, log, ['--history-dependent'])) == 0
+    halo = [v for n, v in calls if n == 'spec_halo']
+    assert halo and halo[0] == 1 and halo[-1] == 2
+    del calls[:]
+    assert cli.main_hiccups(_argv(str(tmp_path / 'b.bedpe'), arc, log)) == 0
+    halo = [v for n, v in calls if n == 'spec_halo']
+    assert halo and set(halo) == {2}
+    del calls[:]
+    monkeypatch.setenv('HPK_SPEC_HALO', '1')
+    assert cli.main_hiccups(_argv(str(tmp_path / 'c.bedpe'), arc, log)) == 0
+    assert not [v for n, v in calls if n == 'spec_halo']          # the environment's choice stands
