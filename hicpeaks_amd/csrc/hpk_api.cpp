@@ -813,7 +813,7 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         s.off_inl = up256(s.off_rowlive + (size_t)n);
         s.head_bytes = s.off_inl + sizeof(HpkSurv) * HPK_HEAD_INLINE;
         s.off_hacc = up256(s.head_bytes);
-        s.off_tc = up256(s.off_hacc + 8 * (size_t)(HPK_MAX_STEPS + 1) * HPK_ACC_STRIDE);
+        s.off_tc = up256(s.off_hacc + 8 * (size_t)HPK_HREP * HPK_ACC_STRIDE);
         s.off_cnt = up256(s.off_tc + sizeof(unsigned) * tiles_max);
         s.off_cu = up256(s.off_cnt + sizeof(unsigned) * HPK_NFAM * HPK_TIGHTEN_MAX);
         const size_t off_wnz = up256(s.off_cu + sizeof(unsigned) * (size_t)(cap / HPK_SCH * HPK_NREG + 1));

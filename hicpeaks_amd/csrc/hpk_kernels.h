@@ -17,7 +17,9 @@
 #define HPK_SCH 64                      // survivor slots a scoring wave reserves at a time (one batch always fits)
 #define HPK_SCH_LOG2 6
 #define HPK_HIST_NCAND HPK_MAX_STEPS    // hist[HPK_MAX_STEPS] counts the candidates
-#define HPK_ACC_STRIDE 16                // u64 words between the chromosome's resolve totals (HpkBandDesc::hist_acc): one per 128 bytes
+#define HPK_HREP 16                      // copies of a chromosome's resolve totals (HpkBandDesc::hist_acc): workgroup g adds to copy g % HPK_HREP
+#define HPK_HREP_OF(g) ((g) & (HPK_HREP - 1))
+#define HPK_ACC_STRIDE 80                // u64 words from one copy to the next: HPK_MAX_STEPS + 1 totals, whole 128-byte lines
 #ifndef HPK_NWAVES
 #define HPK_NWAVES 16                   // waves per stencil workgroup (16 or 8)
 #endif
@@ -26,6 +28,7 @@
 #define HPK_ENT_YSHIFT 8
 #define HPK_ENT_Y(e) (((e) >> HPK_ENT_YSHIFT) & 63u)
 #define HPK_ENT_CNT_SHIFT 14
+#define HPK_HACC 72                     // words of one of hpk_stencil_s's two LDS buffers of resolve counts: 64 widths / steps, the candidates
 #define HPK_TLIST 7680                  // entries of hpk_stencil_s's tile-wide candidate list: TR * TC must fit
 
 // One pixel that can still end with q <= sig (40 bytes).
@@ -109,7 +112,7 @@ struct HpkBandDesc {
     HPK_GP(uint2) units;                       // scoring work list {row block << 8 | column chunk, unit | records of the tile << 8}, appended at tile end
     HPK_GP(unsigned char) small;               // the band's counter block (HPK_OFF_*)
     HPK_GP(uint8_t) gap;                       // [n] preset to 0; set for rows with a non-zero balanced value (gap = !flag)
-    HPK_GP(unsigned long long) hist_acc;       // [(HPK_MAX_STEPS + 1) * HPK_ACC_STRIDE] zeroed resolve totals the stencil workgroups add to
+    HPK_GP(unsigned long long) hist_acc;       // [HPK_HREP][HPK_ACC_STRIDE] zeroed resolve totals the stencil workgroups add to (step s: word s, the candidates: word HPK_MAX_STEPS)
     int32_t n, num;
     int32_t ntiles, chunk;              // chunk = ceil(ntiles / 8): tiles handed to one XCD
     int32_t k0;                         // first index of this band in an XCD's run over the batch (sum of the chunks before)

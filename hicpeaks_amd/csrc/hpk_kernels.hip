@@ -137,15 +137,21 @@ __device__ __noinline__ double2 explicit_sums_wave(const float* __restrict__ raw
 #ifndef HPK_SCORE_REUSE
 #define HPK_SCORE_REUSE 1               // hpk_score, several pairs: the candidate's own loads stay for the pairs of a batch
 #endif
-// -DHPK_CLK_P1 (with HPK_PHASE_CLOCK): phase 1 split - slot 0 wait for the prefetched rows, 1 cells, 2 candidate list, 3 row prefixes
-// and stores; 4 = everything between phase 1 and the batches
-#ifdef HPK_CLK_P1
-#define HPK_CLKP(v) HPK_CLK(v)
-#define HPK_CLKQ(v) HPK_CLK(ck4)
-#else
-#define HPK_CLKP(v)
-#define HPK_CLKQ(v) HPK_CLK(v)
-#endif
+// -DHPK_CLK_P1 (with HPK_PHASE_CLOCK): the top of the tile - from the last barrier to the rows' arrival - booked under slot 4
+// instead of slot 0.  (A mark is an s_memtime and a wait for it, sixteen waves at a time behind every barrier: the build runs
+// ~20 % slower than the plain one and the slots carry a few hundred ticks of that each - shares below ~5 % of a tile, and
+// what sits between two marks close together, are the marks' own.  Round 6 read a 26 % "band switch" and a 29 % "wait for
+// rows" out of them that timing the plain build with either removed did not confirm: profiles/r06_stencil_band_switch.txt.)
+
+// A chromosome's resolve totals (HpkBandDesc::hist_acc): HPK_HREP copies, a stencil workgroup adds to the one its index picks -
+// 256 workgroups leave a band within microseconds of each other, and device-wide adds to one word run one after the other -,
+// the readers add the copies up.
+__device__ __forceinline__ unsigned long long hist_total(const unsigned long long* __restrict__ acc, int i) {
+    unsigned long long v = 0ull;
+#pragma unroll
+    for (int r = 0; r < HPK_HREP; ++r) v += acc[r * HPK_ACC_STRIDE + i];
+    return v;
+}
 
 // ------------------------------------------------------------------ the stencil kernel
 // hpk_stencil_s, per tile (1024 threads = 16 waves, one persistent workgroup per CU):
@@ -468,6 +474,10 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     unsigned* __restrict__ utot = reinterpret_cast<unsigned*>(ctot + 3 * LC);            // [LC] ... of the packed plane's first chunk
 
     unsigned* __restrict__ twl = utot + LC;                      // [16] the tile walk's state between wave 0's steps
+    // resolve counts of the band (segment) the walk left, summed over the waves: [2][HPK_HACC] - lane-indexed widths / steps, then
+    // the candidates -, two buffers in turn; per step its width index | its slot's first width << 8 (what turns widths into steps)
+    unsigned* __restrict__ hacc = twl + 16;
+    unsigned* __restrict__ hstep = hacc + 2 * HPK_HACC;          // [HPK_MAX_STEPS]
 
     const int lane_k = threadIdx.x & 63;
     const int wave_k = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -489,6 +499,13 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
             stepof[lane_k] = plan->step_of[lane_k >> 5][lane_k & 31];
             stepof[64 + lane_k] = plan->step_of[2 + (lane_k >> 5)][lane_k & 31];
             if (lane_k < 2) { tcount[lane_k] = 0u; tcount[4 + lane_k] = 0u; tcount[6 + lane_k] = 0u; }     // list entries | records written | batches dealt, tiles alternate
+        }
+        if (wave_k == 1) {
+            unsigned hs = 0u;
+            if (lane_k < nsteps) { const HpkDevStep& st = plan->steps[lane_k]; hs = (unsigned)st.wi | ((unsigned)plan->slot_wfirst[st.slot] << 8); }
+            hstep[lane_k] = hs;
+            hacc[lane_k] = 0u; hacc[64 + lane_k] = 0u;
+            if (lane_k < 2 * HPK_HACC - 128) hacc[128 + lane_k] = 0u;
         }
         for (int s = 0; s < nsteps; ++s) {
             const int k = (__builtin_amdgcn_readlane(pk0, s) >> 20) & 15;
@@ -557,41 +574,39 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     unsigned tnext = lds_u32(lds0 + (unsigned)((unsigned char*)tseq - smem));
     unsigned bnext = lds_u32(lds0 + (unsigned)((unsigned char*)tband - smem));
     int tpar = 0;                       // which tseq word holds the tile after the current one
-    // ---- the resolve counts of a band (segment) go to that band's totals when the walk leaves it.  Widths are summed over
-    // the waves in LDS (the tables are dead between tiles), then per step s of slot q and width w: the candidates whose
-    // first sufficient width is w (w above the slot's first width) or at most w (at it).  The counts go straight into
-    // the chromosome's totals - one word per cache line - and every scoring workgroup replays the freeze decision on
-    // them; no ticket, no fences, no tail in this kernel.
-    auto flush_hist = [&](const HpkBandDesc* __restrict__ hb) {
+    // ---- the resolve counts of a band (segment) go to that band's totals when the walk leaves it.  Every wave folds its lanes'
+    // width counts and adds them to the LDS buffer of the turn - no barrier: the walk is already in the next band's first tile,
+    // whose rows were requested a tile ahead like any other's.  Behind that tile's first barrier wave 15 - idle in phase 2 -
+    // turns the widths into steps (per step s of slot q and width w: the candidates whose first sufficient width is w - w above
+    // the slot's first width - or at most w - at it) and adds them to the chromosome's totals, one word per cache line, without
+    // waiting for them; every scoring workgroup replays the freeze decision on the totals.  No ticket, no fences, no tail.
+    auto flush_hist = [&](int p) {
         fold_hpack();
-        unsigned* red = reinterpret_cast<unsigned*>(smem);
-        int tix = wave_k * 64 + lane_k;         // (opaque: what hangs on the thread index stays in here instead of being
-        asm volatile("" : "+v"(tix));           //  hoisted out of the tile loop into registers that then spill)
-        __syncthreads();
-        red[tix] = myhist;
-        if (lane_k == 0) red[NW * 64 + wave_k] = mycand;
-        __syncthreads();
-        if (tix < 64) {
-            unsigned tot = 0u;
-            for (int w2 = 0; w2 < NW; ++w2) tot += red[w2 * 64 + tix];
-            red[(NW + 1) * 64 + tix] = tot;
-        }
-        __syncthreads();
-        if (tix <= HPK_MAX_STEPS) {
-            unsigned out = 0u;
-            const unsigned* hw = red + (NW + 1) * 64;
-            if (tix < nsteps) {
-                const HpkDevStep& st = plan->steps[tix];
-                const int wf = plan->slot_wfirst[st.slot];
-                if (generic_p) out = hw[tix];                   // (counted per step)
-                else if (st.wi > wf) out = hw[st.wi];
-                else for (int w = 0; w <= wf && w < 64; ++w) out += hw[w];
-            } else if (tix == HPK_MAX_STEPS) out = red[NW * 64];
-            if (out) atomicAdd(&gptr(hb->hist_acc)[tix * HPK_ACC_STRIDE], (unsigned long long)out);
-        }
-        __syncthreads();                // (the next tile's phase 1 parks its totals where `red` sits)
+        atomicAdd(&hacc[p * HPK_HACC + lane_k], myhist);
+        if (wave_k == 0 && lane_k == 0) atomicAdd(&hacc[p * HPK_HACC + 64], mycand);
         myhist = 0u; mycand = 0u;
     };
+    // (wave 15, behind a barrier that follows the flush)
+    auto publish_hist = [&](const HpkBandDesc* __restrict__ hb, int p) {
+        unsigned* __restrict__ hw = hacc + p * HPK_HACC;
+        unsigned long long* __restrict__ acc = gptr(hb->hist_acc) + HPK_HREP_OF(blockIdx.x) * HPK_ACC_STRIDE;
+        unsigned out = 0u;
+        if (lane_k < nsteps) {
+            const unsigned hs = hstep[lane_k];
+            const int wi = (int)(hs & 0xffu), wf = (int)(hs >> 8);
+            if (generic_p) out = hw[lane_k];                    // (counted per step)
+            else if (wi > wf) out = hw[wi & 63];
+            else for (int w = 0; w <= wf && w < 64; ++w) out += hw[w];
+        }
+        const unsigned nc = hw[64];
+        if (out) atomicAdd(&acc[lane_k], (unsigned long long)out);
+        if (lane_k == 0 && nc) atomicAdd(&acc[HPK_MAX_STEPS], (unsigned long long)nc);
+        hw[lane_k] = 0u;
+        if (lane_k == 0) hw[64] = 0u;
+    };
+    int hp = 0;                         // the buffer of the next flush
+    int pub = -1;                       // a flushed band waiting for wave 15: band << 1 | buffer
+    bool fetched = false;               // the tile on top of the loop has its rows on the way (every tile but the workgroup's first)
     int hband = -1;                     // band whose resolve counts are pending in myhist / hpack / mycand
 #pragma unroll 1
     while (have) {
@@ -610,11 +625,11 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     const int W = bd->W, TR = bd->TR, TC = bd->TC, J_p = bd->J, Dg_p = bd->Dg, tilecap_p = bd->tilecap;
     // a tile out of the redo queue (hpk_stencil_lean gave it up): its candidates and their resolve counts are in the band's totals
     const bool is_redo = QUEUE;
-    // the band's first tile: nothing is prefetched across a boundary; the flush of the band before runs beside the loads
-    tile_load_s<BALF64>(a, bd, rb, cj, wave_k, lane_k, nxt);
-    if (hband >= 0) flush_hist(bands + hband);
+    // the workgroup's first tile: nobody asked for its rows yet (all others, across band boundaries too: a tile ahead)
+    if (!fetched) tile_load_s<BALF64>(a, bd, rb, cj, wave_k, lane_k, nxt);
+    if (hband >= 0) { flush_hist(hp); pub = hband << 1 | hp; hp ^= 1; }
     hband = band;
-    if (!BALF64) {                      // the first tile's column weights (the tiles after it: behind their predecessor's tables)
+    if (!BALF64 && !fetched) {          // the first tile's column weights (the tiles after it: behind their predecessor's tables)
         const int tix = wave_k * 64 + lane_k;
         if (tix < LC) wct[tix] = nxt.wcol == nxt.wcol ? nxt.wcol : 0.0;
         __syncthreads();
@@ -636,7 +651,8 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     const int tn = __builtin_amdgcn_readfirstlane((int)tnext);
     const unsigned bw_next = (unsigned)__builtin_amdgcn_readfirstlane((int)bnext);
     const bool have_next = tn != -1;
-    const bool pre_next = have_next && bw_next == cbw;         // the next tile is this band's: its rows are prefetched
+    const bool pre_next = have_next;                            // the next tile's rows are prefetched, whatever its band
+    const HpkBandDesc* __restrict__ bd_next = bands + (bw_next & 0xffffu);
     const int rb_next = (int)((unsigned)tn >> 8), cj_next = tn & 255;
     if (wave == 0) {                    // the tile after the next one, for everybody's next round
         walk_t tw;
@@ -648,19 +664,25 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     tpar ^= 1;
     if (empty_tile) {
         if (pre_next) {
-            tile_load_s<BALF64>(a, bd, rb_next, cj_next, wave, lane, nxt);
+            tile_load_s<BALF64>(a, bd_next, rb_next, cj_next, wave, lane, nxt);
             if (!BALF64 && wave < 3) {
                 const int tix = wave * 64 + lane;
                 if (tix < LC) wct[tix] = nxt.wcol == nxt.wcol ? nxt.wcol : 0.0;
             }
         }
+        fetched = pre_next;
         have = have_next; rb = rb_next; cj = cj_next; bw = bw_next;
         __syncthreads();                // (rare: the far end of the chromosome) wave 0's word before it is read
+        if (pub >= 0) { if (wave == NW - 1) publish_hist(bands + (pub >> 1), pub & 1); pub = -1; }
         tnext = lds_u32(lds0 + (unsigned)((unsigned char*)tseq - smem) + (unsigned)tpar * 4u);
         bnext = lds_u32(lds0 + (unsigned)((unsigned char*)tband - smem) + (unsigned)tpar * 4u);
         continue;
     }
     unsigned* __restrict__ tcnt = tcount + par;
+#if defined(HPK_CLK_P1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (phase clocks: the wait for the prefetched rows on its own, booked under slot 4)
+    HPK_CLK(ck4)
+#endif
     // ---- phase 1 (rows): balanced values and packed cells of the lane's ten cells, the candidates among them, and the row
     // prefix of both planes - nine adds inside the lane, a scan over the 16 lanes of the DPP row that holds the table row -
     // written straight to the tables.  Four table rows per wave, all 64 in one pass.
@@ -789,8 +811,10 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     }
     HPK_CLK(ck0)
     // The next tile's rows start moving now, from every wave.
-    if (pre_next) tile_load_s<BALF64>(a, bd, rb_next, cj_next, wave, lane, nxt);
+    if (pre_next) tile_load_s<BALF64>(a, bd_next, rb_next, cj_next, wave, lane, nxt);
+    fetched = pre_next;
     __syncthreads();
+    if (pub >= 0) { if (wave == NW - 1) publish_hist(bands + (pub >> 1), pub & 1); pub = -1; }      // (the band before: see flush_hist)
     HPK_CLK(ck1)
     // ---- phase 2 (columns): the tables hold row prefixes; the prefix down the columns runs through LDS.  f64 plane: waves
     // 0-9, a thread per column and chunk of 16 rows; packed plane: waves 10-14, chunks of 32 rows.  A thread sums its chunk in
@@ -1125,9 +1149,17 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rslot) :: "memory");
                 ri = (unsigned)__builtin_amdgcn_readfirstlane((int)rslot) +
                      __builtin_amdgcn_mbcnt_hi((unsigned)(lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm, 0u));
+#ifdef HPK_ABLATE
+                if (live && a.dbg_stop != 3) ent_t[ri] = id;
+#else
                 if (live) ent_t[ri] = id;
+#endif
             }
+#ifdef HPK_ABLATE
+            if (live && a.dbg_stop != 3) {           // (ablation 3: everything but the record stores)
+#else
             if (live) {
+#endif
                 const int64_t o = q * bd->rec_stride + tbase + ri;
                 gptr(bd->rec_S)[o] = make_double2(act ? SK : 0.0, act ? SY : 0.0);
                 gptr(bd->rec_W)[o] = act ? (uint8_t)(sq + 1) : (uint8_t)0;
@@ -1163,7 +1195,11 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
     par ^= 1;
     } while (have && bw == cbw);   // tile loop of the band
     }   // bands
-    if (hband >= 0) flush_hist(bands + hband);
+    if (hband >= 0) {
+        flush_hist(hp);
+        __syncthreads();
+        if (wave_k == NW - 1) publish_hist(bands + hband, hp);
+    }
     const int lane = lane_k, wave = wave_k;
     if (wave == 0 && pend_tid >= 0) {
         const unsigned nu = (pend_c + (unsigned)HPK_UNIT - 1u) / (unsigned)HPK_UNIT;
@@ -1397,7 +1433,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_lean(HpkStencilArgs a, const
                 if (st.wi > wf) out = hw[st.wi];
                 else for (int w = 0; w <= wf && w < 64; ++w) out += hw[w];
             } else if (tix == HPK_MAX_STEPS) out = red[NW * 64];
-            if (out) atomicAdd(&gptr(hb->hist_acc)[tix * HPK_ACC_STRIDE], (unsigned long long)out);
+            if (out) atomicAdd(&gptr(hb->hist_acc)[HPK_HREP_OF(blockIdx.x) * HPK_ACC_STRIDE + tix], (unsigned long long)out);
         }
         {
             unsigned* lc = reinterpret_cast<unsigned*>(gptr(hb->small) + HPK_OFF_LEAN);
@@ -2019,7 +2055,7 @@ __global__ void __launch_bounds__(128) hpk_freeze_tot(const HpkDevPlan* __restri
     unsigned char* small = gptr(bd->small);
     if ((int)threadIdx.x < plan->nsteps) { swi[threadIdx.x] = plan->steps[threadIdx.x].wi; sslot[threadIdx.x] = plan->steps[threadIdx.x].slot; }
     if (threadIdx.x <= HPK_MAX_STEPS) {
-        hist[threadIdx.x] = gptr(bd->hist_acc)[threadIdx.x * HPK_ACC_STRIDE];
+        hist[threadIdx.x] = hist_total(gptr(bd->hist_acc), (int)threadIdx.x);
         reinterpret_cast<unsigned long long*>(small + HPK_OFF_HIST)[threadIdx.x] = hist[threadIdx.x];
     }
     __syncthreads();
@@ -2275,7 +2311,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
     __shared__ unsigned long long lhtot[HPK_MAX_STEPS + 1];
     __shared__ int lslot[HPK_MAX_STEPS];
     __shared__ int lfrozen;
-    if (threadIdx.x <= HPK_MAX_STEPS) lhtot[threadIdx.x] = gptr(bd->hist_acc)[threadIdx.x * HPK_ACC_STRIDE];
+    if (threadIdx.x <= HPK_MAX_STEPS) lhtot[threadIdx.x] = hist_total(gptr(bd->hist_acc), (int)threadIdx.x);
     if (threadIdx.x < HPK_MAX_STEPS) lslot[threadIdx.x] = (threadIdx.x < plan->nsteps) ? plan->steps[threadIdx.x].slot : 0;
     __syncthreads();
     {
@@ -2933,7 +2969,7 @@ __global__ void __launch_bounds__(256) hpk_thr_compact(const HpkBandDesc* __rest
 }  // namespace
 
 // ------------------------------------------------------------------ launchers
-int hpk_stencil_s_lds_bytes() { return LR * LC * 12 + HPK_TLIST * 4 + 128 + HPK_MAX_STEPS * 32 + HPK_KSLOTS * 32 + LC * 8 * 4 + LC * 4 + 64; }
+int hpk_stencil_s_lds_bytes() { return LR * LC * 12 + HPK_TLIST * 4 + 128 + HPK_MAX_STEPS * 32 + HPK_KSLOTS * 32 + LC * 8 * 4 + LC * 4 + 64 + 2 * HPK_HACC * 4 + HPK_MAX_STEPS * 4; }
 
 template <bool BALF64, bool SINGLE, bool QUEUE = false>
 static void launch_stencil_s_t(const HpkStencilArgs& a, const HpkBandDesc* d_bands, hipStream_t st) {

@@ -28,3 +28,7 @@ print('batch-phase ticks per WG, deciles:', np.percentile(wg, [0, 10, 25, 50, 75
 print('ticks per batch (sum batches-phase / sum batches): %.1f' % (a[:, :, 5].sum() / max(nb.sum(), 1)))
 print('sums below the risk threshold (hpk_stencil_s): %d, per-WG max %d; added cell by cell: %d, per-WG max %d' % (
     risky.sum(), risky.sum(axis=1).max(), explicit.sum(), explicit.sum(axis=1).max()))
+if len(sys.argv) > 3:       # per wave index
+    np.set_printoptions(linewidth=200, suppress=True)
+    for i, nm in enumerate(names):
+        print('%-16s' % nm, a[:, :, i].mean(axis=0).round(0))
