@@ -144,6 +144,7 @@ struct Options {
     int gap_kernel = 0;
     int score_div = 6;          // tiles per scoring workgroup of a batch (4 ... 128 measured: profiles/r05_score_div.txt)
     int dbg_stop = 0;
+    int grid_cap = 0;           // tests: at most this many stencil workgroups (0 = one per CU) - long walks, many bands per workgroup
     int host_prof = 0;
     int spec_surv = 1;          // survivor records only up to the cut's histogram bin of the chromosomes before (minus spec_surv_margin bins)
     int spec_surv_margin = 2;
@@ -420,6 +421,7 @@ int hpk_set_option(hpk_ctx* c, const char* name, int64_t v) {
     else if (k == "gap_kernel" && (v == 0 || v == 1)) o.gap_kernel = (int)v;
     else if (k == "score_div" && v >= 1 && v <= 4096) o.score_div = (int)v;
     else if (k == "dbg_stop" && v >= 0 && v <= 16) o.dbg_stop = (int)v;
+    else if (k == "grid_cap" && v >= 0 && v <= 4096) o.grid_cap = (int)v;
     else if (k == "spec_class" && (v == 0 || v == 1)) o.spec_class = (int)v;
     else if (k == "lean" && (v == 0 || v == 1)) o.lean = (int)v;
     else if (k == "lean_max" && v >= 0 && v <= 4096) o.lean_max = (int)v;
@@ -615,6 +617,7 @@ int launch_compute(hpk_ctx* c, hpk_job* j, int b0, int nbl, bool solo, bool with
             int kall = 0;
             for (int b = b0; b < b0 + nbl; ++b) kall += j->bands[b].d.chunk;
             sa.grid = std::max(8, std::min((c->cus / 8) * 8, kall * 8));
+            if (c->opt.grid_cap > 0) sa.grid = std::max(8, std::min(sa.grid, c->opt.grid_cap / 8 * 8));
             if (solo && !solo_lean) { sa.lean_max = 0; sa.redoq = nullptr; }      // (a chromosome on its own again: every tile in full;
             else if (sa.redoq) HIPCHK(c, hipMemsetAsync(sa.redoq, 0, 16, c->stream));    //  solo_lean: the second pass of spec_halo = 2, like a batch of one)
             hpk_launch_stencil_batch(sa, dd, j->balf64, c->cus, c->stream);

@@ -108,6 +108,35 @@ def test_batch_of_one_band_many_times(ctx):
     assert sum(g.timing['stencil'] for g in got) < 40 * want.timing['stencil']        # one launch, one ramp-up, one tail
 
 
+def test_eight_workgroups_walk_forty_chromosomes(ctx):
+    """The stencil's tile walk with few workgroups (option grid_cap: one per XCD): every workgroup crosses every band boundary of a
+    batch of 40 chromosome-sized bands - its resolve counts folded into LDS and published by one wave a tile later, the next band's
+    first tile requested from the last tile of the one before - and walks more than 8 192 tiles, the length at which a walk ends a
+    segment and flushes so that its 16-bit per-lane counters cannot wrap (TileWalk::bword).  Two different chromosomes in turn:
+    counts that ended up in a neighbour's totals would show in both."""
+    res, maxapart, maxww = 10000, 5000000, 10
+    num = maxapart // res + maxww + 1
+    chroms = _chroms([24896, 20011], num, 60.0, 17)
+    prm = _lib.make_params(_lib.MODE_HICCUPS, [2], [5], maxww, 0.05, maxapart, res, 16, 0)
+    want = [ctx.score_host(raw, None, None, None, prm, weight=weight, num=num) for raw, weight in chroms]
+    items = [dict(raw=chroms[i % 2][0], weight=chroms[i % 2][1], num=num) for i in range(40)]
+    try:
+        ctx.set_option('grid_cap', 8)
+        got = ctx.submit_batch_host(items, prm).results()
+        ctx.set_option('lean', 0)                   # ... and every tile through the one kernel
+        got2 = ctx.submit_batch_host(items, prm).results()
+        ctx.set_option('grid_cap', 0)
+        want2 = [ctx.score_host(raw, None, None, None, prm, weight=weight, num=num) for raw, weight in chroms]
+    finally:
+        ctx.set_option('grid_cap', 0)
+        ctx.set_option('lean', 1)
+    assert sum(w.ncand for w in want) > 0 and all(len(w.sets[0]['x']) > 0 for w in want)
+    assert sum(g.tiles for g in got2) > 8 * 8192, [g.tiles for g in got2[:2]]       # (every workgroup's walk ends a segment)
+    for i, (g, g2) in enumerate(zip(got, got2)):
+        _same(g, want[i % 2])
+        _same(g2, want2[i % 2])
+
+
 def test_batch_raises_like_the_single_call(ctx):
     """results() raises for a chromosome the reference raises on (empty widening step) - after the whole batch was
     collected, so the lane is free again; an oversized batch and mixed input kinds are refused."""
