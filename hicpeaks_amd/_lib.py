@@ -455,7 +455,8 @@ class Context(object):
     def set_option(self, name, value):
         """Tuning / test switch of the context (hpk_set_option, include/hpk.h): 'rounds', 'surv_cap', 'spec', 'spec_margin',
         'spec_force', 'spec_halo', 'spec_surv', 'spec_surv_margin', 'spec_surv_force', 'host_threads', 'risk_log2',
-        'tile_order', 'gap_kernel', 'score_div', 'dbg_stop', 'reset_hints'."""
+        'tile_order', 'gap_kernel', 'score_div', 'dbg_stop', 'grid_cap', 'lean', 'lean_max', 'lean_frac_pct', 'kcrit', 'cpu_threads',
+        'reset_hints'."""
         self._check(self.lib.hpk_set_option(self.h, name.encode(), int(value)))
 
     def info(self):
