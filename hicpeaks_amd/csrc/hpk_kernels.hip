@@ -134,6 +134,9 @@ __device__ __noinline__ double2 explicit_sums_wave(const float* __restrict__ raw
 #ifndef HPK_DYN_BATCH
 #define HPK_DYN_BATCH 1                 // hpk_stencil_s: the batches of a tile beyond the waves' first are dealt dynamically
 #endif
+#ifndef HPK_SCORE_ODD_MASK
+#define HPK_SCORE_ODD_MASK 0            // hpk_score: "this batch needs the general chunk rules" as lane masks ORed on the scalar side
+#endif
 #ifndef HPK_SCORE_REUSE
 #define HPK_SCORE_REUSE 1               // hpk_score, several pairs: the candidate's own loads stay for the pairs of a batch
 #endif
@@ -2222,7 +2225,7 @@ __global__ void __launch_bounds__(HPK_ET_THREADS) hpk_etab_edge(const HpkDevPlan
 // blockIdx.y = band of the batch; a band's units are walked by the first `score_wgs` workgroups of its grid row.
 #define HPK_BQ 128                      // hpk_score, bhfdr: entries of a wave's ring of pending pixels (< 64 left behind + 64 new)
 template <bool BH, bool ONE>  // BH: bhfdr (one set, per-pixel lambda = E); otherwise hiccups (lambda chunks); ONE: a single (pw, ww) pair
-__global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDesc* __restrict__ bands) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) hpk_score(HpkScoreArgs a, const HpkBandDesc* __restrict__ bands) {
     const HpkBandDesc* __restrict__ bd = bands + blockIdx.y;
     const int nwg = bd->score_wgs;
     if ((int)blockIdx.x >= nwg) return;
@@ -2478,6 +2481,10 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
         qcount -= nq;
         __builtin_amdgcn_wave_barrier();
     };
+    // Emax of a set (E > 0: a double's order; a negative or NaN E never wins a max against a non-negative one).  One pair (two
+    // sets) or bhfdr (one): a running maximum per lane - one v_max_f64 per set and item -, folded over the wave and into the
+    // block's LDS word when the wave runs out of work.  Several pairs: the set changes with the item (see below).
+    double em0 = 0.0, em1 = 0.0;
     if (gw < nunits) {
         Geo gn;
         decode(b_units[gw], gn);
@@ -2568,9 +2575,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                     const bool valid = eK > 0.0;
                     const unsigned long long vm = __ballot(valid);
                     if (vm != 0ull) {
-                        const unsigned long long ebits = valid ? (unsigned long long)__double_as_longlong(eK) : 0ull;
-                        const bool beats = ebits > lemax[0];
-                        if (__ballot(beats) != 0ull) { if (beats) atomicMax(&lemax[0], ebits); }
+                        asm("v_max_f64 %0, %0, %1" : "+v"(em0) : "v"(eK));
                         if (lane == 0) atomicAdd(&lm[0][1], (unsigned)__popcll(vm));            // one family: chunk 1
                         const unsigned gi = (unsigned)((int)((unsigned long long)__double_as_longlong(eK) >> 48) - HPK_KCL_G0);
                         const int kc = (valid && gi < (unsigned)HPK_KCL_N) ? lkcl[gi] : 0;        // (outside the grid: formed)
@@ -2593,6 +2598,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                     // is straight-line code for both expected values, whose two table reads then travel together; one
                     // ballot sends the rest of a batch through the general rules.
                     unsigned odd = 0u;
+                    unsigned long long oddm = 0ull;
                     int len2[2];
                     unsigned at2[2];
                     bool crit2[2];
@@ -2608,6 +2614,9 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                         ch = ex >= 0 ? ch : 1;
                         asm volatile("" : "+v"(ch));
                         ch = E > 0.0 ? ch : 0;
+#if HPK_SCORE_ODD_MASK
+                        oddm |= __ballot((ex >= 15) | (E == bq) | (E == bA) | (E == bB));     // lambda beyond the table, or on a boundary
+#else
                         asm volatile("" : "+v"(odd));
                         odd = ex >= 15 ? 1u : odd;                             // lambda beyond the table
                         asm volatile("" : "+v"(odd));
@@ -2617,6 +2626,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                         asm volatile("" : "+v"(odd));
                         odd = E == bB ? 1u : odd;
                         asm volatile("" : "+v"(odd));
+#endif
                         chunk2[fl] = ch;
                         const int ct = ch > 1 ? ch : 1;
                         const int base = lptoff[ct];
@@ -2624,7 +2634,7 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                         at2[fl] = (unsigned)(base + (kO < len2[fl] ? kO : 0));
                         crit2[fl] = kO >= lkcrit[ct];
                     }
-                    if (__ballot(odd != 0u) == 0ull) {
+                    if ((HPK_SCORE_ODD_MASK ? oddm : __ballot(odd != 0u)) == 0ull) {
                         // Only p <= sig is ever looked at (the family sizes count every valid pixel), p falls with the count, and
                         // sig is one number per call: a pixel whose count stays below its chunk's critical count - the smallest
                         // one whose table entry is <= sig (hpk_kcrit) - keeps the placeholder 1, and the table - a third
@@ -2669,20 +2679,21 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
                     const bool valid = E > 0.0;                               // callers.py:250 (E = 0 where the record does not count)
                     const int chunk = chunk2[fl];
                     const double p = p2[fl];
-                    // only p <= sig can reach q <= sig; a pixel without a chunk keeps p = 1 (callers.py:259-260)
-                    double psel = valid ? p : 2.0;
-                    asm volatile("" : "+v"(psel));
-                    psel = chunk != 0 ? psel : 2.0;
-                    const bool surv = psel <= a.sig;
+                    // only p <= sig can reach q <= sig; a pixel without a chunk keeps p = 1 (callers.py:259-260); chunk != 0 implies E > 0
+                    const bool surv = (p <= a.sig) & (chunk != 0);
                     const unsigned long long vm = __ballot(valid);
                     const unsigned long long sm = __ballot(surv);
                     if (vm != 0ull) {
                         // Emax of the set: E > 0, so its bit pattern orders like its value (E = 0: never above).  The
                         // block's running maximum settles after a few batches; only lanes that beat it touch the LDS atomic.
                         // (a negative E - negative balanced values - is not valid and must not enter: its sign bit would win)
-                        const unsigned long long ebits = valid ? (unsigned long long)__double_as_longlong(E) : 0ull;
-                        const bool beats = ebits > lemax[set];
-                        if (__ballot(beats) != 0ull) { if (beats) atomicMax(&lemax[set], ebits); }
+                        if (ONE) {
+                            if (fl == 0) asm("v_max_f64 %0, %0, %1" : "+v"(em0) : "v"(E)); else asm("v_max_f64 %0, %0, %1" : "+v"(em1) : "v"(E));
+                        } else {
+                            const unsigned long long ebits = valid ? (unsigned long long)__double_as_longlong(E) : 0ull;
+                            const bool beats = ebits > lemax[set];
+                            if (__ballot(beats) != 0ull) { if (beats) atomicMax(&lemax[set], ebits); }
+                        }
                         // tests per family; family 0 of a set collects its valid pixels without a chunk (the host adds the
                         // families up to the set's number of valid pixels).  (One LDS atomic per lane, onto the handful of words a
                         // wave's chunks share: served one lane at a time, and still the cheapest form - one add of the lanes' count
@@ -2696,6 +2707,17 @@ __global__ void __launch_bounds__(256) hpk_score(HpkScoreArgs a, const HpkBandDe
             }
         }
         if (BH) { while (qcount > 0) drain(qcount < 64 ? qcount : 64); }
+        if (ONE) {
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) {
+                em0 = fmax(em0, __shfl_xor(em0, m));
+                if (!BH) em1 = fmax(em1, __shfl_xor(em1, m));
+            }
+            if (lane == 0) {
+                if (em0 > 0.0) atomicMax(&lemax[0], (unsigned long long)__double_as_longlong(em0));
+                if (!BH && em1 > 0.0) atomicMax(&lemax[1], (unsigned long long)__double_as_longlong(em1));
+            }
+        }
     }
     if (have_chunk && lane == 0 && (int64_t)wbase < b_cap) gptr(kb->chunk_used)[(rbase + (int64_t)wbase) / HPK_SCH] = wused;
 #ifdef HPK_PHASE_CLOCK
