@@ -134,6 +134,9 @@ __device__ __noinline__ double2 explicit_sums_wave(const float* __restrict__ raw
 #ifndef HPK_DYN_BATCH
 #define HPK_DYN_BATCH 1                 // hpk_stencil_s: the batches of a tile beyond the waves' first are dealt dynamically
 #endif
+#ifndef HPK_SCORE_WPE
+#define HPK_SCORE_WPE 6                 // hpk_score: waves per SIMD the register allocation is held to (80 VGPRs; the Emax registers would have made it 83 -> 88 allocated -> 5)
+#endif
 #ifndef HPK_SCORE_ODD_MASK
 #define HPK_SCORE_ODD_MASK 0            // hpk_score: "this batch needs the general chunk rules" as lane masks ORed on the scalar side
 #endif
@@ -2225,7 +2228,7 @@ __global__ void __launch_bounds__(HPK_ET_THREADS) hpk_etab_edge(const HpkDevPlan
 // blockIdx.y = band of the batch; a band's units are walked by the first `score_wgs` workgroups of its grid row.
 #define HPK_BQ 128                      // hpk_score, bhfdr: entries of a wave's ring of pending pixels (< 64 left behind + 64 new)
 template <bool BH, bool ONE>  // BH: bhfdr (one set, per-pixel lambda = E); otherwise hiccups (lambda chunks); ONE: a single (pw, ww) pair
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) hpk_score(HpkScoreArgs a, const HpkBandDesc* __restrict__ bands) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HPK_SCORE_WPE, HPK_SCORE_WPE))) hpk_score(HpkScoreArgs a, const HpkBandDesc* __restrict__ bands) {
     const HpkBandDesc* __restrict__ bd = bands + blockIdx.y;
     const int nwg = bd->score_wgs;
     if ((int)blockIdx.x >= nwg) return;
