@@ -59,6 +59,39 @@ __global__ void __launch_bounds__(1024) bench(double* out, unsigned long long* c
         } else if (KIND == 10) {    // 4 v_cvt_f64_f32
             asm volatile("v_cvt_f64_f32 %0, %4\n v_cvt_f64_f32 %1, %5\n v_cvt_f64_f32 %2, %6\n v_cvt_f64_f32 %3, %7"
                          : "=v"(a0), "=v"(a1), "=v"(a2), "=v"(a3) : "v"(f0), "v"(f1), "v"(f2), "v"(f3));
+        } else if (KIND == 12) {    // 4 v_rcp_f64
+            asm volatile("v_rcp_f64 %0, %0\n v_rcp_f64 %1, %1\n v_rcp_f64 %2, %2\n v_rcp_f64 %3, %3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+        } else if (KIND == 13) {    // 4 v_div_scale_f64
+            asm volatile("v_div_scale_f64 %0, vcc, %0, %4, %0\n v_div_scale_f64 %1, vcc, %1, %4, %1\n v_div_scale_f64 %2, vcc, %2, %4, %2\n v_div_scale_f64 %3, vcc, %3, %4, %3"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed) : "vcc");
+        } else if (KIND == 14) {    // 4 v_div_fmas_f64
+            asm volatile("v_div_fmas_f64 %0, %0, %4, %0\n v_div_fmas_f64 %1, %1, %4, %1\n v_div_fmas_f64 %2, %2, %4, %2\n v_div_fmas_f64 %3, %3, %4, %3"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed) : "vcc");
+        } else if (KIND == 15) {    // 4 v_div_fixup_f64
+            asm volatile("v_div_fixup_f64 %0, %0, %4, %0\n v_div_fixup_f64 %1, %1, %4, %1\n v_div_fixup_f64 %2, %2, %4, %2\n v_div_fixup_f64 %3, %3, %4, %3"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));
+        } else if (KIND == 16) {    // 4 v_fma_f64
+            asm volatile("v_fma_f64 %0, %0, %4, %0\n v_fma_f64 %1, %1, %4, %1\n v_fma_f64 %2, %2, %4, %2\n v_fma_f64 %3, %3, %4, %3"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));
+        } else if (KIND == 17) {    // 4 v_cmp_ge_f64 (to an SGPR pair)
+            unsigned long long m0, m1;
+            asm volatile("v_cmp_ge_f64 %0, %2, %3\n v_cmp_ge_f64 %1, %3, %4\n v_cmp_ge_f64 %0, %4, %5\n v_cmp_ge_f64 %1, %5, %2"
+                         : "=s"(m0), "=s"(m1) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+            u2 += (unsigned)m0 + (unsigned)m1;
+        } else if (KIND == 18) {    // 4 v_mul_lo_u32
+            asm volatile("v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4"
+                         : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(u0));
+        } else if (KIND == 19) {    // 4 v_lshl_add_u64
+            asm volatile("v_lshl_add_u64 %0, %0, 3, %4\n v_lshl_add_u64 %1, %1, 3, %4\n v_lshl_add_u64 %2, %2, 3, %4\n v_lshl_add_u64 %3, %3, 3, %4"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));
+        } else if (KIND == 20) {    // 4 v_mul_u32_u24
+            asm volatile("v_mul_u32_u24 %0, %0, %4\n v_mul_u32_u24 %1, %1, %4\n v_mul_u32_u24 %2, %2, %4\n v_mul_u32_u24 %3, %3, %4"
+                         : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(u0));
+        } else if (KIND == 21) {    // 4 v_cmp_ge_u64
+            unsigned long long m0, m1;
+            asm volatile("v_cmp_ge_u64 %0, %2, %3\n v_cmp_ge_u64 %1, %3, %4\n v_cmp_ge_u64 %0, %4, %5\n v_cmp_ge_u64 %1, %5, %2"
+                         : "=s"(m0), "=s"(m1) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+            u2 += (unsigned)m0 + (unsigned)m1;
         } else if (KIND == 11) {    // 4 v_pk_add_f32 (two f32 per lane each)
             asm volatile("v_pk_add_f32 %0, %0, %4\n v_pk_add_f32 %1, %1, %4\n v_pk_add_f32 %2, %2, %4\n v_pk_add_f32 %3, %3, %4"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(seed));
@@ -99,6 +132,16 @@ int main() {
     run<2>("v_mov_dpp row_shr:1", out, clk);
     run<3>("v_add_u32_dpp row_bcast:15", out, clk);
     run<4>("v_mov_dpp wave_shr:1", out, clk);
+    run<16>("v_fma_f64", out, clk);
+    run<12>("v_rcp_f64", out, clk);
+    run<13>("v_div_scale_f64", out, clk);
+    run<14>("v_div_fmas_f64", out, clk);
+    run<15>("v_div_fixup_f64", out, clk);
+    run<17>("v_cmp_ge_f64 -> sgpr", out, clk);
+    run<21>("v_cmp_ge_u64 -> sgpr", out, clk);
+    run<18>("v_mul_lo_u32", out, clk);
+    run<20>("v_mul_u32_u24", out, clk);
+    run<19>("v_lshl_add_u64", out, clk);
     run<8>("2 v_readlane + s_add + s_nop", out, clk);
     run<9>("4 s_add_u32", out, clk);
     return 0;
