@@ -38,7 +38,7 @@ def group_of(name):
 for cfg in ('chr1_10kb', 'chr1_10kb_union', 'chr1_5kb', 'deep_1kb'):
     vals = {}
     G = group_of(cfg)           # chromosomes per launch of the counter passes: figures below are per chromosome
-    for cnt in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_INSTS_VALU'):
+    for cnt in ('FETCH_SIZE', 'WRITE_SIZE', 'SQ_INSTS_VALU', 'SQ_INSTS_SALU'):
         for kern in ('hpk_stencil', 'hpk_score'):
             m = pmc_means(os.path.join(out, 'pmc_%s_%s' % (cfg, cnt)), kern)
             if cnt in m:
@@ -57,6 +57,11 @@ for cfg in ('chr1_10kb', 'chr1_10kb_union', 'chr1_5kb', 'deep_1kb'):
         traffic[cfg]['valu_insts'] = int(vals[('hpk_stencil', 'SQ_INSTS_VALU')][0])
     if cfg in traffic and ('hpk_score', 'SQ_INSTS_VALU') in vals:
         traffic[cfg]['score_valu_insts'] = int(vals[('hpk_score', 'SQ_INSTS_VALU')][0])
+    # ... and scalar ones (one scalar unit per CU: bench.py prices them at the measured 2.07 cycles each, profiles/r06_instruction_cost.txt)
+    if cfg in traffic and ('hpk_stencil', 'SQ_INSTS_SALU') in vals:
+        traffic[cfg]['salu_insts'] = int(vals[('hpk_stencil', 'SQ_INSTS_SALU')][0])
+    if cfg in traffic and ('hpk_score', 'SQ_INSTS_SALU') in vals:
+        traffic[cfg]['score_salu_insts'] = int(vals[('hpk_score', 'SQ_INSTS_SALU')][0])
 Gs = group_of('sq')
 for kern in ('hpk_stencil', 'hpk_score'):
     lines.append('## %s (chr1_10kb), SQ / TCC counters per launch of %d chromosomes' % (kern, Gs))

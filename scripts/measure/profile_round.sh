@@ -37,8 +37,8 @@ for c in chr1_10kb chr1_10kb_union chr1_5kb deep_1kb; do
   G=8; [ $c = chr1_5kb ] && G=4; [ $c = deep_1kb ] && G=1
   echo $G > $OUT/pmc_group_$c.txt
   PBc="--config $c --steps 1 --warmup 1 --batch $G --group $G --cpu-rows 0 --no-probes --no-extra"
-  # (+ the vector instructions of the same launches: what roofline_valu prices)
-  for cnt in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
+  # (+ the vector and scalar instructions of the same launches: what roofline_valu / salu_frac price)
+  for cnt in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_INSTS_SALU; do
     rocprofv3 --kernel-trace --pmc $cnt -d $OUT/pmc_${c}_$cnt -o c --output-format csv -- python $R/bench.py $PBc > $OUT/pmc_${c}_$cnt.log 2>&1
   done
 done
