@@ -2488,6 +2488,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HPK_SC
     // sets) or bhfdr (one): a running maximum per lane - one v_max_f64 per set and item -, folded over the wave and into the
     // block's LDS word when the wave runs out of work.  Several pairs: the set changes with the item (see below).
     double em0 = 0.0, em1 = 0.0;
+    const bool may_both = b_n < 2 * W + a.D + 2;        // (r < W, c >= n - W and c - r <= D need n < 2 W + D)
     if (gw < nunits) {
         Geo gn;
         decode(b_units[gw], gn);
@@ -2502,25 +2503,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HPK_SC
             ++sck_items;
 #endif
             const Geo g = gn;
-            const int i0 = g.i0;
-            const bool cand = i0 + lane < g.cnt;
-            unsigned ent = ent_b;
+            // (lanes beyond the unit's records hold the tile's first entry and step 0 - issue_round2 -: nothing of theirs is looked at)
+            const unsigned ent = ent_b;
             const int stp0 = stp_b;
             const double2 s20 = s2_b;
             const double ir = ir_b, b1r = b1_b, b2c = b2_b, EK0 = EK_b, EY0 = EY_b;
-            // This item's pixel, and - short chromosomes only - the explicit expected sums of windows clipped by both matrix
-            // ends: a call, placed ahead of the next item's loads so that nothing is in flight (and nothing has to be
-            // parked in scratch) across it.
-            if (!cand) ent = 0u;
-            const int r = g.r0 + (int)HPK_ENT_Y(ent);
-            const int c = g.c0 + (int)HPK_ENT_X(ent);
-            const int d = c - r;
-            // which local-expected table serves this pixel (interior / clipped by one matrix end / both: explicit)
-            const bool top = cand && r < W, right = cand && c >= b_n - W;
-            const bool both = top && right;
+            // This item's pixel: only where it is needed (a survivor, a capped count, bhfdr's ring) - the common path never looks
+            const int g_r0 = g.r0, g_c0 = g.c0;
+            auto pix_r = [&]() { return g_r0 + (int)HPK_ENT_Y(ent); };
+            auto pix_c = [&]() { return g_c0 + (int)HPK_ENT_X(ent); };
+            const int r_bh = BH ? pix_r() : 0, c_bh = BH ? pix_c() : 0;     // (bhfdr parks 3-8 % of its pixels in the ring: most items need them)
+            // ... and - short chromosomes only: a window is clipped by both matrix ends where r < W and c >= n - W, with c - r <= D -
+            // the explicit expected sums of such windows: a call, placed ahead of the next item's loads so that nothing is in
+            // flight (and nothing has to be parked in scratch) across it.
             double EK = EK0, EY = EY0;
-            if (__ballot(both) != 0ull) {                               // (both matrix ends in one window)
-                const bool bo = both && stp0 != 0;
+            if (may_both) {
+                const int r = pix_r(), c = pix_c();
+                const bool bo = (stp0 != 0) && r < W && c >= b_n - W;
                 if (__ballot(bo) != 0ull) {
                     if (bo) {
                         const double2 ee = edge_expected(plan->steps[stp0 - 1].m, plan->steps[stp0 - 1].wi, b_IR, r, c, b_n, kb->num, a.mw);
@@ -2552,7 +2551,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HPK_SC
                 continue;
             }
             float rawpix = (float)(ent >> HPK_ENT_CNT_SHIFT);          // the SAT holds counts capped at HPK_PK_CAP: those are re-read
-            if (cand && (ent >> HPK_ENT_CNT_SHIFT) >= pkcap) rawpix = gptr(kb->raw)[(int64_t)r * kb->ld + d];
+            if (stp0 != 0 && (ent >> HPK_ENT_CNT_SHIFT) >= pkcap) { const int r = pix_r(); rawpix = gptr(kb->raw)[(int64_t)r * kb->ld + (pix_c() - r)]; }
             const double O = (double)rawpix;
             {
                 // The scalar unit is this kernel's busiest one (lane masks ANDed and ORed, exec saved and restored around
@@ -2587,7 +2586,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HPK_SC
                         if (nm != 0ull) {
                             if (need) {
                                 const int qi = qbase + ((qhead + qcount + (int)__popcll(nm & ((1ull << lane) - 1ull))) & (HPK_BQ - 1));
-                                qE[qi] = eK; qO[qi] = rawpix; qr[qi] = r | (eY == 0.0 ? (int)0x80000000 : 0); qc[qi] = c;
+                                qE[qi] = eK; qO[qi] = rawpix; qr[qi] = r_bh | (eY == 0.0 ? (int)0x80000000 : 0); qc[qi] = c_bh;
                             }
                             qcount += (int)__popcll(nm);
                             if (qcount >= 64) drain(64);
@@ -2705,7 +2704,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HPK_SC
                         // profiles/r05_score_ab.txt.)
                         if (valid) atomicAdd(&lm[set][chunk], 1u);
                     }
-                    if (sm != 0ull) survivors(surv, set, chunk, (fl == 0 && eY == 0.0) ? 1 : 0, r, c, rawpix, E, p);
+                    if (sm != 0ull) survivors(surv, set, chunk, (fl == 0 && eY == 0.0) ? 1 : 0, pix_r(), pix_c(), rawpix, E, p);
                 }
             }
         }
