@@ -2391,21 +2391,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HPK_SC
     };
     // second round of the batch whose records are in (ent_b, stp_b); stp_b becomes the step that counts (0: none)
     auto issue_round2 = [&](const Geo& g) {
+        // (a lane beyond the unit's records holds the tile's first one - a pixel like any other, whose loads are in range: only
+        //  its step is taken away, below)
         const bool cn = g.i0 + lane < g.cnt;
-        const unsigned e = cn ? ent_b : 0u;
+        const unsigned e = ent_b;
         const int r = g.r0 + (int)HPK_ENT_Y(e), c = g.c0 + (int)HPK_ENT_X(e), d = c - r;
         if (ONE || !HPK_SCORE_REUSE || g.pj == 0) {
-            ir_b = b_IR[cn ? (unsigned)d : 0u];
-            b2_b = b_b2[cn ? (unsigned)c : 0u];
-            b1_b = b_b1[cn ? (unsigned)r : 0u];
+            ir_b = b_IR[(unsigned)d];
+            b2_b = b_b2[(unsigned)c];
+            b1_b = b_b1[(unsigned)r];
         }
-        // (windows clipped by one matrix end - pixels within maxww of it - take their expected sums from the edge tables: rare)
-        const bool top = cn && r < W, right = cn && c >= b_n - W;
+        // (windows clipped by one matrix end - pixels within maxww of it - take their expected sums from the edge tables: rare, and
+        //  only in tiles that reach into the first maxww rows or the last maxww columns - the unit's scalars say so)
         const double* __restrict__ tab = b_etab;
         unsigned tbase = 0u;
-        if (__ballot(top != right) != 0ull) {
-            tab = (top != right) ? b_eedge : b_etab;
-            tbase = (top != right) ? (unsigned)(((top ? 0 : 1) * W + (top ? r : b_n - 1 - c)) * nsteps_u) * tstride : 0u;
+        if (g.r0 < W || g.c0 + b_TC > b_n - W) {
+            const bool top = r < W, right = c >= b_n - W;
+            if (__ballot(top != right) != 0ull) {
+                tab = (top != right) ? b_eedge : b_etab;
+                tbase = (top != right) ? (unsigned)(((top ? 0 : 1) * W + (top ? r : b_n - 1 - c)) * nsteps_u) * tstride : 0u;
+            }
         }
         int stp = cn ? stp_b : 0;
         const int stepw = lstepw[stp > 0 ? stp - 1 : 0];
@@ -2415,7 +2420,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HPK_SC
         stp = stepw <= frozen ? stp : 0;
         asm volatile("" : "+v"(stp));
         const unsigned srow = (unsigned)(stp > 1 ? stp - 1 : 0);
-        const unsigned to = tbase + srow * tstride + (cn ? (unsigned)d : 0u);
+        const unsigned to = tbase + srow * tstride + (unsigned)d;
         EK_b = tab[to];
         EY_b = tab[to + (unsigned)(a.D + 1)];
         stp_b = stp;
