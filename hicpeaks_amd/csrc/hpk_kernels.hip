@@ -2555,9 +2555,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HPK_SC
                 if (more) issue_round2(gn);
                 continue;
             }
-            float rawpix = (float)(ent >> HPK_ENT_CNT_SHIFT);          // the SAT holds counts capped at HPK_PK_CAP: those are re-read
-            if (stp0 != 0 && (ent >> HPK_ENT_CNT_SHIFT) >= pkcap) { const int r = pix_r(); rawpix = gptr(kb->raw)[(int64_t)r * kb->ld + (pix_c() - r)]; }
-            const double O = (double)rawpix;
+            // the pixel's count: the entry's field - the SAT holds counts capped at HPK_PK_CAP: those are re-read, behind one ballot -
+            // as the integer the table is indexed by; as a float / double only where a survivor, the ring or the series wants it
+            const unsigned cntu = ent >> HPK_ENT_CNT_SHIFT;
+            int kO = (int)cntu;
+            float rawre = 0.f;
+            if (__ballot(cntu >= pkcap) != 0ull) {
+                if (stp0 != 0 && cntu >= pkcap) { const int r = pix_r(); rawre = gptr(kb->raw)[(int64_t)r * kb->ld + (pix_c() - r)]; kO = (int)(double)rawre; }
+            }
+            auto rawpix_of = [&]() { return (stp0 != 0 && cntu >= pkcap) ? rawre : (float)cntu; };
             {
                 // The scalar unit is this kernel's busiest one (lane masks ANDed and ORed, exec saved and restored around
                 // every divergent if): conditions are folded into the values - a record that does not count turns into
@@ -2573,7 +2579,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HPK_SC
                 constexpr int nfl = BH ? 1 : 2;
                 int chunk2[2] = {0, 0};
                 double p2[2] = {1.0, 1.0};
-                const int kO = (int)O;
                 if (BH) {
                     if (more) issue_round2(gn);                 // (bhfdr: one pair; everything below is arithmetic and LDS)
                     // callers.py:517-540.  The family's size counts every valid pixel; only p <= sig is ever looked at beyond that, and
@@ -2591,7 +2596,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HPK_SC
                         if (nm != 0ull) {
                             if (need) {
                                 const int qi = qbase + ((qhead + qcount + (int)__popcll(nm & ((1ull << lane) - 1ull))) & (HPK_BQ - 1));
-                                qE[qi] = eK; qO[qi] = rawpix; qr[qi] = r_bh | (eY == 0.0 ? (int)0x80000000 : 0); qc[qi] = c_bh;
+                                qE[qi] = eK; qO[qi] = rawpix_of(); qr[qi] = r_bh | (eY == 0.0 ? (int)0x80000000 : 0); qc[qi] = c_bh;
                             }
                             qcount += (int)__popcll(nm);
                             if (qcount >= 64) drain(64);
@@ -2672,7 +2677,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HPK_SC
                             if (tabd) p = (kO < len) ? a.ptab[(unsigned)(base + kO)] : 0.0;
                             const bool rare = inch && !tabd;                      // lambda > 2^15: beyond the table
                             if (__ballot(rare) != 0ull) {
-                                if (rare) p = poisson_sf(O, lbounds[chunk - 1], const_cast<const double*>(ka->sfe), a.sig);   // callers.py:268-270
+                                if (rare) p = poisson_sf((double)rawpix_of(), lbounds[chunk - 1], const_cast<const double*>(ka->sfe), a.sig);   // callers.py:268-270
                             }
                             if (fl == 0) { chunk2[0] = chunk; p2[0] = p; } else { chunk2[1] = chunk; p2[1] = p; }
                         }
@@ -2709,7 +2714,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HPK_SC
                         // profiles/r05_score_ab.txt.)
                         if (valid) atomicAdd(&lm[set][chunk], 1u);
                     }
-                    if (sm != 0ull) survivors(surv, set, chunk, (fl == 0 && eY == 0.0) ? 1 : 0, pix_r(), pix_c(), rawpix, E, p);
+                    if (sm != 0ull) survivors(surv, set, chunk, (fl == 0 && eY == 0.0) ? 1 : 0, pix_r(), pix_c(), rawpix_of(), E, p);
                 }
             }
         }
