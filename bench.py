@@ -65,7 +65,7 @@ BYTES_PER_PX = 20.0      # SURVEY.md §8-D3's convention for the >= 70 % target:
 # 4 cycles (f64, DPP, packed: ~5; profiles/r02_instruction_cost.txt) - priced at 4, so the fraction is a lower bound of the issue
 # slots taken; clock: MI355X's 2.4 GHz peak engine clock (MI355X_MICROARCH.md; under load the chip runs at or below it)
 N_SIMD, VALU_CYCLES, CLOCK_GHZ = 1024, 4.0, 2.4
-N_CU, SALU_CYCLES = 256, 2.07        # one scalar unit per CU; cycles per scalar instruction with all sixteen waves issuing (profiles/r06_instruction_cost.txt)
+N_CU, SALU_CYCLES = 256, 2.0         # one scalar unit per CU, one instruction per two cycles with all sixteen waves issuing (measured with its loop: 2.07, profiles/r06_instruction_cost.txt)
 FRAC_LABEL = ('frac / frac_20B_equivalent: 20 B per band pixel per pair (SURVEY 8-D3: what a kernel writing dense E_K, E_Y would move) '
               '/ kernel time / 8 TB/s - how far the instruction stream is from the contract\'s memory floor, NOT HBM utilisation (it can '
               'exceed 1); frac_measured: the bytes rocprofv3 counted / kernel time / 8 TB/s; roofline_valu: vector issue slots taken')
@@ -813,7 +813,7 @@ def main():
                         out['roofline']['bound'] = 'valu-issue'
                     if 'roofline_score' in out and tr.get('score_valu_insts'):
                         out['roofline_score']['valu_frac'] = valu(tr['score_valu_insts'], out['roofline_score']['kernel_ms_per_chromosome'])
-                # scalar issue: SQ_INSTS_SALU x 2.07 cycles (measured: profiles/r06_instruction_cost.txt) / (256 CUs x clock x kernel time) -
+                # scalar issue: SQ_INSTS_SALU x 2 cycles (measured 2.07 with the loop around it: profiles/r06_instruction_cost.txt) / (256 CUs x clock x kernel time) -
                 # the CU's one scalar unit serves its four SIMDs
                 def salu(n_inst, ms):
                     return n_inst * SALU_CYCLES / (N_CU * CLOCK_GHZ * 1e9 * ms * 1e-3)
