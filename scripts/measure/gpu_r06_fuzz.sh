@@ -34,11 +34,11 @@ for b in bad[:20]:
 PY
 }
 {
-  echo "# scripts/measure/gpu_r06_fuzz.sh: scripts/gpu_fuzz.py, HIP path AND back-end #0 (HPK_FUZZ_CPU=$HPK_FUZZ_CPU threads) vs the numpy oracle, $PAR processes side by side"
-  run_slice small ${NSMALL:-4800} 1200000
-  run_slice big ${NBIG:-240} 1300000 HPK_FUZZ_BIG=1
-  run_slice wide ${NWIDE:-12} 1350000 HPK_FUZZ_WIDE=1
+  echo "# scripts/measure/gpu_r06_fuzz.sh (seed offset ${SEED_OFF:-0}): scripts/gpu_fuzz.py, HIP path AND back-end #0 (HPK_FUZZ_CPU=$HPK_FUZZ_CPU threads) vs the numpy oracle, $PAR processes side by side"
+  run_slice small ${NSMALL:-4800} $((1200000 + ${SEED_OFF:-0}))
+  run_slice big ${NBIG:-240} $((1300000 + ${SEED_OFF:-0})) HPK_FUZZ_BIG=1
+  run_slice wide ${NWIDE:-12} $((1350000 + ${SEED_OFF:-0})) HPK_FUZZ_WIDE=1
   echo "# every case with structure (HPK_FUZZ_STRUCT=1)"
-  run_slice struct ${NSTRUCT:-960} 1400000 HPK_FUZZ_STRUCT=1
-  run_slice structbig ${NSTRUCTBIG:-72} 1500000 HPK_FUZZ_STRUCT=1 HPK_FUZZ_BIG=1
-} 2>&1 | tee gpurun_out/fuzz_r06.txt
+  run_slice struct ${NSTRUCT:-960} $((1400000 + ${SEED_OFF:-0})) HPK_FUZZ_STRUCT=1
+  run_slice structbig ${NSTRUCTBIG:-72} $((1500000 + ${SEED_OFF:-0})) HPK_FUZZ_STRUCT=1 HPK_FUZZ_BIG=1
+} 2>&1 | tee gpurun_out/fuzz_r06${SEED_OFF:+_off$SEED_OFF}.txt
