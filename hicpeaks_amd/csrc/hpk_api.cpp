@@ -43,8 +43,12 @@ struct DevBuf {
     hipError_t reserve(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 8 + 256;
+        // (room to grow without a new allocation, bounded: fresh device memory costs ~25 ms per GB - profiles/r06_fresh_context.txt)
+        size_t want = bytes + std::min<size_t>(bytes / 8, (size_t)256 << 20) + 256;
+        static const bool prof = std::getenv("HPK_ALLOC_PROF") != nullptr;      // (what a fresh context's first call spends in hipMalloc)
+        const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&p, want);
+        if (prof) std::fprintf(stderr, "[hpk alloc] %.3f GB in %.1f ms\n", want / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         if (e != hipSuccess) { p = nullptr; return e; }
         cap = want;
         return hipSuccess;
@@ -144,6 +148,7 @@ struct Options {
     int gap_kernel = 0;
     int score_div = 6;          // tiles per scoring workgroup of a batch (4 ... 128 measured: profiles/r05_score_div.txt)
     int dbg_stop = 0;
+    int surv_div = 6;           // survivor capacity of a chromosome: band pixels x sets / surv_div records (p <= sig; more: scored once more with room)
     int grid_cap = 0;           // tests: at most this many stencil workgroups (0 = one per CU) - long walks, many bands per workgroup
     int host_prof = 0;
     int spec_surv = 1;          // survivor records only up to the cut's histogram bin of the chromosomes before (minus spec_surv_margin bins)
@@ -389,6 +394,7 @@ int hpk_create(int device, hpk_ctx** out) {
     o.gap_kernel = env_int("HPK_GAP_KERNEL", o.gap_kernel);
     o.score_div = std::max(1, env_int("HPK_SCORE_DIV", o.score_div));
     o.dbg_stop = env_int("HPK_DBG_STOP", o.dbg_stop);
+    o.surv_div = std::max(1, std::min(1024, env_int("HPK_SURV_DIV", o.surv_div)));
     o.host_prof = env_int("HPK_HOST_PROF", o.host_prof);
     o.kcrit = env_int("HPK_KCRIT", o.kcrit) ? 1 : 0;
     o.side_serial = env_int("HPK_SIDE_SERIAL", o.side_serial) ? 1 : 0;
@@ -422,6 +428,7 @@ int hpk_set_option(hpk_ctx* c, const char* name, int64_t v) {
     else if (k == "score_div" && v >= 1 && v <= 4096) o.score_div = (int)v;
     else if (k == "dbg_stop" && v >= 0 && v <= 16) o.dbg_stop = (int)v;
     else if (k == "grid_cap" && v >= 0 && v <= 4096) o.grid_cap = (int)v;
+    else if (k == "surv_div" && v >= 1 && v <= 1024) o.surv_div = (int)v;
     else if (k == "spec_class" && (v == 0 || v == 1)) o.spec_class = (int)v;
     else if (k == "lean" && (v == 0 || v == 1)) o.lean = (int)v;
     else if (k == "lean_max" && v >= 0 && v <= 4096) o.lean_max = (int)v;
@@ -804,8 +811,10 @@ int submit_impl(hpk_ctx* c, hpk_job* j, const hpk_band* bands, int nb, const hpk
         // scoring workgroups of the band: a single chromosome gets the resident grid; in a batch the bands share it
         int wgs = j->gmax;
         if (nb > 1) wgs = std::max(16, std::min(j->gmax, (s.ntiles + opt.score_div - 1) / opt.score_div));
-        // survivor capacity per region; every scoring wave may hold one partly filled chunk of HPK_SCH records
-        int64_t cap = (std::max<int64_t>(1 << 16, band_px * j->nsets / 6) + (int64_t)std::max(wgs, 1) * 4 * HPK_SCH * 2) / HPK_NREG;
+        // survivor capacity per region; every scoring wave may hold one partly filled chunk of HPK_SCH records.  (band pixels x sets /
+        // surv_div: Poisson bands hold 0.4 % (depth 15) to 6.3 % (depth 150) of their band pixels as p <= 0.1 records over both sets,
+        // the default 6 leaves room for 33 %; a chromosome with more is scored once more with room for everything - below.)
+        int64_t cap = (std::max<int64_t>(1 << 16, band_px * j->nsets / opt.surv_div) + (int64_t)std::max(wgs, 1) * 4 * HPK_SCH * 2) / HPK_NREG;
         if (opt.surv_cap > 0) cap = std::max<int64_t>(256, opt.surv_cap);       // tests: force the overflow rerun
         cap = (cap + 255) / 256 * 256;
         s.cap = cap;
