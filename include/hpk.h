@@ -251,7 +251,8 @@ int  hpk_collect_batch(hpk_ctx* ctx, hpk_job* job, hpk_result** outs, int32_t* s
  * under maxww's halo - runs of one chromosome are then bit-identical whatever the bound; 2: as 1, and a chromosome whose halo was not the one of the
  * width its OWN widening froze at is computed once more under that one, lean tiles included (hpk_result::redone bit 0): E / p / q are a function of the
  * chromosome alone - what the command lines run under), "risk_log2" (exact-fallback threshold 2^-x), "tile_order", "gap_kernel" (1: gap rows by the row kernel),
- * "score_div" (tiles per scoring workgroup of a batch), "dbg_stop" (profiling ablation), "grid_cap" (tests: at most this many stencil workgroups, 0 = one
+ * "score_div" (tiles per scoring workgroup of a batch), "surv_div" (survivor capacity of a chromosome: band pixels x sets / surv_div records with
+ * p <= sig, default 6; a chromosome with more is scored once more with room), "dbg_stop" (profiling ablation), "grid_cap" (tests: at most this many stencil workgroups, 0 = one
  * per CU - every workgroup then crosses every band of a batch and walks long runs of tiles), "lean" (1 [default]: tiles of the column chunks
  * whose mean Reads stays below "lean_frac_pct" % of min_local_reads - sampled per chromosome on the device - are built without their
  * f64 plane; up to "lean_max" candidates of such a tile that resolve within the bound get their sums cell by cell, a tile with more
