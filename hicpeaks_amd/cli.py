@@ -222,19 +222,6 @@ def _score_queue(args_dict, mode, queue, device, shared=False):
     import collections
     import queue as _queue
     import threading
-    ctx = _lib.default_context(device)
-    # every run starts without memory of the chromosomes an earlier run in this process scored
-    ctx.set_option('reset_hints', 1)
-    # The run's mode, on the process-wide context the drop-in hiccups() / bhfdr() score on as well: set for this run and put back
-    # when it ends (_restore_mode below), so that an in-process --history-dependent run does not leave those functions' values
-    # depending on the calls before.  HPK_SPEC_HALO in the environment wins over either flag (it is what the library started with).
-    if 'HPK_SPEC_HALO' not in os.environ:
-        ctx.set_option('spec_halo', 1 if (args_dict.get('history_dependent') and not args_dict.get('deterministic')) else 2)
-
-    def _restore_mode():
-        if 'HPK_SPEC_HALO' not in os.environ:
-            ctx.set_option('spec_halo', 2)          # _lib.default_context's own mode
-    depth = ctx.pipeline_depth
     pending, out = collections.deque(), {}
 
     # The reader: a thread of its own takes chromosomes from the queue and reads them (HDF5 + chunk inflation release the
@@ -280,7 +267,24 @@ def _score_queue(args_dict, mode, queue, device, shared=False):
 
     th = threading.Thread(target=reader, name='hpk-reader', daemon=True)
     th.start()
+    # The context - the HIP runtime's start-up, ~0.3 s in a fresh process - is created while the reader opens the file and reads the
+    # first chromosome (in this thread: a context belongs to the thread that scores on it).
+    ctx = None
+
+    def _restore_mode():
+        if ctx is not None and 'HPK_SPEC_HALO' not in os.environ:
+            ctx.set_option('spec_halo', 2)          # _lib.default_context's own mode
     try:
+        with _Stage('context', '-'):
+            ctx = _lib.default_context(device)
+        # every run starts without memory of the chromosomes an earlier run in this process scored
+        ctx.set_option('reset_hints', 1)
+        # The run's mode, on the process-wide context the drop-in hiccups() / bhfdr() score on as well: set for this run and put back
+        # when it ends (_restore_mode), so that an in-process --history-dependent run does not leave those functions' values
+        # depending on the calls before.  HPK_SPEC_HALO in the environment wins over either flag (it is what the library started with).
+        if 'HPK_SPEC_HALO' not in os.environ:
+            ctx.set_option('spec_halo', 1 if (args_dict.get('history_dependent') and not args_dict.get('deterministic')) else 2)
+        depth = ctx.pipeline_depth
         return _consume(args_dict, mode, device, ctx, depth, fetched, info, pending, out, collections)
     finally:
         # whatever ended the loop: the reader stops taking chromosomes off the (shared) queue, is not left blocked on a full
@@ -469,10 +473,11 @@ def _run(mode, argv):
     if mode == 'hiccups' and (not args.pw or not args.ww):
         parser.error('--pw and --ww are required')
     logger.info('Loading Hi-C data ...')
-    src = io.open_source(args.path)
-    res = src.binsize
-    keys = select_chroms(src.chromnames, args.chroms)
-    sizes = {k: src.nbins(k) for k in keys}
+    with _Stage('open', '-'):
+        src = io.open_source(args.path)
+        res = src.binsize
+        keys = select_chroms(src.chromnames, args.chroms)
+        sizes = {k: src.nbins(k) for k in keys}
     a = vars(args)
     rank, world, local = parallel.dist_env()
     logger.info('Calling Peaks ...')
