@@ -1546,7 +1546,7 @@ int collect_impl(hpk_ctx* c, hpk_job* j) {
         if (FILE* f = std::fopen(path, "wb")) { std::fwrite(h.data(), 8, h.size(), f); std::fclose(f); }
         unsigned long long s8[8];
         HIPCHK(c, hipMemcpy(s8, c->tmpD.as<unsigned long long>() + (size_t)8 * HPK_NWAVES * 1024, sizeof(s8), hipMemcpyDeviceToHost));
-        if (s8[3]) std::fprintf(stderr, "hpk_score clock (100 MHz ticks): waves %llu items %llu; per wave prologue %.1f loop %.1f epilogue %.1f, longest %llu; first start to last end %llu\n",
+        if (s8[3]) std::fprintf(stderr, "hpk_score clock (s_memtime ticks): waves %llu items %llu; per wave prologue %.1f loop %.1f epilogue %.1f, longest %llu; first start to last end %llu\n",
                                 s8[3], s8[4], (double)s8[0] / s8[3], (double)s8[1] / s8[3], (double)s8[2] / s8[3], s8[5], s8[7] - s8[6]);
     }
 #endif
