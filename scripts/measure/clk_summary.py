@@ -2,8 +2,8 @@
 """Summarise a phase-clock dump of hpk_stencil (libhpk built with -DHPK_PHASE_CLOCK, HPK_CLK_DUMP=<file>):
 u64 [workgroups][16 waves][8] = cycles in (0) wait for the prefetched rows + phase 1, (1) prefetch issue + column
 totals + two barriers, (2) scans + SAT stores, (3) barrier, (4) gap rows + candidate lists, (5) candidate batches,
-(6) end-of-tile barrier, and (7) the number of batches.  Ticks are s_memtime's (the shader clock: ~2 per ns - scripts/measure/ubench/valu_cost.hip
-counts 337 000 of them in 0.163 ms).  A mark costs its own s_memtime and the wait for it, sixteen waves at a time behind a barrier: shares below ~5 %
+(6) end-of-tile barrier, and (7) the number of batches.  Ticks are s_memtime's; their rate against wall time did not calibrate the same way twice (2.1 per ns in scripts/measure/ubench/valu_cost.hip,
+~0.6 per ns of this kernel's duration with all 256 workgroups alive from start to end): read the shares, not the ticks.  A mark costs its own s_memtime and the wait for it, sixteen waves at a time behind a barrier: shares below ~5 %
 of a tile, and whatever lies between two marks close together, are the marks' own (profiles/r06_stencil_band_switch.txt)."""
 import sys
 import numpy as np
