@@ -124,7 +124,12 @@ __device__ __noinline__ double2 explicit_sums_wave(const float* __restrict__ raw
 
 // Per-phase cycle accounting (-DHPK_PHASE_CLOCK builds only; scripts/measure/gpu_phase_clock.sh): every wave sums s_memtime
 // deltas per phase of the tile loop and leaves them in a.clk[(workgroup * NW + wave) * 8 + phase].
-#ifdef HPK_PHASE_CLOCK
+#if defined(HPK_PHASE_CLOCK) && defined(HPK_WG_LIFE)
+// (-DHPK_PHASE_CLOCK -DHPK_WG_LIFE: no marks in the tile loop - a wave's first and last s_memrealtime in slots 6 / 7, the phase slots
+//  left at 1: when the workgroups of a launch start and end, scripts/measure/wg_life.py)
+#define HPK_CLK_DECL unsigned long long ck0 = 1, ck1 = 0, ck2 = 0, ck3 = 0, ck4 = 0, ck5 = 0, ck6 = __builtin_amdgcn_s_memrealtime(), ck7 = 0;
+#define HPK_CLK(v)
+#elif defined(HPK_PHASE_CLOCK)
 #define HPK_CLK_DECL unsigned long long ck0 = 0, ck1 = 0, ck2 = 0, ck3 = 0, ck4 = 0, ck5 = 0, ck6 = 0, ck7 = 0, ckt = __builtin_readcyclecounter();
 #define HPK_CLK(v) { const unsigned long long t__ = __builtin_readcyclecounter(); v += t__ - ckt; ckt = t__; }
 #else
@@ -373,7 +378,9 @@ struct TileWalk {
                 if (J > 0) { dr = dk / J; dc = dk - dr * J; drm = dr % J; }
                 fresh = true;
             }
-            const int t = xcd * chunkb + (k - kb);
+            // (which eighth of a band an XCD takes turns with the band: the eighths are not equally heavy - the last one ends in the
+            //  matrix's corner - and a batch evens that out over its bands: round 6, scripts/measure/wg_life.py)
+            const int t = ((xcd + band) & 7) * chunkb + (k - kb);
             if (t < ntb) {
                 if (fresh) { rbk = t / J; ck = t - rbk * J; rm = rbk % J; }
                 return;
@@ -912,7 +919,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
 #pragma unroll 1
     for (int b = wave; b * 64 < total; b += NW) {
 #endif
-#ifdef HPK_PHASE_CLOCK
+#if defined(HPK_PHASE_CLOCK) && !defined(HPK_WG_LIFE)
         ck7 += 1ull;
 #endif
         const int i = b * 64 + lane;
@@ -1112,7 +1119,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
                 const double thr = amax * a.risk;
                 const bool risky = act & ((SK < thr) | ((SY < thr) & (SY != 0.0)));
                 if (ballot64(risky) != 0ull) {
-#ifdef HPK_PHASE_CLOCK
+#if defined(HPK_PHASE_CLOCK) && !defined(HPK_WG_LIFE)
                     ck6 += (unsigned long long)__popcll(ballot64(risky && SK > 0.0)) << 40;
 #endif
                     if (risky) {
@@ -1138,7 +1145,7 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
                     }
                     // what is left has non-zero cells: one pixel at a time, the whole wave on it
                     unsigned long long todo = ballot64(risky && SK != 0.0 && ((SK < thr) | ((SY < thr) & (SY != 0.0))));
-#ifdef HPK_PHASE_CLOCK
+#if defined(HPK_PHASE_CLOCK) && !defined(HPK_WG_LIFE)
                     ck7 += (unsigned long long)__popcll(todo) << 40;
 #endif
                     while (todo != 0ull) {
@@ -1215,6 +1222,9 @@ __global__ void __launch_bounds__(1024) hpk_stencil_s(HpkStencilArgs a, const Hp
 #ifdef HPK_PHASE_CLOCK
     if (a.clk && lane == 0) {
         unsigned long long* o = a.clk + ((size_t)blockIdx.x * NW + wave) * 8;
+#ifdef HPK_WG_LIFE
+        ck7 = __builtin_amdgcn_s_memrealtime();
+#endif
         o[0] = ck0; o[1] = ck1; o[2] = ck2; o[3] = ck3; o[4] = ck4; o[5] = ck5; o[6] = ck6; o[7] = ck7;
     }
 #endif
