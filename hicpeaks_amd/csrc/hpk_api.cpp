@@ -43,8 +43,10 @@ struct DevBuf {
     hipError_t reserve(size_t bytes) {
         if (bytes <= cap) return hipSuccess;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        // (room to grow without a new allocation, bounded: fresh device memory costs ~25 ms per GB - profiles/r06_fresh_context.txt)
-        size_t want = bytes + std::min<size_t>(bytes / 8, (size_t)256 << 20) + 256;
+        // (an eighth of room to grow: a batch's workspaces follow its bands' tile geometries, which move by a few percent with the bounds
+        //  the bands inherit - bounded at 256 MB, chr1 @5 kb re-allocated its 20 GB buffers every few calls at ~25 ms per GB, 0.31 -> 53 ms
+        //  per chromosome on a box whose driver had pages to clear: profiles/r06_fresh_context.txt)
+        size_t want = bytes + bytes / 8 + 256;
         static const bool prof = std::getenv("HPK_ALLOC_PROF") != nullptr;      // (what a fresh context's first call spends in hipMalloc)
         const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&p, want);
